@@ -1,0 +1,143 @@
+/*
+ * uf3_hip.h -- C ABI of the MI355X-native UF3 hot path (libuf3hip.so).
+ *
+ * The reference (uf3 v0.4.0) is pure Python and has no FFI; the boundary it
+ * offers is its object API.  Each entry point below replaces the arithmetic
+ * behind one of those Python surfaces, so that the classes in uf3_amd/ (same
+ * names and signatures as the reference's) are thin ctypes shims:
+ *
+ *   uf3_basis_create      <- uf3/representation/bspline.py:20-88   (BSplineBasis tables)
+ *   uf3_featurize[_dev]   <- uf3/representation/process.py:293-506 (evaluate_configuration,
+ *                            featurize_{energy,force}_{2B,3B}); distances.py:19-143,
+ *                            angles.py:17-232, bspline.py:810-895
+ *   uf3_gram[_dev]        <- uf3/regression/least_squares.py:716-760 (X^T X, X^T y)
+ *   uf3_eval[_dev]        <- uf3/forcefield/calculator.py:156-343  (energy, forces)
+ *   uf3_neighbors_debug   <- distances.py:48-69 / angles.py:289-346 index semantics
+ *
+ * Conventions
+ *   - every function returns 0 on success, a non-zero UF3_E* code otherwise;
+ *     uf3_last_error(ctx) gives the message (ctx may be NULL for create failures);
+ *   - the caller owns all buffers; the library allocates only inside the opaque
+ *     handles (grow-only device workspace) and frees in *_destroy;
+ *   - a ctx is bound to one HIP device and one stream; calls on one ctx must be
+ *     serialised by the caller (one ctx per device / per Python thread);
+ *   - "_dev" entries take HBM pointers for the bulk arrays and enqueue on the ctx
+ *     stream without synchronising; the plain entries take host pointers, copy in
+ *     and out, and synchronise before returning.  Frame metadata (offsets, cells,
+ *     pbc) is always host memory: it is a few hundred bytes per frame;
+ *   - all floating point data is IEEE double, C-contiguous; positions in Angstrom.
+ */
+#ifndef UF3_HIP_H
+#define UF3_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct uf3_ctx uf3_ctx;
+typedef struct uf3_basis uf3_basis;
+
+enum {
+    UF3_OK = 0,
+    UF3_EINVAL = 1,     /* bad argument / unsupported basis */
+    UF3_ESPECIES = 2,   /* a frame contains an element outside the basis (process.py:321-330) */
+    UF3_EHIP = 3,       /* HIP runtime error */
+    UF3_ENOMEM = 4,
+    UF3_EOVERFLOW = 5   /* internal capacity exceeded after retries */
+};
+
+/* Flat description of a BSplineBasis (host memory, copied by uf3_basis_create). */
+typedef struct uf3_basis_spec {
+    int32_t n_species;            /* S */
+    const int32_t *species_z;     /* [S] ascending atomic numbers */
+    int32_t n_pairs;              /* S(S+1)/2 pair blocks in column order */
+    const int32_t *pair_z;        /* [P][2], z0 <= z1 */
+    const int32_t *pair_nk;       /* [P] knots per pair (4-fold ends included) */
+    const double *pair_knots;     /* concatenated */
+    const double *pair_rmin;      /* [P] r_min_map */
+    const double *pair_rmax;      /* [P] r_max_map */
+    const int32_t *pair_col;      /* [P] first column of the block (1-body columns count) */
+    int32_t lead2, trail2;        /* trimmed basis functions of every pair block */
+    int32_t n_trios;              /* 0 for a 2-body basis */
+    const int32_t *trio_z;        /* [T][3] centre, n1 <= n2 */
+    const int32_t *trio_nk;       /* [T][3] knots of the l (ij), m (ik), n (jk) legs */
+    const double *trio_knots;     /* concatenated l, m, n per trio */
+    const int32_t *trio_col;      /* [T] first column of the compressed block */
+    const int32_t *trio_ncol;     /* [T] compressed block width */
+    const int32_t *trio_lut;      /* concatenated [L*M*N] raw bin -> column within block, or -1
+                                     (symmetry fold, template mask and trims already applied) */
+    int32_t n_feat;               /* F = total columns, y excluded */
+    double r_cut;                 /* BSplineBasis.r_cut: image range of the reference supercell */
+} uf3_basis_spec;
+
+/* A batch of frames.  All three arrays live in HOST memory. */
+typedef struct uf3_frames {
+    int32_t n_frames;
+    const int64_t *atom_offsets;  /* [n_frames+1], atom_offsets[0] = 0 */
+    const double *cells;          /* [n_frames][3][3], rows = lattice vectors */
+    const uint8_t *pbc;           /* [n_frames][3] */
+} uf3_frames;
+
+int uf3_ctx_create(int device, uf3_ctx **out);
+void uf3_ctx_destroy(uf3_ctx *ctx);
+/* enqueue on an existing hipStream_t (e.g. torch's current stream); NULL = the ctx's own stream */
+int uf3_ctx_set_stream(uf3_ctx *ctx, void *hip_stream);
+int uf3_ctx_synchronize(uf3_ctx *ctx);
+const char *uf3_last_error(const uf3_ctx *ctx);
+/* timing of the dominant kernel: (re)start / read accumulated HIP-event time in ms and launches */
+int uf3_ctx_timing_reset(uf3_ctx *ctx, int enable);
+int uf3_ctx_timing_read(uf3_ctx *ctx, double *featurize_ms, int64_t *featurize_launches,
+                        double *neighbor_ms, double *gram_ms, double *eval_ms);
+
+int uf3_basis_create(uf3_ctx *ctx, const uf3_basis_spec *spec, uf3_basis **out);
+void uf3_basis_destroy(uf3_basis *basis);
+
+/*
+ * Feature rows of a batch of frames (y column excluded).
+ *   x_e [n_frames][F]   energy rows: element counts | 2-body | 3-body      (NULL: skip)
+ *   x_f [sum N][3][F]   force rows of atom a, component c at ((a*3)+c)*F   (NULL: skip)
+ */
+int uf3_featurize(uf3_basis *basis, const uf3_frames *frames, const double *pos /*[sumN][3]*/,
+                  const int32_t *z /*[sumN]*/, double *x_e, double *x_f);
+int uf3_featurize_dev(uf3_basis *basis, const uf3_frames *frames, const double *d_pos,
+                      const int32_t *d_z, double *d_x_e, double *d_x_f);
+
+/*
+ * Normal-equation pieces of a row block: gram[F][F] (+)= X^T X, ord[F] (+)= X^T y, with
+ * X [n_rows][ld] row-major (first F columns used).  accumulate = 0 overwrites.
+ */
+int uf3_gram(uf3_ctx *ctx, const double *x, const double *y, int64_t n_rows, int32_t n_feat,
+             int64_t ld, int accumulate, double *gram, double *ord);
+int uf3_gram_dev(uf3_ctx *ctx, const double *d_x, const double *d_y, int64_t n_rows,
+                 int32_t n_feat, int64_t ld, int accumulate, double *d_gram, double *d_ord);
+
+/*
+ * Energy and forces of a fitted model on a batch of frames.
+ *   c1 [S]; c2 concatenated pair coefficient vectors (nk-4 each, all basis functions);
+ *   c3 concatenated full L*M*N grids per trio (BSplineBasis.decompress_3B output).
+ *   energies [n_frames]; forces [sum N][3] (NULL: energies only).
+ */
+int uf3_eval(uf3_basis *basis, const uf3_frames *frames, const double *pos, const int32_t *z,
+             const double *c1, const double *c2, const double *c3, double *energies, double *forces);
+int uf3_eval_dev(uf3_basis *basis, const uf3_frames *frames, const double *d_pos, const int32_t *d_z,
+                 const double *c1, const double *c2, const double *c3 /* host */,
+                 double *d_energies, double *d_forces);
+
+/*
+ * Neighbour indices in the reference's supercell numbering (ghost index =
+ * image_rank * N + atom, geometry.py:108-149), single frame, host buffers.
+ *   pair_ij [P][pair_cap][2]  2-body (i, j) per pair block, row-major sorted; pair_count [P]
+ *   n3_ij   [n3_cap][2]       3-body neighbour pairs of real centres;         n3_count [1]
+ * Pass caps of 0 (and NULL arrays) to obtain the counts only.
+ */
+int uf3_neighbors_debug(uf3_basis *basis, const uf3_frames *frame, const double *pos, const int32_t *z,
+                        int64_t *pair_count, int64_t *pair_ij, int64_t pair_cap,
+                        int64_t *n3_count, int64_t *n3_ij, int64_t n3_cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UF3_HIP_H */

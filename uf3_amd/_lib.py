@@ -1,0 +1,259 @@
+"""
+ctypes binding of libuf3hip.so (include/uf3_hip.h) -- the only compute path.
+
+There is deliberately no CPU fallback: if the HIP library is missing or no
+MI355X is visible, every call that needs arithmetic raises ``HipUnavailable``.
+"""
+import ctypes as C
+import os
+import threading
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libuf3hip.so")
+
+EXPORTS = ["uf3_ctx_create", "uf3_ctx_destroy", "uf3_ctx_set_stream", "uf3_ctx_synchronize",
+           "uf3_last_error", "uf3_ctx_timing_reset", "uf3_ctx_timing_read",
+           "uf3_basis_create", "uf3_basis_destroy",
+           "uf3_featurize", "uf3_featurize_dev", "uf3_gram", "uf3_gram_dev",
+           "uf3_eval", "uf3_eval_dev", "uf3_neighbors_debug"]
+
+
+class HipUnavailable(RuntimeError):
+    pass
+
+
+class UF3Error(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__(f"libuf3hip error {code}: {message}")
+        self.code = code
+
+
+class SpeciesError(UF3Error):
+    """A frame contains an element outside the basis (UF3_ESPECIES)."""
+
+
+class BasisSpec(C.Structure):
+    _fields_ = [("n_species", C.c_int32), ("species_z", C.c_void_p),
+                ("n_pairs", C.c_int32), ("pair_z", C.c_void_p), ("pair_nk", C.c_void_p),
+                ("pair_knots", C.c_void_p), ("pair_rmin", C.c_void_p), ("pair_rmax", C.c_void_p),
+                ("pair_col", C.c_void_p), ("lead2", C.c_int32), ("trail2", C.c_int32),
+                ("n_trios", C.c_int32), ("trio_z", C.c_void_p), ("trio_nk", C.c_void_p),
+                ("trio_knots", C.c_void_p), ("trio_col", C.c_void_p), ("trio_ncol", C.c_void_p),
+                ("trio_lut", C.c_void_p), ("n_feat", C.c_int32), ("r_cut", C.c_double)]
+
+
+class Frames(C.Structure):
+    _fields_ = [("n_frames", C.c_int32), ("atom_offsets", C.c_void_p), ("cells", C.c_void_p),
+                ("pbc", C.c_void_p)]
+
+
+_lib = None
+_lock = threading.Lock()
+
+
+def load():
+    """dlopen libuf3hip.so (built in-tree by ``__graft_entry__.build()``)."""
+    global _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise HipUnavailable(
+                f"{LIB_PATH} not found: build it with `make -C uf3_amd/csrc` "
+                "(or `python -c 'import __graft_entry__ as g; g.build()'`). "
+                "uf3_amd has no CPU fallback.")
+        lib = C.CDLL(LIB_PATH)
+        vp, i32, i64, dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_double
+        lib.uf3_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]
+        lib.uf3_ctx_destroy.argtypes = [vp]
+        lib.uf3_ctx_destroy.restype = None
+        lib.uf3_ctx_set_stream.argtypes = [vp, vp]
+        lib.uf3_ctx_synchronize.argtypes = [vp]
+        lib.uf3_last_error.argtypes = [vp]
+        lib.uf3_last_error.restype = C.c_char_p
+        lib.uf3_ctx_timing_reset.argtypes = [vp, C.c_int]
+        lib.uf3_ctx_timing_read.argtypes = [vp, C.POINTER(dbl), C.POINTER(i64), C.POINTER(dbl),
+                                            C.POINTER(dbl), C.POINTER(dbl)]
+        lib.uf3_basis_create.argtypes = [vp, C.POINTER(BasisSpec), C.POINTER(vp)]
+        lib.uf3_basis_destroy.argtypes = [vp]
+        lib.uf3_basis_destroy.restype = None
+        for name in ("uf3_featurize", "uf3_featurize_dev"):
+            getattr(lib, name).argtypes = [vp, C.POINTER(Frames), vp, vp, vp, vp]
+        for name in ("uf3_gram", "uf3_gram_dev"):
+            getattr(lib, name).argtypes = [vp, vp, vp, i64, i32, i64, C.c_int, vp, vp]
+        for name in ("uf3_eval", "uf3_eval_dev"):
+            getattr(lib, name).argtypes = [vp, C.POINTER(Frames), vp, vp, vp, vp, vp, vp, vp]
+        lib.uf3_neighbors_debug.argtypes = [vp, C.POINTER(Frames), vp, vp, vp, vp, i64, vp, vp, i64]
+        _lib = lib
+        return lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class Context:
+    """One HIP device + stream + grow-only workspace.  Not thread-safe: one per thread/device."""
+
+    def __init__(self, device=0):
+        self.lib = load()
+        h = C.c_void_p()
+        rc = self.lib.uf3_ctx_create(int(device), C.byref(h))
+        if rc:
+            msg = self.lib.uf3_last_error(None).decode()
+            raise HipUnavailable(f"cannot create a HIP context on device {device}: {msg}")
+        self.handle = h
+        self.device = int(device)
+        self._pid = os.getpid()
+
+    def check(self, rc):
+        if rc:
+            msg = self.lib.uf3_last_error(self.handle).decode()
+            raise (SpeciesError if rc == 2 else UF3Error)(rc, msg)
+
+    def set_stream(self, stream_ptr):
+        self.check(self.lib.uf3_ctx_set_stream(self.handle, C.c_void_p(stream_ptr or 0)))
+
+    def synchronize(self):
+        self.check(self.lib.uf3_ctx_synchronize(self.handle))
+
+    def timing_reset(self, enable=True):
+        self.check(self.lib.uf3_ctx_timing_reset(self.handle, int(enable)))
+
+    def timing_read(self):
+        f, n, nb, g, e = C.c_double(), C.c_int64(), C.c_double(), C.c_double(), C.c_double()
+        self.check(self.lib.uf3_ctx_timing_read(self.handle, C.byref(f), C.byref(n), C.byref(nb),
+                                                C.byref(g), C.byref(e)))
+        return dict(featurize_ms=f.value, featurize_launches=n.value, neighbor_ms=nb.value,
+                    gram_ms=g.value, eval_ms=e.value)
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None) and os.getpid() == self._pid:
+                self.lib.uf3_ctx_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
+_contexts = {}
+
+
+def get_context(device=None):
+    """Per-process, per-device shared context (device defaults to LOCAL_RANK or 0)."""
+    if device is None:
+        device = int(os.environ.get("UF3_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+    key = (os.getpid(), int(device))
+    if key not in _contexts:
+        _contexts[key] = Context(device)
+    return _contexts[key]
+
+
+def flatten_basis(basis):
+    """BSplineBasis -> (BasisSpec, keep-alive arrays).  Pure host bookkeeping."""
+    from uf3_amd.data.composition import atomic_numbers as Z
+    cs = basis.chemical_system
+    els = list(cs.element_list)
+    sizes, offsets = basis.get_interaction_partitions()
+    pairs = list(cs.interactions_map[2])
+    trios = list(cs.interactions_map.get(3, [])) if cs.degree > 2 else []
+    keep = {}
+    keep["species_z"] = np.array([Z[e] for e in els], dtype=np.int32)
+    keep["pair_z"] = np.array([[Z[a], Z[b]] for a, b in pairs], dtype=np.int32).reshape(-1, 2)
+    pk = [np.asarray(basis.knots_map[p], dtype=np.float64) for p in pairs]
+    keep["pair_nk"] = np.array([len(k) for k in pk], dtype=np.int32)
+    keep["pair_knots"] = np.ascontiguousarray(np.concatenate(pk))
+    keep["pair_rmin"] = np.array([float(basis.r_min_map[p]) for p in pairs])
+    keep["pair_rmax"] = np.array([float(basis.r_max_map[p]) for p in pairs])
+    keep["pair_col"] = np.array([int(offsets[p]) for p in pairs], dtype=np.int32)
+    tk = [[np.asarray(k, dtype=np.float64) for k in basis.knots_map[t]] for t in trios]
+    keep["trio_z"] = np.array([[Z[a], Z[b], Z[c]] for a, b, c in trios], dtype=np.int32).reshape(-1, 3)
+    keep["trio_nk"] = np.array([[len(k) for k in ks] for ks in tk], dtype=np.int32).reshape(-1, 3)
+    keep["trio_knots"] = (np.ascontiguousarray(np.concatenate([k for ks in tk for k in ks]))
+                          if trios else np.zeros(1))
+    keep["trio_col"] = np.array([int(offsets[t]) for t in trios], dtype=np.int32)
+    keep["trio_ncol"] = np.array([int(sizes[t]) for t in trios], dtype=np.int32)
+    luts = []
+    for t in trios:
+        lut, w = basis.column_sources(t)
+        hit = lut >= 0
+        if not np.allclose(w[hit], 1.0, rtol=0, atol=1e-14):
+            raise ValueError(f"symmetry weights of {t} do not fold to 1; unsupported template")
+        luts.append(lut.astype(np.int32))
+    keep["trio_lut"] = np.ascontiguousarray(np.concatenate(luts)) if trios else np.zeros(1, np.int32)
+    s = BasisSpec()
+    s.n_species, s.n_pairs, s.n_trios = len(els), len(pairs), len(trios)
+    for name in ("species_z", "pair_z", "pair_nk", "pair_knots", "pair_rmin", "pair_rmax", "pair_col",
+                 "trio_z", "trio_nk", "trio_knots", "trio_col", "trio_ncol", "trio_lut"):
+        setattr(s, name, _p(keep[name]))
+    s.lead2, s.trail2 = int(basis.leading_trim[2]), int(basis.trailing_trim[2])
+    s.n_feat = int(np.sum(basis.get_feature_partition_sizes()))
+    s.r_cut = float(basis.r_cut)
+    keep["pairs"], keep["trios"] = pairs, trios
+    return s, keep
+
+
+class DeviceBasis:
+    """Device-resident tables of one BSplineBasis on one context."""
+
+    def __init__(self, basis, ctx=None):
+        self.ctx = ctx or get_context()
+        self.spec, self._keep = flatten_basis(basis)
+        self.n_feat = self.spec.n_feat
+        self.n_species = self.spec.n_species
+        self.pairs, self.trios = self._keep["pairs"], self._keep["trios"]
+        h = C.c_void_p()
+        self.ctx.check(self.ctx.lib.uf3_basis_create(self.ctx.handle, C.byref(self.spec), C.byref(h)))
+        self.handle = h
+        self._pid = os.getpid()
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None) and os.getpid() == self._pid and self.ctx.handle:
+                self.ctx.lib.uf3_basis_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
+def device_basis(basis, ctx=None):
+    """Cached DeviceBasis of a BSplineBasis (re-created after fork / unpickling)."""
+    ctx = ctx or get_context()
+    cache = basis.__dict__.setdefault("_device_cache", {})
+    key = (os.getpid(), ctx.device)
+    if key not in cache:
+        cache[key] = DeviceBasis(basis, ctx)
+    return cache[key]
+
+
+class FrameBatch:
+    """Host-side frame metadata + concatenated positions / species of a list of Atoms."""
+
+    def __init__(self, atoms_list, periodic=None):
+        n = [len(a) for a in atoms_list]
+        self.n_frames = len(atoms_list)
+        self.offsets = np.concatenate([[0], np.cumsum(n)]).astype(np.int64)
+        self.pos = np.ascontiguousarray(np.concatenate(
+            [np.asarray(a.get_positions(), dtype=np.float64).reshape(-1, 3) for a in atoms_list]))
+        self.z = np.ascontiguousarray(np.concatenate(
+            [np.asarray(a.get_atomic_numbers(), dtype=np.int32) for a in atoms_list]))
+        self.cells = np.ascontiguousarray(np.array(
+            [np.array(a.get_cell(), dtype=np.float64).reshape(3, 3) for a in atoms_list]))
+        pbc = np.zeros((self.n_frames, 3), dtype=np.uint8)
+        for k, a in enumerate(atoms_list):
+            pbc[k, :] = np.asarray(a.get_pbc() if hasattr(a, "get_pbc") else a.pbc)
+        if periodic is False:
+            pbc[:] = 0
+        self.pbc = pbc
+        self.n_atoms = int(self.offsets[-1])
+        self.struct = make_frames(self.offsets, self.cells, self.pbc)
+
+
+def make_frames(offsets, cells, pbc):
+    f = Frames()
+    f.n_frames = len(offsets) - 1
+    f.atom_offsets, f.cells, f.pbc = _p(offsets), _p(cells), _p(pbc)
+    f._keep = (offsets, cells, pbc)
+    return f

@@ -1,0 +1,209 @@
+// uf3_device.h -- device-side data layout and the small device functions shared by
+// the kernels (cubic B-spline evaluation from per-interval records, periodic cell
+// list traversal, wave64 helpers).  gfx950 only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define UF3_MAX_SPECIES 8
+#define UF3_MAX_PAIRS 36
+#define WAVE 64
+
+// One record per knot interval i (t_i < x <= t_{i+1}): the six knots and the six
+// reciprocal knot differences the de Boor-Cox triangle needs.  96 bytes, 16-B aligned.
+struct KnotRec {
+    double t[6];   // t[i-2] .. t[i+3]
+    double r[6];   // 1/(t[i+1]-t[i]); 1/(t[i+1]-t[i-1]), 1/(t[i+2]-t[i]);
+                   // 1/(t[i+1]-t[i-2]), 1/(t[i+2]-t[i-1]), 1/(t[i+3]-t[i])
+};
+
+struct LegDev {
+    int rec_off;       // first KnotRec of this knot vector (index = interval number)
+    int nk;            // number of knots; valid intervals are 3 .. nk-5
+    double t0, tlast;  // support of the leg
+    double inv_h;      // (nk-7)/(tlast-t0): interval guess, exact for uniform knots
+};
+
+struct PairDev {
+    LegDev leg;
+    int col;           // first column of the block
+    int nb;            // basis functions (nk-4)
+    double rmin, rmax; // strict range: max(r_min,0) < d < r_max
+};
+
+struct TrioDev {
+    LegDev leg[3];     // l (ij), m (ik), n (jk)
+    int col, ncol;
+    int lut_off;       // into BasisDev::lut (also offset of the full grid in c3)
+    int dim_m, dim_n;  // M, N of the L x M x N grid
+    int dim_l;
+};
+
+struct BasisDev {
+    int S, P, T, F;
+    int lead2, trail2;
+    double rmin3, rmax3;   // 3-body neighbour range: rmin3 < d <= rmax3
+    double rmax2;          // largest pair r_max
+    double rsearch;        // cell-list radius = max(rmax2, rmax3) (= BSplineBasis.r_cut)
+    signed char z2s[120];  // atomic number -> species index or -1
+    short pair_of[UF3_MAX_SPECIES * UF3_MAX_SPECIES];
+    short trio_of[UF3_MAX_SPECIES * UF3_MAX_SPECIES * UF3_MAX_SPECIES];  // [centre][a][b], a<=b
+    PairDev pairs[UF3_MAX_PAIRS];
+    const TrioDev *trios;
+    const KnotRec *recs;
+    const int *lut;        // raw bin -> global column, or -1
+};
+
+// Per-frame geometry for the periodic cell list and the reference's ghost numbering.
+struct FrameGeom {
+    double cell[9];     // real lattice rows (image offsets)
+    double inv[9];      // inverse of the effective (completed) cell: frac_k = sum_j x_j inv[3j+k]
+    double binw[3];     // non-periodic axes: bin width in fractional units
+    int nb[3];          // bins per axis
+    int rad[3];         // search radius in bins (periodic) ; unused for non-periodic
+    int per[3];         // periodic flag
+    int fac[3];         // reference image range per axis (0 when not periodic)
+    int cnt[3];         // images per axis in the reference supercell (2*fac+1 or 1)
+    int bin_base;       // first global bin
+    int atom_lo, atom_hi;
+};
+
+struct CellList {
+    const int *bin_start;     // [nbins_total+1] slots
+    const int *s_atom;        // [natoms] atom index (batch-global) per slot
+    const double *s_pos;      // [natoms][3] original positions per slot
+    const int *s_wrap;        // [natoms] packed wrap vector per slot
+    const signed char *s_spec;
+    const int *atom_bin;      // [natoms] local bin id (within frame) per atom
+    const int *atom_wrap;     // [natoms] packed wrap per atom
+};
+
+struct N3Lists {
+    int cap;
+    int *cnt;       // [natoms]
+    int *parent;    // [natoms*cap] batch-global atom index
+    int *shiftc;    // packed image shift
+    int *sidx;      // reference supercell index of the neighbour (seen from a real centre)
+    int *spec;      // species index
+    double *dx, *dy, *dz, *r;
+};
+
+__device__ __forceinline__ int pack3(int a, int b, int c) { return (a + 512) | ((b + 512) << 10) | ((c + 512) << 20); }
+__device__ __forceinline__ void unpack3(int p, int &a, int &b, int &c) {
+    a = (p & 1023) - 512; b = ((p >> 10) & 1023) - 512; c = ((p >> 20) & 1023) - 512;
+}
+
+// position of image index s in the reference's per-axis list 0, +1, -1, +2, -2, ...
+__device__ __forceinline__ int image_pos(int s) { return s == 0 ? 0 : (s > 0 ? 2 * s - 1 : -2 * s); }
+
+__device__ __forceinline__ int supercell_index(const FrameGeom &g, int s0, int s1, int s2, int local_atom) {
+    int rank = (image_pos(s1) * g.cnt[0] + image_pos(s0)) * g.cnt[2] + image_pos(s2);
+    return rank * (g.atom_hi - g.atom_lo) + local_atom;
+}
+
+// ---- cubic B-spline: interval search + de Boor-Cox triangle ---------------------
+// interval i with t_i < x <= t_{i+1}, 3 <= i <= nk-5.  Caller guarantees t0 < x <= tlast.
+__device__ __forceinline__ int find_interval(const KnotRec *recs, const LegDev &leg, double x) {
+    int hi = leg.nk - 5;
+    int i = 3 + (int)((x - leg.t0) * leg.inv_h);
+    i = i < 3 ? 3 : (i > hi ? hi : i);
+    const KnotRec *base = recs + leg.rec_off;
+    for (;;) {
+        double ti = base[i].t[2], ti1 = base[i].t[3];
+        if (x > ti1 && i < hi) ++i;
+        else if (x <= ti && i > 3) --i;
+        else break;
+    }
+    return i;
+}
+
+// values v[0..3] and first derivatives d[0..3] of basis functions i-3 .. i at x
+template <bool DERIV>
+__device__ __forceinline__ void bspline4(const KnotRec &k, double x, double *v, double *d) {
+    double l1 = x - k.t[2], l2 = x - k.t[1], l3 = x - k.t[0];
+    double r1 = k.t[3] - x, r2 = k.t[4] - x, r3 = k.t[5] - x;
+    // degree 1
+    double tmp = k.r[0];
+    double n0 = r1 * tmp, n1 = l1 * tmp;
+    // degree 2
+    tmp = n0 * k.r[1];
+    double q0 = r1 * tmp, saved = l2 * tmp;
+    tmp = n1 * k.r[2];
+    double q1 = saved + r2 * tmp;
+    double q2 = l1 * tmp;
+    // degree 3
+    tmp = q0 * k.r[3];
+    v[0] = r1 * tmp; saved = l3 * tmp;
+    tmp = q1 * k.r[4];
+    v[1] = saved + r2 * tmp; saved = l2 * tmp;
+    tmp = q2 * k.r[5];
+    v[2] = saved + r3 * tmp;
+    v[3] = l1 * tmp;
+    if (DERIV) {
+        double a = 3.0 * q0 * k.r[3], b = 3.0 * q1 * k.r[4], c = 3.0 * q2 * k.r[5];
+        d[0] = -a; d[1] = a - b; d[2] = b - c; d[3] = c;
+    }
+}
+
+// unfused |d|: ((dx*dx + dy*dy) + dz*dz), the order scipy's cdist uses, so that range
+// comparisons at the cut-offs agree with the reference to the last bit
+__device__ __forceinline__ double norm3_rn(double dx, double dy, double dz) {
+    double s = __dadd_rn(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)), __dmul_rn(dz, dz));
+    return sqrt(s);
+}
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+__device__ __forceinline__ int mbcnt(unsigned long long mask) {
+    return __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
+}
+
+// ---- periodic cell-list traversal -------------------------------------------------
+// Calls f(slot, s0, s1, s2) for every (neighbour slot, image shift) candidate of atom m, all
+// 64 lanes striding over the slots of one bin at a time.  Shifts are relative to the ORIGINAL
+// (unwrapped) positions; images outside the reference's range (|s| > fac) are skipped, so the
+// candidate set is exactly the reference's supercell (geometry.py:131-149).
+template <class F>
+__device__ __forceinline__ void for_each_candidate(const FrameGeom &g, const CellList &cl, int m, F f) {
+    int lane = lane_id();
+    int lb = cl.atom_bin[m];
+    int b2 = lb % g.nb[2], b1 = (lb / g.nb[2]) % g.nb[1], b0 = lb / (g.nb[2] * g.nb[1]);
+    int w0, w1, w2;
+    unpack3(cl.atom_wrap[m], w0, w1, w2);
+    int lo[3], hi[3];
+    for (int k = 0; k < 3; k++) {
+        if (g.per[k]) { lo[k] = -g.rad[k]; hi[k] = g.rad[k]; }
+        else if (g.nb[k] == 1) { lo[k] = 0; hi[k] = 0; }
+        else if (g.nb[k] == 2) { lo[k] = 0; hi[k] = 1; }
+        else { lo[k] = -1; hi[k] = 1; }
+    }
+    for (int o0 = lo[0]; o0 <= hi[0]; o0++) {
+        int t0 = b0 + o0, sh0 = (t0 >= 0 ? t0 / g.nb[0] : -((g.nb[0] - 1 - t0) / g.nb[0]));
+        int c0 = t0 - sh0 * g.nb[0];
+        if (!g.per[0]) sh0 = 0;
+        for (int o1 = lo[1]; o1 <= hi[1]; o1++) {
+            int t1 = b1 + o1, sh1 = (t1 >= 0 ? t1 / g.nb[1] : -((g.nb[1] - 1 - t1) / g.nb[1]));
+            int c1 = t1 - sh1 * g.nb[1];
+            if (!g.per[1]) sh1 = 0;
+            for (int o2 = lo[2]; o2 <= hi[2]; o2++) {
+                int t2 = b2 + o2, sh2 = (t2 >= 0 ? t2 / g.nb[2] : -((g.nb[2] - 1 - t2) / g.nb[2]));
+                int c2 = t2 - sh2 * g.nb[2];
+                if (!g.per[2]) sh2 = 0;
+                int gb = g.bin_base + (c0 * g.nb[1] + c1) * g.nb[2] + c2;
+                int s_lo = cl.bin_start[gb], s_hi = cl.bin_start[gb + 1];
+                for (int base = s_lo; base < s_hi; base += WAVE) {
+                    int slot = base + lane;
+                    bool ok = slot < s_hi;
+                    int s0 = 0, s1 = 0, s2 = 0;
+                    if (ok) {
+                        int v0, v1, v2;
+                        unpack3(cl.s_wrap[slot], v0, v1, v2);
+                        s0 = sh0 - v0 + w0; s1 = sh1 - v1 + w1; s2 = sh2 - v2 + w2;
+                        ok = (abs(s0) <= g.fac[0]) && (abs(s1) <= g.fac[1]) && (abs(s2) <= g.fac[2]);
+                        if (ok && cl.s_atom[slot] == m && s0 == 0 && s1 == 0 && s2 == 0) ok = false;
+                    }
+                    f(ok, slot, s0, s1, s2);
+                }
+            }
+        }
+    }
+}

@@ -1,0 +1,842 @@
+// uf3_hip.hip -- C ABI (include/uf3_hip.h) of the MI355X-native UF3 hot path:
+// contexts, device-resident basis tables, per-call frame geometry, kernel launches.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include <hip/hip_runtime.h>
+#include <rocprim/rocprim.hpp>
+
+#include "../../include/uf3_hip.h"
+#include "uf3_kernels.h"
+
+// ------------------------------------------------------------------------------ plumbing
+struct Buf {
+    void *p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t bytes) {
+        if (bytes <= cap) return hipSuccess;
+        if (p) { hipError_t e = hipFree(p); if (e != hipSuccess) return e; p = nullptr; cap = 0; }
+        size_t want = bytes + bytes / 4 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() { if (p) hipFree(p); p = nullptr; cap = 0; }
+    template <class T> T *as() const { return (T *)p; }
+};
+
+struct uf3_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    std::string err;
+    int lds_max = 65536;
+    int n_cu = 256;
+    // grow-only workspace
+    Buf geoms, offsets, frame_of, atom_bin, atom_wrap, spec, key_in, key_out, val_in, val_out, sort_tmp,
+        bin_start, s_atom, s_pos, s_wrap, s_spec, flags,
+        n3_cnt, n3_int, n3_dbl, e_atom, coeff, stage_pos, stage_z, stage_out, stage_out2,
+        gram_tiles, frag, dbg;
+    int n3_cap = 0;
+    bool frag_ready = false;
+    // timing
+    bool timing = false;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    double t_feat = 0, t_nbr = 0, t_gram = 0, t_eval = 0;
+    long long n_feat_launch = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending[4];
+};
+
+struct uf3_basis {
+    uf3_ctx *ctx = nullptr;
+    BasisDev host;              // host mirror (device pointers inside)
+    BasisDev *dev = nullptr;
+    TrioDev *d_trios = nullptr;
+    KnotRec *d_recs = nullptr;
+    int *d_lut = nullptr;
+    std::vector<int> block_bounds;   // column boundaries of interaction blocks (for column windows)
+    size_t c2_len = 0, c3_len = 0;
+    double r_cut = 0;
+};
+
+static thread_local std::string g_err;
+static int fail(uf3_ctx *ctx, int code, const std::string &msg) {
+    if (ctx) ctx->err = msg;
+    g_err = msg;
+    return code;
+}
+#define HIPCHK(ctx, call)                                                                         \
+    do {                                                                                          \
+        hipError_t e__ = (call);                                                                  \
+        if (e__ != hipSuccess)                                                                    \
+            return fail(ctx, UF3_EHIP, std::string(#call) + ": " + hipGetErrorString(e__));       \
+    } while (0)
+
+extern "C" const char *uf3_last_error(const uf3_ctx *ctx) { return ctx ? ctx->err.c_str() : g_err.c_str(); }
+
+extern "C" int uf3_ctx_create(int device, uf3_ctx **out) {
+    if (!out) return fail(nullptr, UF3_EINVAL, "uf3_ctx_create: null out");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(nullptr, UF3_EHIP, std::string("no HIP device available: ") + hipGetErrorString(e));
+    if (device < 0 || device >= n) return fail(nullptr, UF3_EINVAL, "uf3_ctx_create: bad device index");
+    uf3_ctx *c = new uf3_ctx();
+    c->device = device;
+    HIPCHK(c, hipSetDevice(device));
+    HIPCHK(c, hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+    c->stream = c->own_stream;
+    hipDeviceProp_t prop;
+    HIPCHK(c, hipGetDeviceProperties(&prop, device));
+    c->lds_max = (int)prop.sharedMemPerBlock;
+    c->n_cu = prop.multiProcessorCount;
+    if (std::string(prop.gcnArchName).find("gfx950") == std::string::npos) {
+        std::string m = std::string("uf3_hip is built for gfx950 only, device is ") + prop.gcnArchName;
+        delete c;
+        return fail(nullptr, UF3_EHIP, m);
+    }
+    *out = c;
+    return UF3_OK;
+}
+
+extern "C" void uf3_ctx_destroy(uf3_ctx *c) {
+    if (!c) return;
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    Buf *all[] = {&c->geoms, &c->offsets, &c->frame_of, &c->atom_bin, &c->atom_wrap, &c->spec, &c->key_in,
+                  &c->key_out, &c->val_in, &c->val_out, &c->sort_tmp, &c->bin_start, &c->s_atom, &c->s_pos,
+                  &c->s_wrap, &c->s_spec, &c->flags, &c->n3_cnt, &c->n3_int, &c->n3_dbl, &c->e_atom, &c->coeff,
+                  &c->stage_pos, &c->stage_z, &c->stage_out, &c->stage_out2, &c->gram_tiles, &c->frag, &c->dbg};
+    for (Buf *b : all) b->release();
+    for (auto &v : c->pending) for (auto &p : v) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
+    if (c->own_stream) hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+extern "C" int uf3_ctx_set_stream(uf3_ctx *c, void *s) {
+    if (!c) return fail(nullptr, UF3_EINVAL, "null ctx");
+    c->stream = s ? (hipStream_t)s : c->own_stream;
+    return UF3_OK;
+}
+
+static int check_flags(uf3_ctx *c);
+
+extern "C" int uf3_ctx_synchronize(uf3_ctx *c) {
+    if (!c) return fail(nullptr, UF3_EINVAL, "null ctx");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return check_flags(c);
+}
+
+// ---- timing of kernel classes with HIP events on the launch stream ----------------------
+enum { T_FEAT = 0, T_NBR = 1, T_GRAM = 2, T_EVAL = 3 };
+struct Timed {
+    uf3_ctx *c; int cls; hipEvent_t a = nullptr, b = nullptr;
+    Timed(uf3_ctx *c_, int cls_) : c(c_), cls(cls_) {
+        if (c->timing) { hipEventCreate(&a); hipEventCreate(&b); hipEventRecord(a, c->stream); }
+    }
+    ~Timed() {
+        if (c->timing) { hipEventRecord(b, c->stream); c->pending[cls].push_back({a, b}); if (cls == T_FEAT) c->n_feat_launch++; }
+    }
+};
+
+extern "C" int uf3_ctx_timing_reset(uf3_ctx *c, int enable) {
+    if (!c) return fail(nullptr, UF3_EINVAL, "null ctx");
+    hipStreamSynchronize(c->stream);
+    for (auto &v : c->pending) { for (auto &p : v) { hipEventDestroy(p.first); hipEventDestroy(p.second); } v.clear(); }
+    c->t_feat = c->t_nbr = c->t_gram = c->t_eval = 0;
+    c->n_feat_launch = 0;
+    c->timing = enable != 0;
+    return UF3_OK;
+}
+
+extern "C" int uf3_ctx_timing_read(uf3_ctx *c, double *feat_ms, int64_t *feat_launches, double *nbr_ms,
+                                   double *gram_ms, double *eval_ms) {
+    if (!c) return fail(nullptr, UF3_EINVAL, "null ctx");
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    double *acc[4] = {&c->t_feat, &c->t_nbr, &c->t_gram, &c->t_eval};
+    for (int k = 0; k < 4; k++) {
+        for (auto &p : c->pending[k]) {
+            float ms = 0;
+            hipEventElapsedTime(&ms, p.first, p.second);
+            *acc[k] += ms;
+            hipEventDestroy(p.first); hipEventDestroy(p.second);
+        }
+        c->pending[k].clear();
+    }
+    if (feat_ms) *feat_ms = c->t_feat;
+    if (feat_launches) *feat_launches = c->n_feat_launch;
+    if (nbr_ms) *nbr_ms = c->t_nbr;
+    if (gram_ms) *gram_ms = c->t_gram;
+    if (eval_ms) *eval_ms = c->t_eval;
+    return UF3_OK;
+}
+
+// ------------------------------------------------------------------------------ basis
+static void fill_leg(LegDev &leg, const double *t, int nk, int rec_off, std::vector<KnotRec> &recs) {
+    leg.rec_off = rec_off;
+    leg.nk = nk;
+    leg.t0 = t[0];
+    leg.tlast = t[nk - 1];
+    leg.inv_h = (leg.tlast > leg.t0) ? (double)(nk - 7) / (leg.tlast - leg.t0) : 0.0;
+    for (int i = 0; i < nk - 1; i++) {
+        KnotRec r;
+        std::memset(&r, 0, sizeof(r));
+        if (i >= 3 && i <= nk - 5) {
+            for (int q = 0; q < 6; q++) r.t[q] = t[i - 2 + q];
+            auto rc = [](double d) { return d > 0 ? 1.0 / d : 0.0; };
+            r.r[0] = rc(t[i + 1] - t[i]);
+            r.r[1] = rc(t[i + 1] - t[i - 1]); r.r[2] = rc(t[i + 2] - t[i]);
+            r.r[3] = rc(t[i + 1] - t[i - 2]); r.r[4] = rc(t[i + 2] - t[i - 1]); r.r[5] = rc(t[i + 3] - t[i]);
+        }
+        recs.push_back(r);
+    }
+}
+
+extern "C" int uf3_basis_create(uf3_ctx *c, const uf3_basis_spec *s, uf3_basis **out) {
+    if (!c || !s || !out) return fail(c, UF3_EINVAL, "uf3_basis_create: null argument");
+    if (s->n_species < 1 || s->n_species > UF3_MAX_SPECIES)
+        return fail(c, UF3_EINVAL, "uf3_basis_create: 1..8 species supported");
+    if (s->n_pairs != s->n_species * (s->n_species + 1) / 2)
+        return fail(c, UF3_EINVAL, "uf3_basis_create: n_pairs must be S(S+1)/2");
+    HIPCHK(c, hipSetDevice(c->device));
+    uf3_basis *b = new uf3_basis();
+    b->ctx = c;
+    b->r_cut = s->r_cut;
+    BasisDev &h = b->host;
+    std::memset(&h, 0, sizeof(h));
+    h.S = s->n_species; h.P = s->n_pairs; h.T = s->n_trios; h.F = s->n_feat;
+    h.lead2 = s->lead2; h.trail2 = s->trail2;
+    std::memset(h.z2s, -1, sizeof(h.z2s));
+    for (int i = 0; i < h.S; i++) {
+        int z = s->species_z[i];
+        if (z < 1 || z >= 120 || (i && z <= s->species_z[i - 1])) { delete b; return fail(c, UF3_EINVAL, "species_z must be ascending atomic numbers"); }
+        h.z2s[z] = (signed char)i;
+    }
+    for (auto &v : h.pair_of) v = -1;
+    for (auto &v : h.trio_of) v = -1;
+    std::vector<KnotRec> recs;
+    std::vector<int> bounds;
+    for (int i = 0; i <= h.S; i++) bounds.push_back(i);
+    const double *kp = s->pair_knots;
+    h.rmax2 = 0;
+    for (int p = 0; p < h.P; p++) {
+        int za = s->pair_z[2 * p], zb = s->pair_z[2 * p + 1];
+        int a = (za > 0 && za < 120) ? h.z2s[za] : -1, bb = (zb > 0 && zb < 120) ? h.z2s[zb] : -1;
+        int nk = s->pair_nk[p];
+        if (a < 0 || bb < 0 || nk < 8) { delete b; return fail(c, UF3_EINVAL, "bad pair block"); }
+        h.pair_of[a * UF3_MAX_SPECIES + bb] = h.pair_of[bb * UF3_MAX_SPECIES + a] = (short)p;
+        PairDev &pd = h.pairs[p];
+        fill_leg(pd.leg, kp, nk, (int)recs.size(), recs);
+        pd.col = s->pair_col[p];
+        pd.nb = nk - 4;
+        pd.rmin = s->pair_rmin[p] > 0 ? s->pair_rmin[p] : 0.0;   // max(r_min, 0), distances.py:60
+        pd.rmax = s->pair_rmax[p];
+        h.rmax2 = std::max(h.rmax2, pd.rmax);
+        bounds.push_back(pd.col + pd.nb);
+        b->c2_len += (size_t)pd.nb;
+        kp += nk;
+    }
+    std::vector<TrioDev> trios(h.T);
+    const double *tp = s->trio_knots;
+    double lo3 = 1e300, hi3 = -1e300;
+    size_t lut_len = 0;
+    for (int t = 0; t < h.T; t++) {
+        int zc = s->trio_z[3 * t], za = s->trio_z[3 * t + 1], zb = s->trio_z[3 * t + 2];
+        int sc = h.z2s[zc], sa = h.z2s[za], sb = h.z2s[zb];
+        if (sc < 0 || sa < 0 || sb < 0 || sa > sb) { delete b; return fail(c, UF3_EINVAL, "bad trio block"); }
+        h.trio_of[(sc * UF3_MAX_SPECIES + sa) * UF3_MAX_SPECIES + sb] = (short)t;
+        h.trio_of[(sc * UF3_MAX_SPECIES + sb) * UF3_MAX_SPECIES + sa] = (short)t;
+        TrioDev &td = trios[t];
+        for (int d = 0; d < 3; d++) {
+            int nk = s->trio_nk[3 * t + d];
+            if (nk < 8) { delete b; return fail(c, UF3_EINVAL, "trio knot vector too short"); }
+            fill_leg(td.leg[d], tp, nk, (int)recs.size(), recs);
+            for (int q = 0; q < nk; q++) {
+                lo3 = std::min(lo3, tp[q]);
+                if (d < 2) hi3 = std::max(hi3, tp[q]);     // angles.py:322-325: centre legs only
+            }
+            tp += nk;
+        }
+        td.dim_l = td.leg[0].nk - 4; td.dim_m = td.leg[1].nk - 4; td.dim_n = td.leg[2].nk - 4;
+        td.col = s->trio_col[t];
+        td.ncol = s->trio_ncol[t];
+        td.lut_off = (int)lut_len;
+        lut_len += (size_t)td.dim_l * td.dim_m * td.dim_n;
+        bounds.push_back(td.col + td.ncol);
+    }
+    b->c3_len = lut_len;
+    h.rmin3 = h.T ? std::max(lo3, 0.0) : 0.0;
+    h.rmax3 = h.T ? hi3 : 0.0;
+    h.rsearch = std::max(h.rmax2, h.rmax3);
+    std::vector<int> lut(lut_len ? lut_len : 1, -1);
+    for (int t = 0; t < h.T; t++) {
+        size_t n = (size_t)trios[t].dim_l * trios[t].dim_m * trios[t].dim_n;
+        const int32_t *src = s->trio_lut + trios[t].lut_off;
+        for (size_t q = 0; q < n; q++) {
+            int v = src[q];
+            if (v >= trios[t].ncol) { delete b; return fail(c, UF3_EINVAL, "trio_lut entry out of range"); }
+            lut[trios[t].lut_off + q] = v < 0 ? -1 : trios[t].col + v;
+        }
+    }
+    std::sort(bounds.begin(), bounds.end());
+    bounds.erase(std::unique(bounds.begin(), bounds.end()), bounds.end());
+    if (bounds.back() != h.F) { delete b; return fail(c, UF3_EINVAL, "column blocks do not add up to n_feat"); }
+    b->block_bounds = bounds;
+
+    HIPCHK(c, hipMalloc(&b->d_recs, sizeof(KnotRec) * std::max<size_t>(1, recs.size())));
+    HIPCHK(c, hipMemcpy(b->d_recs, recs.data(), sizeof(KnotRec) * recs.size(), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMalloc(&b->d_lut, sizeof(int) * lut.size()));
+    HIPCHK(c, hipMemcpy(b->d_lut, lut.data(), sizeof(int) * lut.size(), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMalloc(&b->d_trios, sizeof(TrioDev) * std::max<size_t>(1, trios.size())));
+    if (!trios.empty())
+        HIPCHK(c, hipMemcpy(b->d_trios, trios.data(), sizeof(TrioDev) * trios.size(), hipMemcpyHostToDevice));
+    h.trios = b->d_trios; h.recs = b->d_recs; h.lut = b->d_lut;
+    HIPCHK(c, hipMalloc(&b->dev, sizeof(BasisDev)));
+    HIPCHK(c, hipMemcpy(b->dev, &h, sizeof(BasisDev), hipMemcpyHostToDevice));
+    *out = b;
+    return UF3_OK;
+}
+
+extern "C" void uf3_basis_destroy(uf3_basis *b) {
+    if (!b) return;
+    hipSetDevice(b->ctx->device);
+    hipStreamSynchronize(b->ctx->stream);
+    hipFree(b->dev); hipFree(b->d_trios); hipFree(b->d_recs); hipFree(b->d_lut);
+    delete b;
+}
+
+// ------------------------------------------------------------------------------ frame geometry
+static void cross3(const double *a, const double *b, double *o) {
+    o[0] = a[1] * b[2] - a[2] * b[1]; o[1] = a[2] * b[0] - a[0] * b[2]; o[2] = a[0] * b[1] - a[1] * b[0];
+}
+static double dot3(const double *a, const double *b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+static double norm3(const double *a) { return std::sqrt(dot3(a, a)); }
+
+// image range of the reference supercell (geometry.py:54-83), on the cell as given
+static void reference_factors(const double *cell, double r_cut, int *fac) {
+    bool all_zero = true, zero_vec = false;
+    for (int i = 0; i < 9; i++) if (cell[i] != 0.0) all_zero = false;
+    for (int i = 0; i < 3; i++) if (norm3(cell + 3 * i) == 0.0) zero_vec = true;
+    if (all_zero || zero_vec) { fac[0] = fac[1] = fac[2] = 1; return; }
+    double n[3][3];
+    cross3(cell + 3, cell + 6, n[0]); cross3(cell, cell + 6, n[1]); cross3(cell, cell + 3, n[2]);
+    for (int i = 0; i < 3; i++) {
+        double s = dot3(cell + 3 * i, n[i]) / dot3(n[i], n[i]);
+        double p[3] = {n[i][0] * s, n[i][1] * s, n[i][2] * s};
+        fac[i] = (int)std::ceil(r_cut / norm3(p));
+    }
+}
+
+static bool invert3(const double *m, double *inv) {
+    double c0[3], c1[3], c2[3];
+    cross3(m + 3, m + 6, c0); cross3(m + 6, m, c1); cross3(m, m + 3, c2);
+    double det = dot3(m, c0);
+    if (!(std::fabs(det) > 1e-300)) return false;
+    for (int k = 0; k < 3; k++) { inv[3 * k] = c0[k] / det; inv[3 * k + 1] = c1[k] / det; inv[3 * k + 2] = c2[k] / det; }
+    return true;
+}
+
+static int make_geom(uf3_ctx *c, const uf3_basis *b, const uf3_frames *fr, int f, FrameGeom &g, int &bin_cursor) {
+    const double *cell = fr->cells + 9 * (size_t)f;
+    const uint8_t *pbc = fr->pbc + 3 * (size_t)f;
+    int64_t lo = fr->atom_offsets[f], hi = fr->atom_offsets[f + 1];
+    std::memset(&g, 0, sizeof(g));
+    g.atom_lo = (int)lo; g.atom_hi = (int)hi;
+    int n = (int)(hi - lo), n_per = 0;
+    for (int k = 0; k < 3; k++) { g.per[k] = pbc[k] ? 1 : 0; n_per += g.per[k]; }
+    std::memcpy(g.cell, cell, sizeof(double) * 9);
+    // effective cell: non-periodic axes become unit vectors orthogonal to the periodic ones
+    double eff[9];
+    std::memcpy(eff, cell, sizeof(eff));
+    if (n_per == 0) {
+        double id[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+        std::memcpy(eff, id, sizeof(eff));
+    } else if (n_per < 3) {
+        int pa[3], np = 0, na[3], nn = 0;
+        for (int k = 0; k < 3; k++) { if (g.per[k]) pa[np++] = k; else na[nn++] = k; }
+        if (np == 2) {
+            double w[3];
+            cross3(eff + 3 * pa[0], eff + 3 * pa[1], w);
+            double l = norm3(w);
+            if (l == 0) return fail(c, UF3_EINVAL, "periodic lattice vectors are parallel");
+            for (int q = 0; q < 3; q++) eff[3 * na[0] + q] = w[q] / l;
+        } else {
+            const double *u = eff + 3 * pa[0];
+            double l = norm3(u);
+            if (l == 0) return fail(c, UF3_EINVAL, "periodic lattice vector has zero length");
+            double t[3] = {0, 0, 0};
+            int mn = 0;
+            for (int q = 1; q < 3; q++) if (std::fabs(u[q]) < std::fabs(u[mn])) mn = q;
+            t[mn] = 1.0;
+            double v[3], w[3];
+            cross3(u, t, v);
+            double lv = norm3(v);
+            for (int q = 0; q < 3; q++) v[q] /= lv;
+            cross3(u, v, w);
+            double lw = norm3(w);
+            for (int q = 0; q < 3; q++) { eff[3 * na[0] + q] = v[q]; eff[3 * na[1] + q] = w[q] / lw; }
+        }
+    }
+    if (!invert3(eff, g.inv)) return fail(c, UF3_EINVAL, "cell is singular along a periodic direction");
+    double rs = b->host.rsearch;
+    if (n_per) {
+        reference_factors(cell, b->r_cut, g.fac);
+        for (int k = 0; k < 3; k++) if (!g.per[k]) g.fac[k] = 0;
+    }
+    // perpendicular heights of the effective cell
+    double nrm[3][3];
+    cross3(eff + 3, eff + 6, nrm[0]); cross3(eff + 6, eff, nrm[1]); cross3(eff, eff + 3, nrm[2]);
+    double vol = std::fabs(dot3(eff, nrm[0]));
+    int nb_np = std::max(1, std::min(32, (int)std::cbrt((double)std::max(1, n) / 4.0)));
+    long long nbins = 1;
+    for (int k = 0; k < 3; k++) {
+        double h = vol / norm3(nrm[k]);
+        g.cnt[k] = g.per[k] ? 2 * g.fac[k] + 1 : 1;
+        if (g.per[k]) {
+            int nb = (int)std::floor(h / rs);
+            nb = std::max(1, std::min(nb, 256));
+            g.nb[k] = nb;
+            g.rad[k] = (int)std::ceil(rs / (h / nb) - 1e-12);
+            if (g.rad[k] < 1) g.rad[k] = 1;
+            g.binw[k] = 1.0 / nb;
+            if (g.fac[k] > 400) return fail(c, UF3_EINVAL, "cell is too small relative to the cutoff");
+        } else {
+            g.nb[k] = nb_np;
+            g.rad[k] = 1;
+            g.binw[k] = rs / h;      // fractional width of a bin of real width rs
+        }
+        nbins *= g.nb[k];
+    }
+    long long m = (long long)g.cnt[0] * g.cnt[1] * g.cnt[2] * n;
+    if (m >= (1LL << 31)) return fail(c, UF3_EINVAL, "reference supercell index exceeds int32");
+    g.bin_base = bin_cursor;
+    if (nbins + bin_cursor >= (1LL << 30)) return fail(c, UF3_EINVAL, "too many cell-list bins");
+    bin_cursor += (int)nbins;
+    return UF3_OK;
+}
+
+// ------------------------------------------------------------------------------ shared pipeline
+struct Prepared {
+    int natoms = 0, n_frames = 0, nbins = 0;
+    CellList cl;
+    N3Lists n3;
+    const FrameGeom *geoms = nullptr;
+    const int *frame_of = nullptr;
+    const signed char *spec = nullptr;
+    const int64_t *d_offsets = nullptr;
+};
+
+static int check_flags(uf3_ctx *c) {
+    if (!c->flags.p) return UF3_OK;
+    int fl[4] = {0, 0, 0, 0};
+    HIPCHK(c, hipMemcpy(fl, c->flags.p, sizeof(fl), hipMemcpyDeviceToHost));
+    if (fl[0] == 2) { hipMemset(c->flags.p, 0, sizeof(fl)); return fail(c, UF3_ESPECIES, "frame contains an element outside the basis"); }
+    if (fl[0] == 1) { hipMemset(c->flags.p, 0, sizeof(fl)); return fail(c, UF3_EINVAL, "atom too far outside the periodic cell (|wrap| > 500)"); }
+    return UF3_OK;
+}
+
+static int n3_alloc(uf3_ctx *c, int natoms, int cap, N3Lists &n3) {
+    HIPCHK(c, c->n3_cnt.ensure(sizeof(int) * (size_t)natoms));
+    HIPCHK(c, c->n3_int.ensure(sizeof(int) * 4 * (size_t)natoms * cap));
+    HIPCHK(c, c->n3_dbl.ensure(sizeof(double) * 4 * (size_t)natoms * cap));
+    size_t n = (size_t)natoms * cap;
+    n3.cap = cap;
+    n3.cnt = c->n3_cnt.as<int>();
+    n3.parent = c->n3_int.as<int>(); n3.shiftc = n3.parent + n; n3.sidx = n3.shiftc + n; n3.spec = n3.sidx + n;
+    n3.dx = c->n3_dbl.as<double>(); n3.dy = n3.dx + n; n3.dz = n3.dy + n; n3.r = n3.dz + n;
+    return UF3_OK;
+}
+
+// cell list + 3-body neighbour lists for a batch (positions / species already in HBM)
+static int prepare(uf3_basis *b, const uf3_frames *fr, const double *d_pos, const int32_t *d_z, bool need_n3,
+                   Prepared &P) {
+    uf3_ctx *c = b->ctx;
+    if (!fr || fr->n_frames < 1 || !fr->atom_offsets || !fr->cells || !fr->pbc)
+        return fail(c, UF3_EINVAL, "bad uf3_frames");
+    if (fr->atom_offsets[0] != 0) return fail(c, UF3_EINVAL, "atom_offsets[0] must be 0");
+    int nf = fr->n_frames;
+    int64_t total = fr->atom_offsets[nf];
+    if (total < 1 || total >= (1LL << 31) / 8) return fail(c, UF3_EINVAL, "batch must hold 1 .. 2^28 atoms");
+    for (int f = 0; f < nf; f++)
+        if (fr->atom_offsets[f + 1] < fr->atom_offsets[f]) return fail(c, UF3_EINVAL, "atom_offsets must be non-decreasing");
+    int natoms = (int)total;
+    std::vector<FrameGeom> geoms(nf);
+    int bin_cursor = 0;
+    double dens = 0;
+    for (int f = 0; f < nf; f++) {
+        int rc = make_geom(c, b, fr, f, geoms[f], bin_cursor);
+        if (rc) return rc;
+        int n = geoms[f].atom_hi - geoms[f].atom_lo;
+        double vol = 0;
+        if (geoms[f].per[0] && geoms[f].per[1] && geoms[f].per[2]) {
+            double cr[3];
+            cross3(geoms[f].cell + 3, geoms[f].cell + 6, cr);
+            vol = std::fabs(dot3(geoms[f].cell, cr));
+        }
+        if (vol > 0) dens = std::max(dens, n / vol);
+    }
+    int nbins = bin_cursor;
+    hipStream_t st = c->stream;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, c->geoms.ensure(sizeof(FrameGeom) * nf));
+    HIPCHK(c, c->offsets.ensure(sizeof(int64_t) * (nf + 1)));
+    HIPCHK(c, hipMemcpyAsync(c->geoms.p, geoms.data(), sizeof(FrameGeom) * nf, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(c->offsets.p, fr->atom_offsets, sizeof(int64_t) * (nf + 1), hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipStreamSynchronize(st));   // geoms / offsets are stack / caller memory
+    size_t na = (size_t)natoms;
+    HIPCHK(c, c->frame_of.ensure(4 * na)); HIPCHK(c, c->atom_bin.ensure(4 * na)); HIPCHK(c, c->atom_wrap.ensure(4 * na));
+    HIPCHK(c, c->spec.ensure(na)); HIPCHK(c, c->key_in.ensure(4 * na)); HIPCHK(c, c->key_out.ensure(4 * na));
+    HIPCHK(c, c->val_in.ensure(4 * na)); HIPCHK(c, c->val_out.ensure(4 * na));
+    HIPCHK(c, c->bin_start.ensure(4 * ((size_t)nbins + 2)));
+    HIPCHK(c, c->s_atom.ensure(4 * na)); HIPCHK(c, c->s_pos.ensure(24 * na)); HIPCHK(c, c->s_wrap.ensure(4 * na));
+    HIPCHK(c, c->s_spec.ensure(na));
+    if (!c->flags.p) { HIPCHK(c, c->flags.ensure(64)); HIPCHK(c, hipMemsetAsync(c->flags.p, 0, 64, st)); }
+    int *flags = c->flags.as<int>();
+
+    Timed tm(c, T_NBR);
+    int tb = 256, gb = (natoms + tb - 1) / tb;
+    hipLaunchKernelGGL(k_frame_bins, dim3(gb), dim3(tb), 0, st, b->dev, c->geoms.as<FrameGeom>(),
+                       c->offsets.as<int64_t>(), nf, natoms, d_pos, d_z, c->frame_of.as<int>(), c->atom_bin.as<int>(),
+                       c->atom_wrap.as<int>(), c->spec.as<signed char>(), c->key_in.as<int>(), c->val_in.as<int>(), flags);
+    int bits = 1;
+    while ((1LL << bits) < (long long)nbins + 1) bits++;
+    size_t tmp_bytes = 0;
+    HIPCHK(c, rocprim::radix_sort_pairs(nullptr, tmp_bytes, c->key_in.as<int>(), c->key_out.as<int>(),
+                                         c->val_in.as<int>(), c->val_out.as<int>(), na, 0, bits, st));
+    HIPCHK(c, c->sort_tmp.ensure(tmp_bytes));
+    HIPCHK(c, rocprim::radix_sort_pairs(c->sort_tmp.p, tmp_bytes, c->key_in.as<int>(), c->key_out.as<int>(),
+                                         c->val_in.as<int>(), c->val_out.as<int>(), na, 0, bits, st));
+    hipLaunchKernelGGL(k_bin_start, dim3((nbins + 1 + tb - 1) / tb), dim3(tb), 0, st, c->key_out.as<int>(), natoms,
+                       nbins, c->bin_start.as<int>());
+    hipLaunchKernelGGL(k_gather_sorted, dim3(gb), dim3(tb), 0, st, c->val_out.as<int>(), natoms, d_pos,
+                       c->atom_wrap.as<int>(), c->spec.as<signed char>(), c->s_atom.as<int>(), c->s_pos.as<double>(),
+                       c->s_wrap.as<int>(), c->s_spec.as<signed char>());
+    HIPCHK(c, hipGetLastError());
+
+    P.natoms = natoms; P.n_frames = nf; P.nbins = nbins;
+    P.geoms = c->geoms.as<FrameGeom>();
+    P.frame_of = c->frame_of.as<int>();
+    P.spec = c->spec.as<signed char>();
+    P.d_offsets = c->offsets.as<int64_t>();
+    P.cl.bin_start = c->bin_start.as<int>(); P.cl.s_atom = c->s_atom.as<int>(); P.cl.s_pos = c->s_pos.as<double>();
+    P.cl.s_wrap = c->s_wrap.as<int>(); P.cl.s_spec = c->s_spec.as<signed char>();
+    P.cl.atom_bin = c->atom_bin.as<int>(); P.cl.atom_wrap = c->atom_wrap.as<int>();
+    std::memset(&P.n3, 0, sizeof(P.n3));
+    if (need_n3 && b->host.T > 0) {
+        // capacity: remembered from earlier calls, else a density estimate; overflow -> grow and redo
+        if (c->n3_cap == 0) {
+            double r = b->host.rmax3;
+            double est = dens > 0 ? 4.18879 * r * r * r * dens : 24.0;
+            c->n3_cap = std::max(16, ((int)(est * 1.8) + 8 + 7) / 8 * 8);
+        }
+        for (int attempt = 0; attempt < 6; attempt++) {
+            int cap = c->n3_cap;
+            int rc = n3_alloc(c, natoms, cap, P.n3);
+            if (rc) return rc;
+            HIPCHK(c, hipMemsetAsync(flags + 1, 0, sizeof(int), st));
+            size_t lds = (size_t)cap * (8 + 32 + 16);
+            if ((int)lds > c->lds_max) return fail(c, UF3_EOVERFLOW, "3-body neighbour list does not fit in LDS");
+            hipLaunchKernelGGL(k_build_n3, dim3(natoms), dim3(64), lds, st, b->dev, P.geoms, P.frame_of, P.cl, P.n3,
+                               d_pos, natoms, flags + 1);
+            HIPCHK(c, hipGetLastError());
+            int need = 0;
+            HIPCHK(c, hipMemcpyAsync(&need, flags + 1, sizeof(int), hipMemcpyDeviceToHost, st));
+            HIPCHK(c, hipStreamSynchronize(st));
+            if (need <= cap) return check_flags(c);
+            c->n3_cap = (need + 8 + 7) / 8 * 8;
+        }
+        return fail(c, UF3_EOVERFLOW, "3-body neighbour capacity did not converge");
+    }
+    return UF3_OK;
+}
+
+// ------------------------------------------------------------------------------ featurize
+static size_t feat_lds_bytes(int W, int cap, bool want_e, bool want_f) {
+    size_t d = (want_f ? 3 * (size_t)W : 0) + (want_e ? (size_t)W : 0) + 4 * (size_t)cap + (size_t)WAVE * ITEM_STRIDE;
+    return d * 8 + ((size_t)5 * cap + 1) * 4 + 16;
+}
+
+extern "C" int uf3_featurize_dev(uf3_basis *b, const uf3_frames *fr, const double *d_pos, const int32_t *d_z,
+                                 double *d_xe, double *d_xf) {
+    if (!b) return fail(nullptr, UF3_EINVAL, "null basis");
+    uf3_ctx *c = b->ctx;
+    if (!d_pos || !d_z) return fail(c, UF3_EINVAL, "null positions / species");
+    if (!d_xe && !d_xf) return UF3_OK;
+    Prepared P;
+    int rc = prepare(b, fr, d_pos, d_z, true, P);
+    if (rc) return rc;
+    hipStream_t st = c->stream;
+    const int F = b->host.F;
+    const bool want_e = d_xe != nullptr, want_f = d_xf != nullptr;
+    if (want_e) HIPCHK(c, hipMemsetAsync(d_xe, 0, sizeof(double) * (size_t)P.n_frames * F, st));
+    int cap = std::max(1, P.n3.cap);
+    // column windows: whole interaction blocks, as many as fit in LDS
+    int budget = std::min(c->lds_max, 160 * 1024) - 512;
+    std::vector<std::pair<int, int>> windows;
+    {
+        const std::vector<int> &bd = b->block_bounds;
+        size_t i = 0;
+        while (i + 1 < bd.size()) {
+            size_t j = i + 1;
+            while (j + 1 < bd.size() && (int)feat_lds_bytes(bd[j + 1] - bd[i], cap, want_e, want_f) <= budget) j++;
+            if ((int)feat_lds_bytes(bd[j] - bd[i], cap, want_e, want_f) > budget)
+                return fail(c, UF3_EOVERFLOW, "one interaction block exceeds the LDS row buffer");
+            windows.push_back({bd[i], bd[j]});
+            i = j;
+        }
+    }
+    // prefer >= 2 resident waves per SIMD when the whole row fits a smaller window set?  keep simple: as few
+    // windows as possible (each window re-walks the neighbour lists)
+    int n_waves = std::min(P.natoms, c->n_cu * 16);
+    int apw = (P.natoms + n_waves - 1) / n_waves;
+    n_waves = (P.natoms + apw - 1) / apw;
+    FeatArgs A;
+    A.B = b->dev; A.geoms = P.geoms; A.frame_of = P.frame_of; A.cl = P.cl; A.n3 = P.n3;
+    if (!A.n3.cap) A.n3.cap = 1;
+    A.pos = d_pos; A.spec = P.spec; A.x_e = d_xe; A.x_f = d_xf; A.natoms = P.natoms; A.atoms_per_wave = apw;
+    for (auto &w : windows) {
+        A.col_lo = w.first; A.col_hi = w.second;
+        size_t lds = feat_lds_bytes(w.second - w.first, A.n3.cap, want_e, want_f);
+        Timed tm(c, T_FEAT);
+        if (want_e && want_f) {
+            HIPCHK(c, hipFuncSetAttribute((const void *)k_featurize<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL((k_featurize<true, true>), dim3(n_waves), dim3(64), lds, st, A);
+        } else if (want_f) {
+            HIPCHK(c, hipFuncSetAttribute((const void *)k_featurize<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL((k_featurize<false, true>), dim3(n_waves), dim3(64), lds, st, A);
+        } else {
+            HIPCHK(c, hipFuncSetAttribute((const void *)k_featurize<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL((k_featurize<true, false>), dim3(n_waves), dim3(64), lds, st, A);
+        }
+        HIPCHK(c, hipGetLastError());
+    }
+    return UF3_OK;
+}
+
+// host-buffer helpers
+static int upload_frames(uf3_ctx *c, const uf3_frames *fr, const double *pos, const int32_t *z, int &natoms) {
+    if (!fr || fr->n_frames < 1 || !fr->atom_offsets) return fail(c, UF3_EINVAL, "bad uf3_frames");
+    int64_t total = fr->atom_offsets[fr->n_frames];
+    if (total < 1 || total >= (1LL << 28)) return fail(c, UF3_EINVAL, "batch must hold 1 .. 2^28 atoms");
+    if (!pos || !z) return fail(c, UF3_EINVAL, "null positions / species");
+    natoms = (int)total;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, c->stage_pos.ensure(24 * (size_t)natoms));
+    HIPCHK(c, c->stage_z.ensure(4 * (size_t)natoms));
+    HIPCHK(c, hipMemcpyAsync(c->stage_pos.p, pos, 24 * (size_t)natoms, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->stage_z.p, z, 4 * (size_t)natoms, hipMemcpyHostToDevice, c->stream));
+    return UF3_OK;
+}
+
+extern "C" int uf3_featurize(uf3_basis *b, const uf3_frames *fr, const double *pos, const int32_t *z, double *xe,
+                             double *xf) {
+    if (!b) return fail(nullptr, UF3_EINVAL, "null basis");
+    uf3_ctx *c = b->ctx;
+    int natoms = 0;
+    int rc = upload_frames(c, fr, pos, z, natoms);
+    if (rc) return rc;
+    size_t F = (size_t)b->host.F;
+    size_t be = xe ? 8 * F * fr->n_frames : 0, bf = xf ? 8 * F * 3 * (size_t)natoms : 0;
+    if (be) HIPCHK(c, c->stage_out.ensure(be));
+    if (bf) HIPCHK(c, c->stage_out2.ensure(bf));
+    rc = uf3_featurize_dev(b, fr, c->stage_pos.as<double>(), c->stage_z.as<int32_t>(),
+                           be ? c->stage_out.as<double>() : nullptr, bf ? c->stage_out2.as<double>() : nullptr);
+    if (rc) return rc;
+    if (be) HIPCHK(c, hipMemcpyAsync(xe, c->stage_out.p, be, hipMemcpyDeviceToHost, c->stream));
+    if (bf) HIPCHK(c, hipMemcpyAsync(xf, c->stage_out2.p, bf, hipMemcpyDeviceToHost, c->stream));
+    return uf3_ctx_synchronize(c);
+}
+
+// ------------------------------------------------------------------------------ eval
+extern "C" int uf3_eval_dev(uf3_basis *b, const uf3_frames *fr, const double *d_pos, const int32_t *d_z,
+                            const double *c1, const double *c2, const double *c3, double *d_energies, double *d_forces) {
+    if (!b) return fail(nullptr, UF3_EINVAL, "null basis");
+    uf3_ctx *c = b->ctx;
+    if (!d_pos || !d_z || !c1 || !d_energies) return fail(c, UF3_EINVAL, "uf3_eval: null argument");
+    if ((b->c2_len && !c2) || (b->c3_len && !c3)) return fail(c, UF3_EINVAL, "uf3_eval: missing coefficients");
+    Prepared P;
+    int rc = prepare(b, fr, d_pos, d_z, true, P);
+    if (rc) return rc;
+    hipStream_t st = c->stream;
+    size_t n1 = (size_t)b->host.S, n2 = b->c2_len, n3 = b->c3_len;
+    HIPCHK(c, c->coeff.ensure(8 * (n1 + n2 + n3 + 1)));
+    double *dc = c->coeff.as<double>();
+    HIPCHK(c, hipMemcpyAsync(dc, c1, 8 * n1, hipMemcpyHostToDevice, st));
+    if (n2) HIPCHK(c, hipMemcpyAsync(dc + n1, c2, 8 * n2, hipMemcpyHostToDevice, st));
+    if (n3) HIPCHK(c, hipMemcpyAsync(dc + n1 + n2, c3, 8 * n3, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    HIPCHK(c, c->e_atom.ensure(8 * (size_t)P.natoms));
+    EvalArgs A;
+    A.B = b->dev; A.geoms = P.geoms; A.frame_of = P.frame_of; A.cl = P.cl; A.n3 = P.n3;
+    if (!A.n3.cap) A.n3.cap = 1;
+    A.pos = d_pos; A.spec = P.spec; A.c1 = dc; A.c2 = dc + n1; A.c3 = dc + n1 + n2;
+    A.e_atom = c->e_atom.as<double>(); A.forces = d_forces; A.natoms = P.natoms;
+    size_t lds = (size_t)A.n3.cap * 32 + ((size_t)5 * A.n3.cap + 1) * 4 + 16;
+    {
+        Timed tm(c, T_EVAL);
+        hipLaunchKernelGGL(k_eval, dim3(P.natoms), dim3(64), lds, st, A);
+        hipLaunchKernelGGL(k_frame_energy, dim3(P.n_frames), dim3(256), 0, st, A.e_atom, P.d_offsets, d_energies);
+    }
+    HIPCHK(c, hipGetLastError());
+    return UF3_OK;
+}
+
+extern "C" int uf3_eval(uf3_basis *b, const uf3_frames *fr, const double *pos, const int32_t *z, const double *c1,
+                        const double *c2, const double *c3, double *energies, double *forces) {
+    if (!b) return fail(nullptr, UF3_EINVAL, "null basis");
+    uf3_ctx *c = b->ctx;
+    if (!energies) return fail(c, UF3_EINVAL, "uf3_eval: null energies");
+    int natoms = 0;
+    int rc = upload_frames(c, fr, pos, z, natoms);
+    if (rc) return rc;
+    HIPCHK(c, c->stage_out.ensure(8 * (size_t)fr->n_frames));
+    if (forces) HIPCHK(c, c->stage_out2.ensure(24 * (size_t)natoms));
+    rc = uf3_eval_dev(b, fr, c->stage_pos.as<double>(), c->stage_z.as<int32_t>(), c1, c2, c3,
+                      c->stage_out.as<double>(), forces ? c->stage_out2.as<double>() : nullptr);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(energies, c->stage_out.p, 8 * (size_t)fr->n_frames, hipMemcpyDeviceToHost, c->stream));
+    if (forces) HIPCHK(c, hipMemcpyAsync(forces, c->stage_out2.p, 24 * (size_t)natoms, hipMemcpyDeviceToHost, c->stream));
+    return uf3_ctx_synchronize(c);
+}
+
+// ------------------------------------------------------------------------------ gram
+static int ensure_frag(uf3_ctx *c) {
+    if (c->frag_ready) return UF3_OK;
+    HIPCHK(c, c->frag.ensure(sizeof(int) * 64 * 4 * 2));
+    hipLaunchKernelGGL(k_mfma_probe, dim3(1), dim3(64), 0, c->stream, c->frag.as<int>());
+    int tab[512];
+    HIPCHK(c, hipMemcpyAsync(tab, c->frag.p, sizeof(tab), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    bool seen[256] = {false};
+    for (int q = 0; q < 256; q++) {
+        int r = tab[2 * q], cc = tab[2 * q + 1];
+        if (r < 0 || r > 15 || cc < 0 || cc > 15 || seen[r * 16 + cc])
+            return fail(c, UF3_EHIP, "unexpected v_mfma_f64_16x16x4 fragment layout");
+        seen[r * 16 + cc] = true;
+    }
+    c->frag_ready = true;
+    return UF3_OK;
+}
+
+extern "C" int uf3_gram_dev(uf3_ctx *c, const double *dx, const double *dy, int64_t n_rows, int32_t n_feat, int64_t ld,
+                            int accumulate, double *d_gram, double *d_ord) {
+    if (!c) return fail(nullptr, UF3_EINVAL, "null ctx");
+    if (!dx || !d_gram || n_feat < 1 || ld < n_feat || n_rows < 0) return fail(c, UF3_EINVAL, "uf3_gram: bad argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = ensure_frag(c);
+    if (rc) return rc;
+    hipStream_t st = c->stream;
+    if (!accumulate) {
+        HIPCHK(c, hipMemsetAsync(d_gram, 0, 8 * (size_t)n_feat * n_feat, st));
+        if (d_ord) HIPCHK(c, hipMemsetAsync(d_ord, 0, 8 * (size_t)n_feat, st));
+    }
+    if (n_rows == 0) return UF3_OK;
+    int nt = (n_feat + 31) / 32;
+    std::vector<int> ti, tj;
+    for (int i = 0; i < nt; i++) for (int j = i; j < nt; j++) { ti.push_back(i); tj.push_back(j); }
+    while (ti.size() % 4) { ti.push_back(-1); tj.push_back(-1); }
+    size_t np = ti.size();
+    HIPCHK(c, c->gram_tiles.ensure(8 * np));
+    int *d_ti = c->gram_tiles.as<int>(), *d_tj = d_ti + np;
+    HIPCHK(c, hipMemcpyAsync(d_ti, ti.data(), 4 * np, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(d_tj, tj.data(), 4 * np, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    // enough row chunks to fill the chip, each a multiple of 4 rows
+    int blocks_xy = (int)(np / 4);
+    int want_chunks = std::max(1, (c->n_cu * 4 + blocks_xy - 1) / blocks_xy);
+    int64_t rpc = (n_rows + want_chunks - 1) / want_chunks;
+    rpc = std::max<int64_t>(64, (rpc + 3) / 4 * 4);
+    int chunks = (int)((n_rows + rpc - 1) / rpc);
+    {
+        Timed tm(c, T_GRAM);
+        hipLaunchKernelGGL(k_gram_mfma, dim3(blocks_xy, chunks), dim3(256), 0, st, dx, n_rows, n_feat, ld, (int)rpc,
+                           d_ti, d_tj, c->frag.as<int>(), d_gram);
+        hipLaunchKernelGGL(k_gram_mirror, dim3((n_feat + 255) / 256, n_feat), dim3(256), 0, st, d_gram, n_feat);
+        if (d_ord && dy) {
+            int ochunks = (int)std::min<int64_t>(1024, (n_rows + 255) / 256);
+            int64_t orpc = (n_rows + ochunks - 1) / ochunks;
+            ochunks = (int)((n_rows + orpc - 1) / orpc);
+            hipLaunchKernelGGL(k_ordinate, dim3((n_feat + 255) / 256, ochunks), dim3(256), 0, st, dx, dy, n_rows, n_feat,
+                               ld, (int)orpc, d_ord);
+        }
+    }
+    HIPCHK(c, hipGetLastError());
+    return UF3_OK;
+}
+
+extern "C" int uf3_gram(uf3_ctx *c, const double *x, const double *y, int64_t n_rows, int32_t n_feat, int64_t ld,
+                        int accumulate, double *gram, double *ord) {
+    if (!c) return fail(nullptr, UF3_EINVAL, "null ctx");
+    if (!x || !gram || n_feat < 1 || ld < n_feat || n_rows < 0) return fail(c, UF3_EINVAL, "uf3_gram: bad argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    size_t bx = 8 * (size_t)n_rows * ld, bg = 8 * (size_t)n_feat * n_feat, bo = 8 * (size_t)n_feat;
+    HIPCHK(c, c->stage_out2.ensure(bx + 8 * (size_t)n_rows + 64));
+    HIPCHK(c, c->stage_out.ensure(bg + bo));
+    double *dxp = c->stage_out2.as<double>(), *dyp = dxp + (size_t)n_rows * ld;
+    double *dg = c->stage_out.as<double>(), *dord = dg + (size_t)n_feat * n_feat;
+    if (n_rows) HIPCHK(c, hipMemcpyAsync(dxp, x, bx, hipMemcpyHostToDevice, c->stream));
+    if (y && n_rows) HIPCHK(c, hipMemcpyAsync(dyp, y, 8 * (size_t)n_rows, hipMemcpyHostToDevice, c->stream));
+    if (accumulate) {
+        HIPCHK(c, hipMemcpyAsync(dg, gram, bg, hipMemcpyHostToDevice, c->stream));
+        if (ord) HIPCHK(c, hipMemcpyAsync(dord, ord, bo, hipMemcpyHostToDevice, c->stream));
+    }
+    int rc = uf3_gram_dev(c, dxp, y ? dyp : nullptr, n_rows, n_feat, ld, accumulate, dg, (ord && y) ? dord : nullptr);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(gram, dg, bg, hipMemcpyDeviceToHost, c->stream));
+    if (ord && y) HIPCHK(c, hipMemcpyAsync(ord, dord, bo, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return UF3_OK;
+}
+
+// ------------------------------------------------------------------------------ neighbour debug
+extern "C" int uf3_neighbors_debug(uf3_basis *b, const uf3_frames *fr, const double *pos, const int32_t *z,
+                                   int64_t *pair_count, int64_t *pair_ij, int64_t pair_cap, int64_t *n3_count,
+                                   int64_t *n3_ij, int64_t n3_cap) {
+    if (!b) return fail(nullptr, UF3_EINVAL, "null basis");
+    uf3_ctx *c = b->ctx;
+    if (!fr || fr->n_frames != 1) return fail(c, UF3_EINVAL, "uf3_neighbors_debug takes exactly one frame");
+    int natoms = 0;
+    int rc = upload_frames(c, fr, pos, z, natoms);
+    if (rc) return rc;
+    Prepared P;
+    rc = prepare(b, fr, c->stage_pos.as<double>(), c->stage_z.as<int32_t>(), false, P);
+    if (rc) return rc;
+    int np = b->host.P;
+    std::vector<long long> counts(np + 2, 0);
+    std::vector<long long> tuples;
+    long long cap = 0;
+    for (int pass = 0; pass < 2; pass++) {
+        HIPCHK(c, c->dbg.ensure(8 * (size_t)(np + 2) + 24 * (size_t)std::max<long long>(1, cap)));
+        long long *d_counts = c->dbg.as<long long>(), *d_tuples = d_counts + np + 2;
+        HIPCHK(c, hipMemsetAsync(d_counts, 0, 8 * (size_t)(np + 2), c->stream));
+        hipLaunchKernelGGL(k_debug_pairs, dim3(natoms), dim3(64), 0, c->stream, b->dev, P.geoms, P.frame_of, P.cl,
+                           (const double *)c->stage_pos.as<double>(), P.spec, natoms, d_counts, d_tuples, cap);
+        HIPCHK(c, hipMemcpyAsync(counts.data(), d_counts, 8 * (size_t)(np + 2), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (pass == 0) { cap = counts[np + 1]; if (cap == 0) break; continue; }
+        tuples.resize(3 * (size_t)cap);
+        HIPCHK(c, hipMemcpy(tuples.data(), d_tuples, 24 * (size_t)cap, hipMemcpyDeviceToHost));
+    }
+    rc = check_flags(c);
+    if (rc) return rc;
+    if (pair_count) for (int p = 0; p < np; p++) pair_count[p] = counts[p];
+    if (n3_count) *n3_count = counts[np];
+    struct T3 { long long p, i, j; };
+    std::vector<T3> v((size_t)cap);
+    for (long long q = 0; q < cap; q++) v[q] = {tuples[3 * q], tuples[3 * q + 1], tuples[3 * q + 2]};
+    std::sort(v.begin(), v.end(), [](const T3 &a, const T3 &bb) {
+        return a.p != bb.p ? a.p < bb.p : (a.i != bb.i ? a.i < bb.i : a.j < bb.j);
+    });
+    std::vector<long long> cur(np + 1, 0);
+    for (const T3 &t : v) {
+        if (t.p < np) {
+            if (pair_ij && cur[t.p] < pair_cap) { pair_ij[2 * (t.p * pair_cap + cur[t.p])] = t.i; pair_ij[2 * (t.p * pair_cap + cur[t.p]) + 1] = t.j; }
+        } else if (n3_ij && cur[np] < n3_cap) { n3_ij[2 * cur[np]] = t.i; n3_ij[2 * cur[np] + 1] = t.j; }
+        cur[t.p]++;
+    }
+    return UF3_OK;
+}

@@ -1,0 +1,143 @@
+"""
+``UFCalculator``: energy and forces of a fitted UF3 model on the MI355X.
+
+Surface follows the reference's ``uf3/forcefield/calculator.py`` (:40-153, helpers
+:490-573): ``UFCalculator(model)``, ASE's ``calculate(atoms, properties,
+system_changes)`` protocol with ``results['energy'|'free_energy'|'forces'|'stress']``,
+``get_potential_energy`` / ``get_forces``.  The evaluation is the featurizer's
+traversal contracted with the coefficients on the fly (``uf3_eval`` in
+``libuf3hip.so``): pair splines from the pair coefficient vectors, trio splines from
+the decompressed L x M x N grids (``decompress_3B``), as the reference builds its
+``ndsplines`` objects.  Stress is numerical (central differences of the energy), as
+in the reference.  ASE is optional: the class derives from ``ase``'s Calculator when
+ASE is importable and is otherwise a duck-typed stand-alone.
+"""
+import ctypes as C
+
+import numpy as np
+
+from uf3_amd import _lib
+
+try:  # pragma: no cover - ASE is not installed on the build / GPU boxes
+    from ase.calculators.calculator import Calculator as _Base, all_changes
+except Exception:  # noqa: BLE001
+    all_changes = ['positions', 'numbers', 'cell', 'pbc', 'initial_charges', 'initial_magmoms']
+
+    class _Base:
+        def __init__(self, **kwargs):
+            self.results = {}
+            self.atoms = None
+
+        def calculate(self, atoms=None, properties=None, system_changes=all_changes):
+            if atoms is not None:
+                self.atoms = atoms.copy() if hasattr(atoms, "copy") else atoms
+
+        def get_property(self, name, atoms=None, allow_calculation=True):
+            self.calculate(atoms, [name], all_changes)
+            return self.results[name]
+
+        def get_potential_energy(self, atoms=None, force_consistent=False):
+            return self.get_property('energy', atoms)
+
+        def get_forces(self, atoms=None):
+            return self.get_property('forces', atoms)
+
+        def get_stress(self, atoms=None):
+            return self.get_property('stress', atoms)
+
+
+def coefficients_by_interaction(element_list, interactions_map, partition_sizes, coefficients):
+    parts = np.array_split(coefficients, np.cumsum(partition_sizes)[:-1])
+    n = len(element_list)
+    solutions = {el: v for el, v in zip(element_list, parts[:n])}
+    for idx, key in enumerate(list(interactions_map[2]) + list(interactions_map.get(3, []))):
+        solutions[key] = parts[n + idx]
+    return solutions
+
+
+class UFCalculator(_Base):
+    implemented_properties = ['energy', 'forces', 'stress']
+
+    def __init__(self, model, device=None, **kwargs):
+        super().__init__(**kwargs)
+        self.bspline_config = model.bspline_config
+        self.model = model
+        self.device = device
+        basis = self.bspline_config
+        self.solutions = coefficients_by_interaction(basis.element_list, basis.interactions_map,
+                                                     basis.partition_sizes, model.coefficients)
+        self.pair_potentials = {p: np.asarray(self.solutions[p], dtype=float)
+                                for p in basis.interactions_map[2]}
+        self.trio_potentials = {}
+        if basis.degree > 2:
+            self.trio_potentials = {t: basis.decompress_3B(np.asarray(self.solutions[t], dtype=float), t)
+                                    for t in basis.interactions_map[3]}
+        self._c1 = np.ascontiguousarray([float(np.ravel(self.solutions[el])[0]) for el in basis.element_list])
+        self._c2 = np.ascontiguousarray(np.concatenate([self.pair_potentials[p] for p in basis.interactions_map[2]]))
+        self._c3 = (np.ascontiguousarray(np.concatenate([self.trio_potentials[t].ravel()
+                                                         for t in basis.interactions_map[3]]))
+                    if self.trio_potentials else np.zeros(1))
+
+    degree = property(lambda self: self.bspline_config.degree)
+    element_list = property(lambda self: self.bspline_config.element_list)
+    interactions_map = property(lambda self: self.bspline_config.interactions_map)
+    r_min_map = property(lambda self: self.bspline_config.r_min_map)
+    r_max_map = property(lambda self: self.bspline_config.r_max_map)
+    r_cut = property(lambda self: self.bspline_config.r_cut)
+    partition_sizes = property(lambda self: self.bspline_config.partition_sizes)
+    coefficients = property(lambda self: self.model.coefficients)
+    chemical_system = property(lambda self: self.bspline_config.chemical_system)
+
+    def __repr__(self):
+        return "\n".join(["UFCalculator:", repr(self.model)])
+
+    def evaluate_frames(self, atoms_list, forces=True):
+        """Energies [n_frames] and forces [sum N, 3] of a batch of frames."""
+        ctx = _lib.get_context(self.device)
+        db = _lib.device_basis(self.bspline_config, ctx)
+        batch = _lib.FrameBatch(atoms_list)
+        e = np.empty(batch.n_frames)
+        f = np.empty((batch.n_atoms, 3)) if forces else None
+        ctx.check(ctx.lib.uf3_eval(db.handle, C.byref(batch.struct), _lib._p(batch.pos), _lib._p(batch.z),
+                                   _lib._p(self._c1), _lib._p(self._c2), _lib._p(self._c3), _lib._p(e), _lib._p(f)))
+        return e, f, batch.offsets
+
+    def calculate(self, atoms=None, properties=None, system_changes=tuple(all_changes)):
+        if properties is None:
+            properties = self.implemented_properties
+        _Base.calculate(self, atoms, properties, system_changes)
+        want_f = 'forces' in properties
+        if ('energy' in properties) or ('free_energy' in properties) or want_f:
+            e, f, _ = self.evaluate_frames([atoms], forces=want_f)
+            self.results['energy'] = float(e[0])
+            self.results['free_energy'] = self.results['energy']
+            if want_f:
+                self.results['forces'] = f
+        if 'stress' in properties:
+            self.results['stress'] = self._get_stress(atoms)
+
+    def _get_potential_energy(self, atoms=None, force_consistent=None):
+        return float(self.evaluate_frames([atoms], forces=False)[0][0])
+
+    def _get_forces(self, atoms=None):
+        return self.evaluate_frames([atoms], forces=True)[1]
+
+    def _get_stress(self, atoms=None, d=1e-6):
+        """Numerical stress, Voigt order (xx, yy, zz, yz, xz, xy); the 12 strained copies run as one batch."""
+        cell = np.array(atoms.get_cell(), dtype=float).reshape(3, 3)
+        pos = np.asarray(atoms.get_positions(), dtype=float)
+        vol = abs(np.linalg.det(cell))
+        from uf3_amd.data.atoms import Atoms
+        frames, pairs = [], [(0, 0), (1, 1), (2, 2), (1, 2), (0, 2), (0, 1)]
+        for i, j in pairs:
+            for sign in (+1, -1):
+                eps = np.eye(3)
+                if i == j:
+                    eps[i, i] += sign * d
+                else:
+                    eps[i, j] += 0.5 * sign * d
+                    eps[j, i] += 0.5 * sign * d
+                frames.append(Atoms(numbers=atoms.get_atomic_numbers(), positions=pos @ eps, cell=cell @ eps,
+                                    pbc=atoms.get_pbc()))
+        e = self.evaluate_frames(frames, forces=False)[0]
+        return np.array([(e[2 * k] - e[2 * k + 1]) / (2 * d * vol) for k in range(6)])

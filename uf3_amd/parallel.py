@@ -1,0 +1,102 @@
+"""
+Frame sharding across the GPUs of a node and the single sum-reduce of the normal
+equations.
+
+The reference fans ``BasisFeaturizer.evaluate`` out over DataFrame chunks with a
+process pool / dask (``uf3/representation/process.py:196-254``,
+``uf3/util/parallel.py:167-251``) and adds the per-table Gram pieces serially
+(``least_squares.py:391-412``).  Here frames are sharded one contiguous block per
+rank (one process per GPU), every rank featurizes and accumulates its own
+``{G_e, G_f, o_e, o_f}`` + target moments, and ONE ``all_reduce(SUM)`` over a packed
+fp64 buffer (2F'^2 + 2F' + 6 doubles; RCCL over xGMI when the backend is "nccl",
+gloo in the CPU tests) yields the global pieces.  Featurize-only work needs no
+collective at all.
+"""
+import numpy as np
+
+
+def shard_range(n_items, rank, world_size):
+    """Contiguous block [lo, hi) of rank; sizes differ by at most one."""
+    base, rem = divmod(int(n_items), int(world_size))
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+PIECE_KEYS = ("gram_e", "gram_f", "ord_e", "ord_f", "m_e", "m_f")
+
+
+def pack_pieces(pieces, n_cols):
+    """dict of additive pieces -> one flat fp64 vector (missing force pieces = zeros)."""
+    shapes = dict(gram_e=(n_cols, n_cols), gram_f=(n_cols, n_cols), ord_e=(n_cols,), ord_f=(n_cols,),
+                  m_e=(3,), m_f=(3,))
+    return np.concatenate([np.asarray(pieces.get(k, np.zeros(shapes[k])), dtype=np.float64).reshape(-1)
+                           for k in PIECE_KEYS])
+
+
+def unpack_pieces(buf, n_cols, with_forces=True):
+    buf = np.asarray(buf, dtype=np.float64)
+    n2 = n_cols * n_cols
+    out, o = {}, 0
+    for k, size, shape in (("gram_e", n2, (n_cols, n_cols)), ("gram_f", n2, (n_cols, n_cols)),
+                           ("ord_e", n_cols, (n_cols,)), ("ord_f", n_cols, (n_cols,)),
+                           ("m_e", 3, (3,)), ("m_f", 3, (3,))):
+        out[k] = buf[o:o + size].reshape(shape).copy()
+        o += size
+    if not with_forces:
+        for k in ("gram_f", "ord_f", "m_f"):
+            out.pop(k)
+    return out
+
+
+def allreduce_pieces(pieces, n_cols, device=None):
+    """
+    Sum the pieces over all ranks of the default process group (no-op when
+    torch.distributed is not initialised).  With the "nccl" backend the packed
+    buffer is reduced on the GPU by RCCL; with "gloo" on the host.
+    """
+    import torch
+    import torch.distributed as dist
+    with_forces = "gram_f" in pieces
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return pieces
+    flat = torch.from_numpy(pack_pieces(pieces, n_cols))
+    if dist.get_backend() == "nccl":
+        dev = torch.device("cuda", torch.cuda.current_device() if device is None else device)
+        t = flat.to(dev)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        flat = t.cpu()
+    else:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    # every rank must agree on whether forces were present
+    return unpack_pieces(flat.numpy(), n_cols, with_forces=with_forces)
+
+
+def sharded_fit(model, featurizer, frames, energies, forces=None, weight=0.5):
+    """
+    Data-parallel ``WeightedLinearModel`` fit: this rank featurizes its block of
+    ``frames`` (list of Atoms; energies [n]; forces list of (N_i, 3) arrays), builds the
+    Gram pieces on its GPU, all ranks sum-reduce once and every rank solves the
+    same small system.  Energy rows and targets are per-atom normalised as in the
+    reference's from-file path (least_squares.py:697-700).
+    """
+    import torch.distributed as dist
+    rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+    world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+    lo, hi = shard_range(len(frames), rank, world)
+    mine = frames[lo:hi]
+    n_el = len(model.bspline_config.element_list)
+    x_e, x_f, _ = featurizer.featurize_frames(mine, energy=True, forces=forces is not None)
+    n_atoms = np.sum(x_e[:, :n_el], axis=1)
+    x_e = x_e / n_atoms[:, None]
+    y_e = np.asarray(energies[lo:hi], dtype=float) / n_atoms
+    if forces is not None:
+        # row order of the reference: all fx, then fy, then fz of a frame does not matter for a Gram
+        x_f = x_f.reshape(-1, x_f.shape[-1])
+        y_f = np.concatenate([np.asarray(f, dtype=float).reshape(-1, 3) for f in forces[lo:hi]]).reshape(-1)
+        pieces = model.gram_pieces(x_e, y_e, x_f, y_f)
+    else:
+        pieces = model.gram_pieces(x_e, y_e)
+    n_cols = model.n_feats - len(model.col_idx)
+    pieces = allreduce_pieces(pieces, n_cols)
+    model.fit_from_pieces(pieces, weight=weight)
+    return pieces

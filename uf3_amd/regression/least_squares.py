@@ -1,0 +1,314 @@
+"""
+``WeightedLinearModel``: regularised normal equations for UF3 coefficients.
+
+Surface follows the reference's ``uf3/regression/least_squares.py``
+(``WeightedLinearModel`` :144-621, gram helpers :716-760, frozen columns :817-890,
+weights :1147-1169).  The heavy part -- ``G = X^T X`` and ``o = X^T y`` over all
+energy and force rows -- runs on the MI355X matrix cores (``uf3_gram`` in
+``libuf3hip.so``; fp64 MFMA).  The F' x F' solve stays on the host (LAPACK dgesv via
+``numpy.linalg.solve``, exactly as the reference, :763-771); it is O(F'^3) once per fit.
+
+``gram_pieces`` / ``fit_from_pieces`` expose the per-shard pieces
+``{G_e, G_f, o_e, o_f}`` + target moments, i.e. what a multi-GPU fit sum-reduces
+(``uf3_amd.parallel``).  No CPU fallback for the Gram accumulation.
+"""
+import warnings
+
+import numpy as np
+
+from uf3_amd import _lib
+from uf3_amd.data import composition
+from uf3_amd.representation import bspline
+from uf3_amd.util import json_io
+
+
+class VarianceRecorder:
+    """Streaming mean / population std (least_squares.py:19-67)."""
+
+    def __init__(self, mean=0, std=0, n=0):
+        self.mean, self.std, self.n = mean, std, int(n)
+
+    def update(self, batch):
+        batch = np.asarray(batch, dtype=float)
+        if self.n == 0:
+            self.mean, self.std, self.n = np.mean(batch, axis=0), np.std(batch, axis=0), len(batch)
+        else:
+            m, n = float(self.n), len(batch)
+            b_std, b_mean = np.std(batch, axis=0), np.mean(batch, axis=0)
+            var = (m / (m + n) * self.std ** 2 + n / (m + n) * b_std ** 2
+                   + m * n / (m + n) ** 2 * (self.mean - b_mean) ** 2)
+            self.std = np.sqrt(var)
+            self.mean = m / (m + n) * self.mean + n / (m + n) * b_mean
+            self.n += n
+        return self.mean, self.std, self.n
+
+
+def moments(y):
+    """(n, sum, sum of squares): the additive form of VarianceRecorder, for reductions."""
+    y = np.asarray(y, dtype=float)
+    return np.array([len(y), np.sum(y), np.sum(y * y)])
+
+
+def std_from_moments(m):
+    n, s, ss = m
+    if n == 0:
+        return 0.0
+    mean = s / n
+    return float(np.sqrt(max(ss / n - mean * mean, 0.0)))
+
+
+def gram_device(x, y, device=None):
+    """(X^T X, X^T y) of a row block on the GPU (fp64 MFMA)."""
+    import ctypes as C
+    ctx = _lib.get_context(device)
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    y = np.ascontiguousarray(y, dtype=np.float64)
+    n_rows, n_feat = x.shape
+    gram = np.empty((n_feat, n_feat))
+    ordinate = np.empty(n_feat)
+    ctx.check(ctx.lib.uf3_gram(ctx.handle, _lib._p(x), _lib._p(y), n_rows, n_feat, n_feat, 0,
+                               _lib._p(gram), _lib._p(ordinate)))
+    return gram, ordinate
+
+
+def moore_penrose_components(x, y):
+    return gram_device(x, y)
+
+
+def batched_moore_penrose(x, y, batch_size=2500):
+    # one device launch covers any number of rows; batch_size kept for signature parity
+    return gram_device(x, y)
+
+
+def lu_factorization(a, b):
+    return np.linalg.solve(a, b)
+
+
+def get_freezing_mask(n_feats, col_idx):
+    return np.setdiff1d(np.arange(n_feats), col_idx)
+
+
+def freeze_columns(x, y, mask, frozen_c, col_idx):
+    x = np.asarray(x)
+    y = np.subtract(y, np.dot(x[:, col_idx], frozen_c))
+    return x[:, mask], y
+
+
+def freeze_regularizer(regularizer, mask):
+    return regularizer[:, mask]
+
+
+def revert_frozen_coefficients(solution, n_coeff, mask, frozen_c, frozen_idx):
+    full = np.zeros(n_coeff)
+    full[mask] = solution
+    full[frozen_idx] = frozen_c
+    return full
+
+
+def calc_E_F_weights(n_e, n_f, std_e, std_f):
+    if std_e == 0:
+        return 1.0, 1 / np.sqrt(n_f)
+    return 1 / np.sqrt(n_e) / std_e, 1 / np.sqrt(n_f) / std_f
+
+
+def rmse_metric(predicted, actual):
+    return np.sqrt(np.mean(np.subtract(predicted, actual) ** 2))
+
+
+def mae_metric(predicted, actual):
+    return np.mean(np.abs(np.subtract(predicted, actual)))
+
+
+def arrange_coefficients(coefficients, bspline_config):
+    parts = np.array_split(coefficients, np.cumsum(bspline_config.partition_sizes)[:-1])
+    els = bspline_config.element_list
+    out = {el: v[0] for el, v in zip(els, parts[:len(els)])}
+    j = len(els)
+    for d in range(2, bspline_config.degree + 1):
+        for interaction in bspline_config.interactions_map[d]:
+            out[interaction] = parts[j]
+            j += 1
+    return out
+
+
+class BasicLinearModel:
+    def __init__(self, regularizer=None):
+        self.coefficients = None
+        self.regularizer = regularizer
+
+    def fit(self, x, y, ridge_penalty=1e-8):
+        gram, ordinate = gram_device(x, y)
+        reg = np.eye(len(gram)) * ridge_penalty if self.regularizer is None else self.regularizer
+        self.coefficients = lu_factorization(gram + np.dot(reg.T, reg), ordinate)
+
+    def predict(self, x):
+        return np.dot(x, self.coefficients)
+
+    def score(self, x, y, weights=None, normalize=True):
+        score = -rmse_metric(y, self.predict(x))
+        return score / np.std(y) if normalize else score
+
+
+class WeightedLinearModel(BasicLinearModel):
+    def __init__(self, bspline_config, regularizer=None, data_coverage=None, **params):
+        super().__init__(regularizer)
+        self.bspline_config = bspline_config
+        n_basis = int(np.sum(bspline_config.get_feature_partition_sizes()))
+        if data_coverage is not None:
+            if len(data_coverage) != n_basis:
+                raise ValueError(f"Incorrect data_coverage shape: {len(data_coverage)} != {n_basis}")
+            self.data_coverage = data_coverage
+        else:
+            self.data_coverage = np.zeros(n_basis, dtype=bool)
+        if self.regularizer is None:
+            self.set_params(**params)
+
+    def set_params(self, **params):
+        if "bspline_config" in params:
+            self.bspline_config = params["bspline_config"]
+        if "regularizer" in params:
+            self.regularizer = params["regularizer"]
+        elif self.regularizer is None:
+            reg = {k: v for k, v in params.items() if isinstance(v, (int, float, np.floating))}
+            self.regularizer = self.bspline_config.get_regularization_matrix(**reg)
+
+    @staticmethod
+    def from_config(config):
+        return WeightedLinearModel.from_dict(config)
+
+    @staticmethod
+    def from_dict(config):
+        basis = bspline.BSplineBasis.from_dict(config)
+        model = WeightedLinearModel(basis, regularizer=config.get("regularizer", None),
+                                    data_coverage=config.get("data_coverage", None))
+        model.load(solution=config)
+        return model
+
+    @staticmethod
+    def from_json(filename):
+        return WeightedLinearModel.from_dict(json_io.load_interaction_map(filename))
+
+    def as_dict(self):
+        solution = arrange_coefficients(self.coefficients, self.bspline_config)
+        for trio in self.bspline_config.interactions_map.get(3, []) if self.bspline_config.degree > 2 else []:
+            solution[trio] = self.bspline_config.decompress_3B(solution[trio], trio)
+        return dict(coefficients=solution, knots=self.bspline_config.knots_map,
+                    data_coverage=self.data_coverage, **self.bspline_config.as_dict())
+
+    dump = as_dict
+
+    def to_json(self, filename):
+        json_io.dump_interaction_map(self.as_dict(), filename=filename, write=True)
+
+    n_feats = property(lambda self: self.bspline_config.n_feats)
+    frozen_c = property(lambda self: self.bspline_config.frozen_c)
+    col_idx = property(lambda self: self.bspline_config.col_idx)
+    mask = property(lambda self: get_freezing_mask(self.n_feats, self.col_idx))
+
+    def __repr__(self):
+        return "\n".join(["WeightedLinearModel:", f"    Fit: {self.coefficients is not None}",
+                          repr(self.bspline_config)])
+
+    # -- fitting ----------------------------------------------------------------------
+    def fit_with_gram(self, gram, ordinate):
+        """Solve (G + R^T R) c = o on the unfrozen columns (least_squares.py:248-272)."""
+        coverage = revert_frozen_coefficients(np.sum(gram, axis=0) != 0, self.n_feats, self.mask,
+                                              self.frozen_c, self.col_idx)
+        self.data_coverage = np.logical_or(self.data_coverage, coverage)
+        reg = freeze_regularizer(self.regularizer, self.mask)
+        solution = lu_factorization(gram + np.dot(reg.T, reg), ordinate)
+        self.coefficients = revert_frozen_coefficients(solution, self.n_feats, self.mask, self.frozen_c,
+                                                       self.col_idx)
+
+    def gram_pieces(self, x_e, y_e, x_f=None, y_f=None):
+        """Additive pieces of one shard: Gram/ordinate of the frozen system + target moments."""
+        x_e, y_e = np.asarray(x_e, dtype=float), np.asarray(y_e, dtype=float)
+        pieces = dict(m_e=moments(y_e))
+        xe, ye = freeze_columns(x_e, y_e, self.mask, self.frozen_c, self.col_idx)
+        pieces["gram_e"], pieces["ord_e"] = gram_device(xe, ye)
+        if x_f is not None:
+            x_f, y_f = np.asarray(x_f, dtype=float), np.asarray(y_f, dtype=float)
+            pieces["m_f"] = moments(y_f)
+            xf, yf = freeze_columns(x_f, y_f, self.mask, self.frozen_c, self.col_idx)
+            pieces["gram_f"], pieces["ord_f"] = gram_device(xf, yf)
+        return pieces
+
+    def fit_from_pieces(self, pieces, weight=0.5):
+        if "gram_f" in pieces:
+            w_e, w_f = calc_E_F_weights(pieces["m_e"][0], pieces["m_f"][0], std_from_moments(pieces["m_e"]),
+                                        std_from_moments(pieces["m_f"]))
+            gram, ordinate = self.combine_weighted_gram(pieces["gram_e"], pieces["gram_f"], pieces["ord_e"],
+                                                        pieces["ord_f"], w_e, w_f, weight)
+        else:
+            gram, ordinate = pieces["gram_e"], pieces["ord_e"]
+        self.fit_with_gram(gram, ordinate)
+
+    def fit(self, x_e, y_e, x_f=None, y_f=None, weight=0.5, batch_size=2500):
+        """Energies (+ forces) -> coefficients (least_squares.py:274-321)."""
+        x_e, y_e = np.asarray(x_e, dtype=float), np.asarray(y_e, dtype=float)
+        xe, ye = freeze_columns(x_e, y_e, self.mask, self.frozen_c, self.col_idx)
+        gram, ordinate = gram_device(xe, ye)
+        if x_f is not None:
+            y_f = np.asarray(y_f, dtype=float)
+            w_e, w_f = calc_E_F_weights(len(y_e), len(y_f), np.std(y_e), np.std(y_f))
+            xf, yf = freeze_columns(np.asarray(x_f, dtype=float), y_f, self.mask, self.frozen_c, self.col_idx)
+            gram_f, ord_f = gram_device(xf, yf)
+            gram, ordinate = self.combine_weighted_gram(gram, gram_f, ordinate, ord_f, w_e, w_f, weight)
+        self.fit_with_gram(gram, ordinate)
+
+    def combine_weighted_gram(self, gram_e, gram_f, ord_e, ord_f, energy_weight, force_weight, weight):
+        gram = (weight * energy_weight ** 2 * gram_e) + ((1 - weight) * force_weight ** 2 * gram_f)
+        ordinate = (weight * energy_weight ** 2 * ord_e) + ((1 - weight) * force_weight ** 2 * ord_f)
+        return gram, ordinate
+
+    def initialize_gram_ordinate(self):
+        n = self.n_feats - len(self.col_idx)
+        return np.zeros((n, n)), np.zeros((n, n)), np.zeros(n), np.zeros(n)
+
+    # -- model files ------------------------------------------------------------------
+    def load(self, solution=None, filename=None):
+        """Flatten a per-interaction coefficient dict (3-body given as full grids) into ``coefficients``."""
+        if filename is not None:
+            if solution is not None:
+                warnings.warn("Provided solutions ignored; loading file.")
+            solution = json_io.load_interaction_map(filename)
+        elif solution is None:
+            raise ValueError("Neither solution nor filename were provided.")
+        if "coefficients" in solution:
+            solution = solution["coefficients"]
+        elif "solution" in solution:
+            warnings.warn("'solution' should be renamed to 'coefficients'")
+            solution = solution["solution"]
+        solution = dict(solution)
+        for key in list(solution):
+            if isinstance(key, tuple):
+                skey = composition.sort_interaction_symbols(key)
+                if skey != key:
+                    solution[skey] = solution[key]
+        basis = self.bspline_config
+        sizes = basis.get_interaction_partitions()[0]
+        for pair in basis.interactions_map[2]:
+            if pair not in solution:
+                warnings.warn(f"{pair} not provided.")
+                solution[pair] = np.zeros(sizes[pair])
+            if len(solution[pair]) != sizes[pair]:
+                raise ValueError(f"Incorrect shape: {pair}, {len(solution[pair])} != {sizes[pair]}")
+        for trio in basis.interactions_map.get(3, []) if basis.degree > 2 else []:
+            if trio not in solution:
+                warnings.warn(f"{trio} not provided.")
+            component = np.array(solution[trio])
+            if component.ndim > 1:
+                solution[trio] = basis.compress_3B(component, trio, fitting=False)
+            if len(solution[trio]) != sizes[trio]:
+                raise ValueError(f"Incorrect shape: {trio}, {len(solution[trio])} != {sizes[trio]}")
+        flat = [[solution[el]] for el in basis.element_list]
+        for degree in range(2, basis.degree + 1):
+            flat.extend(solution[i] for i in basis.interactions_map[degree])
+        if len(flat) != len(basis.partition_sizes):
+            raise ValueError("Incorrect interactions: {} provided, {} expected.".format(
+                len(flat), len(basis.partition_sizes)))
+        flat = np.concatenate([np.atleast_1d(np.asarray(v, dtype=float)) for v in flat])
+        if len(flat) != sum(basis.partition_sizes):
+            raise ValueError("Incorrect coefficients: {} provided, {} expected.".format(
+                len(flat), sum(basis.partition_sizes)))
+        self.coefficients = np.array(flat)

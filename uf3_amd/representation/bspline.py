@@ -108,7 +108,7 @@ def basis_values(knots, points):
     x = np.atleast_1d(np.asarray(points, dtype=float))
     i = find_interval(t, x)
     ok = (i >= 3) & (i <= len(t) - 5) & (x <= t[-1])
-    ii = np.where(ok, i, 3)
+    ii = np.where(ok, i, int(np.argmax(np.diff(t) > 0)))  # any non-degenerate interval for masked points
     n = np.zeros((4, len(x)))
     n[0] = 1.0
     left = np.zeros((4, len(x)))
@@ -138,24 +138,39 @@ def basis_values(knots, points):
 
 class BasisFunction:
     """One cubic B-spline basis element on 5 knots; callable like scipy's
-    ``BSpline.basis_element(..., extrapolate=False)`` with NaN replaced by 0."""
+    ``BSpline.basis_element(..., extrapolate=False)`` with NaN replaced by 0
+    (Cox-de Boor recursion, 0/0 := 0, half-open knot intervals: like scipy, the element
+    evaluates to 0 at its own last knot, also when that knot is the 4-fold end knot)."""
 
     def __init__(self, knots5):
         self.t = np.asarray(knots5, dtype=float)
-        pad = np.concatenate([np.repeat(self.t[0] - 1.0, 3), self.t,
-                              np.repeat(self.t[-1] + 1.0, 3)])
-        self._pad = pad
+
+    def _b(self, s, k, x):
+        t = self.t
+        if k == 0:
+            return ((t[s] <= x) & (x < t[s + 1])).astype(float)
+        out = np.zeros_like(x)
+        d1, d2 = t[s + k] - t[s], t[s + k + 1] - t[s + 1]
+        if d1 > 0:
+            out += (x - t[s]) / d1 * self._b(s, k - 1, x)
+        if d2 > 0:
+            out += (t[s + k + 1] - x) / d2 * self._b(s + 1, k - 1, x)
+        return out
 
     def __call__(self, points, nu=0):
         x = np.atleast_1d(np.asarray(points, dtype=float))
-        first, v, d = basis_values(self._pad, x)
-        src = d if nu == 1 else v
-        if nu not in (0, 1):
+        t = self.t
+        if nu == 0:
+            out = self._b(0, 3, x)
+        elif nu == 1:
+            out = np.zeros_like(x)
+            if t[3] > t[0]:
+                out += 3.0 / (t[3] - t[0]) * self._b(0, 2, x)
+            if t[4] > t[1]:
+                out -= 3.0 / (t[4] - t[1]) * self._b(1, 2, x)
+        else:
             raise NotImplementedError("nu in (0, 1)")
-        k = 3 - first  # position of this element (index 3 of the padded basis)
-        out = np.zeros(len(x))
-        ok = (k >= 0) & (k <= 3) & (x >= self.t[0]) & (x <= self.t[-1])
-        out[ok] = src[np.nonzero(ok)[0], k[ok]]
+        out[(x < t[0]) | (x > t[4])] = 0.0
         return out
 
 

@@ -1,0 +1,192 @@
+"""
+``BasisFeaturizer``: energy / force feature rows of atomic configurations,
+computed by the MI355X kernels in ``uf3_amd/csrc`` through ``libuf3hip.so``.
+
+Surface follows the reference's ``uf3/representation/process.py`` (class :20-536:
+``featurize_{energy,force}_{2B,3B}`` :369-506, ``evaluate_configuration`` :293-367,
+``evaluate`` :121-174, ``evaluate_parallel`` :196-254, ``flatten_by_interactions``
+:619-630).  Differences in mechanism, not in results:
+
+* no supercell is materialised: periodic images come from a cell list with image
+  shifts on the device.  The optional ``supercell`` argument of ``featurize_*`` is
+  only inspected for ``None`` (None -> treat ``geom`` as an isolated cluster, as
+  the reference does when no supercell is passed);
+* frames are processed in batches (``featurize_frames``); ``evaluate_parallel`` needs
+  no worker pool -- the whole batch goes to the GPU of this process.
+
+There is no CPU fallback: without ``libuf3hip.so`` and a gfx950 device every method
+that computes features raises ``uf3_amd._lib.HipUnavailable``.
+"""
+import warnings
+
+import numpy as np
+
+from uf3_amd import _lib
+
+
+class BasisFeaturizer:
+    def __init__(self, bspline_config, fit_forces=True, prefix='x', device=None):
+        self.bspline_config = bspline_config
+        self.fit_forces = fit_forces
+        self.prefix = prefix
+        self.device = device
+        self.columns = self.bspline_config.get_column_names()
+
+    chemical_system = property(lambda self: self.bspline_config.chemical_system)
+    degree = property(lambda self: self.chemical_system.degree)
+    element_list = property(lambda self: self.chemical_system.element_list)
+    interactions_map = property(lambda self: self.chemical_system.interactions_map)
+    r_min_map = property(lambda self: self.bspline_config.r_min_map)
+    r_max_map = property(lambda self: self.bspline_config.r_max_map)
+    resolution_map = property(lambda self: self.bspline_config.resolution_map)
+    r_cut = property(lambda self: self.bspline_config.r_cut)
+    knots_map = property(lambda self: self.bspline_config.knots_map)
+    knot_subintervals = property(lambda self: self.bspline_config.knot_subintervals)
+    basis_functions = property(lambda self: self.bspline_config.basis_functions)
+    partition_sizes = property(lambda self: self.bspline_config.partition_sizes)
+    interaction_hashes = property(lambda self: self.chemical_system.interaction_hashes)
+    leading_trim = property(lambda self: self.bspline_config.leading_trim)
+    trailing_trim = property(lambda self: self.bspline_config.trailing_trim)
+
+    @staticmethod
+    def from_config(bspline_config, config):
+        keys = ['prefix', 'fit_forces']
+        return BasisFeaturizer(bspline_config, **{k: v for k, v in config.items() if k in keys})
+
+    def __repr__(self):
+        return "\n".join(["BasisFeaturizer:", f"    Fit forces: {self.fit_forces}",
+                          f"    Column prefix: {self.prefix}", repr(self.bspline_config)])
+
+    def __getstate__(self):  # device handles are per process; rebuilt lazily after unpickling
+        state = dict(self.__dict__)
+        return state
+
+    # ------------------------------------------------------------------ device plumbing
+    def _dev(self):
+        ctx = _lib.get_context(self.device)
+        return ctx, _lib.device_basis(self.bspline_config, ctx)
+
+    def featurize_frames(self, atoms_list, energy=True, forces=True, periodic=None):
+        """
+        Feature rows of a batch of frames (host arrays in, host arrays out).
+
+        Returns (x_e [n_frames, F] | None, x_f [sum N, 3, F] | None, offsets [n_frames+1]).
+        Column order = ``get_column_names()[1:]`` (no ``y``).
+        """
+        ctx, db = self._dev()
+        batch = _lib.FrameBatch(atoms_list, periodic=periodic)
+        F = db.n_feat
+        x_e = np.empty((batch.n_frames, F)) if energy else None
+        x_f = np.empty((batch.n_atoms, 3, F)) if forces else None
+        import ctypes as C
+        ctx.check(ctx.lib.uf3_featurize(db.handle, C.byref(batch.struct), _lib._p(batch.pos), _lib._p(batch.z),
+                                        _lib._p(x_e), _lib._p(x_f)))
+        return x_e, x_f, batch.offsets
+
+    def featurize_device(self, frames_struct, d_pos, d_z, d_x_e=None, d_x_f=None):
+        """Device-resident entry: raw HBM pointers (ints), asynchronous on the context stream."""
+        import ctypes as C
+        ctx, db = self._dev()
+        ctx.check(ctx.lib.uf3_featurize_dev(db.handle, C.byref(frames_struct), C.c_void_p(d_pos), C.c_void_p(d_z),
+                                            C.c_void_p(d_x_e or 0), C.c_void_p(d_x_f or 0)))
+
+    def neighbor_indices(self, geom):
+        """
+        Neighbour indices in the reference's supercell numbering:
+        ({pair: (n, 2) int64 (i, j)} in row-major order, (n, 2) int64 3-body pairs).
+        """
+        import ctypes as C
+        ctx, db = self._dev()
+        batch = _lib.FrameBatch([geom])
+        P = len(db.pairs)
+        cnt = np.zeros(max(P, 1), dtype=np.int64)
+        n3 = np.zeros(1, dtype=np.int64)
+        args = (db.handle, C.byref(batch.struct), _lib._p(batch.pos), _lib._p(batch.z))
+        ctx.check(ctx.lib.uf3_neighbors_debug(*args, _lib._p(cnt), None, 0, _lib._p(n3), None, 0))
+        cap2, cap3 = max(1, int(cnt.max())), max(1, int(n3[0]))
+        pij = np.zeros((max(P, 1), cap2, 2), dtype=np.int64)
+        nij = np.zeros((cap3, 2), dtype=np.int64)
+        ctx.check(ctx.lib.uf3_neighbors_debug(*args, _lib._p(cnt), _lib._p(pij), cap2, _lib._p(n3), _lib._p(nij), cap3))
+        return ({p: pij[k, :cnt[k]].copy() for k, p in enumerate(db.pairs)}, nij[:int(n3[0])].copy())
+
+    # ------------------------------------------------------------------ reference surface
+    def _block(self, degree):
+        sizes, offsets = self.bspline_config.get_interaction_partitions()
+        inter = self.interactions_map[degree]
+        lo = int(offsets[inter[0]])
+        hi = int(offsets[inter[-1]] + sizes[inter[-1]])
+        return lo, hi
+
+    def _rows(self, geom, supercell, energy, forces):
+        periodic = None if supercell is not None else False
+        return self.featurize_frames([geom], energy=energy, forces=forces, periodic=periodic)
+
+    def featurize_energy_2B(self, geom, supercell=None):
+        lo, hi = self._block(2)
+        return self._rows(geom, supercell, True, False)[0][0, lo:hi]
+
+    def featurize_force_2B(self, geom, supercell=None):
+        lo, hi = self._block(2)
+        return self._rows(geom, supercell, False, True)[1][:, :, lo:hi]
+
+    def featurize_energy_3B(self, geom, supercell=None):
+        lo, hi = self._block(3)
+        return self._rows(geom, supercell, True, False)[0][0, lo:hi]
+
+    def featurize_force_3B(self, geom, supercell=None):
+        lo, hi = self._block(3)
+        return self._rows(geom, supercell, False, True)[1][:, :, lo:hi]
+
+    def evaluate_configuration(self, geom, name=None, energy=None, forces=None, energy_key="energy"):
+        """dict of (1 + F)-vectors: the energy row and the 3N force rows, ``y`` first."""
+        eval_map = {}
+        invalid = set(geom.get_chemical_symbols()).difference(self.element_list)
+        if invalid:
+            msg = "Invalid elements: {}".format(', '.join(invalid))
+            if name is not None:
+                msg += " in configuration " + name
+            warnings.warn(msg, RuntimeWarning)
+            return dict()
+        any_pbc = bool(np.any(geom.get_pbc() if hasattr(geom, "get_pbc") else geom.pbc))
+        x_e, x_f, _ = self.featurize_frames([geom], energy=energy is not None, forces=forces is not None,
+                                            periodic=None if any_pbc else False)
+        if energy is not None:
+            key = (name, energy_key) if name is not None else energy_key
+            eval_map[key] = np.insert(x_e[0], 0, energy)
+        if forces is not None:
+            n_atoms = len(geom)
+            for j, component in enumerate(['fx', 'fy', 'fz']):
+                for i in range(n_atoms):
+                    atom_index = component + '_' + str(i)
+                    key = (name, atom_index) if name is not None else atom_index
+                    eval_map[key] = np.insert(x_f[i, j, :], 0, forces[j][i])
+        return eval_map
+
+    def evaluate(self, df_data, atoms_key="geometry", energy_key="energy", progress="bar"):
+        """DataFrame in -> feature DataFrame out (MultiIndex (name, 'energy'|'fx_i'|...))."""
+        eval_map = {}
+        header = list(df_data.columns)
+        for name, row in zip(df_data.index, df_data.itertuples(index=False, name=None)):
+            rec = dict(zip(header, row))
+            energy = rec.get(energy_key)
+            forces = None
+            if 'fx' in rec and self.fit_forces:
+                forces = [rec[c] for c in ('fx', 'fy', 'fz')]
+                if np.any(np.isnan(np.asarray(forces, dtype=float))):
+                    forces = None
+            eval_map.update(self.evaluate_configuration(rec[atoms_key], name, energy, forces, energy_key))
+        return self.arrange_features_dataframe(eval_map)
+
+    def arrange_features_dataframe(self, eval_map):
+        import pandas as pd
+        df = pd.DataFrame.from_dict(eval_map, orient='index', columns=self.columns)
+        return df.set_index(pd.MultiIndex.from_tuples(df.index))
+
+    def evaluate_parallel(self, df_data, client=None, atoms_key="geometry", energy_key="energy", n_jobs=2,
+                          shuffle=True, progress="bar"):
+        """Kept for drop-in use: the batch runs on this process's GPU, ``client`` is ignored."""
+        return self.evaluate(df_data, atoms_key=atoms_key, energy_key=energy_key, progress=progress)
+
+
+def flatten_by_interactions(vector_map, pair_tuples):
+    return np.concatenate([vector_map[pair] for pair in pair_tuples], axis=-1)
