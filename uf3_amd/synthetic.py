@@ -1,0 +1,64 @@
+"""
+Deterministic synthetic frames for BASELINE.json's configurations:
+rattled, slightly strained bcc / fcc cells with Bernoulli species, pure NumPy.
+"""
+import numpy as np
+
+from uf3_amd.data import composition
+from uf3_amd.data.atoms import Atoms
+from uf3_amd.representation import bspline
+
+
+def lattice_frame(kind, reps, a, numbers, seed, rattle=0.08, strain=0.01):
+    rng = np.random.default_rng(seed)
+    base = {"bcc": [[0, 0, 0], [.5, .5, .5]],
+            "fcc": [[0, 0, 0], [.5, .5, 0], [.5, 0, .5], [0, .5, .5]]}[kind]
+    base = np.array(base)
+    grid = np.stack(np.meshgrid(*[np.arange(r) for r in reps], indexing="ij"), axis=-1).reshape(-1, 1, 3)
+    pts = ((grid + base[None]) * a).reshape(-1, 3)
+    pos = pts + rng.normal(0, rattle, pts.shape)
+    cell = np.diag(np.array(reps, dtype=float) * a) @ (np.eye(3) + rng.uniform(-strain, strain, (3, 3)))
+    z = rng.choice(np.asarray(numbers), len(pts)) if len(numbers) > 1 else np.full(len(pts), numbers[0])
+    return Atoms(numbers=z, positions=pos, cell=cell, pbc=True)
+
+
+def notebook_basis(elements, lead3=3):
+    """Per-interaction settings of the reference's W demo notebook on every pair / trio."""
+    cs = composition.ChemicalSystem(elements, 3)
+    pairs, trios = cs.interactions_map[2], cs.interactions_map[3]
+    return bspline.BSplineBasis(
+        cs,
+        r_min_map={**{p: 0.001 for p in pairs}, **{t: [1.5, 1.5, 1.5] for t in trios}},
+        r_max_map={**{p: 5.5 for p in pairs}, **{t: [3.5, 3.5, 7.0] for t in trios}},
+        resolution_map={**{p: 15 for p in pairs}, **{t: [6, 6, 12] for t in trios}},
+        leading_trim={2: 0, 3: lead3}, trailing_trim={2: 3, 3: 3})
+
+
+def config_c2(frame=0):
+    """W 2+3-body, 1024-atom rattled bcc cell."""
+    return lattice_frame("bcc", (8, 8, 8), 3.165, [74], 1000 + frame), notebook_basis(['W'])
+
+
+def config_c3(frame=0):
+    """Ne-Xe binary, 4096-atom fcc cell, ragged neighbours."""
+    cs = composition.ChemicalSystem(['Ne', 'Xe'], 3)
+    pairs, trios = cs.interactions_map[2], cs.interactions_map[3]
+    basis = bspline.BSplineBasis(
+        cs,
+        r_min_map={**{p: 0.5 for p in pairs}, **{t: [1.5] * 3 for t in trios}},
+        r_max_map={**{p: 6.0 for p in pairs}, **{t: [4.5, 4.5, 9.0] for t in trios}},
+        resolution_map={**{p: 15 for p in pairs}, **{t: [6, 6, 12] for t in trios}})
+    return lattice_frame("fcc", (8, 8, 16), 5.0, [10, 54], 2000 + frame, rattle=0.15), basis
+
+
+def config_c4(frame=0, binary=True):
+    """North-star workload: 10 000-atom bcc cell, 2 elements (W/Mo), 2+3-body, F = 434."""
+    numbers = [42, 74] if binary else [74]
+    basis = notebook_basis(['Mo', 'W'] if binary else ['W'])
+    return lattice_frame("bcc", (10, 20, 25), 3.165, numbers, 3000 + frame), basis
+
+
+def algorithmic_bytes(n_atoms, n_feat, forces=True):
+    """inputs + the rows the reference materialises."""
+    rows = (3 * n_atoms + 1) if forces else 1
+    return 28 * n_atoms + 75 + 8 * n_feat * rows
