@@ -78,7 +78,7 @@ def test_w128_frames_batched(lead):
     assert np.array_equal(n3, d["n3_ij_frame0"])
     # force rows of frame 3 alone == its slice of the batch; oracle agrees
     alone = fz.featurize_frames([frames[3]], energy=False)[1]
-    assert np.array_equal(alone, x_f[off[3]:off[4]])
+    assert rel_err(alone, x_f[off[3]:off[4]]) < 1e-12   # LDS atomics: summation order varies
     ref = O.featurize(O.OracleBasis(basis), frames[3], energy=False)["xf"]
     assert rel_err(alone, ref) < TOL
 

@@ -11,7 +11,7 @@ import threading
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libuf3hip.so")
+LIB_PATH = os.environ.get("UF3_LIB_PATH", os.path.join(_HERE, "csrc", "libuf3hip.so"))
 
 EXPORTS = ["uf3_ctx_create", "uf3_ctx_destroy", "uf3_ctx_set_stream", "uf3_ctx_synchronize",
            "uf3_last_error", "uf3_ctx_timing_reset", "uf3_ctx_timing_read",

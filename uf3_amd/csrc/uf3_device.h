@@ -163,8 +163,10 @@ __device__ __forceinline__ int mbcnt(unsigned long long mask) {
 // (unwrapped) positions; images outside the reference's range (|s| > fac) are skipped, so the
 // candidate set is exactly the reference's supercell (geometry.py:131-149).
 template <class F>
-__device__ __forceinline__ void for_each_candidate(const FrameGeom &g, const CellList &cl, int m, F f) {
+__device__ __forceinline__ void for_each_candidate_strided(const FrameGeom &g, const CellList &cl, int m, int part,
+                                                           int n_parts, F f) {
     int lane = lane_id();
+    int bin_no = 0;
     int lb = cl.atom_bin[m];
     int b2 = lb % g.nb[2], b1 = (lb / g.nb[2]) % g.nb[1], b0 = lb / (g.nb[2] * g.nb[1]);
     int w0, w1, w2;
@@ -188,6 +190,7 @@ __device__ __forceinline__ void for_each_candidate(const FrameGeom &g, const Cel
                 int t2 = b2 + o2, sh2 = (t2 >= 0 ? t2 / g.nb[2] : -((g.nb[2] - 1 - t2) / g.nb[2]));
                 int c2 = t2 - sh2 * g.nb[2];
                 if (!g.per[2]) sh2 = 0;
+                if ((bin_no++ % n_parts) != part) continue;     // bins dealt round-robin to the parts
                 int gb = g.bin_base + (c0 * g.nb[1] + c1) * g.nb[2] + c2;
                 int s_lo = cl.bin_start[gb], s_hi = cl.bin_start[gb + 1];
                 for (int base = s_lo; base < s_hi; base += WAVE) {
@@ -206,4 +209,9 @@ __device__ __forceinline__ void for_each_candidate(const FrameGeom &g, const Cel
             }
         }
     }
+}
+
+template <class F>
+__device__ __forceinline__ void for_each_candidate(const FrameGeom &g, const CellList &cl, int m, F f) {
+    for_each_candidate_strided(g, cl, m, 0, 1, f);
 }

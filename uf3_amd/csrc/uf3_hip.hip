@@ -555,9 +555,11 @@ static int prepare(uf3_basis *b, const uf3_frames *fr, const double *d_pos, cons
 }
 
 // ------------------------------------------------------------------------------ featurize
-static size_t feat_lds_bytes(int W, int cap, bool want_e, bool want_f) {
-    size_t d = (want_f ? 3 * (size_t)W : 0) + (want_e ? (size_t)W : 0) + 4 * (size_t)cap + (size_t)WAVE * ITEM_STRIDE;
-    return d * 8 + ((size_t)5 * cap + 1) * 4 + 16;
+static size_t feat_lds_bytes(int W, int cap, bool want_e, bool want_f, size_t lut_len) {
+    size_t d = (want_f ? 3 * (size_t)W : 0) + (want_e ? (size_t)W : 0) + 4 * (size_t)cap + (cap & 1) +
+               (size_t)NWAVES * HALF * ITEM_STRIDE;
+    size_t ints = (size_t)5 * cap + 1 + ((cap + 1) & 1);
+    return d * 8 + ints * 4 + lut_len * 2 + 32;
 }
 
 extern "C" int uf3_featurize_dev(uf3_basis *b, const uf3_frames *fr, const double *d_pos, const int32_t *d_z,
@@ -574,46 +576,71 @@ extern "C" int uf3_featurize_dev(uf3_basis *b, const uf3_frames *fr, const doubl
     const bool want_e = d_xe != nullptr, want_f = d_xf != nullptr;
     if (want_e) HIPCHK(c, hipMemsetAsync(d_xe, 0, sizeof(double) * (size_t)P.n_frames * F, st));
     int cap = std::max(1, P.n3.cap);
-    // column windows: whole interaction blocks, as many as fit in LDS
-    int budget = std::min(c->lds_max, 160 * 1024) - 512;
+    // column windows: whole interaction blocks, as many as fit in LDS; the uint16 LUT goes to LDS too
+    // when it still fits beside a single window
+    const int budget = 160 * 1024 - 1024;
+    size_t lut_len = (b->c3_len && F < 65535) ? b->c3_len : 0;
+    if (lut_len && (int)feat_lds_bytes(F, cap, want_e, want_f, lut_len) > budget) lut_len = 0;
     std::vector<std::pair<int, int>> windows;
     {
         const std::vector<int> &bd = b->block_bounds;
         size_t i = 0;
         while (i + 1 < bd.size()) {
             size_t j = i + 1;
-            while (j + 1 < bd.size() && (int)feat_lds_bytes(bd[j + 1] - bd[i], cap, want_e, want_f) <= budget) j++;
-            if ((int)feat_lds_bytes(bd[j] - bd[i], cap, want_e, want_f) > budget)
+            while (j + 1 < bd.size() && (int)feat_lds_bytes(bd[j + 1] - bd[i], cap, want_e, want_f, lut_len) <= budget) j++;
+            if ((int)feat_lds_bytes(bd[j] - bd[i], cap, want_e, want_f, lut_len) > budget)
                 return fail(c, UF3_EOVERFLOW, "one interaction block exceeds the LDS row buffer");
             windows.push_back({bd[i], bd[j]});
             i = j;
         }
     }
-    // prefer >= 2 resident waves per SIMD when the whole row fits a smaller window set?  keep simple: as few
-    // windows as possible (each window re-walks the neighbour lists)
-    int n_waves = std::min(P.natoms, c->n_cu * 16);
-    int apw = (P.natoms + n_waves - 1) / n_waves;
-    n_waves = (P.natoms + apw - 1) / apw;
     FeatArgs A;
-    A.B = b->dev; A.geoms = P.geoms; A.frame_of = P.frame_of; A.cl = P.cl; A.n3 = P.n3;
+    A.B = b->dev; A.trios = b->d_trios; A.recs = b->d_recs; A.lut = b->d_lut;
+    A.geoms = P.geoms; A.frame_of = P.frame_of; A.cl = P.cl; A.n3 = P.n3;
     if (!A.n3.cap) A.n3.cap = 1;
-    A.pos = d_pos; A.spec = P.spec; A.x_e = d_xe; A.x_f = d_xf; A.natoms = P.natoms; A.atoms_per_wave = apw;
+    A.pos = d_pos; A.spec = P.spec; A.x_e = d_xe; A.x_f = d_xf; A.natoms = P.natoms;
+    A.lut_len = (int)lut_len;
+    { const char *e = getenv("UF3_DEBUG_SKIP"); A.skip = e ? atoi(e) : 0; }
+    A.prof = nullptr;
+#ifdef UF3_PROFILE
+    HIPCHK(c, c->dbg.ensure(8 * 64));
+    A.prof = c->dbg.as<long long>();
+    HIPCHK(c, hipMemsetAsync(A.prof, 0, 8 * 64, st));
+#endif
     for (auto &w : windows) {
         A.col_lo = w.first; A.col_hi = w.second;
-        size_t lds = feat_lds_bytes(w.second - w.first, A.n3.cap, want_e, want_f);
+        size_t lds = feat_lds_bytes(w.second - w.first, A.n3.cap, want_e, want_f, lut_len);
+        int per_cu = std::max(1, (int)((size_t)(160 * 1024) / lds));
+        per_cu = std::min(per_cu, 32 / NWAVES);
+        int n_blocks = std::min(P.natoms, c->n_cu * per_cu);
+        int apb = (P.natoms + n_blocks - 1) / n_blocks;
+        n_blocks = (P.natoms + apb - 1) / apb;
+        A.atoms_per_block = apb;
         Timed tm(c, T_FEAT);
         if (want_e && want_f) {
             HIPCHK(c, hipFuncSetAttribute((const void *)k_featurize<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL((k_featurize<true, true>), dim3(n_waves), dim3(64), lds, st, A);
+            hipLaunchKernelGGL((k_featurize<true, true>), dim3(n_blocks), dim3(NWAVES * WAVE), lds, st, A);
         } else if (want_f) {
             HIPCHK(c, hipFuncSetAttribute((const void *)k_featurize<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL((k_featurize<false, true>), dim3(n_waves), dim3(64), lds, st, A);
+            hipLaunchKernelGGL((k_featurize<false, true>), dim3(n_blocks), dim3(NWAVES * WAVE), lds, st, A);
         } else {
             HIPCHK(c, hipFuncSetAttribute((const void *)k_featurize<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL((k_featurize<true, false>), dim3(n_waves), dim3(64), lds, st, A);
+            hipLaunchKernelGGL((k_featurize<true, false>), dim3(n_blocks), dim3(NWAVES * WAVE), lds, st, A);
         }
         HIPCHK(c, hipGetLastError());
     }
+#ifdef UF3_PROFILE
+    {
+        long long hp[64];
+        HIPCHK(c, hipMemcpyAsync(hp, A.prof, sizeof(hp), hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipStreamSynchronize(st));
+        const char *nm[8] = {"2body", "geomC", "eval", "scatter", "geomN", "barrier+write", "ownlist", "tail"};
+        double tot = 0; for (int q = 0; q < 8; q++) tot += (double)hp[q];
+        fprintf(stderr, "[uf3 profile] wave0 cycles per section (sum over blocks):");
+        for (int q = 0; q < 8; q++) fprintf(stderr, " %s=%.1f%%", nm[q], 100.0 * hp[q] / tot);
+        fprintf(stderr, " total=%.3g\n", tot);
+    }
+#endif
     return UF3_OK;
 }
 

@@ -174,12 +174,26 @@ __device__ __forceinline__ bool neighbour_is_first(const FrameGeom &g, int sm, i
 // ---------------------------------------------------------------------------------
 // featurizer
 // ---------------------------------------------------------------------------------
-#define ITEM_STRIDE 37   // doubles per staged triplet record (odd multiple of 8 B: conflict-free writes)
-// record layout (doubles): 0-3 Bl, 4-7 Bm, 8-11 Bn, 12-15 B'l, 16-19 B'm, 20-23 B'n,
-// 24-26 A1, 27-29 A2, 30-32 A3, 33 {lut base, stride of l}, 34 {stride of m, energy flag}
+#ifdef UF3_PROFILE
+#define PROF_DECL long long prof_t[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long prof_c = 0;
+#define PROF_T0 prof_c = clock64();
+#define PROF_ADD(k) { long long now__ = clock64(); prof_t[k] += now__ - prof_c; prof_c = now__; }
+#else
+#define PROF_DECL
+#define PROF_T0
+#define PROF_ADD(k)
+#endif
+#define NWAVES 8          // waves of the workgroup that cooperates on one atom
+#define HALF 32           // triplet records staged per wave at a time
+#define ITEM_STRIDE 38    // doubles per staged record (16-B aligned records)
+// record layout (doubles): 0-7 (Bl,B'l)[4], 8-15 (Bm,B'm)[4], 16-23 (Bn,B'n)[4],
+// 24-26 A1, 27-29 A2, 30-32 A3, 34-35 int4 {lut base, stride of l, stride of m, energy flag}
 
 struct FeatArgs {
     const BasisDev *B;
+    const TrioDev *trios;     // explicit global pointers (no flat loads through the struct)
+    const KnotRec *recs;
+    const int *lut;
     const FrameGeom *geoms;
     const int *frame_of;
     CellList cl;
@@ -188,15 +202,23 @@ struct FeatArgs {
     const signed char *spec;
     double *x_e;        // [n_frames][F] or null
     double *x_f;        // [natoms][3][F] or null
-    int natoms, atoms_per_wave;
+    int natoms, atoms_per_block;
     int col_lo, col_hi; // column window held in LDS
+    int lut_len;        // > 0: the uint16 copy of the LUT lives in LDS
+    long long *prof;    // UF3_PROFILE builds: [NWAVES][8] cycle counters
+    int skip;           // profiling ablations (UF3_DEBUG_SKIP): 1 two-body, 2 centre role, 4 neighbour role, 8 scatter
 };
 
 __device__ __forceinline__ void lds_add(double *p, double v) {
     __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
+// LDS traffic inside one wave is in order; only the compiler has to be held back
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
 
-// stage one triplet seen from atom m.  rl, rm, rn: leg lengths in the trio's (l, m, n) order;
+// One triplet seen from atom m.  rl, rm, rn: leg lengths in the trio's (l, m, n) order;
 // a1/a2/a3: -(d r_leg / d R_m) for the three legs (zero vector when the leg does not move with m).
 struct TripletGeom {
     double rl, rm, rn;
@@ -205,109 +227,145 @@ struct TripletGeom {
     bool centre;
 };
 
+struct TripletRec {
+    double v[3][4], d[3][4];
+    int meta[4];
+};
+
 template <bool WANT_F>
-__device__ __forceinline__ bool stage_triplet(const BasisDev *B, const TripletGeom &t, bool valid,
-                                              double *stage, int &n_staged) {
-    const TrioDev *td = nullptr;
-    if (valid) {
-        valid = t.trio >= 0;
-        if (valid) {
-            td = B->trios + t.trio;
-            // leg masks t[0] <= r <= t[-1] (angles.py:502-508).  r == t[0] selects no basis function
-            // (searchsorted - 4 < 0) and at r == t[-1] every selected scipy element evaluates to 0
-            // (half-open last interval), so both ends contribute nothing: open interval here.
-            valid = (t.rl > td->leg[0].t0) && (t.rl < td->leg[0].tlast) &&
-                    (t.rm > td->leg[1].t0) && (t.rm < td->leg[1].tlast) &&
-                    (t.rn > td->leg[2].t0) && (t.rn < td->leg[2].tlast);
-        }
-    }
-    unsigned long long mask = __ballot(valid);
-    if (valid) {
-        double *rec = stage + (size_t)(n_staged + mbcnt(mask)) * ITEM_STRIDE;
-        int il = find_interval(B->recs, td->leg[0], t.rl);
-        int im = find_interval(B->recs, td->leg[1], t.rm);
-        int in = find_interval(B->recs, td->leg[2], t.rn);
-        double v[4], d[4];
-        bspline4<WANT_F>(B->recs[td->leg[0].rec_off + il], t.rl, v, d);
-        for (int q = 0; q < 4; q++) { rec[q] = v[q]; if (WANT_F) rec[12 + q] = d[q]; }
-        bspline4<WANT_F>(B->recs[td->leg[1].rec_off + im], t.rm, v, d);
-        for (int q = 0; q < 4; q++) { rec[4 + q] = v[q]; if (WANT_F) rec[16 + q] = d[q]; }
-        bspline4<WANT_F>(B->recs[td->leg[2].rec_off + in], t.rn, v, d);
-        for (int q = 0; q < 4; q++) { rec[8 + q] = v[q]; if (WANT_F) rec[20 + q] = d[q]; }
-        if (WANT_F) for (int q = 0; q < 3; q++) { rec[24 + q] = t.a1[q]; rec[27 + q] = t.a2[q]; rec[30 + q] = t.a3[q]; }
-        int mn = td->dim_m * td->dim_n;
-        int *meta = (int *)(rec + 33);
-        meta[0] = td->lut_off + (il - 3) * mn + (im - 3) * td->dim_n + (in - 3);
-        meta[1] = mn;
-        meta[2] = td->dim_n;
-        meta[3] = t.centre ? 1 : 0;
-    }
-    n_staged += __popcll(mask);
-    return valid;
+__device__ __forceinline__ bool eval_triplet(const FeatArgs &A, const TripletGeom &t, bool valid, TripletRec &r) {
+    if (!valid || t.trio < 0) return false;
+    const TrioDev *td = A.trios + t.trio;
+    // leg masks t[0] <= r <= t[-1] (angles.py:502-508).  r == t[0] selects no basis function
+    // (searchsorted - 4 < 0) and at r == t[-1] every selected scipy element evaluates to 0
+    // (half-open last interval), so both ends contribute nothing: open interval here.
+    if (!((t.rl > td->leg[0].t0) && (t.rl < td->leg[0].tlast) && (t.rm > td->leg[1].t0) && (t.rm < td->leg[1].tlast) &&
+          (t.rn > td->leg[2].t0) && (t.rn < td->leg[2].tlast))) return false;
+    int il = find_interval(A.recs, td->leg[0], t.rl);
+    int im = find_interval(A.recs, td->leg[1], t.rm);
+    int in = find_interval(A.recs, td->leg[2], t.rn);
+    bspline4<WANT_F>(A.recs[td->leg[0].rec_off + il], t.rl, r.v[0], r.d[0]);
+    bspline4<WANT_F>(A.recs[td->leg[1].rec_off + im], t.rm, r.v[1], r.d[1]);
+    bspline4<WANT_F>(A.recs[td->leg[2].rec_off + in], t.rn, r.v[2], r.d[2]);
+    int mn = td->dim_m * td->dim_n;
+    r.meta[0] = td->lut_off + (il - 3) * mn + (im - 3) * td->dim_n + (in - 3);
+    r.meta[1] = mn;
+    r.meta[2] = td->dim_n;
+    r.meta[3] = t.centre ? 1 : 0;
+    return true;
 }
 
-// phase 2: lanes <-> the 4x4x4 block of basis products of one staged triplet
+// 64 evaluated triplets (one per lane) -> two half-batches through the wave's 32-record LDS stage,
+// each scattered with lanes <-> the 4x4x4 block of basis products of one record at a time.
 template <bool WANT_E, bool WANT_F>
-__device__ __forceinline__ void scatter_staged(const BasisDev *B, const double *stage, int n_staged,
-                                               double *rowbuf, double *erow, int col_lo, int col_hi) {
-    int lane = lane_id();
-    int a = lane >> 4, b = (lane >> 2) & 3, c = lane & 3;
-    int W = col_hi - col_lo;
-    for (int t = 0; t < n_staged; t++) {
-        const double *rec = stage + (size_t)t * ITEM_STRIDE;
-        const int *meta = (const int *)(rec + 33);
-        int col = B->lut[meta[0] + a * meta[1] + b * meta[2] + c];
-        if (col < col_lo || col >= col_hi) continue;
-        col -= col_lo;
-        double bl = rec[a], bm = rec[4 + b], bn = rec[8 + c];
-        double z = bl * bm;
-        if (WANT_E) { if (meta[3]) lds_add(erow + col, z * bn); }
-        if (WANT_F) {
-            double p1 = rec[12 + a] * (bm * bn), p2 = rec[16 + b] * (bl * bn), p3 = rec[20 + c] * z;
-            for (int q = 0; q < 3; q++)
-                lds_add(rowbuf + q * W + col, p1 * rec[24 + q] + p2 * rec[27 + q] + p3 * rec[30 + q]);
+__device__ __forceinline__ void stage_and_scatter(const FeatArgs &A, const TripletGeom &t, const TripletRec &r, bool valid,
+                                                  double *stage, double *rowbuf, double *erow,
+                                                  const unsigned short *lut16) {
+    const int lane = lane_id();
+    const int a = lane >> 4, b = (lane >> 2) & 3, c = lane & 3;
+    const int W = A.col_hi - A.col_lo;
+    for (int half = 0; half < 2; half++) {
+        bool mine = valid && ((lane >> 5) == half);
+        unsigned long long mask = __ballot(mine);
+        if (mask == 0) continue;
+        if (mine) {
+            double *rec = stage + (size_t)mbcnt(mask) * ITEM_STRIDE;
+            for (int leg = 0; leg < 3; leg++)
+                for (int q = 0; q < 4; q++) {
+                    rec[8 * leg + 2 * q] = r.v[leg][q];
+                    if (WANT_F) rec[8 * leg + 2 * q + 1] = r.d[leg][q];
+                }
+            if (WANT_F) for (int q = 0; q < 3; q++) { rec[24 + q] = t.a1[q]; rec[27 + q] = t.a2[q]; rec[30 + q] = t.a3[q]; }
+            int4 mt = make_int4(r.meta[0], r.meta[1], r.meta[2], r.meta[3]);
+            *(int4 *)(rec + 34) = mt;
         }
+        wave_sync();
+        const int n_staged = (A.skip & 8) ? 0 : __popcll(mask);
+        for (int q = 0; q < n_staged; q++) {
+            const double *rec = stage + (size_t)q * ITEM_STRIDE;
+            const int4 mt = *(const int4 *)(rec + 34);
+            const int raw = mt.x + a * mt.y + b * mt.z + c;
+            int col = lut16 ? (int)lut16[raw] : A.lut[raw];
+            if (lut16) col = (col == 0xFFFF) ? -1 : col;
+            if (col < A.col_lo || col >= A.col_hi) continue;
+            col -= A.col_lo;
+            const double2 L = *(const double2 *)(rec + 2 * a);
+            const double2 M = *(const double2 *)(rec + 8 + 2 * b);
+            const double2 N = *(const double2 *)(rec + 16 + 2 * c);
+            const double z = L.x * M.x;
+            if (WANT_E) { if (mt.w) lds_add(erow + col, z * N.x); }
+            if (WANT_F) {
+                const double p1 = L.y * (M.x * N.x), p2 = M.y * (L.x * N.x), p3 = N.y * z;
+                const double2 a01 = *(const double2 *)(rec + 24), a23 = *(const double2 *)(rec + 26),
+                              a45 = *(const double2 *)(rec + 28), a67 = *(const double2 *)(rec + 30);
+                const double a8 = rec[32];
+                // A1 = (a01.x, a01.y, a23.x)  A2 = (a23.y, a45.x, a45.y)  A3 = (a67.x, a67.y, a8)
+                lds_add(rowbuf + col, p1 * a01.x + p2 * a23.y + p3 * a67.x);
+                lds_add(rowbuf + W + col, p1 * a01.y + p2 * a45.x + p3 * a67.y);
+                lds_add(rowbuf + 2 * W + col, p1 * a23.x + p2 * a45.y + p3 * a8);
+            }
+        }
+        wave_sync();
     }
 }
 
 template <bool WANT_E, bool WANT_F>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(NWAVES * WAVE)
 k_featurize(FeatArgs A) {
     extern __shared__ __align__(16) unsigned char smem[];
     const BasisDev *B = A.B;
     const int W = A.col_hi - A.col_lo, cap = A.n3.cap;
     double *rowbuf = (double *)smem;                               // [3][W]   (WANT_F)
     double *erow = rowbuf + (WANT_F ? 3 * W : 0);                  // [W]      (WANT_E)
-    double *ox = erow + (WANT_E ? W : 0), *oy = ox + cap, *oz = oy + cap, *orr = oz + cap;   // own entries
-    double *stage = orr + cap;                                     // [64][ITEM_STRIDE]
-    int *oparent = (int *)(stage + WAVE * ITEM_STRIDE), *oshift = oparent + cap, *osidx = oshift + cap,
-        *ospec = osidx + cap, *ooff = ospec + cap;                 // ooff [cap+1]
+    double *ox = erow + (WANT_E ? W : 0), *oy = ox + cap, *oz = oy + cap, *orr = oz + cap;   // own neighbour list
+    double *stage_all = orr + cap + (cap & 1);                     // [NWAVES][HALF][ITEM_STRIDE], 16-B aligned
+    int *oparent = (int *)(stage_all + (size_t)NWAVES * HALF * ITEM_STRIDE), *oshift = oparent + cap,
+        *osidx = oshift + cap, *ospec = osidx + cap, *ooff = ospec + cap;        // ooff [cap+1]
+    unsigned short *lut_lds = (unsigned short *)(ooff + cap + 1 + ((cap + 1) & 1));
+    const unsigned short *lut16 = A.lut_len > 0 ? lut_lds : nullptr;
 
-    int lane = lane_id();
-    int a0 = blockIdx.x * A.atoms_per_wave, a1 = min(a0 + A.atoms_per_wave, A.natoms);
-    for (int q = lane; q < (WANT_F ? 3 * W : 0) + (WANT_E ? W : 0); q += WAVE) rowbuf[q] = 0.0;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double *stage = stage_all + (size_t)wave * HALF * ITEM_STRIDE;
+    const int nacc = (WANT_F ? 3 * W : 0) + (WANT_E ? W : 0);
+    for (int q = tid; q < nacc; q += NWAVES * WAVE) rowbuf[q] = 0.0;
+    for (int q = tid; q < A.lut_len; q += NWAVES * WAVE) { int v = A.lut[q]; lut_lds[q] = v < 0 ? 0xFFFF : (unsigned short)v; }
     __syncthreads();
+
+    const int a0 = blockIdx.x * A.atoms_per_block, a1 = min(a0 + A.atoms_per_block, A.natoms);
     int cur_frame = -1;
+    PROF_DECL
     for (int m = a0; m < a1; m++) {
-        int fr = A.frame_of[m];
-        if (WANT_E && fr != cur_frame) {
-            if (cur_frame >= 0) {
-                for (int q = lane; q < W; q += WAVE) {
-                    double v = erow[q];
-                    if (v != 0.0) unsafeAtomicAdd(A.x_e + (size_t)cur_frame * B->F + A.col_lo + q, v);
-                    erow[q] = 0.0;
-                }
-                __syncthreads();
+        PROF_T0
+        const int fr = A.frame_of[m];
+        if (WANT_E && fr != cur_frame && cur_frame >= 0) {
+            for (int q = tid; q < W; q += NWAVES * WAVE) {
+                double v = erow[q];
+                if (v != 0.0) unsafeAtomicAdd(A.x_e + (size_t)cur_frame * B->F + A.col_lo + q, v);
+                erow[q] = 0.0;
             }
+            __syncthreads();
         }
         cur_frame = fr;
         const FrameGeom g = A.geoms[fr];
         const int sm = A.spec[m];
-        double pm[3] = {A.pos[3 * (size_t)m], A.pos[3 * (size_t)m + 1], A.pos[3 * (size_t)m + 2]};
-        if (WANT_E && lane == 0 && sm >= A.col_lo && sm < A.col_hi) lds_add(erow + (sm - A.col_lo), 1.0);   // 1-body count
+        const double pm[3] = {A.pos[3 * (size_t)m], A.pos[3 * (size_t)m + 1], A.pos[3 * (size_t)m + 2]};
+        if (WANT_E && tid == 0 && sm >= A.col_lo && sm < A.col_hi) lds_add(erow + (sm - A.col_lo), 1.0);   // 1-body count
 
-        // ---- 2-body: every neighbour image within the pair block's strict range ----------
-        for_each_candidate(g, A.cl, m, [&](bool ok, int slot, int s0, int s1, int s2) {
+        // ---- own 3-body neighbour list -> LDS --------------------------------------------
+        int n = 0;
+        if (B->T > 0) {
+            n = A.n3.cnt[m];
+            size_t base = (size_t)m * cap;
+            for (int e = tid; e < n; e += NWAVES * WAVE) {
+                ox[e] = A.n3.dx[base + e]; oy[e] = A.n3.dy[base + e]; oz[e] = A.n3.dz[base + e]; orr[e] = A.n3.r[base + e];
+                oparent[e] = A.n3.parent[base + e]; oshift[e] = A.n3.shiftc[base + e];
+                osidx[e] = A.n3.sidx[base + e]; ospec[e] = A.n3.spec[base + e];
+            }
+        }
+
+        PROF_ADD(6)
+        // ---- 2-body: the waves share the neighbour bins ------------------------------------
+        if (!(A.skip & 1)) for_each_candidate_strided(g, A.cl, m, wave, NWAVES, [&](bool ok, int slot, int s0, int s1, int s2) {
             if (!ok) return;
             int sj = A.cl.s_spec[slot];
             const PairDev &pd = B->pairs[B->pair_of[sm * UF3_MAX_SPECIES + sj]];
@@ -316,9 +374,9 @@ k_featurize(FeatArgs A) {
             image_delta(g, A.cl, slot, s0, s1, s2, pm, dx, dy, dz);
             double d = norm3_rn(dx, dy, dz);
             if (!(d > pd.rmin && d < pd.rmax)) return;        // distances.py:66 strict both sides
-            int i = find_interval(B->recs, pd.leg, d);
+            int i = find_interval(A.recs, pd.leg, d);
             double v[4], dv[4];
-            bspline4<WANT_F>(B->recs[pd.leg.rec_off + i], d, v, dv);
+            bspline4<WANT_F>(A.recs[pd.leg.rec_off + i], d, v, dv);
             double inv = 2.0 / d;
             for (int q = 0; q < 4; q++) {
                 int bidx = i - 3 + q;
@@ -335,23 +393,22 @@ k_featurize(FeatArgs A) {
                 }
             }
         });
+        PROF_ADD(0)
+        __syncthreads();
+        PROF_ADD(5)
 
         // ---- 3-body ---------------------------------------------------------------------
         if (B->T > 0) {
-            int n = A.n3.cnt[m];
-            size_t base = (size_t)m * cap;
-            for (int e = lane; e < n; e += WAVE) {
-                ox[e] = A.n3.dx[base + e]; oy[e] = A.n3.dy[base + e]; oz[e] = A.n3.dz[base + e]; orr[e] = A.n3.r[base + e];
-                oparent[e] = A.n3.parent[base + e]; oshift[e] = A.n3.shiftc[base + e];
-                osidx[e] = A.n3.sidx[base + e]; ospec[e] = A.n3.spec[base + e];
-            }
-            __syncthreads();
             // (a) m is the centre: neighbour pairs a < b of its own (species, index)-sorted list
-            int n_pairs = n * (n - 1) / 2;
-            for (int p0 = 0; p0 < n_pairs; p0 += WAVE) {
+            const int n_pairs = (A.skip & 2) ? 0 : n * (n - 1) / 2;
+            // items are dealt to the waves in equal contiguous shares (a share is walked 64 at a time)
+            const int share_c = (n_pairs + NWAVES - 1) / NWAVES;
+            const int end_c = min(n_pairs, (wave + 1) * share_c);
+            for (int p0 = wave * share_c; p0 < end_c; p0 += WAVE) {
                 int p = p0 + lane;
-                bool valid = p < n_pairs;
+                bool valid = p < end_c;
                 TripletGeom t;
+                TripletRec r;
                 t.centre = true; t.trio = -1;
                 if (valid) {
                     int bb = (int)((1.0f + sqrtf(1.0f + 8.0f * (float)p)) * 0.5f);
@@ -369,30 +426,36 @@ k_featurize(FeatArgs A) {
                         t.a3[0] = t.a3[1] = t.a3[2] = 0.0;
                     }
                 }
-                int n_staged = 0;
-                stage_triplet<WANT_F>(B, t, valid, stage, n_staged);
-                __syncthreads();
-                scatter_staged<WANT_E, WANT_F>(B, stage, n_staged, rowbuf, erow, A.col_lo, A.col_hi);
-                __syncthreads();
+                PROF_ADD(1)
+                valid = eval_triplet<WANT_F>(A, t, valid, r);
+                PROF_ADD(2)
+                stage_and_scatter<WANT_E, WANT_F>(A, t, r, valid, stage, rowbuf, erow, lut16);
+                PROF_ADD(3)
             }
             // (b) m is a neighbour of centre c = own entry e; the other neighbour k runs over N3(c)
             if (WANT_F) {
-                int total = 0;
-                for (int e0 = 0; e0 < n; e0 += WAVE) {           // exclusive scan of |N3(parent_e)|
-                    int e = e0 + lane;
-                    int cnt = e < n ? A.n3.cnt[oparent[e]] : 0;
-                    int incl = cnt;
-                    for (int sh = 1; sh < WAVE; sh <<= 1) { int o = __shfl_up(incl, sh); if (lane >= sh) incl += o; }
-                    if (e < n) ooff[e] = total + incl - cnt;
-                    total += __shfl(incl, WAVE - 1);
+                if (wave == 0) {
+                    int total = 0;
+                    for (int e0 = 0; e0 < n; e0 += WAVE) {           // exclusive scan of |N3(parent_e)|
+                        int e = e0 + lane;
+                        int cnt = e < n ? A.n3.cnt[oparent[e]] : 0;
+                        int incl = cnt;
+                        for (int sh = 1; sh < WAVE; sh <<= 1) { int o = __shfl_up(incl, sh); if (lane >= sh) incl += o; }
+                        if (e < n) ooff[e] = total + incl - cnt;
+                        total += __shfl(incl, WAVE - 1);
+                    }
+                    if (lane == 0) ooff[n] = total;
                 }
-                if (lane == 0) ooff[n] = total;
                 __syncthreads();
-                int m_local = m - g.atom_lo;
-                for (int p0 = 0; p0 < total; p0 += WAVE) {
+                const int total = (A.skip & 4) ? 0 : ooff[n];
+                const int m_local = m - g.atom_lo;
+                const int share_n = (total + NWAVES - 1) / NWAVES;
+                const int end_n = min(total, (wave + 1) * share_n);
+                for (int p0 = wave * share_n; p0 < end_n; p0 += WAVE) {
                     int p = p0 + lane;
-                    bool valid = p < total;
+                    bool valid = p < end_n;
                     TripletGeom t;
+                    TripletRec r;
                     t.centre = false; t.trio = -1;
                     if (valid) {
                         int lo = 0, hi = n - 1;                  // entry e with ooff[e] <= p < ooff[e+1]
@@ -410,8 +473,7 @@ k_featurize(FeatArgs A) {
                             int msidx = supercell_index(g, -s0, -s1, -s2, m_local);  // m as numbered from c
                             double vx = A.n3.dx[kb], vy = A.n3.dy[kb], vz = A.n3.dz[kb], rk = A.n3.r[kb];
                             double ex = ox[e] + vx, ey = oy[e] + vy, ez = oz[e] + vz;   // m -> k
-                            // same arithmetic as the centre's own view: |(R_k - R_c) - (R_m - R_c)|
-                            t.rn = norm3_rn(vx - (-ox[e]), vy - (-oy[e]), vz - (-oz[e]));
+                            t.rn = norm3_rn(ex, ey, ez);
                             bool m_first = neighbour_is_first(g, sm, ksp, s0, s1, s2, m_local, msidx, ksidx, kshift,
                                                               kparent - g.atom_lo);
                             int sc = ospec[e];
@@ -429,27 +491,33 @@ k_featurize(FeatArgs A) {
                             }
                         }
                     }
-                    int n_staged = 0;
-                    stage_triplet<WANT_F>(B, t, valid, stage, n_staged);
-                    __syncthreads();
-                    scatter_staged<false, WANT_F>(B, stage, n_staged, rowbuf, erow, A.col_lo, A.col_hi);
-                    __syncthreads();
+                    PROF_ADD(4)
+                    valid = eval_triplet<WANT_F>(A, t, valid, r);
+                    PROF_ADD(2)
+                    stage_and_scatter<false, WANT_F>(A, t, r, valid, stage, rowbuf, erow, lut16);
+                    PROF_ADD(3)
                 }
             }
         }
+        PROF_ADD(7)
         __syncthreads();
+        PROF_ADD(5)
         if (WANT_F) {   // the three rows of atom m leave the chip once, coalesced
             double *dst = A.x_f + (size_t)m * 3 * B->F + A.col_lo;
-            for (int q = lane; q < 3 * W; q += WAVE) {
+            for (int q = tid; q < 3 * W; q += NWAVES * WAVE) {
                 int comp = q / W, col = q - comp * W;
                 dst[(size_t)comp * B->F + col] = rowbuf[q];
                 rowbuf[q] = 0.0;
             }
             __syncthreads();
         }
+        PROF_ADD(5)
     }
+#ifdef UF3_PROFILE
+    if (lane == 0 && A.prof) for (int q = 0; q < 8; q++) atomicAdd((unsigned long long *)A.prof + wave * 8 + q, (unsigned long long)prof_t[q]);
+#endif
     if (WANT_E && cur_frame >= 0) {
-        for (int q = lane; q < W; q += WAVE) {
+        for (int q = tid; q < W; q += NWAVES * WAVE) {
             double v = erow[q];
             if (v != 0.0) unsafeAtomicAdd(A.x_e + (size_t)cur_frame * B->F + A.col_lo + q, v);
         }
