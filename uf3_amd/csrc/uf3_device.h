@@ -28,6 +28,7 @@ struct PairDev {
     LegDev leg;
     int col;           // first column of the block
     int nb;            // basis functions (nk-4)
+    int sa, sb;        // species indices, sa <= sb
     double rmin, rmax; // strict range: max(r_min,0) < d < r_max
 };
 
@@ -37,6 +38,8 @@ struct TrioDev {
     int lut_off;       // into BasisDev::lut (also offset of the full grid in c3)
     int dim_m, dim_n;  // M, N of the L x M x N grid
     int dim_l;
+    int sc, sa, sb;    // species indices: centre, neighbours sa <= sb
+    int nsrc, src_off; // symmetry images per column (1, 2, 6) and offset into the colsrc table
 };
 
 struct BasisDev {
@@ -85,6 +88,7 @@ struct N3Lists {
     int *shiftc;    // packed image shift
     int *sidx;      // reference supercell index of the neighbour (seen from a real centre)
     int *spec;      // species index
+    int *spoff;     // [natoms][UF3_MAX_SPECIES+1] first entry of each species in the (species-sorted) list
     double *dx, *dy, *dz, *r;
 };
 

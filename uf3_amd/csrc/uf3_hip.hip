@@ -40,7 +40,7 @@ struct uf3_ctx {
         bin_start, s_atom, s_pos, s_wrap, s_spec, flags,
         n3_cnt, n3_int, n3_dbl, e_atom, coeff, stage_pos, stage_z, stage_out, stage_out2,
         gram_tiles, frag, dbg;
-    int n3_cap = 0;
+    int n3_cap = 0, cand_cap = 0;
     bool frag_ready = false;
     // timing
     bool timing = false;
@@ -57,6 +57,7 @@ struct uf3_basis {
     TrioDev *d_trios = nullptr;
     KnotRec *d_recs = nullptr;
     int *d_lut = nullptr;
+    int *d_colsrc = nullptr;
     std::vector<int> block_bounds;   // column boundaries of interaction blocks (for column windows)
     size_t c2_len = 0, c3_len = 0;
     double r_cut = 0;
@@ -233,6 +234,7 @@ extern "C" int uf3_basis_create(uf3_ctx *c, const uf3_basis_spec *s, uf3_basis *
         fill_leg(pd.leg, kp, nk, (int)recs.size(), recs);
         pd.col = s->pair_col[p];
         pd.nb = nk - 4;
+        pd.sa = std::min(a, bb); pd.sb = std::max(a, bb);
         pd.rmin = s->pair_rmin[p] > 0 ? s->pair_rmin[p] : 0.0;   // max(r_min, 0), distances.py:60
         pd.rmax = s->pair_rmax[p];
         h.rmax2 = std::max(h.rmax2, pd.rmax);
@@ -264,6 +266,7 @@ extern "C" int uf3_basis_create(uf3_ctx *c, const uf3_basis_spec *s, uf3_basis *
         td.dim_l = td.leg[0].nk - 4; td.dim_m = td.leg[1].nk - 4; td.dim_n = td.leg[2].nk - 4;
         td.col = s->trio_col[t];
         td.ncol = s->trio_ncol[t];
+        td.sc = sc; td.sa = sa; td.sb = sb;
         td.lut_off = (int)lut_len;
         lut_len += (size_t)td.dim_l * td.dim_m * td.dim_n;
         bounds.push_back(td.col + td.ncol);
@@ -282,6 +285,26 @@ extern "C" int uf3_basis_create(uf3_ctx *c, const uf3_basis_spec *s, uf3_basis *
             lut[trios[t].lut_off + q] = v < 0 ? -1 : trios[t].col + v;
         }
     }
+    // per column: the distinct raw bins (symmetry images) that feed it, for the output-stationary kernel
+    std::vector<int> colsrc;
+    for (int t = 0; t < h.T; t++) {
+        TrioDev &td = trios[t];
+        if (td.dim_l > 255 || td.dim_m > 255 || td.dim_n > 255) { delete b; return fail(c, UF3_EINVAL, "3-body grid dimension > 255"); }
+        std::vector<std::vector<int>> per_col(td.ncol);
+        size_t n = (size_t)td.dim_l * td.dim_m * td.dim_n;
+        for (size_t q = 0; q < n; q++) {
+            int v = s->trio_lut[td.lut_off + q];
+            if (v < 0) continue;
+            int l = (int)(q / ((size_t)td.dim_m * td.dim_n)), m = (int)((q / td.dim_n) % td.dim_m), nn = (int)(q % td.dim_n);
+            per_col[v].push_back(l | (m << 8) | (nn << 16));
+        }
+        size_t mx = 1;
+        for (auto &v : per_col) mx = std::max(mx, v.size());
+        td.nsrc = mx <= 1 ? 1 : (mx <= 2 ? 2 : 6);
+        if (mx > 6) { delete b; return fail(c, UF3_EINVAL, "a 3-body column is fed by more than 6 raw bins"); }
+        td.src_off = (int)colsrc.size();
+        for (auto &v : per_col) for (int k = 0; k < td.nsrc; k++) colsrc.push_back(k < (int)v.size() ? v[k] : -1);
+    }
     std::sort(bounds.begin(), bounds.end());
     bounds.erase(std::unique(bounds.begin(), bounds.end()), bounds.end());
     if (bounds.back() != h.F) { delete b; return fail(c, UF3_EINVAL, "column blocks do not add up to n_feat"); }
@@ -291,6 +314,8 @@ extern "C" int uf3_basis_create(uf3_ctx *c, const uf3_basis_spec *s, uf3_basis *
     HIPCHK(c, hipMemcpy(b->d_recs, recs.data(), sizeof(KnotRec) * recs.size(), hipMemcpyHostToDevice));
     HIPCHK(c, hipMalloc(&b->d_lut, sizeof(int) * lut.size()));
     HIPCHK(c, hipMemcpy(b->d_lut, lut.data(), sizeof(int) * lut.size(), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMalloc(&b->d_colsrc, sizeof(int) * std::max<size_t>(1, colsrc.size())));
+    if (!colsrc.empty()) HIPCHK(c, hipMemcpy(b->d_colsrc, colsrc.data(), sizeof(int) * colsrc.size(), hipMemcpyHostToDevice));
     HIPCHK(c, hipMalloc(&b->d_trios, sizeof(TrioDev) * std::max<size_t>(1, trios.size())));
     if (!trios.empty())
         HIPCHK(c, hipMemcpy(b->d_trios, trios.data(), sizeof(TrioDev) * trios.size(), hipMemcpyHostToDevice));
@@ -305,7 +330,7 @@ extern "C" void uf3_basis_destroy(uf3_basis *b) {
     if (!b) return;
     hipSetDevice(b->ctx->device);
     hipStreamSynchronize(b->ctx->stream);
-    hipFree(b->dev); hipFree(b->d_trios); hipFree(b->d_recs); hipFree(b->d_lut);
+    hipFree(b->dev); hipFree(b->d_trios); hipFree(b->d_recs); hipFree(b->d_lut); hipFree(b->d_colsrc);
     delete b;
 }
 
@@ -422,6 +447,7 @@ static int make_geom(uf3_ctx *c, const uf3_basis *b, const uf3_frames *fr, int f
 // ------------------------------------------------------------------------------ shared pipeline
 struct Prepared {
     int natoms = 0, n_frames = 0, nbins = 0;
+    double max_density = 0;
     CellList cl;
     N3Lists n3;
     const FrameGeom *geoms = nullptr;
@@ -440,12 +466,13 @@ static int check_flags(uf3_ctx *c) {
 }
 
 static int n3_alloc(uf3_ctx *c, int natoms, int cap, N3Lists &n3) {
-    HIPCHK(c, c->n3_cnt.ensure(sizeof(int) * (size_t)natoms));
+    HIPCHK(c, c->n3_cnt.ensure(sizeof(int) * (size_t)natoms * (UF3_MAX_SPECIES + 2)));
     HIPCHK(c, c->n3_int.ensure(sizeof(int) * 4 * (size_t)natoms * cap));
     HIPCHK(c, c->n3_dbl.ensure(sizeof(double) * 4 * (size_t)natoms * cap));
     size_t n = (size_t)natoms * cap;
     n3.cap = cap;
     n3.cnt = c->n3_cnt.as<int>();
+    n3.spoff = n3.cnt + natoms;
     n3.parent = c->n3_int.as<int>(); n3.shiftc = n3.parent + n; n3.sidx = n3.shiftc + n; n3.spec = n3.sidx + n;
     n3.dx = c->n3_dbl.as<double>(); n3.dy = n3.dx + n; n3.dz = n3.dy + n; n3.r = n3.dz + n;
     return UF3_OK;
@@ -517,7 +544,7 @@ static int prepare(uf3_basis *b, const uf3_frames *fr, const double *d_pos, cons
                        c->s_wrap.as<int>(), c->s_spec.as<signed char>());
     HIPCHK(c, hipGetLastError());
 
-    P.natoms = natoms; P.n_frames = nf; P.nbins = nbins;
+    P.natoms = natoms; P.n_frames = nf; P.nbins = nbins; P.max_density = dens;
     P.geoms = c->geoms.as<FrameGeom>();
     P.frame_of = c->frame_of.as<int>();
     P.spec = c->spec.as<signed char>();
@@ -555,11 +582,12 @@ static int prepare(uf3_basis *b, const uf3_frames *fr, const double *d_pos, cons
 }
 
 // ------------------------------------------------------------------------------ featurize
-static size_t feat_lds_bytes(int W, int cap, bool want_e, bool want_f, size_t lut_len) {
-    size_t d = (want_f ? 3 * (size_t)W : 0) + (want_e ? (size_t)W : 0) + 4 * (size_t)cap + (cap & 1) +
-               (size_t)NWAVES * HALF * ITEM_STRIDE;
-    size_t ints = (size_t)5 * cap + 1 + ((cap + 1) & 1);
-    return d * 8 + ints * 4 + lut_len * 2 + 32;
+static size_t feat_lds_bytes(int F, int cap, int cand_cap, bool want_e) {
+    size_t e_d = want_e ? (size_t)F + (F & 1) : 0;
+    size_t stage_d = (size_t)NSTAGE * ITEM_STRIDE, cand_d = (size_t)cand_cap * 5 + ((cand_cap * 5) & 1);
+    size_t per_wave_d = 4 * (size_t)cap + ((4 * cap) & 1) + stage_d + cand_d;
+    size_t per_wave_i = 3 * (size_t)cap + 2 * ((size_t)cap + 1) + (UF3_MAX_SPECIES + 2);
+    return (e_d + WPB * per_wave_d) * 8 + WPB * per_wave_i * 4 + 32;
 }
 
 extern "C" int uf3_featurize_dev(uf3_basis *b, const uf3_frames *fr, const double *d_pos, const int32_t *d_z,
@@ -574,74 +602,53 @@ extern "C" int uf3_featurize_dev(uf3_basis *b, const uf3_frames *fr, const doubl
     hipStream_t st = c->stream;
     const int F = b->host.F;
     const bool want_e = d_xe != nullptr, want_f = d_xf != nullptr;
-    if (want_e) HIPCHK(c, hipMemsetAsync(d_xe, 0, sizeof(double) * (size_t)P.n_frames * F, st));
     int cap = std::max(1, P.n3.cap);
-    // column windows: whole interaction blocks, as many as fit in LDS; the uint16 LUT goes to LDS too
-    // when it still fits beside a single window
-    const int budget = 160 * 1024 - 1024;
-    size_t lut_len = (b->c3_len && F < 65535) ? b->c3_len : 0;
-    if (lut_len && (int)feat_lds_bytes(F, cap, want_e, want_f, lut_len) > budget) lut_len = 0;
-    std::vector<std::pair<int, int>> windows;
-    {
-        const std::vector<int> &bd = b->block_bounds;
-        size_t i = 0;
-        while (i + 1 < bd.size()) {
-            size_t j = i + 1;
-            while (j + 1 < bd.size() && (int)feat_lds_bytes(bd[j + 1] - bd[i], cap, want_e, want_f, lut_len) <= budget) j++;
-            if ((int)feat_lds_bytes(bd[j] - bd[i], cap, want_e, want_f, lut_len) > budget)
-                return fail(c, UF3_EOVERFLOW, "one interaction block exceeds the LDS row buffer");
-            windows.push_back({bd[i], bd[j]});
-            i = j;
-        }
+    if (c->cand_cap == 0) {
+        double r = b->host.rmax2;
+        double est = P.max_density > 0 ? 4.18879 * r * r * r * P.max_density : 64.0;
+        c->cand_cap = std::max(32, ((int)(est * 1.6) + 16 + 7) / 8 * 8);
     }
     FeatArgs A;
-    A.B = b->dev; A.trios = b->d_trios; A.recs = b->d_recs; A.lut = b->d_lut;
+    A.B = b->dev; A.trios = b->d_trios; A.recs = b->d_recs; A.colsrc = b->d_colsrc;
     A.geoms = P.geoms; A.frame_of = P.frame_of; A.cl = P.cl; A.n3 = P.n3;
     if (!A.n3.cap) A.n3.cap = 1;
     A.pos = d_pos; A.spec = P.spec; A.x_e = d_xe; A.x_f = d_xf; A.natoms = P.natoms;
-    A.lut_len = (int)lut_len;
+    A.cand_need = c->flags.as<int>() + 2;
     { const char *e = getenv("UF3_DEBUG_SKIP"); A.skip = e ? atoi(e) : 0; }
-    A.prof = nullptr;
-#ifdef UF3_PROFILE
-    HIPCHK(c, c->dbg.ensure(8 * 64));
-    A.prof = c->dbg.as<long long>();
-    HIPCHK(c, hipMemsetAsync(A.prof, 0, 8 * 64, st));
-#endif
-    for (auto &w : windows) {
-        A.col_lo = w.first; A.col_hi = w.second;
-        size_t lds = feat_lds_bytes(w.second - w.first, A.n3.cap, want_e, want_f, lut_len);
-        int per_cu = std::max(1, (int)((size_t)(160 * 1024) / lds));
-        per_cu = std::min(per_cu, 32 / NWAVES);
-        int n_blocks = std::min(P.natoms, c->n_cu * per_cu);
-        int apb = (P.natoms + n_blocks - 1) / n_blocks;
+    for (int attempt = 0; attempt < 6; attempt++) {
+        A.cand_cap = c->cand_cap;
+        size_t lds = feat_lds_bytes(F, cap, A.cand_cap, want_e);
+        if (lds > 160 * 1024 - 512) return fail(c, UF3_EOVERFLOW, "featurizer LDS footprint exceeds 160 KB (F or neighbour count too large)");
+        if (want_e) HIPCHK(c, hipMemsetAsync(d_xe, 0, sizeof(double) * (size_t)P.n_frames * F, st));
+        HIPCHK(c, hipMemsetAsync(A.cand_need, 0, sizeof(int), st));
+        // blocks of WPB waves; enough blocks to fill every CU several times over, each block walking a
+        // contiguous run of atoms (keeps the shared energy row on one frame)
+        int per_cu = std::max(1, std::min(8, (int)((size_t)(160 * 1024) / lds)));
+        int n_blocks = std::min((P.natoms + WPB - 1) / WPB, c->n_cu * per_cu * 2);
+        int apb = ((P.natoms + n_blocks - 1) / n_blocks + WPB - 1) / WPB * WPB;
         n_blocks = (P.natoms + apb - 1) / apb;
         A.atoms_per_block = apb;
-        Timed tm(c, T_FEAT);
-        if (want_e && want_f) {
-            HIPCHK(c, hipFuncSetAttribute((const void *)k_featurize<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL((k_featurize<true, true>), dim3(n_blocks), dim3(NWAVES * WAVE), lds, st, A);
-        } else if (want_f) {
-            HIPCHK(c, hipFuncSetAttribute((const void *)k_featurize<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL((k_featurize<false, true>), dim3(n_blocks), dim3(NWAVES * WAVE), lds, st, A);
-        } else {
-            HIPCHK(c, hipFuncSetAttribute((const void *)k_featurize<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL((k_featurize<true, false>), dim3(n_blocks), dim3(NWAVES * WAVE), lds, st, A);
+        {
+            Timed tm(c, T_FEAT);
+            if (want_e && want_f) {
+                HIPCHK(c, hipFuncSetAttribute((const void *)k_featurize<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                hipLaunchKernelGGL((k_featurize<true, true>), dim3(n_blocks), dim3(WPB * WAVE), lds, st, A);
+            } else if (want_f) {
+                HIPCHK(c, hipFuncSetAttribute((const void *)k_featurize<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                hipLaunchKernelGGL((k_featurize<false, true>), dim3(n_blocks), dim3(WPB * WAVE), lds, st, A);
+            } else {
+                HIPCHK(c, hipFuncSetAttribute((const void *)k_featurize<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                hipLaunchKernelGGL((k_featurize<true, false>), dim3(n_blocks), dim3(WPB * WAVE), lds, st, A);
+            }
         }
         HIPCHK(c, hipGetLastError());
-    }
-#ifdef UF3_PROFILE
-    {
-        long long hp[64];
-        HIPCHK(c, hipMemcpyAsync(hp, A.prof, sizeof(hp), hipMemcpyDeviceToHost, st));
+        int need = 0;
+        HIPCHK(c, hipMemcpyAsync(&need, A.cand_need, sizeof(int), hipMemcpyDeviceToHost, st));
         HIPCHK(c, hipStreamSynchronize(st));
-        const char *nm[8] = {"2body", "geomC", "eval", "scatter", "geomN", "barrier+write", "ownlist", "tail"};
-        double tot = 0; for (int q = 0; q < 8; q++) tot += (double)hp[q];
-        fprintf(stderr, "[uf3 profile] wave0 cycles per section (sum over blocks):");
-        for (int q = 0; q < 8; q++) fprintf(stderr, " %s=%.1f%%", nm[q], 100.0 * hp[q] / tot);
-        fprintf(stderr, " total=%.3g\n", tot);
+        if (need <= c->cand_cap) return UF3_OK;
+        c->cand_cap = (need + 16 + 7) / 8 * 8;
     }
-#endif
-    return UF3_OK;
+    return fail(c, UF3_EOVERFLOW, "2-body candidate capacity did not converge");
 }
 
 // host-buffer helpers

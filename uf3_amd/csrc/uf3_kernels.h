@@ -140,6 +140,11 @@ k_build_n3(const BasisDev *B, const FrameGeom *geoms, const int *frame_of, CellL
     __syncthreads();
     if (count > cap) { if (lane == 0) atomicMax(overflow_need, count); count = cap; }
     if (lane == 0) n3.cnt[m] = count;
+    for (int sp = lane; sp <= UF3_MAX_SPECIES; sp += WAVE) {     // entries are species-sorted: offsets per species
+        int below = 0;
+        for (int f = 0; f < count; f++) below += espec[f] < sp;
+        n3.spoff[(size_t)m * (UF3_MAX_SPECIES + 1) + sp] = below;
+    }
     size_t base = (size_t)m * cap;
     for (int e = lane; e < count; e += WAVE) {     // rank sort by (species, supercell index)
         unsigned long long k = key[e];
@@ -174,26 +179,19 @@ __device__ __forceinline__ bool neighbour_is_first(const FrameGeom &g, int sm, i
 // ---------------------------------------------------------------------------------
 // featurizer
 // ---------------------------------------------------------------------------------
-#ifdef UF3_PROFILE
-#define PROF_DECL long long prof_t[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long prof_c = 0;
-#define PROF_T0 prof_c = clock64();
-#define PROF_ADD(k) { long long now__ = clock64(); prof_t[k] += now__ - prof_c; prof_c = now__; }
-#else
-#define PROF_DECL
-#define PROF_T0
-#define PROF_ADD(k)
-#endif
-#define NWAVES 8          // waves of the workgroup that cooperates on one atom
-#define HALF 32           // triplet records staged per wave at a time
-#define ITEM_STRIDE 38    // doubles per staged record (16-B aligned records)
-// record layout (doubles): 0-7 (Bl,B'l)[4], 8-15 (Bm,B'm)[4], 16-23 (Bn,B'n)[4],
-// 24-26 A1, 27-29 A2, 30-32 A3, 34-35 int4 {lut base, stride of l, stride of m, energy flag}
+#define WPB 4             // independent waves per workgroup (they share only the energy row)
+#define NSTAGE 16         // records staged in LDS per wave at a time
+#define ITEM_STRIDE 38    // doubles per staged triplet record (16-B aligned)
+#define PAIR_STRIDE 12    // doubles per staged pair record
+// triplet record (doubles): 0-7 (Bl,B'l)[4], 8-15 (Bm,B'm)[4], 16-23 (Bn,B'n)[4],
+//   24-26 A1, 27-29 A2, 30-32 A3, 34-35 int4 {first l, first m, first n, centre flag}
+// pair record (doubles): 0-7 (B,B')[4], 8-10 2*(R_j-R_m)/r, 11 {first basis index, -}
 
 struct FeatArgs {
     const BasisDev *B;
     const TrioDev *trios;     // explicit global pointers (no flat loads through the struct)
     const KnotRec *recs;
-    const int *lut;
+    const int *colsrc;        // per trio [ncol][nsrc] packed (l | m<<8 | n<<16) raw bins feeding a column, -1 pad
     const FrameGeom *geoms;
     const int *frame_of;
     CellList cl;
@@ -202,11 +200,10 @@ struct FeatArgs {
     const signed char *spec;
     double *x_e;        // [n_frames][F] or null
     double *x_f;        // [natoms][3][F] or null
+    int *cand_need;     // overflow report of the 2-body candidate stage
     int natoms, atoms_per_block;
-    int col_lo, col_hi; // column window held in LDS
-    int lut_len;        // > 0: the uint16 copy of the LUT lives in LDS
-    long long *prof;    // UF3_PROFILE builds: [NWAVES][8] cycle counters
-    int skip;           // profiling ablations (UF3_DEBUG_SKIP): 1 two-body, 2 centre role, 4 neighbour role, 8 scatter
+    int cand_cap;       // 2-body candidates staged per atom
+    int skip;           // profiling ablations (UF3_DEBUG_SKIP): 1 two-body, 2 centre role, 4 neighbour role
 };
 
 __device__ __forceinline__ void lds_add(double *p, double v) {
@@ -218,54 +215,98 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_wave_barrier();
 }
 
+// where a wave adds energy-row contributions: the block's LDS row, or (atoms of a frame other than
+// the one the LDS row currently holds) straight to HBM
+struct ESink {
+    double *lds;     // [F]
+    double *glob;    // x_e row of this atom's frame
+    bool direct;
+    __device__ __forceinline__ void add(int col, double v) const {
+        if (v == 0.0) return;
+        if (direct) unsafeAtomicAdd(glob + col, v); else lds_add(lds + col, v);
+    }
+};
+
 // One triplet seen from atom m.  rl, rm, rn: leg lengths in the trio's (l, m, n) order;
 // a1/a2/a3: -(d r_leg / d R_m) for the three legs (zero vector when the leg does not move with m).
 struct TripletGeom {
     double rl, rm, rn;
     double a1[3], a2[3], a3[3];
-    int trio;
     bool centre;
 };
 
 struct TripletRec {
     double v[3][4], d[3][4];
-    int meta[4];
+    int first[3];
 };
 
 template <bool WANT_F>
-__device__ __forceinline__ bool eval_triplet(const FeatArgs &A, const TripletGeom &t, bool valid, TripletRec &r) {
-    if (!valid || t.trio < 0) return false;
-    const TrioDev *td = A.trios + t.trio;
+__device__ __forceinline__ bool eval_triplet(const KnotRec *recs, const TrioDev *td, const TripletGeom &t, bool valid,
+                                             TripletRec &r) {
+    if (!valid) return false;
     // leg masks t[0] <= r <= t[-1] (angles.py:502-508).  r == t[0] selects no basis function
     // (searchsorted - 4 < 0) and at r == t[-1] every selected scipy element evaluates to 0
     // (half-open last interval), so both ends contribute nothing: open interval here.
     if (!((t.rl > td->leg[0].t0) && (t.rl < td->leg[0].tlast) && (t.rm > td->leg[1].t0) && (t.rm < td->leg[1].tlast) &&
           (t.rn > td->leg[2].t0) && (t.rn < td->leg[2].tlast))) return false;
-    int il = find_interval(A.recs, td->leg[0], t.rl);
-    int im = find_interval(A.recs, td->leg[1], t.rm);
-    int in = find_interval(A.recs, td->leg[2], t.rn);
-    bspline4<WANT_F>(A.recs[td->leg[0].rec_off + il], t.rl, r.v[0], r.d[0]);
-    bspline4<WANT_F>(A.recs[td->leg[1].rec_off + im], t.rm, r.v[1], r.d[1]);
-    bspline4<WANT_F>(A.recs[td->leg[2].rec_off + in], t.rn, r.v[2], r.d[2]);
-    int mn = td->dim_m * td->dim_n;
-    r.meta[0] = td->lut_off + (il - 3) * mn + (im - 3) * td->dim_n + (in - 3);
-    r.meta[1] = mn;
-    r.meta[2] = td->dim_n;
-    r.meta[3] = t.centre ? 1 : 0;
+    int il = find_interval(recs, td->leg[0], t.rl);
+    int im = find_interval(recs, td->leg[1], t.rm);
+    int in = find_interval(recs, td->leg[2], t.rn);
+    bspline4<WANT_F>(recs[td->leg[0].rec_off + il], t.rl, r.v[0], r.d[0]);
+    bspline4<WANT_F>(recs[td->leg[1].rec_off + im], t.rm, r.v[1], r.d[1]);
+    bspline4<WANT_F>(recs[td->leg[2].rec_off + in], t.rn, r.v[2], r.d[2]);
+    r.first[0] = il - 3; r.first[1] = im - 3; r.first[2] = in - 3;
     return true;
 }
 
-// 64 evaluated triplets (one per lane) -> two half-batches through the wave's 32-record LDS stage,
-// each scattered with lanes <-> the 4x4x4 block of basis products of one record at a time.
-template <bool WANT_E, bool WANT_F>
-__device__ __forceinline__ void stage_and_scatter(const FeatArgs &A, const TripletGeom &t, const TripletRec &r, bool valid,
-                                                  double *stage, double *rowbuf, double *erow,
-                                                  const unsigned short *lut16) {
+// Output-stationary accumulation: this lane owns (up to) two columns of the current trio block and
+// gathers, from every staged record, the raw bins that feed them (1, 2 or 6 symmetry images).
+template <bool WANT_E, bool WANT_F, int NSRC>
+__device__ __forceinline__ void gather_records(const double *stage, int n_staged, const int (&src)[2][NSRC],
+                                               double (&acc)[2][4]) {
+    for (int q = 0; q < n_staged; q++) {
+        const double *rec = stage + (size_t)q * ITEM_STRIDE;
+        const int4 mt = *(const int4 *)(rec + 34);
+        double2 a01 = {0, 0}, a23 = {0, 0}, a45 = {0, 0}, a67 = {0, 0};
+        double a8 = 0.0;
+        if (WANT_F) {
+            a01 = *(const double2 *)(rec + 24); a23 = *(const double2 *)(rec + 26);
+            a45 = *(const double2 *)(rec + 28); a67 = *(const double2 *)(rec + 30);
+            a8 = rec[32];
+        }
+#pragma unroll
+        for (int ch = 0; ch < 2; ch++) {
+#pragma unroll
+            for (int k = 0; k < NSRC; k++) {
+                const int sp = src[ch][k];
+                const unsigned a = (unsigned)((sp & 255) - mt.x), b = (unsigned)(((sp >> 8) & 255) - mt.y),
+                               c = (unsigned)(((sp >> 16) & 255) - mt.z);
+                if (sp >= 0 && a < 4u && b < 4u && c < 4u) {
+                    const double2 L = *(const double2 *)(rec + 2 * a);
+                    const double2 M = *(const double2 *)(rec + 8 + 2 * b);
+                    const double2 N = *(const double2 *)(rec + 16 + 2 * c);
+                    const double z = L.x * M.x;
+                    if (WANT_E) { if (mt.w) acc[ch][3] += z * N.x; }
+                    if (WANT_F) {
+                        const double p1 = L.y * (M.x * N.x), p2 = M.y * (L.x * N.x), p3 = N.y * z;
+                        // A1 = (a01.x, a01.y, a23.x)  A2 = (a23.y, a45.x, a45.y)  A3 = (a67.x, a67.y, a8)
+                        acc[ch][0] += p1 * a01.x + p2 * a23.y + p3 * a67.x;
+                        acc[ch][1] += p1 * a01.y + p2 * a45.x + p3 * a67.y;
+                        acc[ch][2] += p1 * a23.x + p2 * a45.y + p3 * a8;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// 64 evaluated triplets (one per lane) pass through the wave's NSTAGE-record LDS stage in quarters
+template <bool WANT_E, bool WANT_F, int NSRC>
+__device__ __forceinline__ void stage_and_gather(const TripletGeom &t, const TripletRec &r, bool valid, double *stage,
+                                                 const int (&src)[2][NSRC], double (&acc)[2][4]) {
     const int lane = lane_id();
-    const int a = lane >> 4, b = (lane >> 2) & 3, c = lane & 3;
-    const int W = A.col_hi - A.col_lo;
-    for (int half = 0; half < 2; half++) {
-        bool mine = valid && ((lane >> 5) == half);
+    for (int part = 0; part < WAVE / NSTAGE; part++) {
+        bool mine = valid && ((lane / NSTAGE) == part);
         unsigned long long mask = __ballot(mine);
         if (mask == 0) continue;
         if (mine) {
@@ -276,251 +317,326 @@ __device__ __forceinline__ void stage_and_scatter(const FeatArgs &A, const Tripl
                     if (WANT_F) rec[8 * leg + 2 * q + 1] = r.d[leg][q];
                 }
             if (WANT_F) for (int q = 0; q < 3; q++) { rec[24 + q] = t.a1[q]; rec[27 + q] = t.a2[q]; rec[30 + q] = t.a3[q]; }
-            int4 mt = make_int4(r.meta[0], r.meta[1], r.meta[2], r.meta[3]);
-            *(int4 *)(rec + 34) = mt;
+            *(int4 *)(rec + 34) = make_int4(r.first[0], r.first[1], r.first[2], t.centre ? 1 : 0);
         }
         wave_sync();
-        const int n_staged = (A.skip & 8) ? 0 : __popcll(mask);
-        for (int q = 0; q < n_staged; q++) {
-            const double *rec = stage + (size_t)q * ITEM_STRIDE;
-            const int4 mt = *(const int4 *)(rec + 34);
-            const int raw = mt.x + a * mt.y + b * mt.z + c;
-            int col = lut16 ? (int)lut16[raw] : A.lut[raw];
-            if (lut16) col = (col == 0xFFFF) ? -1 : col;
-            if (col < A.col_lo || col >= A.col_hi) continue;
-            col -= A.col_lo;
-            const double2 L = *(const double2 *)(rec + 2 * a);
-            const double2 M = *(const double2 *)(rec + 8 + 2 * b);
-            const double2 N = *(const double2 *)(rec + 16 + 2 * c);
-            const double z = L.x * M.x;
-            if (WANT_E) { if (mt.w) lds_add(erow + col, z * N.x); }
-            if (WANT_F) {
-                const double p1 = L.y * (M.x * N.x), p2 = M.y * (L.x * N.x), p3 = N.y * z;
-                const double2 a01 = *(const double2 *)(rec + 24), a23 = *(const double2 *)(rec + 26),
-                              a45 = *(const double2 *)(rec + 28), a67 = *(const double2 *)(rec + 30);
-                const double a8 = rec[32];
-                // A1 = (a01.x, a01.y, a23.x)  A2 = (a23.y, a45.x, a45.y)  A3 = (a67.x, a67.y, a8)
-                lds_add(rowbuf + col, p1 * a01.x + p2 * a23.y + p3 * a67.x);
-                lds_add(rowbuf + W + col, p1 * a01.y + p2 * a45.x + p3 * a67.y);
-                lds_add(rowbuf + 2 * W + col, p1 * a23.x + p2 * a45.y + p3 * a8);
-            }
-        }
+        gather_records<WANT_E, WANT_F, NSRC>(stage, __popcll(mask), src, acc);
         wave_sync();
     }
 }
 
+// per-wave scratch in LDS
+struct WaveLds {
+    double *ox, *oy, *oz, *orr;       // own 3-body neighbour list [cap]
+    int *oparent, *oshift, *osidx;
+    int *noff, *nbase;                 // neighbour-role prefix [cap+1] / start index [cap]
+    int *so;                           // species offsets in the own list [S+1]
+    double *stage;                     // NSTAGE triplet / pair records
+    double *cand;                      // 2-body candidates [cand_cap][5]
+};
+
+template <bool WANT_E, bool WANT_F, int NSRC>
+__device__ __forceinline__ void trio_block(const FeatArgs &A, const BasisDev *B, const FrameGeom &g, const WaveLds &w,
+                                           int m, int sm, int t, const ESink &es) {
+    const int lane = lane_id();
+    const TrioDev *td = A.trios + t;
+    const int sc = td->sc, sa = td->sa, sb = td->sb, cap = A.n3.cap;
+    const int m_local = m - g.atom_lo;
+    // --- which triplets does atom m contribute to this block? ------------------------------
+    int cnt_c = 0, ra_lo = 0, rb_lo = 0, nb_ = 1;
+    if (sm == sc && !(A.skip & 2)) {          // m is the centre: own neighbours of species sa x sb
+        ra_lo = w.so[sa]; rb_lo = w.so[sb];
+        int na = w.so[sa + 1] - ra_lo;
+        nb_ = w.so[sb + 1] - rb_lo;
+        cnt_c = (sa == sb) ? na * (na - 1) / 2 : na * nb_;
+        if (nb_ < 1) nb_ = 1;
+    }
+    int total_n = 0, rc_lo = 0, ncen = 0, sx = -1;
+    if (WANT_F && !(A.skip & 4)) {            // m is a neighbour of a centre of species sc
+        if (sm == sa) sx = sb; else if (sm == sb) sx = sa;
+        if (sx >= 0) {
+            rc_lo = w.so[sc];
+            ncen = w.so[sc + 1] - rc_lo;
+            for (int e0 = 0; e0 < ncen; e0 += WAVE) {           // exclusive scan of |N3_sx(centre e)|
+                int e = e0 + lane;
+                int cnt = 0, base = 0;
+                if (e < ncen) {
+                    const int *sp = A.n3.spoff + (size_t)w.oparent[rc_lo + e] * (UF3_MAX_SPECIES + 1);
+                    base = sp[sx]; cnt = sp[sx + 1] - base;
+                }
+                int incl = cnt;
+                for (int sh = 1; sh < WAVE; sh <<= 1) { int o = __shfl_up(incl, sh); if (lane >= sh) incl += o; }
+                if (e < ncen) { w.noff[e] = total_n + incl - cnt; w.nbase[e] = base; }
+                total_n += __shfl(incl, WAVE - 1);
+            }
+            if (lane == 0) w.noff[ncen] = total_n;
+            wave_sync();
+        }
+    }
+    const int n_items = cnt_c + total_n;
+    const int ncol = td->ncol, F = B->F;
+    for (int c0 = 0; c0 < ncol; c0 += 2 * WAVE) {
+        int src[2][NSRC];
+        double acc[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+#pragma unroll
+        for (int ch = 0; ch < 2; ch++) {
+            int col = c0 + ch * WAVE + lane;
+#pragma unroll
+            for (int k = 0; k < NSRC; k++) src[ch][k] = col < ncol ? A.colsrc[td->src_off + col * NSRC + k] : -1;
+        }
+        for (int p0 = 0; p0 < n_items; p0 += WAVE) {
+            int p = p0 + lane;
+            bool valid = p < n_items;
+            TripletGeom tg;
+            TripletRec r;
+            tg.centre = p < cnt_c;
+            if (valid && tg.centre) {
+                int aa, bb;
+                if (sa == sb) {
+                    bb = (int)((1.0f + sqrtf(1.0f + 8.0f * (float)p)) * 0.5f);
+                    while (bb * (bb - 1) / 2 > p) --bb;
+                    while ((bb + 1) * bb / 2 <= p) ++bb;
+                    aa = p - bb * (bb - 1) / 2;
+                    aa += ra_lo; bb += ra_lo;
+                } else { aa = ra_lo + p / nb_; bb = rb_lo + p % nb_; }
+                tg.rl = w.orr[aa]; tg.rm = w.orr[bb];
+                double ex = w.ox[bb] - w.ox[aa], ey = w.oy[bb] - w.oy[aa], ez = w.oz[bb] - w.oz[aa];
+                tg.rn = norm3_rn(ex, ey, ez);
+                if (WANT_F) {
+                    double il = 1.0 / tg.rl, im = 1.0 / tg.rm;
+                    tg.a1[0] = w.ox[aa] * il; tg.a1[1] = w.oy[aa] * il; tg.a1[2] = w.oz[aa] * il;
+                    tg.a2[0] = w.ox[bb] * im; tg.a2[1] = w.oy[bb] * im; tg.a2[2] = w.oz[bb] * im;
+                    tg.a3[0] = tg.a3[1] = tg.a3[2] = 0.0;
+                }
+            } else if (valid) {
+                int q = p - cnt_c;
+                int lo = 0, hi = ncen - 1;                   // centre e with noff[e] <= q < noff[e+1]
+                while (lo < hi) { int mid = (lo + hi + 1) >> 1; if (w.noff[mid] <= q) lo = mid; else hi = mid - 1; }
+                int e = rc_lo + lo, kk = w.nbase[lo] + (q - w.noff[lo]);
+                int pc = w.oparent[e];
+                size_t kb = (size_t)pc * cap + kk;
+                int s0, s1, s2;
+                unpack3(w.oshift[e], s0, s1, s2);
+                int kparent = A.n3.parent[kb], kshift = A.n3.shiftc[kb];
+                valid = !(kparent == m && kshift == pack3(-s0, -s1, -s2));       // k is m itself
+                if (valid) {
+                    int ksidx = A.n3.sidx[kb];
+                    int msidx = supercell_index(g, -s0, -s1, -s2, m_local);      // m as numbered from c
+                    double vx = A.n3.dx[kb], vy = A.n3.dy[kb], vz = A.n3.dz[kb], rk = A.n3.r[kb];
+                    double ex = w.ox[e] + vx, ey = w.oy[e] + vy, ez = w.oz[e] + vz;   // m -> k
+                    tg.rn = norm3_rn(ex, ey, ez);
+                    bool m_first = neighbour_is_first(g, sm, sx, s0, s1, s2, m_local, msidx, ksidx, kshift,
+                                                      kparent - g.atom_lo);
+                    double ie = 1.0 / w.orr[e], in = 1.0 / tg.rn;
+                    double ue[3] = {w.ox[e] * ie, w.oy[e] * ie, w.oz[e] * ie};
+                    tg.a3[0] = ex * in; tg.a3[1] = ey * in; tg.a3[2] = ez * in;
+                    if (m_first) {
+                        tg.rl = w.orr[e]; tg.rm = rk;
+                        for (int u = 0; u < 3; u++) { tg.a1[u] = ue[u]; tg.a2[u] = 0.0; }
+                    } else {
+                        tg.rl = rk; tg.rm = w.orr[e];
+                        for (int u = 0; u < 3; u++) { tg.a1[u] = 0.0; tg.a2[u] = ue[u]; }
+                    }
+                }
+            }
+            valid = eval_triplet<WANT_F>(A.recs, td, tg, valid, r);
+            stage_and_gather<WANT_E, WANT_F, NSRC>(tg, r, valid, w.stage, src, acc);
+        }
+#pragma unroll
+        for (int ch = 0; ch < 2; ch++) {
+            int col = c0 + ch * WAVE + lane;
+            if (col < ncol) {
+                if (WANT_F) {
+                    double *dst = A.x_f + (size_t)m * 3 * F + td->col + col;
+                    dst[0] = acc[ch][0]; dst[F] = acc[ch][1]; dst[2 * (size_t)F] = acc[ch][2];
+                }
+                if (WANT_E) es.add(td->col + col, acc[ch][3]);
+            }
+        }
+    }
+}
+
+// 2-body block (sm, sx): lanes <-> basis functions, candidates of species sx streamed through LDS
 template <bool WANT_E, bool WANT_F>
-__global__ void __launch_bounds__(NWAVES * WAVE)
+__device__ __forceinline__ void pair_block(const FeatArgs &A, const BasisDev *B, const WaveLds &w, int m, int sx,
+                                           const PairDev &pd, int n_cand, const ESink &es) {
+    const int lane = lane_id(), F = B->F;
+    for (int c0 = 0; c0 < pd.nb; c0 += WAVE) {
+        const int bidx = c0 + lane;
+        const bool keep = bidx < pd.nb && bidx >= B->lead2 && bidx < pd.nb - B->trail2;   // bspline.py:840,880
+        double ae = 0, ax = 0, ay = 0, az = 0;
+        for (int e0 = 0; e0 < n_cand; e0 += WAVE) {
+            int e = e0 + lane;
+            bool valid = e < n_cand;
+            double v[4], dv[4], dir[3] = {0, 0, 0};
+            int first = 0;
+            if (valid) {
+                const double *c = w.cand + (size_t)e * 5;
+                valid = (int)c[4] == sx;
+                if (valid) {
+                    double d = c[3];
+                    int i = find_interval(A.recs, pd.leg, d);
+                    bspline4<WANT_F>(A.recs[pd.leg.rec_off + i], d, v, dv);
+                    first = i - 3;
+                    double s = 2.0 / d;      // both directed images of the bond (distances.py:116-141)
+                    dir[0] = s * c[0]; dir[1] = s * c[1]; dir[2] = s * c[2];
+                }
+            }
+            for (int part = 0; part < WAVE / NSTAGE; part++) {
+                bool mine = valid && ((lane / NSTAGE) == part);
+                unsigned long long mask = __ballot(mine);
+                if (mask == 0) continue;
+                if (mine) {
+                    double *rec = w.stage + (size_t)mbcnt(mask) * PAIR_STRIDE;
+                    for (int q = 0; q < 4; q++) { rec[2 * q] = v[q]; if (WANT_F) rec[2 * q + 1] = dv[q]; }
+                    rec[8] = dir[0]; rec[9] = dir[1]; rec[10] = dir[2];
+                    *(int *)(rec + 11) = first;
+                }
+                wave_sync();
+                const int ns = __popcll(mask);
+                for (int q = 0; q < ns; q++) {
+                    const double *rec = w.stage + (size_t)q * PAIR_STRIDE;
+                    const unsigned k = (unsigned)(bidx - *(const int *)(rec + 11));
+                    if (keep && k < 4u) {
+                        const double2 vd = *(const double2 *)(rec + 2 * k);
+                        if (WANT_E) ae += vd.x;
+                        if (WANT_F) { ax += vd.y * rec[8]; ay += vd.y * rec[9]; az += vd.y * rec[10]; }
+                    }
+                }
+                wave_sync();
+            }
+        }
+        if (bidx < pd.nb) {
+            if (WANT_F) {
+                double *dst = A.x_f + (size_t)m * 3 * F + pd.col + bidx;
+                dst[0] = ax; dst[F] = ay; dst[2 * (size_t)F] = az;
+            }
+            if (WANT_E) es.add(pd.col + bidx, ae);
+        }
+    }
+}
+
+__device__ __forceinline__ void zero_rows(double *x_f, int m, int F, int col, int n) {
+    for (int c = lane_id(); c < n; c += WAVE) {
+        double *dst = x_f + (size_t)m * 3 * F + col + c;
+        dst[0] = 0.0; dst[F] = 0.0; dst[2 * (size_t)F] = 0.0;
+    }
+}
+
+template <bool WANT_E, bool WANT_F>
+__global__ void __launch_bounds__(WPB * WAVE)
 k_featurize(FeatArgs A) {
     extern __shared__ __align__(16) unsigned char smem[];
     const BasisDev *B = A.B;
-    const int W = A.col_hi - A.col_lo, cap = A.n3.cap;
-    double *rowbuf = (double *)smem;                               // [3][W]   (WANT_F)
-    double *erow = rowbuf + (WANT_F ? 3 * W : 0);                  // [W]      (WANT_E)
-    double *ox = erow + (WANT_E ? W : 0), *oy = ox + cap, *oz = oy + cap, *orr = oz + cap;   // own neighbour list
-    double *stage_all = orr + cap + (cap & 1);                     // [NWAVES][HALF][ITEM_STRIDE], 16-B aligned
-    int *oparent = (int *)(stage_all + (size_t)NWAVES * HALF * ITEM_STRIDE), *oshift = oparent + cap,
-        *osidx = oshift + cap, *ospec = osidx + cap, *ooff = ospec + cap;        // ooff [cap+1]
-    unsigned short *lut_lds = (unsigned short *)(ooff + cap + 1 + ((cap + 1) & 1));
-    const unsigned short *lut16 = A.lut_len > 0 ? lut_lds : nullptr;
-
+    const int F = B->F, S = B->S, cap = A.n3.cap;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    double *stage = stage_all + (size_t)wave * HALF * ITEM_STRIDE;
-    const int nacc = (WANT_F ? 3 * W : 0) + (WANT_E ? W : 0);
-    for (int q = tid; q < nacc; q += NWAVES * WAVE) rowbuf[q] = 0.0;
-    for (int q = tid; q < A.lut_len; q += NWAVES * WAVE) { int v = A.lut[q]; lut_lds[q] = v < 0 ? 0xFFFF : (unsigned short)v; }
-    __syncthreads();
+    double *erow = (double *)smem;                                         // [F] shared by the block (WANT_E)
+    const size_t e_d = WANT_E ? (size_t)F + (F & 1) : 0;
+    const size_t stage_d = (size_t)NSTAGE * ITEM_STRIDE, cand_d = (size_t)A.cand_cap * 5 + ((A.cand_cap * 5) & 1);
+    const size_t per_wave_d = 4 * (size_t)cap + ((4 * cap) & 1) + stage_d + cand_d;
+    const size_t per_wave_i = 3 * (size_t)cap + 2 * ((size_t)cap + 1) + (UF3_MAX_SPECIES + 2);
+    double *wd = erow + e_d + (size_t)wave * per_wave_d;
+    int *wi = (int *)(erow + e_d + (size_t)WPB * per_wave_d) + (size_t)wave * per_wave_i;
+    WaveLds w;
+    w.ox = wd; w.oy = w.ox + cap; w.oz = w.oy + cap; w.orr = w.oz + cap;
+    w.stage = w.orr + cap + ((4 * cap) & 1);
+    w.cand = w.stage + stage_d;
+    w.oparent = wi; w.oshift = wi + cap; w.osidx = wi + 2 * cap;
+    w.noff = wi + 3 * cap; w.nbase = w.noff + cap + 1; w.so = w.nbase + cap + 1;
 
-    const int a0 = blockIdx.x * A.atoms_per_block, a1 = min(a0 + A.atoms_per_block, A.natoms);
-    int cur_frame = -1;
-    PROF_DECL
-    for (int m = a0; m < a1; m++) {
-        PROF_T0
-        const int fr = A.frame_of[m];
-        if (WANT_E && fr != cur_frame && cur_frame >= 0) {
-            for (int q = tid; q < W; q += NWAVES * WAVE) {
-                double v = erow[q];
-                if (v != 0.0) unsafeAtomicAdd(A.x_e + (size_t)cur_frame * B->F + A.col_lo + q, v);
-                erow[q] = 0.0;
+    if (WANT_E) { for (int q = tid; q < F; q += WPB * WAVE) erow[q] = 0.0; }
+    __syncthreads();
+    const int block_first = blockIdx.x * A.atoms_per_block;
+    const int block_end = min(block_first + A.atoms_per_block, A.natoms);
+    int erow_frame = -1;
+    for (int m0 = block_first; m0 < block_end; m0 += WPB) {      // the block's waves take consecutive atoms
+        const int m = m0 + wave;
+        const bool active = m < block_end;
+        if (WANT_E) {
+            int f_first = A.frame_of[m0];
+            if (f_first != erow_frame) {                          // block-uniform
+                __syncthreads();
+                if (erow_frame >= 0)
+                    for (int q = tid; q < F; q += WPB * WAVE) {
+                        double v = erow[q];
+                        if (v != 0.0) { unsafeAtomicAdd(A.x_e + (size_t)erow_frame * F + q, v); erow[q] = 0.0; }
+                    }
+                __syncthreads();
+                erow_frame = f_first;
             }
-            __syncthreads();
         }
-        cur_frame = fr;
+        if (!active) continue;
+        const int fr = A.frame_of[m];
         const FrameGeom g = A.geoms[fr];
         const int sm = A.spec[m];
         const double pm[3] = {A.pos[3 * (size_t)m], A.pos[3 * (size_t)m + 1], A.pos[3 * (size_t)m + 2]};
-        if (WANT_E && tid == 0 && sm >= A.col_lo && sm < A.col_hi) lds_add(erow + (sm - A.col_lo), 1.0);   // 1-body count
-
-        // ---- own 3-body neighbour list -> LDS --------------------------------------------
-        int n = 0;
+        ESink es;
+        es.lds = erow; es.glob = WANT_E ? A.x_e + (size_t)fr * F : nullptr; es.direct = (fr != erow_frame);
+        // ---- 1-body columns ------------------------------------------------------------------
+        if (WANT_F) zero_rows(A.x_f, m, F, 0, S);
+        if (WANT_E && lane == 0) es.add(sm, 1.0);
+        // ---- 2-body: neighbour images -> LDS once, then one pass per pair block ------------------
+        {
+            int n_cand = 0;
+            if (!(A.skip & 1)) for_each_candidate(g, A.cl, m, [&](bool ok, int slot, int s0, int s1, int s2) {
+                double dx = 0, dy = 0, dz = 0, d = 0;
+                int sj = 0;
+                if (ok) {
+                    image_delta(g, A.cl, slot, s0, s1, s2, pm, dx, dy, dz);
+                    d = norm3_rn(dx, dy, dz);
+                    sj = A.cl.s_spec[slot];
+                    const PairDev &pd = B->pairs[B->pair_of[sm * UF3_MAX_SPECIES + sj]];
+                    ok = (d > pd.rmin && d < pd.rmax);            // distances.py:66 strict both sides
+                }
+                unsigned long long mask = __ballot(ok);
+                if (ok) {
+                    int e = n_cand + mbcnt(mask);
+                    if (e < A.cand_cap) {
+                        double *c = w.cand + (size_t)e * 5;
+                        c[0] = dx; c[1] = dy; c[2] = dz; c[3] = d; c[4] = (double)sj;
+                    }
+                }
+                n_cand += __popcll(mask);
+            });
+            if (n_cand > A.cand_cap) { if (lane == 0) atomicMax(A.cand_need, n_cand); n_cand = A.cand_cap; }
+            wave_sync();
+            for (int p = 0; p < B->P; p++) {
+                const PairDev &pd = B->pairs[p];
+                if (pd.sa == sm) pair_block<WANT_E, WANT_F>(A, B, w, m, pd.sb, pd, n_cand, es);
+                else if (pd.sb == sm) pair_block<WANT_E, WANT_F>(A, B, w, m, pd.sa, pd, n_cand, es);
+                else if (WANT_F) zero_rows(A.x_f, m, F, pd.col, pd.nb);
+            }
+        }
+        // ---- 3-body ---------------------------------------------------------------------------
         if (B->T > 0) {
-            n = A.n3.cnt[m];
+            const int n = A.n3.cnt[m];
             size_t base = (size_t)m * cap;
-            for (int e = tid; e < n; e += NWAVES * WAVE) {
-                ox[e] = A.n3.dx[base + e]; oy[e] = A.n3.dy[base + e]; oz[e] = A.n3.dz[base + e]; orr[e] = A.n3.r[base + e];
-                oparent[e] = A.n3.parent[base + e]; oshift[e] = A.n3.shiftc[base + e];
-                osidx[e] = A.n3.sidx[base + e]; ospec[e] = A.n3.spec[base + e];
+            wave_sync();
+            for (int e = lane; e < n; e += WAVE) {
+                w.ox[e] = A.n3.dx[base + e]; w.oy[e] = A.n3.dy[base + e]; w.oz[e] = A.n3.dz[base + e];
+                w.orr[e] = A.n3.r[base + e];
+                w.oparent[e] = A.n3.parent[base + e]; w.oshift[e] = A.n3.shiftc[base + e];
+                w.osidx[e] = A.n3.sidx[base + e];
+            }
+            if (lane <= S) w.so[lane] = A.n3.spoff[(size_t)m * (UF3_MAX_SPECIES + 1) + lane];
+            wave_sync();
+            for (int t = 0; t < B->T; t++) {
+                const TrioDev *td = A.trios + t;
+                const bool touches = (td->sc == sm) || (WANT_F && (td->sa == sm || td->sb == sm));
+                if (!touches) { if (WANT_F) zero_rows(A.x_f, m, F, td->col, td->ncol); continue; }
+                if (td->nsrc == 1) trio_block<WANT_E, WANT_F, 1>(A, B, g, w, m, sm, t, es);
+                else if (td->nsrc == 2) trio_block<WANT_E, WANT_F, 2>(A, B, g, w, m, sm, t, es);
+                else trio_block<WANT_E, WANT_F, 6>(A, B, g, w, m, sm, t, es);
             }
         }
-
-        PROF_ADD(6)
-        // ---- 2-body: the waves share the neighbour bins ------------------------------------
-        if (!(A.skip & 1)) for_each_candidate_strided(g, A.cl, m, wave, NWAVES, [&](bool ok, int slot, int s0, int s1, int s2) {
-            if (!ok) return;
-            int sj = A.cl.s_spec[slot];
-            const PairDev &pd = B->pairs[B->pair_of[sm * UF3_MAX_SPECIES + sj]];
-            if (pd.col + pd.nb <= A.col_lo || pd.col >= A.col_hi) return;
-            double dx, dy, dz;
-            image_delta(g, A.cl, slot, s0, s1, s2, pm, dx, dy, dz);
-            double d = norm3_rn(dx, dy, dz);
-            if (!(d > pd.rmin && d < pd.rmax)) return;        // distances.py:66 strict both sides
-            int i = find_interval(A.recs, pd.leg, d);
-            double v[4], dv[4];
-            bspline4<WANT_F>(A.recs[pd.leg.rec_off + i], d, v, dv);
-            double inv = 2.0 / d;
-            for (int q = 0; q < 4; q++) {
-                int bidx = i - 3 + q;
-                if (bidx < B->lead2 || bidx >= pd.nb - B->trail2) continue;   // bspline.py:840,880
-                int col = pd.col + bidx - A.col_lo;
-                if (col < 0 || col >= W) continue;
-                if (WANT_E) lds_add(erow + col, v[q]);
-                if (WANT_F) {
-                    // -sum_p B'(r_p) (delta_mj - delta_mi)(R_j-R_i)/r over both directed images of the bond
-                    double s = dv[q] * inv;
-                    lds_add(rowbuf + col, s * dx);
-                    lds_add(rowbuf + W + col, s * dy);
-                    lds_add(rowbuf + 2 * W + col, s * dz);
-                }
-            }
-        });
-        PROF_ADD(0)
-        __syncthreads();
-        PROF_ADD(5)
-
-        // ---- 3-body ---------------------------------------------------------------------
-        if (B->T > 0) {
-            // (a) m is the centre: neighbour pairs a < b of its own (species, index)-sorted list
-            const int n_pairs = (A.skip & 2) ? 0 : n * (n - 1) / 2;
-            // items are dealt to the waves in equal contiguous shares (a share is walked 64 at a time)
-            const int share_c = (n_pairs + NWAVES - 1) / NWAVES;
-            const int end_c = min(n_pairs, (wave + 1) * share_c);
-            for (int p0 = wave * share_c; p0 < end_c; p0 += WAVE) {
-                int p = p0 + lane;
-                bool valid = p < end_c;
-                TripletGeom t;
-                TripletRec r;
-                t.centre = true; t.trio = -1;
-                if (valid) {
-                    int bb = (int)((1.0f + sqrtf(1.0f + 8.0f * (float)p)) * 0.5f);
-                    while (bb * (bb - 1) / 2 > p) --bb;
-                    while ((bb + 1) * bb / 2 <= p) ++bb;
-                    int aa = p - bb * (bb - 1) / 2;
-                    t.rl = orr[aa]; t.rm = orr[bb];
-                    double ex = ox[bb] - ox[aa], ey = oy[bb] - oy[aa], ez = oz[bb] - oz[aa];
-                    t.rn = norm3_rn(ex, ey, ez);
-                    t.trio = B->trio_of[(sm * UF3_MAX_SPECIES + ospec[aa]) * UF3_MAX_SPECIES + ospec[bb]];
-                    if (WANT_F) {
-                        double il = 1.0 / t.rl, im = 1.0 / t.rm;
-                        t.a1[0] = ox[aa] * il; t.a1[1] = oy[aa] * il; t.a1[2] = oz[aa] * il;
-                        t.a2[0] = ox[bb] * im; t.a2[1] = oy[bb] * im; t.a2[2] = oz[bb] * im;
-                        t.a3[0] = t.a3[1] = t.a3[2] = 0.0;
-                    }
-                }
-                PROF_ADD(1)
-                valid = eval_triplet<WANT_F>(A, t, valid, r);
-                PROF_ADD(2)
-                stage_and_scatter<WANT_E, WANT_F>(A, t, r, valid, stage, rowbuf, erow, lut16);
-                PROF_ADD(3)
-            }
-            // (b) m is a neighbour of centre c = own entry e; the other neighbour k runs over N3(c)
-            if (WANT_F) {
-                if (wave == 0) {
-                    int total = 0;
-                    for (int e0 = 0; e0 < n; e0 += WAVE) {           // exclusive scan of |N3(parent_e)|
-                        int e = e0 + lane;
-                        int cnt = e < n ? A.n3.cnt[oparent[e]] : 0;
-                        int incl = cnt;
-                        for (int sh = 1; sh < WAVE; sh <<= 1) { int o = __shfl_up(incl, sh); if (lane >= sh) incl += o; }
-                        if (e < n) ooff[e] = total + incl - cnt;
-                        total += __shfl(incl, WAVE - 1);
-                    }
-                    if (lane == 0) ooff[n] = total;
-                }
-                __syncthreads();
-                const int total = (A.skip & 4) ? 0 : ooff[n];
-                const int m_local = m - g.atom_lo;
-                const int share_n = (total + NWAVES - 1) / NWAVES;
-                const int end_n = min(total, (wave + 1) * share_n);
-                for (int p0 = wave * share_n; p0 < end_n; p0 += WAVE) {
-                    int p = p0 + lane;
-                    bool valid = p < end_n;
-                    TripletGeom t;
-                    TripletRec r;
-                    t.centre = false; t.trio = -1;
-                    if (valid) {
-                        int lo = 0, hi = n - 1;                  // entry e with ooff[e] <= p < ooff[e+1]
-                        while (lo < hi) { int mid = (lo + hi + 1) >> 1; if (ooff[mid] <= p) lo = mid; else hi = mid - 1; }
-                        int e = lo, kk = p - ooff[e];
-                        int pc = oparent[e];
-                        size_t kb = (size_t)pc * cap + kk;
-                        int s0, s1, s2;
-                        unpack3(oshift[e], s0, s1, s2);
-                        int rev_shift = pack3(-s0, -s1, -s2);
-                        int kparent = A.n3.parent[kb], kshift = A.n3.shiftc[kb];
-                        valid = !(kparent == m && kshift == rev_shift);       // k is m itself
-                        if (valid) {
-                            int ksp = A.n3.spec[kb], ksidx = A.n3.sidx[kb];
-                            int msidx = supercell_index(g, -s0, -s1, -s2, m_local);  // m as numbered from c
-                            double vx = A.n3.dx[kb], vy = A.n3.dy[kb], vz = A.n3.dz[kb], rk = A.n3.r[kb];
-                            double ex = ox[e] + vx, ey = oy[e] + vy, ez = oz[e] + vz;   // m -> k
-                            t.rn = norm3_rn(ex, ey, ez);
-                            bool m_first = neighbour_is_first(g, sm, ksp, s0, s1, s2, m_local, msidx, ksidx, kshift,
-                                                              kparent - g.atom_lo);
-                            int sc = ospec[e];
-                            double ie = 1.0 / orr[e], in = 1.0 / t.rn;
-                            double ue[3] = {ox[e] * ie, oy[e] * ie, oz[e] * ie};
-                            t.a3[0] = ex * in; t.a3[1] = ey * in; t.a3[2] = ez * in;
-                            if (m_first) {
-                                t.rl = orr[e]; t.rm = rk;
-                                t.trio = B->trio_of[(sc * UF3_MAX_SPECIES + sm) * UF3_MAX_SPECIES + ksp];
-                                for (int q = 0; q < 3; q++) { t.a1[q] = ue[q]; t.a2[q] = 0.0; }
-                            } else {
-                                t.rl = rk; t.rm = orr[e];
-                                t.trio = B->trio_of[(sc * UF3_MAX_SPECIES + ksp) * UF3_MAX_SPECIES + sm];
-                                for (int q = 0; q < 3; q++) { t.a1[q] = 0.0; t.a2[q] = ue[q]; }
-                            }
-                        }
-                    }
-                    PROF_ADD(4)
-                    valid = eval_triplet<WANT_F>(A, t, valid, r);
-                    PROF_ADD(2)
-                    stage_and_scatter<false, WANT_F>(A, t, r, valid, stage, rowbuf, erow, lut16);
-                    PROF_ADD(3)
-                }
-            }
-        }
-        PROF_ADD(7)
-        __syncthreads();
-        PROF_ADD(5)
-        if (WANT_F) {   // the three rows of atom m leave the chip once, coalesced
-            double *dst = A.x_f + (size_t)m * 3 * B->F + A.col_lo;
-            for (int q = tid; q < 3 * W; q += NWAVES * WAVE) {
-                int comp = q / W, col = q - comp * W;
-                dst[(size_t)comp * B->F + col] = rowbuf[q];
-                rowbuf[q] = 0.0;
-            }
-            __syncthreads();
-        }
-        PROF_ADD(5)
     }
-#ifdef UF3_PROFILE
-    if (lane == 0 && A.prof) for (int q = 0; q < 8; q++) atomicAdd((unsigned long long *)A.prof + wave * 8 + q, (unsigned long long)prof_t[q]);
-#endif
-    if (WANT_E && cur_frame >= 0) {
-        for (int q = tid; q < W; q += NWAVES * WAVE) {
-            double v = erow[q];
-            if (v != 0.0) unsafeAtomicAdd(A.x_e + (size_t)cur_frame * B->F + A.col_lo + q, v);
-        }
+    if (WANT_E) {
+        __syncthreads();
+        if (erow_frame >= 0)
+            for (int q = tid; q < F; q += WPB * WAVE) {
+                double v = erow[q];
+                if (v != 0.0) unsafeAtomicAdd(A.x_e + (size_t)erow_frame * F + q, v);
+            }
     }
 }
 
