@@ -259,51 +259,67 @@ __device__ __forceinline__ bool eval_triplet(const KnotRec *recs, const TrioDev 
     return true;
 }
 
-// Output-stationary accumulation: this lane owns (up to) two columns of the current trio block and
-// gathers, from every staged record, the raw bins that feed them (1, 2 or 6 symmetry images).
-template <bool WANT_E, bool WANT_F, int NSRC>
-__device__ __forceinline__ void gather_records(const double *stage, int n_staged, const int (&src)[2][NSRC],
-                                               double (&acc)[2][4]) {
-    for (int q = 0; q < n_staged; q++) {
-        const double *rec = stage + (size_t)q * ITEM_STRIDE;
-        const int4 mt = *(const int4 *)(rec + 34);
-        double2 a01 = {0, 0}, a23 = {0, 0}, a45 = {0, 0}, a67 = {0, 0};
-        double a8 = 0.0;
-        if (WANT_F) {
-            a01 = *(const double2 *)(rec + 24); a23 = *(const double2 *)(rec + 26);
-            a45 = *(const double2 *)(rec + 28); a67 = *(const double2 *)(rec + 30);
-            a8 = rec[32];
-        }
+// Output-stationary accumulation: this lane owns NCH columns (one per 64-column chunk) of the current
+// trio block and gathers, from every staged record, the raw bins that feed them (1, 2 or 6 symmetry
+// images).  Branch-free on purpose: out-of-block sources read a clamped slot and are masked through
+// the n-leg pair, so the independent chains of one record (and of two records per trip) interleave.
+template <bool WANT_E, bool WANT_F, int NSRC, int NCH>
+__device__ __forceinline__ void gather_one(const double *rec, const int (&src)[NCH][NSRC], double (&acc)[NCH][4]) {
+    const int4 mt = *(const int4 *)(rec + 34);
+    double2 a01 = {0, 0}, a23 = {0, 0}, a45 = {0, 0}, a67 = {0, 0};
+    double a8 = 0.0;
+    if (WANT_F) {
+        a01 = *(const double2 *)(rec + 24); a23 = *(const double2 *)(rec + 26);
+        a45 = *(const double2 *)(rec + 28); a67 = *(const double2 *)(rec + 30);
+        a8 = rec[32];
+    }
+    const double ce = mt.w ? 1.0 : 0.0;
 #pragma unroll
-        for (int ch = 0; ch < 2; ch++) {
+    for (int ch = 0; ch < NCH; ch++) {
 #pragma unroll
-            for (int k = 0; k < NSRC; k++) {
-                const int sp = src[ch][k];
-                const unsigned a = (unsigned)((sp & 255) - mt.x), b = (unsigned)(((sp >> 8) & 255) - mt.y),
-                               c = (unsigned)(((sp >> 16) & 255) - mt.z);
-                if (sp >= 0 && a < 4u && b < 4u && c < 4u) {
-                    const double2 L = *(const double2 *)(rec + 2 * a);
-                    const double2 M = *(const double2 *)(rec + 8 + 2 * b);
-                    const double2 N = *(const double2 *)(rec + 16 + 2 * c);
-                    const double z = L.x * M.x;
-                    if (WANT_E) { if (mt.w) acc[ch][3] += z * N.x; }
-                    if (WANT_F) {
-                        const double p1 = L.y * (M.x * N.x), p2 = M.y * (L.x * N.x), p3 = N.y * z;
-                        // A1 = (a01.x, a01.y, a23.x)  A2 = (a23.y, a45.x, a45.y)  A3 = (a67.x, a67.y, a8)
-                        acc[ch][0] += p1 * a01.x + p2 * a23.y + p3 * a67.x;
-                        acc[ch][1] += p1 * a01.y + p2 * a45.x + p3 * a67.y;
-                        acc[ch][2] += p1 * a23.x + p2 * a45.y + p3 * a8;
-                    }
-                }
+        for (int k = 0; k < NSRC; k++) {
+            const int sp = src[ch][k];
+            const unsigned a = (unsigned)((sp & 255) - mt.x), b = (unsigned)(((sp >> 8) & 255) - mt.y),
+                           c = (unsigned)(((sp >> 16) & 255) - mt.z);
+            const bool ok = (sp >= 0) & (a < 4u) & (b < 4u) & (c < 4u);
+            const double2 L = *(const double2 *)(rec + 2 * (a & 3u));
+            const double2 M = *(const double2 *)(rec + 8 + 2 * (b & 3u));
+            double2 N = *(const double2 *)(rec + 16 + 2 * (c & 3u));
+            N.x = ok ? N.x : 0.0;
+            N.y = ok ? N.y : 0.0;
+            const double z = L.x * M.x;
+            if (WANT_E) acc[ch][3] += ce * (z * N.x);
+            if (WANT_F) {
+                const double p1 = L.y * (M.x * N.x), p2 = M.y * (L.x * N.x), p3 = N.y * z;
+                // A1 = (a01.x, a01.y, a23.x)  A2 = (a23.y, a45.x, a45.y)  A3 = (a67.x, a67.y, a8)
+                acc[ch][0] += p1 * a01.x + p2 * a23.y + p3 * a67.x;
+                acc[ch][1] += p1 * a01.y + p2 * a45.x + p3 * a67.y;
+                acc[ch][2] += p1 * a23.x + p2 * a45.y + p3 * a8;
             }
         }
     }
 }
 
+template <bool WANT_E, bool WANT_F, int NSRC, int NCH>
+__device__ __forceinline__ void gather_records(const double *stage, int n_staged, const int (&src)[NCH][NSRC],
+                                               double (&acc)[NCH][4]) {
+    double acc2[NCH][4];
+#pragma unroll
+    for (int ch = 0; ch < NCH; ch++) for (int u = 0; u < 4; u++) acc2[ch][u] = 0.0;
+    int q = 0;
+    for (; q + 1 < n_staged; q += 2) {          // two independent records per trip
+        gather_one<WANT_E, WANT_F, NSRC, NCH>(stage + (size_t)q * ITEM_STRIDE, src, acc);
+        gather_one<WANT_E, WANT_F, NSRC, NCH>(stage + (size_t)(q + 1) * ITEM_STRIDE, src, acc2);
+    }
+    if (q < n_staged) gather_one<WANT_E, WANT_F, NSRC, NCH>(stage + (size_t)q * ITEM_STRIDE, src, acc);
+#pragma unroll
+    for (int ch = 0; ch < NCH; ch++) for (int u = 0; u < 4; u++) acc[ch][u] += acc2[ch][u];
+}
+
 // 64 evaluated triplets (one per lane) pass through the wave's NSTAGE-record LDS stage in quarters
-template <bool WANT_E, bool WANT_F, int NSRC>
+template <bool WANT_E, bool WANT_F, int NSRC, int NCH>
 __device__ __forceinline__ void stage_and_gather(const TripletGeom &t, const TripletRec &r, bool valid, double *stage,
-                                                 const int (&src)[2][NSRC], double (&acc)[2][4]) {
+                                                 const int (&src)[NCH][NSRC], double (&acc)[NCH][4]) {
     const int lane = lane_id();
     for (int part = 0; part < WAVE / NSTAGE; part++) {
         bool mine = valid && ((lane / NSTAGE) == part);
@@ -320,7 +336,7 @@ __device__ __forceinline__ void stage_and_gather(const TripletGeom &t, const Tri
             *(int4 *)(rec + 34) = make_int4(r.first[0], r.first[1], r.first[2], t.centre ? 1 : 0);
         }
         wave_sync();
-        gather_records<WANT_E, WANT_F, NSRC>(stage, __popcll(mask), src, acc);
+        gather_records<WANT_E, WANT_F, NSRC, NCH>(stage, __popcll(mask), src, acc);
         wave_sync();
     }
 }
@@ -335,7 +351,7 @@ struct WaveLds {
     double *cand;                      // 2-body candidates [cand_cap][5]
 };
 
-template <bool WANT_E, bool WANT_F, int NSRC>
+template <bool WANT_E, bool WANT_F, int NSRC, int NCH>
 __device__ __forceinline__ void trio_block(const FeatArgs &A, const BasisDev *B, const FrameGeom &g, const WaveLds &w,
                                            int m, int sm, int t, const ESink &es) {
     const int lane = lane_id();
@@ -375,11 +391,13 @@ __device__ __forceinline__ void trio_block(const FeatArgs &A, const BasisDev *B,
     }
     const int n_items = cnt_c + total_n;
     const int ncol = td->ncol, F = B->F;
-    for (int c0 = 0; c0 < ncol; c0 += 2 * WAVE) {
-        int src[2][NSRC];
-        double acc[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+    for (int c0 = 0; c0 < ncol; c0 += NCH * WAVE) {
+        int src[NCH][NSRC];
+        double acc[NCH][4];
 #pragma unroll
-        for (int ch = 0; ch < 2; ch++) {
+        for (int ch = 0; ch < NCH; ch++) for (int u = 0; u < 4; u++) acc[ch][u] = 0.0;
+#pragma unroll
+        for (int ch = 0; ch < NCH; ch++) {
             int col = c0 + ch * WAVE + lane;
 #pragma unroll
             for (int k = 0; k < NSRC; k++) src[ch][k] = col < ncol ? A.colsrc[td->src_off + col * NSRC + k] : -1;
@@ -440,10 +458,10 @@ __device__ __forceinline__ void trio_block(const FeatArgs &A, const BasisDev *B,
                 }
             }
             valid = eval_triplet<WANT_F>(A.recs, td, tg, valid, r);
-            stage_and_gather<WANT_E, WANT_F, NSRC>(tg, r, valid, w.stage, src, acc);
+            stage_and_gather<WANT_E, WANT_F, NSRC, NCH>(tg, r, valid, w.stage, src, acc);
         }
 #pragma unroll
-        for (int ch = 0; ch < 2; ch++) {
+        for (int ch = 0; ch < NCH; ch++) {
             int col = c0 + ch * WAVE + lane;
             if (col < ncol) {
                 if (WANT_F) {
@@ -624,9 +642,10 @@ k_featurize(FeatArgs A) {
                 const TrioDev *td = A.trios + t;
                 const bool touches = (td->sc == sm) || (WANT_F && (td->sa == sm || td->sb == sm));
                 if (!touches) { if (WANT_F) zero_rows(A.x_f, m, F, td->col, td->ncol); continue; }
-                if (td->nsrc == 1) trio_block<WANT_E, WANT_F, 1>(A, B, g, w, m, sm, t, es);
-                else if (td->nsrc == 2) trio_block<WANT_E, WANT_F, 2>(A, B, g, w, m, sm, t, es);
-                else trio_block<WANT_E, WANT_F, 6>(A, B, g, w, m, sm, t, es);
+                const bool wide = td->ncol > WAVE;      // two 64-column chunks per walk over the triplets
+                if (td->nsrc == 1) { if (wide) trio_block<WANT_E, WANT_F, 1, 2>(A, B, g, w, m, sm, t, es); else trio_block<WANT_E, WANT_F, 1, 1>(A, B, g, w, m, sm, t, es); }
+                else if (td->nsrc == 2) { if (wide) trio_block<WANT_E, WANT_F, 2, 2>(A, B, g, w, m, sm, t, es); else trio_block<WANT_E, WANT_F, 2, 1>(A, B, g, w, m, sm, t, es); }
+                else trio_block<WANT_E, WANT_F, 6, 1>(A, B, g, w, m, sm, t, es);
             }
         }
     }
