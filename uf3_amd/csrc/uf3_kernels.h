@@ -180,7 +180,7 @@ __device__ __forceinline__ bool neighbour_is_first(const FrameGeom &g, int sm, i
 // featurizer
 // ---------------------------------------------------------------------------------
 #define WPB 4             // independent waves per workgroup (they share only the energy row)
-#define NSTAGE 16         // records staged in LDS per wave at a time
+#define NSTAGE 32         // records staged in LDS per wave at a time
 #define ITEM_STRIDE 38    // doubles per staged triplet record (16-B aligned)
 #define PAIR_STRIDE 12    // doubles per staged pair record
 // triplet record (doubles): 0-7 (Bl,B'l)[4], 8-15 (Bm,B'm)[4], 16-23 (Bn,B'n)[4],
@@ -263,8 +263,10 @@ __device__ __forceinline__ bool eval_triplet(const KnotRec *recs, const TrioDev 
 // trio block and gathers, from every staged record, the raw bins that feed them (1, 2 or 6 symmetry
 // images).  Branch-free on purpose: out-of-block sources read a clamped slot and are masked through
 // the n-leg pair, so the independent chains of one record (and of two records per trip) interleave.
+struct ColSrc { int l, m, n; };   // one raw bin feeding a column; l = 1 << 20 marks "none"
+
 template <bool WANT_E, bool WANT_F, int NSRC, int NCH>
-__device__ __forceinline__ void gather_one(const double *rec, const int (&src)[NCH][NSRC], double (&acc)[NCH][4]) {
+__device__ __forceinline__ void gather_one(const double *rec, const ColSrc (&src)[NCH][NSRC], double (&acc)[NCH][4]) {
     const int4 mt = *(const int4 *)(rec + 34);
     double2 a01 = {0, 0}, a23 = {0, 0}, a45 = {0, 0}, a67 = {0, 0};
     double a8 = 0.0;
@@ -278,30 +280,29 @@ __device__ __forceinline__ void gather_one(const double *rec, const int (&src)[N
     for (int ch = 0; ch < NCH; ch++) {
 #pragma unroll
         for (int k = 0; k < NSRC; k++) {
-            const int sp = src[ch][k];
-            const unsigned a = (unsigned)((sp & 255) - mt.x), b = (unsigned)(((sp >> 8) & 255) - mt.y),
-                           c = (unsigned)(((sp >> 16) & 255) - mt.z);
-            const bool ok = (sp >= 0) & (a < 4u) & (b < 4u) & (c < 4u);
+            const unsigned a = (unsigned)(src[ch][k].l - mt.x), b = (unsigned)(src[ch][k].m - mt.y),
+                           c = (unsigned)(src[ch][k].n - mt.z);
+            const bool ok = (a | b | c) < 4u;
             const double2 L = *(const double2 *)(rec + 2 * (a & 3u));
             const double2 M = *(const double2 *)(rec + 8 + 2 * (b & 3u));
             double2 N = *(const double2 *)(rec + 16 + 2 * (c & 3u));
             N.x = ok ? N.x : 0.0;
             N.y = ok ? N.y : 0.0;
             const double z = L.x * M.x;
-            if (WANT_E) acc[ch][3] += ce * (z * N.x);
+            if (WANT_E) acc[ch][3] = fma(ce, z * N.x, acc[ch][3]);
             if (WANT_F) {
                 const double p1 = L.y * (M.x * N.x), p2 = M.y * (L.x * N.x), p3 = N.y * z;
                 // A1 = (a01.x, a01.y, a23.x)  A2 = (a23.y, a45.x, a45.y)  A3 = (a67.x, a67.y, a8)
-                acc[ch][0] += p1 * a01.x + p2 * a23.y + p3 * a67.x;
-                acc[ch][1] += p1 * a01.y + p2 * a45.x + p3 * a67.y;
-                acc[ch][2] += p1 * a23.x + p2 * a45.y + p3 * a8;
+                acc[ch][0] = fma(p3, a67.x, fma(p2, a23.y, fma(p1, a01.x, acc[ch][0])));
+                acc[ch][1] = fma(p3, a67.y, fma(p2, a45.x, fma(p1, a01.y, acc[ch][1])));
+                acc[ch][2] = fma(p3, a8, fma(p2, a45.y, fma(p1, a23.x, acc[ch][2])));
             }
         }
     }
 }
 
 template <bool WANT_E, bool WANT_F, int NSRC, int NCH>
-__device__ __forceinline__ void gather_records(const double *stage, int n_staged, const int (&src)[NCH][NSRC],
+__device__ __forceinline__ void gather_records(const double *stage, int n_staged, const ColSrc (&src)[NCH][NSRC],
                                                double (&acc)[NCH][4]) {
     double acc2[NCH][4];
 #pragma unroll
@@ -319,7 +320,7 @@ __device__ __forceinline__ void gather_records(const double *stage, int n_staged
 // 64 evaluated triplets (one per lane) pass through the wave's NSTAGE-record LDS stage in quarters
 template <bool WANT_E, bool WANT_F, int NSRC, int NCH>
 __device__ __forceinline__ void stage_and_gather(const TripletGeom &t, const TripletRec &r, bool valid, double *stage,
-                                                 const int (&src)[NCH][NSRC], double (&acc)[NCH][4]) {
+                                                 const ColSrc (&src)[NCH][NSRC], double (&acc)[NCH][4]) {
     const int lane = lane_id();
     for (int part = 0; part < WAVE / NSTAGE; part++) {
         bool mine = valid && ((lane / NSTAGE) == part);
@@ -392,7 +393,7 @@ __device__ __forceinline__ void trio_block(const FeatArgs &A, const BasisDev *B,
     const int n_items = cnt_c + total_n;
     const int ncol = td->ncol, F = B->F;
     for (int c0 = 0; c0 < ncol; c0 += NCH * WAVE) {
-        int src[NCH][NSRC];
+        ColSrc src[NCH][NSRC];
         double acc[NCH][4];
 #pragma unroll
         for (int ch = 0; ch < NCH; ch++) for (int u = 0; u < 4; u++) acc[ch][u] = 0.0;
@@ -400,7 +401,12 @@ __device__ __forceinline__ void trio_block(const FeatArgs &A, const BasisDev *B,
         for (int ch = 0; ch < NCH; ch++) {
             int col = c0 + ch * WAVE + lane;
 #pragma unroll
-            for (int k = 0; k < NSRC; k++) src[ch][k] = col < ncol ? A.colsrc[td->src_off + col * NSRC + k] : -1;
+            for (int k = 0; k < NSRC; k++) {
+                int sp = col < ncol ? A.colsrc[td->src_off + col * NSRC + k] : -1;
+                src[ch][k].l = sp < 0 ? (1 << 20) : (sp & 255);
+                src[ch][k].m = (sp >> 8) & 255;
+                src[ch][k].n = (sp >> 16) & 255;
+            }
         }
         for (int p0 = 0; p0 < n_items; p0 += WAVE) {
             int p = p0 + lane;
