@@ -120,8 +120,17 @@ def main():
         # algorithmic fp64 work: ~100 flop per directed pair, ~3.1 kflop per triplet
         pairs_per_atom, trip_per_atom = 58.0, 91.0
         flops_frame = n_atoms * (100.0 * pairs_per_atom + 3100.0 * trip_per_atom)
+        # HBM bytes per launch from the PMC passes of this same command (separate rocprofv3 --pmc FETCH_SIZE /
+        # WRITE_SIZE runs, summary committed under profiles/); null when the workload differs
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "round1_hbm_counters.json")))
+            if pmc["workload"] == dict(atoms_per_frame=n_atoms, n_feat=F, frames_per_step=B):
+                traffic = pmc["hbm_bytes_per_launch_raw"]
+        except (OSError, KeyError, ValueError):
+            pass
         roofline = dict(bound="hbm", achieved=round(achieved, 2), peak=8000.0, unit="GB/s",
-                        frac=round(achieved / 8000.0, 5), traffic=None,
+                        frac=round(achieved / 8000.0, 5), traffic=traffic,
                         kernel="k_featurize<true,true>", launch_ms=round(launch_ms, 4), launches=launches,
                         algorithmic_bytes_per_launch=bytes_per_launch,
                         fp64_tflops=round(flops_frame * B / (launch_ms * 1e-3) / 1e12, 3), fp64_peak_tflops=78.6,
