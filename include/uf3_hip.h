@@ -83,7 +83,9 @@ typedef struct uf3_frames {
 
 int uf3_ctx_create(int device, uf3_ctx **out);
 void uf3_ctx_destroy(uf3_ctx *ctx);
-/* enqueue on an existing hipStream_t (e.g. torch's current stream); NULL = the ctx's own stream */
+/* enqueue on an existing hipStream_t, e.g. torch's current stream; NULL = HIP's null stream (torch's
+ * default).  Until this is called the ctx uses a private non-blocking stream, which is NOT ordered with
+ * work the caller enqueues elsewhere: callers of the _dev entries should always set their stream. */
 int uf3_ctx_set_stream(uf3_ctx *ctx, void *hip_stream);
 int uf3_ctx_synchronize(uf3_ctx *ctx);
 const char *uf3_last_error(const uf3_ctx *ctx);

@@ -1,0 +1,101 @@
+#!/usr/bin/env python3
+"""
+Secondary measurements (not the bench.py contract): X^T X on the fp64 matrix cores and the
+energy/force evaluator, device-resident, HIP-event timed through the library's own timers.
+
+    python tools/bench_kernels.py [--quick]
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--quick", action="store_true")
+    args = ap.parse_args()
+    import torch
+    from uf3_amd import _lib, synthetic
+    from uf3_amd.data import composition
+    from uf3_amd.representation import bspline, process
+    dev = torch.device("cuda", 0)
+    ctx = _lib.get_context(0)
+    ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+    out = {}
+
+    # ---- Gram: rows of one 10k-atom frame (3N+1 = 30001 rows) at F' = 425 and a 4-frame block ------
+    for rows, F in ([(30001, 425)] if args.quick else [(30001, 425), (120004, 425), (30001, 70)]):
+        x = torch.randn((rows, F), dtype=torch.float64, device=dev)
+        y = torch.randn((rows,), dtype=torch.float64, device=dev)
+        g = torch.empty((F, F), dtype=torch.float64, device=dev)
+        o = torch.empty((F,), dtype=torch.float64, device=dev)
+        call = lambda: ctx.check(ctx.lib.uf3_gram_dev(ctx.handle, C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr()),  # noqa: E731
+                                                     rows, F, F, 0, C.c_void_p(g.data_ptr()), C.c_void_p(o.data_ptr())))
+        call(); torch.cuda.synchronize()
+        ref = x.T @ x
+        err = ((g - ref).abs().max() / ref.abs().max()).item()
+        ctx.timing_reset(True)
+        n = 5
+        for _ in range(n):
+            call()
+        t = ctx.timing_read()["gram_ms"] / n
+        ctx.timing_reset(False)
+        t0 = time.perf_counter()
+        for _ in range(n):
+            ref = x.T @ x
+        torch.cuda.synchronize()
+        t_blas = (time.perf_counter() - t0) / n * 1e3
+        flops = 2.0 * rows * F * F
+        out[f"gram_{rows}x{F}"] = dict(ms=round(t, 4), tflops_full=round(flops / t / 1e9, 2), rel_err=err,
+                                       torch_matmul_ms=round(t_blas, 4), peak_tflops=78.6)
+
+    # ---- evaluator: 10k-atom binary frame and (unless --quick) the 50k-atom ternary config C5 ------
+    cases = [("eval_10k_binary", synthetic.lattice_frame("bcc", (10, 20, 25), 3.165, [42, 74], 3000), synthetic.notebook_basis(['Mo', 'W']))]
+    if not args.quick:
+        cases.append(("eval_50k_ternary", synthetic.lattice_frame("bcc", (25, 25, 40), 3.165, [23, 42, 74], 4000),
+                      synthetic.notebook_basis(['V', 'Mo', 'W'])))
+    from uf3_amd.regression import least_squares as ls
+    from uf3_amd.forcefield import calculator
+    for name, atoms, basis in cases:
+        model = ls.WeightedLinearModel(basis)
+        rng = np.random.default_rng(11)
+        coeff = rng.normal(0, 0.05, basis.n_feats)
+        coeff[basis.col_idx] = 0.0
+        model.coefficients = coeff
+        calc = calculator.UFCalculator(model)
+        db = _lib.device_basis(basis, ctx)
+        batch = _lib.FrameBatch([atoms])
+        d_pos = torch.from_numpy(batch.pos).to(dev)
+        d_z = torch.from_numpy(batch.z).to(dev)
+        d_e = torch.empty((1,), dtype=torch.float64, device=dev)
+        d_f = torch.empty((batch.n_atoms, 3), dtype=torch.float64, device=dev)
+        call = lambda: ctx.check(ctx.lib.uf3_eval_dev(db.handle, C.byref(batch.struct), C.c_void_p(d_pos.data_ptr()),  # noqa: E731
+                                                     C.c_void_p(d_z.data_ptr()), _lib._p(calc._c1), _lib._p(calc._c2),
+                                                     _lib._p(calc._c3), C.c_void_p(d_e.data_ptr()), C.c_void_p(d_f.data_ptr())))
+        call(); torch.cuda.synchronize()
+        ctx.timing_reset(True)
+        n = 5
+        t0 = time.perf_counter()
+        for _ in range(n):
+            call()
+        torch.cuda.synchronize()
+        wall = (time.perf_counter() - t0) / n * 1e3
+        t = ctx.timing_read()
+        ctx.timing_reset(False)
+        f = d_f.cpu().numpy()
+        out[name] = dict(atoms=batch.n_atoms, n_feat=basis.n_feats, eval_kernel_ms=round(t["eval_ms"] / n, 4),
+                         neighbor_ms=round(t["neighbor_ms"] / n, 4), wall_ms_per_step=round(wall, 4),
+                         atom_steps_per_s=round(batch.n_atoms / (wall * 1e-3)), energy=float(d_e.item()),
+                         net_force=float(np.abs(f.sum(axis=0)).max()), max_force=float(np.abs(f).max()))
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()

@@ -119,7 +119,7 @@ extern "C" void uf3_ctx_destroy(uf3_ctx *c) {
 
 extern "C" int uf3_ctx_set_stream(uf3_ctx *c, void *s) {
     if (!c) return fail(nullptr, UF3_EINVAL, "null ctx");
-    c->stream = s ? (hipStream_t)s : c->own_stream;
+    c->stream = (hipStream_t)s;     // NULL is HIP's null stream (what torch's default stream is)
     return UF3_OK;
 }
 
