@@ -206,3 +206,49 @@ def test_unknown_species_raises():
     fz = process.BasisFeaturizer(basis_from_meta(meta))
     with pytest.raises(_lib.SpeciesError):
         fz.featurize_frames([Atoms("Ar2", positions=[[0, 0, 0], [3, 0, 0]])])
+
+
+def test_device_resident_fit_pipeline_matches_host_rows():
+    """frames -> rows -> Gram pieces entirely in HBM == oracle fit on the downloaded rows."""
+    import torch
+    from uf3_amd import pipeline
+    basis = synthetic.notebook_basis(['W'])
+    frames = [synthetic.lattice_frame("bcc", (3, 3, 3), 3.165, [74], seed=50 + k) for k in range(6)]
+    fz = process.BasisFeaturizer(basis)
+    reg = basis.get_regularization_matrix(ridge_1b=1e-8, ridge_2b=0.0, ridge_3b=1e-8, curvature_2b=1e-8, curvature_3b=0.0)
+    rng = np.random.default_rng(7)
+    c_true = rng.normal(0, 1, basis.n_feats)
+    c_true[basis.col_idx] = 0
+    x_e, x_f, off = fz.featurize_frames(frames)
+    energies = x_e @ c_true + rng.normal(0, 1e-3, len(frames))
+    forces_flat = x_f.reshape(-1, basis.n_feats) @ c_true + rng.normal(0, 1e-3, 3 * off[-1])
+    forces = [forces_flat[3 * off[k]:3 * off[k + 1]].reshape(-1, 3) for k in range(len(frames))]
+    model = ls.WeightedLinearModel(basis, regularizer=reg)
+    pieces = pipeline.fit_frames(model, fz, frames, energies, forces, weight=0.4, reduce=False)
+    n = x_e[:, :1].sum(axis=1)
+    ref = O.fit(basis, reg, x_e / n[:, None], energies / n, x_f.reshape(-1, basis.n_feats), forces_flat, weight=0.4)
+    assert np.allclose(pieces["gram_f"], ref["gram_f"], rtol=1e-10, atol=1e-9)
+    assert np.allclose(pieces["gram_e"], ref["gram_e"], rtol=1e-10, atol=1e-12)
+    assert np.allclose(model.predict(x_f.reshape(-1, basis.n_feats)), x_f.reshape(-1, basis.n_feats) @ ref["coefficients"],
+                       rtol=1e-6, atol=1e-7)
+    # the planted model is recovered wherever the data reach (short-range pair columns see no data)
+    pred, true = x_f.reshape(-1, basis.n_feats) @ model.coefficients, x_f.reshape(-1, basis.n_feats) @ c_true
+    assert np.abs(pred - true).max() < 2e-2 * np.abs(true).max()
+
+
+def test_device_entries_follow_the_callers_stream():
+    """_dev entries on torch's (null) stream see data produced just before on that stream."""
+    import ctypes as C
+    import torch
+    dev = torch.device("cuda", 0)
+    ctx = _lib.get_context(0)
+    ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+    for rows in (50000, 200000):
+        x = torch.randn((rows, 160), dtype=torch.float64, device=dev)      # produced on the same stream, no sync
+        y = torch.randn((rows,), dtype=torch.float64, device=dev)
+        g = torch.empty((160, 160), dtype=torch.float64, device=dev)
+        o = torch.empty((160,), dtype=torch.float64, device=dev)
+        ctx.check(ctx.lib.uf3_gram_dev(ctx.handle, C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr()), rows, 160, 160, 0,
+                                       C.c_void_p(g.data_ptr()), C.c_void_p(o.data_ptr())))
+        ref = x.T @ x
+        assert ((g - ref).abs().max() / ref.abs().max()).item() < 1e-12

@@ -73,30 +73,16 @@ def allreduce_pieces(pieces, n_cols, device=None):
 
 def sharded_fit(model, featurizer, frames, energies, forces=None, weight=0.5):
     """
-    Data-parallel ``WeightedLinearModel`` fit: this rank featurizes its block of
-    ``frames`` (list of Atoms; energies [n]; forces list of (N_i, 3) arrays), builds the
-    Gram pieces on its GPU, all ranks sum-reduce once and every rank solves the
-    same small system.  Energy rows and targets are per-atom normalised as in the
-    reference's from-file path (least_squares.py:697-700).
+    Data-parallel ``WeightedLinearModel`` fit over ALL frames: this rank takes its contiguous block,
+    featurizes it and accumulates the Gram pieces on its GPU without the rows leaving HBM
+    (``pipeline.DeviceFitAccumulator``), all ranks sum-reduce once and every rank solves the same
+    small system.  Energy rows / targets are per-atom normalised as in the reference's from-file
+    path (least_squares.py:697-700).
     """
     import torch.distributed as dist
-    rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
-    world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+    from uf3_amd import pipeline
+    on = dist.is_available() and dist.is_initialized()
+    rank, world = (dist.get_rank(), dist.get_world_size()) if on else (0, 1)
     lo, hi = shard_range(len(frames), rank, world)
-    mine = frames[lo:hi]
-    n_el = len(model.bspline_config.element_list)
-    x_e, x_f, _ = featurizer.featurize_frames(mine, energy=True, forces=forces is not None)
-    n_atoms = np.sum(x_e[:, :n_el], axis=1)
-    x_e = x_e / n_atoms[:, None]
-    y_e = np.asarray(energies[lo:hi], dtype=float) / n_atoms
-    if forces is not None:
-        # row order of the reference: all fx, then fy, then fz of a frame does not matter for a Gram
-        x_f = x_f.reshape(-1, x_f.shape[-1])
-        y_f = np.concatenate([np.asarray(f, dtype=float).reshape(-1, 3) for f in forces[lo:hi]]).reshape(-1)
-        pieces = model.gram_pieces(x_e, y_e, x_f, y_f)
-    else:
-        pieces = model.gram_pieces(x_e, y_e)
-    n_cols = model.n_feats - len(model.col_idx)
-    pieces = allreduce_pieces(pieces, n_cols)
-    model.fit_from_pieces(pieces, weight=weight)
-    return pieces
+    return pipeline.fit_frames(model, featurizer, frames[lo:hi], energies[lo:hi],
+                               None if forces is None else forces[lo:hi], weight=weight)
