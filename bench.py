@@ -53,13 +53,14 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    distributed = "RANK" in os.environ and "MASTER_PORT" in os.environ      # launched by torch.distributed.run
+    if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     else:
         torch.cuda.set_device(0)
-    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    dev = torch.device("cuda", local_rank if distributed else 0)
     os.environ["UF3_DEVICE"] = str(dev.index)
 
     # ---- workload ---------------------------------------------------------------------
@@ -86,7 +87,7 @@ def main():
         fz.featurize_device(batch.struct, d_pos.data_ptr(), d_z.data_ptr(), d_xe.data_ptr(), d_xf.data_ptr())
 
     def fence():
-        if world > 1:
+        if distributed:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -101,7 +102,7 @@ def main():
     elapsed = time.perf_counter() - t0
     timing = ctx.timing_read()
     ctx.timing_reset(False)
-    if world > 1:
+    if distributed:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -159,7 +160,7 @@ def main():
                                sharding=f"frames x{world}, no data-path collective"),
                    roofline=roofline, cpu_baseline=cpu)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if distributed:
         dist.barrier()
         dist.destroy_process_group()
     return out
