@@ -190,13 +190,24 @@ __device__ __forceinline__ void for_each_candidate_strided(const FrameGeom &g, c
             int t1 = b1 + o1, sh1 = (t1 >= 0 ? t1 / g.nb[1] : -((g.nb[1] - 1 - t1) / g.nb[1]));
             int c1 = t1 - sh1 * g.nb[1];
             if (!g.per[1]) sh1 = 0;
-            for (int o2 = lo[2]; o2 <= hi[2]; o2++) {
+            // bins along the fastest axis are contiguous in memory: walk maximal runs that share one image
+            // shift as a single slot range (3 bins ~ 40 atoms per 64-lane step instead of ~13)
+            int o2 = lo[2];
+            while (o2 <= hi[2]) {
                 int t2 = b2 + o2, sh2 = (t2 >= 0 ? t2 / g.nb[2] : -((g.nb[2] - 1 - t2) / g.nb[2]));
                 int c2 = t2 - sh2 * g.nb[2];
+                int run = 1;
+                while (o2 + run <= hi[2] && c2 + run < g.nb[2]) {
+                    int tn = b2 + o2 + run;
+                    int shn = (tn >= 0 ? tn / g.nb[2] : -((g.nb[2] - 1 - tn) / g.nb[2]));
+                    if (shn != sh2) break;
+                    ++run;
+                }
+                o2 += run;
                 if (!g.per[2]) sh2 = 0;
-                if ((bin_no++ % n_parts) != part) continue;     // bins dealt round-robin to the parts
+                if ((bin_no++ % n_parts) != part) continue;     // runs dealt round-robin to the parts
                 int gb = g.bin_base + (c0 * g.nb[1] + c1) * g.nb[2] + c2;
-                int s_lo = cl.bin_start[gb], s_hi = cl.bin_start[gb + 1];
+                int s_lo = cl.bin_start[gb], s_hi = cl.bin_start[gb + run];
                 for (int base = s_lo; base < s_hi; base += WAVE) {
                     int slot = base + lane;
                     bool ok = slot < s_hi;
