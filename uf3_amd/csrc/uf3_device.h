@@ -81,15 +81,22 @@ struct CellList {
     const int *atom_wrap;     // [natoms] packed wrap per atom
 };
 
+// one 3-body neighbour (48 B, 16-B aligned): vector from the centre to this image, its length, and the
+// identifiers the triplet logic needs; lists are padded to `cap` entries per atom and sorted by
+// (species, reference supercell index)
+struct __attribute__((aligned(16))) N3Entry {
+    double dx, dy, dz, r;
+    int parent;     // batch-global atom index of the neighbour
+    int shiftc;     // packed image shift relative to the centre's home cell
+    int sidx;       // reference supercell index of the neighbour (seen from a real centre)
+    int spec;       // species index
+};
+
 struct N3Lists {
     int cap;
     int *cnt;       // [natoms]
-    int *parent;    // [natoms*cap] batch-global atom index
-    int *shiftc;    // packed image shift
-    int *sidx;      // reference supercell index of the neighbour (seen from a real centre)
-    int *spec;      // species index
-    int *spoff;     // [natoms][UF3_MAX_SPECIES+1] first entry of each species in the (species-sorted) list
-    double *dx, *dy, *dz, *r;
+    int *spoff;     // [natoms][UF3_MAX_SPECIES+1] first entry of each species in the list
+    N3Entry *ent;   // [natoms*cap]
 };
 
 __device__ __forceinline__ int pack3(int a, int b, int c) { return (a + 512) | ((b + 512) << 10) | ((c + 512) << 20); }

@@ -467,14 +467,11 @@ static int check_flags(uf3_ctx *c) {
 
 static int n3_alloc(uf3_ctx *c, int natoms, int cap, N3Lists &n3) {
     HIPCHK(c, c->n3_cnt.ensure(sizeof(int) * (size_t)natoms * (UF3_MAX_SPECIES + 2)));
-    HIPCHK(c, c->n3_int.ensure(sizeof(int) * 4 * (size_t)natoms * cap));
-    HIPCHK(c, c->n3_dbl.ensure(sizeof(double) * 4 * (size_t)natoms * cap));
-    size_t n = (size_t)natoms * cap;
+    HIPCHK(c, c->n3_dbl.ensure(sizeof(N3Entry) * (size_t)natoms * cap));
     n3.cap = cap;
     n3.cnt = c->n3_cnt.as<int>();
     n3.spoff = n3.cnt + natoms;
-    n3.parent = c->n3_int.as<int>(); n3.shiftc = n3.parent + n; n3.sidx = n3.shiftc + n; n3.spec = n3.sidx + n;
-    n3.dx = c->n3_dbl.as<double>(); n3.dy = n3.dx + n; n3.dz = n3.dy + n; n3.r = n3.dz + n;
+    n3.ent = c->n3_dbl.as<N3Entry>();
     return UF3_OK;
 }
 

@@ -150,9 +150,10 @@ k_build_n3(const BasisDev *B, const FrameGeom *geoms, const int *frame_of, CellL
         unsigned long long k = key[e];
         int rank = 0;
         for (int f = 0; f < count; f++) rank += key[f] < k;
-        size_t o = base + rank;
-        n3.parent[o] = eparent[e]; n3.shiftc[o] = eshift[e]; n3.sidx[o] = esidx[e]; n3.spec[o] = espec[e];
-        n3.dx[o] = ex[e]; n3.dy[o] = ey[e]; n3.dz[o] = ez[e]; n3.r[o] = er[e];
+        N3Entry out;
+        out.dx = ex[e]; out.dy = ey[e]; out.dz = ez[e]; out.r = er[e];
+        out.parent = eparent[e]; out.shiftc = eshift[e]; out.sidx = esidx[e]; out.spec = espec[e];
+        n3.ent[base + rank] = out;
     }
 }
 
@@ -441,12 +442,13 @@ __device__ __forceinline__ void trio_block(const FeatArgs &A, const BasisDev *B,
                 size_t kb = (size_t)pc * cap + kk;
                 int s0, s1, s2;
                 unpack3(w.oshift[e], s0, s1, s2);
-                int kparent = A.n3.parent[kb], kshift = A.n3.shiftc[kb];
+                const N3Entry ke = A.n3.ent[kb];
+                int kparent = ke.parent, kshift = ke.shiftc;
                 valid = !(kparent == m && kshift == pack3(-s0, -s1, -s2));       // k is m itself
                 if (valid) {
-                    int ksidx = A.n3.sidx[kb];
+                    int ksidx = ke.sidx;
                     int msidx = supercell_index(g, -s0, -s1, -s2, m_local);      // m as numbered from c
-                    double vx = A.n3.dx[kb], vy = A.n3.dy[kb], vz = A.n3.dz[kb], rk = A.n3.r[kb];
+                    double vx = ke.dx, vy = ke.dy, vz = ke.dz, rk = ke.r;
                     double ex = w.ox[e] + vx, ey = w.oy[e] + vy, ez = w.oz[e] + vz;   // m -> k
                     tg.rn = norm3_rn(ex, ey, ez);
                     bool m_first = neighbour_is_first(g, sm, sx, s0, s1, s2, m_local, msidx, ksidx, kshift,
@@ -637,10 +639,9 @@ k_featurize(FeatArgs A) {
             size_t base = (size_t)m * cap;
             wave_sync();
             for (int e = lane; e < n; e += WAVE) {
-                w.ox[e] = A.n3.dx[base + e]; w.oy[e] = A.n3.dy[base + e]; w.oz[e] = A.n3.dz[base + e];
-                w.orr[e] = A.n3.r[base + e];
-                w.oparent[e] = A.n3.parent[base + e]; w.oshift[e] = A.n3.shiftc[base + e];
-                w.osidx[e] = A.n3.sidx[base + e];
+                const N3Entry en = A.n3.ent[base + e];
+                w.ox[e] = en.dx; w.oy[e] = en.dy; w.oz[e] = en.dz; w.orr[e] = en.r;
+                w.oparent[e] = en.parent; w.oshift[e] = en.shiftc; w.osidx[e] = en.sidx;
             }
             if (lane <= S) w.so[lane] = A.n3.spoff[(size_t)m * (UF3_MAX_SPECIES + 1) + lane];
             wave_sync();
@@ -754,9 +755,9 @@ k_eval(EvalArgs A) {
         int n = A.n3.cnt[m];
         size_t base = (size_t)m * cap;
         for (int q = lane; q < n; q += WAVE) {
-            ox[q] = A.n3.dx[base + q]; oy[q] = A.n3.dy[base + q]; oz[q] = A.n3.dz[base + q]; orr[q] = A.n3.r[base + q];
-            oparent[q] = A.n3.parent[base + q]; oshift[q] = A.n3.shiftc[base + q];
-            osidx[q] = A.n3.sidx[base + q]; ospec[q] = A.n3.spec[base + q];
+            const N3Entry en = A.n3.ent[base + q];
+            ox[q] = en.dx; oy[q] = en.dy; oz[q] = en.dz; orr[q] = en.r;
+            oparent[q] = en.parent; oshift[q] = en.shiftc; osidx[q] = en.sidx; ospec[q] = en.spec;
         }
         __syncthreads();
         int n_pairs = n * (n - 1) / 2;
@@ -796,14 +797,15 @@ k_eval(EvalArgs A) {
                 size_t kb = (size_t)oparent[q] * cap + kk;
                 int s0, s1, s2;
                 unpack3(oshift[q], s0, s1, s2);
-                if (A.n3.parent[kb] == m && A.n3.shiftc[kb] == pack3(-s0, -s1, -s2)) continue;
-                int ksp = A.n3.spec[kb], ksidx = A.n3.sidx[kb];
+                const N3Entry ke = A.n3.ent[kb];
+                if (ke.parent == m && ke.shiftc == pack3(-s0, -s1, -s2)) continue;
+                int ksp = ke.spec, ksidx = ke.sidx;
                 int msidx = supercell_index(g, -s0, -s1, -s2, m_local);
-                double vx = A.n3.dx[kb], vy = A.n3.dy[kb], vz = A.n3.dz[kb], rk = A.n3.r[kb];
+                double vx = ke.dx, vy = ke.dy, vz = ke.dz, rk = ke.r;
                 double ex = ox[q] + vx, ey = oy[q] + vy, ez = oz[q] + vz;
                 double rn = norm3_rn(vx - (-ox[q]), vy - (-oy[q]), vz - (-oz[q]));
-                bool m_first = neighbour_is_first(g, sm, ksp, s0, s1, s2, m_local, msidx, ksidx, A.n3.shiftc[kb],
-                                                  A.n3.parent[kb] - g.atom_lo);
+                bool m_first = neighbour_is_first(g, sm, ksp, s0, s1, s2, m_local, msidx, ksidx, ke.shiftc,
+                                                  ke.parent - g.atom_lo);
                 int sc = ospec[q];
                 double val, gr[3];
                 int trio; double rl, rm;
