@@ -581,8 +581,9 @@ static int prepare(uf3_basis *b, const uf3_frames *fr, const double *d_pos, cons
 // ------------------------------------------------------------------------------ featurize
 static size_t feat_lds_bytes(int F, int cap, int cand_cap, bool want_e) {
     size_t e_d = want_e ? (size_t)F + (F & 1) : 0;
-    size_t stage_d = (size_t)NSTAGE * ITEM_STRIDE, cand_d = (size_t)cand_cap * 5 + ((cand_cap * 5) & 1);
-    size_t per_wave_d = 4 * (size_t)cap + ((4 * cap) & 1) + stage_d + cand_d;
+    size_t cand_d = (size_t)cand_cap * 5 + ((cand_cap * 5) & 1);
+    size_t stage_d = std::max((size_t)NSTAGE * ITEM_STRIDE, cand_d + (size_t)NSTAGE * PAIR_STRIDE);
+    size_t per_wave_d = 4 * (size_t)cap + ((4 * cap) & 1) + stage_d;
     size_t per_wave_i = 3 * (size_t)cap + 2 * ((size_t)cap + 1) + (UF3_MAX_SPECIES + 2);
     return (e_d + WPB * per_wave_d) * 8 + WPB * per_wave_i * 4 + 32;
 }

@@ -309,10 +309,13 @@ __device__ __forceinline__ void gather_records(const double *stage, int n_staged
 #pragma unroll
     for (int ch = 0; ch < NCH; ch++) for (int u = 0; u < 4; u++) acc2[ch][u] = 0.0;
     int q = 0;
-    for (; q + 1 < n_staged; q += 2) {          // two independent records per trip
-        gather_one<WANT_E, WANT_F, NSRC, NCH>(stage + (size_t)q * ITEM_STRIDE, src, acc);
-        gather_one<WANT_E, WANT_F, NSRC, NCH>(stage + (size_t)(q + 1) * ITEM_STRIDE, src, acc2);
-    }
+    if (NSRC * NCH <= 2)                         // narrow variants: two independent records per trip
+        for (; q + 1 < n_staged; q += 2) {
+            gather_one<WANT_E, WANT_F, NSRC, NCH>(stage + (size_t)q * ITEM_STRIDE, src, acc);
+            gather_one<WANT_E, WANT_F, NSRC, NCH>(stage + (size_t)(q + 1) * ITEM_STRIDE, src, acc2);
+        }
+    else
+        for (; q < n_staged; q++) gather_one<WANT_E, WANT_F, NSRC, NCH>(stage + (size_t)q * ITEM_STRIDE, src, acc);
     if (q < n_staged) gather_one<WANT_E, WANT_F, NSRC, NCH>(stage + (size_t)q * ITEM_STRIDE, src, acc);
 #pragma unroll
     for (int ch = 0; ch < NCH; ch++) for (int u = 0; u < 4; u++) acc[ch][u] += acc2[ch][u];
@@ -350,7 +353,8 @@ struct WaveLds {
     int *noff, *nbase;                 // neighbour-role prefix [cap+1] / start index [cap]
     int *so;                           // species offsets in the own list [S+1]
     double *stage;                     // NSTAGE triplet / pair records
-    double *cand;                      // 2-body candidates [cand_cap][5]
+    double *cand;                      // 2-body candidates [cand_cap][5] (aliases stage)
+    double *pstage;                    // pair records (behind the candidates, inside stage)
 };
 
 template <bool WANT_E, bool WANT_F, int NSRC, int NCH>
@@ -513,7 +517,7 @@ __device__ __forceinline__ void pair_block(const FeatArgs &A, const BasisDev *B,
                 unsigned long long mask = __ballot(mine);
                 if (mask == 0) continue;
                 if (mine) {
-                    double *rec = w.stage + (size_t)mbcnt(mask) * PAIR_STRIDE;
+                    double *rec = w.pstage + (size_t)mbcnt(mask) * PAIR_STRIDE;
                     for (int q = 0; q < 4; q++) { rec[2 * q] = v[q]; if (WANT_F) rec[2 * q + 1] = dv[q]; }
                     rec[8] = dir[0]; rec[9] = dir[1]; rec[10] = dir[2];
                     *(int *)(rec + 11) = first;
@@ -521,7 +525,7 @@ __device__ __forceinline__ void pair_block(const FeatArgs &A, const BasisDev *B,
                 wave_sync();
                 const int ns = __popcll(mask);
                 for (int q = 0; q < ns; q++) {
-                    const double *rec = w.stage + (size_t)q * PAIR_STRIDE;
+                    const double *rec = w.pstage + (size_t)q * PAIR_STRIDE;
                     const unsigned k = (unsigned)(bidx - *(const int *)(rec + 11));
                     if (keep && k < 4u) {
                         const double2 vd = *(const double2 *)(rec + 2 * k);
@@ -558,15 +562,19 @@ k_featurize(FeatArgs A) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     double *erow = (double *)smem;                                         // [F] shared by the block (WANT_E)
     const size_t e_d = WANT_E ? (size_t)F + (F & 1) : 0;
-    const size_t stage_d = (size_t)NSTAGE * ITEM_STRIDE, cand_d = (size_t)A.cand_cap * 5 + ((A.cand_cap * 5) & 1);
-    const size_t per_wave_d = 4 * (size_t)cap + ((4 * cap) & 1) + stage_d + cand_d;
+    // the stage buffer holds triplet records in the 3-body phase and, in the 2-body phase, the candidate
+    // list followed by the pair records
+    const size_t cand_d = (size_t)A.cand_cap * 5 + ((A.cand_cap * 5) & 1);
+    const size_t stage_d = max((size_t)NSTAGE * ITEM_STRIDE, cand_d + (size_t)NSTAGE * PAIR_STRIDE);
+    const size_t per_wave_d = 4 * (size_t)cap + ((4 * cap) & 1) + stage_d;
     const size_t per_wave_i = 3 * (size_t)cap + 2 * ((size_t)cap + 1) + (UF3_MAX_SPECIES + 2);
     double *wd = erow + e_d + (size_t)wave * per_wave_d;
     int *wi = (int *)(erow + e_d + (size_t)WPB * per_wave_d) + (size_t)wave * per_wave_i;
     WaveLds w;
     w.ox = wd; w.oy = w.ox + cap; w.oz = w.oy + cap; w.orr = w.oz + cap;
     w.stage = w.orr + cap + ((4 * cap) & 1);
-    w.cand = w.stage + stage_d;
+    w.cand = w.stage;
+    w.pstage = w.stage + cand_d;
     w.oparent = wi; w.oshift = wi + cap; w.osidx = wi + 2 * cap;
     w.noff = wi + 3 * cap; w.nbase = w.noff + cap + 1; w.so = w.nbase + cap + 1;
 
