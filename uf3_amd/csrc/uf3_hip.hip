@@ -59,7 +59,7 @@ struct uf3_basis {
     int *d_lut = nullptr;
     int *d_colsrc = nullptr;
     std::vector<int> block_bounds;   // column boundaries of interaction blocks (for column windows)
-    size_t c2_len = 0, c3_len = 0;
+    size_t c2_len = 0, c3_len = 0, n_recs = 0;
     double r_cut = 0;
 };
 
@@ -310,6 +310,7 @@ extern "C" int uf3_basis_create(uf3_ctx *c, const uf3_basis_spec *s, uf3_basis *
     if (bounds.back() != h.F) { delete b; return fail(c, UF3_EINVAL, "column blocks do not add up to n_feat"); }
     b->block_bounds = bounds;
 
+    b->n_recs = recs.size();
     HIPCHK(c, hipMalloc(&b->d_recs, sizeof(KnotRec) * std::max<size_t>(1, recs.size())));
     HIPCHK(c, hipMemcpy(b->d_recs, recs.data(), sizeof(KnotRec) * recs.size(), hipMemcpyHostToDevice));
     HIPCHK(c, hipMalloc(&b->d_lut, sizeof(int) * lut.size()));
@@ -579,13 +580,14 @@ static int prepare(uf3_basis *b, const uf3_frames *fr, const double *d_pos, cons
 }
 
 // ------------------------------------------------------------------------------ featurize
-static size_t feat_lds_bytes(int F, int cap, int cand_cap, bool want_e) {
+static size_t feat_lds_bytes(int F, int cap, int cand_cap, bool want_e, size_t n_recs) {
     size_t e_d = want_e ? (size_t)F + (F & 1) : 0;
     size_t cand_d = (size_t)cand_cap * 5 + ((cand_cap * 5) & 1);
     size_t stage_d = std::max((size_t)NSTAGE * ITEM_STRIDE, cand_d + (size_t)NSTAGE * PAIR_STRIDE);
     size_t per_wave_d = 4 * (size_t)cap + ((4 * cap) & 1) + stage_d;
     size_t per_wave_i = 3 * (size_t)cap + 2 * ((size_t)cap + 1) + (UF3_MAX_SPECIES + 2);
-    return (e_d + WPB * per_wave_d) * 8 + WPB * per_wave_i * 4 + 32;
+    size_t ints = ((size_t)WPB * per_wave_i + 3) & ~(size_t)3;
+    return (e_d + WPB * per_wave_d) * 8 + ints * 4 + n_recs * sizeof(KnotRec) + 32;
 }
 
 extern "C" int uf3_featurize_dev(uf3_basis *b, const uf3_frames *fr, const double *d_pos, const int32_t *d_z,
@@ -615,7 +617,12 @@ extern "C" int uf3_featurize_dev(uf3_basis *b, const uf3_frames *fr, const doubl
     { const char *e = getenv("UF3_DEBUG_SKIP"); A.skip = e ? atoi(e) : 0; }
     for (int attempt = 0; attempt < 6; attempt++) {
         A.cand_cap = c->cand_cap;
-        size_t lds = feat_lds_bytes(F, cap, A.cand_cap, want_e);
+        A.n_recs = (int)b->n_recs;
+        // knot records go to LDS when two blocks per CU still fit with them
+        size_t lds_plain = feat_lds_bytes(F, cap, A.cand_cap, want_e, 0);
+        size_t lds_recs = feat_lds_bytes(F, cap, A.cand_cap, want_e, b->n_recs);
+        bool recs_lds = lds_recs <= 80 * 1024 && !getenv("UF3_NO_LDS_RECS");
+        size_t lds = recs_lds ? lds_recs : lds_plain;
         if (lds > 160 * 1024 - 512) return fail(c, UF3_EOVERFLOW, "featurizer LDS footprint exceeds 160 KB (F or neighbour count too large)");
         if (want_e) HIPCHK(c, hipMemsetAsync(d_xe, 0, sizeof(double) * (size_t)P.n_frames * F, st));
         HIPCHK(c, hipMemsetAsync(A.cand_need, 0, sizeof(int), st));
@@ -628,16 +635,15 @@ extern "C" int uf3_featurize_dev(uf3_basis *b, const uf3_frames *fr, const doubl
         A.atoms_per_block = apb;
         {
             Timed tm(c, T_FEAT);
-            if (want_e && want_f) {
-                HIPCHK(c, hipFuncSetAttribute((const void *)k_featurize<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                hipLaunchKernelGGL((k_featurize<true, true>), dim3(n_blocks), dim3(WPB * WAVE), lds, st, A);
-            } else if (want_f) {
-                HIPCHK(c, hipFuncSetAttribute((const void *)k_featurize<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                hipLaunchKernelGGL((k_featurize<false, true>), dim3(n_blocks), dim3(WPB * WAVE), lds, st, A);
-            } else {
-                HIPCHK(c, hipFuncSetAttribute((const void *)k_featurize<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                hipLaunchKernelGGL((k_featurize<true, false>), dim3(n_blocks), dim3(WPB * WAVE), lds, st, A);
-            }
+#define UF3_LAUNCH(E, Fo, R)                                                                                         \
+    do {                                                                                                            \
+        HIPCHK(c, hipFuncSetAttribute((const void *)k_featurize<E, Fo, R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL((k_featurize<E, Fo, R>), dim3(n_blocks), dim3(WPB * WAVE), lds, st, A);                   \
+    } while (0)
+            if (want_e && want_f) { if (recs_lds) UF3_LAUNCH(true, true, true); else UF3_LAUNCH(true, true, false); }
+            else if (want_f) { if (recs_lds) UF3_LAUNCH(false, true, true); else UF3_LAUNCH(false, true, false); }
+            else { if (recs_lds) UF3_LAUNCH(true, false, true); else UF3_LAUNCH(true, false, false); }
+#undef UF3_LAUNCH
         }
         HIPCHK(c, hipGetLastError());
         int need = 0;

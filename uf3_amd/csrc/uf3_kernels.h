@@ -204,6 +204,7 @@ struct FeatArgs {
     int *cand_need;     // overflow report of the 2-body candidate stage
     int natoms, atoms_per_block;
     int cand_cap;       // 2-body candidates staged per atom
+    int n_recs;         // KnotRec count (for the LDS copy)
     int skip;           // profiling ablations (UF3_DEBUG_SKIP): 1 two-body, 2 centre role, 4 neighbour role
 };
 
@@ -358,8 +359,8 @@ struct WaveLds {
 };
 
 template <bool WANT_E, bool WANT_F, int NSRC, int NCH>
-__device__ __forceinline__ void trio_block(const FeatArgs &A, const BasisDev *B, const FrameGeom &g, const WaveLds &w,
-                                           int m, int sm, int t, const ESink &es) {
+__device__ __forceinline__ void trio_block(const FeatArgs &A, const BasisDev *B, const KnotRec *recs, const FrameGeom &g,
+                                           const WaveLds &w, int m, int sm, int t, const ESink &es) {
     const int lane = lane_id();
     const TrioDev *td = A.trios + t;
     const int sc = td->sc, sa = td->sa, sb = td->sb, cap = A.n3.cap;
@@ -469,7 +470,7 @@ __device__ __forceinline__ void trio_block(const FeatArgs &A, const BasisDev *B,
                     }
                 }
             }
-            valid = eval_triplet<WANT_F>(A.recs, td, tg, valid, r);
+            valid = eval_triplet<WANT_F>(recs, td, tg, valid, r);
             stage_and_gather<WANT_E, WANT_F, NSRC, NCH>(tg, r, valid, w.stage, src, acc);
         }
 #pragma unroll
@@ -488,8 +489,8 @@ __device__ __forceinline__ void trio_block(const FeatArgs &A, const BasisDev *B,
 
 // 2-body block (sm, sx): lanes <-> basis functions, candidates of species sx streamed through LDS
 template <bool WANT_E, bool WANT_F>
-__device__ __forceinline__ void pair_block(const FeatArgs &A, const BasisDev *B, const WaveLds &w, int m, int sx,
-                                           const PairDev &pd, int n_cand, const ESink &es) {
+__device__ __forceinline__ void pair_block(const FeatArgs &A, const BasisDev *B, const KnotRec *recs, const WaveLds &w, int m,
+                                           int sx, const PairDev &pd, int n_cand, const ESink &es) {
     const int lane = lane_id(), F = B->F;
     for (int c0 = 0; c0 < pd.nb; c0 += WAVE) {
         const int bidx = c0 + lane;
@@ -505,8 +506,8 @@ __device__ __forceinline__ void pair_block(const FeatArgs &A, const BasisDev *B,
                 valid = (int)c[4] == sx;
                 if (valid) {
                     double d = c[3];
-                    int i = find_interval(A.recs, pd.leg, d);
-                    bspline4<WANT_F>(A.recs[pd.leg.rec_off + i], d, v, dv);
+                    int i = find_interval(recs, pd.leg, d);
+                    bspline4<WANT_F>(recs[pd.leg.rec_off + i], d, v, dv);
                     first = i - 3;
                     double s = 2.0 / d;      // both directed images of the bond (distances.py:116-141)
                     dir[0] = s * c[0]; dir[1] = s * c[1]; dir[2] = s * c[2];
@@ -553,7 +554,7 @@ __device__ __forceinline__ void zero_rows(double *x_f, int m, int F, int col, in
     }
 }
 
-template <bool WANT_E, bool WANT_F>
+template <bool WANT_E, bool WANT_F, bool RECS_LDS>
 __global__ void __launch_bounds__(WPB * WAVE)
 k_featurize(FeatArgs A) {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -578,6 +579,19 @@ k_featurize(FeatArgs A) {
     w.oparent = wi; w.oshift = wi + cap; w.osidx = wi + 2 * cap;
     w.noff = wi + 3 * cap; w.nbase = w.noff + cap + 1; w.so = w.nbase + cap + 1;
 
+    // knot-interval records (de Boor-Cox coefficients) of every pair / trio leg: staged in LDS when they fit
+    KnotRec *recs_lds = (KnotRec *)(wi + (size_t)(WPB - wave) * per_wave_i + (((size_t)WPB * per_wave_i) & 1) * 0);
+    {
+        size_t ints_total = (size_t)WPB * per_wave_i;
+        ints_total = (ints_total + 3) & ~(size_t)3;                        // 16-B alignment
+        recs_lds = (KnotRec *)((int *)(erow + e_d + (size_t)WPB * per_wave_d) + ints_total);
+    }
+    if (RECS_LDS) {
+        const double *srcp = (const double *)A.recs;
+        double *dstp = (double *)recs_lds;
+        for (int q = tid; q < A.n_recs * 12; q += WPB * WAVE) dstp[q] = srcp[q];
+    }
+    const KnotRec *recs = RECS_LDS ? recs_lds : A.recs;
     if (WANT_E) { for (int q = tid; q < F; q += WPB * WAVE) erow[q] = 0.0; }
     __syncthreads();
     const int block_first = blockIdx.x * A.atoms_per_block;
@@ -636,8 +650,8 @@ k_featurize(FeatArgs A) {
             wave_sync();
             for (int p = 0; p < B->P; p++) {
                 const PairDev &pd = B->pairs[p];
-                if (pd.sa == sm) pair_block<WANT_E, WANT_F>(A, B, w, m, pd.sb, pd, n_cand, es);
-                else if (pd.sb == sm) pair_block<WANT_E, WANT_F>(A, B, w, m, pd.sa, pd, n_cand, es);
+                if (pd.sa == sm) pair_block<WANT_E, WANT_F>(A, B, recs, w, m, pd.sb, pd, n_cand, es);
+                else if (pd.sb == sm) pair_block<WANT_E, WANT_F>(A, B, recs, w, m, pd.sa, pd, n_cand, es);
                 else if (WANT_F) zero_rows(A.x_f, m, F, pd.col, pd.nb);
             }
         }
@@ -658,9 +672,9 @@ k_featurize(FeatArgs A) {
                 const bool touches = (td->sc == sm) || (WANT_F && (td->sa == sm || td->sb == sm));
                 if (!touches) { if (WANT_F) zero_rows(A.x_f, m, F, td->col, td->ncol); continue; }
                 const bool wide = td->ncol > WAVE;      // two 64-column chunks per walk over the triplets
-                if (td->nsrc == 1) { if (wide) trio_block<WANT_E, WANT_F, 1, 2>(A, B, g, w, m, sm, t, es); else trio_block<WANT_E, WANT_F, 1, 1>(A, B, g, w, m, sm, t, es); }
-                else if (td->nsrc == 2) { if (wide) trio_block<WANT_E, WANT_F, 2, 2>(A, B, g, w, m, sm, t, es); else trio_block<WANT_E, WANT_F, 2, 1>(A, B, g, w, m, sm, t, es); }
-                else trio_block<WANT_E, WANT_F, 6, 1>(A, B, g, w, m, sm, t, es);
+                if (td->nsrc == 1) { if (wide) trio_block<WANT_E, WANT_F, 1, 2>(A, B, recs, g, w, m, sm, t, es); else trio_block<WANT_E, WANT_F, 1, 1>(A, B, recs, g, w, m, sm, t, es); }
+                else if (td->nsrc == 2) { if (wide) trio_block<WANT_E, WANT_F, 2, 2>(A, B, recs, g, w, m, sm, t, es); else trio_block<WANT_E, WANT_F, 2, 1>(A, B, recs, g, w, m, sm, t, es); }
+                else trio_block<WANT_E, WANT_F, 6, 1>(A, B, recs, g, w, m, sm, t, es);
             }
         }
     }
