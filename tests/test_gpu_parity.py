@@ -252,3 +252,90 @@ def test_device_entries_follow_the_callers_stream():
                                        C.c_void_p(g.data_ptr()), C.c_void_p(o.data_ptr())))
         ref = x.T @ x
         assert ((g - ref).abs().max() / ref.abs().max()).item() < 1e-12
+
+
+# ------------------------------------------------------------------------------------------------
+# edge cases (the oracle is the checker)
+# ------------------------------------------------------------------------------------------------
+def _check_against_oracle(basis, frames, tol=TOL):
+    fz = process.BasisFeaturizer(basis)
+    x_e, x_f, off = fz.featurize_frames(frames)
+    ob = O.OracleBasis(basis)
+    for k, atoms in enumerate(frames):
+        ref = O.featurize(ob, atoms)
+        assert rel_err(x_e[k], ref["xe"]) < tol, k
+        assert rel_err(x_f[off[k]:off[k + 1]], ref["xf"]) < tol, k
+    return x_e, x_f
+
+
+def test_ragged_batch_mixed_boundary_conditions():
+    """one call: isolated atom, dimer out of range, cluster, slab, tiny triclinic cell, 300-atom bulk."""
+    rng = np.random.default_rng(3)
+    basis = synthetic.notebook_basis(['Mo', 'W'], lead3=0)
+    cell = np.array([[4.1, 0.3, 0.0], [-0.5, 3.9, 0.2], [0.4, -0.3, 4.4]])
+    frames = [
+        Atoms(numbers=[74], positions=[[0.0, 0.0, 0.0]]),                                    # no neighbours at all
+        Atoms(numbers=[74, 42], positions=[[0, 0, 0], [9.0, 0, 0]]),                        # out of every range
+        Atoms(numbers=rng.choice([42, 74], 9), positions=rng.uniform(0, 5.5, (9, 3))),      # cluster
+        Atoms(numbers=rng.choice([42, 74], 12), positions=rng.uniform(-1, 7, (12, 3)),
+              cell=np.diag([6.3, 6.9, 20.0]), pbc=[True, True, False]),                     # slab, atoms outside cell
+        Atoms(numbers=rng.choice([42, 74], 3), positions=rng.uniform(0, 4, (3, 3)), cell=cell, pbc=True),   # cell < r_cut
+        synthetic.lattice_frame("bcc", (5, 5, 6), 3.165, [42, 74], seed=9),
+    ]
+    x_e, x_f = _check_against_oracle(basis, frames)
+    assert np.count_nonzero(x_f[0]) == 0 and x_e[0, 1] == 1.0 and np.count_nonzero(x_e[0, 2:]) == 0
+
+
+def test_dense_neighbourhoods_and_capacity_regrowth():
+    """> 64 three-body neighbours per atom and > 128 pair candidates: list loops and capacity retries."""
+    rng = np.random.default_rng(5)
+    cs = synthetic.composition.ChemicalSystem(['W'], 3)
+    basis = synthetic.bspline.BSplineBasis(
+        cs, r_min_map={('W', 'W'): 0.3, ('W', 'W', 'W'): [0.5, 0.5, 0.5]},
+        r_max_map={('W', 'W'): 6.5, ('W', 'W', 'W'): [5.0, 5.0, 10.0]},
+        resolution_map={('W', 'W'): 12, ('W', 'W', 'W'): [5, 5, 10]}, leading_trim=0, trailing_trim=3)
+    # 4 x 2.6 A = 10.4 A >= 2 r_max3: the reference's supercell holds every third atom of a ghost-centred
+    # triplet (below that it silently drops force terms -- DESIGN.md section 7 -- and parity is undefined)
+    atoms = synthetic.lattice_frame("bcc", (4, 4, 4), 2.6, [74], seed=2, rattle=0.1)      # rho = 0.114 / A^3
+    _check_against_oracle(basis, [atoms], tol=1e-8)
+    _, n3 = process.BasisFeaturizer(basis).neighbor_indices(atoms)
+    assert len(n3) / len(atoms) > 50
+
+
+def test_three_species_wide_blocks():
+    """ternary, lead 0: 18 trio blocks of 139/233 columns (several 64-column chunks, nsrc 1 and 2)."""
+    d, meta, atoms = load_case("case_ternary24_slab")
+    basis = basis_from_meta(meta)
+    wide = synthetic.bspline.BSplineBasis(basis.chemical_system, leading_trim=0, trailing_trim=3,
+                                          r_min_map=basis.r_min_map, r_max_map=basis.r_max_map,
+                                          resolution_map=basis.resolution_map)
+    assert wide.n_feats > 2000
+    _check_against_oracle(wide, [atoms])
+
+
+def test_evaluate_dataframe_surface():
+    """tests/test_representation.py:539-603 of the reference: DataFrame in, MultiIndex frame out."""
+    import pandas as pd
+    cs = synthetic.composition.ChemicalSystem(['H', 'O'])
+    basis = synthetic.bspline.BSplineBasis(cs)
+    fz = process.BasisFeaturizer(basis)
+    water = Atoms('H2O', positions=[[0, 0, 0], [3, 0.0, 0.0], [0, 4.0, 0]])
+    df = pd.DataFrame({'geometry': [water, water], 'energy': [1.5, 1.5],
+                       'fx': [[4, 3, 0], [4.1, 3.1, 0]], 'fy': [[0, 1, 2], [0, 1.1, 2.1]], 'fz': [[2, 1, 0], [2, 1, 0]]})
+    out = fz.evaluate(df, 'geometry', 'energy', progress=False)
+    assert len(out) == 2 * (1 + 3 * 3) and len(out.columns) == 1 + 2 + 18 * 3
+    assert list(out.index[:4]) == [(0, 'energy'), (0, 'fx_0'), (0, 'fx_1'), (0, 'fx_2')]
+    assert np.allclose(out['y'].to_numpy()[:10], [1.5, 4, 3, 0, 0, 1, 2, 2, 1, 0])
+    assert out.loc[(0, 'energy'), 'n_H'] == 2 and out.loc[(0, 'energy'), 'n_O'] == 1
+    ref = O.featurize(O.OracleBasis(basis), water)
+    assert rel_err(out.loc[(1, 'energy')].to_numpy()[1:], ref["xe"]) < TOL
+    assert rel_err(out.loc[(1, 'fy_2')].to_numpy()[1:], ref["xf"][2, 1]) < TOL
+
+
+def test_energy_only_and_forces_only_modes_agree():
+    atoms, basis = synthetic.config_c2()
+    fz = process.BasisFeaturizer(basis)
+    x_e, x_f, _ = fz.featurize_frames([atoms])
+    e_only = fz.featurize_frames([atoms], forces=False)[0]
+    f_only = fz.featurize_frames([atoms], energy=False)[1]
+    assert rel_err(e_only, x_e) < 1e-12 and rel_err(f_only, x_f) < 1e-12
