@@ -137,7 +137,7 @@ def main():
                         fp64_tflops=round(flops_frame * B / (launch_ms * 1e-3) / 1e12, 3), fp64_peak_tflops=78.6,
                         neighbor_ms_per_step=round(timing["neighbor_ms"] / args.steps, 4))
         cpu = None
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # reported at N=1 only
             from oracle import oracle as O
             ob = O.OracleBasis(basis)
             t1 = time.perf_counter()

@@ -339,3 +339,22 @@ def test_energy_only_and_forces_only_modes_agree():
     e_only = fz.featurize_frames([atoms], forces=False)[0]
     f_only = fz.featurize_frames([atoms], energy=False)[1]
     assert rel_err(e_only, x_e) < 1e-12 and rel_err(f_only, x_f) < 1e-12
+
+
+def test_evaluator_50k_atom_ternary():
+    """configs[4]: 3-element 50k-atom cell, energy/forces of a random smooth model vs the oracle."""
+    atoms = synthetic.lattice_frame("bcc", (25, 25, 40), 3.165, [23, 42, 74], seed=4000)
+    assert len(atoms) == 50000
+    basis = synthetic.notebook_basis(['V', 'Mo', 'W'])
+    model = ls.WeightedLinearModel(basis)
+    rng = np.random.default_rng(11)
+    coeff = rng.normal(0, 0.05, basis.n_feats)
+    coeff[basis.col_idx] = 0.0
+    model.coefficients = coeff
+    calc = calculator.UFCalculator(model)
+    e, f, _ = calc.evaluate_frames([atoms])
+    e_ref, f_ref = O.evaluate(O.OracleBasis(basis), atoms, coeff)
+    assert abs(e[0] - e_ref) <= 1e-9 * abs(e_ref)
+    assert rel_err(f, f_ref) < 1e-9                       # north_star: forces within 1e-6 of the CPU path
+    x_e = process.BasisFeaturizer(basis).featurize_frames([atoms], forces=False)[0]
+    assert abs(x_e[0] @ coeff - e[0]) <= 1e-10 * abs(e[0])

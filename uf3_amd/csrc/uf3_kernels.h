@@ -185,7 +185,7 @@ __device__ __forceinline__ bool neighbour_is_first(const FrameGeom &g, int sm, i
 #define ITEM_STRIDE 38    // doubles per staged triplet record (16-B aligned)
 #define PAIR_STRIDE 12    // doubles per staged pair record
 // triplet record (doubles): 0-7 (Bl,B'l)[4], 8-15 (Bm,B'm)[4], 16-23 (Bn,B'n)[4],
-//   24-26 A1, 27-29 A2, 30-32 A3, 34-35 int4 {first l, first m, first n, centre flag}
+//   24-26 A1, 27-29 A2, 30-32 A3, 34-35 int4 {first l, first m, first n, centre flag}, 36-37 zero pair
 // pair record (doubles): 0-7 (B,B')[4], 8-10 2*(R_j-R_m)/r, 11 {first basis index, -}
 
 struct FeatArgs {
@@ -277,7 +277,7 @@ __device__ __forceinline__ void gather_one(const double *rec, const ColSrc (&src
         a45 = *(const double2 *)(rec + 28); a67 = *(const double2 *)(rec + 30);
         a8 = rec[32];
     }
-    const double ce = mt.w ? 1.0 : 0.0;
+    const bool centre = WANT_E && mt.w != 0;         // wave-uniform: only centre-role records feed the energy row
 #pragma unroll
     for (int ch = 0; ch < NCH; ch++) {
 #pragma unroll
@@ -287,11 +287,10 @@ __device__ __forceinline__ void gather_one(const double *rec, const ColSrc (&src
             const bool ok = (a | b | c) < 4u;
             const double2 L = *(const double2 *)(rec + 2 * (a & 3u));
             const double2 M = *(const double2 *)(rec + 8 + 2 * (b & 3u));
-            double2 N = *(const double2 *)(rec + 16 + 2 * (c & 3u));
-            N.x = ok ? N.x : 0.0;
-            N.y = ok ? N.y : 0.0;
+            // out-of-block sources read the record's zero pair (slot 33 is never written: kept 0,0 at 36-37)
+            const double2 N = *(const double2 *)(rec + (ok ? 16 + 2 * (c & 3u) : 36));
             const double z = L.x * M.x;
-            if (WANT_E) acc[ch][3] = fma(ce, z * N.x, acc[ch][3]);
+            if (centre) acc[ch][3] = fma(z, N.x, acc[ch][3]);
             if (WANT_F) {
                 const double p1 = L.y * (M.x * N.x), p2 = M.y * (L.x * N.x), p3 = N.y * z;
                 // A1 = (a01.x, a01.y, a23.x)  A2 = (a23.y, a45.x, a45.y)  A3 = (a67.x, a67.y, a8)
@@ -340,6 +339,7 @@ __device__ __forceinline__ void stage_and_gather(const TripletGeom &t, const Tri
                 }
             if (WANT_F) for (int q = 0; q < 3; q++) { rec[24 + q] = t.a1[q]; rec[27 + q] = t.a2[q]; rec[30 + q] = t.a3[q]; }
             *(int4 *)(rec + 34) = make_int4(r.first[0], r.first[1], r.first[2], t.centre ? 1 : 0);
+            rec[36] = 0.0; rec[37] = 0.0;
         }
         wave_sync();
         gather_records<WANT_E, WANT_F, NSRC, NCH>(stage, __popcll(mask), src, acc);
