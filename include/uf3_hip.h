@@ -129,6 +129,18 @@ int uf3_eval_dev(uf3_basis *basis, const uf3_frames *frames, const double *d_pos
                  double *d_energies, double *d_forces);
 
 /*
+ * Same, plus the analytic strain derivative of the energy per frame: virials [n_frames][6] = dE/d(eps) in
+ * Voigt order (xx, yy, zz, yz, xz, xy), eV; stress = virial / cell volume.  Row N3 of SURVEY section 8f: the
+ * reference only offers finite differences (calculator.py:399-404).
+ */
+int uf3_eval_virial(uf3_basis *basis, const uf3_frames *frames, const double *pos, const int32_t *z,
+                    const double *c1, const double *c2, const double *c3, double *energies, double *forces,
+                    double *virials);
+int uf3_eval_virial_dev(uf3_basis *basis, const uf3_frames *frames, const double *d_pos, const int32_t *d_z,
+                        const double *c1, const double *c2, const double *c3 /* host */,
+                        double *d_energies, double *d_forces, double *d_virials);
+
+/*
  * Neighbour indices in the reference's supercell numbering (ghost index =
  * image_rank * N + atom, geometry.py:108-149), single frame, host buffers.
  *   pair_ij [P][pair_cap][2]  2-body (i, j) per pair block, row-major sorted; pair_count [P]

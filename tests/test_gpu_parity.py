@@ -120,8 +120,10 @@ def test_energy_and_forces_are_rows_dot_coefficients():
     assert np.allclose(x_e @ model.coefficients, e, rtol=1e-11)
     assert np.allclose(x_f @ model.coefficients, f, rtol=1e-9, atol=1e-10)
     assert abs(e[0] - CALC["w128_model23_energy"]["energy"]) < 1e-8
-    stress = calc._get_stress(frames[0])
+    stress = calc._get_stress(frames[0])                      # analytic virial / volume
+    numeric = calc._get_stress(frames[0], numerical=True)     # the reference's finite-difference route
     assert stress.shape == (6,) and np.all(np.isfinite(stress))
+    assert np.abs(stress - numeric).max() < 1e-6 * max(1e-3, np.abs(numeric).max())
 
 
 def test_gram_and_fit_against_reference_capture():
@@ -358,3 +360,12 @@ def test_evaluator_50k_atom_ternary():
     assert rel_err(f, f_ref) < 1e-9                       # north_star: forces within 1e-6 of the CPU path
     x_e = process.BasisFeaturizer(basis).featurize_frames([atoms], forces=False)[0]
     assert abs(x_e[0] @ coeff - e[0]) <= 1e-10 * abs(e[0])
+
+
+def test_featurize_frames_chunking_is_transparent():
+    basis = synthetic.notebook_basis(['W'])
+    frames = [synthetic.lattice_frame("bcc", (2, 2, 2 + (k % 2)), 3.165, [74], seed=70 + k) for k in range(7)]
+    fz = process.BasisFeaturizer(basis)
+    a_e, a_f, off = fz.featurize_frames(frames)
+    b_e, b_f, off2 = fz.featurize_frames(frames, max_bytes=40 * 24 * basis.n_feats)      # ~2 frames per chunk
+    assert np.array_equal(off, off2) and rel_err(b_e, a_e) < 1e-12 and rel_err(b_f, a_f) < 1e-12

@@ -702,6 +702,7 @@ struct EvalArgs {
     const double *c1, *c2, *c3;   // device copies; c2 indexed by (pair col - S) + b, c3 by lut offset + raw
     double *e_atom;               // [natoms]
     double *forces;               // [natoms][3] or null
+    double *virial;               // [natoms][6] dE/d(strain) shares (xx,yy,zz,yz,xz,xy) or null
     int natoms;
 };
 
@@ -751,7 +752,8 @@ k_eval(EvalArgs A) {
     int lane = lane_id();
     const FrameGeom g = A.geoms[A.frame_of[m]];
     const int sm = A.spec[m];
-    const bool want_f = A.forces != nullptr;
+    const bool want_f = A.forces != nullptr, want_v = A.virial != nullptr;
+    double vir[6] = {0, 0, 0, 0, 0, 0};
     double pm[3] = {A.pos[3 * (size_t)m], A.pos[3 * (size_t)m + 1], A.pos[3 * (size_t)m + 2]};
     double e = 0.0, fx = 0.0, fy = 0.0, fz = 0.0;
     if (lane == 0) e = A.c1[sm];
@@ -772,6 +774,11 @@ k_eval(EvalArgs A) {
         e += phi;
         double s = 2.0 * dphi / d;
         fx += s * dx; fy += s * dy; fz += s * dz;
+        if (want_v) {   // d/d(strain) of the directed pair sum: phi'(r) r (x) r / r
+            double t = dphi / d;
+            vir[0] += t * dx * dx; vir[1] += t * dy * dy; vir[2] += t * dz * dz;
+            vir[3] += t * dy * dz; vir[4] += t * dx * dz; vir[5] += t * dx * dy;
+        }
     });
     if (B->T > 0) {
         int n = A.n3.cnt[m];
@@ -792,11 +799,21 @@ k_eval(EvalArgs A) {
             double rn = norm3_rn(ox[bb] - ox[aa], oy[bb] - oy[aa], oz[bb] - oz[aa]);
             int trio = B->trio_of[(sm * UF3_MAX_SPECIES + ospec[aa]) * UF3_MAX_SPECIES + ospec[bb]];
             double val, gr[3];
-            if (!trio_value(B, A.c3, trio, rl, rm, rn, want_f, val, gr)) continue;
+            if (!trio_value(B, A.c3, trio, rl, rm, rn, want_f || want_v, val, gr)) continue;
             e += val;
             if (want_f) {   // F_m = -dV/dR_m = gl * u_ij + gm * u_ik
                 double a = gr[0] / rl, b = gr[1] / rm;
                 fx += a * ox[aa] + b * ox[bb]; fy += a * oy[aa] + b * oy[bb]; fz += a * oz[aa] + b * oz[bb];
+            }
+            if (want_v) {   // each triplet once (at its centre): sum over legs of dV/dr * r (x) r / r
+                double ta = gr[0] / rl, tb = gr[1] / rm, tc = gr[2] / rn;
+                double cx = ox[bb] - ox[aa], cy = oy[bb] - oy[aa], cz = oz[bb] - oz[aa];
+                vir[0] += ta * ox[aa] * ox[aa] + tb * ox[bb] * ox[bb] + tc * cx * cx;
+                vir[1] += ta * oy[aa] * oy[aa] + tb * oy[bb] * oy[bb] + tc * cy * cy;
+                vir[2] += ta * oz[aa] * oz[aa] + tb * oz[bb] * oz[bb] + tc * cz * cz;
+                vir[3] += ta * oy[aa] * oz[aa] + tb * oy[bb] * oz[bb] + tc * cy * cz;
+                vir[4] += ta * ox[aa] * oz[aa] + tb * ox[bb] * oz[bb] + tc * cx * cz;
+                vir[5] += ta * ox[aa] * oy[aa] + tb * ox[bb] * oy[bb] + tc * cx * cy;
             }
         }
         if (want_f) {
@@ -841,25 +858,28 @@ k_eval(EvalArgs A) {
     }
     e = wave_sum(e);
     if (lane == 0) A.e_atom[m] = e;
+    if (want_v) {
+        for (int q = 0; q < 6; q++) { double v = wave_sum(vir[q]); if (lane == 0) A.virial[6 * (size_t)m + q] = v; }
+    }
     if (want_f) {
         fx = wave_sum(fx); fy = wave_sum(fy); fz = wave_sum(fz);
         if (lane == 0) { A.forces[3 * (size_t)m] = fx; A.forces[3 * (size_t)m + 1] = fy; A.forces[3 * (size_t)m + 2] = fz; }
     }
 }
 
-// frame energies: deterministic tree sum of the per-atom energies
-__global__ void k_frame_energy(const double *e_atom, const int64_t *atom_offsets, double *energies) {
+// per-frame sums of per-atom quantities (energy: width 1, virial: width 6): deterministic tree
+__global__ void k_frame_sum(const double *per_atom, const int64_t *atom_offsets, int width, double *out) {
     __shared__ double part[256];
-    int f = blockIdx.x;
+    int f = blockIdx.x, comp = blockIdx.y;
     double s = 0.0;
-    for (int64_t a = atom_offsets[f] + threadIdx.x; a < atom_offsets[f + 1]; a += blockDim.x) s += e_atom[a];
+    for (int64_t a = atom_offsets[f] + threadIdx.x; a < atom_offsets[f + 1]; a += blockDim.x) s += per_atom[a * width + comp];
     part[threadIdx.x] = s;
     __syncthreads();
     for (int w = blockDim.x / 2; w > 0; w >>= 1) {
         if ((int)threadIdx.x < w) part[threadIdx.x] += part[threadIdx.x + w];
         __syncthreads();
     }
-    if (threadIdx.x == 0) energies[f] = part[0];
+    if (threadIdx.x == 0) out[(size_t)f * width + comp] = part[0];
 }
 
 // ---------------------------------------------------------------------------------

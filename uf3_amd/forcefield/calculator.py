@@ -91,15 +91,20 @@ class UFCalculator(_Base):
     def __repr__(self):
         return "\n".join(["UFCalculator:", repr(self.model)])
 
-    def evaluate_frames(self, atoms_list, forces=True):
-        """Energies [n_frames] and forces [sum N, 3] of a batch of frames."""
+    def evaluate_frames(self, atoms_list, forces=True, virial=False):
+        """Energies [n_frames], forces [sum N, 3] (and dE/d(strain) [n_frames, 6]) of a batch of frames."""
         ctx = _lib.get_context(self.device)
         db = _lib.device_basis(self.bspline_config, ctx)
         batch = _lib.FrameBatch(atoms_list)
         e = np.empty(batch.n_frames)
         f = np.empty((batch.n_atoms, 3)) if forces else None
-        ctx.check(ctx.lib.uf3_eval(db.handle, C.byref(batch.struct), _lib._p(batch.pos), _lib._p(batch.z),
-                                   _lib._p(self._c1), _lib._p(self._c2), _lib._p(self._c3), _lib._p(e), _lib._p(f)))
+        args = (db.handle, C.byref(batch.struct), _lib._p(batch.pos), _lib._p(batch.z), _lib._p(self._c1),
+                _lib._p(self._c2), _lib._p(self._c3), _lib._p(e), _lib._p(f))
+        if virial:
+            v = np.empty((batch.n_frames, 6))
+            ctx.check(ctx.lib.uf3_eval_virial(*args, _lib._p(v)))
+            return e, f, batch.offsets, v
+        ctx.check(ctx.lib.uf3_eval(*args))
         return e, f, batch.offsets
 
     def calculate(self, atoms=None, properties=None, system_changes=tuple(all_changes)):
@@ -122,11 +127,18 @@ class UFCalculator(_Base):
     def _get_forces(self, atoms=None):
         return self.evaluate_frames([atoms], forces=True)[1]
 
-    def _get_stress(self, atoms=None, d=1e-6):
-        """Numerical stress, Voigt order (xx, yy, zz, yz, xz, xy); the 12 strained copies run as one batch."""
+    def _get_stress(self, atoms=None, numerical=False, d=1e-6):
+        """
+        Stress in Voigt order (xx, yy, zz, yz, xz, xy), eV/A^3.  Default: analytic virial accumulated in
+        the same neighbour traversal as the forces.  ``numerical=True`` reproduces the
+        reference's route (central differences of the energy under strain, calculator.py:399-404), the 12
+        strained copies going to the GPU as one batch.
+        """
         cell = np.array(atoms.get_cell(), dtype=float).reshape(3, 3)
-        pos = np.asarray(atoms.get_positions(), dtype=float)
         vol = abs(np.linalg.det(cell))
+        if not numerical:
+            return self.evaluate_frames([atoms], forces=False, virial=True)[3][0] / vol
+        pos = np.asarray(atoms.get_positions(), dtype=float)
         from uf3_amd.data.atoms import Atoms
         frames, pairs = [], [(0, 0), (1, 1), (2, 2), (1, 2), (0, 2), (0, 1)]
         for i, j in pairs:

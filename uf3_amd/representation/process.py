@@ -66,22 +66,35 @@ class BasisFeaturizer:
         ctx = _lib.get_context(self.device)
         return ctx, _lib.device_basis(self.bspline_config, ctx)
 
-    def featurize_frames(self, atoms_list, energy=True, forces=True, periodic=None):
+    def featurize_frames(self, atoms_list, energy=True, forces=True, periodic=None, max_bytes=2 << 30):
         """
         Feature rows of a batch of frames (host arrays in, host arrays out).
 
         Returns (x_e [n_frames, F] | None, x_f [sum N, 3, F] | None, offsets [n_frames+1]).
-        Column order = ``get_column_names()[1:]`` (no ``y``).
+        Column order = ``get_column_names()[1:]`` (no ``y``).  Long lists go to the device in chunks of at
+        most ``max_bytes`` of force rows, so the staging buffers stay bounded.
         """
-        ctx, db = self._dev()
-        batch = _lib.FrameBatch(atoms_list, periodic=periodic)
-        F = db.n_feat
-        x_e = np.empty((batch.n_frames, F)) if energy else None
-        x_f = np.empty((batch.n_atoms, 3, F)) if forces else None
         import ctypes as C
-        ctx.check(ctx.lib.uf3_featurize(db.handle, C.byref(batch.struct), _lib._p(batch.pos), _lib._p(batch.z),
-                                        _lib._p(x_e), _lib._p(x_f)))
-        return x_e, x_f, batch.offsets
+        ctx, db = self._dev()
+        F = db.n_feat
+        counts = [len(a) for a in atoms_list]
+        offsets = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+        x_e = np.empty((len(atoms_list), F)) if energy else None
+        x_f = np.empty((int(offsets[-1]), 3, F)) if forces else None
+        per_atom = 24 * F if forces else 0
+        start = 0
+        while start < len(atoms_list):
+            stop, nbytes = start, 0
+            while stop < len(atoms_list) and (stop == start or nbytes + counts[stop] * per_atom <= max_bytes):
+                nbytes += counts[stop] * per_atom
+                stop += 1
+            batch = _lib.FrameBatch(atoms_list[start:stop], periodic=periodic)
+            xe_c = x_e[start:stop] if energy else None
+            xf_c = x_f[offsets[start]:offsets[stop]] if forces else None
+            ctx.check(ctx.lib.uf3_featurize(db.handle, C.byref(batch.struct), _lib._p(batch.pos), _lib._p(batch.z),
+                                            _lib._p(xe_c), _lib._p(xf_c)))
+            start = stop
+        return x_e, x_f, offsets
 
     def featurize_device(self, frames_struct, d_pos, d_z, d_x_e=None, d_x_f=None):
         """Device-resident entry: raw HBM pointers (ints), asynchronous on the context stream."""
