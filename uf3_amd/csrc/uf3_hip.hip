@@ -60,6 +60,8 @@ struct uf3_basis {
     int *d_colsrc = nullptr;
     std::vector<int> block_bounds;   // column boundaries of interaction blocks (for column windows)
     size_t c2_len = 0, c3_len = 0, n_recs = 0;
+    size_t n_pair_recs = 0;
+    int modes = 1;                   // bit m set: some trio block is handled by featurizer specialisation m
     double r_cut = 0;
 };
 
@@ -242,6 +244,7 @@ extern "C" int uf3_basis_create(uf3_ctx *c, const uf3_basis_spec *s, uf3_basis *
         b->c2_len += (size_t)pd.nb;
         kp += nk;
     }
+    b->n_pair_recs = recs.size();
     std::vector<TrioDev> trios(h.T);
     const double *tp = s->trio_knots;
     double lo3 = 1e300, hi3 = -1e300;
@@ -303,6 +306,7 @@ extern "C" int uf3_basis_create(uf3_ctx *c, const uf3_basis_spec *s, uf3_basis *
         td.nsrc = mx <= 1 ? 1 : (mx <= 2 ? 2 : 6);
         if (mx > 6) { delete b; return fail(c, UF3_EINVAL, "a 3-body column is fed by more than 6 raw bins"); }
         td.src_off = (int)colsrc.size();
+        b->modes |= 1 << (td.nsrc == 1 ? (td.ncol > WAVE ? 2 : 1) : (td.nsrc == 2 ? (td.ncol > WAVE ? 4 : 3) : 5));
         for (auto &v : per_col) for (int k = 0; k < td.nsrc; k++) colsrc.push_back(k < (int)v.size() ? v[k] : -1);
     }
     std::sort(bounds.begin(), bounds.end());
@@ -580,12 +584,13 @@ static int prepare(uf3_basis *b, const uf3_frames *fr, const double *d_pos, cons
 }
 
 // ------------------------------------------------------------------------------ featurize
-static size_t feat_lds_bytes(int F, int cap, int cand_cap, bool want_e, size_t n_recs) {
+static size_t feat_lds_bytes(int F, int cap, int cand_cap, bool want_e, size_t n_recs, int mode) {
     size_t e_d = want_e ? (size_t)F + (F & 1) : 0;
     size_t cand_d = (size_t)cand_cap * 5 + ((cand_cap * 5) & 1);
-    size_t stage_d = std::max((size_t)NSTAGE * ITEM_STRIDE, cand_d + (size_t)NSTAGE * PAIR_STRIDE);
-    size_t per_wave_d = 4 * (size_t)cap + ((4 * cap) & 1) + stage_d;
-    size_t per_wave_i = 3 * (size_t)cap + 2 * ((size_t)cap + 1) + (UF3_MAX_SPECIES + 2);
+    size_t stage_d = mode == 0 ? cand_d + (size_t)NSTAGE * PAIR_STRIDE : (size_t)NSTAGE * ITEM_STRIDE;
+    size_t list_d = mode == 0 ? 0 : 4 * (size_t)cap + ((4 * cap) & 1);
+    size_t per_wave_d = list_d + stage_d + (stage_d & 1);
+    size_t per_wave_i = mode == 0 ? 0 : 3 * (size_t)cap + 2 * ((size_t)cap + 1) + (UF3_MAX_SPECIES + 2);
     size_t ints = ((size_t)WPB * per_wave_i + 3) & ~(size_t)3;
     return (e_d + WPB * per_wave_d) * 8 + ints * 4 + n_recs * sizeof(KnotRec) + 32;
 }
@@ -618,32 +623,50 @@ extern "C" int uf3_featurize_dev(uf3_basis *b, const uf3_frames *fr, const doubl
     for (int attempt = 0; attempt < 6; attempt++) {
         A.cand_cap = c->cand_cap;
         A.n_recs = (int)b->n_recs;
-        // knot records go to LDS when two blocks per CU still fit with them
-        size_t lds_plain = feat_lds_bytes(F, cap, A.cand_cap, want_e, 0);
-        size_t lds_recs = feat_lds_bytes(F, cap, A.cand_cap, want_e, b->n_recs);
-        bool recs_lds = lds_recs <= 80 * 1024 && !getenv("UF3_NO_LDS_RECS");
-        size_t lds = recs_lds ? lds_recs : lds_plain;
-        if (lds > 160 * 1024 - 512) return fail(c, UF3_EOVERFLOW, "featurizer LDS footprint exceeds 160 KB (F or neighbour count too large)");
+        A.n_pair_recs = (int)b->n_pair_recs;
         if (want_e) HIPCHK(c, hipMemsetAsync(d_xe, 0, sizeof(double) * (size_t)P.n_frames * F, st));
         HIPCHK(c, hipMemsetAsync(A.cand_need, 0, sizeof(int), st));
-        // blocks of WPB waves; enough blocks to fill every CU several times over, each block walking a
-        // contiguous run of atoms (keeps the shared energy row on one frame)
-        int per_cu = std::max(1, std::min(8, (int)((size_t)(160 * 1024) / lds)));
-        int n_blocks = std::min((P.natoms + WPB - 1) / WPB, c->n_cu * per_cu * 2);
-        int apb = ((P.natoms + n_blocks - 1) / n_blocks + WPB - 1) / WPB * WPB;
-        n_blocks = (P.natoms + apb - 1) / apb;
-        A.atoms_per_block = apb;
         {
             Timed tm(c, T_FEAT);
-#define UF3_LAUNCH(E, Fo, R)                                                                                         \
+            for (int mode = 0; mode <= 5; mode++) {
+                if (!(b->modes & (1 << mode))) continue;
+                // knot records go to LDS when the block then still reaches the occupancy its registers allow
+                size_t n_rec_mode = mode == 0 ? b->n_pair_recs : b->n_recs;
+                size_t lds_plain = feat_lds_bytes(F, cap, A.cand_cap, want_e, 0, mode);
+                size_t lds_recs = feat_lds_bytes(F, cap, A.cand_cap, want_e, n_rec_mode, mode);
+                const size_t lds_target = (size_t)(160 * 1024 - 1024) / (mode == 0 ? 4 : 2);
+                bool recs_lds = lds_recs <= lds_target && !getenv("UF3_NO_LDS_RECS");
+                size_t lds = recs_lds ? lds_recs : lds_plain;
+                if (lds > 160 * 1024 - 512) return fail(c, UF3_EOVERFLOW, "featurizer LDS footprint exceeds 160 KB (F or neighbour count too large)");
+                // blocks of WPB waves, each walking a contiguous run of atoms (keeps the shared energy row on
+                // one frame); about two blocks per resident slot for tail balance
+                int per_cu = std::max(1, std::min(8, (int)((size_t)(160 * 1024) / lds)));
+                int n_blocks = std::min((P.natoms + WPB - 1) / WPB, c->n_cu * per_cu * 2);
+                int apb = ((P.natoms + n_blocks - 1) / n_blocks + WPB - 1) / WPB * WPB;
+                n_blocks = (P.natoms + apb - 1) / apb;
+                A.atoms_per_block = apb;
+#define UF3_LAUNCH1(E, Fo, R, M)                                                                                      \
     do {                                                                                                            \
-        HIPCHK(c, hipFuncSetAttribute((const void *)k_featurize<E, Fo, R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        hipLaunchKernelGGL((k_featurize<E, Fo, R>), dim3(n_blocks), dim3(WPB * WAVE), lds, st, A);                   \
+        HIPCHK(c, hipFuncSetAttribute((const void *)k_featurize<E, Fo, R, M>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL((k_featurize<E, Fo, R, M>), dim3(n_blocks), dim3(WPB * WAVE), lds, st, A);                \
     } while (0)
-            if (want_e && want_f) { if (recs_lds) UF3_LAUNCH(true, true, true); else UF3_LAUNCH(true, true, false); }
-            else if (want_f) { if (recs_lds) UF3_LAUNCH(false, true, true); else UF3_LAUNCH(false, true, false); }
-            else { if (recs_lds) UF3_LAUNCH(true, false, true); else UF3_LAUNCH(true, false, false); }
+#define UF3_LAUNCH(M)                                                                                               \
+    do {                                                                                                            \
+        if (want_e && want_f) { if (recs_lds) UF3_LAUNCH1(true, true, true, M); else UF3_LAUNCH1(true, true, false, M); }      \
+        else if (want_f) { if (recs_lds) UF3_LAUNCH1(false, true, true, M); else UF3_LAUNCH1(false, true, false, M); }       \
+        else { if (recs_lds) UF3_LAUNCH1(true, false, true, M); else UF3_LAUNCH1(true, false, false, M); }                  \
+    } while (0)
+                switch (mode) {
+                    case 0: UF3_LAUNCH(0); break;
+                    case 1: UF3_LAUNCH(1); break;
+                    case 2: UF3_LAUNCH(2); break;
+                    case 3: UF3_LAUNCH(3); break;
+                    case 4: UF3_LAUNCH(4); break;
+                    default: UF3_LAUNCH(5); break;
+                }
 #undef UF3_LAUNCH
+#undef UF3_LAUNCH1
+            }
         }
         HIPCHK(c, hipGetLastError());
         int need = 0;

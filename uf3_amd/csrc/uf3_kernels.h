@@ -205,6 +205,7 @@ struct FeatArgs {
     int natoms, atoms_per_block;
     int cand_cap;       // 2-body candidates staged per atom
     int n_recs;         // KnotRec count (for the LDS copy)
+    int n_pair_recs;    // ... of which belong to the pair blocks (they come first)
     int skip;           // profiling ablations (UF3_DEBUG_SKIP): 1 two-body, 2 centre role, 4 neighbour role
 };
 
@@ -554,7 +555,15 @@ __device__ __forceinline__ void zero_rows(double *x_f, int m, int F, int col, in
     }
 }
 
-template <bool WANT_E, bool WANT_F, bool RECS_LDS>
+// MODE selects the column blocks a launch is responsible for, so that each specialisation carries only the
+// registers of its own path: 0 = one-body + pair blocks; 1..5 = trio blocks whose (nsrc, 64-column chunks
+// per walk) is (1,1), (1,2), (2,1), (2,2), (6,1).  Every block is written by exactly one launch.
+__device__ __forceinline__ int trio_mode(const TrioDev *td) {
+    const bool wide = td->ncol > WAVE;
+    return td->nsrc == 1 ? (wide ? 2 : 1) : (td->nsrc == 2 ? (wide ? 4 : 3) : 5);
+}
+
+template <bool WANT_E, bool WANT_F, bool RECS_LDS, int MODE>
 __global__ void __launch_bounds__(WPB * WAVE)
 k_featurize(FeatArgs A) {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -563,33 +572,34 @@ k_featurize(FeatArgs A) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     double *erow = (double *)smem;                                         // [F] shared by the block (WANT_E)
     const size_t e_d = WANT_E ? (size_t)F + (F & 1) : 0;
-    // the stage buffer holds triplet records in the 3-body phase and, in the 2-body phase, the candidate
-    // list followed by the pair records
+    // LDS carve (must match feat_lds_bytes on the host).  MODE 0 (pairs): candidate list + pair records, pair
+    // knot records only; trio modes: own neighbour list + triplet records, all knot records.
     const size_t cand_d = (size_t)A.cand_cap * 5 + ((A.cand_cap * 5) & 1);
-    const size_t stage_d = max((size_t)NSTAGE * ITEM_STRIDE, cand_d + (size_t)NSTAGE * PAIR_STRIDE);
-    const size_t per_wave_d = 4 * (size_t)cap + ((4 * cap) & 1) + stage_d;
-    const size_t per_wave_i = 3 * (size_t)cap + 2 * ((size_t)cap + 1) + (UF3_MAX_SPECIES + 2);
+    const size_t stage_d = MODE == 0 ? cand_d + (size_t)NSTAGE * PAIR_STRIDE : (size_t)NSTAGE * ITEM_STRIDE;
+    const size_t list_d = MODE == 0 ? 0 : 4 * (size_t)cap + ((4 * cap) & 1);
+    const size_t per_wave_d = list_d + stage_d + (stage_d & 1);
+    const size_t per_wave_i = MODE == 0 ? 0 : 3 * (size_t)cap + 2 * ((size_t)cap + 1) + (UF3_MAX_SPECIES + 2);
     double *wd = erow + e_d + (size_t)wave * per_wave_d;
     int *wi = (int *)(erow + e_d + (size_t)WPB * per_wave_d) + (size_t)wave * per_wave_i;
     WaveLds w;
     w.ox = wd; w.oy = w.ox + cap; w.oz = w.oy + cap; w.orr = w.oz + cap;
-    w.stage = w.orr + cap + ((4 * cap) & 1);
+    w.stage = wd + list_d;
     w.cand = w.stage;
     w.pstage = w.stage + cand_d;
     w.oparent = wi; w.oshift = wi + cap; w.osidx = wi + 2 * cap;
     w.noff = wi + 3 * cap; w.nbase = w.noff + cap + 1; w.so = w.nbase + cap + 1;
 
-    // knot-interval records (de Boor-Cox coefficients) of every pair / trio leg: staged in LDS when they fit
-    KnotRec *recs_lds = (KnotRec *)(wi + (size_t)(WPB - wave) * per_wave_i + (((size_t)WPB * per_wave_i) & 1) * 0);
+    // knot-interval records (de Boor-Cox coefficients): staged in LDS when they fit
+    KnotRec *recs_lds;
     {
-        size_t ints_total = (size_t)WPB * per_wave_i;
-        ints_total = (ints_total + 3) & ~(size_t)3;                        // 16-B alignment
+        size_t ints_total = ((size_t)WPB * per_wave_i + 3) & ~(size_t)3;   // 16-B alignment
         recs_lds = (KnotRec *)((int *)(erow + e_d + (size_t)WPB * per_wave_d) + ints_total);
     }
     if (RECS_LDS) {
+        const int n_copy = MODE == 0 ? A.n_pair_recs : A.n_recs;            // pair records come first
         const double *srcp = (const double *)A.recs;
         double *dstp = (double *)recs_lds;
-        for (int q = tid; q < A.n_recs * 12; q += WPB * WAVE) dstp[q] = srcp[q];
+        for (int q = tid; q < n_copy * 12; q += WPB * WAVE) dstp[q] = srcp[q];
     }
     const KnotRec *recs = RECS_LDS ? recs_lds : A.recs;
     if (WANT_E) { for (int q = tid; q < F; q += WPB * WAVE) erow[q] = 0.0; }
@@ -621,10 +631,10 @@ k_featurize(FeatArgs A) {
         ESink es;
         es.lds = erow; es.glob = WANT_E ? A.x_e + (size_t)fr * F : nullptr; es.direct = (fr != erow_frame);
         // ---- 1-body columns ------------------------------------------------------------------
-        if (WANT_F) zero_rows(A.x_f, m, F, 0, S);
-        if (WANT_E && lane == 0) es.add(sm, 1.0);
+        if (MODE == 0 && WANT_F) zero_rows(A.x_f, m, F, 0, S);
+        if (MODE == 0 && WANT_E && lane == 0) es.add(sm, 1.0);
         // ---- 2-body: neighbour images -> LDS once, then one pass per pair block ------------------
-        {
+        if (MODE == 0) {
             int n_cand = 0;
             if (!(A.skip & 1)) for_each_candidate(g, A.cl, m, [&](bool ok, int slot, int s0, int s1, int s2) {
                 double dx = 0, dy = 0, dz = 0, d = 0;
@@ -656,7 +666,7 @@ k_featurize(FeatArgs A) {
             }
         }
         // ---- 3-body ---------------------------------------------------------------------------
-        if (B->T > 0) {
+        if (MODE != 0 && B->T > 0) {
             const int n = A.n3.cnt[m];
             size_t base = (size_t)m * cap;
             wave_sync();
@@ -669,11 +679,13 @@ k_featurize(FeatArgs A) {
             wave_sync();
             for (int t = 0; t < B->T; t++) {
                 const TrioDev *td = A.trios + t;
+                if (trio_mode(td) != MODE) continue;
                 const bool touches = (td->sc == sm) || (WANT_F && (td->sa == sm || td->sb == sm));
                 if (!touches) { if (WANT_F) zero_rows(A.x_f, m, F, td->col, td->ncol); continue; }
-                const bool wide = td->ncol > WAVE;      // two 64-column chunks per walk over the triplets
-                if (td->nsrc == 1) { if (wide) trio_block<WANT_E, WANT_F, 1, 2>(A, B, recs, g, w, m, sm, t, es); else trio_block<WANT_E, WANT_F, 1, 1>(A, B, recs, g, w, m, sm, t, es); }
-                else if (td->nsrc == 2) { if (wide) trio_block<WANT_E, WANT_F, 2, 2>(A, B, recs, g, w, m, sm, t, es); else trio_block<WANT_E, WANT_F, 2, 1>(A, B, recs, g, w, m, sm, t, es); }
+                if (MODE == 1) trio_block<WANT_E, WANT_F, 1, 1>(A, B, recs, g, w, m, sm, t, es);
+                else if (MODE == 2) trio_block<WANT_E, WANT_F, 1, 2>(A, B, recs, g, w, m, sm, t, es);
+                else if (MODE == 3) trio_block<WANT_E, WANT_F, 2, 1>(A, B, recs, g, w, m, sm, t, es);
+                else if (MODE == 4) trio_block<WANT_E, WANT_F, 2, 2>(A, B, recs, g, w, m, sm, t, es);
                 else trio_block<WANT_E, WANT_F, 6, 1>(A, B, recs, g, w, m, sm, t, es);
             }
         }
