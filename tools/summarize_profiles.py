@@ -1,0 +1,107 @@
+"""Condense rocprofv3 CSV output (gpurun_out/<run>/...) into the small summaries kept under profiles/.
+
+    python tools/summarize_profiles.py gpurun_out/r1c profiles/round1
+
+Reads   <run>/trace/*_kernel_stats.csv           (rocprofv3 --kernel-trace --stats --output-format csv)
+        <run>/pmc_fetch, <run>/pmc_write         (--pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes)
+        <run>/pmc1, <run>/pmc2                   (two passes of SQ counters)
+        <run>/bench_default.json, <run>/kernels.json
+Writes  <prefix>_kernel_stats.csv, <prefix>_hbm_counters.json, <prefix>_sq_counters.txt,
+        <prefix>_bench_n1.json, <prefix>_secondary_kernels.json
+Counters are summed over the k_featurize<...> specialisations of one step (one "launch group") and
+averaged over the steps seen.
+"""
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+from collections import defaultdict
+
+
+def counter_rows(directory):
+    for path in glob.glob(os.path.join(directory, "*_counter_collection.csv")):
+        with open(path, newline="") as fh:
+            yield from csv.DictReader(fh)
+
+
+def featurize_counters(directory):
+    """{counter: {kernel name: [values per dispatch]}} for the featurizer kernels"""
+    out = defaultdict(lambda: defaultdict(list))
+    for row in counter_rows(directory):
+        name = row["Kernel_Name"]
+        if "k_featurize" in name:
+            out[row["Counter_Name"]][name].append(float(row["Counter_Value"]))
+    return out
+
+
+def group_mean(per_kernel):
+    """mean over steps of the sum over the specialisations launched in one step"""
+    return sum(sum(v) / len(v) for v in per_kernel.values())
+
+
+def main(run, prefix):
+    stats = glob.glob(os.path.join(run, "trace", "*_kernel_stats.csv"))[0]
+    shutil.copy(stats, prefix + "_kernel_stats.csv")
+    shutil.copy(os.path.join(run, "bench_default.json"), prefix + "_bench_n1.json")
+    if os.path.exists(os.path.join(run, "kernels.json")):
+        shutil.copy(os.path.join(run, "kernels.json"), prefix + "_secondary_kernels.json")
+
+    with open(stats, newline="") as fh:
+        feat = [r for r in csv.DictReader(fh) if "k_featurize" in r["Name"]]
+    rocprof_group_ms = sum(float(r["AverageNs"]) for r in feat) / 1e6
+    bench = json.load(open(os.path.join(run, "bench_default.json")))
+
+    fetch = featurize_counters(os.path.join(run, "pmc_fetch"))["FETCH_SIZE"]
+    write = featurize_counters(os.path.join(run, "pmc_write"))["WRITE_SIZE"]
+    fetch_kib, write_kib = group_mean(fetch), group_mean(write)
+    hbm = {
+        "command": "python bench.py --steps 3 --warmup 1 --no-cpu-baseline (8 frames x 10k atoms per step, F=434)",
+        "tool": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --output-format csv)",
+        "kernel": "k_featurize<E,F,R,MODE>: the specialised launches of one step, summed",
+        "per_specialisation_KiB": {
+            "FETCH_SIZE": {k: sum(v) / len(v) for k, v in fetch.items()},
+            "WRITE_SIZE": {k: sum(v) / len(v) for k, v in write.items()},
+        },
+        "FETCH_SIZE_KiB_per_launch": fetch_kib,
+        "WRITE_SIZE_KiB_per_launch": write_kib,
+        "hbm_bytes_per_launch_raw": (fetch_kib + write_kib) * 1024,
+        "hbm_bytes_per_launch_fetch_x2": (2 * fetch_kib + write_kib) * 1024,
+        "algorithmic_bytes_per_launch": bench["roofline"]["algorithmic_bytes_per_launch"],
+        "kernel_time_agreement": {
+            "hip_events_ms_per_step (bench.py, live)": bench["roofline"]["launch_ms"],
+            "rocprofv3_kernel_stats_sum_of_averages_ms": rocprof_group_ms,
+            "per_specialisation_ms": {r["Name"]: float(r["AverageNs"]) / 1e6 for r in feat},
+        },
+        "note": "MI355X_MICROARCH.md: on gfx950 FETCH_SIZE can report 1/2 of the bytes of a wide coalesced "
+                "streaming read; the reads here are mostly 48-B gathers of neighbour-list entries, so the "
+                "uncorrected sum is quoted as `traffic` and the x2-corrected sum as the upper bound. Every "
+                "specialisation reads the neighbour lists again, and the trio specialisations read-modify-"
+                "write nothing: rows are written once per (atom, column range).",
+        "workload": {"atoms_per_frame": 10000, "n_feat": 434, "frames_per_step": 8},
+    }
+    json.dump(hbm, open(prefix + "_hbm_counters.json", "w"), indent=1)
+
+    lines = ["# rocprofv3 --pmc (two passes of 8 SQ counters), 8 frames x 10k atoms per step (F=434)",
+             "# SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles summed over waves; "
+             "SQ_INSTS_* count wave-instructions", ""]
+    sq = {}
+    for d in ("pmc1", "pmc2"):
+        sq.update(featurize_counters(os.path.join(run, d)))
+    kernels = sorted({k for per in sq.values() for k in per})
+    for kern in kernels + ["ALL k_featurize launches of one step"]:
+        lines.append("## " + kern)
+        for name in sorted(sq):
+            per = sq[name]
+            val = group_mean(per) if kern.startswith("ALL") else (
+                sum(per[kern]) / len(per[kern]) if kern in per else float("nan"))
+            lines.append(f"{name:<24} {val:.4g}")
+        lines.append("")
+    open(prefix + "_sq_counters.txt", "w").write("\n".join(lines))
+    print(json.dumps({"rocprof_group_ms": rocprof_group_ms, "hip_events_ms": bench["roofline"]["launch_ms"],
+                      "traffic_raw": hbm["hbm_bytes_per_launch_raw"]}))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2])

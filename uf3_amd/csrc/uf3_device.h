@@ -40,6 +40,9 @@ struct TrioDev {
     int dim_l;
     int sc, sa, sb;    // species indices: centre, neighbours sa <= sb
     int nsrc, src_off; // symmetry images per column (1, 2, 6) and offset into the colsrc table
+    // dense accumulation window = bounding box of the raw bins that feed a column.  dense != 0: the box is
+    // small enough (3 * ext[0] * ext[1] <= 32 rows, ext[2] <= 16) for the MFMA specialisation of the featurizer
+    int dense, lo[3], ext[3];
 };
 
 struct BasisDev {

@@ -58,9 +58,12 @@ struct uf3_basis {
     KnotRec *d_recs = nullptr;
     int *d_lut = nullptr;
     int *d_colsrc = nullptr;
+    int *d_dsrc = nullptr;           // colsrc as offsets into the dumped dense window (MFMA specialisation)
+    size_t n_dsrc = 0;
     std::vector<int> block_bounds;   // column boundaries of interaction blocks (for column windows)
     size_t c2_len = 0, c3_len = 0, n_recs = 0;
     size_t n_pair_recs = 0;
+    int dense_stage = DENSE_DUMP;    // per-wave LDS stage (doubles) of the MFMA featurizer specialisation
     int modes = 1;                   // bit m set: some trio block is handled by featurizer specialisation m
     double r_cut = 0;
 };
@@ -179,12 +182,14 @@ extern "C" int uf3_ctx_timing_read(uf3_ctx *c, double *feat_ms, int64_t *feat_la
 }
 
 // ------------------------------------------------------------------------------ basis
-static void fill_leg(LegDev &leg, const double *t, int nk, int rec_off, std::vector<KnotRec> &recs) {
-    leg.rec_off = rec_off;
+// Interval records of one knot sequence; identical sequences (common: the same settings on every pair / trio)
+// share one run of the table, which keeps it small enough to live in LDS.
+static void fill_leg(LegDev &leg, const double *t, int nk, std::vector<KnotRec> &recs) {
     leg.nk = nk;
     leg.t0 = t[0];
     leg.tlast = t[nk - 1];
     leg.inv_h = (leg.tlast > leg.t0) ? (double)(nk - 7) / (leg.tlast - leg.t0) : 0.0;
+    std::vector<KnotRec> mine;
     for (int i = 0; i < nk - 1; i++) {
         KnotRec r;
         std::memset(&r, 0, sizeof(r));
@@ -195,8 +200,12 @@ static void fill_leg(LegDev &leg, const double *t, int nk, int rec_off, std::vec
             r.r[1] = rc(t[i + 1] - t[i - 1]); r.r[2] = rc(t[i + 2] - t[i]);
             r.r[3] = rc(t[i + 1] - t[i - 2]); r.r[4] = rc(t[i + 2] - t[i - 1]); r.r[5] = rc(t[i + 3] - t[i]);
         }
-        recs.push_back(r);
+        mine.push_back(r);
     }
+    for (size_t off = 0; off + mine.size() <= recs.size(); off++)
+        if (std::memcmp(&recs[off], mine.data(), sizeof(KnotRec) * mine.size()) == 0) { leg.rec_off = (int)off; return; }
+    leg.rec_off = (int)recs.size();
+    recs.insert(recs.end(), mine.begin(), mine.end());
 }
 
 extern "C" int uf3_basis_create(uf3_ctx *c, const uf3_basis_spec *s, uf3_basis **out) {
@@ -233,7 +242,7 @@ extern "C" int uf3_basis_create(uf3_ctx *c, const uf3_basis_spec *s, uf3_basis *
         if (a < 0 || bb < 0 || nk < 8) { delete b; return fail(c, UF3_EINVAL, "bad pair block"); }
         h.pair_of[a * UF3_MAX_SPECIES + bb] = h.pair_of[bb * UF3_MAX_SPECIES + a] = (short)p;
         PairDev &pd = h.pairs[p];
-        fill_leg(pd.leg, kp, nk, (int)recs.size(), recs);
+        fill_leg(pd.leg, kp, nk, recs);
         pd.col = s->pair_col[p];
         pd.nb = nk - 4;
         pd.sa = std::min(a, bb); pd.sb = std::max(a, bb);
@@ -259,7 +268,7 @@ extern "C" int uf3_basis_create(uf3_ctx *c, const uf3_basis_spec *s, uf3_basis *
         for (int d = 0; d < 3; d++) {
             int nk = s->trio_nk[3 * t + d];
             if (nk < 8) { delete b; return fail(c, UF3_EINVAL, "trio knot vector too short"); }
-            fill_leg(td.leg[d], tp, nk, (int)recs.size(), recs);
+            fill_leg(td.leg[d], tp, nk, recs);
             for (int q = 0; q < nk; q++) {
                 lo3 = std::min(lo3, tp[q]);
                 if (d < 2) hi3 = std::max(hi3, tp[q]);     // angles.py:322-325: centre legs only
@@ -289,7 +298,7 @@ extern "C" int uf3_basis_create(uf3_ctx *c, const uf3_basis_spec *s, uf3_basis *
         }
     }
     // per column: the distinct raw bins (symmetry images) that feed it, for the output-stationary kernel
-    std::vector<int> colsrc;
+    std::vector<int> colsrc, dsrc;
     for (int t = 0; t < h.T; t++) {
         TrioDev &td = trios[t];
         if (td.dim_l > 255 || td.dim_m > 255 || td.dim_n > 255) { delete b; return fail(c, UF3_EINVAL, "3-body grid dimension > 255"); }
@@ -306,8 +315,26 @@ extern "C" int uf3_basis_create(uf3_ctx *c, const uf3_basis_spec *s, uf3_basis *
         td.nsrc = mx <= 1 ? 1 : (mx <= 2 ? 2 : 6);
         if (mx > 6) { delete b; return fail(c, UF3_EINVAL, "a 3-body column is fed by more than 6 raw bins"); }
         td.src_off = (int)colsrc.size();
-        b->modes |= 1 << (td.nsrc == 1 ? (td.ncol > WAVE ? 2 : 1) : (td.nsrc == 2 ? (td.ncol > WAVE ? 4 : 3) : 5));
-        for (auto &v : per_col) for (int k = 0; k < td.nsrc; k++) colsrc.push_back(k < (int)v.size() ? v[k] : -1);
+        // bounding box of the feeding raw bins; small boxes go to the MFMA specialisation (mode 6)
+        int lo[3] = {1 << 20, 1 << 20, 1 << 20}, hi[3] = {-1, -1, -1};
+        for (auto &v : per_col) for (int sp : v) {
+            int idx[3] = {sp & 255, (sp >> 8) & 255, (sp >> 16) & 255};
+            for (int a = 0; a < 3; a++) { lo[a] = std::min(lo[a], idx[a]); hi[a] = std::max(hi[a], idx[a]); }
+        }
+        td.dense = 0;
+        for (int a = 0; a < 3; a++) { td.lo[a] = hi[a] < 0 ? 0 : lo[a]; td.ext[a] = hi[a] < 0 ? 1 : hi[a] - lo[a] + 1; }
+        if (3 * td.ext[0] * td.ext[1] <= 32 && td.ext[2] <= 16 && !getenv("UF3_NO_MFMA_FEAT")) {
+            td.dense = 1;
+            DenseLayout dl = dense_layout(td.ext[0], td.ext[1], td.ext[2]);
+            b->dense_stage = std::max(b->dense_stage, std::max(DENSE_DUMP, dl.nstage * dl.stride));
+        }
+        b->modes |= 1 << (td.dense ? 6 : td.nsrc == 1 ? (td.ncol > WAVE ? 2 : 1) : (td.nsrc == 2 ? (td.ncol > WAVE ? 4 : 3) : 5));
+        for (auto &v : per_col) for (int k = 0; k < td.nsrc; k++) {
+            int sp = k < (int)v.size() ? v[k] : -1;
+            colsrc.push_back(sp);
+            dsrc.push_back(sp < 0 || !td.dense ? -1
+                           : (((sp & 255) - td.lo[0]) * td.ext[1] + (((sp >> 8) & 255) - td.lo[1])) * 16 + (((sp >> 16) & 255) - td.lo[2]));
+        }
     }
     std::sort(bounds.begin(), bounds.end());
     bounds.erase(std::unique(bounds.begin(), bounds.end()), bounds.end());
@@ -321,6 +348,9 @@ extern "C" int uf3_basis_create(uf3_ctx *c, const uf3_basis_spec *s, uf3_basis *
     HIPCHK(c, hipMemcpy(b->d_lut, lut.data(), sizeof(int) * lut.size(), hipMemcpyHostToDevice));
     HIPCHK(c, hipMalloc(&b->d_colsrc, sizeof(int) * std::max<size_t>(1, colsrc.size())));
     if (!colsrc.empty()) HIPCHK(c, hipMemcpy(b->d_colsrc, colsrc.data(), sizeof(int) * colsrc.size(), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMalloc(&b->d_dsrc, sizeof(int) * std::max<size_t>(1, dsrc.size())));
+    if (!dsrc.empty()) HIPCHK(c, hipMemcpy(b->d_dsrc, dsrc.data(), sizeof(int) * dsrc.size(), hipMemcpyHostToDevice));
+    b->n_dsrc = dsrc.size();
     HIPCHK(c, hipMalloc(&b->d_trios, sizeof(TrioDev) * std::max<size_t>(1, trios.size())));
     if (!trios.empty())
         HIPCHK(c, hipMemcpy(b->d_trios, trios.data(), sizeof(TrioDev) * trios.size(), hipMemcpyHostToDevice));
@@ -335,7 +365,7 @@ extern "C" void uf3_basis_destroy(uf3_basis *b) {
     if (!b) return;
     hipSetDevice(b->ctx->device);
     hipStreamSynchronize(b->ctx->stream);
-    hipFree(b->dev); hipFree(b->d_trios); hipFree(b->d_recs); hipFree(b->d_lut); hipFree(b->d_colsrc);
+    hipFree(b->dev); hipFree(b->d_trios); hipFree(b->d_recs); hipFree(b->d_lut); hipFree(b->d_colsrc); hipFree(b->d_dsrc);
     delete b;
 }
 
@@ -584,13 +614,17 @@ static int prepare(uf3_basis *b, const uf3_frames *fr, const double *d_pos, cons
 }
 
 // ------------------------------------------------------------------------------ featurize
-static size_t feat_lds_bytes(int F, int cap, int cand_cap, bool want_e, size_t n_recs, int mode) {
+static int ensure_frag(uf3_ctx *c);
+
+static size_t feat_lds_bytes(int F, int cap, int cand_cap, bool want_e, size_t n_recs, int mode, int dense_stage) {
     size_t e_d = want_e ? (size_t)F + (F & 1) : 0;
     size_t cand_d = (size_t)cand_cap * 5 + ((cand_cap * 5) & 1);
-    size_t stage_d = mode == 0 ? cand_d + (size_t)NSTAGE * PAIR_STRIDE : (size_t)NSTAGE * ITEM_STRIDE;
+    size_t stage_d = mode == 0 ? cand_d + (size_t)NSTAGE * PAIR_STRIDE
+                     : (mode == 6 ? (size_t)dense_stage : (size_t)NSTAGE * ITEM_STRIDE);
     size_t list_d = mode == 0 ? 0 : 4 * (size_t)cap + ((4 * cap) & 1);
     size_t per_wave_d = list_d + stage_d + (stage_d & 1);
-    size_t per_wave_i = mode == 0 ? 0 : 3 * (size_t)cap + 2 * ((size_t)cap + 1) + (UF3_MAX_SPECIES + 2);
+    size_t per_wave_i = mode == 0 ? 0 : 3 * (size_t)cap + 2 * ((size_t)cap + 1) + (UF3_MAX_SPECIES + 2) +
+                                        (size_t)cap * (UF3_MAX_SPECIES + 1);
     size_t ints = ((size_t)WPB * per_wave_i + 3) & ~(size_t)3;
     return (e_d + WPB * per_wave_d) * 8 + ints * 4 + n_recs * sizeof(KnotRec) + 32;
 }
@@ -615,6 +649,11 @@ extern "C" int uf3_featurize_dev(uf3_basis *b, const uf3_frames *fr, const doubl
     }
     FeatArgs A;
     A.B = b->dev; A.trios = b->d_trios; A.recs = b->d_recs; A.colsrc = b->d_colsrc;
+    A.frag = nullptr;
+    A.dense_stage = b->dense_stage;
+    A.dsrc = b->d_dsrc; A.n_dsrc = (int)b->n_dsrc;
+    A.dsrc_lds = (b->modes & (1 << 6)) && b->n_dsrc * sizeof(int) <= 8192;
+    if (b->modes & (1 << 6)) { rc = ensure_frag(c); if (rc) return rc; A.frag = c->frag.as<int>(); }
     A.geoms = P.geoms; A.frame_of = P.frame_of; A.cl = P.cl; A.n3 = P.n3;
     if (!A.n3.cap) A.n3.cap = 1;
     A.pos = d_pos; A.spec = P.spec; A.x_e = d_xe; A.x_f = d_xf; A.natoms = P.natoms;
@@ -628,12 +667,13 @@ extern "C" int uf3_featurize_dev(uf3_basis *b, const uf3_frames *fr, const doubl
         HIPCHK(c, hipMemsetAsync(A.cand_need, 0, sizeof(int), st));
         {
             Timed tm(c, T_FEAT);
-            for (int mode = 0; mode <= 5; mode++) {
+            for (int mode = 0; mode <= 6; mode++) {
                 if (!(b->modes & (1 << mode))) continue;
                 // knot records go to LDS when the block then still reaches the occupancy its registers allow
                 size_t n_rec_mode = mode == 0 ? b->n_pair_recs : b->n_recs;
-                size_t lds_plain = feat_lds_bytes(F, cap, A.cand_cap, want_e, 0, mode);
-                size_t lds_recs = feat_lds_bytes(F, cap, A.cand_cap, want_e, n_rec_mode, mode);
+                size_t lds_extra = (mode == 6 && A.dsrc_lds) ? sizeof(int) * b->n_dsrc : 0;
+                size_t lds_plain = feat_lds_bytes(F, cap, A.cand_cap, want_e, 0, mode, A.dense_stage) + lds_extra;
+                size_t lds_recs = feat_lds_bytes(F, cap, A.cand_cap, want_e, n_rec_mode, mode, A.dense_stage) + lds_extra;
                 const size_t lds_target = (size_t)(160 * 1024 - 1024) / (mode == 0 ? 4 : 2);
                 bool recs_lds = lds_recs <= lds_target && !getenv("UF3_NO_LDS_RECS");
                 size_t lds = recs_lds ? lds_recs : lds_plain;
@@ -645,6 +685,10 @@ extern "C" int uf3_featurize_dev(uf3_basis *b, const uf3_frames *fr, const doubl
                 int apb = ((P.natoms + n_blocks - 1) / n_blocks + WPB - 1) / WPB * WPB;
                 n_blocks = (P.natoms + apb - 1) / apb;
                 A.atoms_per_block = apb;
+                if (getenv("UF3_DEBUG_LDS"))
+                    fprintf(stderr, "uf3 featurize mode %d: lds %zu B (plain %zu, with recs %zu), recs_lds %d, cap %d, cand_cap %d, "
+                            "blocks %d x %d atoms, n_recs %zu\n", mode, lds, lds_plain, lds_recs, (int)recs_lds, cap, A.cand_cap,
+                            n_blocks, apb, n_rec_mode);
 #define UF3_LAUNCH1(E, Fo, R, M)                                                                                      \
     do {                                                                                                            \
         HIPCHK(c, hipFuncSetAttribute((const void *)k_featurize<E, Fo, R, M>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
@@ -662,7 +706,8 @@ extern "C" int uf3_featurize_dev(uf3_basis *b, const uf3_frames *fr, const doubl
                     case 2: UF3_LAUNCH(2); break;
                     case 3: UF3_LAUNCH(3); break;
                     case 4: UF3_LAUNCH(4); break;
-                    default: UF3_LAUNCH(5); break;
+                    case 5: UF3_LAUNCH(5); break;
+                    default: UF3_LAUNCH(6); break;
                 }
 #undef UF3_LAUNCH
 #undef UF3_LAUNCH1

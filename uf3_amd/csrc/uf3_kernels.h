@@ -193,6 +193,9 @@ struct FeatArgs {
     const TrioDev *trios;     // explicit global pointers (no flat loads through the struct)
     const KnotRec *recs;
     const int *colsrc;        // per trio [ncol][nsrc] packed (l | m<<8 | n<<16) raw bins feeding a column, -1 pad
+    const int *frag;          // v_mfma_f64_16x16x4 accumulator layout: [lane][4] -> (row, col), from k_mfma_probe
+    const int *dsrc;          // dense trios: colsrc entries as offsets (pair * 16 + n bin) into the dumped window, -1 pad
+    int n_dsrc, dsrc_lds;     // table length; staged in LDS by the MFMA specialisation when dsrc_lds != 0
     const FrameGeom *geoms;
     const int *frame_of;
     CellList cl;
@@ -206,6 +209,7 @@ struct FeatArgs {
     int cand_cap;       // 2-body candidates staged per atom
     int n_recs;         // KnotRec count (for the LDS copy)
     int n_pair_recs;    // ... of which belong to the pair blocks (they come first)
+    int dense_stage;    // doubles of per-wave stage the MFMA specialisation needs (max over dense trios)
     int skip;           // profiling ablations (UF3_DEBUG_SKIP): 1 two-body, 2 centre role, 4 neighbour role
 };
 
@@ -354,50 +358,126 @@ struct WaveLds {
     int *oparent, *oshift, *osidx;
     int *noff, *nbase;                 // neighbour-role prefix [cap+1] / start index [cap]
     int *so;                           // species offsets in the own list [S+1]
+    int *ospoff;                       // species offsets of every own neighbour's list [cap][UF3_MAX_SPECIES+1]
     double *stage;                     // NSTAGE triplet / pair records
     double *cand;                      // 2-body candidates [cand_cap][5] (aliases stage)
     double *pstage;                    // pair records (behind the candidates, inside stage)
 };
+
+// Which triplets does atom m contribute to trio block td?  Items [0, cnt_c) are the triplets m centres (own
+// neighbours of species sa x sb); items [cnt_c, n_items) the triplets in which m is a neighbour of a centre of
+// species sc (one of m's own neighbours e), enumerated through that centre's list.
+struct TrioWalk {
+    int cnt_c, ra_lo, rb_lo, nb_;
+    int total_n, rc_lo, ncen, sx;
+    int n_items;
+};
+
+template <bool WANT_F>
+__device__ __forceinline__ void trio_walk_setup(const FeatArgs &A, const WaveLds &w, const TrioDev *td, int sm, TrioWalk &k) {
+    const int lane = lane_id();
+    const int sc = td->sc, sa = td->sa, sb = td->sb;
+    k.cnt_c = 0; k.ra_lo = 0; k.rb_lo = 0; k.nb_ = 1;
+    if (sm == sc && !(A.skip & 2)) {          // m is the centre: own neighbours of species sa x sb
+        k.ra_lo = w.so[sa]; k.rb_lo = w.so[sb];
+        int na = w.so[sa + 1] - k.ra_lo;
+        k.nb_ = w.so[sb + 1] - k.rb_lo;
+        k.cnt_c = (sa == sb) ? na * (na - 1) / 2 : na * k.nb_;
+        if (k.nb_ < 1) k.nb_ = 1;
+    }
+    k.total_n = 0; k.rc_lo = 0; k.ncen = 0; k.sx = -1;
+    if (WANT_F && !(A.skip & 4)) {            // m is a neighbour of a centre of species sc
+        if (sm == sa) k.sx = sb; else if (sm == sb) k.sx = sa;
+        if (k.sx >= 0) {
+            k.rc_lo = w.so[sc];
+            k.ncen = w.so[sc + 1] - k.rc_lo;
+            for (int e0 = 0; e0 < k.ncen; e0 += WAVE) {           // exclusive scan of |N3_sx(centre e)|
+                int e = e0 + lane;
+                int cnt = 0, base = 0;
+                if (e < k.ncen) {
+                    const int *sp = w.ospoff + (size_t)(k.rc_lo + e) * (UF3_MAX_SPECIES + 1);
+                    base = sp[k.sx]; cnt = sp[k.sx + 1] - base;
+                }
+                int incl = cnt;
+                for (int sh = 1; sh < WAVE; sh <<= 1) { int o = __shfl_up(incl, sh); if (lane >= sh) incl += o; }
+                if (e < k.ncen) { w.noff[e] = k.total_n + incl - cnt; w.nbase[e] = base; }
+                k.total_n += __shfl(incl, WAVE - 1);
+            }
+            if (lane == 0) w.noff[k.ncen] = k.total_n;
+            wave_sync();
+        }
+    }
+    k.n_items = k.cnt_c + k.total_n;
+}
+
+// geometry of item p of the walk; false when the item is void (p out of range, or the third atom is m itself)
+template <bool WANT_F>
+__device__ __forceinline__ bool trio_walk_geom(const FeatArgs &A, const FrameGeom &g, const WaveLds &w, const TrioDev *td,
+                                               const TrioWalk &k, int m, int sm, int p, TripletGeom &tg) {
+    const int sa = td->sa, sb = td->sb, cap = A.n3.cap;
+    const int m_local = m - g.atom_lo;
+    bool valid = p < k.n_items;
+    tg.centre = p < k.cnt_c;
+    if (valid && tg.centre) {
+        int aa, bb;
+        if (sa == sb) {
+            bb = (int)((1.0f + sqrtf(1.0f + 8.0f * (float)p)) * 0.5f);
+            while (bb * (bb - 1) / 2 > p) --bb;
+            while ((bb + 1) * bb / 2 <= p) ++bb;
+            aa = p - bb * (bb - 1) / 2;
+            aa += k.ra_lo; bb += k.ra_lo;
+        } else { aa = k.ra_lo + p / k.nb_; bb = k.rb_lo + p % k.nb_; }
+        tg.rl = w.orr[aa]; tg.rm = w.orr[bb];
+        double ex = w.ox[bb] - w.ox[aa], ey = w.oy[bb] - w.oy[aa], ez = w.oz[bb] - w.oz[aa];
+        tg.rn = norm3_rn(ex, ey, ez);
+        if (WANT_F) {
+            double il = 1.0 / tg.rl, im = 1.0 / tg.rm;
+            tg.a1[0] = w.ox[aa] * il; tg.a1[1] = w.oy[aa] * il; tg.a1[2] = w.oz[aa] * il;
+            tg.a2[0] = w.ox[bb] * im; tg.a2[1] = w.oy[bb] * im; tg.a2[2] = w.oz[bb] * im;
+            tg.a3[0] = tg.a3[1] = tg.a3[2] = 0.0;
+        }
+    } else if (valid) {
+        int q = p - k.cnt_c;
+        int lo = 0, hi = k.ncen - 1;                   // centre e with noff[e] <= q < noff[e+1]
+        while (lo < hi) { int mid = (lo + hi + 1) >> 1; if (w.noff[mid] <= q) lo = mid; else hi = mid - 1; }
+        int e = k.rc_lo + lo, kk = w.nbase[lo] + (q - w.noff[lo]);
+        int pc = w.oparent[e];
+        size_t kb = (size_t)pc * cap + kk;
+        int s0, s1, s2;
+        unpack3(w.oshift[e], s0, s1, s2);
+        const N3Entry ke = A.n3.ent[kb];
+        int kparent = ke.parent, kshift = ke.shiftc;
+        valid = !(kparent == m && kshift == pack3(-s0, -s1, -s2));       // k is m itself
+        if (valid) {
+            int ksidx = ke.sidx;
+            int msidx = supercell_index(g, -s0, -s1, -s2, m_local);      // m as numbered from c
+            double vx = ke.dx, vy = ke.dy, vz = ke.dz, rk = ke.r;
+            double ex = w.ox[e] + vx, ey = w.oy[e] + vy, ez = w.oz[e] + vz;   // m -> k
+            tg.rn = norm3_rn(ex, ey, ez);
+            bool m_first = neighbour_is_first(g, sm, k.sx, s0, s1, s2, m_local, msidx, ksidx, kshift,
+                                              kparent - g.atom_lo);
+            double ie = 1.0 / w.orr[e], in = 1.0 / tg.rn;
+            double ue[3] = {w.ox[e] * ie, w.oy[e] * ie, w.oz[e] * ie};
+            tg.a3[0] = ex * in; tg.a3[1] = ey * in; tg.a3[2] = ez * in;
+            if (m_first) {
+                tg.rl = w.orr[e]; tg.rm = rk;
+                for (int u = 0; u < 3; u++) { tg.a1[u] = ue[u]; tg.a2[u] = 0.0; }
+            } else {
+                tg.rl = rk; tg.rm = w.orr[e];
+                for (int u = 0; u < 3; u++) { tg.a1[u] = 0.0; tg.a2[u] = ue[u]; }
+            }
+        }
+    }
+    return valid;
+}
 
 template <bool WANT_E, bool WANT_F, int NSRC, int NCH>
 __device__ __forceinline__ void trio_block(const FeatArgs &A, const BasisDev *B, const KnotRec *recs, const FrameGeom &g,
                                            const WaveLds &w, int m, int sm, int t, const ESink &es) {
     const int lane = lane_id();
     const TrioDev *td = A.trios + t;
-    const int sc = td->sc, sa = td->sa, sb = td->sb, cap = A.n3.cap;
-    const int m_local = m - g.atom_lo;
-    // --- which triplets does atom m contribute to this block? ------------------------------
-    int cnt_c = 0, ra_lo = 0, rb_lo = 0, nb_ = 1;
-    if (sm == sc && !(A.skip & 2)) {          // m is the centre: own neighbours of species sa x sb
-        ra_lo = w.so[sa]; rb_lo = w.so[sb];
-        int na = w.so[sa + 1] - ra_lo;
-        nb_ = w.so[sb + 1] - rb_lo;
-        cnt_c = (sa == sb) ? na * (na - 1) / 2 : na * nb_;
-        if (nb_ < 1) nb_ = 1;
-    }
-    int total_n = 0, rc_lo = 0, ncen = 0, sx = -1;
-    if (WANT_F && !(A.skip & 4)) {            // m is a neighbour of a centre of species sc
-        if (sm == sa) sx = sb; else if (sm == sb) sx = sa;
-        if (sx >= 0) {
-            rc_lo = w.so[sc];
-            ncen = w.so[sc + 1] - rc_lo;
-            for (int e0 = 0; e0 < ncen; e0 += WAVE) {           // exclusive scan of |N3_sx(centre e)|
-                int e = e0 + lane;
-                int cnt = 0, base = 0;
-                if (e < ncen) {
-                    const int *sp = A.n3.spoff + (size_t)w.oparent[rc_lo + e] * (UF3_MAX_SPECIES + 1);
-                    base = sp[sx]; cnt = sp[sx + 1] - base;
-                }
-                int incl = cnt;
-                for (int sh = 1; sh < WAVE; sh <<= 1) { int o = __shfl_up(incl, sh); if (lane >= sh) incl += o; }
-                if (e < ncen) { w.noff[e] = total_n + incl - cnt; w.nbase[e] = base; }
-                total_n += __shfl(incl, WAVE - 1);
-            }
-            if (lane == 0) w.noff[ncen] = total_n;
-            wave_sync();
-        }
-    }
-    const int n_items = cnt_c + total_n;
+    TrioWalk k;
+    trio_walk_setup<WANT_F>(A, w, td, sm, k);
     const int ncol = td->ncol, F = B->F;
     for (int c0 = 0; c0 < ncol; c0 += NCH * WAVE) {
         ColSrc src[NCH][NSRC];
@@ -408,69 +488,17 @@ __device__ __forceinline__ void trio_block(const FeatArgs &A, const BasisDev *B,
         for (int ch = 0; ch < NCH; ch++) {
             int col = c0 + ch * WAVE + lane;
 #pragma unroll
-            for (int k = 0; k < NSRC; k++) {
-                int sp = col < ncol ? A.colsrc[td->src_off + col * NSRC + k] : -1;
-                src[ch][k].l = sp < 0 ? (1 << 20) : (sp & 255);
-                src[ch][k].m = (sp >> 8) & 255;
-                src[ch][k].n = (sp >> 16) & 255;
+            for (int q = 0; q < NSRC; q++) {
+                int sp = col < ncol ? A.colsrc[td->src_off + col * NSRC + q] : -1;
+                src[ch][q].l = sp < 0 ? (1 << 20) : (sp & 255);
+                src[ch][q].m = (sp >> 8) & 255;
+                src[ch][q].n = (sp >> 16) & 255;
             }
         }
-        for (int p0 = 0; p0 < n_items; p0 += WAVE) {
-            int p = p0 + lane;
-            bool valid = p < n_items;
+        for (int p0 = 0; p0 < k.n_items; p0 += WAVE) {
             TripletGeom tg;
             TripletRec r;
-            tg.centre = p < cnt_c;
-            if (valid && tg.centre) {
-                int aa, bb;
-                if (sa == sb) {
-                    bb = (int)((1.0f + sqrtf(1.0f + 8.0f * (float)p)) * 0.5f);
-                    while (bb * (bb - 1) / 2 > p) --bb;
-                    while ((bb + 1) * bb / 2 <= p) ++bb;
-                    aa = p - bb * (bb - 1) / 2;
-                    aa += ra_lo; bb += ra_lo;
-                } else { aa = ra_lo + p / nb_; bb = rb_lo + p % nb_; }
-                tg.rl = w.orr[aa]; tg.rm = w.orr[bb];
-                double ex = w.ox[bb] - w.ox[aa], ey = w.oy[bb] - w.oy[aa], ez = w.oz[bb] - w.oz[aa];
-                tg.rn = norm3_rn(ex, ey, ez);
-                if (WANT_F) {
-                    double il = 1.0 / tg.rl, im = 1.0 / tg.rm;
-                    tg.a1[0] = w.ox[aa] * il; tg.a1[1] = w.oy[aa] * il; tg.a1[2] = w.oz[aa] * il;
-                    tg.a2[0] = w.ox[bb] * im; tg.a2[1] = w.oy[bb] * im; tg.a2[2] = w.oz[bb] * im;
-                    tg.a3[0] = tg.a3[1] = tg.a3[2] = 0.0;
-                }
-            } else if (valid) {
-                int q = p - cnt_c;
-                int lo = 0, hi = ncen - 1;                   // centre e with noff[e] <= q < noff[e+1]
-                while (lo < hi) { int mid = (lo + hi + 1) >> 1; if (w.noff[mid] <= q) lo = mid; else hi = mid - 1; }
-                int e = rc_lo + lo, kk = w.nbase[lo] + (q - w.noff[lo]);
-                int pc = w.oparent[e];
-                size_t kb = (size_t)pc * cap + kk;
-                int s0, s1, s2;
-                unpack3(w.oshift[e], s0, s1, s2);
-                const N3Entry ke = A.n3.ent[kb];
-                int kparent = ke.parent, kshift = ke.shiftc;
-                valid = !(kparent == m && kshift == pack3(-s0, -s1, -s2));       // k is m itself
-                if (valid) {
-                    int ksidx = ke.sidx;
-                    int msidx = supercell_index(g, -s0, -s1, -s2, m_local);      // m as numbered from c
-                    double vx = ke.dx, vy = ke.dy, vz = ke.dz, rk = ke.r;
-                    double ex = w.ox[e] + vx, ey = w.oy[e] + vy, ez = w.oz[e] + vz;   // m -> k
-                    tg.rn = norm3_rn(ex, ey, ez);
-                    bool m_first = neighbour_is_first(g, sm, sx, s0, s1, s2, m_local, msidx, ksidx, kshift,
-                                                      kparent - g.atom_lo);
-                    double ie = 1.0 / w.orr[e], in = 1.0 / tg.rn;
-                    double ue[3] = {w.ox[e] * ie, w.oy[e] * ie, w.oz[e] * ie};
-                    tg.a3[0] = ex * in; tg.a3[1] = ey * in; tg.a3[2] = ez * in;
-                    if (m_first) {
-                        tg.rl = w.orr[e]; tg.rm = rk;
-                        for (int u = 0; u < 3; u++) { tg.a1[u] = ue[u]; tg.a2[u] = 0.0; }
-                    } else {
-                        tg.rl = rk; tg.rm = w.orr[e];
-                        for (int u = 0; u < 3; u++) { tg.a1[u] = 0.0; tg.a2[u] = ue[u]; }
-                    }
-                }
-            }
+            bool valid = trio_walk_geom<WANT_F>(A, g, w, td, k, m, sm, p0 + lane, tg);
             valid = eval_triplet<WANT_F>(recs, td, tg, valid, r);
             stage_and_gather<WANT_E, WANT_F, NSRC, NCH>(tg, r, valid, w.stage, src, acc);
         }
@@ -486,6 +514,173 @@ __device__ __forceinline__ void trio_block(const FeatArgs &A, const BasisDev *B,
             }
         }
     }
+}
+
+// ---- MFMA specialisation (MODE 6): dense accumulation of a small raw-bin window on the fp64 matrix cores ----
+// For one atom and trio block the force rows are X_c[l][m][n] = sum over records of
+//     P_c(l,m) * B_n(n) + Q_c(l,m) * B'_n(n),   P_c = B'_l B_m A1_c + B_l B'_m A2_c,   Q_c = B_l B_m A3_c,
+// i.e. a (3*Pk x 2T) * (2T x Nk) product with Pk = ext_l * ext_m window pairs and Nk = ext_n window bins.  One
+// v_mfma_f64_16x16x4 step consumes two records (K = {P, Q} x 2) per 16-row tile; the energy row is the same
+// product with A = B_l B_m (centre-role records only), four records per step.  The accumulators are the raw
+// window; the symmetry fold into columns happens once per (atom, block) through the colsrc table.
+//
+// Staged record: the four values of each leg are scattered to their position inside the window, so that every
+// operand address is a per-lane constant plus the record stride (no per-record index arithmetic, no masks):
+//   L  (B, B') x ext_l | L~ (B', B) x ext_l | M (B, B') x ext_m | N (B, B') x ext_n |
+//   (A1_c, A2_c) c = x,y,z | (A3_c, 0) c = x,y,z | zero pair
+// K slot "P" lanes read L~, slot "Q" lanes read L:  a = (L.x * M.x) * F.x + (L.y * M.y) * F.y  serves both.
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+struct DenseLayout {
+    int off_l1, off_m, off_n, off_f, off_z, stride;      // in doubles (off_l0 = 0)
+    int nstage;                                           // records staged per pass: 32 or 16
+};
+__host__ __device__ __forceinline__ DenseLayout dense_layout(int ext_l, int ext_m, int ext_n) {
+    DenseLayout d;
+    d.off_l1 = 2 * ext_l; d.off_m = 4 * ext_l; d.off_n = d.off_m + 2 * ext_m; d.off_f = d.off_n + 2 * ext_n;
+    d.off_z = d.off_f + 12; d.stride = d.off_z + 2;
+    d.nstage = d.stride <= 50 ? 32 : 16;
+    return d;
+}
+#define DENSE_DUMP 768    // doubles: 32 force rows + 16 energy rows of 16 bins
+
+template <bool WANT_E, bool WANT_F, bool MASK>
+__device__ __forceinline__ void mfma_pair(const double *rec, bool live, const int (&a_l)[2], const int (&a_m)[2],
+                                          const int (&a_f)[2], int a_n, double4_t (&accf)[2]) {
+    const double bv = rec[a_n];
+#pragma unroll
+    for (int tm = 0; tm < 2; tm++) {
+        const double2 L = *(const double2 *)(rec + a_l[tm]);
+        const double2 M = *(const double2 *)(rec + a_m[tm]);
+        const double2 Fv = *(const double2 *)(rec + a_f[tm]);
+        double av = fma(L.x * M.x, Fv.x, (L.y * M.y) * Fv.y);
+        if (MASK) av = live ? av : 0.0;
+        accf[tm] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, accf[tm], 0, 0, 0);
+    }
+}
+
+template <bool WANT_E, bool WANT_F>
+__device__ __forceinline__ void mfma_records(const double *stage, int stride, int n_staged, int n_centre, const int (&a_l)[2],
+                                             const int (&a_m)[2], const int (&a_f)[2], int a_n, int e_l, int e_m, int e_n,
+                                             double4_t (&accf)[2], double4_t &acce) {
+    const int ks = lane_id() >> 4;
+    if (WANT_F) {
+        const double *rec = stage + (size_t)(ks >> 1) * stride;
+        const int n_full = n_staged & ~1;
+        int q = 0;
+#pragma unroll 2
+        for (; q < n_full; q += 2, rec += 2 * stride) mfma_pair<WANT_E, WANT_F, false>(rec, true, a_l, a_m, a_f, a_n, accf);
+        if (q < n_staged) mfma_pair<WANT_E, WANT_F, true>(rec, (ks >> 1) == 0, a_l, a_m, a_f, a_n, accf);
+    }
+    if (WANT_E) {
+        const double *rec = stage + (size_t)ks * stride;
+        for (int q = 0; q < n_centre; q += 4, rec += 4 * stride) {
+            const double L = rec[e_l], M = rec[e_m], N = rec[e_n];
+            const double av = (q + ks < n_centre) ? L * M : 0.0;
+            acce = __builtin_amdgcn_mfma_f64_16x16x4f64(av, N, acce, 0, 0, 0);
+        }
+    }
+}
+
+template <bool WANT_E, bool WANT_F>
+__device__ __forceinline__ void trio_block_mfma(const FeatArgs &A, const BasisDev *B, const KnotRec *recs, const FrameGeom &g,
+                                                const WaveLds &w, int m, int sm, int t, const ESink &es,
+                                                const int (&fragp)[4], const int *dsrc) {
+    const int lane = lane_id();
+    const TrioDev *td = A.trios + t;
+    TrioWalk k;
+    trio_walk_setup<WANT_F>(A, w, td, sm, k);
+    const int ncol = td->ncol, F = B->F;
+    const int lo_l = td->lo[0], lo_m = td->lo[1], lo_n = td->lo[2];
+    const int ext_l = td->ext[0], ext_m = td->ext[1], ext_n = td->ext[2];
+    const int Pk = ext_l * ext_m;
+    const DenseLayout dl = dense_layout(ext_l, ext_m, ext_n);
+    const int r16 = lane & 15, type = (lane >> 4) & 1;
+    // per-lane operand offsets inside a record (doubles); small quotients by multiply-shift (exact for < 64)
+    const int inv_pk = (65536 + Pk - 1) / Pk, inv_em = (65536 + ext_m - 1) / ext_m;      // wave-uniform
+    int a_l[2], a_m[2], a_f[2];
+#pragma unroll
+    for (int tm = 0; tm < 2; tm++) {
+        const int row = tm * 16 + r16;
+        const int c = (row * inv_pk) >> 16, p = row - c * Pk;
+        const int pl = (p * inv_em) >> 16, pm = p - pl * ext_m;
+        const bool ok = row < 3 * Pk;
+        a_l[tm] = ok ? (type ? 0 : dl.off_l1) + 2 * pl : dl.off_z;
+        a_m[tm] = ok ? dl.off_m + 2 * pm : dl.off_z;
+        a_f[tm] = dl.off_f + 6 * type + 2 * (ok ? c : 0);
+    }
+    const int a_n = r16 < ext_n ? dl.off_n + 2 * r16 + type : dl.off_z;
+    const int el = (r16 * inv_em) >> 16;
+    const int e_l = r16 < Pk ? 2 * el : dl.off_z, e_m = dl.off_m + 2 * (r16 - el * ext_m);
+    const int e_n = r16 < ext_n ? dl.off_n + 2 * r16 : dl.off_z;
+    double4_t accf[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}}, acce = {0, 0, 0, 0};
+    for (int p0 = 0; p0 < k.n_items; p0 += WAVE) {
+        TripletGeom tg;
+        TripletRec r;
+        bool valid = trio_walk_geom<WANT_F>(A, g, w, td, k, m, sm, p0 + lane, tg);
+        if (!(A.skip & 16)) valid = eval_triplet<WANT_F>(recs, td, tg, valid, r);
+        else { for (int a = 0; a < 3; a++) { r.first[a] = 3; for (int q = 0; q < 4; q++) { r.v[a][q] = tg.rl; r.d[a][q] = tg.rm; } } }
+        for (int part = 0; part < WAVE / dl.nstage; part++) {
+            const bool mine = valid && ((lane / dl.nstage) == part);
+            const unsigned long long mask = __ballot(mine);
+            if (mask == 0) continue;
+            // centre-role records come first in the walk, hence first in the stage
+            const int n_centre = WANT_E ? __popcll(__ballot(mine && tg.centre)) : 0;
+            if (mine) {
+                double *rec = w.stage + (size_t)mbcnt(mask) * dl.stride;
+                const double2 zz = {0.0, 0.0};
+                for (int q = 0; q < dl.off_f; q += 2) *(double2 *)(rec + q) = zz;
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const unsigned wl = (unsigned)(r.first[0] + q - lo_l), wm = (unsigned)(r.first[1] + q - lo_m),
+                                   wn = (unsigned)(r.first[2] + q - lo_n);
+                    if (wl < (unsigned)ext_l) {
+                        *(double2 *)(rec + 2 * wl) = double2{r.v[0][q], WANT_F ? r.d[0][q] : 0.0};
+                        if (WANT_F) *(double2 *)(rec + dl.off_l1 + 2 * wl) = double2{r.d[0][q], r.v[0][q]};
+                    }
+                    if (wm < (unsigned)ext_m) *(double2 *)(rec + dl.off_m + 2 * wm) = double2{r.v[1][q], WANT_F ? r.d[1][q] : 0.0};
+                    if (wn < (unsigned)ext_n) *(double2 *)(rec + dl.off_n + 2 * wn) = double2{r.v[2][q], WANT_F ? r.d[2][q] : 0.0};
+                }
+                if (WANT_F)
+#pragma unroll
+                    for (int q = 0; q < 3; q++) {
+                        *(double2 *)(rec + dl.off_f + 2 * q) = double2{tg.a1[q], tg.a2[q]};
+                        *(double2 *)(rec + dl.off_f + 6 + 2 * q) = double2{tg.a3[q], 0.0};
+                    }
+                *(double2 *)(rec + dl.off_z) = zz;
+            }
+            wave_sync();
+            if (!(A.skip & 8))
+                mfma_records<WANT_E, WANT_F>(w.stage, dl.stride, __popcll(mask), n_centre, a_l, a_m, a_f, a_n, e_l, e_m, e_n, accf, acce);
+            wave_sync();
+        }
+    }
+    // accumulator window -> LDS (rows: 32 force rows (c, l, m), then 16 energy rows (l, m); 16 n bins each),
+    // then lanes <-> columns fold the symmetry images and write the rows
+    double *dump = w.stage;
+#pragma unroll
+    for (int v = 0; v < 4; v++) {
+        if (WANT_F) { dump[fragp[v]] = accf[0][v]; dump[256 + fragp[v]] = accf[1][v]; }
+        if (WANT_E) dump[512 + fragp[v]] = acce[v];
+    }
+    wave_sync();
+    const int nsrc = td->nsrc;
+    for (int col = lane; col < ncol; col += WAVE) {
+        double fx = 0, fy = 0, fz = 0, en = 0;
+        for (int q = 0; q < nsrc; q++) {
+            const int o = dsrc[td->src_off + col * nsrc + q];
+            if (o < 0) continue;
+            if (WANT_F) { fx += dump[o]; fy += dump[Pk * 16 + o]; fz += dump[2 * Pk * 16 + o]; }
+            if (WANT_E) en += dump[512 + o];
+        }
+        if (WANT_F && !(A.skip & 32)) {
+            double *dst = A.x_f + (size_t)m * 3 * F + td->col + col;
+            dst[0] = fx; dst[F] = fy; dst[2 * (size_t)F] = fz;
+        }
+        if (WANT_E) es.add(td->col + col, en);
+    }
+    wave_sync();
+    // the dump left window values in the stage: stale slots must stay finite (they are multiplied by 0), which they are
 }
 
 // 2-body block (sm, sx): lanes <-> basis functions, candidates of species sx streamed through LDS
@@ -557,14 +752,16 @@ __device__ __forceinline__ void zero_rows(double *x_f, int m, int F, int col, in
 
 // MODE selects the column blocks a launch is responsible for, so that each specialisation carries only the
 // registers of its own path: 0 = one-body + pair blocks; 1..5 = trio blocks whose (nsrc, 64-column chunks
-// per walk) is (1,1), (1,2), (2,1), (2,2), (6,1).  Every block is written by exactly one launch.
+// per walk) is (1,1), (1,2), (2,1), (2,2), (6,1); 6 = trio blocks with a small dense window, accumulated on the
+// matrix cores (trio_block_mfma).  Every block is written by exactly one launch.
 __device__ __forceinline__ int trio_mode(const TrioDev *td) {
+    if (td->dense) return 6;
     const bool wide = td->ncol > WAVE;
     return td->nsrc == 1 ? (wide ? 2 : 1) : (td->nsrc == 2 ? (wide ? 4 : 3) : 5);
 }
 
 template <bool WANT_E, bool WANT_F, bool RECS_LDS, int MODE>
-__global__ void __launch_bounds__(WPB * WAVE)
+__global__ void __launch_bounds__(WPB * WAVE, MODE == 0 ? 4 : 2)
 k_featurize(FeatArgs A) {
     extern __shared__ __align__(16) unsigned char smem[];
     const BasisDev *B = A.B;
@@ -575,10 +772,12 @@ k_featurize(FeatArgs A) {
     // LDS carve (must match feat_lds_bytes on the host).  MODE 0 (pairs): candidate list + pair records, pair
     // knot records only; trio modes: own neighbour list + triplet records, all knot records.
     const size_t cand_d = (size_t)A.cand_cap * 5 + ((A.cand_cap * 5) & 1);
-    const size_t stage_d = MODE == 0 ? cand_d + (size_t)NSTAGE * PAIR_STRIDE : (size_t)NSTAGE * ITEM_STRIDE;
+    const size_t stage_d = MODE == 0 ? cand_d + (size_t)NSTAGE * PAIR_STRIDE
+                           : (MODE == 6 ? (size_t)A.dense_stage : (size_t)NSTAGE * ITEM_STRIDE);
     const size_t list_d = MODE == 0 ? 0 : 4 * (size_t)cap + ((4 * cap) & 1);
     const size_t per_wave_d = list_d + stage_d + (stage_d & 1);
-    const size_t per_wave_i = MODE == 0 ? 0 : 3 * (size_t)cap + 2 * ((size_t)cap + 1) + (UF3_MAX_SPECIES + 2);
+    const size_t per_wave_i = MODE == 0 ? 0 : 3 * (size_t)cap + 2 * ((size_t)cap + 1) + (UF3_MAX_SPECIES + 2) +
+                                                  (size_t)cap * (UF3_MAX_SPECIES + 1);
     double *wd = erow + e_d + (size_t)wave * per_wave_d;
     int *wi = (int *)(erow + e_d + (size_t)WPB * per_wave_d) + (size_t)wave * per_wave_i;
     WaveLds w;
@@ -588,6 +787,7 @@ k_featurize(FeatArgs A) {
     w.pstage = w.stage + cand_d;
     w.oparent = wi; w.oshift = wi + cap; w.osidx = wi + 2 * cap;
     w.noff = wi + 3 * cap; w.nbase = w.noff + cap + 1; w.so = w.nbase + cap + 1;
+    w.ospoff = w.so + (UF3_MAX_SPECIES + 2);
 
     // knot-interval records (de Boor-Cox coefficients): staged in LDS when they fit
     KnotRec *recs_lds;
@@ -602,7 +802,18 @@ k_featurize(FeatArgs A) {
         for (int q = tid; q < n_copy * 12; q += WPB * WAVE) dstp[q] = srcp[q];
     }
     const KnotRec *recs = RECS_LDS ? recs_lds : A.recs;
+    int fragp[4] = {0, 0, 0, 0};
+    const int *dsrc = A.dsrc;
+    if (MODE == 6) {
+        for (int v = 0; v < 4; v++) fragp[v] = A.frag[(lane * 4 + v) * 2] * 16 + A.frag[(lane * 4 + v) * 2 + 1];
+        if (A.dsrc_lds) {
+            int *dl = (int *)(recs_lds + (RECS_LDS ? A.n_recs : 0));
+            for (int q = tid; q < A.n_dsrc; q += WPB * WAVE) dl[q] = A.dsrc[q];
+            dsrc = dl;
+        }
+    }
     if (WANT_E) { for (int q = tid; q < F; q += WPB * WAVE) erow[q] = 0.0; }
+    if (MODE == 6) for (int q = lane; q < (int)stage_d; q += WAVE) w.stage[q] = 0.0;   // masked operands read stale slots
     __syncthreads();
     const int block_first = blockIdx.x * A.atoms_per_block;
     const int block_end = min(block_first + A.atoms_per_block, A.natoms);
@@ -658,6 +869,7 @@ k_featurize(FeatArgs A) {
             });
             if (n_cand > A.cand_cap) { if (lane == 0) atomicMax(A.cand_need, n_cand); n_cand = A.cand_cap; }
             wave_sync();
+            if (A.skip & 256) n_cand = 0;
             for (int p = 0; p < B->P; p++) {
                 const PairDev &pd = B->pairs[p];
                 if (pd.sa == sm) pair_block<WANT_E, WANT_F>(A, B, recs, w, m, pd.sb, pd, n_cand, es);
@@ -667,7 +879,7 @@ k_featurize(FeatArgs A) {
         }
         // ---- 3-body ---------------------------------------------------------------------------
         if (MODE != 0 && B->T > 0) {
-            const int n = A.n3.cnt[m];
+            const int n = (A.skip & 64) ? 0 : A.n3.cnt[m];
             size_t base = (size_t)m * cap;
             wave_sync();
             for (int e = lane; e < n; e += WAVE) {
@@ -677,16 +889,23 @@ k_featurize(FeatArgs A) {
             }
             if (lane <= S) w.so[lane] = A.n3.spoff[(size_t)m * (UF3_MAX_SPECIES + 1) + lane];
             wave_sync();
-            for (int t = 0; t < B->T; t++) {
+            if (WANT_F)                                            // neighbour role: the lists of m's neighbours
+                for (int q = lane; q < n * (S + 1); q += WAVE) {
+                    const int e = q / (S + 1), sp = q - e * (S + 1);
+                    w.ospoff[e * (UF3_MAX_SPECIES + 1) + sp] = A.n3.spoff[(size_t)w.oparent[e] * (UF3_MAX_SPECIES + 1) + sp];
+                }
+            wave_sync();
+            for (int t = 0; t < ((A.skip & 128) ? 0 : B->T); t++) {
                 const TrioDev *td = A.trios + t;
                 if (trio_mode(td) != MODE) continue;
                 const bool touches = (td->sc == sm) || (WANT_F && (td->sa == sm || td->sb == sm));
-                if (!touches) { if (WANT_F) zero_rows(A.x_f, m, F, td->col, td->ncol); continue; }
+                if (!touches) { if (WANT_F && !(A.skip & 32)) zero_rows(A.x_f, m, F, td->col, td->ncol); continue; }
                 if (MODE == 1) trio_block<WANT_E, WANT_F, 1, 1>(A, B, recs, g, w, m, sm, t, es);
                 else if (MODE == 2) trio_block<WANT_E, WANT_F, 1, 2>(A, B, recs, g, w, m, sm, t, es);
                 else if (MODE == 3) trio_block<WANT_E, WANT_F, 2, 1>(A, B, recs, g, w, m, sm, t, es);
                 else if (MODE == 4) trio_block<WANT_E, WANT_F, 2, 2>(A, B, recs, g, w, m, sm, t, es);
-                else trio_block<WANT_E, WANT_F, 6, 1>(A, B, recs, g, w, m, sm, t, es);
+                else if (MODE == 5) trio_block<WANT_E, WANT_F, 6, 1>(A, B, recs, g, w, m, sm, t, es);
+                else trio_block_mfma<WANT_E, WANT_F>(A, B, recs, g, w, m, sm, t, es, fragp, dsrc);
             }
         }
     }
@@ -897,7 +1116,6 @@ __global__ void k_frame_sum(const double *per_atom, const int64_t *atom_offsets,
 // ---------------------------------------------------------------------------------
 // normal equations: G (+)= X^T X on the fp64 matrix cores, o (+)= X^T y
 // ---------------------------------------------------------------------------------
-typedef double double4_t __attribute__((ext_vector_type(4)));
 
 // D-fragment layout probe: element v of lane l of a 16x16 f64 accumulator is D[row][col]
 __global__ void k_mfma_probe(int *rowcol) {
