@@ -74,12 +74,22 @@ struct FrameGeom {
     int atom_lo, atom_hi;
 };
 
+// one atom in bin order (32 B, one load): original position, batch-global index, packed wrap vector + species
+struct __attribute__((aligned(16))) SlotRec {
+    double x, y, z;
+    int atom;
+    int ws;                   // pack3(wrap) | species << 30 would not fit: wrap 3 x 9 bits, species bits 27..30
+};
+__device__ __forceinline__ int pack_ws(int w0, int w1, int w2, int spec) {
+    return (w0 + 256) | ((w1 + 256) << 9) | ((w2 + 256) << 18) | (spec << 27);
+}
+__device__ __forceinline__ void unpack_ws(int p, int &w0, int &w1, int &w2, int &spec) {
+    w0 = (p & 511) - 256; w1 = ((p >> 9) & 511) - 256; w2 = ((p >> 18) & 511) - 256; spec = (p >> 27) & 15;
+}
+
 struct CellList {
     const int *bin_start;     // [nbins_total+1] slots
-    const int *s_atom;        // [natoms] atom index (batch-global) per slot
-    const double *s_pos;      // [natoms][3] original positions per slot
-    const int *s_wrap;        // [natoms] packed wrap vector per slot
-    const signed char *s_spec;
+    const SlotRec *slots;     // [natoms] atoms in bin order
     const int *atom_bin;      // [natoms] local bin id (within frame) per atom
     const int *atom_wrap;     // [natoms] packed wrap per atom
 };
@@ -177,12 +187,10 @@ __device__ __forceinline__ int mbcnt(unsigned long long mask) {
 // (unwrapped) positions; images outside the reference's range (|s| > fac) are skipped, so the
 // candidate set is exactly the reference's supercell (geometry.py:131-149).
 template <class F>
-__device__ __forceinline__ void for_each_candidate_strided(const FrameGeom &g, const CellList &cl, int m, int part,
-                                                           int n_parts, F f) {
-    int lane = lane_id();
-    int bin_no = 0;
-    int lb = cl.atom_bin[m];
-    int b2 = lb % g.nb[2], b1 = (lb / g.nb[2]) % g.nb[1], b0 = lb / (g.nb[2] * g.nb[1]);
+__device__ __forceinline__ void for_each_candidate(const FrameGeom &g, const CellList &cl, int m, F f) {
+    const int lane = lane_id();
+    const int lb = cl.atom_bin[m];
+    const int b2 = lb % g.nb[2], b1 = (lb / g.nb[2]) % g.nb[1], b0 = lb / (g.nb[2] * g.nb[1]);
     int w0, w1, w2;
     unpack3(cl.atom_wrap[m], w0, w1, w2);
     int lo[3], hi[3];
@@ -192,51 +200,57 @@ __device__ __forceinline__ void for_each_candidate_strided(const FrameGeom &g, c
         else if (g.nb[k] == 2) { lo[k] = 0; hi[k] = 1; }
         else { lo[k] = -1; hi[k] = 1; }
     }
-    for (int o0 = lo[0]; o0 <= hi[0]; o0++) {
-        int t0 = b0 + o0, sh0 = (t0 >= 0 ? t0 / g.nb[0] : -((g.nb[0] - 1 - t0) / g.nb[0]));
-        int c0 = t0 - sh0 * g.nb[0];
-        if (!g.per[0]) sh0 = 0;
-        for (int o1 = lo[1]; o1 <= hi[1]; o1++) {
-            int t1 = b1 + o1, sh1 = (t1 >= 0 ? t1 / g.nb[1] : -((g.nb[1] - 1 - t1) / g.nb[1]));
-            int c1 = t1 - sh1 * g.nb[1];
+    auto fdiv = [](int t, int n) { return t >= 0 ? t / n : -((n - 1 - t) / n); };
+    // Bins along the fastest axis are contiguous in memory: a maximal range of them that shares one image
+    // shift is a single slot range ("run").  Lanes describe the runs in parallel (one bin_start round trip for
+    // all of them), a prefix sum lays their slots out in one flat candidate index, and the wave then walks that
+    // index 64 candidates per step.
+    const int n1 = hi[1] - lo[1] + 1, n01 = (hi[0] - lo[0] + 1) * n1;
+    const int sh2_lo = fdiv(b2 + lo[2], g.nb[2]), nr2 = fdiv(b2 + hi[2], g.nb[2]) - sh2_lo + 1;
+    const int n_runs = n01 * nr2;
+    for (int r0 = 0; r0 < n_runs; r0 += WAVE) {
+        const int r = r0 + lane;
+        int len = 0, slot0 = 0, shp = 0;
+        if (r < n_runs) {
+            const int i01 = r / nr2, q = r - i01 * nr2, i0 = i01 / n1, i1 = i01 - i0 * n1;
+            const int t0 = b0 + lo[0] + i0, t1 = b1 + lo[1] + i1;
+            int sh0 = fdiv(t0, g.nb[0]), sh1 = fdiv(t1, g.nb[1]), sh2 = sh2_lo + q;
+            const int c0 = t0 - sh0 * g.nb[0], c1 = t1 - sh1 * g.nb[1];
+            const int o2a = max(lo[2], sh2 * g.nb[2] - b2), o2b = min(hi[2], (sh2 + 1) * g.nb[2] - 1 - b2);
+            const int c2 = b2 + o2a - sh2 * g.nb[2];
+            if (!g.per[0]) sh0 = 0;
             if (!g.per[1]) sh1 = 0;
-            // bins along the fastest axis are contiguous in memory: walk maximal runs that share one image
-            // shift as a single slot range (3 bins ~ 40 atoms per 64-lane step instead of ~13)
-            int o2 = lo[2];
-            while (o2 <= hi[2]) {
-                int t2 = b2 + o2, sh2 = (t2 >= 0 ? t2 / g.nb[2] : -((g.nb[2] - 1 - t2) / g.nb[2]));
-                int c2 = t2 - sh2 * g.nb[2];
-                int run = 1;
-                while (o2 + run <= hi[2] && c2 + run < g.nb[2]) {
-                    int tn = b2 + o2 + run;
-                    int shn = (tn >= 0 ? tn / g.nb[2] : -((g.nb[2] - 1 - tn) / g.nb[2]));
-                    if (shn != sh2) break;
-                    ++run;
-                }
-                o2 += run;
-                if (!g.per[2]) sh2 = 0;
-                if ((bin_no++ % n_parts) != part) continue;     // runs dealt round-robin to the parts
-                int gb = g.bin_base + (c0 * g.nb[1] + c1) * g.nb[2] + c2;
-                int s_lo = cl.bin_start[gb], s_hi = cl.bin_start[gb + run];
-                for (int base = s_lo; base < s_hi; base += WAVE) {
-                    int slot = base + lane;
-                    bool ok = slot < s_hi;
-                    int s0 = 0, s1 = 0, s2 = 0;
-                    if (ok) {
-                        int v0, v1, v2;
-                        unpack3(cl.s_wrap[slot], v0, v1, v2);
-                        s0 = sh0 - v0 + w0; s1 = sh1 - v1 + w1; s2 = sh2 - v2 + w2;
-                        ok = (abs(s0) <= g.fac[0]) && (abs(s1) <= g.fac[1]) && (abs(s2) <= g.fac[2]);
-                        if (ok && cl.s_atom[slot] == m && s0 == 0 && s1 == 0 && s2 == 0) ok = false;
-                    }
-                    f(ok, slot, s0, s1, s2);
-                }
+            if (!g.per[2]) sh2 = 0;
+            const int gb = g.bin_base + (c0 * g.nb[1] + c1) * g.nb[2] + c2;
+            slot0 = cl.bin_start[gb];
+            len = cl.bin_start[gb + (o2b - o2a + 1)] - slot0;
+            shp = pack3(sh0, sh1, sh2);
+        }
+        int incl = len;
+        for (int sh = 1; sh < WAVE; sh <<= 1) { int o = __shfl_up(incl, sh); if (lane >= sh) incl += o; }
+        const int total = __shfl(incl, WAVE - 1);
+        const int rel = slot0 - (incl - len);                 // slot = rel + flat index, inside this run
+        const int last = min(WAVE, n_runs - r0) - 1;
+        for (int base = 0; base < total; base += WAVE) {
+            const int idx = base + lane;
+            int run = 0;
+            for (int rr = 0; rr < last; rr++) run += idx >= __builtin_amdgcn_readlane(incl, rr);
+            const int slot = __shfl(rel, run) + idx;
+            int sh0, sh1, sh2;
+            unpack3(__shfl(shp, run), sh0, sh1, sh2);
+            bool ok = idx < total;
+            int s0 = 0, s1 = 0, s2 = 0, sj = 0;
+            SlotRec sr;
+            sr.x = sr.y = sr.z = 0.0; sr.atom = 0; sr.ws = 0;
+            if (ok) {
+                sr = cl.slots[slot];
+                int v0, v1, v2;
+                unpack_ws(sr.ws, v0, v1, v2, sj);
+                s0 = sh0 - v0 + w0; s1 = sh1 - v1 + w1; s2 = sh2 - v2 + w2;
+                ok = (abs(s0) <= g.fac[0]) && (abs(s1) <= g.fac[1]) && (abs(s2) <= g.fac[2]);
+                if (ok && sr.atom == m && s0 == 0 && s1 == 0 && s2 == 0) ok = false;
             }
+            f(ok, sr, sj, s0, s1, s2);
         }
     }
-}
-
-template <class F>
-__device__ __forceinline__ void for_each_candidate(const FrameGeom &g, const CellList &cl, int m, F f) {
-    for_each_candidate_strided(g, cl, m, 0, 1, f);
 }

@@ -37,7 +37,7 @@ struct uf3_ctx {
     int n_cu = 256;
     // grow-only workspace
     Buf geoms, offsets, frame_of, atom_bin, atom_wrap, spec, key_in, key_out, val_in, val_out, sort_tmp,
-        bin_start, s_atom, s_pos, s_wrap, s_spec, flags,
+        bin_start, slots, flags,
         n3_cnt, n3_int, n3_dbl, e_atom, coeff, stage_pos, stage_z, stage_out, stage_out2,
         gram_tiles, frag, dbg;
     int n3_cap = 0, cand_cap = 0;
@@ -113,8 +113,7 @@ extern "C" void uf3_ctx_destroy(uf3_ctx *c) {
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
     Buf *all[] = {&c->geoms, &c->offsets, &c->frame_of, &c->atom_bin, &c->atom_wrap, &c->spec, &c->key_in,
-                  &c->key_out, &c->val_in, &c->val_out, &c->sort_tmp, &c->bin_start, &c->s_atom, &c->s_pos,
-                  &c->s_wrap, &c->s_spec, &c->flags, &c->n3_cnt, &c->n3_int, &c->n3_dbl, &c->e_atom, &c->coeff,
+                  &c->key_out, &c->val_in, &c->val_out, &c->sort_tmp, &c->bin_start, &c->slots, &c->flags, &c->n3_cnt, &c->n3_int, &c->n3_dbl, &c->e_atom, &c->coeff,
                   &c->stage_pos, &c->stage_z, &c->stage_out, &c->stage_out2, &c->gram_tiles, &c->frag, &c->dbg};
     for (Buf *b : all) b->release();
     for (auto &v : c->pending) for (auto &p : v) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
@@ -496,7 +495,7 @@ static int check_flags(uf3_ctx *c) {
     int fl[4] = {0, 0, 0, 0};
     HIPCHK(c, hipMemcpy(fl, c->flags.p, sizeof(fl), hipMemcpyDeviceToHost));
     if (fl[0] == 2) { hipMemset(c->flags.p, 0, sizeof(fl)); return fail(c, UF3_ESPECIES, "frame contains an element outside the basis"); }
-    if (fl[0] == 1) { hipMemset(c->flags.p, 0, sizeof(fl)); return fail(c, UF3_EINVAL, "atom too far outside the periodic cell (|wrap| > 500)"); }
+    if (fl[0] == 1) { hipMemset(c->flags.p, 0, sizeof(fl)); return fail(c, UF3_EINVAL, "atom too far outside the periodic cell (|wrap| > 250)"); }
     return UF3_OK;
 }
 
@@ -551,8 +550,7 @@ static int prepare(uf3_basis *b, const uf3_frames *fr, const double *d_pos, cons
     HIPCHK(c, c->spec.ensure(na)); HIPCHK(c, c->key_in.ensure(4 * na)); HIPCHK(c, c->key_out.ensure(4 * na));
     HIPCHK(c, c->val_in.ensure(4 * na)); HIPCHK(c, c->val_out.ensure(4 * na));
     HIPCHK(c, c->bin_start.ensure(4 * ((size_t)nbins + 2)));
-    HIPCHK(c, c->s_atom.ensure(4 * na)); HIPCHK(c, c->s_pos.ensure(24 * na)); HIPCHK(c, c->s_wrap.ensure(4 * na));
-    HIPCHK(c, c->s_spec.ensure(na));
+    HIPCHK(c, c->slots.ensure(sizeof(SlotRec) * na));
     if (!c->flags.p) { HIPCHK(c, c->flags.ensure(64)); HIPCHK(c, hipMemsetAsync(c->flags.p, 0, 64, st)); }
     int *flags = c->flags.as<int>();
 
@@ -572,8 +570,7 @@ static int prepare(uf3_basis *b, const uf3_frames *fr, const double *d_pos, cons
     hipLaunchKernelGGL(k_bin_start, dim3((nbins + 1 + tb - 1) / tb), dim3(tb), 0, st, c->key_out.as<int>(), natoms,
                        nbins, c->bin_start.as<int>());
     hipLaunchKernelGGL(k_gather_sorted, dim3(gb), dim3(tb), 0, st, c->val_out.as<int>(), natoms, d_pos,
-                       c->atom_wrap.as<int>(), c->spec.as<signed char>(), c->s_atom.as<int>(), c->s_pos.as<double>(),
-                       c->s_wrap.as<int>(), c->s_spec.as<signed char>());
+                       c->atom_wrap.as<int>(), c->spec.as<signed char>(), c->slots.as<SlotRec>());
     HIPCHK(c, hipGetLastError());
 
     P.natoms = natoms; P.n_frames = nf; P.nbins = nbins; P.max_density = dens;
@@ -581,8 +578,7 @@ static int prepare(uf3_basis *b, const uf3_frames *fr, const double *d_pos, cons
     P.frame_of = c->frame_of.as<int>();
     P.spec = c->spec.as<signed char>();
     P.d_offsets = c->offsets.as<int64_t>();
-    P.cl.bin_start = c->bin_start.as<int>(); P.cl.s_atom = c->s_atom.as<int>(); P.cl.s_pos = c->s_pos.as<double>();
-    P.cl.s_wrap = c->s_wrap.as<int>(); P.cl.s_spec = c->s_spec.as<signed char>();
+    P.cl.bin_start = c->bin_start.as<int>(); P.cl.slots = c->slots.as<SlotRec>();
     P.cl.atom_bin = c->atom_bin.as<int>(); P.cl.atom_wrap = c->atom_wrap.as<int>();
     std::memset(&P.n3, 0, sizeof(P.n3));
     if (need_n3 && b->host.T > 0) {

@@ -46,7 +46,7 @@ __global__ void k_frame_bins(const BasisDev *B, const FrameGeom *geoms, const in
             int b = (int)((f - fl) * g.nb[k]);
             bin[k] = b >= g.nb[k] ? g.nb[k] - 1 : (b < 0 ? 0 : b);
             wrap[k] = (int)fl;
-            if (wrap[k] < -500 || wrap[k] > 500) { atomicExch(err_flag, 1); wrap[k] = 0; }
+            if (wrap[k] < -250 || wrap[k] > 250) { atomicExch(err_flag, 1); wrap[k] = 0; }
         } else {
             long long q = (long long)floor(f / g.binw[k]);
             int b = (int)(q % g.nb[k]);
@@ -73,28 +73,28 @@ __global__ void k_bin_start(const int *sorted_key, int natoms, int nbins, int *b
 }
 
 __global__ void k_gather_sorted(const int *sorted_val, int natoms, const double *pos, const int *atom_wrap,
-                                const signed char *spec, int *s_atom, double *s_pos, int *s_wrap,
-                                signed char *s_spec) {
+                                const signed char *spec, SlotRec *slots) {
     int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= natoms) return;
     int a = sorted_val[s];
-    s_atom[s] = a;
-    s_pos[3 * (size_t)s] = pos[3 * (size_t)a];
-    s_pos[3 * (size_t)s + 1] = pos[3 * (size_t)a + 1];
-    s_pos[3 * (size_t)s + 2] = pos[3 * (size_t)a + 2];
-    s_wrap[s] = atom_wrap[a];
-    s_spec[s] = spec[a];
+    SlotRec r;
+    r.x = pos[3 * (size_t)a]; r.y = pos[3 * (size_t)a + 1]; r.z = pos[3 * (size_t)a + 2];
+    r.atom = a;
+    int w0, w1, w2;
+    unpack3(atom_wrap[a], w0, w1, w2);
+    r.ws = pack_ws(w0, w1, w2, spec[a]);
+    slots[s] = r;
 }
 
 // vector from atom m (original position pm) to the image (slot, shift) of a neighbour
-__device__ __forceinline__ void image_delta(const FrameGeom &g, const CellList &cl, int slot, int s0, int s1, int s2,
+__device__ __forceinline__ void image_delta(const FrameGeom &g, const SlotRec &sr, int s0, int s1, int s2,
                                             const double *pm, double &dx, double &dy, double &dz) {
     double off[3];
     for (int k = 0; k < 3; k++) off[k] = s0 * g.cell[k] + s1 * g.cell[3 + k] + s2 * g.cell[6 + k];
     // (p_j + offset) - p_i, as the reference tiles positions first (geometry.py:146-148)
-    dx = (cl.s_pos[3 * (size_t)slot] + off[0]) - pm[0];
-    dy = (cl.s_pos[3 * (size_t)slot + 1] + off[1]) - pm[1];
-    dz = (cl.s_pos[3 * (size_t)slot + 2] + off[2]) - pm[2];
+    dx = (sr.x + off[0]) - pm[0];
+    dy = (sr.y + off[1]) - pm[1];
+    dz = (sr.z + off[2]) - pm[2];
 }
 
 // ---------------------------------------------------------------------------------
@@ -116,10 +116,10 @@ k_build_n3(const BasisDev *B, const FrameGeom *geoms, const int *frame_of, CellL
     double pm[3] = {pos[3 * (size_t)m], pos[3 * (size_t)m + 1], pos[3 * (size_t)m + 2]};
     double rmin3 = B->rmin3, rmax3 = B->rmax3;
     int count = 0;
-    for_each_candidate(g, cl, m, [&](bool ok, int slot, int s0, int s1, int s2) {
+    for_each_candidate(g, cl, m, [&](bool ok, const SlotRec &sr, int sj, int s0, int s1, int s2) {
         double dx = 0, dy = 0, dz = 0, d = 0;
         if (ok) {
-            image_delta(g, cl, slot, s0, s1, s2, pm, dx, dy, dz);
+            image_delta(g, sr, s0, s1, s2, pm, dx, dy, dz);
             d = norm3_rn(dx, dy, dz);
             ok = (d > rmin3) && (d <= rmax3);            // angles.py:340: lower strict, upper inclusive
         }
@@ -127,9 +127,9 @@ k_build_n3(const BasisDev *B, const FrameGeom *geoms, const int *frame_of, CellL
         if (ok) {
             int e = count + mbcnt(mask);
             if (e < cap) {
-                int j = cl.s_atom[slot];
+                int j = sr.atom;
                 int sidx = supercell_index(g, s0, s1, s2, j - g.atom_lo);
-                int sp = cl.s_spec[slot];
+                int sp = sj;
                 key[e] = ((unsigned long long)sp << 32) | (unsigned)sidx;
                 ex[e] = dx; ey[e] = dy; ez[e] = dz; er[e] = d;
                 eparent[e] = j; eshift[e] = pack3(s0, s1, s2); esidx[e] = sidx; espec[e] = sp;
@@ -847,13 +847,11 @@ k_featurize(FeatArgs A) {
         // ---- 2-body: neighbour images -> LDS once, then one pass per pair block ------------------
         if (MODE == 0) {
             int n_cand = 0;
-            if (!(A.skip & 1)) for_each_candidate(g, A.cl, m, [&](bool ok, int slot, int s0, int s1, int s2) {
+            if (!(A.skip & 1)) for_each_candidate(g, A.cl, m, [&](bool ok, const SlotRec &sr, int sj, int s0, int s1, int s2) {
                 double dx = 0, dy = 0, dz = 0, d = 0;
-                int sj = 0;
                 if (ok) {
-                    image_delta(g, A.cl, slot, s0, s1, s2, pm, dx, dy, dz);
+                    image_delta(g, sr, s0, s1, s2, pm, dx, dy, dz);
                     d = norm3_rn(dx, dy, dz);
-                    sj = A.cl.s_spec[slot];
                     const PairDev &pd = B->pairs[B->pair_of[sm * UF3_MAX_SPECIES + sj]];
                     ok = (d > pd.rmin && d < pd.rmax);            // distances.py:66 strict both sides
                 }
@@ -988,12 +986,11 @@ k_eval(EvalArgs A) {
     double pm[3] = {A.pos[3 * (size_t)m], A.pos[3 * (size_t)m + 1], A.pos[3 * (size_t)m + 2]};
     double e = 0.0, fx = 0.0, fy = 0.0, fz = 0.0;
     if (lane == 0) e = A.c1[sm];
-    for_each_candidate(g, A.cl, m, [&](bool ok, int slot, int s0, int s1, int s2) {
+    for_each_candidate(g, A.cl, m, [&](bool ok, const SlotRec &sr, int sj, int s0, int s1, int s2) {
         if (!ok) return;
-        int sj = A.cl.s_spec[slot];
         const PairDev &pd = B->pairs[B->pair_of[sm * UF3_MAX_SPECIES + sj]];
         double dx, dy, dz;
-        image_delta(g, A.cl, slot, s0, s1, s2, pm, dx, dy, dz);
+        image_delta(g, sr, s0, s1, s2, pm, dx, dy, dz);
         double d = norm3_rn(dx, dy, dz);
         if (!(d > pd.rmin && d < pd.rmax)) return;
         int i = find_interval(B->recs, pd.leg, d);
@@ -1209,14 +1206,14 @@ k_debug_pairs(const BasisDev *B, const FrameGeom *geoms, const int *frame_of, Ce
     const FrameGeom g = geoms[frame_of[m]];
     const int sm = spec[m];
     double pm[3] = {pos[3 * (size_t)m], pos[3 * (size_t)m + 1], pos[3 * (size_t)m + 2]};
-    for_each_candidate(g, cl, m, [&](bool ok, int slot, int s0, int s1, int s2) {
+    for_each_candidate(g, cl, m, [&](bool ok, const SlotRec &sr, int sj, int s0, int s1, int s2) {
         if (!ok) return;
         double dx, dy, dz;
-        image_delta(g, cl, slot, s0, s1, s2, pm, dx, dy, dz);
+        image_delta(g, sr, s0, s1, s2, pm, dx, dy, dz);
         double d = norm3_rn(dx, dy, dz);
-        int j = cl.s_atom[slot];
+        int j = sr.atom;
         long long sidx = supercell_index(g, s0, s1, s2, j - g.atom_lo);
-        int p = B->pair_of[sm * UF3_MAX_SPECIES + cl.s_spec[slot]];
+        int p = B->pair_of[sm * UF3_MAX_SPECIES + sj];
         const PairDev &pd = B->pairs[p];
         if (d > pd.rmin && d < pd.rmax) {
             atomicAdd((unsigned long long *)&counts[p], 1ULL);
