@@ -141,6 +141,24 @@ __device__ __forceinline__ int find_interval(const KnotRec *recs, const LegDev &
     return i;
 }
 
+// Same search, returning the interval's record as well: the whole record at the initial guess is fetched at once
+// and only re-fetched when the guess was off (non-uniform knots, or x on an interval boundary), so the common
+// case costs one memory round trip instead of two.
+__device__ __forceinline__ int load_interval(const KnotRec *recs, const LegDev &leg, double x, KnotRec &k) {
+    const int hi = leg.nk - 5;
+    int i = 3 + (int)((x - leg.t0) * leg.inv_h);
+    i = i < 3 ? 3 : (i > hi ? hi : i);
+    const KnotRec *base = recs + leg.rec_off;
+    k = base[i];
+    for (;;) {
+        if (x > k.t[3] && i < hi) ++i;
+        else if (x <= k.t[2] && i > 3) --i;
+        else break;
+        k = base[i];
+    }
+    return i;
+}
+
 // values v[0..3] and first derivatives d[0..3] of basis functions i-3 .. i at x
 template <bool DERIV>
 __device__ __forceinline__ void bspline4(const KnotRec &k, double x, double *v, double *d) {
@@ -177,6 +195,16 @@ __device__ __forceinline__ double norm3_rn(double dx, double dy, double dz) {
 }
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+// inclusive prefix sum over the 64 lanes on the DPP network (row shifts, then row broadcasts): no LDS round trips
+__device__ __forceinline__ int wave_scan_incl(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);     // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);     // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);     // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);     // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);    // row_bcast:15 -> rows 1, 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);    // row_bcast:31 -> rows 2, 3
+    return v;
+}
 __device__ __forceinline__ int mbcnt(unsigned long long mask) {
     return __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
 }
@@ -226,9 +254,8 @@ __device__ __forceinline__ void for_each_candidate(const FrameGeom &g, const Cel
             len = cl.bin_start[gb + (o2b - o2a + 1)] - slot0;
             shp = pack3(sh0, sh1, sh2);
         }
-        int incl = len;
-        for (int sh = 1; sh < WAVE; sh <<= 1) { int o = __shfl_up(incl, sh); if (lane >= sh) incl += o; }
-        const int total = __shfl(incl, WAVE - 1);
+        const int incl = wave_scan_incl(len);
+        const int total = __builtin_amdgcn_readlane(incl, WAVE - 1);
         const int rel = slot0 - (incl - len);                 // slot = rel + flat index, inside this run
         const int last = min(WAVE, n_runs - r0) - 1;
         for (int base = 0; base < total; base += WAVE) {

@@ -325,7 +325,7 @@ extern "C" int uf3_basis_create(uf3_ctx *c, const uf3_basis_spec *s, uf3_basis *
         if (3 * td.ext[0] * td.ext[1] <= 32 && td.ext[2] <= 16 && !getenv("UF3_NO_MFMA_FEAT")) {
             td.dense = 1;
             DenseLayout dl = dense_layout(td.ext[0], td.ext[1], td.ext[2]);
-            b->dense_stage = std::max(b->dense_stage, std::max(DENSE_DUMP, dl.nstage * dl.stride));
+            b->dense_stage = std::max(b->dense_stage, std::max(DENSE_DUMP, dl.nrec * dl.stride));
         }
         b->modes |= 1 << (td.dense ? 6 : td.nsrc == 1 ? (td.ncol > WAVE ? 2 : 1) : (td.nsrc == 2 ? (td.ncol > WAVE ? 4 : 3) : 5));
         for (auto &v : per_col) for (int k = 0; k < td.nsrc; k++) {
@@ -618,7 +618,8 @@ static size_t feat_lds_bytes(int F, int cap, int cand_cap, bool want_e, size_t n
     size_t stage_d = mode == 0 ? cand_d + (size_t)NSTAGE * PAIR_STRIDE
                      : (mode == 6 ? (size_t)dense_stage : (size_t)NSTAGE * ITEM_STRIDE);
     size_t list_d = mode == 0 ? 0 : 4 * (size_t)cap + ((4 * cap) & 1);
-    size_t per_wave_d = list_d + stage_d + (stage_d & 1);
+    size_t geo_d = mode == 6 ? (size_t)DENSE_BATCH * GEO_STRIDE : 0;
+    size_t per_wave_d = list_d + stage_d + (stage_d & 1) + geo_d;
     size_t per_wave_i = mode == 0 ? 0 : 3 * (size_t)cap + 2 * ((size_t)cap + 1) + (UF3_MAX_SPECIES + 2) +
                                         (size_t)cap * (UF3_MAX_SPECIES + 1);
     size_t ints = ((size_t)WPB * per_wave_i + 3) & ~(size_t)3;
@@ -971,3 +972,14 @@ extern "C" int uf3_neighbors_debug(uf3_basis *b, const uf3_frames *fr, const dou
     }
     return UF3_OK;
 }
+
+#ifdef UF3_PHASE_TIMING
+// experiments only: read (and clear) the in-kernel phase timers
+extern "C" int uf3_debug_phase(unsigned long long *out16) {
+    hipDeviceSynchronize();
+    hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_phase), sizeof(unsigned long long) * 16);
+    unsigned long long z[16] = {0};
+    hipMemcpyToSymbol(HIP_SYMBOL(g_phase), z, sizeof(z));
+    return 0;
+}
+#endif

@@ -188,6 +188,24 @@ __device__ __forceinline__ bool neighbour_is_first(const FrameGeom &g, int sm, i
 //   24-26 A1, 27-29 A2, 30-32 A3, 34-35 int4 {first l, first m, first n, centre flag}, 36-37 zero pair
 // pair record (doubles): 0-7 (B,B')[4], 8-10 2*(R_j-R_m)/r, 11 {first basis index, -}
 
+// optional in-kernel phase timers (experiments only: -DUF3_PHASE_TIMING); lane 0 of every wave adds the
+// cycles it spent in a phase to a global table
+#ifdef UF3_PHASE_TIMING
+__device__ unsigned long long g_phase[16];
+struct PhaseClock {
+    unsigned long long t;
+    __device__ __forceinline__ PhaseClock() : t(__builtin_amdgcn_s_memtime()) {}
+    __device__ __forceinline__ void lap(int phase) {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // charge outstanding loads to this phase
+        unsigned long long n = __builtin_amdgcn_s_memtime();
+        if (lane_id() == 0) atomicAdd(&g_phase[phase], n - t);
+        t = __builtin_amdgcn_s_memtime();
+    }
+};
+#else
+struct PhaseClock { __device__ __forceinline__ void lap(int) {} };
+#endif
+
 struct FeatArgs {
     const BasisDev *B;
     const TrioDev *trios;     // explicit global pointers (no flat loads through the struct)
@@ -240,6 +258,7 @@ struct TripletGeom {
     double rl, rm, rn;
     double a1[3], a2[3], a3[3];
     bool centre;
+    bool first;      // neighbour role: m is the trio's first neighbour (leg l joins the centre and m)
 };
 
 struct TripletRec {
@@ -256,12 +275,13 @@ __device__ __forceinline__ bool eval_triplet(const KnotRec *recs, const TrioDev 
     // (half-open last interval), so both ends contribute nothing: open interval here.
     if (!((t.rl > td->leg[0].t0) && (t.rl < td->leg[0].tlast) && (t.rm > td->leg[1].t0) && (t.rm < td->leg[1].tlast) &&
           (t.rn > td->leg[2].t0) && (t.rn < td->leg[2].tlast))) return false;
-    int il = find_interval(recs, td->leg[0], t.rl);
-    int im = find_interval(recs, td->leg[1], t.rm);
-    int in = find_interval(recs, td->leg[2], t.rn);
-    bspline4<WANT_F>(recs[td->leg[0].rec_off + il], t.rl, r.v[0], r.d[0]);
-    bspline4<WANT_F>(recs[td->leg[1].rec_off + im], t.rm, r.v[1], r.d[1]);
-    bspline4<WANT_F>(recs[td->leg[2].rec_off + in], t.rn, r.v[2], r.d[2]);
+    KnotRec kl, km, kn;
+    int il = load_interval(recs, td->leg[0], t.rl, kl);
+    int im = load_interval(recs, td->leg[1], t.rm, km);
+    int in = load_interval(recs, td->leg[2], t.rn, kn);
+    bspline4<WANT_F>(kl, t.rl, r.v[0], r.d[0]);
+    bspline4<WANT_F>(km, t.rm, r.v[1], r.d[1]);
+    bspline4<WANT_F>(kn, t.rn, r.v[2], r.d[2]);
     r.first[0] = il - 3; r.first[1] = im - 3; r.first[2] = in - 3;
     return true;
 }
@@ -359,6 +379,7 @@ struct WaveLds {
     int *noff, *nbase;                 // neighbour-role prefix [cap+1] / start index [cap]
     int *so;                           // species offsets in the own list [S+1]
     int *ospoff;                       // species offsets of every own neighbour's list [cap][UF3_MAX_SPECIES+1]
+    double *geo;                       // MFMA specialisation: geometry of the walked triplets [DENSE_BATCH][GEO_STRIDE]
     double *stage;                     // NSTAGE triplet / pair records
     double *cand;                      // 2-body candidates [cand_cap][5] (aliases stage)
     double *pstage;                    // pair records (behind the candidates, inside stage)
@@ -398,15 +419,19 @@ __device__ __forceinline__ void trio_walk_setup(const FeatArgs &A, const WaveLds
                     const int *sp = w.ospoff + (size_t)(k.rc_lo + e) * (UF3_MAX_SPECIES + 1);
                     base = sp[k.sx]; cnt = sp[k.sx + 1] - base;
                 }
-                int incl = cnt;
-                for (int sh = 1; sh < WAVE; sh <<= 1) { int o = __shfl_up(incl, sh); if (lane >= sh) incl += o; }
+                const int incl = wave_scan_incl(cnt);
                 if (e < k.ncen) { w.noff[e] = k.total_n + incl - cnt; w.nbase[e] = base; }
-                k.total_n += __shfl(incl, WAVE - 1);
+                k.total_n += __builtin_amdgcn_readlane(incl, WAVE - 1);
             }
             if (lane == 0) w.noff[k.ncen] = k.total_n;
             wave_sync();
         }
     }
+    // everything above is the same in all lanes: keep it in scalar registers
+    k.cnt_c = __builtin_amdgcn_readfirstlane(k.cnt_c); k.ra_lo = __builtin_amdgcn_readfirstlane(k.ra_lo);
+    k.rb_lo = __builtin_amdgcn_readfirstlane(k.rb_lo); k.nb_ = __builtin_amdgcn_readfirstlane(k.nb_);
+    k.total_n = __builtin_amdgcn_readfirstlane(k.total_n); k.rc_lo = __builtin_amdgcn_readfirstlane(k.rc_lo);
+    k.ncen = __builtin_amdgcn_readfirstlane(k.ncen); k.sx = __builtin_amdgcn_readfirstlane(k.sx);
     k.n_items = k.cnt_c + k.total_n;
 }
 
@@ -418,6 +443,7 @@ __device__ __forceinline__ bool trio_walk_geom(const FeatArgs &A, const FrameGeo
     const int m_local = m - g.atom_lo;
     bool valid = p < k.n_items;
     tg.centre = p < k.cnt_c;
+    tg.first = false;
     if (valid && tg.centre) {
         int aa, bb;
         if (sa == sb) {
@@ -439,13 +465,16 @@ __device__ __forceinline__ bool trio_walk_geom(const FeatArgs &A, const FrameGeo
     } else if (valid) {
         int q = p - k.cnt_c;
         int lo = 0, hi = k.ncen - 1;                   // centre e with noff[e] <= q < noff[e+1]
+        if (A.skip & 1024) { lo = q % k.ncen; hi = lo; }
         while (lo < hi) { int mid = (lo + hi + 1) >> 1; if (w.noff[mid] <= q) lo = mid; else hi = mid - 1; }
         int e = k.rc_lo + lo, kk = w.nbase[lo] + (q - w.noff[lo]);
         int pc = w.oparent[e];
         size_t kb = (size_t)pc * cap + kk;
         int s0, s1, s2;
         unpack3(w.oshift[e], s0, s1, s2);
-        const N3Entry ke = A.n3.ent[kb];
+        N3Entry ke;
+        if (A.skip & 512) { ke.dx = w.ox[e] * 0.5; ke.dy = w.oy[e] + 1.0; ke.dz = w.oz[e] - 1.0; ke.r = w.orr[e]; ke.parent = pc; ke.shiftc = w.oshift[e]; ke.sidx = w.osidx[e] + kk; ke.spec = 0; }
+        else ke = A.n3.ent[kb];
         int kparent = ke.parent, kshift = ke.shiftc;
         valid = !(kparent == m && kshift == pack3(-s0, -s1, -s2));       // k is m itself
         if (valid) {
@@ -459,6 +488,7 @@ __device__ __forceinline__ bool trio_walk_geom(const FeatArgs &A, const FrameGeo
             double ie = 1.0 / w.orr[e], in = 1.0 / tg.rn;
             double ue[3] = {w.ox[e] * ie, w.oy[e] * ie, w.oz[e] * ie};
             tg.a3[0] = ex * in; tg.a3[1] = ey * in; tg.a3[2] = ez * in;
+            tg.first = m_first;
             if (m_first) {
                 tg.rl = w.orr[e]; tg.rm = rk;
                 for (int u = 0; u < 3; u++) { tg.a1[u] = ue[u]; tg.a2[u] = 0.0; }
@@ -533,16 +563,19 @@ typedef double double4_t __attribute__((ext_vector_type(4)));
 
 struct DenseLayout {
     int off_l1, off_m, off_n, off_f, off_z, stride;      // in doubles (off_l0 = 0)
-    int nstage;                                           // records staged per pass: 32 or 16
+    int nrec;                                             // records staged per pass (3 lanes each): <= 21
 };
 __host__ __device__ __forceinline__ DenseLayout dense_layout(int ext_l, int ext_m, int ext_n) {
     DenseLayout d;
     d.off_l1 = 2 * ext_l; d.off_m = 4 * ext_l; d.off_n = d.off_m + 2 * ext_m; d.off_f = d.off_n + 2 * ext_n;
     d.off_z = d.off_f + 12; d.stride = d.off_z + 2;
-    d.nstage = d.stride <= 50 ? 32 : 16;
+    d.nrec = 1056 / d.stride;
+    if (d.nrec > 21) d.nrec = 21;
     return d;
 }
 #define DENSE_DUMP 768    // doubles: 32 force rows + 16 energy rows of 16 bins
+#define DENSE_BATCH 63    // triplets walked per step (three staging passes of 21)
+#define GEO_STRIDE 10     // doubles per walked triplet: rl, rm, rn | v1[3] | v2[3] | role code
 
 template <bool WANT_E, bool WANT_F, bool MASK>
 __device__ __forceinline__ void mfma_pair(const double *rec, bool live, const int (&a_l)[2], const int (&a_m)[2],
@@ -559,20 +592,51 @@ __device__ __forceinline__ void mfma_pair(const double *rec, bool live, const in
     }
 }
 
+// Centre-role records have A3 = 0, so their K slot "Q" is empty: they are consumed four per step (lanes' K index =
+// record), and the energy tile reuses the operands of force tile 0 (rows 0 .. Pk-1 of tile 0 are (x, l, m)).
+template <bool WANT_E, bool MASK>
+__device__ __forceinline__ void mfma_quad(const double *rec, bool live, const int (&c_l)[2], const int (&a_m)[2],
+                                          const int (&c_f)[2], int e_n, bool e_row, double4_t (&accf)[2], double4_t &acce) {
+    const double bv = rec[e_n];
+#pragma unroll
+    for (int tm = 0; tm < 2; tm++) {
+        const double2 L = *(const double2 *)(rec + c_l[tm]);       // (B', B)
+        const double2 M = *(const double2 *)(rec + a_m[tm]);       // (B, B')
+        const double2 Fv = *(const double2 *)(rec + c_f[tm]);      // (A1_c, A2_c)
+        double av = fma(L.x * M.x, Fv.x, (L.y * M.y) * Fv.y);
+        if (MASK) av = live ? av : 0.0;
+        accf[tm] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, accf[tm], 0, 0, 0);
+        if (WANT_E && tm == 0) {
+            double ae = e_row ? L.y * M.x : 0.0;
+            if (MASK) ae = live ? ae : 0.0;
+            acce = __builtin_amdgcn_mfma_f64_16x16x4f64(ae, bv, acce, 0, 0, 0);
+        }
+    }
+}
+
 template <bool WANT_E, bool WANT_F>
 __device__ __forceinline__ void mfma_records(const double *stage, int stride, int n_staged, int n_centre, const int (&a_l)[2],
-                                             const int (&a_m)[2], const int (&a_f)[2], int a_n, int e_l, int e_m, int e_n,
+                                             const int (&a_m)[2], const int (&a_f)[2], int a_n, const int (&c_l)[2],
+                                             const int (&c_f)[2], bool e_row, int e_l, int e_m, int e_n,
                                              double4_t (&accf)[2], double4_t &acce) {
     const int ks = lane_id() >> 4;
     if (WANT_F) {
-        const double *rec = stage + (size_t)(ks >> 1) * stride;
-        const int n_full = n_staged & ~1;
-        int q = 0;
+        {   // centre-role records [0, n_centre): four per step
+            const double *rec = stage + (size_t)ks * stride;
+            const int n_full = n_centre & ~3;
+            int q = 0;
+            for (; q < n_full; q += 4, rec += 4 * stride) mfma_quad<WANT_E, false>(rec, true, c_l, a_m, c_f, e_n, e_row, accf, acce);
+            if (q < n_centre) mfma_quad<WANT_E, true>(rec, q + ks < n_centre, c_l, a_m, c_f, e_n, e_row, accf, acce);
+        }
+        {   // neighbour-role records [n_centre, n_staged): two per step (K = {P, Q} x 2)
+            const double *rec = stage + (size_t)(n_centre + (ks >> 1)) * stride;
+            const int n_nb = n_staged - n_centre, n_full = n_nb & ~1;
+            int q = 0;
 #pragma unroll 2
-        for (; q < n_full; q += 2, rec += 2 * stride) mfma_pair<WANT_E, WANT_F, false>(rec, true, a_l, a_m, a_f, a_n, accf);
-        if (q < n_staged) mfma_pair<WANT_E, WANT_F, true>(rec, (ks >> 1) == 0, a_l, a_m, a_f, a_n, accf);
-    }
-    if (WANT_E) {
+            for (; q < n_full; q += 2, rec += 2 * stride) mfma_pair<WANT_E, WANT_F, false>(rec, true, a_l, a_m, a_f, a_n, accf);
+            if (q < n_nb) mfma_pair<WANT_E, WANT_F, true>(rec, (ks >> 1) == 0, a_l, a_m, a_f, a_n, accf);
+        }
+    } else if (WANT_E) {
         const double *rec = stage + (size_t)ks * stride;
         for (int q = 0; q < n_centre; q += 4, rec += 4 * stride) {
             const double L = rec[e_l], M = rec[e_m], N = rec[e_n];
@@ -588,6 +652,7 @@ __device__ __forceinline__ void trio_block_mfma(const FeatArgs &A, const BasisDe
                                                 const int (&fragp)[4], const int *dsrc) {
     const int lane = lane_id();
     const TrioDev *td = A.trios + t;
+    PhaseClock pc;
     TrioWalk k;
     trio_walk_setup<WANT_F>(A, w, td, sm, k);
     const int ncol = td->ncol, F = B->F;
@@ -598,7 +663,7 @@ __device__ __forceinline__ void trio_block_mfma(const FeatArgs &A, const BasisDe
     const int r16 = lane & 15, type = (lane >> 4) & 1;
     // per-lane operand offsets inside a record (doubles); small quotients by multiply-shift (exact for < 64)
     const int inv_pk = (65536 + Pk - 1) / Pk, inv_em = (65536 + ext_m - 1) / ext_m;      // wave-uniform
-    int a_l[2], a_m[2], a_f[2];
+    int a_l[2], a_m[2], a_f[2], c_l[2], c_f[2];
 #pragma unroll
     for (int tm = 0; tm < 2; tm++) {
         const int row = tm * 16 + r16;
@@ -608,51 +673,98 @@ __device__ __forceinline__ void trio_block_mfma(const FeatArgs &A, const BasisDe
         a_l[tm] = ok ? (type ? 0 : dl.off_l1) + 2 * pl : dl.off_z;
         a_m[tm] = ok ? dl.off_m + 2 * pm : dl.off_z;
         a_f[tm] = dl.off_f + 6 * type + 2 * (ok ? c : 0);
+        c_l[tm] = ok ? dl.off_l1 + 2 * pl : dl.off_z;          // centre-role steps: every K slot is a "P" slot
+        c_f[tm] = dl.off_f + 2 * (ok ? c : 0);
     }
+    const bool e_row = r16 < Pk;
     const int a_n = r16 < ext_n ? dl.off_n + 2 * r16 + type : dl.off_z;
     const int el = (r16 * inv_em) >> 16;
     const int e_l = r16 < Pk ? 2 * el : dl.off_z, e_m = dl.off_m + 2 * (r16 - el * ext_m);
     const int e_n = r16 < ext_n ? dl.off_n + 2 * r16 : dl.off_z;
+    // staging role of this lane: leg `leg` of staged record `li` (lanes 3*li .. 3*li+2)
+    const int li = (lane * 21846) >> 16, leg = lane - 3 * li;
+    LegDev lg;
+    lg.rec_off = leg == 0 ? td->leg[0].rec_off : (leg == 1 ? td->leg[1].rec_off : td->leg[2].rec_off);
+    lg.nk = leg == 0 ? td->leg[0].nk : (leg == 1 ? td->leg[1].nk : td->leg[2].nk);
+    lg.t0 = leg == 0 ? td->leg[0].t0 : (leg == 1 ? td->leg[1].t0 : td->leg[2].t0);
+    lg.tlast = leg == 0 ? td->leg[0].tlast : (leg == 1 ? td->leg[1].tlast : td->leg[2].tlast);
+    lg.inv_h = leg == 0 ? td->leg[0].inv_h : (leg == 1 ? td->leg[1].inv_h : td->leg[2].inv_h);
+    const int w_off = leg == 0 ? 0 : (leg == 1 ? dl.off_m : dl.off_n);
+    const int w_ext = leg == 0 ? ext_l : (leg == 1 ? ext_m : ext_n), w_lo = leg == 0 ? lo_l : (leg == 1 ? lo_m : lo_n);
+    const int z_ext = leg == 0 ? 2 * ext_l : w_ext;                       // L and its swapped copy are adjacent
+    const int z_max = max(2 * ext_l, max(ext_m, ext_n));
     double4_t accf[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}}, acce = {0, 0, 0, 0};
-    for (int p0 = 0; p0 < k.n_items; p0 += WAVE) {
-        TripletGeom tg;
-        TripletRec r;
-        bool valid = trio_walk_geom<WANT_F>(A, g, w, td, k, m, sm, p0 + lane, tg);
-        if (!(A.skip & 16)) valid = eval_triplet<WANT_F>(recs, td, tg, valid, r);
-        else { for (int a = 0; a < 3; a++) { r.first[a] = 3; for (int q = 0; q < 4; q++) { r.v[a][q] = tg.rl; r.d[a][q] = tg.rm; } } }
-        for (int part = 0; part < WAVE / dl.nstage; part++) {
-            const bool mine = valid && ((lane / dl.nstage) == part);
-            const unsigned long long mask = __ballot(mine);
-            if (mask == 0) continue;
-            // centre-role records come first in the walk, hence first in the stage
-            const int n_centre = WANT_E ? __popcll(__ballot(mine && tg.centre)) : 0;
-            if (mine) {
-                double *rec = w.stage + (size_t)mbcnt(mask) * dl.stride;
+    pc.lap(1);
+    for (int p0 = 0; p0 < k.n_items; p0 += DENSE_BATCH) {
+        // ---- walk: one triplet per lane, geometry to LDS in walk order (centre-role triplets first) ----------
+        int n_valid, n_centre_all;
+        {
+            TripletGeom tg;
+            bool valid = lane < DENSE_BATCH && p0 + lane < k.n_items;
+            if (valid && (A.skip & 2048)) { tg.rl = tg.rm = 2.9; tg.rn = 3.0 + 0.01 * lane; tg.centre = p0 + lane < k.cnt_c; tg.first = true;
+                for (int u = 0; u < 3; u++) { tg.a1[u] = 0.1; tg.a2[u] = 0.2; tg.a3[u] = 0.3; } }
+            else if (valid) valid = trio_walk_geom<WANT_F>(A, g, w, td, k, m, sm, p0 + lane, tg);
+            // leg masks t[0] <= r <= t[-1] (angles.py:502-508); both ends contribute nothing (see eval_triplet)
+            if (valid)
+                valid = (tg.rl > td->leg[0].t0) && (tg.rl < td->leg[0].tlast) && (tg.rm > td->leg[1].t0) &&
+                        (tg.rm < td->leg[1].tlast) && (tg.rn > td->leg[2].t0) && (tg.rn < td->leg[2].tlast);
+            const unsigned long long mask = __ballot(valid);
+            n_valid = __popcll(mask);
+            n_centre_all = __popcll(__ballot(valid && tg.centre));
+            if (valid) {
+                double *ge = w.geo + (size_t)mbcnt(mask) * GEO_STRIDE;
+                *(double2 *)(ge) = double2{tg.rl, tg.rm};
+                if (WANT_F) {
+                    const bool a_first = tg.centre || tg.first;
+                    const double v1[3] = {a_first ? tg.a1[0] : tg.a2[0], a_first ? tg.a1[1] : tg.a2[1], a_first ? tg.a1[2] : tg.a2[2]};
+                    const double v2[3] = {tg.centre ? tg.a2[0] : tg.a3[0], tg.centre ? tg.a2[1] : tg.a3[1], tg.centre ? tg.a2[2] : tg.a3[2]};
+                    *(double2 *)(ge + 2) = double2{tg.rn, v1[0]};
+                    *(double2 *)(ge + 4) = double2{v1[1], v1[2]};
+                    *(double2 *)(ge + 6) = double2{v2[0], v2[1]};
+                    *(double2 *)(ge + 8) = double2{v2[2], tg.centre ? 0.0 : (tg.first ? 1.0 : 2.0)};
+                } else ge[2] = tg.rn;
+            }
+        }
+        wave_sync();
+        pc.lap(2);
+        // ---- staging passes: lane (record li, leg) evaluates one leg and scatters it into the window ---------
+        for (int base = 0; base < n_valid; base += dl.nrec) {
+            const int n_part = min(dl.nrec, n_valid - base);
+            if (li < n_part && !(A.skip & 16)) {
+                const double *ge = w.geo + (size_t)(base + li) * GEO_STRIDE;
+                const double x = ge[leg == 2 && WANT_F ? 2 : leg];
+                KnotRec kr;
+                double v[4], d[4];
+                const int first = load_interval(recs, lg, x, kr) - 3;
+                bspline4<WANT_F>(kr, x, v, d);
+                double *rec = w.stage + (size_t)li * dl.stride;
                 const double2 zz = {0.0, 0.0};
-                for (int q = 0; q < dl.off_f; q += 2) *(double2 *)(rec + q) = zz;
+                for (int q = 0; q < z_max; q++) if (q < z_ext) *(double2 *)(rec + w_off + 2 * q) = zz;
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
-                    const unsigned wl = (unsigned)(r.first[0] + q - lo_l), wm = (unsigned)(r.first[1] + q - lo_m),
-                                   wn = (unsigned)(r.first[2] + q - lo_n);
-                    if (wl < (unsigned)ext_l) {
-                        *(double2 *)(rec + 2 * wl) = double2{r.v[0][q], WANT_F ? r.d[0][q] : 0.0};
-                        if (WANT_F) *(double2 *)(rec + dl.off_l1 + 2 * wl) = double2{r.d[0][q], r.v[0][q]};
+                    const unsigned ws = (unsigned)(first + q - w_lo);
+                    if (ws < (unsigned)w_ext) {
+                        *(double2 *)(rec + w_off + 2 * ws) = double2{v[q], WANT_F ? d[q] : 0.0};
+                        if (WANT_F && leg == 0) *(double2 *)(rec + dl.off_l1 + 2 * ws) = double2{d[q], v[q]};
                     }
-                    if (wm < (unsigned)ext_m) *(double2 *)(rec + dl.off_m + 2 * wm) = double2{r.v[1][q], WANT_F ? r.d[1][q] : 0.0};
-                    if (wn < (unsigned)ext_n) *(double2 *)(rec + dl.off_n + 2 * wn) = double2{r.v[2][q], WANT_F ? r.d[2][q] : 0.0};
                 }
-                if (WANT_F)
-#pragma unroll
-                    for (int q = 0; q < 3; q++) {
-                        *(double2 *)(rec + dl.off_f + 2 * q) = double2{tg.a1[q], tg.a2[q]};
-                        *(double2 *)(rec + dl.off_f + 6 + 2 * q) = double2{tg.a3[q], 0.0};
-                    }
-                *(double2 *)(rec + dl.off_z) = zz;
+                if (WANT_F) {                       // direction component `leg` of the three legs
+                    const double v1 = ge[3 + leg], v2 = ge[6 + leg], code = ge[9];
+                    const double a1 = code == 2.0 ? 0.0 : v1;
+                    const double a2 = code == 0.0 ? v2 : (code == 2.0 ? v1 : 0.0);
+                    const double a3 = code == 0.0 ? 0.0 : v2;
+                    *(double2 *)(rec + dl.off_f + 2 * leg) = double2{a1, a2};
+                    *(double2 *)(rec + dl.off_f + 6 + 2 * leg) = double2{a3, 0.0};
+                }
+                if (leg == 0) *(double2 *)(rec + dl.off_z) = zz;
             }
             wave_sync();
+            pc.lap(4);
+            const int n_centre = max(0, min(n_part, n_centre_all - base));
             if (!(A.skip & 8))
-                mfma_records<WANT_E, WANT_F>(w.stage, dl.stride, __popcll(mask), n_centre, a_l, a_m, a_f, a_n, e_l, e_m, e_n, accf, acce);
+                mfma_records<WANT_E, WANT_F>(w.stage, dl.stride, n_part, n_centre, a_l, a_m, a_f, a_n, c_l, c_f, e_row, e_l, e_m, e_n, accf, acce);
             wave_sync();
+            pc.lap(5);
         }
     }
     // accumulator window -> LDS (rows: 32 force rows (c, l, m), then 16 energy rows (l, m); 16 n bins each),
@@ -680,6 +792,7 @@ __device__ __forceinline__ void trio_block_mfma(const FeatArgs &A, const BasisDe
         if (WANT_E) es.add(td->col + col, en);
     }
     wave_sync();
+    pc.lap(6);
     // the dump left window values in the stage: stale slots must stay finite (they are multiplied by 0), which they are
 }
 
@@ -702,8 +815,9 @@ __device__ __forceinline__ void pair_block(const FeatArgs &A, const BasisDev *B,
                 valid = (int)c[4] == sx;
                 if (valid) {
                     double d = c[3];
-                    int i = find_interval(recs, pd.leg, d);
-                    bspline4<WANT_F>(recs[pd.leg.rec_off + i], d, v, dv);
+                    KnotRec kr;
+                    int i = load_interval(recs, pd.leg, d, kr);
+                    bspline4<WANT_F>(kr, d, v, dv);
                     first = i - 3;
                     double s = 2.0 / d;      // both directed images of the bond (distances.py:116-141)
                     dir[0] = s * c[0]; dir[1] = s * c[1]; dir[2] = s * c[2];
@@ -775,7 +889,8 @@ k_featurize(FeatArgs A) {
     const size_t stage_d = MODE == 0 ? cand_d + (size_t)NSTAGE * PAIR_STRIDE
                            : (MODE == 6 ? (size_t)A.dense_stage : (size_t)NSTAGE * ITEM_STRIDE);
     const size_t list_d = MODE == 0 ? 0 : 4 * (size_t)cap + ((4 * cap) & 1);
-    const size_t per_wave_d = list_d + stage_d + (stage_d & 1);
+    const size_t geo_d = MODE == 6 ? (size_t)DENSE_BATCH * GEO_STRIDE : 0;
+    const size_t per_wave_d = list_d + stage_d + (stage_d & 1) + geo_d;
     const size_t per_wave_i = MODE == 0 ? 0 : 3 * (size_t)cap + 2 * ((size_t)cap + 1) + (UF3_MAX_SPECIES + 2) +
                                                   (size_t)cap * (UF3_MAX_SPECIES + 1);
     double *wd = erow + e_d + (size_t)wave * per_wave_d;
@@ -783,6 +898,7 @@ k_featurize(FeatArgs A) {
     WaveLds w;
     w.ox = wd; w.oy = w.ox + cap; w.oz = w.oy + cap; w.orr = w.oz + cap;
     w.stage = wd + list_d;
+    w.geo = w.stage + stage_d + (stage_d & 1);
     w.cand = w.stage;
     w.pstage = w.stage + cand_d;
     w.oparent = wi; w.oshift = wi + cap; w.osidx = wi + 2 * cap;
@@ -877,6 +993,7 @@ k_featurize(FeatArgs A) {
         }
         // ---- 3-body ---------------------------------------------------------------------------
         if (MODE != 0 && B->T > 0) {
+            PhaseClock pcl;
             const int n = (A.skip & 64) ? 0 : A.n3.cnt[m];
             size_t base = (size_t)m * cap;
             wave_sync();
@@ -893,6 +1010,7 @@ k_featurize(FeatArgs A) {
                     w.ospoff[e * (UF3_MAX_SPECIES + 1) + sp] = A.n3.spoff[(size_t)w.oparent[e] * (UF3_MAX_SPECIES + 1) + sp];
                 }
             wave_sync();
+            pcl.lap(0);
             for (int t = 0; t < ((A.skip & 128) ? 0 : B->T); t++) {
                 const TrioDev *td = A.trios + t;
                 if (trio_mode(td) != MODE) continue;
@@ -942,12 +1060,13 @@ __device__ __forceinline__ bool trio_value(const BasisDev *B, const double *c3, 
     const TrioDev *td = B->trios + trio;
     if (!((rl > td->leg[0].t0) && (rl < td->leg[0].tlast) && (rm > td->leg[1].t0) && (rm < td->leg[1].tlast) &&
           (rn > td->leg[2].t0) && (rn < td->leg[2].tlast))) return false;
-    int il = find_interval(B->recs, td->leg[0], rl), im = find_interval(B->recs, td->leg[1], rm),
-        in = find_interval(B->recs, td->leg[2], rn);
+    KnotRec kl, km, kn;
+    int il = load_interval(B->recs, td->leg[0], rl, kl), im = load_interval(B->recs, td->leg[1], rm, km),
+        in = load_interval(B->recs, td->leg[2], rn, kn);
     double vl[4], vm[4], vn[4], dl[4], dm[4], dn[4];
-    bspline4<true>(B->recs[td->leg[0].rec_off + il], rl, vl, dl);
-    bspline4<true>(B->recs[td->leg[1].rec_off + im], rm, vm, dm);
-    bspline4<true>(B->recs[td->leg[2].rec_off + in], rn, vn, dn);
+    bspline4<true>(kl, rl, vl, dl);
+    bspline4<true>(km, rm, vm, dm);
+    bspline4<true>(kn, rn, vn, dn);
     int mn = td->dim_m * td->dim_n;
     const double *c = c3 + td->lut_off + (il - 3) * mn + (im - 3) * td->dim_n + (in - 3);
     double v = 0, g0 = 0, g1 = 0, g2 = 0;
@@ -993,9 +1112,10 @@ k_eval(EvalArgs A) {
         image_delta(g, sr, s0, s1, s2, pm, dx, dy, dz);
         double d = norm3_rn(dx, dy, dz);
         if (!(d > pd.rmin && d < pd.rmax)) return;
-        int i = find_interval(B->recs, pd.leg, d);
+        KnotRec kr;
+        int i = load_interval(B->recs, pd.leg, d, kr);
         double v[4], dv[4];
-        bspline4<true>(B->recs[pd.leg.rec_off + i], d, v, dv);
+        bspline4<true>(kr, d, v, dv);
         const double *c = A.c2 + (pd.col - B->S) + (i - 3);
         double phi = 0, dphi = 0;
         for (int q = 0; q < 4; q++) { phi += c[q] * v[q]; dphi += c[q] * dv[q]; }
@@ -1049,10 +1169,9 @@ k_eval(EvalArgs A) {
             for (int e0 = 0; e0 < n; e0 += WAVE) {
                 int q = e0 + lane;
                 int cnt = q < n ? A.n3.cnt[oparent[q]] : 0;
-                int incl = cnt;
-                for (int sh = 1; sh < WAVE; sh <<= 1) { int o = __shfl_up(incl, sh); if (lane >= sh) incl += o; }
+                const int incl = wave_scan_incl(cnt);
                 if (q < n) ooff[q] = total + incl - cnt;
-                total += __shfl(incl, WAVE - 1);
+                total += __builtin_amdgcn_readlane(incl, WAVE - 1);
             }
             if (lane == 0) ooff[n] = total;
             __syncthreads();
