@@ -369,3 +369,78 @@ def test_featurize_frames_chunking_is_transparent():
     a_e, a_f, off = fz.featurize_frames(frames)
     b_e, b_f, off2 = fz.featurize_frames(frames, max_bytes=40 * 24 * basis.n_feats)      # ~2 frames per chunk
     assert np.array_equal(off, off2) and rel_err(b_e, a_e) < 1e-12 and rel_err(b_f, a_f) < 1e-12
+
+
+def _fresh_rows(basis, frames, **env):
+    """Rows from a featurizer whose device tables are built under the given environment."""
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        basis.__dict__.pop("_device_cache", None)
+        fz = process.BasisFeaturizer(basis)
+        _, db = fz._dev()
+        modes = db.featurizer_modes
+        x_e, x_f, _ = fz.featurize_frames(frames)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+        basis.__dict__.pop("_device_cache", None)
+    return x_e, x_f, modes
+
+
+def _asymmetric_window_basis():
+    """Mo/W basis whose mixed trios have 2 x 5 x 16 kept bins (record stride 60: fewer than 21 records per pass)."""
+    from uf3_amd.data import composition
+    from uf3_amd.representation import bspline
+    cs = composition.ChemicalSystem(['Mo', 'W'], 3)
+    pairs, trios = cs.interactions_map[2], cs.interactions_map[3]
+    res = {p: 12 for p in pairs}
+    for t in trios:
+        res[t] = [5, 8, 19] if t[1] != t[2] else [6, 6, 12]
+    return bspline.BSplineBasis(
+        cs, r_min_map={**{p: 0.5 for p in pairs}, **{t: [1.5, 1.5, 1.5] for t in trios}},
+        r_max_map={**{p: 5.0 for p in pairs}, **{t: [3.6, 3.6, 7.2] for t in trios}},
+        resolution_map=res, leading_trim={2: 0, 3: 3}, trailing_trim={2: 3, 3: 3})
+
+
+@pytest.mark.parametrize("which", ["notebook_binary", "asymmetric_window", "h2o_golden", "w16_sym1", "w16_sym3"])
+def test_matrix_core_and_generic_trio_kernels_agree(which):
+    """The fp64 MFMA specialisation (mode bit 6) against the output-stationary kernels on the same inputs, and
+    both against the oracle."""
+    if which == "notebook_binary":
+        frames = [synthetic.lattice_frame("bcc", (3, 3, 4), 3.165, [42, 74], 11 + k) for k in range(2)]
+        basis = synthetic.notebook_basis(['Mo', 'W'])
+    elif which == "asymmetric_window":
+        frames = [synthetic.lattice_frame("bcc", (3, 4, 3), 3.2, [42, 74], 5, rattle=0.12)]
+        basis = _asymmetric_window_basis()
+    else:
+        d, meta, atoms = load_case({"h2o_golden": "case_h2o", "w16_sym1": "case_w16_sym1", "w16_sym3": "case_w16_sym3"}[which])
+        if which != "h2o_golden":        # the captured bases keep too many bins: trim the leading ones as well
+            meta = json.loads(json.dumps(meta))
+            meta["basis_kwargs"]["leading_trim"] = {"2": 0, "3": 3}
+            meta["basis_kwargs"]["trailing_trim"] = {"2": 3, "3": 3}
+        frames, basis = [atoms], basis_from_meta(meta)
+    xe_m, xf_m, modes_m = _fresh_rows(basis, frames)
+    xe_g, xf_g, modes_g = _fresh_rows(basis, frames, UF3_NO_MFMA_FEAT="1")
+    assert modes_m & (1 << 6), "expected the matrix-core specialisation for this basis"
+    assert not (modes_g & (1 << 6)) and (modes_g & 0x3e)
+    assert rel_err(xe_m, xe_g) < 1e-12 and rel_err(xf_m, xf_g) < 1e-12
+    ob = O.OracleBasis(basis)
+    off = 0
+    for k, fr in enumerate(frames):
+        ref = O.featurize(ob, fr)
+        assert rel_err(xe_m[k], ref["xe"]) < TOL
+        assert rel_err(xf_m[off:off + len(fr)].reshape(ref["xf"].shape), ref["xf"]) < TOL
+        off += len(fr)
+
+
+def test_wide_windows_stay_on_generic_kernels():
+    """leading_trim 0 keeps 6 x 6 x 12 bins per trio: too wide for the matrix-core tiles."""
+    fz = process.BasisFeaturizer(synthetic.notebook_basis(['W'], lead3=0))
+    modes = fz._dev()[1].featurizer_modes
+    assert not (modes & (1 << 6)) and (modes & 0x3e)
+    # the reference's default trims (3 leading, 3 trailing) give 3 x 3 x 9: matrix cores
+    assert process.BasisFeaturizer(synthetic.config_c3()[1])._dev()[1].featurizer_modes & (1 << 6)

@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("UF3_LIB_PATH", os.path.join(_HERE, "csrc", "libuf3hip
 
 EXPORTS = ["uf3_ctx_create", "uf3_ctx_destroy", "uf3_ctx_set_stream", "uf3_ctx_synchronize",
            "uf3_last_error", "uf3_ctx_timing_reset", "uf3_ctx_timing_read",
-           "uf3_basis_create", "uf3_basis_destroy",
+           "uf3_basis_create", "uf3_basis_destroy", "uf3_basis_featurizer_modes",
            "uf3_featurize", "uf3_featurize_dev", "uf3_gram", "uf3_gram_dev",
            "uf3_eval", "uf3_eval_dev", "uf3_eval_virial", "uf3_eval_virial_dev", "uf3_neighbors_debug"]
 
@@ -79,6 +79,7 @@ def load():
         lib.uf3_basis_create.argtypes = [vp, C.POINTER(BasisSpec), C.POINTER(vp)]
         lib.uf3_basis_destroy.argtypes = [vp]
         lib.uf3_basis_destroy.restype = None
+        lib.uf3_basis_featurizer_modes.argtypes = [vp, vp]
         for name in ("uf3_featurize", "uf3_featurize_dev"):
             getattr(lib, name).argtypes = [vp, C.POINTER(Frames), vp, vp, vp, vp]
         for name in ("uf3_gram", "uf3_gram_dev"):
@@ -210,6 +211,13 @@ class DeviceBasis:
         self.ctx.check(self.ctx.lib.uf3_basis_create(self.ctx.handle, C.byref(self.spec), C.byref(h)))
         self.handle = h
         self._pid = os.getpid()
+
+    @property
+    def featurizer_modes(self):
+        """Bit mask of the featurizer specialisations in use (include/uf3_hip.h: uf3_basis_featurizer_modes)."""
+        mask = C.c_int32(0)
+        self.ctx.check(self.ctx.lib.uf3_basis_featurizer_modes(self.handle, C.byref(mask)))
+        return mask.value
 
     def __del__(self):
         try:

@@ -360,6 +360,12 @@ extern "C" int uf3_basis_create(uf3_ctx *c, const uf3_basis_spec *s, uf3_basis *
     return UF3_OK;
 }
 
+extern "C" int uf3_basis_featurizer_modes(const uf3_basis *b, int32_t *mask) {
+    if (!b || !mask) return UF3_EINVAL;
+    *mask = b->modes;
+    return UF3_OK;
+}
+
 extern "C" void uf3_basis_destroy(uf3_basis *b) {
     if (!b) return;
     hipSetDevice(b->ctx->device);

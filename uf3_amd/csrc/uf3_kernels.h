@@ -228,7 +228,8 @@ struct FeatArgs {
     int n_recs;         // KnotRec count (for the LDS copy)
     int n_pair_recs;    // ... of which belong to the pair blocks (they come first)
     int dense_stage;    // doubles of per-wave stage the MFMA specialisation needs (max over dense trios)
-    int skip;           // profiling ablations (UF3_DEBUG_SKIP): 1 two-body, 2 centre role, 4 neighbour role
+    int skip;           // profiling ablations (UF3_DEBUG_SKIP): 1 two-body, 2 centre role, 4 neighbour role,
+                        // 8 MFMA steps, 16 leg evaluation + staging, 32 row stores (mode 6)
 };
 
 __device__ __forceinline__ void lds_add(double *p, double v) {
@@ -465,16 +466,13 @@ __device__ __forceinline__ bool trio_walk_geom(const FeatArgs &A, const FrameGeo
     } else if (valid) {
         int q = p - k.cnt_c;
         int lo = 0, hi = k.ncen - 1;                   // centre e with noff[e] <= q < noff[e+1]
-        if (A.skip & 1024) { lo = q % k.ncen; hi = lo; }
         while (lo < hi) { int mid = (lo + hi + 1) >> 1; if (w.noff[mid] <= q) lo = mid; else hi = mid - 1; }
         int e = k.rc_lo + lo, kk = w.nbase[lo] + (q - w.noff[lo]);
         int pc = w.oparent[e];
         size_t kb = (size_t)pc * cap + kk;
         int s0, s1, s2;
         unpack3(w.oshift[e], s0, s1, s2);
-        N3Entry ke;
-        if (A.skip & 512) { ke.dx = w.ox[e] * 0.5; ke.dy = w.oy[e] + 1.0; ke.dz = w.oz[e] - 1.0; ke.r = w.orr[e]; ke.parent = pc; ke.shiftc = w.oshift[e]; ke.sidx = w.osidx[e] + kk; ke.spec = 0; }
-        else ke = A.n3.ent[kb];
+        const N3Entry ke = A.n3.ent[kb];
         int kparent = ke.parent, kshift = ke.shiftc;
         valid = !(kparent == m && kshift == pack3(-s0, -s1, -s2));       // k is m itself
         if (valid) {
@@ -549,25 +547,26 @@ __device__ __forceinline__ void trio_block(const FeatArgs &A, const BasisDev *B,
 // ---- MFMA specialisation (MODE 6): dense accumulation of a small raw-bin window on the fp64 matrix cores ----
 // For one atom and trio block the force rows are X_c[l][m][n] = sum over records of
 //     P_c(l,m) * B_n(n) + Q_c(l,m) * B'_n(n),   P_c = B'_l B_m A1_c + B_l B'_m A2_c,   Q_c = B_l B_m A3_c,
-// i.e. a (3*Pk x 2T) * (2T x Nk) product with Pk = ext_l * ext_m window pairs and Nk = ext_n window bins.  One
-// v_mfma_f64_16x16x4 step consumes two records (K = {P, Q} x 2) per 16-row tile; the energy row is the same
-// product with A = B_l B_m (centre-role records only), four records per step.  The accumulators are the raw
-// window; the symmetry fold into columns happens once per (atom, block) through the colsrc table.
+// i.e. a (3*Pk x 2T) * (2T x Nk) product with Pk = ext_l * ext_m window pairs and Nk = ext_n window bins, on
+// v_mfma_f64_16x16x4 (rows (c, l, m) in two 16-row tiles, K = records x {P, Q}).  The accumulators are the raw
+// window; the symmetry fold into columns happens once per (atom, block) through the dsrc table.
 //
-// Staged record: the four values of each leg are scattered to their position inside the window, so that every
-// operand address is a per-lane constant plus the record stride (no per-record index arithmetic, no masks):
-//   L  (B, B') x ext_l | L~ (B', B) x ext_l | M (B, B') x ext_m | N (B, B') x ext_n |
-//   (A1_c, A2_c) c = x,y,z | (A3_c, 0) c = x,y,z | zero pair
-// K slot "P" lanes read L~, slot "Q" lanes read L:  a = (L.x * M.x) * F.x + (L.y * M.y) * F.y  serves both.
+// Records are walked 63 at a time (geometry to LDS), sorted into three classes, and staged 21 at a time by lanes
+// (record, leg) that evaluate one leg each and scatter its four values to their position inside the window, so
+// that every operand address in the MFMA loop is a per-lane constant plus the record stride:
+//   L (B, B') x ext_l | M (B, B') x ext_m | N (B, B') x ext_n | (A1_c, A2_c) c = x,y,z | (A3_c, 0) c = x,y,z | zero pair
+//   class 0  centre role (A3 = 0: no Q slot)         4 records per step, K index = record; energy tile rides along
+//   class 1  neighbour role, m on leg l (A2 = 0)     2 records per step, P = B'_l B_m A1_c     } single products:
+//   class 2  neighbour role, m on leg m (A1 = 0)     2 records per step, P = B_l B'_m A2_c     } 8-byte operands
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
 struct DenseLayout {
-    int off_l1, off_m, off_n, off_f, off_z, stride;      // in doubles (off_l0 = 0)
-    int nrec;                                             // records staged per pass (3 lanes each): <= 21
+    int off_m, off_n, off_f, off_z, stride;      // in doubles (L window at 0)
+    int nrec;                                     // records staged per pass (3 lanes each): <= 21
 };
 __host__ __device__ __forceinline__ DenseLayout dense_layout(int ext_l, int ext_m, int ext_n) {
     DenseLayout d;
-    d.off_l1 = 2 * ext_l; d.off_m = 4 * ext_l; d.off_n = d.off_m + 2 * ext_m; d.off_f = d.off_n + 2 * ext_n;
+    d.off_m = 2 * ext_l; d.off_n = d.off_m + 2 * ext_m; d.off_f = d.off_n + 2 * ext_n;
     d.off_z = d.off_f + 12; d.stride = d.off_z + 2;
     d.nrec = 1056 / d.stride;
     if (d.nrec > 21) d.nrec = 21;
@@ -575,73 +574,80 @@ __host__ __device__ __forceinline__ DenseLayout dense_layout(int ext_l, int ext_
 }
 #define DENSE_DUMP 768    // doubles: 32 force rows + 16 energy rows of 16 bins
 #define DENSE_BATCH 63    // triplets walked per step (three staging passes of 21)
-#define GEO_STRIDE 10     // doubles per walked triplet: rl, rm, rn | v1[3] | v2[3] | role code
+#define GEO_STRIDE 10     // doubles per walked triplet: rl, rm, rn | v1[3] | v2[3] | class
 
-template <bool WANT_E, bool WANT_F, bool MASK>
-__device__ __forceinline__ void mfma_pair(const double *rec, bool live, const int (&a_l)[2], const int (&a_m)[2],
-                                          const int (&a_f)[2], int a_n, double4_t (&accf)[2]) {
-    const double bv = rec[a_n];
-#pragma unroll
-    for (int tm = 0; tm < 2; tm++) {
-        const double2 L = *(const double2 *)(rec + a_l[tm]);
-        const double2 M = *(const double2 *)(rec + a_m[tm]);
-        const double2 Fv = *(const double2 *)(rec + a_f[tm]);
-        double av = fma(L.x * M.x, Fv.x, (L.y * M.y) * Fv.y);
-        if (MASK) av = live ? av : 0.0;
-        accf[tm] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, accf[tm], 0, 0, 0);
-    }
-}
+// per-lane operand offsets (doubles, relative to the record of the lane's K slot)
+struct DenseLane {
+    int l[2], m[2], f[2];    // row (c, l, m) of tile 0 / 1: L pair, M pair, (A1_c, A2_c) pair
+    int q;                   // 1 for K slot "Q" lanes of the two-record steps, else 0
+    int n;                   // N pair of this lane's window bin
+    bool e_row;              // tile-0 row is an energy row (c = x, pair < Pk)
+};
 
-// Centre-role records have A3 = 0, so their K slot "Q" is empty: they are consumed four per step (lanes' K index =
-// record), and the energy tile reuses the operands of force tile 0 (rows 0 .. Pk-1 of tile 0 are (x, l, m)).
 template <bool WANT_E, bool MASK>
-__device__ __forceinline__ void mfma_quad(const double *rec, bool live, const int (&c_l)[2], const int (&a_m)[2],
-                                          const int (&c_f)[2], int e_n, bool e_row, double4_t (&accf)[2], double4_t &acce) {
-    const double bv = rec[e_n];
+__device__ __forceinline__ void mfma_quad(const double *rec, bool live, const DenseLane &o, double4_t (&accf)[2], double4_t &acce) {
+    const double bv = rec[o.n];
 #pragma unroll
     for (int tm = 0; tm < 2; tm++) {
-        const double2 L = *(const double2 *)(rec + c_l[tm]);       // (B', B)
-        const double2 M = *(const double2 *)(rec + a_m[tm]);       // (B, B')
-        const double2 Fv = *(const double2 *)(rec + c_f[tm]);      // (A1_c, A2_c)
-        double av = fma(L.x * M.x, Fv.x, (L.y * M.y) * Fv.y);
+        const double2 L = *(const double2 *)(rec + o.l[tm]);
+        const double2 M = *(const double2 *)(rec + o.m[tm]);
+        const double2 Fv = *(const double2 *)(rec + o.f[tm]);
+        double av = fma(L.y * M.x, Fv.x, (L.x * M.y) * Fv.y);
         if (MASK) av = live ? av : 0.0;
         accf[tm] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, accf[tm], 0, 0, 0);
         if (WANT_E && tm == 0) {
-            double ae = e_row ? L.y * M.x : 0.0;
+            double ae = o.e_row ? L.x * M.x : 0.0;
             if (MASK) ae = live ? ae : 0.0;
             acce = __builtin_amdgcn_mfma_f64_16x16x4f64(ae, bv, acce, 0, 0, 0);
         }
     }
 }
 
+// two neighbour-role records per step; x/y/z: this lane's three factors (B or B' of leg l, of leg m, direction)
+template <bool MASK>
+__device__ __forceinline__ void mfma_pair(const double *rec, bool live, const int (&x)[2], const int (&y)[2], const int (&z)[2],
+                                          int bn, double4_t (&accf)[2]) {
+    const double bv = rec[bn];
+#pragma unroll
+    for (int tm = 0; tm < 2; tm++) {
+        double av = (rec[x[tm]] * rec[y[tm]]) * rec[z[tm]];
+        if (MASK) av = live ? av : 0.0;
+        accf[tm] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, accf[tm], 0, 0, 0);
+    }
+}
+
 template <bool WANT_E, bool WANT_F>
-__device__ __forceinline__ void mfma_records(const double *stage, int stride, int n_staged, int n_centre, const int (&a_l)[2],
-                                             const int (&a_m)[2], const int (&a_f)[2], int a_n, const int (&c_l)[2],
-                                             const int (&c_f)[2], bool e_row, int e_l, int e_m, int e_n,
+__device__ __forceinline__ void mfma_records(const double *stage, int stride, int n0, int n1, int n2, const DenseLane &o,
                                              double4_t (&accf)[2], double4_t &acce) {
     const int ks = lane_id() >> 4;
     if (WANT_F) {
-        {   // centre-role records [0, n_centre): four per step
+        {   // class 0: four records per step
             const double *rec = stage + (size_t)ks * stride;
-            const int n_full = n_centre & ~3;
+            const int n_full = n0 & ~3;
             int q = 0;
-            for (; q < n_full; q += 4, rec += 4 * stride) mfma_quad<WANT_E, false>(rec, true, c_l, a_m, c_f, e_n, e_row, accf, acce);
-            if (q < n_centre) mfma_quad<WANT_E, true>(rec, q + ks < n_centre, c_l, a_m, c_f, e_n, e_row, accf, acce);
+            for (; q < n_full; q += 4, rec += 4 * stride) mfma_quad<WANT_E, false>(rec, true, o, accf, acce);
+            if (q < n0) mfma_quad<WANT_E, true>(rec, q + ks < n0, o, accf, acce);
         }
-        {   // neighbour-role records [n_centre, n_staged): two per step (K = {P, Q} x 2)
-            const double *rec = stage + (size_t)(n_centre + (ks >> 1)) * stride;
-            const int n_nb = n_staged - n_centre, n_full = n_nb & ~1;
+        const int pl = 1 - o.q;                        // "P" lanes pick the derivative of the leg that joins centre and m
+        const int bn = o.n + o.q;                      // B operand: B_n for P slots, B'_n for Q slots
+#pragma unroll
+        for (int cls = 1; cls <= 2; cls++) {
+            const int cnt = cls == 1 ? n1 : n2, start = cls == 1 ? n0 : n0 + n1;
+            const int dx = cls == 1 ? pl : 0, dy = cls == 1 ? 0 : pl;
+            const int x[2] = {o.l[0] + dx, o.l[1] + dx}, y[2] = {o.m[0] + dy, o.m[1] + dy};
+            const int z[2] = {o.f[0] + 6 * o.q + dy, o.f[1] + 6 * o.q + dy};
+            const double *rec = stage + (size_t)(start + (ks >> 1)) * stride;
+            const int n_full = cnt & ~1;
             int q = 0;
 #pragma unroll 2
-            for (; q < n_full; q += 2, rec += 2 * stride) mfma_pair<WANT_E, WANT_F, false>(rec, true, a_l, a_m, a_f, a_n, accf);
-            if (q < n_nb) mfma_pair<WANT_E, WANT_F, true>(rec, (ks >> 1) == 0, a_l, a_m, a_f, a_n, accf);
+            for (; q < n_full; q += 2, rec += 2 * stride) mfma_pair<false>(rec, true, x, y, z, bn, accf);
+            if (q < cnt) mfma_pair<true>(rec, (ks >> 1) == 0, x, y, z, bn, accf);
         }
     } else if (WANT_E) {
         const double *rec = stage + (size_t)ks * stride;
-        for (int q = 0; q < n_centre; q += 4, rec += 4 * stride) {
-            const double L = rec[e_l], M = rec[e_m], N = rec[e_n];
-            const double av = (q + ks < n_centre) ? L * M : 0.0;
-            acce = __builtin_amdgcn_mfma_f64_16x16x4f64(av, N, acce, 0, 0, 0);
+        for (int q = 0; q < n0; q += 4, rec += 4 * stride) {
+            const double av = (q + ks < n0 && o.e_row) ? rec[o.l[0]] * rec[o.m[0]] : 0.0;
+            acce = __builtin_amdgcn_mfma_f64_16x16x4f64(av, rec[o.n], acce, 0, 0, 0);
         }
     }
 }
@@ -660,27 +666,23 @@ __device__ __forceinline__ void trio_block_mfma(const FeatArgs &A, const BasisDe
     const int ext_l = td->ext[0], ext_m = td->ext[1], ext_n = td->ext[2];
     const int Pk = ext_l * ext_m;
     const DenseLayout dl = dense_layout(ext_l, ext_m, ext_n);
-    const int r16 = lane & 15, type = (lane >> 4) & 1;
-    // per-lane operand offsets inside a record (doubles); small quotients by multiply-shift (exact for < 64)
+    const int r16 = lane & 15;
+    // per-lane operand offsets; small quotients by multiply-shift (exact for < 64)
     const int inv_pk = (65536 + Pk - 1) / Pk, inv_em = (65536 + ext_m - 1) / ext_m;      // wave-uniform
-    int a_l[2], a_m[2], a_f[2], c_l[2], c_f[2];
+    DenseLane o;
 #pragma unroll
     for (int tm = 0; tm < 2; tm++) {
         const int row = tm * 16 + r16;
         const int c = (row * inv_pk) >> 16, p = row - c * Pk;
         const int pl = (p * inv_em) >> 16, pm = p - pl * ext_m;
         const bool ok = row < 3 * Pk;
-        a_l[tm] = ok ? (type ? 0 : dl.off_l1) + 2 * pl : dl.off_z;
-        a_m[tm] = ok ? dl.off_m + 2 * pm : dl.off_z;
-        a_f[tm] = dl.off_f + 6 * type + 2 * (ok ? c : 0);
-        c_l[tm] = ok ? dl.off_l1 + 2 * pl : dl.off_z;          // centre-role steps: every K slot is a "P" slot
-        c_f[tm] = dl.off_f + 2 * (ok ? c : 0);
+        o.l[tm] = ok ? 2 * pl : dl.off_z;
+        o.m[tm] = ok ? dl.off_m + 2 * pm : dl.off_z;
+        o.f[tm] = ok ? dl.off_f + 2 * c : dl.off_z - 6;       // (+6 for Q lanes stays inside the record: zero pair)
     }
-    const bool e_row = r16 < Pk;
-    const int a_n = r16 < ext_n ? dl.off_n + 2 * r16 + type : dl.off_z;
-    const int el = (r16 * inv_em) >> 16;
-    const int e_l = r16 < Pk ? 2 * el : dl.off_z, e_m = dl.off_m + 2 * (r16 - el * ext_m);
-    const int e_n = r16 < ext_n ? dl.off_n + 2 * r16 : dl.off_z;
+    o.q = (lane >> 4) & 1;
+    o.n = r16 < ext_n ? dl.off_n + 2 * r16 : dl.off_z;
+    o.e_row = r16 < Pk;
     // staging role of this lane: leg `leg` of staged record `li` (lanes 3*li .. 3*li+2)
     const int li = (lane * 21846) >> 16, leg = lane - 3 * li;
     LegDev lg;
@@ -691,28 +693,26 @@ __device__ __forceinline__ void trio_block_mfma(const FeatArgs &A, const BasisDe
     lg.inv_h = leg == 0 ? td->leg[0].inv_h : (leg == 1 ? td->leg[1].inv_h : td->leg[2].inv_h);
     const int w_off = leg == 0 ? 0 : (leg == 1 ? dl.off_m : dl.off_n);
     const int w_ext = leg == 0 ? ext_l : (leg == 1 ? ext_m : ext_n), w_lo = leg == 0 ? lo_l : (leg == 1 ? lo_m : lo_n);
-    const int z_ext = leg == 0 ? 2 * ext_l : w_ext;                       // L and its swapped copy are adjacent
-    const int z_max = max(2 * ext_l, max(ext_m, ext_n));
+    const int z_max = max(ext_l, max(ext_m, ext_n));
     double4_t accf[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}}, acce = {0, 0, 0, 0};
     pc.lap(1);
     for (int p0 = 0; p0 < k.n_items; p0 += DENSE_BATCH) {
-        // ---- walk: one triplet per lane, geometry to LDS in walk order (centre-role triplets first) ----------
-        int n_valid, n_centre_all;
+        // ---- walk: one triplet per lane, geometry to LDS sorted by class ------------------------------------
+        int n0, n1, n2;
         {
             TripletGeom tg;
             bool valid = lane < DENSE_BATCH && p0 + lane < k.n_items;
-            if (valid && (A.skip & 2048)) { tg.rl = tg.rm = 2.9; tg.rn = 3.0 + 0.01 * lane; tg.centre = p0 + lane < k.cnt_c; tg.first = true;
-                for (int u = 0; u < 3; u++) { tg.a1[u] = 0.1; tg.a2[u] = 0.2; tg.a3[u] = 0.3; } }
-            else if (valid) valid = trio_walk_geom<WANT_F>(A, g, w, td, k, m, sm, p0 + lane, tg);
+            if (valid) valid = trio_walk_geom<WANT_F>(A, g, w, td, k, m, sm, p0 + lane, tg);
             // leg masks t[0] <= r <= t[-1] (angles.py:502-508); both ends contribute nothing (see eval_triplet)
             if (valid)
                 valid = (tg.rl > td->leg[0].t0) && (tg.rl < td->leg[0].tlast) && (tg.rm > td->leg[1].t0) &&
                         (tg.rm < td->leg[1].tlast) && (tg.rn > td->leg[2].t0) && (tg.rn < td->leg[2].tlast);
-            const unsigned long long mask = __ballot(valid);
-            n_valid = __popcll(mask);
-            n_centre_all = __popcll(__ballot(valid && tg.centre));
+            const bool is0 = valid && tg.centre, is1 = valid && !tg.centre && tg.first, is2 = valid && !tg.centre && !tg.first;
+            const unsigned long long m0 = __ballot(is0), m1 = __ballot(is1), m2 = __ballot(is2);
+            n0 = __popcll(m0); n1 = __popcll(m1); n2 = __popcll(m2);
             if (valid) {
-                double *ge = w.geo + (size_t)mbcnt(mask) * GEO_STRIDE;
+                const int rank = is0 ? mbcnt(m0) : (is1 ? n0 + mbcnt(m1) : n0 + n1 + mbcnt(m2));
+                double *ge = w.geo + (size_t)rank * GEO_STRIDE;
                 *(double2 *)(ge) = double2{tg.rl, tg.rm};
                 if (WANT_F) {
                     const bool a_first = tg.centre || tg.first;
@@ -721,32 +721,30 @@ __device__ __forceinline__ void trio_block_mfma(const FeatArgs &A, const BasisDe
                     *(double2 *)(ge + 2) = double2{tg.rn, v1[0]};
                     *(double2 *)(ge + 4) = double2{v1[1], v1[2]};
                     *(double2 *)(ge + 6) = double2{v2[0], v2[1]};
-                    *(double2 *)(ge + 8) = double2{v2[2], tg.centre ? 0.0 : (tg.first ? 1.0 : 2.0)};
+                    *(double2 *)(ge + 8) = double2{v2[2], is0 ? 0.0 : (is1 ? 1.0 : 2.0)};
                 } else ge[2] = tg.rn;
             }
         }
         wave_sync();
         pc.lap(2);
         // ---- staging passes: lane (record li, leg) evaluates one leg and scatters it into the window ---------
+        const int n_valid = n0 + n1 + n2;
         for (int base = 0; base < n_valid; base += dl.nrec) {
             const int n_part = min(dl.nrec, n_valid - base);
             if (li < n_part && !(A.skip & 16)) {
                 const double *ge = w.geo + (size_t)(base + li) * GEO_STRIDE;
-                const double x = ge[leg == 2 && WANT_F ? 2 : leg];
+                const double x = ge[leg];
                 KnotRec kr;
                 double v[4], d[4];
                 const int first = load_interval(recs, lg, x, kr) - 3;
                 bspline4<WANT_F>(kr, x, v, d);
                 double *rec = w.stage + (size_t)li * dl.stride;
                 const double2 zz = {0.0, 0.0};
-                for (int q = 0; q < z_max; q++) if (q < z_ext) *(double2 *)(rec + w_off + 2 * q) = zz;
+                for (int q = 0; q < z_max; q++) if (q < w_ext) *(double2 *)(rec + w_off + 2 * q) = zz;
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
                     const unsigned ws = (unsigned)(first + q - w_lo);
-                    if (ws < (unsigned)w_ext) {
-                        *(double2 *)(rec + w_off + 2 * ws) = double2{v[q], WANT_F ? d[q] : 0.0};
-                        if (WANT_F && leg == 0) *(double2 *)(rec + dl.off_l1 + 2 * ws) = double2{d[q], v[q]};
-                    }
+                    if (ws < (unsigned)w_ext) *(double2 *)(rec + w_off + 2 * ws) = double2{v[q], WANT_F ? d[q] : 0.0};
                 }
                 if (WANT_F) {                       // direction component `leg` of the three legs
                     const double v1 = ge[3 + leg], v2 = ge[6 + leg], code = ge[9];
@@ -760,9 +758,9 @@ __device__ __forceinline__ void trio_block_mfma(const FeatArgs &A, const BasisDe
             }
             wave_sync();
             pc.lap(4);
-            const int n_centre = max(0, min(n_part, n_centre_all - base));
-            if (!(A.skip & 8))
-                mfma_records<WANT_E, WANT_F>(w.stage, dl.stride, n_part, n_centre, a_l, a_m, a_f, a_n, c_l, c_f, e_row, e_l, e_m, e_n, accf, acce);
+            // class counts inside this pass
+            const int c0 = max(0, min(n_part, n0 - base)), c01 = max(0, min(n_part, n0 + n1 - base));
+            if (!(A.skip & 8)) mfma_records<WANT_E, WANT_F>(w.stage, dl.stride, c0, c01 - c0, n_part - c01, o, accf, acce);
             wave_sync();
             pc.lap(5);
         }
@@ -780,10 +778,10 @@ __device__ __forceinline__ void trio_block_mfma(const FeatArgs &A, const BasisDe
     for (int col = lane; col < ncol; col += WAVE) {
         double fx = 0, fy = 0, fz = 0, en = 0;
         for (int q = 0; q < nsrc; q++) {
-            const int o = dsrc[td->src_off + col * nsrc + q];
-            if (o < 0) continue;
-            if (WANT_F) { fx += dump[o]; fy += dump[Pk * 16 + o]; fz += dump[2 * Pk * 16 + o]; }
-            if (WANT_E) en += dump[512 + o];
+            const int off = dsrc[td->src_off + col * nsrc + q];
+            if (off < 0) continue;
+            if (WANT_F) { fx += dump[off]; fy += dump[Pk * 16 + off]; fz += dump[2 * Pk * 16 + off]; }
+            if (WANT_E) en += dump[512 + off];
         }
         if (WANT_F && !(A.skip & 32)) {
             double *dst = A.x_f + (size_t)m * 3 * F + td->col + col;
@@ -983,7 +981,6 @@ k_featurize(FeatArgs A) {
             });
             if (n_cand > A.cand_cap) { if (lane == 0) atomicMax(A.cand_need, n_cand); n_cand = A.cand_cap; }
             wave_sync();
-            if (A.skip & 256) n_cand = 0;
             for (int p = 0; p < B->P; p++) {
                 const PairDev &pd = B->pairs[p];
                 if (pd.sa == sm) pair_block<WANT_E, WANT_F>(A, B, recs, w, m, pd.sb, pd, n_cand, es);
@@ -994,7 +991,7 @@ k_featurize(FeatArgs A) {
         // ---- 3-body ---------------------------------------------------------------------------
         if (MODE != 0 && B->T > 0) {
             PhaseClock pcl;
-            const int n = (A.skip & 64) ? 0 : A.n3.cnt[m];
+            const int n = A.n3.cnt[m];
             size_t base = (size_t)m * cap;
             wave_sync();
             for (int e = lane; e < n; e += WAVE) {
@@ -1011,7 +1008,7 @@ k_featurize(FeatArgs A) {
                 }
             wave_sync();
             pcl.lap(0);
-            for (int t = 0; t < ((A.skip & 128) ? 0 : B->T); t++) {
+            for (int t = 0; t < B->T; t++) {
                 const TrioDev *td = A.trios + t;
                 if (trio_mode(td) != MODE) continue;
                 const bool touches = (td->sc == sm) || (WANT_F && (td->sa == sm || td->sb == sm));
