@@ -4,7 +4,7 @@
 
 Reads   <run>/trace/*_kernel_stats.csv           (rocprofv3 --kernel-trace --stats --output-format csv)
         <run>/pmc_fetch, <run>/pmc_write         (--pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes)
-        <run>/pmc1, <run>/pmc2                   (two passes of SQ counters)
+        <run>/pmc1, <run>/pmc2, <run>/pmc3       (passes of SQ counters; pmc3 = MFMA / LDS activity)
         <run>/bench_default.json, <run>/kernels.json
 Writes  <prefix>_kernel_stats.csv, <prefix>_hbm_counters.json, <prefix>_sq_counters.txt,
         <prefix>_bench_n1.json, <prefix>_secondary_kernels.json
@@ -77,17 +77,17 @@ def main(run, prefix):
         "note": "MI355X_MICROARCH.md: on gfx950 FETCH_SIZE can report 1/2 of the bytes of a wide coalesced "
                 "streaming read; the reads here are mostly 48-B gathers of neighbour-list entries, so the "
                 "uncorrected sum is quoted as `traffic` and the x2-corrected sum as the upper bound. Every "
-                "specialisation reads the neighbour lists again, and the trio specialisations read-modify-"
-                "write nothing: rows are written once per (atom, column range).",
+                "specialisation reads the neighbour lists again; nothing is read-modify-written: rows are "
+                "written once per (atom, column range).",
         "workload": {"atoms_per_frame": 10000, "n_feat": 434, "frames_per_step": 8},
     }
     json.dump(hbm, open(prefix + "_hbm_counters.json", "w"), indent=1)
 
-    lines = ["# rocprofv3 --pmc (two passes of 8 SQ counters), 8 frames x 10k atoms per step (F=434)",
+    lines = ["# rocprofv3 --pmc (separate passes of <= 8 SQ counters), 8 frames x 10k atoms per step (F=434)",
              "# SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles summed over waves; "
              "SQ_INSTS_* count wave-instructions", ""]
     sq = {}
-    for d in ("pmc1", "pmc2"):
+    for d in ("pmc1", "pmc2", "pmc3"):
         sq.update(featurize_counters(os.path.join(run, d)))
     kernels = sorted({k for per in sq.values() for k in per})
     for kern in kernels + ["ALL k_featurize launches of one step"]:
@@ -96,7 +96,7 @@ def main(run, prefix):
             per = sq[name]
             val = group_mean(per) if kern.startswith("ALL") else (
                 sum(per[kern]) / len(per[kern]) if kern in per else float("nan"))
-            lines.append(f"{name:<24} {val:.4g}")
+            lines.append(f"{name:<30} {val:.4g}")
         lines.append("")
     open(prefix + "_sq_counters.txt", "w").write("\n".join(lines))
     print(json.dumps({"rocprof_group_ms": rocprof_group_ms, "hip_events_ms": bench["roofline"]["launch_ms"],
