@@ -153,3 +153,80 @@ class UFCalculator(_Base):
                                     pbc=atoms.get_pbc()))
         e = self.evaluate_frames(frames, forces=False)[0]
         return np.array([(e[2 * k] - e[2 * k + 1]) / (2 * d * vol) for k in range(6)])
+
+    def relax_fmax(self, geom, fmax=0.05, relax_cell=True, verbose=False, timeout=60.0, max_steps=2000, dt=0.1):
+        """
+        Minimise the maximum force (reference: calculator.py:406-436, which drives ASE's BFGSLineSearch on an
+        ExpCellFilter).  ASE is not a dependency here: the same objective -- atomic forces, plus for fully
+        periodic frames with ``relax_cell`` the strain derivative (analytic virial) -- is minimised with FIRE
+        (Bitzek et al., PRL 97, 170201).  Returns a relaxed copy; warns and returns the last iterate on timeout.
+        """
+        import time
+        import warnings
+        from uf3_amd.data.atoms import Atoms
+        numbers = np.asarray(geom.get_atomic_numbers())
+        pos = np.array(geom.get_positions(), dtype=float)
+        cell0 = np.array(geom.get_cell(), dtype=float).reshape(3, 3)
+        pbc = np.asarray(geom.get_pbc(), dtype=bool)
+        with_cell = bool(relax_cell and np.all(pbc))
+        n = len(numbers)
+        # generalised coordinates: scaled positions * cell0 (so they are lengths) and, optionally, the deformation
+        # gradient D (cell = cell0 @ D), weighted by n like ASE's cell filters
+        frac = pos @ np.linalg.inv(cell0) if with_cell else None
+        D = np.eye(3)
+        x_vel = np.zeros((n + (3 if with_cell else 0), 3))
+        alpha0, f_inc, f_dec, f_alpha, n_min, dt_max = 0.1, 1.1, 0.5, 0.99, 5, 10 * dt
+        alpha, n_pos, t0 = alpha0, 0, time.time()
+
+        def evaluate(pos_, cell_):
+            frame = Atoms(numbers=numbers, positions=pos_, cell=cell_, pbc=pbc)
+            if with_cell:
+                e, f, _, v = self.evaluate_frames([frame], forces=True, virial=True)
+                vv = v[0]
+                sigma_v = np.array([[vv[0], vv[5], vv[4]], [vv[5], vv[1], vv[3]], [vv[4], vv[3], vv[2]]])   # dE/d(eps)
+                return float(e[0]), f, sigma_v
+            e, f, _ = self.evaluate_frames([frame], forces=True)
+            return float(e[0]), f, None
+
+        cell = cell0.copy()
+        for step in range(max_steps):
+            e, f, dE_deps = evaluate(pos, cell)
+            if with_cell:
+                # positions move with the cell: q = frac @ cell0, x = q @ D; dE/dq = -f @ D^T; dE/dD = D^-T dE/deps
+                g_cell = -(np.linalg.inv(D).T @ dE_deps) / max(n, 1)
+                force = np.vstack([f @ D.T, g_cell])
+                crit = max(np.abs(f).max(), np.abs(dE_deps).max() / max(n, 1))
+            else:
+                force, crit = f, np.abs(f).max()
+            if verbose:
+                print(f"relax_fmax step {step}: E = {e:.8f}  max|F| = {np.abs(f).max():.5f}")
+            if crit < fmax:
+                break
+            if (time.time() - t0) > timeout:
+                warnings.warn("Relaxation timed out.", RuntimeWarning)
+                break
+            power = float(np.sum(force * x_vel))
+            if power > 0:
+                fn, vn = np.linalg.norm(force), np.linalg.norm(x_vel)
+                x_vel = (1 - alpha) * x_vel + (alpha * vn / fn) * force if fn > 0 else x_vel
+                n_pos += 1
+                if n_pos > n_min:
+                    dt, alpha = min(dt * f_inc, dt_max), alpha * f_alpha
+            else:
+                x_vel[:] = 0.0
+                n_pos, dt, alpha = 0, dt * f_dec, alpha0
+            x_vel = x_vel + dt * force
+            step_x = dt * x_vel
+            big = np.abs(step_x).max()
+            if big > 0.2:                                   # trust radius (Angstrom / unit strain)
+                step_x *= 0.2 / big
+            if with_cell:
+                q = frac @ cell0 + step_x[:n]
+                frac = q @ np.linalg.inv(cell0)
+                D = D + step_x[n:] / max(n, 1)
+                cell = cell0 @ D
+                pos = frac @ cell
+            else:
+                pos = pos + step_x
+        return Atoms(numbers=numbers, positions=pos, cell=cell, pbc=pbc)
+
