@@ -41,6 +41,7 @@ struct uf3_ctx {
         n3_cnt, n3_int, n3_dbl, e_atom, coeff, stage_pos, stage_z, stage_out, stage_out2,
         gram_tiles, frag, dbg;
     int n3_cap = 0, cand_cap = 0;
+    bool n3_tuned = false;           // capacity re-sized once to the lists actually seen
     bool frag_ready = false;
     // timing
     bool timing = false;
@@ -63,7 +64,7 @@ struct uf3_basis {
     std::vector<int> block_bounds;   // column boundaries of interaction blocks (for column windows)
     size_t c2_len = 0, c3_len = 0, n_recs = 0;
     size_t n_pair_recs = 0;
-    int dense_stage = DENSE_DUMP;    // per-wave LDS stage (doubles) of the MFMA featurizer specialisation
+    int dense_stride = 24;           // largest staged-record stride (doubles) among the dense trios
     int modes = 1;                   // bit m set: some trio block is handled by featurizer specialisation m
     double r_cut = 0;
 };
@@ -325,7 +326,7 @@ extern "C" int uf3_basis_create(uf3_ctx *c, const uf3_basis_spec *s, uf3_basis *
         if (3 * td.ext[0] * td.ext[1] <= 32 && td.ext[2] <= 16 && !getenv("UF3_NO_MFMA_FEAT")) {
             td.dense = 1;
             DenseLayout dl = dense_layout(td.ext[0], td.ext[1], td.ext[2]);
-            b->dense_stage = std::max(b->dense_stage, std::max(DENSE_DUMP, dl.nrec * dl.stride));
+            b->dense_stride = std::max(b->dense_stride, dl.stride);
         }
         b->modes |= 1 << (td.dense ? 6 : td.nsrc == 1 ? (td.ncol > WAVE ? 2 : 1) : (td.nsrc == 2 ? (td.ncol > WAVE ? 4 : 3) : 5));
         for (auto &v : per_col) for (int k = 0; k < td.nsrc; k++) {
@@ -607,7 +608,21 @@ static int prepare(uf3_basis *b, const uf3_frames *fr, const double *d_pos, cons
             int need = 0;
             HIPCHK(c, hipMemcpyAsync(&need, flags + 1, sizeof(int), hipMemcpyDeviceToHost, st));
             HIPCHK(c, hipStreamSynchronize(st));
-            if (need <= cap) return check_flags(c);
+            if (need <= cap) {
+                if (!c->n3_tuned) {
+                    // the density estimate is generous; later calls pad to what this batch really needed (a batch
+                    // that needs more trips the overflow path above and grows the capacity again)
+                    c->n3_tuned = true;
+                    HIPCHK(c, hipMemsetAsync(flags + 3, 0, sizeof(int), st));
+                    hipLaunchKernelGGL(k_max_count, dim3(64), dim3(256), 0, st, P.n3.cnt, natoms, flags + 3);
+                    int seen = 0;
+                    HIPCHK(c, hipMemcpyAsync(&seen, flags + 3, sizeof(int), hipMemcpyDeviceToHost, st));
+                    HIPCHK(c, hipStreamSynchronize(st));
+                    c->n3_cap = std::max(8, (seen + 7) / 8 * 8);
+                }
+                return check_flags(c);
+            }
+            c->n3_tuned = true;
             c->n3_cap = (need + 8 + 7) / 8 * 8;
         }
         return fail(c, UF3_EOVERFLOW, "3-body neighbour capacity did not converge");
@@ -618,16 +633,19 @@ static int prepare(uf3_basis *b, const uf3_frames *fr, const double *d_pos, cons
 // ------------------------------------------------------------------------------ featurize
 static int ensure_frag(uf3_ctx *c);
 
-static size_t feat_lds_bytes(int F, int cap, int cand_cap, bool want_e, size_t n_recs, int mode, int dense_stage) {
+// LDS bytes of one featurizer workgroup; must mirror the carve at the top of k_featurize
+static size_t feat_lds_bytes(int F, int S, int cap, int cand_cap, bool want_e, size_t n_recs, int mode, int dense_stage,
+                             int dense_nrec) {
+    const bool dense = mode >= 6;
     size_t e_d = want_e ? (size_t)F + (F & 1) : 0;
     size_t cand_d = (size_t)cand_cap * 5 + ((cand_cap * 5) & 1);
     size_t stage_d = mode == 0 ? cand_d + (size_t)NSTAGE * PAIR_STRIDE
-                     : (mode == 6 ? (size_t)dense_stage : (size_t)NSTAGE * ITEM_STRIDE);
-    size_t list_d = mode == 0 ? 0 : 4 * (size_t)cap + ((4 * cap) & 1);
-    size_t geo_d = mode == 6 ? (size_t)DENSE_BATCH * GEO_STRIDE : 0;
+                     : (dense ? (size_t)dense_stage : (size_t)NSTAGE * ITEM_STRIDE);
+    size_t list_d = mode == 0 ? 0 : 5 * (size_t)cap + ((5 * cap) & 1);
+    size_t geo_d = dense ? (size_t)3 * dense_nrec * GEO_STRIDE : 0;
     size_t per_wave_d = list_d + stage_d + (stage_d & 1) + geo_d;
     size_t per_wave_i = mode == 0 ? 0 : 3 * (size_t)cap + 2 * ((size_t)cap + 1) + (UF3_MAX_SPECIES + 2) +
-                                        (size_t)cap * (UF3_MAX_SPECIES + 1);
+                                        (size_t)cap * (S + 1);
     size_t ints = ((size_t)WPB * per_wave_i + 3) & ~(size_t)3;
     return (e_d + WPB * per_wave_d) * 8 + ints * 4 + n_recs * sizeof(KnotRec) + 32;
 }
@@ -653,9 +671,10 @@ extern "C" int uf3_featurize_dev(uf3_basis *b, const uf3_frames *fr, const doubl
     FeatArgs A;
     A.B = b->dev; A.trios = b->d_trios; A.recs = b->d_recs; A.colsrc = b->d_colsrc;
     A.frag = nullptr;
-    A.dense_stage = b->dense_stage;
+    A.dense_stage = DENSE_DUMP; A.dense_nrec = DENSE_NREC;
     A.dsrc = b->d_dsrc; A.n_dsrc = (int)b->n_dsrc;
-    A.dsrc_lds = (b->modes & (1 << 6)) && b->n_dsrc * sizeof(int) <= 8192;
+    const bool dsrc_ok = (b->modes & (1 << 6)) && b->n_dsrc * sizeof(int) <= 8192 && !getenv("UF3_NO_LDS_DSRC");
+    A.dsrc_lds = dsrc_ok;
     if (b->modes & (1 << 6)) { rc = ensure_frag(c); if (rc) return rc; A.frag = c->frag.as<int>(); }
     A.geoms = P.geoms; A.frame_of = P.frame_of; A.cl = P.cl; A.n3 = P.n3;
     if (!A.n3.cap) A.n3.cap = 1;
@@ -674,12 +693,43 @@ extern "C" int uf3_featurize_dev(uf3_basis *b, const uf3_frames *fr, const doubl
                 if (!(b->modes & (1 << mode))) continue;
                 // knot records go to LDS when the block then still reaches the occupancy its registers allow
                 size_t n_rec_mode = mode == 0 ? b->n_pair_recs : b->n_recs;
+                const int S = b->host.S;
+                const size_t cu_lds = 160 * 1024 - 1024;
+                if (mode == 6) A.dsrc_lds = dsrc_ok;
                 size_t lds_extra = (mode == 6 && A.dsrc_lds) ? sizeof(int) * b->n_dsrc : 0;
-                size_t lds_plain = feat_lds_bytes(F, cap, A.cand_cap, want_e, 0, mode, A.dense_stage) + lds_extra;
-                size_t lds_recs = feat_lds_bytes(F, cap, A.cand_cap, want_e, n_rec_mode, mode, A.dense_stage) + lds_extra;
-                const size_t lds_target = (size_t)(160 * 1024 - 1024) / (mode == 0 ? 4 : 2);
-                bool recs_lds = lds_recs <= lds_target && !getenv("UF3_NO_LDS_RECS");
-                size_t lds = recs_lds ? lds_recs : lds_plain;
+                int launch_mode = mode;
+                bool recs_lds = false;
+                size_t lds = 0, lds_plain = 0, lds_recs = 0;
+                if (mode == 6) {
+                    // records per staging pass: as many as the stage allows; fewer (smaller stage and geometry
+                    // buffer) if that lets a third workgroup onto the CU -- the kernel is latency-bound
+                    const int nrec_max = std::max(4, std::min(DENSE_NREC, 1056 / b->dense_stride));
+                    const int tries[3] = {nrec_max, std::min(nrec_max, 18), std::min(nrec_max, 15)};
+                    // three workgroups per CU need <= 52 KB each (LDS is granted in coarse granules: 53 KB did not fit)
+                    const size_t budget = 52 * 1024;
+                    const bool dsrc_allowed = A.dsrc_lds;
+                    bool found = false;
+                    for (int q = 0; q < 6 && !found && !getenv("UF3_NO_OCC3"); q++) {
+                        const int nr = tries[q / 2];
+                        const bool with_dsrc = dsrc_allowed && (q % 2 == 0);
+                        if (!dsrc_allowed && (q % 2 == 0)) continue;
+                        int stage = std::max(DENSE_DUMP, nr * b->dense_stride);
+                        size_t need = feat_lds_bytes(F, S, cap, A.cand_cap, want_e, n_rec_mode, 6, stage, nr) +
+                                      (with_dsrc ? sizeof(int) * b->n_dsrc : 0);
+                        if (need <= budget) {
+                            found = true; launch_mode = 7; recs_lds = true; lds = lds_recs = need;
+                            A.dense_nrec = nr; A.dense_stage = stage; A.dsrc_lds = with_dsrc;
+                        }
+                    }
+                    if (!found) { A.dense_nrec = nrec_max; A.dense_stage = std::max(DENSE_DUMP, nrec_max * b->dense_stride); }
+                }
+                if (launch_mode != 7) {
+                    lds_plain = feat_lds_bytes(F, S, cap, A.cand_cap, want_e, 0, mode, A.dense_stage, A.dense_nrec) + lds_extra;
+                    lds_recs = feat_lds_bytes(F, S, cap, A.cand_cap, want_e, n_rec_mode, mode, A.dense_stage, A.dense_nrec) + lds_extra;
+                    const size_t lds_target = cu_lds / (mode == 0 ? 4 : 2);
+                    recs_lds = lds_recs <= lds_target && !getenv("UF3_NO_LDS_RECS");
+                    lds = recs_lds ? lds_recs : lds_plain;
+                }
                 if (lds > 160 * 1024 - 512) return fail(c, UF3_EOVERFLOW, "featurizer LDS footprint exceeds 160 KB (F or neighbour count too large)");
                 // blocks of WPB waves, each walking a contiguous run of atoms (keeps the shared energy row on
                 // one frame); about two blocks per resident slot for tail balance
@@ -690,8 +740,8 @@ extern "C" int uf3_featurize_dev(uf3_basis *b, const uf3_frames *fr, const doubl
                 A.atoms_per_block = apb;
                 if (getenv("UF3_DEBUG_LDS"))
                     fprintf(stderr, "uf3 featurize mode %d: lds %zu B (plain %zu, with recs %zu), recs_lds %d, cap %d, cand_cap %d, "
-                            "blocks %d x %d atoms, n_recs %zu\n", mode, lds, lds_plain, lds_recs, (int)recs_lds, cap, A.cand_cap,
-                            n_blocks, apb, n_rec_mode);
+                            "blocks %d x %d atoms, n_recs %zu, dense nrec %d stage %d\n", launch_mode, lds, lds_plain, lds_recs,
+                            (int)recs_lds, cap, A.cand_cap, n_blocks, apb, n_rec_mode, A.dense_nrec, A.dense_stage);
 #define UF3_LAUNCH1(E, Fo, R, M)                                                                                      \
     do {                                                                                                            \
         HIPCHK(c, hipFuncSetAttribute((const void *)k_featurize<E, Fo, R, M>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
@@ -703,14 +753,15 @@ extern "C" int uf3_featurize_dev(uf3_basis *b, const uf3_frames *fr, const doubl
         else if (want_f) { if (recs_lds) UF3_LAUNCH1(false, true, true, M); else UF3_LAUNCH1(false, true, false, M); }       \
         else { if (recs_lds) UF3_LAUNCH1(true, false, true, M); else UF3_LAUNCH1(true, false, false, M); }                  \
     } while (0)
-                switch (mode) {
+                switch (launch_mode) {
                     case 0: UF3_LAUNCH(0); break;
                     case 1: UF3_LAUNCH(1); break;
                     case 2: UF3_LAUNCH(2); break;
                     case 3: UF3_LAUNCH(3); break;
                     case 4: UF3_LAUNCH(4); break;
                     case 5: UF3_LAUNCH(5); break;
-                    default: UF3_LAUNCH(6); break;
+                    case 6: UF3_LAUNCH(6); break;
+                    default: UF3_LAUNCH(7); break;
                 }
 #undef UF3_LAUNCH
 #undef UF3_LAUNCH1

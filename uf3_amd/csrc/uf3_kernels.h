@@ -158,6 +158,14 @@ k_build_n3(const BasisDev *B, const FrameGeom *geoms, const int *frame_of, CellL
 }
 
 
+// largest list length of a batch (capacity tuning after the first build of a context)
+__global__ void k_max_count(const int *cnt, int n, int *out) {
+    int v = 0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) v = max(v, cnt[i]);
+    for (int sh = 32; sh > 0; sh >>= 1) v = max(v, __shfl_xor(v, sh));
+    if ((threadIdx.x & 63) == 0) atomicMax(out, v);
+}
+
 // Which of the two neighbours (m itself, or k) of centre c is the reference's "j" (leg l)?
 // Different species: the lower atomic number.  Same species: the reference keeps pairs j < k by
 // supercell index (angles.py:474).  Its force loop numbers atoms in the TRUE supercell even when
@@ -228,6 +236,7 @@ struct FeatArgs {
     int n_recs;         // KnotRec count (for the LDS copy)
     int n_pair_recs;    // ... of which belong to the pair blocks (they come first)
     int dense_stage;    // doubles of per-wave stage the MFMA specialisation needs (max over dense trios)
+    int dense_nrec;     // records staged per pass by the MFMA specialisation (<= DENSE_NREC)
     int skip;           // profiling ablations (UF3_DEBUG_SKIP): 1 two-body, 2 centre role, 4 neighbour role,
                         // 8 MFMA steps, 16 leg evaluation + staging, 32 row stores (mode 6)
 };
@@ -260,6 +269,7 @@ struct TripletGeom {
     double a1[3], a2[3], a3[3];
     bool centre;
     bool first;      // neighbour role: m is the trio's first neighbour (leg l joins the centre and m)
+    int i1, i2;      // own-list entries the unit vectors come from: (aa, bb) centre role, (e, -) neighbour role
 };
 
 struct TripletRec {
@@ -375,12 +385,13 @@ __device__ __forceinline__ void stage_and_gather(const TripletGeom &t, const Tri
 
 // per-wave scratch in LDS
 struct WaveLds {
-    double *ox, *oy, *oz, *orr;       // own 3-body neighbour list [cap]
+    double *ox, *oy, *oz, *orr, *oir; // own 3-body neighbour list [cap]: vector, length, 1 / length
     int *oparent, *oshift, *osidx;
     int *noff, *nbase;                 // neighbour-role prefix [cap+1] / start index [cap]
     int *so;                           // species offsets in the own list [S+1]
-    int *ospoff;                       // species offsets of every own neighbour's list [cap][UF3_MAX_SPECIES+1]
-    double *geo;                       // MFMA specialisation: geometry of the walked triplets [DENSE_BATCH][GEO_STRIDE]
+    int *ospoff;                       // species offsets of every own neighbour's list [cap][S+1]
+    int sp_stride;                     // S + 1
+    double *geo;                       // MFMA specialisation: geometry of the walked triplets [3 * nrec][GEO_STRIDE]
     double *stage;                     // NSTAGE triplet / pair records
     double *cand;                      // 2-body candidates [cand_cap][5] (aliases stage)
     double *pstage;                    // pair records (behind the candidates, inside stage)
@@ -417,7 +428,7 @@ __device__ __forceinline__ void trio_walk_setup(const FeatArgs &A, const WaveLds
                 int e = e0 + lane;
                 int cnt = 0, base = 0;
                 if (e < k.ncen) {
-                    const int *sp = w.ospoff + (size_t)(k.rc_lo + e) * (UF3_MAX_SPECIES + 1);
+                    const int *sp = w.ospoff + (size_t)(k.rc_lo + e) * w.sp_stride;
                     base = sp[k.sx]; cnt = sp[k.sx + 1] - base;
                 }
                 const int incl = wave_scan_incl(cnt);
@@ -445,6 +456,7 @@ __device__ __forceinline__ bool trio_walk_geom(const FeatArgs &A, const FrameGeo
     bool valid = p < k.n_items;
     tg.centre = p < k.cnt_c;
     tg.first = false;
+    tg.i1 = tg.i2 = 0;
     if (valid && tg.centre) {
         int aa, bb;
         if (sa == sb) {
@@ -455,10 +467,11 @@ __device__ __forceinline__ bool trio_walk_geom(const FeatArgs &A, const FrameGeo
             aa += k.ra_lo; bb += k.ra_lo;
         } else { aa = k.ra_lo + p / k.nb_; bb = k.rb_lo + p % k.nb_; }
         tg.rl = w.orr[aa]; tg.rm = w.orr[bb];
+        tg.i1 = aa; tg.i2 = bb;
         double ex = w.ox[bb] - w.ox[aa], ey = w.oy[bb] - w.oy[aa], ez = w.oz[bb] - w.oz[aa];
         tg.rn = norm3_rn(ex, ey, ez);
         if (WANT_F) {
-            double il = 1.0 / tg.rl, im = 1.0 / tg.rm;
+            double il = w.oir[aa], im = w.oir[bb];
             tg.a1[0] = w.ox[aa] * il; tg.a1[1] = w.oy[aa] * il; tg.a1[2] = w.oz[aa] * il;
             tg.a2[0] = w.ox[bb] * im; tg.a2[1] = w.oy[bb] * im; tg.a2[2] = w.oz[bb] * im;
             tg.a3[0] = tg.a3[1] = tg.a3[2] = 0.0;
@@ -483,7 +496,8 @@ __device__ __forceinline__ bool trio_walk_geom(const FeatArgs &A, const FrameGeo
             tg.rn = norm3_rn(ex, ey, ez);
             bool m_first = neighbour_is_first(g, sm, k.sx, s0, s1, s2, m_local, msidx, ksidx, kshift,
                                               kparent - g.atom_lo);
-            double ie = 1.0 / w.orr[e], in = 1.0 / tg.rn;
+            tg.i1 = e; tg.i2 = e;
+            double ie = w.oir[e], in = 1.0 / tg.rn;
             double ue[3] = {w.ox[e] * ie, w.oy[e] * ie, w.oz[e] * ie};
             tg.a3[0] = ex * in; tg.a3[1] = ey * in; tg.a3[2] = ez * in;
             tg.first = m_first;
@@ -554,7 +568,7 @@ __device__ __forceinline__ void trio_block(const FeatArgs &A, const BasisDev *B,
 // Records are walked 63 at a time (geometry to LDS), sorted into three classes, and staged 21 at a time by lanes
 // (record, leg) that evaluate one leg each and scatter its four values to their position inside the window, so
 // that every operand address in the MFMA loop is a per-lane constant plus the record stride:
-//   L (B, B') x ext_l | M (B, B') x ext_m | N (B, B') x ext_n | (A1_c, A2_c) c = x,y,z | (A3_c, 0) c = x,y,z | zero pair
+//   L (B, B') x ext_l | M (B, B') x ext_m | N (B, B') x ext_n | (A1_c, A2_c) c = x,y,z | A3_c c = x,y,z, pad | zero pair
 //   class 0  centre role (A3 = 0: no Q slot)         4 records per step, K index = record; energy tile rides along
 //   class 1  neighbour role, m on leg l (A2 = 0)     2 records per step, P = B'_l B_m A1_c     } single products:
 //   class 2  neighbour role, m on leg m (A1 = 0)     2 records per step, P = B_l B'_m A2_c     } 8-byte operands
@@ -562,23 +576,21 @@ typedef double double4_t __attribute__((ext_vector_type(4)));
 
 struct DenseLayout {
     int off_m, off_n, off_f, off_z, stride;      // in doubles (L window at 0)
-    int nrec;                                     // records staged per pass (3 lanes each): <= 21
 };
 __host__ __device__ __forceinline__ DenseLayout dense_layout(int ext_l, int ext_m, int ext_n) {
     DenseLayout d;
     d.off_m = 2 * ext_l; d.off_n = d.off_m + 2 * ext_m; d.off_f = d.off_n + 2 * ext_n;
-    d.off_z = d.off_f + 12; d.stride = d.off_z + 2;
-    d.nrec = 1056 / d.stride;
-    if (d.nrec > 21) d.nrec = 21;
+    d.off_z = d.off_f + 10; d.stride = d.off_z + 2;
     return d;
 }
 #define DENSE_DUMP 768    // doubles: 32 force rows + 16 energy rows of 16 bins
-#define DENSE_BATCH 63    // triplets walked per step (three staging passes of 21)
-#define GEO_STRIDE 10     // doubles per walked triplet: rl, rm, rn | v1[3] | v2[3] | class
+#define DENSE_NREC 21     // records staged per pass (3 lanes each), upper bound; the launch may use fewer
+#define GEO_STRIDE 8      // doubles per walked triplet: rl, rm, rn | e[3] (neighbour role: m -> k) | packed ints | pad
 
 // per-lane operand offsets (doubles, relative to the record of the lane's K slot)
 struct DenseLane {
     int l[2], m[2], f[2];    // row (c, l, m) of tile 0 / 1: L pair, M pair, (A1_c, A2_c) pair
+    int g[2];                // ... A3_c
     int q;                   // 1 for K slot "Q" lanes of the two-record steps, else 0
     int n;                   // N pair of this lane's window bin
     bool e_row;              // tile-0 row is an energy row (c = x, pair < Pk)
@@ -626,7 +638,8 @@ __device__ __forceinline__ void mfma_records(const double *stage, int stride, in
             const int n_full = n0 & ~3;
             int q = 0;
             for (; q < n_full; q += 4, rec += 4 * stride) mfma_quad<WANT_E, false>(rec, true, o, accf, acce);
-            if (q < n0) mfma_quad<WANT_E, true>(rec, q + ks < n0, o, accf, acce);
+            // (lanes past the end read record 0: whatever lies behind the stage need not be finite)
+            if (q < n0) mfma_quad<WANT_E, true>(q + ks < n0 ? rec : stage, q + ks < n0, o, accf, acce);
         }
         const int pl = 1 - o.q;                        // "P" lanes pick the derivative of the leg that joins centre and m
         const int bn = o.n + o.q;                      // B operand: B_n for P slots, B'_n for Q slots
@@ -635,19 +648,20 @@ __device__ __forceinline__ void mfma_records(const double *stage, int stride, in
             const int cnt = cls == 1 ? n1 : n2, start = cls == 1 ? n0 : n0 + n1;
             const int dx = cls == 1 ? pl : 0, dy = cls == 1 ? 0 : pl;
             const int x[2] = {o.l[0] + dx, o.l[1] + dx}, y[2] = {o.m[0] + dy, o.m[1] + dy};
-            const int z[2] = {o.f[0] + 6 * o.q + dy, o.f[1] + 6 * o.q + dy};
+            const int z[2] = {o.q ? o.g[0] : o.f[0] + dy, o.q ? o.g[1] : o.f[1] + dy};
             const double *rec = stage + (size_t)(start + (ks >> 1)) * stride;
             const int n_full = cnt & ~1;
             int q = 0;
 #pragma unroll 2
             for (; q < n_full; q += 2, rec += 2 * stride) mfma_pair<false>(rec, true, x, y, z, bn, accf);
-            if (q < cnt) mfma_pair<true>(rec, (ks >> 1) == 0, x, y, z, bn, accf);
+            if (q < cnt) mfma_pair<true>((ks >> 1) == 0 ? rec : stage, (ks >> 1) == 0, x, y, z, bn, accf);
         }
     } else if (WANT_E) {
         const double *rec = stage + (size_t)ks * stride;
         for (int q = 0; q < n0; q += 4, rec += 4 * stride) {
-            const double av = (q + ks < n0 && o.e_row) ? rec[o.l[0]] * rec[o.m[0]] : 0.0;
-            acce = __builtin_amdgcn_mfma_f64_16x16x4f64(av, rec[o.n], acce, 0, 0, 0);
+            const double *r = q + ks < n0 ? rec : stage;
+            const double av = (q + ks < n0 && o.e_row) ? r[o.l[0]] * r[o.m[0]] : 0.0;
+            acce = __builtin_amdgcn_mfma_f64_16x16x4f64(av, r[o.n], acce, 0, 0, 0);
         }
     }
 }
@@ -678,7 +692,8 @@ __device__ __forceinline__ void trio_block_mfma(const FeatArgs &A, const BasisDe
         const bool ok = row < 3 * Pk;
         o.l[tm] = ok ? 2 * pl : dl.off_z;
         o.m[tm] = ok ? dl.off_m + 2 * pm : dl.off_z;
-        o.f[tm] = ok ? dl.off_f + 2 * c : dl.off_z - 6;       // (+6 for Q lanes stays inside the record: zero pair)
+        o.f[tm] = ok ? dl.off_f + 2 * c : dl.off_z;
+        o.g[tm] = ok ? dl.off_f + 6 + c : dl.off_z;
     }
     o.q = (lane >> 4) & 1;
     o.n = r16 < ext_n ? dl.off_n + 2 * r16 : dl.off_z;
@@ -696,12 +711,13 @@ __device__ __forceinline__ void trio_block_mfma(const FeatArgs &A, const BasisDe
     const int z_max = max(ext_l, max(ext_m, ext_n));
     double4_t accf[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}}, acce = {0, 0, 0, 0};
     pc.lap(1);
-    for (int p0 = 0; p0 < k.n_items; p0 += DENSE_BATCH) {
+    const int nrec = A.dense_nrec, batch = 3 * nrec;
+    for (int p0 = 0; p0 < k.n_items; p0 += batch) {
         // ---- walk: one triplet per lane, geometry to LDS sorted by class ------------------------------------
         int n0, n1, n2;
         {
             TripletGeom tg;
-            bool valid = lane < DENSE_BATCH && p0 + lane < k.n_items;
+            bool valid = lane < batch && p0 + lane < k.n_items;
             if (valid) valid = trio_walk_geom<WANT_F>(A, g, w, td, k, m, sm, p0 + lane, tg);
             // leg masks t[0] <= r <= t[-1] (angles.py:502-508); both ends contribute nothing (see eval_triplet)
             if (valid)
@@ -715,13 +731,9 @@ __device__ __forceinline__ void trio_block_mfma(const FeatArgs &A, const BasisDe
                 double *ge = w.geo + (size_t)rank * GEO_STRIDE;
                 *(double2 *)(ge) = double2{tg.rl, tg.rm};
                 if (WANT_F) {
-                    const bool a_first = tg.centre || tg.first;
-                    const double v1[3] = {a_first ? tg.a1[0] : tg.a2[0], a_first ? tg.a1[1] : tg.a2[1], a_first ? tg.a1[2] : tg.a2[2]};
-                    const double v2[3] = {tg.centre ? tg.a2[0] : tg.a3[0], tg.centre ? tg.a2[1] : tg.a3[1], tg.centre ? tg.a2[2] : tg.a3[2]};
-                    *(double2 *)(ge + 2) = double2{tg.rn, v1[0]};
-                    *(double2 *)(ge + 4) = double2{v1[1], v1[2]};
-                    *(double2 *)(ge + 6) = double2{v2[0], v2[1]};
-                    *(double2 *)(ge + 8) = double2{v2[2], is0 ? 0.0 : (is1 ? 1.0 : 2.0)};
+                    *(double2 *)(ge + 2) = double2{tg.rn, tg.a3[0]};
+                    *(double2 *)(ge + 4) = double2{tg.a3[1], tg.a3[2]};
+                    *(int2 *)(ge + 6) = make_int2(tg.i1 | (tg.i2 << 16), is0 ? 0 : (is1 ? 1 : 2));
                 } else ge[2] = tg.rn;
             }
         }
@@ -729,8 +741,8 @@ __device__ __forceinline__ void trio_block_mfma(const FeatArgs &A, const BasisDe
         pc.lap(2);
         // ---- staging passes: lane (record li, leg) evaluates one leg and scatters it into the window ---------
         const int n_valid = n0 + n1 + n2;
-        for (int base = 0; base < n_valid; base += dl.nrec) {
-            const int n_part = min(dl.nrec, n_valid - base);
+        for (int base = 0; base < n_valid; base += nrec) {
+            const int n_part = min(nrec, n_valid - base);
             if (li < n_part && !(A.skip & 16)) {
                 const double *ge = w.geo + (size_t)(base + li) * GEO_STRIDE;
                 const double x = ge[leg];
@@ -746,13 +758,18 @@ __device__ __forceinline__ void trio_block_mfma(const FeatArgs &A, const BasisDe
                     const unsigned ws = (unsigned)(first + q - w_lo);
                     if (ws < (unsigned)w_ext) *(double2 *)(rec + w_off + 2 * ws) = double2{v[q], WANT_F ? d[q] : 0.0};
                 }
-                if (WANT_F) {                       // direction component `leg` of the three legs
-                    const double v1 = ge[3 + leg], v2 = ge[6 + leg], code = ge[9];
-                    const double a1 = code == 2.0 ? 0.0 : v1;
-                    const double a2 = code == 0.0 ? v2 : (code == 2.0 ? v1 : 0.0);
-                    const double a3 = code == 0.0 ? 0.0 : v2;
+                if (WANT_F) {
+                    // component `leg` of the three direction vectors: unit vectors of own-list entries, and e
+                    const int2 pk = *(const int2 *)(ge + 6);
+                    const int i1 = pk.x & 0xffff, i2 = pk.x >> 16, cls = pk.y;
+                    const double *oc = w.ox + (size_t)leg * A.n3.cap;           // ox | oy | oz are consecutive [cap] arrays
+                    const double v1 = oc[i1] * w.oir[i1];
+                    const double v2 = cls == 0 ? oc[i2] * w.oir[i2] : ge[3 + leg];
+                    const double a1 = cls == 2 ? 0.0 : v1;
+                    const double a2 = cls == 0 ? v2 : (cls == 2 ? v1 : 0.0);
+                    const double a3 = cls == 0 ? 0.0 : v2;
                     *(double2 *)(rec + dl.off_f + 2 * leg) = double2{a1, a2};
-                    *(double2 *)(rec + dl.off_f + 6 + 2 * leg) = double2{a3, 0.0};
+                    rec[dl.off_f + 6 + leg] = a3;
                 }
                 if (leg == 0) *(double2 *)(rec + dl.off_z) = zz;
             }
@@ -866,6 +883,7 @@ __device__ __forceinline__ void zero_rows(double *x_f, int m, int F, int col, in
 // registers of its own path: 0 = one-body + pair blocks; 1..5 = trio blocks whose (nsrc, 64-column chunks
 // per walk) is (1,1), (1,2), (2,1), (2,2), (6,1); 6 = trio blocks with a small dense window, accumulated on the
 // matrix cores (trio_block_mfma).  Every block is written by exactly one launch.
+// (MODE 7 = MODE 6 compiled for three waves per SIMD; launched when its LDS footprint allows three workgroups per CU.)
 __device__ __forceinline__ int trio_mode(const TrioDev *td) {
     if (td->dense) return 6;
     const bool wide = td->ncol > WAVE;
@@ -873,7 +891,7 @@ __device__ __forceinline__ int trio_mode(const TrioDev *td) {
 }
 
 template <bool WANT_E, bool WANT_F, bool RECS_LDS, int MODE>
-__global__ void __launch_bounds__(WPB * WAVE, MODE == 0 ? 4 : 2)
+__global__ void __launch_bounds__(WPB * WAVE, MODE == 0 ? 4 : (MODE == 7 ? 3 : 2))
 k_featurize(FeatArgs A) {
     extern __shared__ __align__(16) unsigned char smem[];
     const BasisDev *B = A.B;
@@ -884,17 +902,18 @@ k_featurize(FeatArgs A) {
     // LDS carve (must match feat_lds_bytes on the host).  MODE 0 (pairs): candidate list + pair records, pair
     // knot records only; trio modes: own neighbour list + triplet records, all knot records.
     const size_t cand_d = (size_t)A.cand_cap * 5 + ((A.cand_cap * 5) & 1);
+    constexpr bool DENSE = MODE >= 6;
     const size_t stage_d = MODE == 0 ? cand_d + (size_t)NSTAGE * PAIR_STRIDE
-                           : (MODE == 6 ? (size_t)A.dense_stage : (size_t)NSTAGE * ITEM_STRIDE);
-    const size_t list_d = MODE == 0 ? 0 : 4 * (size_t)cap + ((4 * cap) & 1);
-    const size_t geo_d = MODE == 6 ? (size_t)DENSE_BATCH * GEO_STRIDE : 0;
+                           : (DENSE ? (size_t)A.dense_stage : (size_t)NSTAGE * ITEM_STRIDE);
+    const size_t list_d = MODE == 0 ? 0 : 5 * (size_t)cap + ((5 * cap) & 1);
+    const size_t geo_d = DENSE ? (size_t)3 * A.dense_nrec * GEO_STRIDE : 0;
     const size_t per_wave_d = list_d + stage_d + (stage_d & 1) + geo_d;
     const size_t per_wave_i = MODE == 0 ? 0 : 3 * (size_t)cap + 2 * ((size_t)cap + 1) + (UF3_MAX_SPECIES + 2) +
-                                                  (size_t)cap * (UF3_MAX_SPECIES + 1);
+                                                  (size_t)cap * (S + 1);
     double *wd = erow + e_d + (size_t)wave * per_wave_d;
     int *wi = (int *)(erow + e_d + (size_t)WPB * per_wave_d) + (size_t)wave * per_wave_i;
     WaveLds w;
-    w.ox = wd; w.oy = w.ox + cap; w.oz = w.oy + cap; w.orr = w.oz + cap;
+    w.ox = wd; w.oy = w.ox + cap; w.oz = w.oy + cap; w.orr = w.oz + cap; w.oir = w.orr + cap;
     w.stage = wd + list_d;
     w.geo = w.stage + stage_d + (stage_d & 1);
     w.cand = w.stage;
@@ -902,6 +921,7 @@ k_featurize(FeatArgs A) {
     w.oparent = wi; w.oshift = wi + cap; w.osidx = wi + 2 * cap;
     w.noff = wi + 3 * cap; w.nbase = w.noff + cap + 1; w.so = w.nbase + cap + 1;
     w.ospoff = w.so + (UF3_MAX_SPECIES + 2);
+    w.sp_stride = S + 1;
 
     // knot-interval records (de Boor-Cox coefficients): staged in LDS when they fit
     KnotRec *recs_lds;
@@ -918,7 +938,7 @@ k_featurize(FeatArgs A) {
     const KnotRec *recs = RECS_LDS ? recs_lds : A.recs;
     int fragp[4] = {0, 0, 0, 0};
     const int *dsrc = A.dsrc;
-    if (MODE == 6) {
+    if (DENSE) {
         for (int v = 0; v < 4; v++) fragp[v] = A.frag[(lane * 4 + v) * 2] * 16 + A.frag[(lane * 4 + v) * 2 + 1];
         if (A.dsrc_lds) {
             int *dl = (int *)(recs_lds + (RECS_LDS ? A.n_recs : 0));
@@ -927,7 +947,7 @@ k_featurize(FeatArgs A) {
         }
     }
     if (WANT_E) { for (int q = tid; q < F; q += WPB * WAVE) erow[q] = 0.0; }
-    if (MODE == 6) for (int q = lane; q < (int)stage_d; q += WAVE) w.stage[q] = 0.0;   // masked operands read stale slots
+    if (DENSE) for (int q = lane; q < (int)stage_d; q += WAVE) w.stage[q] = 0.0;   // masked operands read stale slots
     __syncthreads();
     const int block_first = blockIdx.x * A.atoms_per_block;
     const int block_end = min(block_first + A.atoms_per_block, A.natoms);
@@ -996,7 +1016,7 @@ k_featurize(FeatArgs A) {
             wave_sync();
             for (int e = lane; e < n; e += WAVE) {
                 const N3Entry en = A.n3.ent[base + e];
-                w.ox[e] = en.dx; w.oy[e] = en.dy; w.oz[e] = en.dz; w.orr[e] = en.r;
+                w.ox[e] = en.dx; w.oy[e] = en.dy; w.oz[e] = en.dz; w.orr[e] = en.r; w.oir[e] = 1.0 / en.r;
                 w.oparent[e] = en.parent; w.oshift[e] = en.shiftc; w.osidx[e] = en.sidx;
             }
             if (lane <= S) w.so[lane] = A.n3.spoff[(size_t)m * (UF3_MAX_SPECIES + 1) + lane];
@@ -1004,13 +1024,13 @@ k_featurize(FeatArgs A) {
             if (WANT_F)                                            // neighbour role: the lists of m's neighbours
                 for (int q = lane; q < n * (S + 1); q += WAVE) {
                     const int e = q / (S + 1), sp = q - e * (S + 1);
-                    w.ospoff[e * (UF3_MAX_SPECIES + 1) + sp] = A.n3.spoff[(size_t)w.oparent[e] * (UF3_MAX_SPECIES + 1) + sp];
+                    w.ospoff[e * (S + 1) + sp] = A.n3.spoff[(size_t)w.oparent[e] * (UF3_MAX_SPECIES + 1) + sp];
                 }
             wave_sync();
             pcl.lap(0);
             for (int t = 0; t < B->T; t++) {
                 const TrioDev *td = A.trios + t;
-                if (trio_mode(td) != MODE) continue;
+                if (trio_mode(td) != (DENSE ? 6 : MODE)) continue;
                 const bool touches = (td->sc == sm) || (WANT_F && (td->sa == sm || td->sb == sm));
                 if (!touches) { if (WANT_F && !(A.skip & 32)) zero_rows(A.x_f, m, F, td->col, td->ncol); continue; }
                 if (MODE == 1) trio_block<WANT_E, WANT_F, 1, 1>(A, B, recs, g, w, m, sm, t, es);
