@@ -635,11 +635,11 @@ static int ensure_frag(uf3_ctx *c);
 
 // LDS bytes of one featurizer workgroup; must mirror the carve at the top of k_featurize
 static size_t feat_lds_bytes(int F, int S, int cap, int cand_cap, bool want_e, size_t n_recs, int mode, int dense_stage,
-                             int dense_nrec) {
+                             int dense_nrec, int n_pair_cols) {
     const bool dense = mode >= 6;
     size_t e_d = want_e ? (size_t)F + (F & 1) : 0;
     size_t cand_d = (size_t)cand_cap * 5 + ((cand_cap * 5) & 1);
-    size_t stage_d = mode == 0 ? cand_d + (size_t)NSTAGE * PAIR_STRIDE
+    size_t stage_d = mode == 0 ? cand_d + 4 * (size_t)n_pair_cols
                      : (dense ? (size_t)dense_stage : (size_t)NSTAGE * ITEM_STRIDE);
     size_t list_d = mode == 0 ? 0 : 5 * (size_t)cap + ((5 * cap) & 1);
     size_t geo_d = dense ? (size_t)3 * dense_nrec * GEO_STRIDE : 0;
@@ -685,6 +685,8 @@ extern "C" int uf3_featurize_dev(uf3_basis *b, const uf3_frames *fr, const doubl
         A.cand_cap = c->cand_cap;
         A.n_recs = (int)b->n_recs;
         A.n_pair_recs = (int)b->n_pair_recs;
+        A.n_pair_cols = 0;
+        for (int p = 0; p < b->host.P; p++) A.n_pair_cols += b->host.pairs[p].nb;
         if (want_e) HIPCHK(c, hipMemsetAsync(d_xe, 0, sizeof(double) * (size_t)P.n_frames * F, st));
         HIPCHK(c, hipMemsetAsync(A.cand_need, 0, sizeof(int), st));
         {
@@ -714,7 +716,7 @@ extern "C" int uf3_featurize_dev(uf3_basis *b, const uf3_frames *fr, const doubl
                         const bool with_dsrc = dsrc_allowed && (q % 2 == 0);
                         if (!dsrc_allowed && (q % 2 == 0)) continue;
                         int stage = std::max(DENSE_DUMP, nr * b->dense_stride);
-                        size_t need = feat_lds_bytes(F, S, cap, A.cand_cap, want_e, n_rec_mode, 6, stage, nr) +
+                        size_t need = feat_lds_bytes(F, S, cap, A.cand_cap, want_e, n_rec_mode, 6, stage, nr, A.n_pair_cols) +
                                       (with_dsrc ? sizeof(int) * b->n_dsrc : 0);
                         if (need <= budget) {
                             found = true; launch_mode = 7; recs_lds = true; lds = lds_recs = need;
@@ -724,8 +726,8 @@ extern "C" int uf3_featurize_dev(uf3_basis *b, const uf3_frames *fr, const doubl
                     if (!found) { A.dense_nrec = nrec_max; A.dense_stage = std::max(DENSE_DUMP, nrec_max * b->dense_stride); }
                 }
                 if (launch_mode != 7) {
-                    lds_plain = feat_lds_bytes(F, S, cap, A.cand_cap, want_e, 0, mode, A.dense_stage, A.dense_nrec) + lds_extra;
-                    lds_recs = feat_lds_bytes(F, S, cap, A.cand_cap, want_e, n_rec_mode, mode, A.dense_stage, A.dense_nrec) + lds_extra;
+                    lds_plain = feat_lds_bytes(F, S, cap, A.cand_cap, want_e, 0, mode, A.dense_stage, A.dense_nrec, A.n_pair_cols) + lds_extra;
+                    lds_recs = feat_lds_bytes(F, S, cap, A.cand_cap, want_e, n_rec_mode, mode, A.dense_stage, A.dense_nrec, A.n_pair_cols) + lds_extra;
                     const size_t lds_target = cu_lds / (mode == 0 ? 4 : 2);
                     recs_lds = lds_recs <= lds_target && !getenv("UF3_NO_LDS_RECS");
                     lds = recs_lds ? lds_recs : lds_plain;

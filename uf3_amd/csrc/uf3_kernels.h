@@ -191,7 +191,6 @@ __device__ __forceinline__ bool neighbour_is_first(const FrameGeom &g, int sm, i
 #define WPB 4             // independent waves per workgroup (they share only the energy row)
 #define NSTAGE 32         // records staged in LDS per wave at a time
 #define ITEM_STRIDE 38    // doubles per staged triplet record (16-B aligned)
-#define PAIR_STRIDE 12    // doubles per staged pair record
 // triplet record (doubles): 0-7 (Bl,B'l)[4], 8-15 (Bm,B'm)[4], 16-23 (Bn,B'n)[4],
 //   24-26 A1, 27-29 A2, 30-32 A3, 34-35 int4 {first l, first m, first n, centre flag}, 36-37 zero pair
 // pair record (doubles): 0-7 (B,B')[4], 8-10 2*(R_j-R_m)/r, 11 {first basis index, -}
@@ -235,6 +234,7 @@ struct FeatArgs {
     int cand_cap;       // 2-body candidates staged per atom
     int n_recs;         // KnotRec count (for the LDS copy)
     int n_pair_recs;    // ... of which belong to the pair blocks (they come first)
+    int n_pair_cols;    // columns of all pair blocks together (they follow the S one-body columns)
     int dense_stage;    // doubles of per-wave stage the MFMA specialisation needs (max over dense trios)
     int dense_nrec;     // records staged per pass by the MFMA specialisation (<= DENSE_NREC)
     int skip;           // profiling ablations (UF3_DEBUG_SKIP): 1 two-body, 2 centre role, 4 neighbour role,
@@ -394,7 +394,7 @@ struct WaveLds {
     double *geo;                       // MFMA specialisation: geometry of the walked triplets [3 * nrec][GEO_STRIDE]
     double *stage;                     // NSTAGE triplet / pair records
     double *cand;                      // 2-body candidates [cand_cap][5] (aliases stage)
-    double *pstage;                    // pair records (behind the candidates, inside stage)
+    double *pstage;                    // 2-body row buffer [4][n_pair_cols] (behind the candidates, inside stage)
 };
 
 // Which triplets does atom m contribute to trio block td?  Items [0, cnt_c) are the triplets m centres (own
@@ -811,65 +811,51 @@ __device__ __forceinline__ void trio_block_mfma(const FeatArgs &A, const BasisDe
     // the dump left window values in the stage: stale slots must stay finite (they are multiplied by 0), which they are
 }
 
-// 2-body block (sm, sx): lanes <-> basis functions, candidates of species sx streamed through LDS
+// 2-body columns of atom m: lanes <-> neighbour images (the candidates collected in LDS).  Each lane evaluates its
+// bond once and adds its four basis values / derivatives into a per-wave row buffer in LDS (native ds_add_f64;
+// bonds of one shell hit the same four columns, the LDS serialises those); the buffer then leaves as coalesced
+// rows.  Columns of pair blocks the atom does not belong to stay zero in the buffer.
 template <bool WANT_E, bool WANT_F>
-__device__ __forceinline__ void pair_block(const FeatArgs &A, const BasisDev *B, const KnotRec *recs, const WaveLds &w, int m,
-                                           int sx, const PairDev &pd, int n_cand, const ESink &es) {
-    const int lane = lane_id(), F = B->F;
-    for (int c0 = 0; c0 < pd.nb; c0 += WAVE) {
-        const int bidx = c0 + lane;
-        const bool keep = bidx < pd.nb && bidx >= B->lead2 && bidx < pd.nb - B->trail2;   // bspline.py:840,880
-        double ae = 0, ax = 0, ay = 0, az = 0;
-        for (int e0 = 0; e0 < n_cand; e0 += WAVE) {
-            int e = e0 + lane;
-            bool valid = e < n_cand;
-            double v[4], dv[4], dir[3] = {0, 0, 0};
-            int first = 0;
-            if (valid) {
-                const double *c = w.cand + (size_t)e * 5;
-                valid = (int)c[4] == sx;
-                if (valid) {
-                    double d = c[3];
-                    KnotRec kr;
-                    int i = load_interval(recs, pd.leg, d, kr);
-                    bspline4<WANT_F>(kr, d, v, dv);
-                    first = i - 3;
-                    double s = 2.0 / d;      // both directed images of the bond (distances.py:116-141)
-                    dir[0] = s * c[0]; dir[1] = s * c[1]; dir[2] = s * c[2];
+__device__ __forceinline__ void pair_rows(const FeatArgs &A, const BasisDev *B, const KnotRec *recs, const WaveLds &w, int m,
+                                          int sm, int n_cand, const ESink &es) {
+    const int lane = lane_id(), F = B->F, S = B->S;
+    const int n2 = A.n_pair_cols;                       // pair columns are [S, S + n2)
+    double *row = w.pstage;                             // [4][n2]: energy, fx, fy, fz
+    for (int q = lane; q < 4 * n2; q += WAVE) row[q] = 0.0;
+    wave_sync();
+    for (int e0 = 0; e0 < n_cand; e0 += WAVE) {
+        const int e = e0 + lane;
+        if (e < n_cand) {
+            const double *c = w.cand + (size_t)e * 5;
+            const double d = c[3];
+            const PairDev &pd = B->pairs[B->pair_of[sm * UF3_MAX_SPECIES + (int)c[4]]];
+            KnotRec kr;
+            double v[4], dv[4];
+            const int first = load_interval(recs, pd.leg, d, kr) - 3;
+            bspline4<WANT_F>(kr, d, v, dv);
+            const double s = 2.0 / d;                   // both directed images of the bond (distances.py:116-141)
+            const double dir[3] = {s * c[0], s * c[1], s * c[2]};
+            const int hi = pd.nb - B->trail2, base = pd.col - S;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int bf = first + q;
+                if (bf >= B->lead2 && bf < hi) {        // bspline.py:840,880
+                    double *dst = row + base + bf;
+                    if (WANT_E) lds_add(dst, v[q]);
+                    if (WANT_F) { lds_add(dst + n2, dv[q] * dir[0]); lds_add(dst + 2 * n2, dv[q] * dir[1]); lds_add(dst + 3 * n2, dv[q] * dir[2]); }
                 }
             }
-            for (int part = 0; part < WAVE / NSTAGE; part++) {
-                bool mine = valid && ((lane / NSTAGE) == part);
-                unsigned long long mask = __ballot(mine);
-                if (mask == 0) continue;
-                if (mine) {
-                    double *rec = w.pstage + (size_t)mbcnt(mask) * PAIR_STRIDE;
-                    for (int q = 0; q < 4; q++) { rec[2 * q] = v[q]; if (WANT_F) rec[2 * q + 1] = dv[q]; }
-                    rec[8] = dir[0]; rec[9] = dir[1]; rec[10] = dir[2];
-                    *(int *)(rec + 11) = first;
-                }
-                wave_sync();
-                const int ns = __popcll(mask);
-                for (int q = 0; q < ns; q++) {
-                    const double *rec = w.pstage + (size_t)q * PAIR_STRIDE;
-                    const unsigned k = (unsigned)(bidx - *(const int *)(rec + 11));
-                    if (keep && k < 4u) {
-                        const double2 vd = *(const double2 *)(rec + 2 * k);
-                        if (WANT_E) ae += vd.x;
-                        if (WANT_F) { ax += vd.y * rec[8]; ay += vd.y * rec[9]; az += vd.y * rec[10]; }
-                    }
-                }
-                wave_sync();
-            }
-        }
-        if (bidx < pd.nb) {
-            if (WANT_F) {
-                double *dst = A.x_f + (size_t)m * 3 * F + pd.col + bidx;
-                dst[0] = ax; dst[F] = ay; dst[2 * (size_t)F] = az;
-            }
-            if (WANT_E) es.add(pd.col + bidx, ae);
         }
     }
+    wave_sync();
+    for (int col = lane; col < n2; col += WAVE) {
+        if (WANT_F) {
+            double *dst = A.x_f + (size_t)m * 3 * F + S + col;
+            dst[0] = row[n2 + col]; dst[F] = row[2 * n2 + col]; dst[2 * (size_t)F] = row[3 * n2 + col];
+        }
+        if (WANT_E) es.add(S + col, row[col]);
+    }
+    wave_sync();
 }
 
 __device__ __forceinline__ void zero_rows(double *x_f, int m, int F, int col, int n) {
@@ -903,7 +889,7 @@ k_featurize(FeatArgs A) {
     // knot records only; trio modes: own neighbour list + triplet records, all knot records.
     const size_t cand_d = (size_t)A.cand_cap * 5 + ((A.cand_cap * 5) & 1);
     constexpr bool DENSE = MODE >= 6;
-    const size_t stage_d = MODE == 0 ? cand_d + (size_t)NSTAGE * PAIR_STRIDE
+    const size_t stage_d = MODE == 0 ? cand_d + 4 * (size_t)A.n_pair_cols
                            : (DENSE ? (size_t)A.dense_stage : (size_t)NSTAGE * ITEM_STRIDE);
     const size_t list_d = MODE == 0 ? 0 : 5 * (size_t)cap + ((5 * cap) & 1);
     const size_t geo_d = DENSE ? (size_t)3 * A.dense_nrec * GEO_STRIDE : 0;
@@ -1001,12 +987,7 @@ k_featurize(FeatArgs A) {
             });
             if (n_cand > A.cand_cap) { if (lane == 0) atomicMax(A.cand_need, n_cand); n_cand = A.cand_cap; }
             wave_sync();
-            for (int p = 0; p < B->P; p++) {
-                const PairDev &pd = B->pairs[p];
-                if (pd.sa == sm) pair_block<WANT_E, WANT_F>(A, B, recs, w, m, pd.sb, pd, n_cand, es);
-                else if (pd.sb == sm) pair_block<WANT_E, WANT_F>(A, B, recs, w, m, pd.sa, pd, n_cand, es);
-                else if (WANT_F) zero_rows(A.x_f, m, F, pd.col, pd.nb);
-            }
+            pair_rows<WANT_E, WANT_F>(A, B, recs, w, m, sm, n_cand, es);
         }
         // ---- 3-body ---------------------------------------------------------------------------
         if (MODE != 0 && B->T > 0) {
