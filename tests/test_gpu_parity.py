@@ -485,3 +485,25 @@ def test_relax_fmax_positions_and_cell():
     vol = abs(np.linalg.det(np.array(both.get_cell(), dtype=float).reshape(3, 3)))
     assert np.abs(calc._get_stress(both)).max() * vol / len(both) < 0.01
     assert calc.get_potential_energy(both) <= calc.get_potential_energy(relaxed) + 1e-9
+
+
+def test_fused_and_separate_neighbour_list_builds_agree():
+    """The 3-body lists built inside the pair launch (from its LDS candidates) against k_build_n3's."""
+    cases = [(synthetic.notebook_basis(['Mo', 'W']), [synthetic.lattice_frame("bcc", (3, 4, 3), 3.165, [42, 74], 21)])]
+    cs = synthetic.composition.ChemicalSystem(['W'], 3)
+    dense = synthetic.bspline.BSplineBasis(
+        cs, r_min_map={('W', 'W'): 0.3, ('W', 'W', 'W'): [0.5, 0.5, 0.5]},
+        r_max_map={('W', 'W'): 4.0, ('W', 'W', 'W'): [5.0, 5.0, 10.0]},          # 3-body range beyond the pair range
+        resolution_map={('W', 'W'): 8, ('W', 'W', 'W'): [5, 5, 10]})
+    cases.append((dense, [synthetic.lattice_frame("bcc", (4, 4, 4), 2.6, [74], seed=3, rattle=0.1)]))
+    for basis, frames in cases:
+        fz = process.BasisFeaturizer(basis)
+        x_e, x_f, _ = fz.featurize_frames(frames)
+        os.environ["UF3_SEPARATE_N3"] = "1"
+        try:
+            y_e, y_f, _ = fz.featurize_frames(frames)
+        finally:
+            del os.environ["UF3_SEPARATE_N3"]
+        assert rel_err(x_e, y_e) < 1e-13 and rel_err(x_f, y_f) < 1e-13
+        ref = O.featurize(O.OracleBasis(basis), frames[0])
+        assert rel_err(x_e[0], ref["xe"]) < 1e-8 and rel_err(x_f, ref["xf"]) < 1e-8

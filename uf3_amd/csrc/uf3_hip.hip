@@ -516,6 +516,27 @@ static int n3_alloc(uf3_ctx *c, int natoms, int cap, N3Lists &n3) {
     return UF3_OK;
 }
 
+static int n3_cap_estimate(const uf3_basis *b, double dens) {
+    double r = b->host.rmax3;
+    double est = dens > 0 ? 4.18879 * r * r * r * dens : 24.0;
+    return std::max(16, ((int)(est * 1.8) + 8 + 7) / 8 * 8);
+}
+
+// The density estimate is generous: after the first successful build later calls pad to what that batch really
+// needed (a batch that needs more trips the overflow path and grows the capacity again).
+static int n3_tune(uf3_ctx *c, const N3Lists &n3, int natoms) {
+    hipStream_t st = c->stream;
+    int *flags = c->flags.as<int>();
+    c->n3_tuned = true;
+    HIPCHK(c, hipMemsetAsync(flags + 3, 0, sizeof(int), st));
+    hipLaunchKernelGGL(k_max_count, dim3(64), dim3(256), 0, st, n3.cnt, natoms, flags + 3);
+    int seen = 0;
+    HIPCHK(c, hipMemcpyAsync(&seen, flags + 3, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    c->n3_cap = std::max(8, (seen + 7) / 8 * 8);
+    return UF3_OK;
+}
+
 // cell list + 3-body neighbour lists for a batch (positions / species already in HBM)
 static int prepare(uf3_basis *b, const uf3_frames *fr, const double *d_pos, const int32_t *d_z, bool need_n3,
                    Prepared &P) {
@@ -590,11 +611,7 @@ static int prepare(uf3_basis *b, const uf3_frames *fr, const double *d_pos, cons
     std::memset(&P.n3, 0, sizeof(P.n3));
     if (need_n3 && b->host.T > 0) {
         // capacity: remembered from earlier calls, else a density estimate; overflow -> grow and redo
-        if (c->n3_cap == 0) {
-            double r = b->host.rmax3;
-            double est = dens > 0 ? 4.18879 * r * r * r * dens : 24.0;
-            c->n3_cap = std::max(16, ((int)(est * 1.8) + 8 + 7) / 8 * 8);
-        }
+        if (c->n3_cap == 0) c->n3_cap = n3_cap_estimate(b, dens);
         for (int attempt = 0; attempt < 6; attempt++) {
             int cap = c->n3_cap;
             int rc = n3_alloc(c, natoms, cap, P.n3);
@@ -609,17 +626,7 @@ static int prepare(uf3_basis *b, const uf3_frames *fr, const double *d_pos, cons
             HIPCHK(c, hipMemcpyAsync(&need, flags + 1, sizeof(int), hipMemcpyDeviceToHost, st));
             HIPCHK(c, hipStreamSynchronize(st));
             if (need <= cap) {
-                if (!c->n3_tuned) {
-                    // the density estimate is generous; later calls pad to what this batch really needed (a batch
-                    // that needs more trips the overflow path above and grows the capacity again)
-                    c->n3_tuned = true;
-                    HIPCHK(c, hipMemsetAsync(flags + 3, 0, sizeof(int), st));
-                    hipLaunchKernelGGL(k_max_count, dim3(64), dim3(256), 0, st, P.n3.cnt, natoms, flags + 3);
-                    int seen = 0;
-                    HIPCHK(c, hipMemcpyAsync(&seen, flags + 3, sizeof(int), hipMemcpyDeviceToHost, st));
-                    HIPCHK(c, hipStreamSynchronize(st));
-                    c->n3_cap = std::max(8, (seen + 7) / 8 * 8);
-                }
+                if (!c->n3_tuned) { int rt = n3_tune(c, P.n3, natoms); if (rt) return rt; }
                 return check_flags(c);
             }
             c->n3_tuned = true;
@@ -638,8 +645,9 @@ static size_t feat_lds_bytes(int F, int S, int cap, int cand_cap, bool want_e, s
                              int dense_nrec, int n_pair_cols) {
     const bool dense = mode >= 6;
     size_t e_d = want_e ? (size_t)F + (F & 1) : 0;
-    size_t cand_d = (size_t)cand_cap * 5 + ((cand_cap * 5) & 1);
-    size_t stage_d = mode == 0 ? cand_d + 4 * (size_t)n_pair_cols
+    size_t cand_d = (size_t)cand_cap * CAND_STRIDE;
+    size_t pair_buf_d = std::max(4 * (size_t)n_pair_cols, (3 * (size_t)cap + 1) / 2 + 2);
+    size_t stage_d = mode == 0 ? cand_d + pair_buf_d
                      : (dense ? (size_t)dense_stage : (size_t)NSTAGE * ITEM_STRIDE);
     size_t list_d = mode == 0 ? 0 : 5 * (size_t)cap + ((5 * cap) & 1);
     size_t geo_d = dense ? (size_t)3 * dense_nrec * GEO_STRIDE : 0;
@@ -657,14 +665,17 @@ extern "C" int uf3_featurize_dev(uf3_basis *b, const uf3_frames *fr, const doubl
     if (!d_pos || !d_z) return fail(c, UF3_EINVAL, "null positions / species");
     if (!d_xe && !d_xf) return UF3_OK;
     Prepared P;
-    int rc = prepare(b, fr, d_pos, d_z, true, P);
+    const bool old_n3 = getenv("UF3_SEPARATE_N3") != nullptr;     // debugging: lists from k_build_n3 instead
+    int rc = prepare(b, fr, d_pos, d_z, old_n3, P);       // cell list only: MODE 0 builds the 3-body lists itself
     if (rc) return rc;
     hipStream_t st = c->stream;
     const int F = b->host.F;
     const bool want_e = d_xe != nullptr, want_f = d_xf != nullptr;
-    int cap = std::max(1, P.n3.cap);
+    const bool has3 = b->host.T > 0 && !old_n3;
+    if (has3 && c->n3_cap == 0) c->n3_cap = n3_cap_estimate(b, P.max_density);
+    int cap = 1;
     if (c->cand_cap == 0) {
-        double r = b->host.rmax2;
+        double r = b->host.rsearch;
         double est = P.max_density > 0 ? 4.18879 * r * r * r * P.max_density : 64.0;
         c->cand_cap = std::max(32, ((int)(est * 1.6) + 16 + 7) / 8 * 8);
     }
@@ -676,8 +687,12 @@ extern "C" int uf3_featurize_dev(uf3_basis *b, const uf3_frames *fr, const doubl
     const bool dsrc_ok = (b->modes & (1 << 6)) && b->n_dsrc * sizeof(int) <= 8192 && !getenv("UF3_NO_LDS_DSRC");
     A.dsrc_lds = dsrc_ok;
     if (b->modes & (1 << 6)) { rc = ensure_frag(c); if (rc) return rc; A.frag = c->frag.as<int>(); }
-    A.geoms = P.geoms; A.frame_of = P.frame_of; A.cl = P.cl; A.n3 = P.n3;
-    if (!A.n3.cap) A.n3.cap = 1;
+    A.geoms = P.geoms; A.frame_of = P.frame_of; A.cl = P.cl;
+    std::memset(&A.n3, 0, sizeof(A.n3));
+    A.n3.cap = 1;
+    if (old_n3 && P.n3.cap) A.n3 = P.n3;
+    A.build_n3 = has3 ? 1 : 0;
+    A.n3_need = c->flags.as<int>() + 1;
     A.pos = d_pos; A.spec = P.spec; A.x_e = d_xe; A.x_f = d_xf; A.natoms = P.natoms;
     A.cand_need = c->flags.as<int>() + 2;
     { const char *e = getenv("UF3_DEBUG_SKIP"); A.skip = e ? atoi(e) : 0; }
@@ -687,8 +702,14 @@ extern "C" int uf3_featurize_dev(uf3_basis *b, const uf3_frames *fr, const doubl
         A.n_pair_recs = (int)b->n_pair_recs;
         A.n_pair_cols = 0;
         for (int p = 0; p < b->host.P; p++) A.n_pair_cols += b->host.pairs[p].nb;
+        if (old_n3) cap = A.n3.cap;
+        if (has3) {
+            cap = c->n3_cap;
+            rc = n3_alloc(c, P.natoms, cap, A.n3);
+            if (rc) return rc;
+        }
         if (want_e) HIPCHK(c, hipMemsetAsync(d_xe, 0, sizeof(double) * (size_t)P.n_frames * F, st));
-        HIPCHK(c, hipMemsetAsync(A.cand_need, 0, sizeof(int), st));
+        HIPCHK(c, hipMemsetAsync(A.n3_need, 0, 2 * sizeof(int), st));       // n3_need, cand_need
         {
             Timed tm(c, T_FEAT);
             for (int mode = 0; mode <= 6; mode++) {
@@ -770,13 +791,18 @@ extern "C" int uf3_featurize_dev(uf3_basis *b, const uf3_frames *fr, const doubl
             }
         }
         HIPCHK(c, hipGetLastError());
-        int need = 0;
-        HIPCHK(c, hipMemcpyAsync(&need, A.cand_need, sizeof(int), hipMemcpyDeviceToHost, st));
+        int fl[3] = {0, 0, 0};                                               // error flag, n3 need, candidate need
+        HIPCHK(c, hipMemcpyAsync(fl, c->flags.p, sizeof(fl), hipMemcpyDeviceToHost, st));
         HIPCHK(c, hipStreamSynchronize(st));
-        if (need <= c->cand_cap) return UF3_OK;
-        c->cand_cap = (need + 16 + 7) / 8 * 8;
+        if (fl[0]) return check_flags(c);
+        bool redo = false;
+        if (has3 && fl[1] > cap) { c->n3_cap = (fl[1] + 8 + 7) / 8 * 8; c->n3_tuned = true; redo = true; }
+        if (fl[2] > c->cand_cap) { c->cand_cap = (fl[2] + 16 + 7) / 8 * 8; redo = true; }
+        if (redo) continue;
+        if (has3 && !c->n3_tuned) { rc = n3_tune(c, A.n3, P.natoms); if (rc) return rc; }
+        return UF3_OK;
     }
-    return fail(c, UF3_EOVERFLOW, "2-body candidate capacity did not converge");
+    return fail(c, UF3_EOVERFLOW, "neighbour capacities did not converge");
 }
 
 // host-buffer helpers

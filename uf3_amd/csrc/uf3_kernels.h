@@ -190,6 +190,7 @@ __device__ __forceinline__ bool neighbour_is_first(const FrameGeom &g, int sm, i
 // ---------------------------------------------------------------------------------
 #define WPB 4             // independent waves per workgroup (they share only the energy row)
 #define NSTAGE 32         // records staged in LDS per wave at a time
+#define CAND_STRIDE 6     // doubles per 2-body candidate: dx, dy, dz, d | species | int2 {atom, packed image shift}
 #define ITEM_STRIDE 38    // doubles per staged triplet record (16-B aligned)
 // triplet record (doubles): 0-7 (Bl,B'l)[4], 8-15 (Bm,B'm)[4], 16-23 (Bn,B'n)[4],
 //   24-26 A1, 27-29 A2, 30-32 A3, 34-35 int4 {first l, first m, first n, centre flag}, 36-37 zero pair
@@ -230,6 +231,8 @@ struct FeatArgs {
     double *x_e;        // [n_frames][F] or null
     double *x_f;        // [natoms][3][F] or null
     int *cand_need;     // overflow report of the 2-body candidate stage
+    int *n3_need;       // ... of the 3-body neighbour lists (MODE 0 builds them when build_n3 != 0)
+    int build_n3;
     int natoms, atoms_per_block;
     int cand_cap;       // 2-body candidates staged per atom
     int n_recs;         // KnotRec count (for the LDS copy)
@@ -393,7 +396,7 @@ struct WaveLds {
     int sp_stride;                     // S + 1
     double *geo;                       // MFMA specialisation: geometry of the walked triplets [3 * nrec][GEO_STRIDE]
     double *stage;                     // NSTAGE triplet / pair records
-    double *cand;                      // 2-body candidates [cand_cap][5] (aliases stage)
+    double *cand;                      // 2-body candidates [cand_cap][CAND_STRIDE] (aliases stage)
     double *pstage;                    // 2-body row buffer [4][n_pair_cols] (behind the candidates, inside stage)
 };
 
@@ -826,9 +829,10 @@ __device__ __forceinline__ void pair_rows(const FeatArgs &A, const BasisDev *B, 
     for (int e0 = 0; e0 < n_cand; e0 += WAVE) {
         const int e = e0 + lane;
         if (e < n_cand) {
-            const double *c = w.cand + (size_t)e * 5;
+            const double *c = w.cand + (size_t)e * CAND_STRIDE;
             const double d = c[3];
             const PairDev &pd = B->pairs[B->pair_of[sm * UF3_MAX_SPECIES + (int)c[4]]];
+            if (!(d > pd.rmin && d < pd.rmax)) continue;              // a 3-body-only neighbour
             KnotRec kr;
             double v[4], dv[4];
             const int first = load_interval(recs, pd.leg, d, kr) - 3;
@@ -854,6 +858,55 @@ __device__ __forceinline__ void pair_rows(const FeatArgs &A, const BasisDev *B, 
             dst[0] = row[n2 + col]; dst[F] = row[2 * n2 + col]; dst[2 * (size_t)F] = row[3 * n2 + col];
         }
         if (WANT_E) es.add(S + col, row[col]);
+    }
+    wave_sync();
+}
+
+// 3-body neighbour list of atom m from the candidates MODE 0 already holds in LDS (same output as k_build_n3):
+// images with r_min3 < d <= r_max3 (angles.py:340), sorted by (species, reference supercell index), padded to cap.
+__device__ __forceinline__ void build_n3_list(const FeatArgs &A, const BasisDev *B, const FrameGeom &g, const WaveLds &w,
+                                              int m, int n_cand) {
+    const int lane = lane_id(), cap = A.n3.cap;
+    unsigned long long *key = (unsigned long long *)w.pstage;      // the row buffer is free again
+    int *src = (int *)(key + cap);
+    const double rmin3 = B->rmin3, rmax3 = B->rmax3;
+    int count = 0;
+    for (int e0 = 0; e0 < n_cand; e0 += WAVE) {
+        const int e = e0 + lane;
+        const double *c = w.cand + (size_t)e * CAND_STRIDE;
+        const bool ok = e < n_cand && c[3] > rmin3 && c[3] <= rmax3;
+        const unsigned long long mask = __ballot(ok);
+        if (ok) {
+            const int slot = count + mbcnt(mask);
+            if (slot < cap) {
+                const int2 ps = *(const int2 *)(c + 5);
+                int s0, s1, s2;
+                unpack3(ps.y, s0, s1, s2);
+                const int sidx = supercell_index(g, s0, s1, s2, ps.x - g.atom_lo);
+                key[slot] = ((unsigned long long)(int)c[4] << 32) | (unsigned)sidx;
+                src[slot] = e;
+            }
+        }
+        count += __popcll(mask);
+    }
+    wave_sync();
+    if (count > cap) { if (lane == 0) atomicMax(A.n3_need, count); count = cap; }
+    if (lane == 0) A.n3.cnt[m] = count;
+    for (int sp = lane; sp <= UF3_MAX_SPECIES; sp += WAVE) {        // entries are species-sorted: offsets per species
+        int below = 0;
+        for (int f = 0; f < count; f++) below += (int)(key[f] >> 32) < sp;
+        A.n3.spoff[(size_t)m * (UF3_MAX_SPECIES + 1) + sp] = below;
+    }
+    for (int e = lane; e < count; e += WAVE) {                      // rank sort
+        const unsigned long long k = key[e];
+        int rank = 0;
+        for (int f = 0; f < count; f++) rank += key[f] < k;
+        const double *c = w.cand + (size_t)src[e] * CAND_STRIDE;
+        const int2 ps = *(const int2 *)(c + 5);
+        N3Entry out;
+        out.dx = c[0]; out.dy = c[1]; out.dz = c[2]; out.r = c[3];
+        out.parent = ps.x; out.shiftc = ps.y; out.sidx = (int)(unsigned)k; out.spec = (int)(k >> 32);
+        A.n3.ent[(size_t)m * cap + rank] = out;
     }
     wave_sync();
 }
@@ -887,9 +940,10 @@ k_featurize(FeatArgs A) {
     const size_t e_d = WANT_E ? (size_t)F + (F & 1) : 0;
     // LDS carve (must match feat_lds_bytes on the host).  MODE 0 (pairs): candidate list + pair records, pair
     // knot records only; trio modes: own neighbour list + triplet records, all knot records.
-    const size_t cand_d = (size_t)A.cand_cap * 5 + ((A.cand_cap * 5) & 1);
+    const size_t cand_d = (size_t)A.cand_cap * CAND_STRIDE;
+    const size_t pair_buf_d = max(4 * (size_t)A.n_pair_cols, (3 * (size_t)cap + 1) / 2 + 2);   // row buffer / sort keys
     constexpr bool DENSE = MODE >= 6;
-    const size_t stage_d = MODE == 0 ? cand_d + 4 * (size_t)A.n_pair_cols
+    const size_t stage_d = MODE == 0 ? cand_d + pair_buf_d
                            : (DENSE ? (size_t)A.dense_stage : (size_t)NSTAGE * ITEM_STRIDE);
     const size_t list_d = MODE == 0 ? 0 : 5 * (size_t)cap + ((5 * cap) & 1);
     const size_t geo_d = DENSE ? (size_t)3 * A.dense_nrec * GEO_STRIDE : 0;
@@ -973,14 +1027,18 @@ k_featurize(FeatArgs A) {
                     image_delta(g, sr, s0, s1, s2, pm, dx, dy, dz);
                     d = norm3_rn(dx, dy, dz);
                     const PairDev &pd = B->pairs[B->pair_of[sm * UF3_MAX_SPECIES + sj]];
-                    ok = (d > pd.rmin && d < pd.rmax);            // distances.py:66 strict both sides
+                    // kept if inside its pair's range (distances.py:66, strict both sides) or a 3-body neighbour
+                    ok = (d > pd.rmin && d < pd.rmax) || (A.build_n3 && d > B->rmin3 && d <= B->rmax3);
                 }
                 unsigned long long mask = __ballot(ok);
                 if (ok) {
                     int e = n_cand + mbcnt(mask);
                     if (e < A.cand_cap) {
-                        double *c = w.cand + (size_t)e * 5;
-                        c[0] = dx; c[1] = dy; c[2] = dz; c[3] = d; c[4] = (double)sj;
+                        double *c = w.cand + (size_t)e * CAND_STRIDE;
+                        *(double2 *)(c) = double2{dx, dy};
+                        *(double2 *)(c + 2) = double2{dz, d};
+                        c[4] = (double)sj;
+                        *(int2 *)(c + 5) = make_int2(sr.atom, pack3(s0, s1, s2));
                     }
                 }
                 n_cand += __popcll(mask);
@@ -988,6 +1046,7 @@ k_featurize(FeatArgs A) {
             if (n_cand > A.cand_cap) { if (lane == 0) atomicMax(A.cand_need, n_cand); n_cand = A.cand_cap; }
             wave_sync();
             pair_rows<WANT_E, WANT_F>(A, B, recs, w, m, sm, n_cand, es);
+            if (A.build_n3) build_n3_list(A, B, g, w, m, n_cand);
         }
         // ---- 3-body ---------------------------------------------------------------------------
         if (MODE != 0 && B->T > 0) {
