@@ -132,8 +132,8 @@ def main():
             pass
         roofline = dict(bound="hbm", achieved=round(achieved, 2), peak=8000.0, unit="GB/s",
                         frac=round(achieved / 8000.0, 5), traffic=traffic,
-                        kernel="k_featurize<E,F,R,MODE> launch group of one step: MODE 0 (one-body + pairs) + MODE 6 "
-                               "(3-body windows on the fp64 matrix cores)",
+                        kernel="k_featurize<E,F,R,MODE> launch group of one step: MODE 0 (one-body + pairs + 3-body list "
+                               "build) + MODE 7 (3-body windows on the fp64 matrix cores, 3 waves/SIMD)",
                         launch_ms=round(launch_ms, 4), launches=launches,
                         algorithmic_bytes_per_launch=bytes_per_launch,
                         fp64_tflops=round(flops_frame * B / (launch_ms * 1e-3) / 1e12, 3), fp64_peak_tflops=78.6,
