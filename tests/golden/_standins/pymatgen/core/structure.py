@@ -1,0 +1,2 @@
+class Structure:      # imported, unused by write_uf3_lammps_pot_files
+    pass
