@@ -449,6 +449,8 @@ static int make_geom(uf3_ctx *c, const uf3_basis *b, const uf3_frames *fr, int f
     }
     if (!invert3(eff, g.inv)) return fail(c, UF3_EINVAL, "cell is singular along a periodic direction");
     double rs = b->host.rsearch;
+    // bins of half the search radius (scan radius 2): 125 bins cover 15.6 r^3 instead of 27 r^3 for 27 full-size bins
+    const double bin_frac = getenv("UF3_BIN_FRAC") ? atof(getenv("UF3_BIN_FRAC")) : 0.5;
     if (n_per) {
         reference_factors(cell, b->r_cut, g.fac);
         for (int k = 0; k < 3; k++) if (!g.per[k]) g.fac[k] = 0;
@@ -463,7 +465,7 @@ static int make_geom(uf3_ctx *c, const uf3_basis *b, const uf3_frames *fr, int f
         double h = vol / norm3(nrm[k]);
         g.cnt[k] = g.per[k] ? 2 * g.fac[k] + 1 : 1;
         if (g.per[k]) {
-            int nb = (int)std::floor(h / rs);
+            int nb = (int)std::floor(h / (rs * bin_frac));
             nb = std::max(1, std::min(nb, 256));
             g.nb[k] = nb;
             g.rad[k] = (int)std::ceil(rs / (h / nb) - 1e-12);
