@@ -935,7 +935,8 @@ k_featurize(FeatArgs A) {
     extern __shared__ __align__(16) unsigned char smem[];
     const BasisDev *B = A.B;
     const int F = B->F, S = B->S, cap = A.n3.cap;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);           // wave-uniform: LDS pointers and atom indices in SGPRs
     double *erow = (double *)smem;                                         // [F] shared by the block (WANT_E)
     const size_t e_d = WANT_E ? (size_t)F + (F & 1) : 0;
     // LDS carve (must match feat_lds_bytes on the host).  MODE 0 (pairs): candidate list + pair records, pair
