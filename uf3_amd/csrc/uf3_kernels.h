@@ -601,34 +601,35 @@ struct DenseLane {
 
 template <bool WANT_E, bool MASK>
 __device__ __forceinline__ void mfma_quad(const double *rec, bool live, const DenseLane &o, double4_t (&accf)[2], double4_t &acce) {
+    // reads first, then the products, then the MFMAs (see mfma_pair)
     const double bv = rec[o.n];
-#pragma unroll
-    for (int tm = 0; tm < 2; tm++) {
-        const double2 L = *(const double2 *)(rec + o.l[tm]);
-        const double2 M = *(const double2 *)(rec + o.m[tm]);
-        const double2 Fv = *(const double2 *)(rec + o.f[tm]);
-        double av = fma(L.y * M.x, Fv.x, (L.x * M.y) * Fv.y);
-        if (MASK) av = live ? av : 0.0;
-        accf[tm] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, accf[tm], 0, 0, 0);
-        if (WANT_E && tm == 0) {
-            double ae = o.e_row ? L.x * M.x : 0.0;
-            if (MASK) ae = live ? ae : 0.0;
-            acce = __builtin_amdgcn_mfma_f64_16x16x4f64(ae, bv, acce, 0, 0, 0);
-        }
-    }
+    const double2 L0 = *(const double2 *)(rec + o.l[0]), M0 = *(const double2 *)(rec + o.m[0]), F0 = *(const double2 *)(rec + o.f[0]);
+    const double2 L1 = *(const double2 *)(rec + o.l[1]), M1 = *(const double2 *)(rec + o.m[1]), F1 = *(const double2 *)(rec + o.f[1]);
+    __builtin_amdgcn_sched_group_barrier(0x100, 7, 0);
+    double a0 = fma(L0.y * M0.x, F0.x, (L0.x * M0.y) * F0.y);
+    double a1 = fma(L1.y * M1.x, F1.x, (L1.x * M1.y) * F1.y);
+    double ae = (WANT_E && o.e_row) ? L0.x * M0.x : 0.0;
+    if (MASK) { a0 = live ? a0 : 0.0; a1 = live ? a1 : 0.0; ae = live ? ae : 0.0; }
+    accf[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, bv, accf[0], 0, 0, 0);
+    accf[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, bv, accf[1], 0, 0, 0);
+    if (WANT_E) acce = __builtin_amdgcn_mfma_f64_16x16x4f64(ae, bv, acce, 0, 0, 0);
 }
 
 // two neighbour-role records per step; x/y/z: this lane's three factors (B or B' of leg l, of leg m, direction)
 template <bool MASK>
 __device__ __forceinline__ void mfma_pair(const double *rec, bool live, const int (&x)[2], const int (&y)[2], const int (&z)[2],
                                           int bn, double4_t (&accf)[2]) {
+    // all seven operand reads go out before anything waits on them (left alone, the scheduler keeps the register
+    // count minimal and waits after every read: four LDS round trips per step instead of one)
     const double bv = rec[bn];
-#pragma unroll
-    for (int tm = 0; tm < 2; tm++) {
-        double av = (rec[x[tm]] * rec[y[tm]]) * rec[z[tm]];
-        if (MASK) av = live ? av : 0.0;
-        accf[tm] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, accf[tm], 0, 0, 0);
-    }
+    const double x0 = rec[x[0]], y0 = rec[y[0]], z0 = rec[z[0]], x1 = rec[x[1]], y1 = rec[y[1]], z1 = rec[z[1]];
+    __builtin_amdgcn_sched_group_barrier(0x100, 7, 0);      // 7 DS reads
+    double a0 = (x0 * y0) * z0, a1 = (x1 * y1) * z1;
+    if (MASK) { a0 = live ? a0 : 0.0; a1 = live ? a1 : 0.0; }
+    __builtin_amdgcn_sched_group_barrier(0x2, MASK ? 8 : 4, 0);   // VALU
+    accf[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, bv, accf[0], 0, 0, 0);
+    accf[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, bv, accf[1], 0, 0, 0);
+    __builtin_amdgcn_sched_group_barrier(0x8, 2, 0);        // 2 MFMA
 }
 
 template <bool WANT_E, bool WANT_F>
