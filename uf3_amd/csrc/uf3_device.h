@@ -150,11 +150,10 @@ __device__ __forceinline__ int load_interval(const KnotRec *recs, const LegDev &
     i = i < 3 ? 3 : (i > hi ? hi : i);
     const KnotRec *base = recs + leg.rec_off;
     k = base[i];
-    for (;;) {
-        if (x > k.t[3] && i < hi) ++i;
-        else if (x <= k.t[2] && i > 3) --i;
-        else break;
-        k = base[i];
+    if (__builtin_expect(x > k.t[3] && i < hi, 0)) {
+        do { ++i; k = base[i]; } while (x > k.t[3] && i < hi);
+    } else if (__builtin_expect(x <= k.t[2] && i > 3, 0)) {
+        do { --i; k = base[i]; } while (x <= k.t[2] && i > 3);
     }
     return i;
 }

@@ -712,7 +712,7 @@ __device__ __forceinline__ void trio_block_mfma(const FeatArgs &A, const BasisDe
     lg.inv_h = leg == 0 ? td->leg[0].inv_h : (leg == 1 ? td->leg[1].inv_h : td->leg[2].inv_h);
     const int w_off = leg == 0 ? 0 : (leg == 1 ? dl.off_m : dl.off_n);
     const int w_ext = leg == 0 ? ext_l : (leg == 1 ? ext_m : ext_n), w_lo = leg == 0 ? lo_l : (leg == 1 ? lo_m : lo_n);
-    const int z_max = max(ext_l, max(ext_m, ext_n));
+    const int n_clear = (dl.off_f / 2 + 2) / 3;                          // window pairs each of a record's lanes clears
     double4_t accf[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}}, acce = {0, 0, 0, 0};
     pc.lap(1);
     const int nrec = A.dense_nrec, batch = 3 * nrec;
@@ -756,7 +756,12 @@ __device__ __forceinline__ void trio_block_mfma(const FeatArgs &A, const BasisDe
                 bspline4<WANT_F>(kr, x, v, d);
                 double *rec = w.stage + (size_t)li * dl.stride;
                 const double2 zz = {0.0, 0.0};
-                for (int q = 0; q < z_max; q++) if (q < w_ext) *(double2 *)(rec + w_off + 2 * q) = zz;
+                // the three lanes of a record clear its windows together (LDS writes of a wave stay in program
+                // order, so every clear lands before any lane's scatter below)
+                for (int q = 0; q < n_clear; q++) {
+                    const int slot = leg * n_clear + q;
+                    if (2 * slot < dl.off_f) *(double2 *)(rec + 2 * slot) = zz;
+                }
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
                     const unsigned ws = (unsigned)(first + q - w_lo);
@@ -768,7 +773,8 @@ __device__ __forceinline__ void trio_block_mfma(const FeatArgs &A, const BasisDe
                     const int i1 = pk.x & 0xffff, i2 = pk.x >> 16, cls = pk.y;
                     const double *oc = w.ox + (size_t)leg * A.n3.cap;           // ox | oy | oz are consecutive [cap] arrays
                     const double v1 = oc[i1] * w.oir[i1];
-                    const double v2 = cls == 0 ? oc[i2] * w.oir[i2] : ge[3 + leg];
+                    const double v2c = oc[i2] * w.oir[i2], v2n = ge[3 + leg];   // both fetched: no divergent round trip
+                    const double v2 = cls == 0 ? v2c : v2n;
                     const double a1 = cls == 2 ? 0.0 : v1;
                     const double a2 = cls == 0 ? v2 : (cls == 2 ? v1 : 0.0);
                     const double a3 = cls == 0 ? 0.0 : v2;
