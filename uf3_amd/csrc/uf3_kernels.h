@@ -716,6 +716,8 @@ __device__ __forceinline__ void trio_block_mfma(const FeatArgs &A, const BasisDe
     double4_t accf[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}}, acce = {0, 0, 0, 0};
     pc.lap(1);
     const int nrec = A.dense_nrec, batch = 3 * nrec;
+    const double lo_r[3] = {td->leg[0].t0, td->leg[1].t0, td->leg[2].t0};
+    const double hi_r[3] = {td->leg[0].tlast, td->leg[1].tlast, td->leg[2].tlast};
     for (int p0 = 0; p0 < k.n_items; p0 += batch) {
         // ---- walk: one triplet per lane, geometry to LDS sorted by class ------------------------------------
         int n0, n1, n2;
@@ -724,9 +726,9 @@ __device__ __forceinline__ void trio_block_mfma(const FeatArgs &A, const BasisDe
             bool valid = lane < batch && p0 + lane < k.n_items;
             if (valid) valid = trio_walk_geom<WANT_F>(A, g, w, td, k, m, sm, p0 + lane, tg);
             // leg masks t[0] <= r <= t[-1] (angles.py:502-508); both ends contribute nothing (see eval_triplet)
-            if (valid)
-                valid = (tg.rl > td->leg[0].t0) && (tg.rl < td->leg[0].tlast) && (tg.rm > td->leg[1].t0) &&
-                        (tg.rm < td->leg[1].tlast) && (tg.rn > td->leg[2].t0) && (tg.rn < td->leg[2].tlast);
+            if (valid)                   // (bounds hoisted; `&`, not `&&`: no branch, no memory access per clause)
+                valid = (tg.rl > lo_r[0]) & (tg.rl < hi_r[0]) & (tg.rm > lo_r[1]) & (tg.rm < hi_r[1]) &
+                        (tg.rn > lo_r[2]) & (tg.rn < hi_r[2]);
             const bool is0 = valid && tg.centre, is1 = valid && !tg.centre && tg.first, is2 = valid && !tg.centre && !tg.first;
             const unsigned long long m0 = __ballot(is0), m1 = __ballot(is1), m2 = __ballot(is2);
             n0 = __popcll(m0); n1 = __popcll(m1); n2 = __popcll(m2);
