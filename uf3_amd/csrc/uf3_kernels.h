@@ -675,7 +675,17 @@ __device__ __forceinline__ void trio_block_mfma(const FeatArgs &A, const BasisDe
                                                 const WaveLds &w, int m, int sm, int t, const ESink &es,
                                                 const int (&fragp)[4], const int *dsrc) {
     const int lane = lane_id();
-    const TrioDev *td = A.trios + t;
+    // the descriptor through the constant address space: scalar loads into SGPRs (the tables never change while a
+    // kernel runs; through a plain global pointer every field read is a vector load the compiler cannot hoist)
+    TrioDev td_copy;
+    {
+        typedef const __attribute__((address_space(4))) int *ConstInts;
+        ConstInts src = (ConstInts)(unsigned long long)(A.trios + t);
+        int *dst = (int *)&td_copy;
+#pragma unroll
+        for (int q = 0; q < (int)(sizeof(TrioDev) / sizeof(int)); q++) dst[q] = src[q];
+    }
+    const TrioDev *td = &td_copy;
     PhaseClock pc;
     TrioWalk k;
     trio_walk_setup<WANT_F>(A, w, td, sm, k);
