@@ -214,6 +214,21 @@ struct PhaseClock {
 struct PhaseClock { __device__ __forceinline__ void lap(int) {} };
 #endif
 
+// Read-only tables (descriptors, knot records ...) never change while a kernel runs.  Through a plain global
+// pointer the compiler must use vector loads it cannot hoist or merge (the kernels also store to global memory);
+// through the constant address space a wave-uniform address becomes scalar loads into SGPRs.
+template <class T>
+__device__ __forceinline__ T load_const(const T *p) {
+    static_assert(sizeof(T) % sizeof(int) == 0, "word-sized tables only");
+    typedef const __attribute__((address_space(4))) int *ConstInts;
+    ConstInts src = (ConstInts)(unsigned long long)p;
+    T out;
+    int *dst = (int *)&out;
+#pragma unroll
+    for (int q = 0; q < (int)(sizeof(T) / sizeof(int)); q++) dst[q] = src[q];
+    return out;
+}
+
 struct FeatArgs {
     const BasisDev *B;
     const TrioDev *trios;     // explicit global pointers (no flat loads through the struct)
@@ -677,14 +692,7 @@ __device__ __forceinline__ void trio_block_mfma(const FeatArgs &A, const BasisDe
     const int lane = lane_id();
     // the descriptor through the constant address space: scalar loads into SGPRs (the tables never change while a
     // kernel runs; through a plain global pointer every field read is a vector load the compiler cannot hoist)
-    TrioDev td_copy;
-    {
-        typedef const __attribute__((address_space(4))) int *ConstInts;
-        ConstInts src = (ConstInts)(unsigned long long)(A.trios + t);
-        int *dst = (int *)&td_copy;
-#pragma unroll
-        for (int q = 0; q < (int)(sizeof(TrioDev) / sizeof(int)); q++) dst[q] = src[q];
-    }
+    const TrioDev td_copy = load_const(A.trios + t);
     const TrioDev *td = &td_copy;
     PhaseClock pc;
     TrioWalk k;
@@ -1090,9 +1098,12 @@ k_featurize(FeatArgs A) {
             pcl.lap(0);
             for (int t = 0; t < B->T; t++) {
                 const TrioDev *td = A.trios + t;
-                if (trio_mode(td) != (DENSE ? 6 : MODE)) continue;
-                const bool touches = (td->sc == sm) || (WANT_F && (td->sa == sm || td->sb == sm));
-                if (!touches) { if (WANT_F && !(A.skip & 32)) zero_rows(A.x_f, m, F, td->col, td->ncol); continue; }
+                const int t_dense = load_const(&td->dense), t_nsrc = load_const(&td->nsrc), t_ncol = load_const(&td->ncol);
+                const int t_mode = t_dense ? 6 : (t_nsrc == 1 ? (t_ncol > WAVE ? 2 : 1) : (t_nsrc == 2 ? (t_ncol > WAVE ? 4 : 3) : 5));
+                if (t_mode != (DENSE ? 6 : MODE)) continue;
+                const int t_sc = load_const(&td->sc), t_sa = load_const(&td->sa), t_sb = load_const(&td->sb);
+                const bool touches = (t_sc == sm) || (WANT_F && (t_sa == sm || t_sb == sm));
+                if (!touches) { if (WANT_F && !(A.skip & 32)) zero_rows(A.x_f, m, F, load_const(&td->col), t_ncol); continue; }
                 if (MODE == 1) trio_block<WANT_E, WANT_F, 1, 1>(A, B, recs, g, w, m, sm, t, es);
                 else if (MODE == 2) trio_block<WANT_E, WANT_F, 1, 2>(A, B, recs, g, w, m, sm, t, es);
                 else if (MODE == 3) trio_block<WANT_E, WANT_F, 2, 1>(A, B, recs, g, w, m, sm, t, es);
