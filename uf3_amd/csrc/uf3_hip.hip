@@ -865,7 +865,7 @@ static int eval_impl(uf3_basis *b, const uf3_frames *fr, const double *d_pos, co
     A.pos = d_pos; A.spec = P.spec; A.c1 = dc; A.c2 = dc + n1; A.c3 = dc + n1 + n2;
     A.e_atom = c->e_atom.as<double>(); A.forces = d_forces; A.natoms = P.natoms;
     A.virial = d_virials ? A.e_atom + P.natoms : nullptr;
-    size_t lds = (size_t)A.n3.cap * 32 + ((size_t)5 * A.n3.cap + 1) * 4 + 16;
+    size_t lds = (size_t)A.n3.cap * 32 + ((size_t)5 * A.n3.cap + 2) * 4 + 16 + 2 * WAVE * EVAL_Q * sizeof(double);
     {
         Timed tm(c, T_EVAL);
         hipLaunchKernelGGL(k_eval, dim3(P.natoms), dim3(64), lds, st, A);

@@ -1145,23 +1145,25 @@ struct EvalArgs {
 __device__ __forceinline__ bool trio_value(const BasisDev *B, const double *c3, int trio, double rl, double rm, double rn,
                                            bool want_grad, double &val, double *grad) {
     if (trio < 0) return false;
-    const TrioDev *td = B->trios + trio;
-    if (!((rl > td->leg[0].t0) && (rl < td->leg[0].tlast) && (rm > td->leg[1].t0) && (rm < td->leg[1].tlast) &&
-          (rn > td->leg[2].t0) && (rn < td->leg[2].tlast))) return false;
+    const TrioDev *td = load_const(&B->trios) + trio;
+    const KnotRec *recs = load_const(&B->recs);
+    // all descriptor fields in flight together (per-lane trio: vector loads), then a branch-free range test
+    const LegDev l0 = td->leg[0], l1 = td->leg[1], l2 = td->leg[2];
+    const int dim_m = td->dim_m, dim_n = td->dim_n, lut_off = td->lut_off;
+    if (!((rl > l0.t0) & (rl < l0.tlast) & (rm > l1.t0) & (rm < l1.tlast) & (rn > l2.t0) & (rn < l2.tlast))) return false;
     KnotRec kl, km, kn;
-    int il = load_interval(B->recs, td->leg[0], rl, kl), im = load_interval(B->recs, td->leg[1], rm, km),
-        in = load_interval(B->recs, td->leg[2], rn, kn);
+    int il = load_interval(recs, l0, rl, kl), im = load_interval(recs, l1, rm, km), in = load_interval(recs, l2, rn, kn);
     double vl[4], vm[4], vn[4], dl[4], dm[4], dn[4];
     bspline4<true>(kl, rl, vl, dl);
     bspline4<true>(km, rm, vm, dm);
     bspline4<true>(kn, rn, vn, dn);
-    int mn = td->dim_m * td->dim_n;
-    const double *c = c3 + td->lut_off + (il - 3) * mn + (im - 3) * td->dim_n + (in - 3);
+    int mn = dim_m * dim_n;
+    const double *c = c3 + lut_off + (il - 3) * mn + (im - 3) * dim_n + (in - 3);
     double v = 0, g0 = 0, g1 = 0, g2 = 0;
     for (int a = 0; a < 4; a++)
         for (int b = 0; b < 4; b++) {
             double s = 0, sd = 0;
-            const double *row = c + a * mn + b * td->dim_n;
+            const double *row = c + a * mn + b * dim_n;
             for (int q = 0; q < 4; q++) { double cc = row[q]; s += cc * vn[q]; sd += cc * dn[q]; }
             v += vl[a] * vm[b] * s;
             if (want_grad) { g0 += dl[a] * vm[b] * s; g1 += vl[a] * dm[b] * s; g2 += vl[a] * vm[b] * sd; }
@@ -1175,11 +1177,14 @@ __device__ __forceinline__ double wave_sum(double v) {
     return v;
 }
 
+#define EVAL_Q 5          // doubles per queued bond of the evaluator
 __global__ void __launch_bounds__(64)
 k_eval(EvalArgs A) {
     extern __shared__ __align__(16) unsigned char smem[];
     const BasisDev *B = A.B;
     const int cap = A.n3.cap;
+    const KnotRec *recs_g = load_const(&B->recs);
+    const int S = load_const(&B->S);
     double *ox = (double *)smem, *oy = ox + cap, *oz = oy + cap, *orr = oz + cap;
     int *oparent = (int *)(orr + cap), *oshift = oparent + cap, *osidx = oshift + cap, *ospec = osidx + cap,
         *ooff = ospec + cap;
@@ -1193,29 +1198,65 @@ k_eval(EvalArgs A) {
     double pm[3] = {A.pos[3 * (size_t)m], A.pos[3 * (size_t)m + 1], A.pos[3 * (size_t)m + 2]};
     double e = 0.0, fx = 0.0, fy = 0.0, fz = 0.0;
     if (lane == 0) e = A.c1[sm];
+    // 2-body: bonds inside their pair's range are queued in LDS and evaluated 64 at a time (about one candidate in
+    // five survives the range test: evaluating in place would leave most lanes idle in the spline code)
+    double *queue = (double *)(ooff + cap + 1 + ((cap + 1) & 1));          // [128][EVAL_Q]: dx, dy, dz, d, species
+    int queued = 0;
+    auto drain = [&](int count) {
+        const double *c = queue + (size_t)lane * EVAL_Q;
+        if (lane < count) {
+            const double dx = c[0], dy = c[1], dz = c[2], d = c[3];
+            const PairDev &pd = B->pairs[B->pair_of[sm * UF3_MAX_SPECIES + (int)c[4]]];
+            KnotRec kr;
+            const LegDev leg = pd.leg;
+            const int col = pd.col;
+            int i = load_interval(recs_g, leg, d, kr);
+            double v[4], dv[4];
+            bspline4<true>(kr, d, v, dv);
+            const double *cf = A.c2 + (col - S) + (i - 3);
+            double phi = 0, dphi = 0;
+            for (int q = 0; q < 4; q++) { phi += cf[q] * v[q]; dphi += cf[q] * dv[q]; }
+            e += phi;
+            double s = 2.0 * dphi / d;
+            fx += s * dx; fy += s * dy; fz += s * dz;
+            if (want_v) {   // d/d(strain) of the directed pair sum: phi'(r) r (x) r / r
+                double t = dphi / d;
+                vir[0] += t * dx * dx; vir[1] += t * dy * dy; vir[2] += t * dz * dz;
+                vir[3] += t * dy * dz; vir[4] += t * dx * dz; vir[5] += t * dx * dy;
+            }
+        }
+    };
     for_each_candidate(g, A.cl, m, [&](bool ok, const SlotRec &sr, int sj, int s0, int s1, int s2) {
-        if (!ok) return;
-        const PairDev &pd = B->pairs[B->pair_of[sm * UF3_MAX_SPECIES + sj]];
-        double dx, dy, dz;
-        image_delta(g, sr, s0, s1, s2, pm, dx, dy, dz);
-        double d = norm3_rn(dx, dy, dz);
-        if (!(d > pd.rmin && d < pd.rmax)) return;
-        KnotRec kr;
-        int i = load_interval(B->recs, pd.leg, d, kr);
-        double v[4], dv[4];
-        bspline4<true>(kr, d, v, dv);
-        const double *c = A.c2 + (pd.col - B->S) + (i - 3);
-        double phi = 0, dphi = 0;
-        for (int q = 0; q < 4; q++) { phi += c[q] * v[q]; dphi += c[q] * dv[q]; }
-        e += phi;
-        double s = 2.0 * dphi / d;
-        fx += s * dx; fy += s * dy; fz += s * dz;
-        if (want_v) {   // d/d(strain) of the directed pair sum: phi'(r) r (x) r / r
-            double t = dphi / d;
-            vir[0] += t * dx * dx; vir[1] += t * dy * dy; vir[2] += t * dz * dz;
-            vir[3] += t * dy * dz; vir[4] += t * dx * dz; vir[5] += t * dx * dy;
+        double dx = 0, dy = 0, dz = 0, d = 0;
+        if (ok) {
+            const PairDev &pd = B->pairs[B->pair_of[sm * UF3_MAX_SPECIES + sj]];
+            const double rmin = pd.rmin, rmax = pd.rmax;
+            image_delta(g, sr, s0, s1, s2, pm, dx, dy, dz);
+            d = norm3_rn(dx, dy, dz);
+            ok = (d > rmin) & (d < rmax);
+        }
+        const unsigned long long mask = __ballot(ok);
+        if (ok) {
+            double *c = queue + (size_t)(queued + mbcnt(mask)) * EVAL_Q;
+            c[0] = dx; c[1] = dy; c[2] = dz; c[3] = d; c[4] = (double)sj;
+        }
+        queued += __popcll(mask);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (queued >= WAVE) {
+            drain(WAVE);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            queued -= WAVE;                                             // move the tail to the front
+            double tail[EVAL_Q];
+            if (lane < queued) for (int q = 0; q < EVAL_Q; q++) tail[q] = queue[(size_t)(WAVE + lane) * EVAL_Q + q];
+            __builtin_amdgcn_wave_barrier();
+            if (lane < queued) for (int q = 0; q < EVAL_Q; q++) queue[(size_t)lane * EVAL_Q + q] = tail[q];
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
         }
     });
+    drain(queued);
     if (B->T > 0) {
         int n = A.n3.cnt[m];
         size_t base = (size_t)m * cap;
