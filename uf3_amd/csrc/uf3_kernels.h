@@ -1388,7 +1388,9 @@ __global__ void k_mfma_probe(int *rowcol) {
 
 // One wave computes a 32x32 tile of G over a chunk of rows; 4 waves per block share nothing.
 // grid = (tile pairs (ti <= tj), row chunks).  A = X^T (16 x 4 per MFMA), B = X (4 x 16).
-__global__ void __launch_bounds__(256)
+// (min 4 waves/SIMD: with the default target of 8 the accumulators are shuttled between VGPRs and AGPRs around
+// every MFMA group -- 64 v_accvgpr moves per 4 MFMAs)
+__global__ void __launch_bounds__(256, 4)
 k_gram_mfma(const double *x, int64_t n_rows, int n_feat, int64_t ld, int rows_per_chunk,
             const int *tile_i, const int *tile_j, const int *frag_rowcol, double *gram) {
     int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -1399,14 +1401,36 @@ k_gram_mfma(const double *x, int64_t n_rows, int n_feat, int64_t ld, int rows_pe
     if (r1 > n_rows) r1 = n_rows;
     int i = lane & 15, k = lane >> 4;
     int ca0 = ti * 32 + i, ca1 = ca0 + 16, cb0 = tj * 32 + i, cb1 = cb0 + 16;
-    bool va0 = ca0 < n_feat, va1 = ca1 < n_feat, vb0 = cb0 < n_feat, vb1 = cb1 < n_feat;
+    const bool va0 = ca0 < n_feat, va1 = ca1 < n_feat, vb0 = cb0 < n_feat, vb1 = cb1 < n_feat;
+    // columns past n_feat are read from column 0 and zeroed by a select: the loads stay unconditional (a guarded
+    // load is a branch, and four branches per step keep only one step's loads in flight)
+    const double *pa0 = x + (va0 ? ca0 : 0), *pa1 = x + (va1 ? ca1 : 0), *pb0 = x + (vb0 ? cb0 : 0), *pb1 = x + (vb1 ? cb1 : 0);
     double4_t acc00 = {0, 0, 0, 0}, acc01 = {0, 0, 0, 0}, acc10 = {0, 0, 0, 0}, acc11 = {0, 0, 0, 0};
-    for (int64_t r = r0; r < r1; r += 4) {
-        int64_t row = r + k;
-        bool vr = row < r1;
-        const double *xr = x + row * ld;
-        double a0 = (vr && va0) ? xr[ca0] : 0.0, a1 = (vr && va1) ? xr[ca1] : 0.0;
-        double b0 = (vr && vb0) ? xr[cb0] : 0.0, b1 = (vr && vb1) ? xr[cb1] : 0.0;
+    int64_t r = r0;
+    constexpr int KU = 4;                                           // k-steps per trip: 4 * KU loads in flight
+    for (; r + 4 * KU <= r1; r += 4 * KU) {
+        double a0[KU], a1[KU], b0[KU], b1[KU];
+#pragma unroll
+        for (int u = 0; u < KU; u++) {
+            const int64_t o = (r + 4 * u + k) * ld;
+            a0[u] = pa0[o]; a1[u] = pa1[o]; b0[u] = pb0[o]; b1[u] = pb1[o];
+        }
+        __builtin_amdgcn_sched_group_barrier(0x20, 4 * KU, 0);      // all VMEM reads first
+#pragma unroll
+        for (int u = 0; u < KU; u++) {
+            const double x0 = va0 ? a0[u] : 0.0, x1 = va1 ? a1[u] : 0.0, y0 = vb0 ? b0[u] : 0.0, y1 = vb1 ? b1[u] : 0.0;
+            acc00 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, y0, acc00, 0, 0, 0);
+            acc01 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, y1, acc01, 0, 0, 0);
+            acc10 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, y0, acc10, 0, 0, 0);
+            acc11 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, y1, acc11, 0, 0, 0);
+        }
+    }
+    for (; r < r1; r += 4) {                                        // ragged end of the chunk
+        const int64_t row = r + k;
+        const bool vr = row < r1;
+        const int64_t o0 = (vr ? row : r0) * ld;
+        double a0 = pa0[o0], a1 = pa1[o0], b0 = pb0[o0], b1 = pb1[o0];
+        a0 = (vr && va0) ? a0 : 0.0; a1 = (vr && va1) ? a1 : 0.0; b0 = (vr && vb0) ? b0 : 0.0; b1 = (vr && vb1) ? b1 : 0.0;
         acc00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc00, 0, 0, 0);
         acc01 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc01, 0, 0, 0);
         acc10 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc10, 0, 0, 0);
