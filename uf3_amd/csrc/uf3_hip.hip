@@ -966,14 +966,15 @@ extern "C" int uf3_gram_dev(uf3_ctx *c, const double *dx, const double *dy, int6
     HIPCHK(c, hipStreamSynchronize(st));
     // enough row chunks to fill the chip, each a multiple of 4 rows
     int blocks_xy = (int)(np / 4);
-    int want_chunks = std::max(1, (c->n_cu * 4 + blocks_xy - 1) / blocks_xy);
+    int want_chunks = std::max(1, (c->n_cu * 8 + blocks_xy - 1) / blocks_xy);
     int64_t rpc = (n_rows + want_chunks - 1) / want_chunks;
     rpc = std::max<int64_t>(64, (rpc + 3) / 4 * 4);
     int chunks = (int)((n_rows + rpc - 1) / rpc);
     {
         Timed tm(c, T_GRAM);
-        hipLaunchKernelGGL(k_gram_mfma, dim3(blocks_xy, chunks), dim3(256), 0, st, dx, n_rows, n_feat, ld, (int)rpc,
-                           d_ti, d_tj, c->frag.as<int>(), d_gram);
+        const int chunks8 = (chunks + 7) / 8 * 8;                  // whole rounds over the 8 XCDs
+        hipLaunchKernelGGL(k_gram_mfma, dim3(blocks_xy * chunks8), dim3(256), 0, st, dx, n_rows, n_feat, ld, (int)rpc,
+                           blocks_xy, d_ti, d_tj, c->frag.as<int>(), d_gram);
         hipLaunchKernelGGL(k_gram_mirror, dim3((n_feat + 255) / 256, n_feat), dim3(256), 0, st, d_gram, n_feat);
         if (d_ord && dy) {
             int ochunks = (int)std::min<int64_t>(4096, (n_rows + 63) / 64);

@@ -1391,13 +1391,19 @@ __global__ void k_mfma_probe(int *rowcol) {
 // (min 4 waves/SIMD: with the default target of 8 the accumulators are shuttled between VGPRs and AGPRs around
 // every MFMA group -- 64 v_accvgpr moves per 4 MFMAs)
 __global__ void __launch_bounds__(256, 4)
-k_gram_mfma(const double *x, int64_t n_rows, int n_feat, int64_t ld, int rows_per_chunk,
+k_gram_mfma(const double *x, int64_t n_rows, int n_feat, int64_t ld, int rows_per_chunk, int blocks_xy,
             const int *tile_i, const int *tile_j, const int *frag_rowcol, double *gram) {
     int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    int pair = blockIdx.x * 4 + wave;
+    // XCD-aware order: workgroups are dealt to the 8 XCDs round-robin by their linear id, and each XCD has its own
+    // L2.  All tile pairs of one row chunk go to the same XCD, back to back, so that the chunk (rows x n_feat
+    // doubles, a few MB) is fetched into that L2 once and the other reads of it hit there.
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int chunk = xcd + 8 * (slot / blocks_xy), pair_block = slot % blocks_xy;
+    int pair = pair_block * 4 + wave;
     int ti = tile_i[pair], tj = tile_j[pair];
     if (ti < 0) return;
-    int64_t r0 = (int64_t)blockIdx.y * rows_per_chunk, r1 = r0 + rows_per_chunk;
+    int64_t r0 = (int64_t)chunk * rows_per_chunk, r1 = r0 + rows_per_chunk;
+    if (r0 >= n_rows) return;
     if (r1 > n_rows) r1 = n_rows;
     int i = lane & 15, k = lane >> 4;
     int ca0 = ti * 32 + i, ca1 = ca0 + 16, cb0 = tj * 32 + i, cb1 = cb0 + 16;
