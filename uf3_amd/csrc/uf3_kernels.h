@@ -961,7 +961,7 @@ __global__ void __launch_bounds__(WPB * WAVE, MODE == 0 ? 4 : (MODE == 7 ? 3 : 2
 k_featurize(FeatArgs A) {
     extern __shared__ __align__(16) unsigned char smem[];
     const BasisDev *B = A.B;
-    const int F = B->F, S = B->S, cap = A.n3.cap;
+    const int F = load_const(&B->F), S = load_const(&B->S), n_trios = load_const(&B->T), cap = A.n3.cap;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);           // wave-uniform: LDS pointers and atom indices in SGPRs
     double *erow = (double *)smem;                                         // [F] shared by the block (WANT_E)
@@ -1024,7 +1024,7 @@ k_featurize(FeatArgs A) {
         const int m = m0 + wave;
         const bool active = m < block_end;
         if (WANT_E) {
-            int f_first = A.frame_of[m0];
+            int f_first = load_const(A.frame_of + m0);
             if (f_first != erow_frame) {                          // block-uniform
                 __syncthreads();
                 if (erow_frame >= 0)
@@ -1037,9 +1037,9 @@ k_featurize(FeatArgs A) {
             }
         }
         if (!active) continue;
-        const int fr = A.frame_of[m];
+        const int fr = load_const(A.frame_of + m);
         const FrameGeom g = A.geoms[fr];
-        const int sm = A.spec[m];
+        const int sm = ((const __attribute__((address_space(4))) signed char *)(unsigned long long)A.spec)[m];
         const double pm[3] = {A.pos[3 * (size_t)m], A.pos[3 * (size_t)m + 1], A.pos[3 * (size_t)m + 2]};
         ESink es;
         es.lds = erow; es.glob = WANT_E ? A.x_e + (size_t)fr * F : nullptr; es.direct = (fr != erow_frame);
@@ -1077,9 +1077,9 @@ k_featurize(FeatArgs A) {
             if (A.build_n3) build_n3_list(A, B, g, w, m, n_cand);
         }
         // ---- 3-body ---------------------------------------------------------------------------
-        if (MODE != 0 && B->T > 0) {
+        if (MODE != 0 && n_trios > 0) {
             PhaseClock pcl;
-            const int n = A.n3.cnt[m];
+            const int n = load_const(A.n3.cnt + m);
             size_t base = (size_t)m * cap;
             wave_sync();
             for (int e = lane; e < n; e += WAVE) {
@@ -1096,7 +1096,7 @@ k_featurize(FeatArgs A) {
                 }
             wave_sync();
             pcl.lap(0);
-            for (int t = 0; t < B->T; t++) {
+            for (int t = 0; t < n_trios; t++) {
                 const TrioDev *td = A.trios + t;
                 const int t_dense = load_const(&td->dense), t_nsrc = load_const(&td->nsrc), t_ncol = load_const(&td->ncol);
                 const int t_mode = t_dense ? 6 : (t_nsrc == 1 ? (t_ncol > WAVE ? 2 : 1) : (t_nsrc == 2 ? (t_ncol > WAVE ? 4 : 3) : 5));
