@@ -535,7 +535,8 @@ template <bool WANT_E, bool WANT_F, int NSRC, int NCH>
 __device__ __forceinline__ void trio_block(const FeatArgs &A, const BasisDev *B, const KnotRec *recs, const FrameGeom &g,
                                            const WaveLds &w, int m, int sm, int t, const ESink &es) {
     const int lane = lane_id();
-    const TrioDev *td = A.trios + t;
+    const TrioDev td_copy = load_const(A.trios + t);          // scalar loads (see load_const)
+    const TrioDev *td = &td_copy;
     TrioWalk k;
     trio_walk_setup<WANT_F>(A, w, td, sm, k);
     const int ncol = td->ncol, F = B->F;
