@@ -99,7 +99,8 @@ void uf3_basis_destroy(uf3_basis *basis);
 /* Diagnostics: which featurizer specialisations the basis uses.  Bit 0: one-body + pair blocks; bits 1..5: 3-body
  * blocks on the generic output-stationary kernels ((symmetry images, 64-column chunks) = (1,1) (1,2) (2,1) (2,2)
  * (6,1)); bit 6: 3-body blocks whose window of non-trimmed bins is small enough (3*ext_l*ext_m <= 32, ext_n <= 16)
- * for the fp64 matrix-core kernel.  Setting UF3_NO_MFMA_FEAT in the environment before uf3_basis_create keeps
+ * for the fp64 matrix-core kernel with two 16-row tiles; bits 8 / 9: wider windows (<= 64 / <= 128 rows) on the same
+ * kernel with four / eight row tiles.  Setting UF3_NO_MFMA_FEAT in the environment before uf3_basis_create keeps
  * every block on the generic kernels (used by the tests to compare the two paths). */
 int uf3_basis_featurizer_modes(const uf3_basis *basis, int32_t *mask);
 

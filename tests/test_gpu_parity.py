@@ -406,16 +406,39 @@ def _asymmetric_window_basis():
         resolution_map=res, leading_trim={2: 0, 3: 3}, trailing_trim={2: 3, 3: 3})
 
 
-@pytest.mark.parametrize("which", ["notebook_binary", "asymmetric_window", "h2o_golden", "w16_sym1", "w16_sym3"])
-def test_matrix_core_and_generic_trio_kernels_agree(which):
-    """The fp64 MFMA specialisation (mode bit 6) against the output-stationary kernels on the same inputs, and
-    both against the oracle."""
+def _resolution_basis(res3, lead3=3, elements=('Mo', 'W')):
+    from uf3_amd.data import composition
+    from uf3_amd.representation import bspline
+    cs = composition.ChemicalSystem(list(elements), 3)
+    pairs, trios = cs.interactions_map[2], cs.interactions_map[3]
+    return bspline.BSplineBasis(
+        cs, r_min_map={**{p: 0.001 for p in pairs}, **{t: [1.5, 1.5, 1.5] for t in trios}},
+        r_max_map={**{p: 5.5 for p in pairs}, **{t: [3.5, 3.5, 7.0] for t in trios}},
+        resolution_map={**{p: 15 for p in pairs}, **{t: list(res3) for t in trios}},
+        leading_trim={2: 0, 3: lead3}, trailing_trim={2: 3, 3: 3})
+
+
+@pytest.mark.parametrize("which,bit", [("notebook_binary", 6), ("asymmetric_window", 6), ("h2o_golden", 6), ("w16_sym1", 6),
+                                       ("w16_sym3", 6), ("four_row_tiles", 8), ("eight_row_tiles", 9),
+                                       ("eight_row_tiles_unary", 9)])
+def test_matrix_core_and_generic_trio_kernels_agree(which, bit):
+    """The fp64 MFMA specialisations (mode bits 6 / 8 / 9: two / four / eight 16-row tiles) against the
+    output-stationary kernels on the same inputs, and both against the oracle."""
     if which == "notebook_binary":
         frames = [synthetic.lattice_frame("bcc", (3, 3, 4), 3.165, [42, 74], 11 + k) for k in range(2)]
         basis = synthetic.notebook_basis(['Mo', 'W'])
     elif which == "asymmetric_window":
         frames = [synthetic.lattice_frame("bcc", (3, 4, 3), 3.2, [42, 74], 5, rattle=0.12)]
         basis = _asymmetric_window_basis()
+    elif which == "four_row_tiles":            # 4 x 4 x 11 kept bins: 48 rows
+        frames = [synthetic.lattice_frame("bcc", (3, 3, 4), 3.165, [42, 74], 31, rattle=0.1)]
+        basis = _resolution_basis([7, 7, 14])
+    elif which == "eight_row_tiles":           # 6 x 6 x 12 kept bins (no leading trim): 108 rows, 3 energy tiles
+        frames = [synthetic.lattice_frame("bcc", (3, 4, 3), 3.165, [42, 74], 32, rattle=0.1)]
+        basis = synthetic.notebook_basis(['Mo', 'W'], lead3=0)
+    elif which == "eight_row_tiles_unary":     # 5 x 5 x 13 kept bins, symmetry 2 fold
+        frames = [synthetic.lattice_frame("bcc", (3, 3, 3), 3.165, [74], 33, rattle=0.1)]
+        basis = _resolution_basis([8, 8, 16], elements=('W',))
     else:
         d, meta, atoms = load_case({"h2o_golden": "case_h2o", "w16_sym1": "case_w16_sym1", "w16_sym3": "case_w16_sym3"}[which])
         if which != "h2o_golden":        # the captured bases keep too many bins: trim the leading ones as well
@@ -425,8 +448,8 @@ def test_matrix_core_and_generic_trio_kernels_agree(which):
         frames, basis = [atoms], basis_from_meta(meta)
     xe_m, xf_m, modes_m = _fresh_rows(basis, frames)
     xe_g, xf_g, modes_g = _fresh_rows(basis, frames, UF3_NO_MFMA_FEAT="1")
-    assert modes_m & (1 << 6), "expected the matrix-core specialisation for this basis"
-    assert not (modes_g & (1 << 6)) and (modes_g & 0x3e)
+    assert modes_m & (1 << bit), f"expected featurizer mode bit {bit} for this basis, got {modes_m:#x}"
+    assert not (modes_g & 0x340) and (modes_g & 0x3e)
     assert rel_err(xe_m, xe_g) < 1e-12 and rel_err(xf_m, xf_g) < 1e-12
     ob = O.OracleBasis(basis)
     off = 0
@@ -435,14 +458,20 @@ def test_matrix_core_and_generic_trio_kernels_agree(which):
         assert rel_err(xe_m[k], ref["xe"]) < TOL
         assert rel_err(xf_m[off:off + len(fr)].reshape(ref["xf"].shape), ref["xf"]) < TOL
         off += len(fr)
+    # energy-only and forces-only launches of the same specialisation
+    fz = process.BasisFeaturizer(basis)
+    assert rel_err(fz.featurize_frames(frames, forces=False)[0], xe_m) < 1e-12
+    assert rel_err(fz.featurize_frames(frames, energy=False)[1], xf_m) < 1e-12
 
 
-def test_wide_windows_stay_on_generic_kernels():
-    """leading_trim 0 keeps 6 x 6 x 12 bins per trio: too wide for the matrix-core tiles."""
-    fz = process.BasisFeaturizer(synthetic.notebook_basis(['W'], lead3=0))
+def test_windows_too_wide_for_the_tiles_stay_on_generic_kernels():
+    """More than 16 kept n bins (or more than 128 rows): output-stationary kernels; default trims: matrix cores."""
+    fz = process.BasisFeaturizer(_resolution_basis([6, 6, 20], lead3=0, elements=('W',)))     # 6 x 6 x 20 kept bins
     modes = fz._dev()[1].featurizer_modes
-    assert not (modes & (1 << 6)) and (modes & 0x3e)
-    # the reference's default trims (3 leading, 3 trailing) give 3 x 3 x 9: matrix cores
+    assert not (modes & 0x340) and (modes & 0x3e)
+    atoms = synthetic.lattice_frame("bcc", (3, 3, 3), 3.165, [74], 35, rattle=0.1)
+    _check_against_oracle(fz.bspline_config, [atoms])
+    # the reference's default trims (3 leading, 3 trailing) give 3 x 3 x 9: matrix cores, two row tiles
     assert process.BasisFeaturizer(synthetic.config_c3()[1])._dev()[1].featurizer_modes & (1 << 6)
 
 

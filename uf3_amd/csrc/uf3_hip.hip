@@ -323,12 +323,15 @@ extern "C" int uf3_basis_create(uf3_ctx *c, const uf3_basis_spec *s, uf3_basis *
         }
         td.dense = 0;
         for (int a = 0; a < 3; a++) { td.lo[a] = hi[a] < 0 ? 0 : lo[a]; td.ext[a] = hi[a] < 0 ? 1 : hi[a] - lo[a] + 1; }
-        if (3 * td.ext[0] * td.ext[1] <= 32 && td.ext[2] <= 16 && !getenv("UF3_NO_MFMA_FEAT")) {
-            td.dense = 1;
+        // 16-row tiles the (c, l, m) rows of the window need: 2, 4 or 8 (wider windows stay on the generic kernels)
+        const int rows3 = 3 * td.ext[0] * td.ext[1];
+        const int tiles = rows3 <= 32 ? 2 : (rows3 <= 64 ? 4 : (rows3 <= 128 ? 8 : 0));
+        if (tiles && td.ext[2] <= 16 && !getenv("UF3_NO_MFMA_FEAT") && (tiles == 2 || !getenv("UF3_NO_WIDE_MFMA"))) {
+            td.dense = tiles;
             DenseLayout dl = dense_layout(td.ext[0], td.ext[1], td.ext[2]);
             b->dense_stride = std::max(b->dense_stride, dl.stride);
         }
-        b->modes |= 1 << (td.dense ? 6 : td.nsrc == 1 ? (td.ncol > WAVE ? 2 : 1) : (td.nsrc == 2 ? (td.ncol > WAVE ? 4 : 3) : 5));
+        b->modes |= 1 << (td.dense == 2 ? 6 : td.dense == 4 ? 8 : td.dense == 8 ? 9 : td.nsrc == 1 ? (td.ncol > WAVE ? 2 : 1) : (td.nsrc == 2 ? (td.ncol > WAVE ? 4 : 3) : 5));
         for (auto &v : per_col) for (int k = 0; k < td.nsrc; k++) {
             int sp = k < (int)v.size() ? v[k] : -1;
             colsrc.push_back(sp);
@@ -686,9 +689,10 @@ extern "C" int uf3_featurize_dev(uf3_basis *b, const uf3_frames *fr, const doubl
     A.frag = nullptr;
     A.dense_stage = DENSE_DUMP; A.dense_nrec = DENSE_NREC;
     A.dsrc = b->d_dsrc; A.n_dsrc = (int)b->n_dsrc;
-    const bool dsrc_ok = (b->modes & (1 << 6)) && b->n_dsrc * sizeof(int) <= 8192 && !getenv("UF3_NO_LDS_DSRC");
+    const int dense_modes = (1 << 6) | (1 << 8) | (1 << 9);
+    const bool dsrc_ok = (b->modes & dense_modes) && b->n_dsrc * sizeof(int) <= 8192 && !getenv("UF3_NO_LDS_DSRC");
     A.dsrc_lds = dsrc_ok;
-    if (b->modes & (1 << 6)) { rc = ensure_frag(c); if (rc) return rc; A.frag = c->frag.as<int>(); }
+    if (b->modes & dense_modes) { rc = ensure_frag(c); if (rc) return rc; A.frag = c->frag.as<int>(); }
     A.geoms = P.geoms; A.frame_of = P.frame_of; A.cl = P.cl;
     std::memset(&A.n3, 0, sizeof(A.n3));
     A.n3.cap = 1;
@@ -714,14 +718,15 @@ extern "C" int uf3_featurize_dev(uf3_basis *b, const uf3_frames *fr, const doubl
         HIPCHK(c, hipMemsetAsync(A.n3_need, 0, 2 * sizeof(int), st));       // n3_need, cand_need
         {
             Timed tm(c, T_FEAT);
-            for (int mode = 0; mode <= 6; mode++) {
-                if (!(b->modes & (1 << mode))) continue;
+            for (int mode = 0; mode <= 9; mode++) {
+                if (mode == 7 || !(b->modes & (1 << mode))) continue;             // (7 = mode 6 at 3 waves/SIMD)
+                const bool dense_mode = mode == 6 || mode >= 8;
                 // knot records go to LDS when the block then still reaches the occupancy its registers allow
                 size_t n_rec_mode = mode == 0 ? b->n_pair_recs : b->n_recs;
                 const int S = b->host.S;
                 const size_t cu_lds = 160 * 1024 - 1024;
-                if (mode == 6) A.dsrc_lds = dsrc_ok;
-                size_t lds_extra = (mode == 6 && A.dsrc_lds) ? sizeof(int) * b->n_dsrc : 0;
+                if (dense_mode) A.dsrc_lds = dsrc_ok;
+                size_t lds_extra = (dense_mode && A.dsrc_lds) ? sizeof(int) * b->n_dsrc : 0;
                 int launch_mode = mode;
                 bool recs_lds = false;
                 size_t lds = 0, lds_plain = 0, lds_recs = 0;
@@ -747,6 +752,9 @@ extern "C" int uf3_featurize_dev(uf3_basis *b, const uf3_frames *fr, const doubl
                         }
                     }
                     if (!found) { A.dense_nrec = nrec_max; A.dense_stage = std::max(DENSE_DUMP, nrec_max * b->dense_stride); }
+                } else if (dense_mode) {
+                    A.dense_nrec = std::max(4, std::min(DENSE_NREC, 1056 / b->dense_stride));
+                    A.dense_stage = std::max(DENSE_DUMP, A.dense_nrec * b->dense_stride);
                 }
                 if (launch_mode != 7) {
                     lds_plain = feat_lds_bytes(F, S, cap, A.cand_cap, want_e, 0, mode, A.dense_stage, A.dense_nrec, A.n_pair_cols) + lds_extra;
@@ -786,7 +794,9 @@ extern "C" int uf3_featurize_dev(uf3_basis *b, const uf3_frames *fr, const doubl
                     case 4: UF3_LAUNCH(4); break;
                     case 5: UF3_LAUNCH(5); break;
                     case 6: UF3_LAUNCH(6); break;
-                    default: UF3_LAUNCH(7); break;
+                    case 7: UF3_LAUNCH(7); break;
+                    case 8: UF3_LAUNCH(8); break;
+                    default: UF3_LAUNCH(9); break;
                 }
 #undef UF3_LAUNCH
 #undef UF3_LAUNCH1

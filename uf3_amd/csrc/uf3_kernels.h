@@ -606,60 +606,96 @@ __host__ __device__ __forceinline__ DenseLayout dense_layout(int ext_l, int ext_
 #define DENSE_NREC 21     // records staged per pass (3 lanes each), upper bound; the launch may use fewer
 #define GEO_STRIDE 8      // doubles per walked triplet: rl, rm, rn | e[3] (neighbour role: m -> k) | packed ints | pad
 
-// per-lane operand offsets (doubles, relative to the record of the lane's K slot)
+// per-lane operand offsets (doubles, relative to the record of the lane's K slot).  TM = 16-row tiles of the
+// (c, l, m) rows: 2 (windows of <= 10 pairs: the reference's default trims), 4 or 8 (wider windows); the energy rows
+// (c = x, pair < Pk) sit in the first TE = ceil(Pk / 16) tiles.
+template <int TM>
 struct DenseLane {
-    int l[2], m[2], f[2];    // row (c, l, m) of tile 0 / 1: L pair, M pair, (A1_c, A2_c) pair
-    int g[2];                // ... A3_c
+    int l[TM], m[TM], f[TM]; // row (c, l, m) of tile tm: L pair, M pair, (A1_c, A2_c) pair
+    int g[TM];               // ... A3_c
     int q;                   // 1 for K slot "Q" lanes of the two-record steps, else 0
     int n;                   // N pair of this lane's window bin
-    bool e_row;              // tile-0 row is an energy row (c = x, pair < Pk)
+    unsigned e_rows;         // bit te: this lane's row of tile te is an energy row
 };
+__host__ __device__ constexpr int dense_te(int tm) { return tm == 2 ? 1 : (tm == 4 ? 2 : 3); }
 
-template <bool WANT_E, bool MASK>
-__device__ __forceinline__ void mfma_quad(const double *rec, bool live, const DenseLane &o, double4_t (&accf)[2], double4_t &acce) {
-    // reads first, then the products, then the MFMAs (see mfma_pair)
+template <bool WANT_E, bool MASK, int TM>
+__device__ __forceinline__ void mfma_quad(const double *rec, bool live, const DenseLane<TM> &o, double4_t (&accf)[TM],
+                                          double4_t (&acce)[dense_te(TM)]) {
+    // reads first, then the products, then the MFMAs (see mfma_pair); at most four tiles' operands live at a time
+    constexpr int TE = dense_te(TM);
+    constexpr int TC = TM < 4 ? TM : 4;
     const double bv = rec[o.n];
-    const double2 L0 = *(const double2 *)(rec + o.l[0]), M0 = *(const double2 *)(rec + o.m[0]), F0 = *(const double2 *)(rec + o.f[0]);
-    const double2 L1 = *(const double2 *)(rec + o.l[1]), M1 = *(const double2 *)(rec + o.m[1]), F1 = *(const double2 *)(rec + o.f[1]);
-    __builtin_amdgcn_sched_group_barrier(0x100, 7, 0);
-    double a0 = fma(L0.y * M0.x, F0.x, (L0.x * M0.y) * F0.y);
-    double a1 = fma(L1.y * M1.x, F1.x, (L1.x * M1.y) * F1.y);
-    double ae = (WANT_E && o.e_row) ? L0.x * M0.x : 0.0;
-    if (MASK) { a0 = live ? a0 : 0.0; a1 = live ? a1 : 0.0; ae = live ? ae : 0.0; }
-    accf[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, bv, accf[0], 0, 0, 0);
-    accf[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, bv, accf[1], 0, 0, 0);
-    if (WANT_E) acce = __builtin_amdgcn_mfma_f64_16x16x4f64(ae, bv, acce, 0, 0, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+#pragma unroll
+    for (int t0 = 0; t0 < TM; t0 += TC) {
+        double2 L[TC], M[TC], Fv[TC];
+#pragma unroll
+        for (int u = 0; u < TC; u++) {
+            L[u] = *(const double2 *)(rec + o.l[t0 + u]); M[u] = *(const double2 *)(rec + o.m[t0 + u]);
+            Fv[u] = *(const double2 *)(rec + o.f[t0 + u]);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x100, 3 * TC, 0);
+        double a[TC], ae[TC];
+#pragma unroll
+        for (int u = 0; u < TC; u++) {
+            a[u] = fma(L[u].y * M[u].x, Fv[u].x, (L[u].x * M[u].y) * Fv[u].y);
+            if (MASK) a[u] = live ? a[u] : 0.0;
+            ae[u] = (WANT_E && t0 + u < TE && ((o.e_rows >> (t0 + u)) & 1u)) ? L[u].x * M[u].x : 0.0;
+            if (MASK) ae[u] = live ? ae[u] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < TC; u++) accf[t0 + u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], bv, accf[t0 + u], 0, 0, 0);
+        if (WANT_E)
+#pragma unroll
+            for (int u = 0; u < TC; u++)
+                if (t0 + u < TE) acce[t0 + u] = __builtin_amdgcn_mfma_f64_16x16x4f64(ae[u], bv, acce[t0 + u], 0, 0, 0);
+    }
 }
 
 // two neighbour-role records per step; x/y/z: this lane's three factors (B or B' of leg l, of leg m, direction)
-template <bool MASK>
-__device__ __forceinline__ void mfma_pair(const double *rec, bool live, const int (&x)[2], const int (&y)[2], const int (&z)[2],
-                                          int bn, double4_t (&accf)[2]) {
-    // all seven operand reads go out before anything waits on them (left alone, the scheduler keeps the register
-    // count minimal and waits after every read: four LDS round trips per step instead of one)
+template <bool MASK, int TM>
+__device__ __forceinline__ void mfma_pair(const double *rec, bool live, const DenseLane<TM> &o, int dx, int dy, int bn,
+                                          double4_t (&accf)[TM]) {
+    // all operand reads (of up to four tiles) go out before anything waits on them (left alone, the scheduler keeps
+    // the register count minimal and waits after every read: one LDS round trip per read instead of one per step)
+    constexpr int TC = TM < 4 ? TM : 4;
     const double bv = rec[bn];
-    const double x0 = rec[x[0]], y0 = rec[y[0]], z0 = rec[z[0]], x1 = rec[x[1]], y1 = rec[y[1]], z1 = rec[z[1]];
-    __builtin_amdgcn_sched_group_barrier(0x100, 7, 0);      // 7 DS reads
-    double a0 = (x0 * y0) * z0, a1 = (x1 * y1) * z1;
-    if (MASK) { a0 = live ? a0 : 0.0; a1 = live ? a1 : 0.0; }
-    __builtin_amdgcn_sched_group_barrier(0x2, MASK ? 8 : 4, 0);   // VALU
-    accf[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, bv, accf[0], 0, 0, 0);
-    accf[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, bv, accf[1], 0, 0, 0);
-    __builtin_amdgcn_sched_group_barrier(0x8, 2, 0);        // 2 MFMA
+    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+#pragma unroll
+    for (int t0 = 0; t0 < TM; t0 += TC) {
+        double xv[TC], yv[TC], zv[TC];
+#pragma unroll
+        for (int u = 0; u < TC; u++) {
+            xv[u] = rec[o.l[t0 + u] + dx]; yv[u] = rec[o.m[t0 + u] + dy]; zv[u] = rec[o.q ? o.g[t0 + u] : o.f[t0 + u] + dy];
+        }
+        __builtin_amdgcn_sched_group_barrier(0x100, 3 * TC, 0);                           // DS reads
+        double a[TC];
+#pragma unroll
+        for (int u = 0; u < TC; u++) {
+            a[u] = (xv[u] * yv[u]) * zv[u];
+            if (MASK) a[u] = live ? a[u] : 0.0;
+        }
+        __builtin_amdgcn_sched_group_barrier(0x2, (MASK ? 4 : 2) * TC, 0);                // VALU
+#pragma unroll
+        for (int u = 0; u < TC; u++) accf[t0 + u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], bv, accf[t0 + u], 0, 0, 0);
+        __builtin_amdgcn_sched_group_barrier(0x8, TC, 0);                                 // MFMA
+    }
 }
 
-template <bool WANT_E, bool WANT_F>
-__device__ __forceinline__ void mfma_records(const double *stage, int stride, int n0, int n1, int n2, const DenseLane &o,
-                                             double4_t (&accf)[2], double4_t &acce) {
+template <bool WANT_E, bool WANT_F, int TM>
+__device__ __forceinline__ void mfma_records(const double *stage, int stride, int n0, int n1, int n2, const DenseLane<TM> &o,
+                                             double4_t (&accf)[TM], double4_t (&acce)[dense_te(TM)]) {
+    constexpr int TE = dense_te(TM);
     const int ks = lane_id() >> 4;
     if (WANT_F) {
         {   // class 0: four records per step
             const double *rec = stage + (size_t)ks * stride;
             const int n_full = n0 & ~3;
             int q = 0;
-            for (; q < n_full; q += 4, rec += 4 * stride) mfma_quad<WANT_E, false>(rec, true, o, accf, acce);
+            for (; q < n_full; q += 4, rec += 4 * stride) mfma_quad<WANT_E, false, TM>(rec, true, o, accf, acce);
             // (lanes past the end read record 0: whatever lies behind the stage need not be finite)
-            if (q < n0) mfma_quad<WANT_E, true>(q + ks < n0 ? rec : stage, q + ks < n0, o, accf, acce);
+            if (q < n0) mfma_quad<WANT_E, true, TM>(q + ks < n0 ? rec : stage, q + ks < n0, o, accf, acce);
         }
         const int pl = 1 - o.q;                        // "P" lanes pick the derivative of the leg that joins centre and m
         const int bn = o.n + o.q;                      // B operand: B_n for P slots, B'_n for Q slots
@@ -667,29 +703,32 @@ __device__ __forceinline__ void mfma_records(const double *stage, int stride, in
         for (int cls = 1; cls <= 2; cls++) {
             const int cnt = cls == 1 ? n1 : n2, start = cls == 1 ? n0 : n0 + n1;
             const int dx = cls == 1 ? pl : 0, dy = cls == 1 ? 0 : pl;
-            const int x[2] = {o.l[0] + dx, o.l[1] + dx}, y[2] = {o.m[0] + dy, o.m[1] + dy};
-            const int z[2] = {o.q ? o.g[0] : o.f[0] + dy, o.q ? o.g[1] : o.f[1] + dy};
             const double *rec = stage + (size_t)(start + (ks >> 1)) * stride;
             const int n_full = cnt & ~1;
             int q = 0;
 #pragma unroll 2
-            for (; q < n_full; q += 2, rec += 2 * stride) mfma_pair<false>(rec, true, x, y, z, bn, accf);
-            if (q < cnt) mfma_pair<true>((ks >> 1) == 0 ? rec : stage, (ks >> 1) == 0, x, y, z, bn, accf);
+            for (; q < n_full; q += 2, rec += 2 * stride) mfma_pair<false, TM>(rec, true, o, dx, dy, bn, accf);
+            if (q < cnt) mfma_pair<true, TM>((ks >> 1) == 0 ? rec : stage, (ks >> 1) == 0, o, dx, dy, bn, accf);
         }
     } else if (WANT_E) {
         const double *rec = stage + (size_t)ks * stride;
         for (int q = 0; q < n0; q += 4, rec += 4 * stride) {
             const double *r = q + ks < n0 ? rec : stage;
-            const double av = (q + ks < n0 && o.e_row) ? r[o.l[0]] * r[o.m[0]] : 0.0;
-            acce = __builtin_amdgcn_mfma_f64_16x16x4f64(av, r[o.n], acce, 0, 0, 0);
+            const double bv = r[o.n];
+#pragma unroll
+            for (int te = 0; te < TE; te++) {
+                const double av = (q + ks < n0 && ((o.e_rows >> te) & 1u)) ? r[o.l[te]] * r[o.m[te]] : 0.0;
+                acce[te] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acce[te], 0, 0, 0);
+            }
         }
     }
 }
 
-template <bool WANT_E, bool WANT_F>
+template <bool WANT_E, bool WANT_F, int TM>
 __device__ __forceinline__ void trio_block_mfma(const FeatArgs &A, const BasisDev *B, const KnotRec *recs, const FrameGeom &g,
                                                 const WaveLds &w, int m, int sm, int t, const ESink &es,
                                                 const int (&fragp)[4], const int *dsrc) {
+    constexpr int TE = dense_te(TM);
     const int lane = lane_id();
     // the descriptor through the constant address space: scalar loads into SGPRs (the tables never change while a
     // kernel runs; through a plain global pointer every field read is a vector load the compiler cannot hoist)
@@ -706,9 +745,10 @@ __device__ __forceinline__ void trio_block_mfma(const FeatArgs &A, const BasisDe
     const int r16 = lane & 15;
     // per-lane operand offsets; small quotients by multiply-shift (exact for < 64)
     const int inv_pk = (65536 + Pk - 1) / Pk, inv_em = (65536 + ext_m - 1) / ext_m;      // wave-uniform
-    DenseLane o;
+    DenseLane<TM> o;
+    o.e_rows = 0;
 #pragma unroll
-    for (int tm = 0; tm < 2; tm++) {
+    for (int tm = 0; tm < TM; tm++) {
         const int row = tm * 16 + r16;
         const int c = (row * inv_pk) >> 16, p = row - c * Pk;
         const int pl = (p * inv_em) >> 16, pm = p - pl * ext_m;
@@ -717,10 +757,10 @@ __device__ __forceinline__ void trio_block_mfma(const FeatArgs &A, const BasisDe
         o.m[tm] = ok ? dl.off_m + 2 * pm : dl.off_z;
         o.f[tm] = ok ? dl.off_f + 2 * c : dl.off_z;
         o.g[tm] = ok ? dl.off_f + 6 + c : dl.off_z;
+        if (tm < TE && row < Pk) o.e_rows |= 1u << tm;
     }
     o.q = (lane >> 4) & 1;
     o.n = r16 < ext_n ? dl.off_n + 2 * r16 : dl.off_z;
-    o.e_row = r16 < Pk;
     // staging role of this lane: leg `leg` of staged record `li` (lanes 3*li .. 3*li+2)
     const int li = (lane * 21846) >> 16, leg = lane - 3 * li;
     LegDev lg;
@@ -732,7 +772,11 @@ __device__ __forceinline__ void trio_block_mfma(const FeatArgs &A, const BasisDe
     const int w_off = leg == 0 ? 0 : (leg == 1 ? dl.off_m : dl.off_n);
     const int w_ext = leg == 0 ? ext_l : (leg == 1 ? ext_m : ext_n), w_lo = leg == 0 ? lo_l : (leg == 1 ? lo_m : lo_n);
     const int n_clear = (dl.off_f / 2 + 2) / 3;                          // window pairs each of a record's lanes clears
-    double4_t accf[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}}, acce = {0, 0, 0, 0};
+    double4_t accf[TM], acce[TE];
+#pragma unroll
+    for (int tm = 0; tm < TM; tm++) accf[tm] = double4_t{0, 0, 0, 0};
+#pragma unroll
+    for (int te = 0; te < TE; te++) acce[te] = double4_t{0, 0, 0, 0};
     pc.lap(1);
     const int nrec = A.dense_nrec, batch = 3 * nrec;
     const double lo_r[3] = {td->leg[0].t0, td->leg[1].t0, td->leg[2].t0};
@@ -808,34 +852,68 @@ __device__ __forceinline__ void trio_block_mfma(const FeatArgs &A, const BasisDe
             pc.lap(4);
             // class counts inside this pass
             const int c0 = max(0, min(n_part, n0 - base)), c01 = max(0, min(n_part, n0 + n1 - base));
-            if (!(A.skip & 8)) mfma_records<WANT_E, WANT_F>(w.stage, dl.stride, c0, c01 - c0, n_part - c01, o, accf, acce);
+            if (!(A.skip & 8)) mfma_records<WANT_E, WANT_F, TM>(w.stage, dl.stride, c0, c01 - c0, n_part - c01, o, accf, acce);
             wave_sync();
             pc.lap(5);
         }
     }
-    // accumulator window -> LDS (rows: 32 force rows (c, l, m), then 16 energy rows (l, m); 16 n bins each),
-    // then lanes <-> columns fold the symmetry images and write the rows
+    // accumulator window -> LDS, then lanes <-> columns fold the symmetry images and write the rows
     double *dump = w.stage;
-#pragma unroll
-    for (int v = 0; v < 4; v++) {
-        if (WANT_F) { dump[fragp[v]] = accf[0][v]; dump[256 + fragp[v]] = accf[1][v]; }
-        if (WANT_E) dump[512 + fragp[v]] = acce[v];
-    }
-    wave_sync();
     const int nsrc = td->nsrc;
-    for (int col = lane; col < ncol; col += WAVE) {
-        double fx = 0, fy = 0, fz = 0, en = 0;
-        for (int q = 0; q < nsrc; q++) {
-            const int off = dsrc[td->src_off + col * nsrc + q];
-            if (off < 0) continue;
-            if (WANT_F) { fx += dump[off]; fy += dump[Pk * 16 + off]; fz += dump[2 * Pk * 16 + off]; }
-            if (WANT_E) en += dump[512 + off];
+    if (TM == 2) {
+        // rows: 32 force rows (c, l, m), then 16 energy rows (l, m); 16 n bins each: one pass
+#pragma unroll
+        for (int v = 0; v < 4; v++) {
+            if (WANT_F) { dump[fragp[v]] = accf[0][v]; dump[256 + fragp[v]] = accf[1][v]; }
+            if (WANT_E) dump[512 + fragp[v]] = acce[0][v];
         }
-        if (WANT_F && !(A.skip & 32)) {
-            double *dst = A.x_f + (size_t)m * 3 * F + td->col + col;
-            dst[0] = fx; dst[F] = fy; dst[2 * (size_t)F] = fz;
+        wave_sync();
+        for (int col = lane; col < ncol; col += WAVE) {
+            double fx = 0, fy = 0, fz = 0, en = 0;
+            for (int q = 0; q < nsrc; q++) {
+                const int off = dsrc[td->src_off + col * nsrc + q];
+                if (off < 0) continue;
+                if (WANT_F) { fx += dump[off]; fy += dump[Pk * 16 + off]; fz += dump[2 * Pk * 16 + off]; }
+                if (WANT_E) en += dump[512 + off];
+            }
+            if (WANT_F && !(A.skip & 32)) {
+                double *dst = A.x_f + (size_t)m * 3 * F + td->col + col;
+                dst[0] = fx; dst[F] = fy; dst[2 * (size_t)F] = fz;
+            }
+            if (WANT_E) es.add(td->col + col, en);
         }
-        if (WANT_E) es.add(td->col + col, en);
+    } else {
+        // wider windows do not fit the stage at once: one pass per component (x, y, z, energy), Pk rows each
+        for (int comp = WANT_F ? 0 : 3; comp < (WANT_E ? 4 : 3); comp++) {
+            wave_sync();
+#pragma unroll
+            for (int v = 0; v < 4; v++) {
+                const int fr = fragp[v] >> 4, fc = fragp[v] & 15;
+                if (comp < 3) {
+#pragma unroll
+                    for (int tm = 0; tm < TM; tm++) {
+                        const int p = tm * 16 + fr - comp * Pk;
+                        if (p >= 0 && p < Pk) dump[p * 16 + fc] = accf[tm][v];
+                    }
+                } else {
+#pragma unroll
+                    for (int te = 0; te < TE; te++) {
+                        const int p = te * 16 + fr;
+                        if (p < Pk) dump[p * 16 + fc] = acce[te][v];
+                    }
+                }
+            }
+            wave_sync();
+            for (int col = lane; col < ncol; col += WAVE) {
+                double sum = 0;
+                for (int q = 0; q < nsrc; q++) {
+                    const int off = dsrc[td->src_off + col * nsrc + q];
+                    if (off >= 0) sum += dump[off];
+                }
+                if (comp < 3) { if (!(A.skip & 32)) A.x_f[(size_t)m * 3 * F + (size_t)comp * F + td->col + col] = sum; }
+                else es.add(td->col + col, sum);
+            }
+        }
     }
     wave_sync();
     pc.lap(6);
@@ -952,7 +1030,7 @@ __device__ __forceinline__ void zero_rows(double *x_f, int m, int F, int col, in
 // matrix cores (trio_block_mfma).  Every block is written by exactly one launch.
 // (MODE 7 = MODE 6 compiled for three waves per SIMD; launched when its LDS footprint allows three workgroups per CU.)
 __device__ __forceinline__ int trio_mode(const TrioDev *td) {
-    if (td->dense) return 6;
+    if (td->dense) return td->dense == 2 ? 6 : (td->dense == 4 ? 8 : 9);
     const bool wide = td->ncol > WAVE;
     return td->nsrc == 1 ? (wide ? 2 : 1) : (td->nsrc == 2 ? (wide ? 4 : 3) : 5);
 }
@@ -1100,8 +1178,8 @@ k_featurize(FeatArgs A) {
             for (int t = 0; t < n_trios; t++) {
                 const TrioDev *td = A.trios + t;
                 const int t_dense = load_const(&td->dense), t_nsrc = load_const(&td->nsrc), t_ncol = load_const(&td->ncol);
-                const int t_mode = t_dense ? 6 : (t_nsrc == 1 ? (t_ncol > WAVE ? 2 : 1) : (t_nsrc == 2 ? (t_ncol > WAVE ? 4 : 3) : 5));
-                if (t_mode != (DENSE ? 6 : MODE)) continue;
+                const int t_mode = t_dense ? (t_dense == 2 ? 6 : (t_dense == 4 ? 8 : 9)) : (t_nsrc == 1 ? (t_ncol > WAVE ? 2 : 1) : (t_nsrc == 2 ? (t_ncol > WAVE ? 4 : 3) : 5));
+                if (t_mode != (MODE == 7 ? 6 : MODE)) continue;
                 const int t_sc = load_const(&td->sc), t_sa = load_const(&td->sa), t_sb = load_const(&td->sb);
                 const bool touches = (t_sc == sm) || (WANT_F && (t_sa == sm || t_sb == sm));
                 if (!touches) { if (WANT_F && !(A.skip & 32)) zero_rows(A.x_f, m, F, load_const(&td->col), t_ncol); continue; }
@@ -1110,7 +1188,7 @@ k_featurize(FeatArgs A) {
                 else if (MODE == 3) trio_block<WANT_E, WANT_F, 2, 1>(A, B, recs, g, w, m, sm, t, es);
                 else if (MODE == 4) trio_block<WANT_E, WANT_F, 2, 2>(A, B, recs, g, w, m, sm, t, es);
                 else if (MODE == 5) trio_block<WANT_E, WANT_F, 6, 1>(A, B, recs, g, w, m, sm, t, es);
-                else trio_block_mfma<WANT_E, WANT_F>(A, B, recs, g, w, m, sm, t, es, fragp, dsrc);
+                else trio_block_mfma<WANT_E, WANT_F, (MODE == 8 ? 4 : (MODE == 9 ? 8 : 2))>(A, B, recs, g, w, m, sm, t, es, fragp, dsrc);
             }
         }
     }
