@@ -1128,14 +1128,17 @@ k_featurize(FeatArgs A) {
         // ---- 2-body: neighbour images -> LDS once, then one pass per pair block ------------------
         if (MODE == 0) {
             int n_cand = 0;
+            const bool build3 = A.build_n3 != 0;
+            const double rmin3 = load_const(&B->rmin3), rmax3 = load_const(&B->rmax3);
             if (!(A.skip & 1)) for_each_candidate(g, A.cl, m, [&](bool ok, const SlotRec &sr, int sj, int s0, int s1, int s2) {
                 double dx = 0, dy = 0, dz = 0, d = 0;
                 if (ok) {
                     image_delta(g, sr, s0, s1, s2, pm, dx, dy, dz);
                     d = norm3_rn(dx, dy, dz);
-                    const PairDev &pd = B->pairs[B->pair_of[sm * UF3_MAX_SPECIES + sj]];
-                    // kept if inside its pair's range (distances.py:66, strict both sides) or a 3-body neighbour
-                    ok = (d > pd.rmin && d < pd.rmax) || (A.build_n3 && d > B->rmin3 && d <= B->rmax3);
+                    // kept if inside its pair's range (distances.py:66, strict both sides) or a 3-body neighbour;
+                    // (r_min, r_max) in one load, no short-circuit: every clause evaluated would be a memory round trip
+                    const double2 rr = *(const double2 *)&B->pairs[B->pair_of[sm * UF3_MAX_SPECIES + sj]].rmin;
+                    ok = ((d > rr.x) & (d < rr.y)) | (build3 & (d > rmin3) & (d <= rmax3));
                 }
                 unsigned long long mask = __ballot(ok);
                 if (ok) {
