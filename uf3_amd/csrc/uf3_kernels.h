@@ -1244,9 +1244,10 @@ __device__ __forceinline__ bool trio_value(const BasisDev *B, const double *c3, 
     double v = 0, g0 = 0, g1 = 0, g2 = 0;
     for (int a = 0; a < 4; a++)
         for (int b = 0; b < 4; b++) {
-            double s = 0, sd = 0;
-            const double *row = c + a * mn + b * dim_n;
-            for (int q = 0; q < 4; q++) { double cc = row[q]; s += cc * vn[q]; sd += cc * dn[q]; }
+            typedef double coeff4 __attribute__((ext_vector_type(4), aligned(8)));
+            const coeff4 cc = *(const coeff4 *)(c + a * mn + b * dim_n);       // four consecutive n bins in one request
+            const double s = cc[0] * vn[0] + cc[1] * vn[1] + cc[2] * vn[2] + cc[3] * vn[3];
+            const double sd = cc[0] * dn[0] + cc[1] * dn[1] + cc[2] * dn[2] + cc[3] * dn[3];
             v += vl[a] * vm[b] * s;
             if (want_grad) { g0 += dl[a] * vm[b] * s; g1 += vl[a] * dm[b] * s; g2 += vl[a] * vm[b] * sd; }
         }
