@@ -40,7 +40,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--frames-per-step", type=int, default=8)
+    ap.add_argument("--frames-per-step", type=int, default=32,
+                    help="frames per step and rank (32 x 10k atoms: 3.3 GB of rows in HBM); smaller batches leave a "
+                         "few per cent on the table to workgroup tail effects")
     ap.add_argument("--atoms", type=int, default=10000, help="10000 = north-star; smaller = debug only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()

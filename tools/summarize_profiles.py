@@ -61,7 +61,8 @@ def main(run, prefix):
     write = featurize_counters(os.path.join(run, "pmc_write"))["WRITE_SIZE"]
     fetch_kib, write_kib = group_mean(fetch), group_mean(write)
     hbm = {
-        "command": "python bench.py --steps 3 --warmup 1 --no-cpu-baseline (8 frames x 10k atoms per step, F=434)",
+        "command": "python bench.py --steps 6 --warmup 2 --no-cpu-baseline (%d frames x 10k atoms per step, F=434)"
+                   % bench["config"]["frames_per_step"],
         "tool": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --output-format csv)",
         "kernel": "k_featurize<E,F,R,MODE>: the specialised launches of one step, summed",
         "per_specialisation_KiB": {
@@ -83,11 +84,13 @@ def main(run, prefix):
                 "uncorrected sum is quoted as `traffic` and the x2-corrected sum as the upper bound. Every "
                 "specialisation reads the neighbour lists again; nothing is read-modify-written: rows are "
                 "written once per (atom, column range).",
-        "workload": {"atoms_per_frame": 10000, "n_feat": 434, "frames_per_step": 8},
+        "workload": {"atoms_per_frame": bench["config"]["atoms_per_frame"], "n_feat": bench["config"]["n_feat"],
+                     "frames_per_step": bench["config"]["frames_per_step"]},
     }
     json.dump(hbm, open(prefix + "_hbm_counters.json", "w"), indent=1)
 
-    lines = ["# rocprofv3 --pmc (separate passes of <= 8 SQ counters), 8 frames x 10k atoms per step (F=434)",
+    lines = ["# rocprofv3 --pmc (separate passes of <= 8 SQ counters), %d frames x 10k atoms per step (F=434)"
+             % bench["config"]["frames_per_step"],
              "# SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles summed over waves; "
              "SQ_INSTS_* count wave-instructions", ""]
     sq = {}
