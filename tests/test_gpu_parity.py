@@ -362,6 +362,17 @@ def test_evaluator_50k_atom_ternary():
     assert abs(x_e[0] @ coeff - e[0]) <= 1e-10 * abs(e[0])
 
 
+def test_featurize_frames_into_caller_buffers():
+    atoms, basis = synthetic.config_c2()
+    fz = process.BasisFeaturizer(basis)
+    x_e, x_f, _ = fz.featurize_frames([atoms])
+    buf_e, buf_f = np.full_like(x_e, np.nan), np.full_like(x_f, np.nan)
+    y_e, y_f, _ = fz.featurize_frames([atoms], out=(buf_e, buf_f))
+    assert y_e is buf_e and y_f is buf_f and rel_err(buf_e, x_e) < 1e-12 and rel_err(buf_f, x_f) < 1e-12
+    with pytest.raises(ValueError):
+        fz.featurize_frames([atoms], out=(buf_e, buf_f[:, :2]))
+
+
 def test_featurize_frames_chunking_is_transparent():
     basis = synthetic.notebook_basis(['W'])
     frames = [synthetic.lattice_frame("bcc", (2, 2, 2 + (k % 2)), 3.165, [74], seed=70 + k) for k in range(7)]

@@ -66,13 +66,17 @@ class BasisFeaturizer:
         ctx = _lib.get_context(self.device)
         return ctx, _lib.device_basis(self.bspline_config, ctx)
 
-    def featurize_frames(self, atoms_list, energy=True, forces=True, periodic=None, max_bytes=2 << 30):
+    def featurize_frames(self, atoms_list, energy=True, forces=True, periodic=None, max_bytes=2 << 30, out=None):
         """
         Feature rows of a batch of frames (host arrays in, host arrays out).
 
         Returns (x_e [n_frames, F] | None, x_f [sum N, 3, F] | None, offsets [n_frames+1]).
         Column order = ``get_column_names()[1:]`` (no ``y``).  Long lists go to the device in chunks of at
         most ``max_bytes`` of force rows, so the staging buffers stay bounded.
+
+        ``out=(x_e, x_f)``: C-contiguous float64 arrays of those shapes to fill instead of fresh ones.  Worth it
+        for repeated calls: 104 MB of rows per 10k-atom frame come back at ~46 GB/s into memory that has been
+        touched before, at ~15 GB/s into a fresh ``np.empty`` (first-touch page faults): 440 vs 140 frames/s.
         """
         import ctypes as C
         ctx, db = self._dev()
@@ -81,6 +85,13 @@ class BasisFeaturizer:
         offsets = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
         x_e = np.empty((len(atoms_list), F)) if energy else None
         x_f = np.empty((int(offsets[-1]), 3, F)) if forces else None
+        if out is not None:
+            for given, fresh, name in ((out[0], x_e, "x_e"), (out[1], x_f, "x_f")):
+                if fresh is not None and (given is None or given.shape != fresh.shape or given.dtype != np.float64
+                                          or not given.flags.c_contiguous):
+                    raise ValueError(f"out: {name} must be a C-contiguous float64 array of shape {fresh.shape}")
+            x_e = out[0] if energy else None
+            x_f = out[1] if forces else None
         per_atom = 24 * F if forces else 0
         start = 0
         while start < len(atoms_list):
