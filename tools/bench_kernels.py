@@ -94,6 +94,28 @@ def main():
                          neighbor_ms=round(t["neighbor_ms"] / n, 4), wall_ms_per_step=round(wall, 4),
                          atom_steps_per_s=round(batch.n_atoms / (wall * 1e-3)), energy=float(d_e.item()),
                          net_force=float(np.abs(f.sum(axis=0)).max()), max_force=float(np.abs(f).max()))
+    # ---- fit accumulation (BASELINE config 4, one GPU's share): frames -> rows -> X^T X / X^T y, rows stay in HBM ---
+    if not args.quick:
+        from uf3_amd import pipeline
+        for name, els in (("fit_accumulate_10k_W", ['W']), ("fit_accumulate_10k_WMo", ['Mo', 'W'])):
+            basis = synthetic.notebook_basis(els)
+            zs = [74] if els == ['W'] else [42, 74]
+            frames = [synthetic.lattice_frame("bcc", (10, 20, 25), 3.165, zs, 5000 + k) for k in range(16)]
+            rng = np.random.default_rng(3)
+            energies = rng.normal(-8.9 * 10000, 5.0, len(frames))
+            forces = [rng.normal(0, 0.5, (len(f), 3)) for f in frames]
+            model = ls.WeightedLinearModel(basis)
+            fz = process.BasisFeaturizer(basis, device=0)
+            acc = pipeline.DeviceFitAccumulator(model, fz)
+            acc.add_frames(frames[:8], energies[:8], forces[:8])           # warm-up (capacities, LDS modes)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            acc.add_frames(frames, energies, forces)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            out[name] = dict(frames=len(frames), n_feat=basis.n_feats, wall_ms=round(dt * 1e3, 2),
+                             frames_per_s=round(len(frames) / dt, 1),
+                             note="host frame packing + H2D of positions + featurize + Gram of energy and force rows")
     print(json.dumps(out, indent=1))
 
 
