@@ -699,14 +699,12 @@ __device__ __forceinline__ void mfma_records(const double *stage, int stride, in
         }
         const int pl = 1 - o.q;                        // "P" lanes pick the derivative of the leg that joins centre and m
         const int bn = o.n + o.q;                      // B operand: B_n for P slots, B'_n for Q slots
-#pragma unroll
         for (int cls = 1; cls <= 2; cls++) {
             const int cnt = cls == 1 ? n1 : n2, start = cls == 1 ? n0 : n0 + n1;
             const int dx = cls == 1 ? pl : 0, dy = cls == 1 ? 0 : pl;
             const double *rec = stage + (size_t)(start + (ks >> 1)) * stride;
             const int n_full = cnt & ~1;
             int q = 0;
-#pragma unroll 2
             for (; q < n_full; q += 2, rec += 2 * stride) mfma_pair<false, TM>(rec, true, o, dx, dy, bn, accf);
             if (q < cnt) mfma_pair<true, TM>((ks >> 1) == 0 ? rec : stage, (ks >> 1) == 0, o, dx, dy, bn, accf);
         }
