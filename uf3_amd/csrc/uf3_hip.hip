@@ -739,15 +739,17 @@ extern "C" int uf3_featurize_dev(uf3_basis *b, const uf3_frames *fr, const doubl
                     const size_t budget = 52 * 1024;
                     const bool dsrc_allowed = A.dsrc_lds;
                     bool found = false;
-                    for (int q = 0; q < 6 && !found && !getenv("UF3_NO_OCC3"); q++) {
-                        const int nr = tries[q / 2];
-                        const bool with_dsrc = dsrc_allowed && (q % 2 == 0);
-                        if (!dsrc_allowed && (q % 2 == 0)) continue;
+                    // candidates in order of preference: more records per pass first, tables in LDS before tables in HBM
+                    const bool recs_allowed = !getenv("UF3_NO_LDS_RECS");
+                    for (int q = 0; q < 12 && !found && !getenv("UF3_NO_OCC3"); q++) {
+                        const int nr = tries[q / 4];
+                        const bool with_recs = (q & 2) == 0, with_dsrc = (q & 1) == 0;
+                        if ((with_recs && !recs_allowed) || (with_dsrc && !dsrc_allowed)) continue;
                         int stage = std::max(DENSE_DUMP, nr * b->dense_stride);
-                        size_t need = feat_lds_bytes(F, S, cap, A.cand_cap, want_e, n_rec_mode, 6, stage, nr, A.n_pair_cols) +
-                                      (with_dsrc ? sizeof(int) * b->n_dsrc : 0);
+                        size_t need = feat_lds_bytes(F, S, cap, A.cand_cap, want_e, with_recs ? n_rec_mode : 0, 6, stage, nr,
+                                                     A.n_pair_cols) + (with_dsrc ? sizeof(int) * b->n_dsrc : 0);
                         if (need <= budget) {
-                            found = true; launch_mode = 7; recs_lds = true; lds = lds_recs = need;
+                            found = true; launch_mode = 7; recs_lds = with_recs; lds = lds_recs = need;
                             A.dense_nrec = nr; A.dense_stage = stage; A.dsrc_lds = with_dsrc;
                         }
                     }
