@@ -547,3 +547,51 @@ def test_fused_and_separate_neighbour_list_builds_agree():
         assert rel_err(x_e, y_e) < 1e-13 and rel_err(x_f, y_f) < 1e-13
         ref = O.featurize(O.OracleBasis(basis), frames[0])
         assert rel_err(x_e[0], ref["xe"]) < 1e-8 and rel_err(x_f, ref["xf"]) < 1e-8
+
+
+def test_energy_row_longer_than_lds():
+    """F = 15925 columns: the block-shared energy row (8 F bytes) no longer fits LDS; contributions go to HBM."""
+    basis = _resolution_basis([9, 9, 17], lead3=0, elements=('Al', 'Cu', 'Zr'))
+    assert basis.n_feats * 8 > 48 * 1024
+    rng = np.random.default_rng(12)
+    atoms = synthetic.lattice_frame("bcc", (3, 3, 3), 3.1, [13, 29, 40], 41, rattle=0.1)
+    _check_against_oracle(basis, [atoms])
+    e_only = process.BasisFeaturizer(basis).featurize_frames([atoms], forces=False)[0]
+    assert rel_err(e_only[0], O.featurize(O.OracleBasis(basis), atoms, forces=False)["xe"]) < TOL
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_random_bases_and_cells_against_oracle(seed):
+    """Random species sets, resolutions, trims, cut-offs, strained cells and periodicity patterns (a short version
+    of tools/experiments/random_parity.py): feature rows and evaluator against the oracle."""
+    from uf3_amd.data import composition
+    from uf3_amd.representation import bspline
+    rng = np.random.default_rng(100 + seed)
+    zmap = {'Al': 13, 'Cu': 29, 'Mo': 42, 'W': 74, 'Zr': 40}
+    for _ in range(3):
+        els = sorted(rng.choice(list(zmap), int(rng.integers(1, 4)), replace=False).tolist())
+        cs = composition.ChemicalSystem(els, 3)
+        pairs, trios = cs.interactions_map[2], cs.interactions_map[3]
+        r3 = float(rng.uniform(3.0, 4.2))
+        res_l, res_n = int(rng.integers(4, 10)), int(rng.integers(8, 20))
+        basis = bspline.BSplineBasis(
+            cs, r_min_map={**{p: float(rng.uniform(0.2, 1.0)) for p in pairs}, **{t: [float(rng.uniform(0.8, 1.6))] * 3 for t in trios}},
+            r_max_map={**{p: float(rng.uniform(4.0, 6.0)) for p in pairs}, **{t: [r3, r3, 2 * r3] for t in trios}},
+            resolution_map={**{p: int(rng.integers(6, 18)) for p in pairs}, **{t: [res_l, res_l, res_n] for t in trios}},
+            leading_trim={2: 0, 3: int(rng.choice([0, 3]))}, trailing_trim={2: 3, 3: int(rng.choice([3, 2]))})
+        reps = tuple(int(x) for x in rng.integers(3, 5, 3))
+        a = float(rng.uniform(2.9, 3.4))
+        grid = np.array([[i, j, k] for i in range(reps[0]) for j in range(reps[1]) for k in range(reps[2])], float)
+        frac = (grid[:, None, :] + np.array([[0, 0, 0], [.5, .5, .5]])[None]).reshape(-1, 3)
+        cell = np.diag(np.array(reps, float) * a) @ (np.eye(3) + rng.normal(0, 0.02, (3, 3)))
+        pos = (frac / np.array(reps)) @ cell + rng.normal(0, 0.1, (len(frac), 3))
+        pbc = [True, True, True] if rng.random() < 0.6 else [bool(b) for b in rng.integers(0, 2, 3)]
+        atoms = Atoms(numbers=rng.choice([zmap[e] for e in els], len(pos)), positions=pos, cell=cell, pbc=pbc)
+        _check_against_oracle(basis, [atoms])
+        coeff = rng.normal(0, 0.05, basis.n_feats)
+        coeff[basis.col_idx] = 0.0
+        model = ls.WeightedLinearModel(basis)
+        model.coefficients = coeff
+        e, f, _ = calculator.UFCalculator(model).evaluate_frames([atoms])
+        e_ref, f_ref = O.evaluate(O.OracleBasis(basis), atoms, coeff)
+        assert abs(e[0] - e_ref) <= TOL * max(1.0, abs(e_ref)) and rel_err(f, f_ref) < TOL

@@ -698,6 +698,8 @@ extern "C" int uf3_featurize_dev(uf3_basis *b, const uf3_frames *fr, const doubl
     A.n3.cap = 1;
     if (old_n3 && P.n3.cap) A.n3 = P.n3;
     A.build_n3 = has3 ? 1 : 0;
+    // the block-shared energy row costs 8 F bytes of LDS: past 48 KB the contributions go straight to HBM instead
+    A.e_direct = (want_e && (size_t)F * 8 > 48 * 1024) ? 1 : 0;
     A.n3_need = c->flags.as<int>() + 1;
     A.pos = d_pos; A.spec = P.spec; A.x_e = d_xe; A.x_f = d_xf; A.natoms = P.natoms;
     A.cand_need = c->flags.as<int>() + 2;
@@ -746,7 +748,7 @@ extern "C" int uf3_featurize_dev(uf3_basis *b, const uf3_frames *fr, const doubl
                         const bool with_recs = (q & 2) == 0, with_dsrc = (q & 1) == 0;
                         if ((with_recs && !recs_allowed) || (with_dsrc && !dsrc_allowed)) continue;
                         int stage = std::max(DENSE_DUMP, nr * b->dense_stride);
-                        size_t need = feat_lds_bytes(F, S, cap, A.cand_cap, want_e, with_recs ? n_rec_mode : 0, 6, stage, nr,
+                        size_t need = feat_lds_bytes(F, S, cap, A.cand_cap, want_e && !A.e_direct, with_recs ? n_rec_mode : 0, 6, stage, nr,
                                                      A.n_pair_cols) + (with_dsrc ? sizeof(int) * b->n_dsrc : 0);
                         if (need <= budget) {
                             found = true; launch_mode = 7; recs_lds = with_recs; lds = lds_recs = need;
@@ -759,8 +761,8 @@ extern "C" int uf3_featurize_dev(uf3_basis *b, const uf3_frames *fr, const doubl
                     A.dense_stage = std::max(DENSE_DUMP, A.dense_nrec * b->dense_stride);
                 }
                 if (launch_mode != 7) {
-                    lds_plain = feat_lds_bytes(F, S, cap, A.cand_cap, want_e, 0, mode, A.dense_stage, A.dense_nrec, A.n_pair_cols) + lds_extra;
-                    lds_recs = feat_lds_bytes(F, S, cap, A.cand_cap, want_e, n_rec_mode, mode, A.dense_stage, A.dense_nrec, A.n_pair_cols) + lds_extra;
+                    lds_plain = feat_lds_bytes(F, S, cap, A.cand_cap, want_e && !A.e_direct, 0, mode, A.dense_stage, A.dense_nrec, A.n_pair_cols) + lds_extra;
+                    lds_recs = feat_lds_bytes(F, S, cap, A.cand_cap, want_e && !A.e_direct, n_rec_mode, mode, A.dense_stage, A.dense_nrec, A.n_pair_cols) + lds_extra;
                     const size_t lds_target = cu_lds / (mode == 0 ? 4 : 2);
                     recs_lds = lds_recs <= lds_target && !getenv("UF3_NO_LDS_RECS");
                     lds = recs_lds ? lds_recs : lds_plain;

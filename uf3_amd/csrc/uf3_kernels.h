@@ -248,6 +248,7 @@ struct FeatArgs {
     int *cand_need;     // overflow report of the 2-body candidate stage
     int *n3_need;       // ... of the 3-body neighbour lists (MODE 0 builds them when build_n3 != 0)
     int build_n3;
+    int e_direct;       // energy row too long for LDS: every contribution goes straight to HBM (global atomics)
     int natoms, atoms_per_block;
     int cand_cap;       // 2-body candidates staged per atom
     int n_recs;         // KnotRec count (for the LDS copy)
@@ -1042,7 +1043,8 @@ k_featurize(FeatArgs A) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);           // wave-uniform: LDS pointers and atom indices in SGPRs
     double *erow = (double *)smem;                                         // [F] shared by the block (WANT_E)
-    const size_t e_d = WANT_E ? (size_t)F + (F & 1) : 0;
+    const bool e_lds = WANT_E && !A.e_direct;
+    const size_t e_d = e_lds ? (size_t)F + (F & 1) : 0;
     // LDS carve (must match feat_lds_bytes on the host).  MODE 0 (pairs): candidate list + pair records, pair
     // knot records only; trio modes: own neighbour list + triplet records, all knot records.
     const size_t cand_d = (size_t)A.cand_cap * CAND_STRIDE;
@@ -1091,7 +1093,7 @@ k_featurize(FeatArgs A) {
             dsrc = dl;
         }
     }
-    if (WANT_E) { for (int q = tid; q < F; q += WPB * WAVE) erow[q] = 0.0; }
+    if (e_lds) { for (int q = tid; q < F; q += WPB * WAVE) erow[q] = 0.0; }
     if (DENSE) for (int q = lane; q < (int)stage_d; q += WAVE) w.stage[q] = 0.0;   // masked operands read stale slots
     __syncthreads();
     const int block_first = blockIdx.x * A.atoms_per_block;
@@ -1100,7 +1102,7 @@ k_featurize(FeatArgs A) {
     for (int m0 = block_first; m0 < block_end; m0 += WPB) {      // the block's waves take consecutive atoms
         const int m = m0 + wave;
         const bool active = m < block_end;
-        if (WANT_E) {
+        if (e_lds) {
             int f_first = load_const(A.frame_of + m0);
             if (f_first != erow_frame) {                          // block-uniform
                 __syncthreads();
@@ -1119,7 +1121,7 @@ k_featurize(FeatArgs A) {
         const int sm = ((const __attribute__((address_space(4))) signed char *)(unsigned long long)A.spec)[m];
         const double pm[3] = {A.pos[3 * (size_t)m], A.pos[3 * (size_t)m + 1], A.pos[3 * (size_t)m + 2]};
         ESink es;
-        es.lds = erow; es.glob = WANT_E ? A.x_e + (size_t)fr * F : nullptr; es.direct = (fr != erow_frame);
+        es.lds = erow; es.glob = WANT_E ? A.x_e + (size_t)fr * F : nullptr; es.direct = !e_lds || (fr != erow_frame);
         // ---- 1-body columns ------------------------------------------------------------------
         if (MODE == 0 && WANT_F) zero_rows(A.x_f, m, F, 0, S);
         if (MODE == 0 && WANT_E && lane == 0) es.add(sm, 1.0);
@@ -1193,7 +1195,7 @@ k_featurize(FeatArgs A) {
             }
         }
     }
-    if (WANT_E) {
+    if (e_lds) {
         __syncthreads();
         if (erow_frame >= 0)
             for (int q = tid; q < F; q += WPB * WAVE) {
