@@ -1,19 +1,22 @@
 // uf3_kernels.h -- the gfx950 kernels of the UF3 hot path.
 //
 //   k_frame_bins      atom -> (frame, wrapped fractional bin)            [HBM-trivial]
-//   k_bin_start / k_gather_sorted   cell list over radix-sorted atoms
+//   k_bin_start / k_gather_sorted   cell list over radix-sorted atoms (32-B slot records in bin order)
 //   k_build_n3        per-atom 3-body neighbour lists with image shifts, sorted by
-//                     (species, reference supercell index)               one wave / atom
-//   k_featurize       energy row + 3 force rows per atom                 one wave / atom
-//   k_eval            energy + forces of a fitted model                  one wave / atom
-//   k_gram_mfma       X^T X on the fp64 matrix cores
+//                     (species, reference supercell index)               one wave / atom (evaluator path)
+//   k_featurize<E, F, R, MODE>   energy row + 3 force rows per atom      one wave / atom, one launch per block family:
+//                     MODE 0      one-body + pair columns; also builds the 3-body lists from its candidates
+//                     MODE 6 / 7  3-body windows of <= 32 rows on the fp64 matrix cores (7: three waves / SIMD)
+//                     MODE 8 / 9  ... of <= 64 / <= 128 rows
+//                     MODE 1-5    generic output-stationary 3-body kernels (wider windows)
+//   k_eval            energy + forces (+ virial) of a fitted model        one wave / atom
+//   k_gram_mfma       X^T X on the fp64 matrix cores;  k_ordinate  X^T y
 //
-// Formulation: every atom m GATHERS all pair terms and all
-// triplet terms it takes part in -- as centre, or as one of the two neighbours of
-// a centre c in N3(m) -- so its three force-feature rows are accumulated in LDS and
-// written exactly once, coalesced, with no global atomics.  A triplet is visited by
-// each of its three atoms; translation invariance makes the three visits the three
-// slices of the reference's arrange_deriv_3b (angles.py:235-286) output.
+// Formulation: every atom m GATHERS all pair terms and all triplet terms it takes part in --
+// as centre, or as one of the two neighbours of a centre c in N3(m) -- so its three force-feature rows are complete
+// when its wave is done and are written exactly once, coalesced, with no global atomics.  A triplet is visited by
+// each of its three atoms; translation invariance makes the three visits the three slices of the reference's
+// arrange_deriv_3b (angles.py:235-286) output.
 #pragma once
 #include "uf3_device.h"
 
