@@ -1,0 +1,36 @@
+"""DataFrame plumbing of the fit against the reference's own functions (tests/golden/make_dataframe_golden.py)."""
+import os
+
+import numpy as np
+import pandas as pd
+
+from uf3_amd.regression import least_squares as ls
+from _util import GOLDEN
+
+D = np.load(os.path.join(GOLDEN, "dataframe_tuples.npz"), allow_pickle=False)
+
+
+def _table():
+    index = pd.MultiIndex.from_tuples(list(zip(D["index_names"].tolist(), D["index_keys"].tolist())))
+    return pd.DataFrame(D["table"], index=index, columns=["y"] + [f"c{k}" for k in range(D["table"].shape[1] - 1)])
+
+
+def test_dataframe_to_tuples_matches_reference():
+    df = _table()
+    weights = {"frame_a": 0.5, "frame_c": 2.0}
+    for tag, kw in [("plain", {}), ("norm", dict(n_elements=2)), ("weighted", dict(sample_weights=weights)),
+                    ("norm_weighted", dict(n_elements=2, sample_weights=weights))]:
+        got = ls.dataframe_to_tuples(df, **kw)
+        for arr, name in zip(got, ("x_e", "y_e", "x_f", "y_f")):
+            assert np.array_equal(arr, D[f"{tag}_{name}"]), (tag, name)
+
+
+def test_subset_prediction_matches_reference():
+    class Model:
+        def predict(self, x):
+            return np.dot(x, D["coeff"])
+
+    y_e, p_e, y_f, p_f = ls.subset_prediction(_table(), Model(), subset_keys=["frame_c", "frame_a", "missing"], n_elements=2)
+    assert np.array_equal(y_e, D["sub_y_e"]) and np.allclose(p_e, D["sub_p_e"], rtol=1e-15)
+    assert np.array_equal(y_f, D["sub_y_f"]) and np.allclose(p_f, D["sub_p_f"], rtol=1e-15)
+    assert ls.subset_prediction(_table(), Model(), subset_keys=["nope"]) == ([], [], [], [])

@@ -332,6 +332,14 @@ def test_evaluate_dataframe_surface():
     ref = O.featurize(O.OracleBasis(basis), water)
     assert rel_err(out.loc[(1, 'energy')].to_numpy()[1:], ref["xe"]) < TOL
     assert rel_err(out.loc[(1, 'fy_2')].to_numpy()[1:], ref["xf"][2, 1]) < TOL
+    # the reference's in-memory workflow: table -> tuples (per-atom energies) -> fit -> predictions
+    x_e, y_e, x_f, y_f = ls.dataframe_to_tuples(out, n_elements=2)
+    assert x_e.shape == (2, 56) and np.allclose(y_e, 0.5) and np.allclose(x_e[0, :2], [2 / 3, 1 / 3])
+    assert rel_err(x_f[:9].reshape(3, 3, 56), ref["xf"].transpose(1, 0, 2)) < TOL         # rows fx_0..2, fy_0..2, fz_0..2
+    model = ls.WeightedLinearModel(basis)
+    model.fit(x_e, y_e, x_f, y_f, weight=0.5)
+    y_e2, p_e, y_f2, p_f = ls.subset_prediction(out, model, subset_keys=[1], n_elements=2)
+    assert len(p_e) == 1 and len(p_f) == 9 and np.all(np.isfinite(p_e)) and np.all(np.isfinite(p_f))
 
 
 def test_energy_only_and_forces_only_modes_agree():

@@ -312,3 +312,42 @@ class WeightedLinearModel(BasicLinearModel):
             raise ValueError("Incorrect coefficients: {} provided, {} expected.".format(
                 len(flat), sum(basis.partition_sizes)))
         self.coefficients = np.array(flat)
+
+
+def dataframe_to_tuples(df_features, n_elements=None, energy_key='energy', sample_weights=None):
+    """
+    Split a feature table (``BasisFeaturizer.evaluate`` layout: MultiIndex (name, 'energy' | 'fx_i' ...), target ``y``
+    in the first column) into energy and force inputs / targets (reference: least_squares.py:666-713).
+
+    ``n_elements``: the energy rows and targets are divided by the sum of the first ``n_elements`` feature columns
+    (the per-element atom counts), i.e. normalised per atom.  ``sample_weights``: {name: weight}, default 1, applied
+    to rows and targets.  Returns (x_e, y_e, x_f, y_f).
+    """
+    keys = np.asarray(df_features.index.get_level_values(-1))
+    is_energy = keys == energy_key
+    table = df_features.to_numpy()
+    y, x = table[:, 0], table[:, 1:]
+    x_e, y_e, x_f, y_f = x[is_energy], y[is_energy], x[~is_energy], y[~is_energy]
+    if n_elements is not None:
+        n_atoms = x_e[:, :n_elements].sum(axis=1)
+        x_e, y_e = x_e / n_atoms[:, None], y_e / n_atoms
+    if sample_weights is not None:
+        w = np.array([sample_weights.get(name, 1.0) for name in df_features.index.get_level_values(0)])
+        w_e, w_f = w[is_energy], w[~is_energy]
+        x_e, y_e, x_f, y_f = x_e * w_e[:, None], y_e * w_e, x_f * w_f[:, None], y_f * w_f
+    return x_e, y_e, x_f, y_f
+
+
+def subset_prediction(df, model, subset_keys=None, **kwargs):
+    """
+    Targets and predictions of (a subset of) a feature table (reference: least_squares.py:933-962).
+    Returns (y_e, p_e, y_f, p_f); four empty lists when none of ``subset_keys`` is in the table.
+    """
+    if subset_keys is not None:
+        present = df.index.unique(level=0).intersection(subset_keys)
+        if len(present) == 0:
+            return list(), list(), list(), list()
+        df = df.loc[present]
+    x_e, y_e, x_f, y_f = dataframe_to_tuples(df, **kwargs)
+    return y_e, model.predict(x_e), y_f, model.predict(x_f)
+
