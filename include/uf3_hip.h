@@ -148,6 +148,21 @@ int uf3_eval_virial_dev(uf3_basis *basis, const uf3_frames *frames, const double
                         double *d_energies, double *d_forces, double *d_virials);
 
 /*
+ * The share of atoms [atom_begin, atom_end) (indices into the concatenated batch) of the same quantities: the
+ * one-body, pair and centre-role triplet energies of those atoms, their force rows (the other rows of `forces`
+ * are zero on return from the host variant and untouched by the _dev variant) and their share of the strain
+ * derivative.  Every atom gathers its own force, so shares over disjoint ranges add up to uf3_eval_virial's
+ * results: the spatial decomposition of ONE large frame over GPUs is a range per rank + one sum-reduce (SURVEY
+ * section 8f row N4; not in the reference, whose calculator is single-process).  forces / virials may be NULL.
+ */
+int uf3_eval_atoms(uf3_basis *basis, const uf3_frames *frames, const double *pos, const int32_t *z,
+                   const double *c1, const double *c2, const double *c3, int64_t atom_begin, int64_t atom_end,
+                   double *energies, double *forces, double *virials);
+int uf3_eval_atoms_dev(uf3_basis *basis, const uf3_frames *frames, const double *d_pos, const int32_t *d_z,
+                       const double *c1, const double *c2, const double *c3 /* host */, int64_t atom_begin,
+                       int64_t atom_end, double *d_energies, double *d_forces, double *d_virials);
+
+/*
  * Neighbour indices in the reference's supercell numbering (ghost index =
  * image_rank * N + atom, geometry.py:108-149), single frame, host buffers.
  *   pair_ij [P][pair_cap][2]  2-body (i, j) per pair block, row-major sorted; pair_count [P]

@@ -370,6 +370,34 @@ def test_evaluator_50k_atom_ternary():
     assert abs(x_e[0] @ coeff - e[0]) <= 1e-10 * abs(e[0])
 
 
+def test_atom_range_shares_add_up_to_the_frame():
+    """uf3_eval_atoms: shares of disjoint atom blocks (what each rank of a decomposed frame computes) sum to
+    the whole-frame energy / virial, and their force rows are the whole-frame rows, bit for bit."""
+    from uf3_amd import parallel
+    atoms = synthetic.lattice_frame("bcc", (5, 6, 7), 3.165, [42, 74], seed=77)
+    basis = synthetic.notebook_basis(['Mo', 'W'])
+    model = ls.WeightedLinearModel(basis)
+    coeff = np.random.default_rng(5).normal(0, 0.05, basis.n_feats)
+    coeff[basis.col_idx] = 0.0
+    model.coefficients = coeff
+    calc = calculator.UFCalculator(model)
+    e, f, _, v = calc.evaluate_frames([atoms], virial=True)
+    n, world = len(atoms), 3
+    shares = [calc.evaluate_atom_range(atoms, *parallel.shard_range(n, r, world), virial=True) for r in range(world)]
+    assert abs(sum(s[0] for s in shares) - e[0]) <= 1e-12 * abs(e[0])
+    assert rel_err(sum(s[2] for s in shares), v[0]) < 1e-12
+    for r, (_, fs, _) in enumerate(shares):
+        lo, hi = parallel.shard_range(n, r, world)
+        assert np.array_equal(fs[lo:hi], f[lo:hi])
+        assert not fs[:lo].any() and not fs[hi:].any()
+    e1, f1, v1 = parallel.sharded_evaluate(calc, atoms, virial=True)          # no process group: whole frame
+    assert e1 == e[0] and np.array_equal(f1, f) and np.array_equal(v1, v[0])
+    e0, f0, v0 = calc.evaluate_atom_range(atoms, 10, 10)                      # empty block
+    assert e0 == 0.0 and not f0.any() and v0 is None
+    with pytest.raises(RuntimeError):
+        calc.evaluate_atom_range(atoms, 5, n + 1)
+
+
 def test_featurize_frames_into_caller_buffers():
     atoms, basis = synthetic.config_c2()
     fz = process.BasisFeaturizer(basis)

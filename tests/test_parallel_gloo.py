@@ -49,6 +49,49 @@ def test_two_rank_reduce_reproduces_single_process_fit(tmp_path):
     assert np.allclose(np.load(tmp_path / "gram_0.npy"), d["gram_f"], rtol=1e-9, atol=1e-9)
 
 
+class _TableCalculator:
+    """per-atom shares from a table (the GPU computes them in production: tests/test_gpu_parity.py checks that
+    uf3_eval_atoms' shares add up); exercises the block assignment, packing and the reduce"""
+
+    def __init__(self, e_atom, f_atom, v_atom):
+        self.e, self.f, self.v = e_atom, f_atom, v_atom
+
+    def evaluate_atom_range(self, atoms, lo, hi, forces=True, virial=False):
+        f = np.zeros_like(self.f)
+        f[lo:hi] = self.f[lo:hi]
+        return float(self.e[lo:hi].sum()), (f if forces else None), (self.v[lo:hi].sum(0) if virial else None)
+
+
+def _eval_worker(rank, world, port, out_dir):
+    import torch.distributed as dist
+    from uf3_amd import parallel
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rng = np.random.default_rng(3)
+    n = 101
+    calc = _TableCalculator(rng.normal(size=n), rng.normal(size=(n, 3)), rng.normal(size=(n, 6)))
+    e, f, v = parallel.sharded_evaluate(calc, [None] * n, forces=True, virial=True)
+    e2, f2, v2 = parallel.sharded_evaluate(calc, [None] * n, forces=False, virial=False)
+    assert f2 is None and v2 is None and abs(e2 - e) < 1e-12
+    np.savez(os.path.join(out_dir, f"eval_{rank}.npz"), e=e, f=f, v=v, e_ref=calc.e.sum(), f_ref=calc.f,
+             v_ref=calc.v.sum(0))
+    dist.destroy_process_group()
+
+
+def test_two_rank_decomposed_frame_evaluation(tmp_path):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_eval_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    for rank in range(2):
+        d = np.load(tmp_path / f"eval_{rank}.npz")
+        assert abs(d["e"] - d["e_ref"]) < 1e-12
+        assert np.array_equal(d["f"], d["f_ref"])                # each row comes from exactly one rank (+ zeros)
+        assert np.allclose(d["v"], d["v_ref"], rtol=1e-12, atol=1e-12)
+
+
 def test_shard_range_and_packing():
     from uf3_amd import parallel
     parts = [parallel.shard_range(10, r, 4) for r in range(4)]

@@ -17,7 +17,8 @@ EXPORTS = ["uf3_ctx_create", "uf3_ctx_destroy", "uf3_ctx_set_stream", "uf3_ctx_s
            "uf3_last_error", "uf3_ctx_timing_reset", "uf3_ctx_timing_read",
            "uf3_basis_create", "uf3_basis_destroy", "uf3_basis_featurizer_modes",
            "uf3_featurize", "uf3_featurize_dev", "uf3_gram", "uf3_gram_dev",
-           "uf3_eval", "uf3_eval_dev", "uf3_eval_virial", "uf3_eval_virial_dev", "uf3_neighbors_debug"]
+           "uf3_eval", "uf3_eval_dev", "uf3_eval_virial", "uf3_eval_virial_dev", "uf3_eval_atoms", "uf3_eval_atoms_dev",
+           "uf3_neighbors_debug"]
 
 
 class HipUnavailable(RuntimeError):
@@ -88,6 +89,8 @@ def load():
             getattr(lib, name).argtypes = [vp, C.POINTER(Frames), vp, vp, vp, vp, vp, vp, vp]
         for name in ("uf3_eval_virial", "uf3_eval_virial_dev"):
             getattr(lib, name).argtypes = [vp, C.POINTER(Frames), vp, vp, vp, vp, vp, vp, vp, vp]
+        for name in ("uf3_eval_atoms", "uf3_eval_atoms_dev"):
+            getattr(lib, name).argtypes = [vp, C.POINTER(Frames), vp, vp, vp, vp, vp, i64, i64, vp, vp, vp]
         lib.uf3_neighbors_debug.argtypes = [vp, C.POINTER(Frames), vp, vp, vp, vp, i64, vp, vp, i64]
         _lib = lib
         return lib

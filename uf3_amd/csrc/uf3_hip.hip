@@ -857,7 +857,8 @@ extern "C" int uf3_featurize(uf3_basis *b, const uf3_frames *fr, const double *p
 
 // ------------------------------------------------------------------------------ eval
 static int eval_impl(uf3_basis *b, const uf3_frames *fr, const double *d_pos, const int32_t *d_z, const double *c1,
-                     const double *c2, const double *c3, double *d_energies, double *d_forces, double *d_virials) {
+                     const double *c2, const double *c3, double *d_energies, double *d_forces, double *d_virials,
+                     int64_t atom_begin = 0, int64_t atom_end = -1) {
     uf3_ctx *c = b->ctx;
     if (!d_pos || !d_z || !c1 || !d_energies) return fail(c, UF3_EINVAL, "uf3_eval: null argument");
     if ((b->c2_len && !c2) || (b->c3_len && !c3)) return fail(c, UF3_EINVAL, "uf3_eval: missing coefficients");
@@ -873,16 +874,24 @@ static int eval_impl(uf3_basis *b, const uf3_frames *fr, const double *d_pos, co
     if (n3) HIPCHK(c, hipMemcpyAsync(dc + n1 + n2, c3, 8 * n3, hipMemcpyHostToDevice, st));
     HIPCHK(c, hipStreamSynchronize(st));
     HIPCHK(c, c->e_atom.ensure(8 * (size_t)P.natoms * (d_virials ? 7 : 1)));
+    if (atom_end < 0) atom_end = P.natoms;
+    if (atom_begin < 0 || atom_begin > atom_end || atom_end > P.natoms)
+        return fail(c, UF3_EINVAL, "uf3_eval_atoms: atom range outside the batch");
+    const bool partial = atom_begin != 0 || atom_end != P.natoms;
+    if (partial)    // atoms outside the range contribute zero to the per-frame sums
+        HIPCHK(c, hipMemsetAsync(c->e_atom.p, 0, 8 * (size_t)P.natoms * (d_virials ? 7 : 1), st));
     EvalArgs A;
     A.B = b->dev; A.geoms = P.geoms; A.frame_of = P.frame_of; A.cl = P.cl; A.n3 = P.n3;
     if (!A.n3.cap) A.n3.cap = 1;
     A.pos = d_pos; A.spec = P.spec; A.c1 = dc; A.c2 = dc + n1; A.c3 = dc + n1 + n2;
     A.e_atom = c->e_atom.as<double>(); A.forces = d_forces; A.natoms = P.natoms;
+    A.atom_lo = (int)atom_begin; A.atom_hi = (int)atom_end;
     A.virial = d_virials ? A.e_atom + P.natoms : nullptr;
     size_t lds = (size_t)A.n3.cap * 32 + ((size_t)5 * A.n3.cap + 2) * 4 + 16 + 2 * WAVE * EVAL_Q * sizeof(double);
     {
         Timed tm(c, T_EVAL);
-        hipLaunchKernelGGL(k_eval, dim3(P.natoms), dim3(64), lds, st, A);
+        if (atom_end > atom_begin)
+            hipLaunchKernelGGL(k_eval, dim3((unsigned)(atom_end - atom_begin)), dim3(64), lds, st, A);
         hipLaunchKernelGGL(k_frame_sum, dim3(P.n_frames, 1), dim3(256), 0, st, A.e_atom, P.d_offsets, 1, d_energies);
         if (d_virials)
             hipLaunchKernelGGL(k_frame_sum, dim3(P.n_frames, 6), dim3(256), 0, st, A.virial, P.d_offsets, 6, d_virials);
@@ -905,7 +914,8 @@ extern "C" int uf3_eval_virial_dev(uf3_basis *b, const uf3_frames *fr, const dou
 }
 
 static int eval_host(uf3_basis *b, const uf3_frames *fr, const double *pos, const int32_t *z, const double *c1,
-                     const double *c2, const double *c3, double *energies, double *forces, double *virials) {
+                     const double *c2, const double *c3, double *energies, double *forces, double *virials,
+                     int64_t atom_begin = 0, int64_t atom_end = -1) {
     uf3_ctx *c = b->ctx;
     if (!energies) return fail(c, UF3_EINVAL, "uf3_eval: null energies");
     int natoms = 0;
@@ -914,9 +924,11 @@ static int eval_host(uf3_basis *b, const uf3_frames *fr, const double *pos, cons
     size_t nf = (size_t)fr->n_frames;
     HIPCHK(c, c->stage_out.ensure(8 * nf * 7));
     if (forces) HIPCHK(c, c->stage_out2.ensure(24 * (size_t)natoms));
+    if (forces && (atom_begin != 0 || (atom_end >= 0 && atom_end != natoms)))   // rows of other ranks' atoms: zero
+        HIPCHK(c, hipMemsetAsync(c->stage_out2.p, 0, 24 * (size_t)natoms, c->stream));
     double *d_e = c->stage_out.as<double>(), *d_v = d_e + nf;
     rc = eval_impl(b, fr, c->stage_pos.as<double>(), c->stage_z.as<int32_t>(), c1, c2, c3, d_e,
-                   forces ? c->stage_out2.as<double>() : nullptr, virials ? d_v : nullptr);
+                   forces ? c->stage_out2.as<double>() : nullptr, virials ? d_v : nullptr, atom_begin, atom_end);
     if (rc) return rc;
     HIPCHK(c, hipMemcpyAsync(energies, d_e, 8 * nf, hipMemcpyDeviceToHost, c->stream));
     if (virials) HIPCHK(c, hipMemcpyAsync(virials, d_v, 48 * nf, hipMemcpyDeviceToHost, c->stream));
@@ -934,6 +946,22 @@ extern "C" int uf3_eval_virial(uf3_basis *b, const uf3_frames *fr, const double 
                                const double *c2, const double *c3, double *energies, double *forces, double *virials) {
     if (!b) return fail(nullptr, UF3_EINVAL, "null basis");
     return eval_host(b, fr, pos, z, c1, c2, c3, energies, forces, virials);
+}
+
+extern "C" int uf3_eval_atoms_dev(uf3_basis *b, const uf3_frames *fr, const double *d_pos, const int32_t *d_z,
+                                  const double *c1, const double *c2, const double *c3, int64_t atom_begin,
+                                  int64_t atom_end, double *d_energies, double *d_forces, double *d_virials) {
+    if (!b) return fail(nullptr, UF3_EINVAL, "null basis");
+    if (atom_end < 0) return fail(b->ctx, UF3_EINVAL, "uf3_eval_atoms: atom range outside the batch");
+    return eval_impl(b, fr, d_pos, d_z, c1, c2, c3, d_energies, d_forces, d_virials, atom_begin, atom_end);
+}
+
+extern "C" int uf3_eval_atoms(uf3_basis *b, const uf3_frames *fr, const double *pos, const int32_t *z, const double *c1,
+                              const double *c2, const double *c3, int64_t atom_begin, int64_t atom_end,
+                              double *energies, double *forces, double *virials) {
+    if (!b) return fail(nullptr, UF3_EINVAL, "null basis");
+    if (atom_end < 0) return fail(b->ctx, UF3_EINVAL, "uf3_eval_atoms: atom range outside the batch");
+    return eval_host(b, fr, pos, z, c1, c2, c3, energies, forces, virials, atom_begin, atom_end);
 }
 
 // ------------------------------------------------------------------------------ gram

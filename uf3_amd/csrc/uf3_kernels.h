@@ -1224,6 +1224,8 @@ struct EvalArgs {
     double *forces;               // [natoms][3] or null
     double *virial;               // [natoms][6] dE/d(strain) shares (xx,yy,zz,yz,xz,xy) or null
     int natoms;
+    int atom_lo;                  // first atom of this launch (blocks cover [atom_lo, natoms_end))
+    int atom_hi;
 };
 
 // V and its three leg partials at (rl, rm, rn) from the full coefficient grid of a trio
@@ -1274,8 +1276,8 @@ k_eval(EvalArgs A) {
     double *ox = (double *)smem, *oy = ox + cap, *oz = oy + cap, *orr = oz + cap;
     int *oparent = (int *)(orr + cap), *oshift = oparent + cap, *osidx = oshift + cap, *ospec = osidx + cap,
         *ooff = ospec + cap;
-    int m = blockIdx.x;
-    if (m >= A.natoms) return;
+    int m = A.atom_lo + blockIdx.x;
+    if (m >= A.atom_hi) return;
     int lane = lane_id();
     const FrameGeom g = A.geoms[A.frame_of[m]];
     const int sm = A.spec[m];

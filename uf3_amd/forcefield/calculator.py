@@ -107,6 +107,23 @@ class UFCalculator(_Base):
         ctx.check(ctx.lib.uf3_eval(*args))
         return e, f, batch.offsets
 
+    def evaluate_atom_range(self, atoms, atom_begin, atom_end, forces=True, virial=False):
+        """
+        Share of atoms [atom_begin, atom_end) of one frame: (energy share, forces [N, 3] with the other
+        atoms' rows zero, dE/d(strain) share [6] or None).  Shares over disjoint ranges covering the frame
+        add up to ``evaluate_frames`` (``uf3_eval_atoms``; used by ``parallel.sharded_evaluate``).
+        """
+        ctx = _lib.get_context(self.device)
+        db = _lib.device_basis(self.bspline_config, ctx)
+        batch = _lib.FrameBatch([atoms])
+        e = np.empty(1)
+        f = np.empty((batch.n_atoms, 3)) if forces else None
+        v = np.empty((1, 6)) if virial else None
+        ctx.check(ctx.lib.uf3_eval_atoms(db.handle, C.byref(batch.struct), _lib._p(batch.pos), _lib._p(batch.z),
+                                         _lib._p(self._c1), _lib._p(self._c2), _lib._p(self._c3), int(atom_begin),
+                                         int(atom_end), _lib._p(e), _lib._p(f), _lib._p(v)))
+        return float(e[0]), f, (v[0] if virial else None)
+
     def calculate(self, atoms=None, properties=None, system_changes=tuple(all_changes)):
         if properties is None:
             properties = self.implemented_properties
