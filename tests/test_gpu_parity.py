@@ -372,7 +372,8 @@ def test_evaluator_50k_atom_ternary():
 
 def test_atom_range_shares_add_up_to_the_frame():
     """uf3_eval_atoms: shares of disjoint atom blocks (what each rank of a decomposed frame computes) sum to
-    the whole-frame energy / virial, and their force rows are the whole-frame rows, bit for bit."""
+    the whole-frame energy / virial, and their force rows are the whole-frame rows (the whole frame takes the
+    two-pass route -- every triplet once, at its centre -- and a block the gather route: two independent traversals)."""
     from uf3_amd import parallel
     atoms = synthetic.lattice_frame("bcc", (5, 6, 7), 3.165, [42, 74], seed=77)
     basis = synthetic.notebook_basis(['Mo', 'W'])
@@ -388,14 +389,48 @@ def test_atom_range_shares_add_up_to_the_frame():
     assert rel_err(sum(s[2] for s in shares), v[0]) < 1e-12
     for r, (_, fs, _) in enumerate(shares):
         lo, hi = parallel.shard_range(n, r, world)
-        assert np.array_equal(fs[lo:hi], f[lo:hi])
+        assert rel_err(fs[lo:hi], f[lo:hi]) < 1e-12
         assert not fs[:lo].any() and not fs[hi:].any()
+    os.environ["UF3_EVAL_GATHER"] = "1"                                       # whole frame through the gather route
+    try:
+        e_g, f_g, _, v_g = calc.evaluate_frames([atoms], virial=True)
+    finally:
+        del os.environ["UF3_EVAL_GATHER"]
+    assert e_g[0] == e[0] and np.array_equal(v_g, v) and rel_err(f_g, f) < 1e-12
+    for r, (_, fs, _) in enumerate(shares):
+        lo, hi = parallel.shard_range(n, r, world)
+        assert np.array_equal(fs[lo:hi], f_g[lo:hi])
     e1, f1, v1 = parallel.sharded_evaluate(calc, atoms, virial=True)          # no process group: whole frame
     assert e1 == e[0] and np.array_equal(f1, f) and np.array_equal(v1, v[0])
     e0, f0, v0 = calc.evaluate_atom_range(atoms, 10, 10)                      # empty block
     assert e0 == 0.0 and not f0.any() and v0 is None
     with pytest.raises(RuntimeError):
         calc.evaluate_atom_range(atoms, 5, n + 1)
+
+
+def test_evaluator_list_capacity_regrows_between_calls():
+    """Small batches read the neighbour stage's flags together with the results: a frame denser than any seen
+    before overflows the remembered list capacity, and the call must notice and repeat itself."""
+    basis = synthetic.notebook_basis(['W'])
+    model = ls.WeightedLinearModel(basis)
+    coeff = np.random.default_rng(9).normal(0, 0.05, basis.n_feats)
+    coeff[basis.col_idx] = 0.0
+    model.coefficients = coeff
+    calc = calculator.UFCalculator(model)
+    ob = O.OracleBasis(basis)
+    for a0 in (3.6, 3.165, 2.7, 3.3, 2.5):                 # neighbours inside the 3-body range: few -> many
+        atoms = synthetic.lattice_frame("bcc", (3, 3, 4), a0, [74], seed=int(a0 * 1000))
+        e, f, _, v = calc.evaluate_frames([atoms], virial=True)
+        e_ref, f_ref = O.evaluate(ob, atoms, coeff)
+        assert abs(e[0] - e_ref) <= 1e-10 * max(1.0, abs(e_ref)), a0
+        assert rel_err(f, f_ref) < 1e-10, a0
+    with pytest.raises(RuntimeError):                      # the species error takes the same deferred route
+        bad = synthetic.lattice_frame("bcc", (3, 3, 4), 3.165, [29], seed=1)
+        calc.evaluate_frames([bad])
+    atoms = synthetic.lattice_frame("bcc", (3, 3, 4), 3.165, [74], seed=2)
+    e, f, _ = calc.evaluate_frames([atoms])                # ... and leaves the context usable
+    e_ref, f_ref = O.evaluate(ob, atoms, coeff)
+    assert abs(e[0] - e_ref) <= 1e-10 * abs(e_ref) and rel_err(f, f_ref) < 1e-10
 
 
 def test_featurize_frames_into_caller_buffers():

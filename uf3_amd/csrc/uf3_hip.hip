@@ -29,6 +29,24 @@ struct Buf {
     template <class T> T *as() const { return (T *)p; }
 };
 
+// grow-only pinned host memory: small transfers go through it so that they are true asynchronous copies (a copy
+// from / to pageable caller memory is staged by the runtime and waits)
+struct PinBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t bytes) {
+        if (bytes <= cap) return hipSuccess;
+        if (p) hipHostFree(p);
+        p = nullptr; cap = 0;
+        size_t want = std::max(bytes, (size_t)4096);
+        hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() { if (p) hipHostFree(p); p = nullptr; cap = 0; }
+};
+#define UF3_PIN_LIMIT (512 * 1024)   // bytes: larger transfers go straight from / to the caller's memory
+
 struct uf3_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
@@ -38,11 +56,16 @@ struct uf3_ctx {
     // grow-only workspace
     Buf geoms, offsets, frame_of, atom_bin, atom_wrap, spec, key_in, key_out, val_in, val_out, sort_tmp,
         bin_start, slots, flags,
-        n3_cnt, n3_int, n3_dbl, e_atom, coeff, stage_pos, stage_z, stage_out, stage_out2,
+        n3_cnt, n3_int, n3_dbl, e_atom, nbr_f, coeff, stage_pos, stage_z, stage_out, stage_out2,
         gram_tiles, frag, dbg;
     int n3_cap = 0, cand_cap = 0;
     bool n3_tuned = false;           // capacity re-sized once to the lists actually seen
     bool frag_ready = false;
+    int32_t *d_stage_z = nullptr;       // species of the staged batch (tail of stage_pos)
+    PinBuf pin_in, pin_geo, pin_out;    // positions + species | frame geometry + offsets | results
+    hipEvent_t pin_in_done = nullptr, pin_geo_done = nullptr;   // the copies out of pin_in / pin_geo have executed
+    std::vector<double> coeff_shadow;   // host copy of the model last uploaded by uf3_eval (c1 | c2 | c3)
+    const void *coeff_dev = nullptr;    // ... and where it lives
     // timing
     bool timing = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -96,6 +119,8 @@ extern "C" int uf3_ctx_create(int device, uf3_ctx **out) {
     HIPCHK(c, hipSetDevice(device));
     HIPCHK(c, hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     c->stream = c->own_stream;
+    HIPCHK(c, hipEventCreateWithFlags(&c->pin_in_done, hipEventDisableTiming));
+    HIPCHK(c, hipEventCreateWithFlags(&c->pin_geo_done, hipEventDisableTiming));
     hipDeviceProp_t prop;
     HIPCHK(c, hipGetDeviceProperties(&prop, device));
     c->lds_max = (int)prop.sharedMemPerBlock;
@@ -114,9 +139,12 @@ extern "C" void uf3_ctx_destroy(uf3_ctx *c) {
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
     Buf *all[] = {&c->geoms, &c->offsets, &c->frame_of, &c->atom_bin, &c->atom_wrap, &c->spec, &c->key_in,
-                  &c->key_out, &c->val_in, &c->val_out, &c->sort_tmp, &c->bin_start, &c->slots, &c->flags, &c->n3_cnt, &c->n3_int, &c->n3_dbl, &c->e_atom, &c->coeff,
+                  &c->key_out, &c->val_in, &c->val_out, &c->sort_tmp, &c->bin_start, &c->slots, &c->flags, &c->n3_cnt, &c->n3_int, &c->n3_dbl, &c->e_atom, &c->nbr_f, &c->coeff,
                   &c->stage_pos, &c->stage_z, &c->stage_out, &c->stage_out2, &c->gram_tiles, &c->frag, &c->dbg};
     for (Buf *b : all) b->release();
+    c->pin_in.release(); c->pin_geo.release(); c->pin_out.release();
+    if (c->pin_in_done) hipEventDestroy(c->pin_in_done);
+    if (c->pin_geo_done) hipEventDestroy(c->pin_geo_done);
     for (auto &v : c->pending) for (auto &p : v) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
     if (c->own_stream) hipStreamDestroy(c->own_stream);
     delete c;
@@ -500,6 +528,7 @@ struct Prepared {
     const int *frame_of = nullptr;
     const signed char *spec = nullptr;
     const int64_t *d_offsets = nullptr;
+    bool deferred = false;      // the list-capacity / error flags of this build have not been read yet
 };
 
 static int check_flags(uf3_ctx *c) {
@@ -543,8 +572,10 @@ static int n3_tune(uf3_ctx *c, const N3Lists &n3, int natoms) {
 }
 
 // cell list + 3-body neighbour lists for a batch (positions / species already in HBM)
+// defer_check: once the list capacity is tuned, do not wait for the build's flags; the caller reads them together
+// with its results and repeats the call if the lists overflowed (all kernels are safe on clipped lists)
 static int prepare(uf3_basis *b, const uf3_frames *fr, const double *d_pos, const int32_t *d_z, bool need_n3,
-                   Prepared &P) {
+                   Prepared &P, bool defer_check = false) {
     uf3_ctx *c = b->ctx;
     if (!fr || fr->n_frames < 1 || !fr->atom_offsets || !fr->cells || !fr->pbc)
         return fail(c, UF3_EINVAL, "bad uf3_frames");
@@ -573,11 +604,17 @@ static int prepare(uf3_basis *b, const uf3_frames *fr, const double *d_pos, cons
     int nbins = bin_cursor;
     hipStream_t st = c->stream;
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, c->geoms.ensure(sizeof(FrameGeom) * nf));
-    HIPCHK(c, c->offsets.ensure(sizeof(int64_t) * (nf + 1)));
-    HIPCHK(c, hipMemcpyAsync(c->geoms.p, geoms.data(), sizeof(FrameGeom) * nf, hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipMemcpyAsync(c->offsets.p, fr->atom_offsets, sizeof(int64_t) * (nf + 1), hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipStreamSynchronize(st));   // geoms / offsets are stack / caller memory
+    // frame geometry | atom offsets: one block, staged in pinned memory (the copy is asynchronous; the event tells
+    // the next call when the staging block may be overwritten)
+    const size_t geo_bytes = (sizeof(FrameGeom) * nf + 15) / 16 * 16, off_bytes = sizeof(int64_t) * (nf + 1);
+    HIPCHK(c, c->geoms.ensure(geo_bytes + off_bytes));
+    HIPCHK(c, hipEventSynchronize(c->pin_geo_done));
+    HIPCHK(c, c->pin_geo.ensure(geo_bytes + off_bytes));
+    std::memcpy(c->pin_geo.p, geoms.data(), sizeof(FrameGeom) * nf);
+    std::memcpy((char *)c->pin_geo.p + geo_bytes, fr->atom_offsets, off_bytes);
+    HIPCHK(c, hipMemcpyAsync(c->geoms.p, c->pin_geo.p, geo_bytes + off_bytes, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipEventRecord(c->pin_geo_done, st));
+    const int64_t *d_offsets = (const int64_t *)((const char *)c->geoms.p + geo_bytes);
     size_t na = (size_t)natoms;
     HIPCHK(c, c->frame_of.ensure(4 * na)); HIPCHK(c, c->atom_bin.ensure(4 * na)); HIPCHK(c, c->atom_wrap.ensure(4 * na));
     HIPCHK(c, c->spec.ensure(na)); HIPCHK(c, c->key_in.ensure(4 * na)); HIPCHK(c, c->key_out.ensure(4 * na));
@@ -590,7 +627,7 @@ static int prepare(uf3_basis *b, const uf3_frames *fr, const double *d_pos, cons
     Timed tm(c, T_NBR);
     int tb = 256, gb = (natoms + tb - 1) / tb;
     hipLaunchKernelGGL(k_frame_bins, dim3(gb), dim3(tb), 0, st, b->dev, c->geoms.as<FrameGeom>(),
-                       c->offsets.as<int64_t>(), nf, natoms, d_pos, d_z, c->frame_of.as<int>(), c->atom_bin.as<int>(),
+                       d_offsets, nf, natoms, d_pos, d_z, c->frame_of.as<int>(), c->atom_bin.as<int>(),
                        c->atom_wrap.as<int>(), c->spec.as<signed char>(), c->key_in.as<int>(), c->val_in.as<int>(), flags);
     int bits = 1;
     while ((1LL << bits) < (long long)nbins + 1) bits++;
@@ -610,7 +647,7 @@ static int prepare(uf3_basis *b, const uf3_frames *fr, const double *d_pos, cons
     P.geoms = c->geoms.as<FrameGeom>();
     P.frame_of = c->frame_of.as<int>();
     P.spec = c->spec.as<signed char>();
-    P.d_offsets = c->offsets.as<int64_t>();
+    P.d_offsets = d_offsets;
     P.cl.bin_start = c->bin_start.as<int>(); P.cl.slots = c->slots.as<SlotRec>();
     P.cl.atom_bin = c->atom_bin.as<int>(); P.cl.atom_wrap = c->atom_wrap.as<int>();
     std::memset(&P.n3, 0, sizeof(P.n3));
@@ -627,12 +664,15 @@ static int prepare(uf3_basis *b, const uf3_frames *fr, const double *d_pos, cons
             hipLaunchKernelGGL(k_build_n3, dim3(natoms), dim3(64), lds, st, b->dev, P.geoms, P.frame_of, P.cl, P.n3,
                                d_pos, natoms, flags + 1);
             HIPCHK(c, hipGetLastError());
-            int need = 0;
-            HIPCHK(c, hipMemcpyAsync(&need, flags + 1, sizeof(int), hipMemcpyDeviceToHost, st));
+            if (defer_check && c->n3_tuned) { P.deferred = true; return UF3_OK; }
+            int fl[4] = {0, 0, 0, 0};                                   // error flag | list length needed | .. | ..
+            HIPCHK(c, hipMemcpyAsync(fl, flags, sizeof(fl), hipMemcpyDeviceToHost, st));
             HIPCHK(c, hipStreamSynchronize(st));
+            if (fl[0]) return check_flags(c);
+            const int need = fl[1];
             if (need <= cap) {
                 if (!c->n3_tuned) { int rt = n3_tune(c, P.n3, natoms); if (rt) return rt; }
-                return check_flags(c);
+                return UF3_OK;
             }
             c->n3_tuned = true;
             c->n3_cap = (need + 8 + 7) / 8 * 8;
@@ -829,10 +869,20 @@ static int upload_frames(uf3_ctx *c, const uf3_frames *fr, const double *pos, co
     if (!pos || !z) return fail(c, UF3_EINVAL, "null positions / species");
     natoms = (int)total;
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, c->stage_pos.ensure(24 * (size_t)natoms));
-    HIPCHK(c, c->stage_z.ensure(4 * (size_t)natoms));
-    HIPCHK(c, hipMemcpyAsync(c->stage_pos.p, pos, 24 * (size_t)natoms, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->stage_z.p, z, 4 * (size_t)natoms, hipMemcpyHostToDevice, c->stream));
+    const size_t bp = 24 * (size_t)natoms, bz = 4 * (size_t)natoms;
+    HIPCHK(c, c->stage_pos.ensure(bp + bz));                       // positions | species, one block
+    c->d_stage_z = (int32_t *)((char *)c->stage_pos.p + bp);
+    if (bp + bz <= UF3_PIN_LIMIT) {
+        HIPCHK(c, hipEventSynchronize(c->pin_in_done));
+        HIPCHK(c, c->pin_in.ensure(bp + bz));
+        std::memcpy(c->pin_in.p, pos, bp);
+        std::memcpy((char *)c->pin_in.p + bp, z, bz);
+        HIPCHK(c, hipMemcpyAsync(c->stage_pos.p, c->pin_in.p, bp + bz, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipEventRecord(c->pin_in_done, c->stream));
+    } else {
+        HIPCHK(c, hipMemcpyAsync(c->stage_pos.p, pos, bp, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->d_stage_z, z, bz, hipMemcpyHostToDevice, c->stream));
+    }
     return UF3_OK;
 }
 
@@ -847,7 +897,7 @@ extern "C" int uf3_featurize(uf3_basis *b, const uf3_frames *fr, const double *p
     size_t be = xe ? 8 * F * fr->n_frames : 0, bf = xf ? 8 * F * 3 * (size_t)natoms : 0;
     if (be) HIPCHK(c, c->stage_out.ensure(be));
     if (bf) HIPCHK(c, c->stage_out2.ensure(bf));
-    rc = uf3_featurize_dev(b, fr, c->stage_pos.as<double>(), c->stage_z.as<int32_t>(),
+    rc = uf3_featurize_dev(b, fr, c->stage_pos.as<double>(), c->d_stage_z,
                            be ? c->stage_out.as<double>() : nullptr, bf ? c->stage_out2.as<double>() : nullptr);
     if (rc) return rc;
     if (be) HIPCHK(c, hipMemcpyAsync(xe, c->stage_out.p, be, hipMemcpyDeviceToHost, c->stream));
@@ -858,21 +908,32 @@ extern "C" int uf3_featurize(uf3_basis *b, const uf3_frames *fr, const double *p
 // ------------------------------------------------------------------------------ eval
 static int eval_impl(uf3_basis *b, const uf3_frames *fr, const double *d_pos, const int32_t *d_z, const double *c1,
                      const double *c2, const double *c3, double *d_energies, double *d_forces, double *d_virials,
-                     int64_t atom_begin = 0, int64_t atom_end = -1) {
+                     int64_t atom_begin = 0, int64_t atom_end = -1, int *deferred_cap = nullptr) {
     uf3_ctx *c = b->ctx;
     if (!d_pos || !d_z || !c1 || !d_energies) return fail(c, UF3_EINVAL, "uf3_eval: null argument");
     if ((b->c2_len && !c2) || (b->c3_len && !c3)) return fail(c, UF3_EINVAL, "uf3_eval: missing coefficients");
     Prepared P;
-    int rc = prepare(b, fr, d_pos, d_z, true, P);
+    int rc = prepare(b, fr, d_pos, d_z, true, P, deferred_cap != nullptr);
     if (rc) return rc;
+    if (deferred_cap) *deferred_cap = P.deferred ? P.n3.cap : 0;
     hipStream_t st = c->stream;
     size_t n1 = (size_t)b->host.S, n2 = b->c2_len, n3 = b->c3_len;
     HIPCHK(c, c->coeff.ensure(8 * (n1 + n2 + n3 + 1)));
     double *dc = c->coeff.as<double>();
-    HIPCHK(c, hipMemcpyAsync(dc, c1, 8 * n1, hipMemcpyHostToDevice, st));
-    if (n2) HIPCHK(c, hipMemcpyAsync(dc + n1, c2, 8 * n2, hipMemcpyHostToDevice, st));
-    if (n3) HIPCHK(c, hipMemcpyAsync(dc + n1 + n2, c3, 8 * n3, hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipStreamSynchronize(st));
+    // an MD loop passes the same model every step: upload (and wait for the caller's buffers) only when they changed
+    std::vector<double> &sh = c->coeff_shadow;
+    const bool same = c->coeff_dev == (const void *)dc && sh.size() == n1 + n2 + n3 && !memcmp(sh.data(), c1, 8 * n1) &&
+                      (!n2 || !memcmp(sh.data() + n1, c2, 8 * n2)) && (!n3 || !memcmp(sh.data() + n1 + n2, c3, 8 * n3));
+    if (!same) {
+        sh.resize(n1 + n2 + n3);
+        memcpy(sh.data(), c1, 8 * n1);
+        if (n2) memcpy(sh.data() + n1, c2, 8 * n2);
+        if (n3) memcpy(sh.data() + n1 + n2, c3, 8 * n3);
+        c->coeff_dev = nullptr;
+        HIPCHK(c, hipMemcpyAsync(dc, sh.data(), 8 * sh.size(), hipMemcpyHostToDevice, st));
+        HIPCHK(c, hipStreamSynchronize(st));
+        c->coeff_dev = dc;
+    }
     HIPCHK(c, c->e_atom.ensure(8 * (size_t)P.natoms * (d_virials ? 7 : 1)));
     if (atom_end < 0) atom_end = P.natoms;
     if (atom_begin < 0 || atom_begin > atom_end || atom_end > P.natoms)
@@ -887,14 +948,24 @@ static int eval_impl(uf3_basis *b, const uf3_frames *fr, const double *d_pos, co
     A.e_atom = c->e_atom.as<double>(); A.forces = d_forces; A.natoms = P.natoms;
     A.atom_lo = (int)atom_begin; A.atom_hi = (int)atom_end;
     A.virial = d_virials ? A.e_atom + P.natoms : nullptr;
-    size_t lds = (size_t)A.n3.cap * 32 + ((size_t)5 * A.n3.cap + 2) * 4 + 16 + 2 * WAVE * EVAL_Q * sizeof(double);
+    size_t lds = (size_t)A.n3.cap * 32 + ((size_t)5 * A.n3.cap + 2) * 4 + 16 + 2 * WAVE * EVAL_Q * sizeof(double) +
+                 (size_t)A.n3.cap * 24;
+    // whole batch with forces and 3-body terms: every triplet once, at its centre, + a collection pass; a block of
+    // atoms (its neighbours' centres may lie outside the block): every atom walks the triplets it belongs to
+    const bool two_pass = !partial && d_forces && b->host.T > 0 && !getenv("UF3_EVAL_GATHER");
+    if (two_pass) {
+        HIPCHK(c, c->nbr_f.ensure(24 * (size_t)P.natoms * A.n3.cap));
+        A.nbr_f = c->nbr_f.as<double>();
+    } else A.nbr_f = nullptr;
     {
         Timed tm(c, T_EVAL);
-        if (atom_end > atom_begin)
-            hipLaunchKernelGGL(k_eval, dim3((unsigned)(atom_end - atom_begin)), dim3(64), lds, st, A);
-        hipLaunchKernelGGL(k_frame_sum, dim3(P.n_frames, 1), dim3(256), 0, st, A.e_atom, P.d_offsets, 1, d_energies);
-        if (d_virials)
-            hipLaunchKernelGGL(k_frame_sum, dim3(P.n_frames, 6), dim3(256), 0, st, A.virial, P.d_offsets, 6, d_virials);
+        if (two_pass) {
+            hipLaunchKernelGGL(k_eval<false>, dim3((unsigned)P.natoms), dim3(64), lds, st, A);
+            hipLaunchKernelGGL(k_eval_collect, dim3((unsigned)((P.natoms + 15) / 16)), dim3(256), 0, st, A);
+        } else if (atom_end > atom_begin)
+            hipLaunchKernelGGL(k_eval<true>, dim3((unsigned)(atom_end - atom_begin)), dim3(64), lds, st, A);
+        hipLaunchKernelGGL(k_frame_sum, dim3(P.n_frames, d_virials ? 7 : 1), dim3(256), 0, st, A.e_atom, A.virial,
+                           P.d_offsets, d_energies, d_virials);
     }
     HIPCHK(c, hipGetLastError());
     return UF3_OK;
@@ -921,18 +992,46 @@ static int eval_host(uf3_basis *b, const uf3_frames *fr, const double *pos, cons
     int natoms = 0;
     int rc = upload_frames(c, fr, pos, z, natoms);
     if (rc) return rc;
-    size_t nf = (size_t)fr->n_frames;
-    HIPCHK(c, c->stage_out.ensure(8 * nf * 7));
-    if (forces) HIPCHK(c, c->stage_out2.ensure(24 * (size_t)natoms));
+    // results in one block: energies [nf] | virials [nf][6] | forces [natoms][3]
+    const size_t nf = (size_t)fr->n_frames, bf = forces ? 24 * (size_t)natoms : 0, total = 8 * nf * 7 + bf;
+    HIPCHK(c, c->stage_out.ensure(total));
+    double *d_e = c->stage_out.as<double>(), *d_v = d_e + nf, *d_f = d_e + 7 * nf;
     if (forces && (atom_begin != 0 || (atom_end >= 0 && atom_end != natoms)))   // rows of other ranks' atoms: zero
-        HIPCHK(c, hipMemsetAsync(c->stage_out2.p, 0, 24 * (size_t)natoms, c->stream));
-    double *d_e = c->stage_out.as<double>(), *d_v = d_e + nf;
-    rc = eval_impl(b, fr, c->stage_pos.as<double>(), c->stage_z.as<int32_t>(), c1, c2, c3, d_e,
-                   forces ? c->stage_out2.as<double>() : nullptr, virials ? d_v : nullptr, atom_begin, atom_end);
+        HIPCHK(c, hipMemsetAsync(d_f, 0, bf, c->stream));
+    if (total + 16 <= UF3_PIN_LIMIT) {
+        // small batch (an MD step): results and the neighbour stage's flags come back in ONE wait -- the lists are
+        // built at the remembered capacity and the evaluation runs on them right away; if they overflowed (or a
+        // species / wrap error was flagged) the results are discarded and the call repeated / failed
+        HIPCHK(c, c->pin_out.ensure(total + 16));
+        for (int attempt = 0; attempt < 6; attempt++) {
+            int cap_used = 0;
+            rc = eval_impl(b, fr, c->stage_pos.as<double>(), c->d_stage_z, c1, c2, c3, d_e, forces ? d_f : nullptr,
+                           virials ? d_v : nullptr, atom_begin, atom_end, &cap_used);
+            if (rc) return rc;
+            HIPCHK(c, hipMemcpyAsync(c->pin_out.p, d_e, total, hipMemcpyDeviceToHost, c->stream));
+            if (cap_used)
+                HIPCHK(c, hipMemcpyAsync((char *)c->pin_out.p + total, c->flags.p, 16, hipMemcpyDeviceToHost, c->stream));
+            rc = uf3_ctx_synchronize(c);
+            if (rc) return rc;
+            if (cap_used) {
+                const int *fl = (const int *)((const char *)c->pin_out.p + total);
+                if (fl[0]) return check_flags(c);
+                if (fl[1] > cap_used) { c->n3_cap = (fl[1] + 8 + 7) / 8 * 8; continue; }
+            }
+            const double *h = (const double *)c->pin_out.p;
+            std::memcpy(energies, h, 8 * nf);
+            if (virials) std::memcpy(virials, h + nf, 48 * nf);
+            if (forces) std::memcpy(forces, h + 7 * nf, bf);
+            return UF3_OK;
+        }
+        return fail(c, UF3_EOVERFLOW, "3-body neighbour capacity did not converge");
+    }
+    rc = eval_impl(b, fr, c->stage_pos.as<double>(), c->d_stage_z, c1, c2, c3, d_e, forces ? d_f : nullptr,
+                   virials ? d_v : nullptr, atom_begin, atom_end);
     if (rc) return rc;
     HIPCHK(c, hipMemcpyAsync(energies, d_e, 8 * nf, hipMemcpyDeviceToHost, c->stream));
     if (virials) HIPCHK(c, hipMemcpyAsync(virials, d_v, 48 * nf, hipMemcpyDeviceToHost, c->stream));
-    if (forces) HIPCHK(c, hipMemcpyAsync(forces, c->stage_out2.p, 24 * (size_t)natoms, hipMemcpyDeviceToHost, c->stream));
+    if (forces) HIPCHK(c, hipMemcpyAsync(forces, d_f, bf, hipMemcpyDeviceToHost, c->stream));
     return uf3_ctx_synchronize(c);
 }
 
@@ -1065,7 +1164,7 @@ extern "C" int uf3_neighbors_debug(uf3_basis *b, const uf3_frames *fr, const dou
     int rc = upload_frames(c, fr, pos, z, natoms);
     if (rc) return rc;
     Prepared P;
-    rc = prepare(b, fr, c->stage_pos.as<double>(), c->stage_z.as<int32_t>(), false, P);
+    rc = prepare(b, fr, c->stage_pos.as<double>(), c->d_stage_z, false, P);
     if (rc) return rc;
     int np = b->host.P;
     std::vector<long long> counts(np + 2, 0);

@@ -1223,6 +1223,7 @@ struct EvalArgs {
     double *e_atom;               // [natoms]
     double *forces;               // [natoms][3] or null
     double *virial;               // [natoms][6] dE/d(strain) shares (xx,yy,zz,yz,xz,xy) or null
+    double *nbr_f;                // [natoms * cap][3] force each centre's triplets put on its list entries (two-pass route)
     int natoms;
     int atom_lo;                  // first atom of this launch (blocks cover [atom_lo, natoms_end))
     int atom_hi;
@@ -1266,6 +1267,11 @@ __device__ __forceinline__ double wave_sum(double v) {
 }
 
 #define EVAL_Q 5          // doubles per queued bond of the evaluator
+// GATHER: every atom also walks the triplets it belongs to as a neighbour (each triplet evaluated at its three atoms;
+// what a block of atoms of a decomposed frame needs).  !GATHER: each triplet once, at its centre, which also sums the
+// force it puts on each of its list entries (nbr_f, in LDS first); k_eval_collect then adds to every atom what its
+// neighbours' triplets put on it.  One wave owns a centre and LDS adds of a wave keep their order: deterministic.
+template <bool GATHER>
 __global__ void __launch_bounds__(64)
 k_eval(EvalArgs A) {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -1276,6 +1282,8 @@ k_eval(EvalArgs A) {
     double *ox = (double *)smem, *oy = ox + cap, *oz = oy + cap, *orr = oz + cap;
     int *oparent = (int *)(orr + cap), *oshift = oparent + cap, *osidx = oshift + cap, *ospec = osidx + cap,
         *ooff = ospec + cap;
+    double *queue = (double *)(ooff + cap + 1 + ((cap + 1) & 1));          // [128][EVAL_Q]: dx, dy, dz, d, species
+    double *gx = queue + 2 * WAVE * EVAL_Q, *gy = gx + cap, *gz = gy + cap;  // !GATHER: force on the list entries
     int m = A.atom_lo + blockIdx.x;
     if (m >= A.atom_hi) return;
     int lane = lane_id();
@@ -1288,7 +1296,6 @@ k_eval(EvalArgs A) {
     if (lane == 0) e = A.c1[sm];
     // 2-body: bonds inside their pair's range are queued in LDS and evaluated 64 at a time (about one candidate in
     // five survives the range test: evaluating in place would leave most lanes idle in the spline code)
-    double *queue = (double *)(ooff + cap + 1 + ((cap + 1) & 1));          // [128][EVAL_Q]: dx, dy, dz, d, species
     int queued = 0;
     auto drain = [&](int count) {
         const double *c = queue + (size_t)lane * EVAL_Q;
@@ -1352,6 +1359,7 @@ k_eval(EvalArgs A) {
             const N3Entry en = A.n3.ent[base + q];
             ox[q] = en.dx; oy[q] = en.dy; oz[q] = en.dz; orr[q] = en.r;
             oparent[q] = en.parent; oshift[q] = en.shiftc; osidx[q] = en.sidx; ospec[q] = en.spec;
+            if (!GATHER) { gx[q] = 0.0; gy[q] = 0.0; gz[q] = 0.0; }
         }
         __syncthreads();
         int n_pairs = n * (n - 1) / 2;
@@ -1369,6 +1377,12 @@ k_eval(EvalArgs A) {
             if (want_f) {   // F_m = -dV/dR_m = gl * u_ij + gm * u_ik
                 double a = gr[0] / rl, b = gr[1] / rm;
                 fx += a * ox[aa] + b * ox[bb]; fy += a * oy[aa] + b * oy[bb]; fz += a * oz[aa] + b * oz[bb];
+                if (!GATHER) {   // F_j = -gl u_ij + gn (R_k - R_j) / rn,  F_k = -gm u_ik - gn (R_k - R_j) / rn
+                    const double cc = gr[2] / rn;
+                    const double cx = cc * (ox[bb] - ox[aa]), cy = cc * (oy[bb] - oy[aa]), cz = cc * (oz[bb] - oz[aa]);
+                    lds_add(gx + aa, cx - a * ox[aa]); lds_add(gy + aa, cy - a * oy[aa]); lds_add(gz + aa, cz - a * oz[aa]);
+                    lds_add(gx + bb, -cx - b * ox[bb]); lds_add(gy + bb, -cy - b * oy[bb]); lds_add(gz + bb, -cz - b * oz[bb]);
+                }
             }
             if (want_v) {   // each triplet once (at its centre): sum over legs of dV/dr * r (x) r / r
                 double ta = gr[0] / rl, tb = gr[1] / rm, tc = gr[2] / rn;
@@ -1381,7 +1395,14 @@ k_eval(EvalArgs A) {
                 vir[5] += ta * ox[aa] * oy[aa] + tb * ox[bb] * oy[bb] + tc * cx * cy;
             }
         }
-        if (want_f) {
+        if (want_f && !GATHER) {
+            __syncthreads();
+            for (int q = lane; q < n; q += WAVE) {
+                double *dst = A.nbr_f + 3 * (base + q);
+                dst[0] = gx[q]; dst[1] = gy[q]; dst[2] = gz[q];
+            }
+        }
+        if (want_f && GATHER) {
             int total = 0;
             for (int e0 = 0; e0 < n; e0 += WAVE) {
                 int q = e0 + lane;
@@ -1431,19 +1452,56 @@ k_eval(EvalArgs A) {
     }
 }
 
-// per-frame sums of per-atom quantities (energy: width 1, virial: width 6): deterministic tree
-__global__ void k_frame_sum(const double *per_atom, const int64_t *atom_offsets, int width, double *out) {
+// second pass of the two-pass evaluator: 16 lanes per atom m; for every entry (centre c, image shift s) of m's list the
+// lanes look m up in c's list (entry with parent m and shift -s: the lists are symmetric) and take what c's triplets put
+// on it; fixed lane order + a fixed shuffle tree: deterministic
+__global__ void __launch_bounds__(256)
+k_eval_collect(EvalArgs A) {
+    const int m = blockIdx.x * 16 + (threadIdx.x >> 4), sub = threadIdx.x & 15;
+    if (m >= A.natoms) return;
+    const int cap = A.n3.cap, n = A.n3.cnt[m];
+    const N3Entry *mine = A.n3.ent + (size_t)m * cap;
+    double sx = 0.0, sy = 0.0, sz = 0.0;
+    // lanes <-> own entries; each lane scans its centre's list (independent loads: three dependent round trips per
+    // entry instead of three per list position)
+    for (int q = sub; q < n; q += 16) {
+        const int2 me = *(const int2 *)&mine[q].parent;
+        const int c = me.x;
+        int s0, s1, s2;
+        unpack3(me.y, s0, s1, s2);
+        const int back = pack3(-s0, -s1, -s2), nc = A.n3.cnt[c];
+        const N3Entry *theirs = A.n3.ent + (size_t)c * cap;
+        int hit = -1;
+        for (int r = 0; r < nc; r++) {
+            const int2 key = *(const int2 *)&theirs[r].parent;
+            if (key.x == m && key.y == back) hit = r;
+        }
+        if (hit >= 0) {
+            const double *f = A.nbr_f + 3 * ((size_t)c * cap + hit);
+            sx += f[0]; sy += f[1]; sz += f[2];
+        }
+    }
+    for (int sh = 8; sh > 0; sh >>= 1) { sx += __shfl_xor(sx, sh, 16); sy += __shfl_xor(sy, sh, 16); sz += __shfl_xor(sz, sh, 16); }
+    if (sub == 0) { double *f = A.forces + 3 * (size_t)m; f[0] += sx; f[1] += sy; f[2] += sz; }
+}
+
+// per-frame sums of per-atom quantities: blockIdx.y = 0 energy (width 1), 1..6 virial components (width 6, if
+// given); deterministic tree
+__global__ void k_frame_sum(const double *e_atom, const double *v_atom, const int64_t *atom_offsets, double *e_out,
+                            double *v_out) {
     __shared__ double part[256];
-    int f = blockIdx.x, comp = blockIdx.y;
+    const int f = blockIdx.x, comp = (int)blockIdx.y - 1;
+    const double *src = comp < 0 ? e_atom : v_atom + comp;
+    const int width = comp < 0 ? 1 : 6;
     double s = 0.0;
-    for (int64_t a = atom_offsets[f] + threadIdx.x; a < atom_offsets[f + 1]; a += blockDim.x) s += per_atom[a * width + comp];
+    for (int64_t a = atom_offsets[f] + threadIdx.x; a < atom_offsets[f + 1]; a += blockDim.x) s += src[a * width];
     part[threadIdx.x] = s;
     __syncthreads();
     for (int w = blockDim.x / 2; w > 0; w >>= 1) {
         if ((int)threadIdx.x < w) part[threadIdx.x] += part[threadIdx.x + w];
         __syncthreads();
     }
-    if (threadIdx.x == 0) out[(size_t)f * width + comp] = part[0];
+    if (threadIdx.x == 0) { if (comp < 0) e_out[f] = part[0]; else v_out[(size_t)f * 6 + comp] = part[0]; }
 }
 
 // ---------------------------------------------------------------------------------
