@@ -593,8 +593,10 @@ __device__ __forceinline__ void trio_block(const FeatArgs &A, const BasisDev *B,
 // that every operand address in the MFMA loop is a per-lane constant plus the record stride:
 //   L (B, B') x ext_l | M (B, B') x ext_m | N (B, B') x ext_n | (A1_c, A2_c) c = x,y,z | A3_c c = x,y,z, pad | zero pair
 //   class 0  centre role (A3 = 0: no Q slot)         4 records per step, K index = record; energy tile rides along
-//   class 1  neighbour role, m on leg l (A2 = 0)     2 records per step, P = B'_l B_m A1_c     } single products:
-//   class 2  neighbour role, m on leg m (A1 = 0)     2 records per step, P = B_l B'_m A2_c     } 8-byte operands
+//   class 1  neighbour role, m on leg l (A2 = 0)     2 records per step, P = B'_l B_m A1_c     } single products, 8-byte
+//   class 2  neighbour role, m on leg m (A1 = 0)     2 records per step, P = B_l B'_m A2_c     } operands; ONE loop:
+//            class 1 stores its M pair as (B, B), class 2 its L pair as (B, B), its M pair as (B', B) and its direction
+//            in the A1 slot, so that P lanes read L.y M.x f.x and Q lanes L.x M.y A3 whatever the class
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
 struct DenseLayout {
@@ -671,7 +673,7 @@ __device__ __forceinline__ void mfma_pair(const double *rec, bool live, const De
         double xv[TC], yv[TC], zv[TC];
 #pragma unroll
         for (int u = 0; u < TC; u++) {
-            xv[u] = rec[o.l[t0 + u] + dx]; yv[u] = rec[o.m[t0 + u] + dy]; zv[u] = rec[o.q ? o.g[t0 + u] : o.f[t0 + u] + dy];
+            xv[u] = rec[o.l[t0 + u] + dx]; yv[u] = rec[o.m[t0 + u] + dy]; zv[u] = rec[o.q ? o.g[t0 + u] : o.f[t0 + u]];
         }
         __builtin_amdgcn_sched_group_barrier(0x100, 3 * TC, 0);                           // DS reads
         double a[TC];
@@ -701,16 +703,19 @@ __device__ __forceinline__ void mfma_records(const double *stage, int stride, in
             // (lanes past the end read record 0: whatever lies behind the stage need not be finite)
             if (q < n0) mfma_quad<WANT_E, true, TM>(q + ks < n0 ? rec : stage, q + ks < n0, o, accf, acce);
         }
-        const int pl = 1 - o.q;                        // "P" lanes pick the derivative of the leg that joins centre and m
-        const int bn = o.n + o.q;                      // B operand: B_n for P slots, B'_n for Q slots
-        for (int cls = 1; cls <= 2; cls++) {
-            const int cnt = cls == 1 ? n1 : n2, start = cls == 1 ? n0 : n0 + n1;
-            const int dx = cls == 1 ? pl : 0, dy = cls == 1 ? 0 : pl;
-            const double *rec = stage + (size_t)(start + (ks >> 1)) * stride;
+        // neighbour-role records, two per step (K slots: record 0 P, record 0 Q, record 1 P, record 1 Q).  The staging
+        // pass arranged their (L, M) pairs by class so that both classes read the same slots: P lanes L.y * M.x * f.x
+        // (the derivative of the leg that joins the centre and m, the other leg's value, that leg's direction),
+        // Q lanes L.x * M.y * A3
+        {
+            const int pl = 1 - o.q;
+            const int bn = o.n + o.q;                  // B operand: B_n for P slots, B'_n for Q slots
+            const int cnt = n1 + n2;
+            const double *rec = stage + (size_t)(n0 + (ks >> 1)) * stride;
             const int n_full = cnt & ~1;
             int q = 0;
-            for (; q < n_full; q += 2, rec += 2 * stride) mfma_pair<false, TM>(rec, true, o, dx, dy, bn, accf);
-            if (q < cnt) mfma_pair<true, TM>((ks >> 1) == 0 ? rec : stage, (ks >> 1) == 0, o, dx, dy, bn, accf);
+            for (; q < n_full; q += 2, rec += 2 * stride) mfma_pair<false, TM>(rec, true, o, pl, o.q, bn, accf);
+            if (q < cnt) mfma_pair<true, TM>((ks >> 1) == 0 ? rec : stage, (ks >> 1) == 0, o, pl, o.q, bn, accf);
         }
     } else if (WANT_E) {
         const double *rec = stage + (size_t)ks * stride;
@@ -829,21 +834,28 @@ __device__ __forceinline__ void trio_block_mfma(const FeatArgs &A, const BasisDe
                     const int slot = leg * n_clear + q;
                     if (2 * slot < dl.off_f) *(double2 *)(rec + 2 * slot) = zz;
                 }
+                const int2 pk = WANT_F ? *(const int2 *)(ge + 6) : make_int2(0, 0);
+                const int cls = pk.y;
+                // (value, derivative) pairs; neighbour-role records store the pair of the leg that does not carry the
+                // derivative as (value, value) and class 2 swaps its M pair, so that one MFMA loop serves both classes
+                const bool dup = WANT_F && ((cls == 1 && leg == 1) || (cls == 2 && leg == 0));
+                const bool swp = WANT_F && cls == 2 && leg == 1;
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
                     const unsigned ws = (unsigned)(first + q - w_lo);
-                    if (ws < (unsigned)w_ext) *(double2 *)(rec + w_off + 2 * ws) = double2{v[q], WANT_F ? d[q] : 0.0};
+                    const double dq = WANT_F ? d[q] : 0.0;
+                    if (ws < (unsigned)w_ext)
+                        *(double2 *)(rec + w_off + 2 * ws) = double2{swp ? dq : v[q], (dup | swp) ? v[q] : dq};
                 }
                 if (WANT_F) {
                     // component `leg` of the three direction vectors: unit vectors of own-list entries, and e
-                    const int2 pk = *(const int2 *)(ge + 6);
-                    const int i1 = pk.x & 0xffff, i2 = pk.x >> 16, cls = pk.y;
+                    const int i1 = pk.x & 0xffff, i2 = pk.x >> 16;
                     const double *oc = w.ox + (size_t)leg * A.n3.cap;           // ox | oy | oz are consecutive [cap] arrays
                     const double v1 = oc[i1] * w.oir[i1];
                     const double v2c = oc[i2] * w.oir[i2], v2n = ge[3 + leg];   // both fetched: no divergent round trip
                     const double v2 = cls == 0 ? v2c : v2n;
-                    const double a1 = cls == 2 ? 0.0 : v1;
-                    const double a2 = cls == 0 ? v2 : (cls == 2 ? v1 : 0.0);
+                    const double a1 = v1;                                  // neighbour role: the one direction, in .x
+                    const double a2 = cls == 0 ? v2 : 0.0;
                     const double a3 = cls == 0 ? 0.0 : v2;
                     *(double2 *)(rec + dl.off_f + 2 * leg) = double2{a1, a2};
                     rec[dl.off_f + 6 + leg] = a3;
