@@ -74,6 +74,9 @@ def main(run, prefix):
         "hbm_bytes_per_launch_raw": (fetch_kib + write_kib) * 1024,
         "hbm_bytes_per_launch_fetch_x2": (2 * fetch_kib + write_kib) * 1024,
         "algorithmic_bytes_per_launch": bench["roofline"]["algorithmic_bytes_per_launch"],
+        "known_write_bytes_per_launch (rows + 3-body lists at capacity 16)":
+            bench["roofline"]["algorithmic_bytes_per_launch"]
+            + 48 * 16 * bench["config"]["atoms_per_frame"] * bench["config"]["frames_per_step"],
         "kernel_time_agreement": {
             "hip_events_ms_per_step (bench.py, live)": bench["roofline"]["launch_ms"],
             "rocprofv3_kernel_stats_ms_per_step": rocprof_group_ms,
@@ -83,7 +86,9 @@ def main(run, prefix):
                 "streaming read; the reads here are mostly 48-B gathers of neighbour-list entries, so the "
                 "uncorrected sum is quoted as `traffic` and the x2-corrected sum as the upper bound. Every "
                 "specialisation reads the neighbour lists again; nothing is read-modify-written: rows are "
-                "written once per (atom, column range).",
+                "written once per (atom, column range).  WRITE_SIZE (uncalibrated per the guide) checks out against "
+                "this kernel's known writes: rows (= the algorithmic bytes) + 3-body lists (48 B x capacity 16 per "
+                "atom) are written exactly once, and the counter reads within a few per cent of their sum.",
         "workload": {"atoms_per_frame": bench["config"]["atoms_per_frame"], "n_feat": bench["config"]["n_feat"],
                      "frames_per_step": bench["config"]["frames_per_step"]},
     }
