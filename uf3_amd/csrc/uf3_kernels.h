@@ -9,7 +9,9 @@
 //                     MODE 6 / 7  3-body windows of <= 32 rows on the fp64 matrix cores (7: three waves / SIMD)
 //                     MODE 8 / 9  ... of <= 64 / <= 128 rows
 //                     MODE 1-5    generic output-stationary 3-body kernels (wider windows)
-//   k_eval            energy + forces (+ virial) of a fitted model        one wave / atom
+//   k_eval<GATHER>    energy + forces (+ virial) of a fitted model        one wave / atom: every triplet once at its
+//                     centre + k_eval_collect (whole batch), or gathered at its three atoms (a block of atoms)
+//   k_frame_sum       per-frame sums of the per-atom energies / virial shares
 //   k_gram_mfma       X^T X on the fp64 matrix cores;  k_ordinate  X^T y
 //
 // Formulation: every atom m GATHERS all pair terms and all triplet terms it takes part in --
