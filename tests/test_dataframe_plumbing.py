@@ -34,3 +34,32 @@ def test_subset_prediction_matches_reference():
     assert np.array_equal(y_e, D["sub_y_e"]) and np.allclose(p_e, D["sub_p_e"], rtol=1e-15)
     assert np.array_equal(y_f, D["sub_y_f"]) and np.allclose(p_f, D["sub_p_f"], rtol=1e-15)
     assert ls.subset_prediction(_table(), Model(), subset_keys=["nope"]) == ([], [], [], [])
+
+
+T = np.load(os.path.join(GOLDEN, "table_fit.npz"), allow_pickle=False)
+
+
+def test_variance_recorder_components_and_weight_helpers():
+    vr = ls.VarianceRecorder()
+    vr.update_with_components(pd.DataFrame({"fx": [[0.1, -0.2], [0.3], np.nan], "fy": [[0.0, 0.5], [-0.7], [1.0]],
+                                            "fz": [[0.2, 0.2], [0.9], [2.0]]}))
+    vr.update_with_components(pd.DataFrame({"fx": [[1.5, -1.0, 0.2]], "fy": [[0.4, 0.1, 0.0]], "fz": [[-0.3, 0.8, 0.6]]}))
+    assert np.allclose([vr.mean, vr.std, vr.n], T["components_stats"], rtol=1e-15, atol=0)
+    x, y = np.arange(6.0).reshape(3, 2), np.array([1.0, 2.0, 3.0])
+    xw, yw = ls.apply_weights(x, y, np.array([4.0, 0.0, 1.0]))
+    assert np.array_equal(xw, x * np.array([2.0, 0.0, 1.0])[:, None]) and np.array_equal(yw, [2.0, 0.0, 3.0])
+    assert ls.apply_weights(x, y, None)[0] is not None
+    for bad in (np.array([1.0, 1.0]), np.array([1.0, -1.0, 1.0])):
+        try:
+            ls.apply_weights(x, y, bad)
+        except ValueError:
+            continue
+        raise AssertionError("bad weights accepted")
+    assert ls.validate_regularizer(np.zeros((5, 2)), 2) is None
+    try:
+        ls.validate_regularizer(np.zeros((5, 3)), 2)
+    except ValueError:
+        pass
+    else:
+        raise AssertionError("bad regularizer accepted")
+    assert np.array_equal(ls.apply_weighted_gram(np.eye(2), 3.0), 9.0 * np.eye(2))

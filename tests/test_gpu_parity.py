@@ -342,6 +342,49 @@ def test_evaluate_dataframe_surface():
     assert len(p_e) == 1 and len(p_f) == 9 and np.all(np.isfinite(p_e)) and np.all(np.isfinite(p_f))
 
 
+def _table_fit_case():
+    import pandas as pd
+    t = np.load(os.path.join(GOLDEN, "table_fit.npz"), allow_pickle=False)
+    basis = basis_from_meta(json.loads(str(t["meta"])))
+    columns = basis.get_column_names()
+    tables = [pd.DataFrame(t[f"table{k}"], columns=columns, index=pd.MultiIndex.from_tuples(
+        list(zip(t[f"table{k}_names"].tolist(), t[f"table{k}_keys"].tolist())))) for k in range(3)]
+    weights = dict(zip(t["weight_names"].tolist(), t["weight_values"].tolist()))
+    return t, basis, tables, weights
+
+
+def test_fit_from_feature_tables_against_reference_capture():
+    """The from-file workflow (gram_from_df per table, streamed statistics, one solve; batched prediction) against
+    the reference's functions run table by table (tests/golden/make_table_fit_golden.py)."""
+    t, basis, tables, weights = _table_fit_case()
+    subset = t["subset"].tolist()
+    model = ls.WeightedLinearModel(basis, regularizer=t["regularizer"])
+    e_var, f_var = ls.VarianceRecorder(), ls.VarianceRecorder()
+    for k, df in enumerate(tables):
+        keys = df.index.unique(level=0).intersection(subset)
+        pieces = model.gram_from_df(df, keys, e_variance=e_var, f_variance=f_var, sample_weights=weights)
+        for got, name in zip(pieces, ("gram_e", "gram_f", "ord_e", "ord_f")):
+            assert rel_err(got, t[f"{name}{k}"]) < 1e-12, (name, k)
+    assert np.allclose([e_var.mean, e_var.std, e_var.n], t["e_stats"], rtol=1e-13)
+    assert np.allclose([f_var.mean, f_var.std, f_var.n], t["f_stats"], rtol=1e-13)
+    model.fit_from_tables(tables, subset, weight=float(t["kappa"][0]), sample_weights=weights)
+    assert np.allclose(model.coefficients, t["coefficients"], rtol=1e-7, atol=1e-9)
+    assert np.array_equal(model.data_coverage, t["data_coverage"])
+    model.coefficients = t["coefficients"]
+    y_e, p_e, y_f, p_f = model.batched_predict(keys=["a1", "b0", "c2", "c3"], score=False, tables=tables)
+    assert np.array_equal(y_e, t["pred_y_e"]) and np.allclose(p_e, t["pred_p_e"], rtol=1e-13)
+    assert np.array_equal(y_f, t["pred_y_f"]) and np.allclose(p_f, t["pred_p_f"], rtol=1e-13, atol=1e-14)
+    assert len(model.batched_predict(keys=["a1"], score=True, tables=tables)) == 6
+    # the stand-alone solvers: same normal equations as numpy's least squares
+    rng = np.random.default_rng(3)
+    x, y, w = rng.normal(size=(200, 12)), rng.normal(size=200), rng.uniform(0.1, 2.0, 200)
+    assert np.allclose(ls.linear_least_squares(x, y), np.linalg.lstsq(x, y, rcond=None)[0], rtol=1e-9)
+    reg = 0.1 * np.eye(12)
+    sw = np.sqrt(w)
+    expect = np.linalg.lstsq(np.vstack([x * sw[:, None], reg]), np.concatenate([y * sw, np.zeros(12)]), rcond=None)[0]
+    assert np.allclose(ls.weighted_least_squares(x, y, weights=w, regularizer=reg), expect, rtol=1e-9)
+
+
 def test_energy_only_and_forces_only_modes_agree():
     atoms, basis = synthetic.config_c2()
     fz = process.BasisFeaturizer(basis)

@@ -42,6 +42,19 @@ class VarianceRecorder:
             self.n += n
         return self.mean, self.std, self.n
 
+    def update_with_components(self, df, keys=None):
+        """Force components spread over columns (default fx, fy, fz), rows holding NaN skipped (:55-67)."""
+        keys = ["fx", "fy", "fz"] if keys is None else keys
+        batch = []
+        for _, *components in df[keys].itertuples():
+            if any(component is np.nan for component in components):
+                continue
+            if np.ndim(components) > 1:
+                components = list(np.concatenate(components))
+            batch.extend(components)
+        self.update(batch)
+        return self.mean, self.std, self.n
+
 
 def moments(y):
     """(n, sum, sum of squares): the additive form of VarianceRecorder, for reductions."""
@@ -265,6 +278,72 @@ class WeightedLinearModel(BasicLinearModel):
         n = self.n_feats - len(self.col_idx)
         return np.zeros((n, n)), np.zeros((n, n)), np.zeros(n), np.zeros(n)
 
+    # -- feature tables (the from-file workflow, least_squares.py:355-526) ------------------
+    def gram_from_df(self, df, keys, e_variance=None, f_variance=None, sample_weights=None, energy_key="energy",
+                     batch_size=2500):
+        """(gram_e, gram_f, ordinate_e, ordinate_f) of the rows of ``keys`` in one feature table (:435-483); the
+        products run on the GPU (``uf3_gram``), ``batch_size`` is accepted for signature parity only."""
+        x_e, y_e, x_f, y_f = dataframe_to_tuples(df.loc[keys], n_elements=len(self.bspline_config.element_list),
+                                                 energy_key=energy_key, sample_weights=sample_weights)
+        x_e, y_e = freeze_columns(x_e, y_e, self.mask, self.frozen_c, self.col_idx)
+        x_f, y_f = freeze_columns(x_f, y_f, self.mask, self.frozen_c, self.col_idx)
+        if e_variance is not None and f_variance is not None:
+            e_variance.update(y_e)
+            f_variance.update(y_f)
+        gram_e, ord_e = gram_device(x_e, y_e)
+        gram_f, ord_f = gram_device(x_f, y_f)
+        return gram_e, gram_f, ord_e, ord_f
+
+    def fit_from_tables(self, tables, subset, weight=0.5, batch_size=2500, sample_weights=None, energy_key="energy",
+                        drop_columns=None):
+        """The accumulation loop of ``fit_from_file`` (:386-424) over any iterable of feature tables
+        (DataFrames as ``BasisFeaturizer.evaluate`` returns them): Gram pieces summed table by table, energy /
+        force weights from the streamed target statistics, one solve."""
+        gram_e, gram_f, ord_e, ord_f = self.initialize_gram_ordinate()
+        e_variance, f_variance = VarianceRecorder(), VarianceRecorder()
+        for df in tables:
+            keys = df.index.unique(level=0).intersection(subset)
+            if len(keys) == 0:
+                continue
+            if drop_columns is not None:
+                df = df.drop(columns=drop_columns)
+            g_e, g_f, o_e, o_f = self.gram_from_df(df, keys, e_variance=e_variance, f_variance=f_variance,
+                                                   sample_weights=sample_weights, energy_key=energy_key,
+                                                   batch_size=batch_size)
+            gram_e += g_e
+            gram_f += g_f
+            ord_e += o_e
+            ord_f += o_f
+        w_e, w_f = calc_E_F_weights(e_variance.n, f_variance.n, e_variance.std, f_variance.std)
+        gram, ordinate = self.combine_weighted_gram(gram_e, gram_f, ord_e, ord_f, w_e, w_f, weight)
+        self.fit_with_gram(gram, ordinate)
+
+    def fit_from_file(self, filename, subset, weight=0.5, batch_size=2500, sample_weights=None, energy_key="energy",
+                      progress="bar", drop_columns=None):
+        """``fit_from_tables`` over the tables of an HDF5 feature file written by the reference's
+        ``batched_to_hdf`` (:355-424).  Reading goes through ``pandas.read_hdf`` and therefore needs PyTables, which
+        the build image lacks: this wrapper is not exercised by the tests (the loop it delegates to is)."""
+        import os
+        if not os.path.isfile(filename):
+            raise FileNotFoundError(filename)
+        names = hdf_table_names(filename)
+        self.fit_from_tables((pd_read_hdf(filename, name) for name in names), subset, weight=weight,
+                             batch_size=batch_size, sample_weights=sample_weights, energy_key=energy_key,
+                             drop_columns=drop_columns)
+
+    def batched_predict(self, filename=None, keys=None, table_names=None, score=True, drop_columns=None, tables=None):
+        """Targets and predictions over the tables of a feature file (:485-526), or over ``tables`` (an iterable
+        of DataFrames) when given."""
+        y_e, p_e, y_f, p_f = batched_prediction(self, filename, table_names=table_names, subset_keys=keys,
+                                                drop_columns=drop_columns, tables=tables,
+                                                n_elements=len(self.bspline_config.element_list))
+        if score:
+            rmse_e, rmse_f = rmse_metric(y_e, p_e), rmse_metric(y_f, p_f)
+            print(f"RMSE (energy): {rmse_e:.3F}")
+            print(f"RMSE (forces): {rmse_f:.3F}")
+            return y_e, p_e, y_f, p_f, rmse_e, rmse_f
+        return y_e, p_e, y_f, p_f
+
     # -- model files ------------------------------------------------------------------
     def load(self, solution=None, filename=None):
         """Flatten a per-interaction coefficient dict (3-body given as full grids) into ``coefficients``."""
@@ -351,3 +430,71 @@ def subset_prediction(df, model, subset_keys=None, **kwargs):
     x_e, y_e, x_f, y_f = dataframe_to_tuples(df, **kwargs)
     return y_e, model.predict(x_e), y_f, model.predict(x_f)
 
+
+
+def hdf_table_names(filename):
+    """Sorted names of the top-level tables of an HDF5 feature file (io.py:943-956); needs PyTables."""
+    import pandas as pd
+    with pd.HDFStore(filename, mode="r") as store:
+        return sorted(key.lstrip("/").split("/")[0] for key in store.keys())
+
+
+def pd_read_hdf(filename, table_name):
+    import pandas as pd
+    return pd.read_hdf(filename, table_name)
+
+
+def batched_prediction(model, filename=None, table_names=None, subset_keys=None, drop_columns=None, tables=None,
+                       **kwargs):
+    """``subset_prediction`` table by table, concatenated (least_squares.py:965-1014); ``tables``: DataFrames
+    instead of a file."""
+    if tables is None:
+        if table_names is None:
+            table_names = hdf_table_names(filename)
+        tables = (pd_read_hdf(filename, name) for name in table_names)
+    parts = ([], [], [], [])
+    for df in tables:
+        if drop_columns is not None:
+            df = df.drop(columns=drop_columns)
+        for dst, piece in zip(parts, subset_prediction(df, model, subset_keys=subset_keys, **kwargs)):
+            dst.append(piece)
+    return tuple(np.concatenate(p) for p in parts)
+
+
+def linear_least_squares(x, y):
+    """Unregularised solve through the normal equations (least_squares.py:774-787); products on the GPU."""
+    gram, ordinate = gram_device(x, y)
+    return lu_factorization(gram, ordinate)
+
+
+def apply_weights(x, y, weights):
+    """Rows and targets scaled by sqrt(weight) (least_squares.py:899-913)."""
+    x, y = np.asarray(x, dtype=float), np.asarray(y, dtype=float)
+    if weights is None:
+        return x, y
+    weights = np.asarray(weights, dtype=float)
+    if len(weights) != len(x) or np.any(weights < 0):
+        raise ValueError("Weights must be non-negative, one per sample.")
+    w = np.sqrt(weights)
+    return x * w[:, None], y * w
+
+
+def weighted_least_squares(x, y, weights=None, regularizer=None):
+    """Weighted, optionally regularised solve (least_squares.py:790-814)."""
+    x, y = apply_weights(x, y, weights)
+    gram, ordinate = gram_device(x, y)
+    if regularizer is not None:
+        regularizer = np.asarray(regularizer, dtype=float)
+        gram = gram + regularizer.T @ regularizer
+    return lu_factorization(gram, ordinate)
+
+
+def validate_regularizer(regularizer, n_feats):
+    """Shape check of a user-supplied penalty matrix (least_squares.py:916-930)."""
+    n_row, n_col = np.shape(regularizer)
+    if n_col != n_feats:
+        raise ValueError(f"Expected regularizer shape: N x {n_feats}. Provided: {n_row} x {n_col}")
+
+
+def apply_weighted_gram(gram_matrix, weight):
+    return gram_matrix * weight ** 2
