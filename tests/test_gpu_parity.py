@@ -342,6 +342,44 @@ def test_evaluate_dataframe_surface():
     assert len(p_e) == 1 and len(p_f) == 9 and np.all(np.isfinite(p_e)) and np.all(np.isfinite(p_f))
 
 
+def test_batched_evaluate_equals_frame_by_frame_evaluation():
+    """``evaluate`` batches the frames of a table; rows, order and skip rules must be those of the reference's
+    frame-by-frame loop over ``evaluate_configuration`` (process.py:121-194, 293-367)."""
+    import pandas as pd
+    basis = synthetic.notebook_basis(['Mo', 'W'])
+    fz = process.BasisFeaturizer(basis)
+    rng = np.random.default_rng(8)
+    geoms = [synthetic.lattice_frame("bcc", (2, 2, 2), 3.165, [42, 74], seed=1),
+             synthetic.lattice_frame("bcc", (2, 3, 2), 3.2, [42, 74], seed=2),
+             Atoms('W2Mo', positions=[[0, 0, 0], [2.6, 0, 0], [0, 2.8, 0.3]]),                  # cluster
+             synthetic.lattice_frame("bcc", (2, 2, 2), 3.165, [29], seed=3),                     # Cu: not in the basis
+             synthetic.lattice_frame("bcc", (3, 2, 2), 3.1, [74], seed=4)]
+    fcols = {c: [] for c in ('fx', 'fy', 'fz')}
+    for k, g in enumerate(geoms):
+        for c in fcols:
+            f = rng.normal(0, 1, len(g))
+            if k == 1:
+                f[0] = np.nan                                                                    # forces unusable
+            fcols[c].append(f.tolist())
+    df = pd.DataFrame(dict(geometry=geoms, energy=[-10.0, -20.0, -1.0, -5.0, -30.0], **fcols),
+                      index=["a", "b", "c", "d", "e"])
+    with pytest.warns(RuntimeWarning, match="Invalid elements"):
+        got = fz.evaluate(df, progress=False)
+    expect = {}
+    with pytest.warns(RuntimeWarning):
+        for name, row in df.iterrows():
+            forces = [row[c] for c in ('fx', 'fy', 'fz')]
+            forces = None if np.any(np.isnan(np.asarray(forces, dtype=float))) else forces
+            expect.update(fz.evaluate_configuration(row["geometry"], name, row["energy"], forces, "energy"))
+    expect = fz.arrange_features_dataframe(expect)
+    assert list(got.index) == list(expect.index) and list(got.columns) == list(expect.columns)
+    assert ("d", "energy") not in got.index and ("b", "fx_0") not in got.index and ("b", "energy") in got.index
+    assert np.array_equal(got["y"].to_numpy(), expect["y"].to_numpy())
+    assert rel_err(got.to_numpy(), expect.to_numpy()) < 1e-13
+    with pytest.warns(RuntimeWarning):
+        assert len(fz.evaluate(df.iloc[[3]], progress=False)) == 0
+
+
 def _table_fit_case():
     import pandas as pd
     t = np.load(os.path.join(GOLDEN, "table_fit.npz"), allow_pickle=False)
