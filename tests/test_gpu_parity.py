@@ -380,6 +380,27 @@ def test_batched_evaluate_equals_frame_by_frame_evaluation():
         assert len(fz.evaluate(df.iloc[[3]], progress=False)) == 0
 
 
+def test_results_are_bitwise_repeatable():
+    """No run-to-run drift: force rows, energies, forces and virials come out bit-identical on repeated calls, also
+    when calls on frames of other sizes come in between (one wave owns an atom's sums; the evaluator's LDS adds keep
+    their order).  Energy rows go through global atomics across workgroups: compared to 1e-13."""
+    basis = synthetic.notebook_basis(['Mo', 'W'])
+    model = ls.WeightedLinearModel(basis)
+    coeff = np.random.default_rng(1).normal(0, 0.05, basis.n_feats)
+    coeff[basis.col_idx] = 0.0
+    model.coefficients = coeff
+    calc, fz = calculator.UFCalculator(model), process.BasisFeaturizer(basis)
+    frames = [synthetic.lattice_frame("bcc", r, a, [42, 74], seed=k) for k, (r, a) in
+              enumerate((((3, 3, 3), 3.165), ((6, 5, 4), 3.0), ((2, 2, 2), 3.3)))]
+    first = [(calc.evaluate_frames([f], virial=True), fz.featurize_frames([f])) for f in frames]
+    for it in range(12):
+        k = it % 3
+        (e, f, _, v), (x_e, x_f, _) = calc.evaluate_frames([frames[k]], virial=True), fz.featurize_frames([frames[k]])
+        (e0, f0, _, v0), (x_e0, x_f0, _) = first[k]
+        assert np.array_equal(e, e0) and np.array_equal(f, f0) and np.array_equal(v, v0)
+        assert np.array_equal(x_f, x_f0) and rel_err(x_e, x_e0) < 1e-13
+
+
 def _table_fit_case():
     import pandas as pd
     t = np.load(os.path.join(GOLDEN, "table_fit.npz"), allow_pickle=False)
