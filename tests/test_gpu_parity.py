@@ -499,6 +499,16 @@ def test_atom_range_shares_add_up_to_the_frame():
     finally:
         del os.environ["UF3_EVAL_GATHER"]
     assert e_g[0] == e[0] and np.array_equal(v_g, v) and rel_err(f_g, f) < 1e-12
+    os.environ["UF3_SEPARATE_N3"] = "1"                                       # lists from k_build_n3 instead of the
+    try:                                                                      # centre pass's own walk: same lists
+        e_s, f_s, _, v_s = calc.evaluate_frames([atoms], virial=True)
+        big = [atoms] * 40                                                    # results > the pinned-staging limit:
+        e_b, f_b, off_b = calc.evaluate_frames(big)                           # the non-deferred flag check
+    finally:
+        del os.environ["UF3_SEPARATE_N3"]
+    assert np.array_equal(e_s, e) and np.array_equal(f_s, f) and np.array_equal(v_s, v)
+    e_b2, f_b2, _ = calc.evaluate_frames(big)
+    assert np.array_equal(e_b, e_b2) and np.array_equal(f_b, f_b2) and np.array_equal(f_b[off_b[7]:off_b[8]], f)
     for r, (_, fs, _) in enumerate(shares):
         lo, hi = parallel.shard_range(n, r, world)
         assert np.array_equal(fs[lo:hi], f_g[lo:hi])

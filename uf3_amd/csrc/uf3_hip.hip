@@ -913,8 +913,16 @@ static int eval_impl(uf3_basis *b, const uf3_frames *fr, const double *d_pos, co
     uf3_ctx *c = b->ctx;
     if (!d_pos || !d_z || !c1 || !d_energies) return fail(c, UF3_EINVAL, "uf3_eval: null argument");
     if ((b->c2_len && !c2) || (b->c3_len && !c3)) return fail(c, UF3_EINVAL, "uf3_eval: missing coefficients");
+    // whole batch with forces and 3-body terms: every triplet once, at its centre, + a collection pass; a block of
+    // atoms (its neighbours' centres may lie outside the block): every atom walks the triplets it belongs to.
+    // Two-pass route, list capacity known: the centre pass builds each atom's 3-body list from the candidates of
+    // its own pair walk (no k_build_n3 launch, one neighbourhood scan less).
+    const int64_t total = (fr && fr->atom_offsets && fr->n_frames >= 1) ? fr->atom_offsets[fr->n_frames] : -1;
+    const bool whole = atom_begin == 0 && (atom_end < 0 || atom_end == total);
+    const bool two_pass = whole && d_forces && b->host.T > 0 && !getenv("UF3_EVAL_GATHER");
+    const bool fuse = two_pass && c->n3_tuned && c->n3_cap > 0 && !getenv("UF3_SEPARATE_N3");
     Prepared P;
-    int rc = prepare(b, fr, d_pos, d_z, true, P, deferred_cap != nullptr);
+    int rc = prepare(b, fr, d_pos, d_z, !fuse, P, deferred_cap != nullptr);
     if (rc) return rc;
     if (deferred_cap) *deferred_cap = P.deferred ? P.n3.cap : 0;
     hipStream_t st = c->stream;
@@ -949,23 +957,45 @@ static int eval_impl(uf3_basis *b, const uf3_frames *fr, const double *d_pos, co
     A.e_atom = c->e_atom.as<double>(); A.forces = d_forces; A.natoms = P.natoms;
     A.atom_lo = (int)atom_begin; A.atom_hi = (int)atom_end;
     A.virial = d_virials ? A.e_atom + P.natoms : nullptr;
-    size_t lds = (size_t)A.n3.cap * 32 + ((size_t)5 * A.n3.cap + 2) * 4 + 16 + 2 * WAVE * EVAL_Q * sizeof(double) +
-                 (size_t)A.n3.cap * 24;
-    // whole batch with forces and 3-body terms: every triplet once, at its centre, + a collection pass; a block of
-    // atoms (its neighbours' centres may lie outside the block): every atom walks the triplets it belongs to
-    const bool two_pass = !partial && d_forces && b->host.T > 0 && !getenv("UF3_EVAL_GATHER");
-    if (two_pass) {
-        HIPCHK(c, c->nbr_f.ensure(24 * (size_t)P.natoms * A.n3.cap));
-        A.nbr_f = c->nbr_f.as<double>();
-    } else A.nbr_f = nullptr;
+    A.nbr_f = nullptr; A.n3_need = nullptr; A.fuse_n3 = 0;
     {
         Timed tm(c, T_EVAL);
-        if (two_pass) {
-            hipLaunchKernelGGL(k_eval<false>, dim3((unsigned)P.natoms), dim3(64), lds, st, A);
-            hipLaunchKernelGGL(k_eval_collect, dim3((unsigned)((P.natoms + 15) / 16)), dim3(256), 0, st, A);
-        } else if (atom_end > atom_begin)
-            hipLaunchKernelGGL(k_eval<true>, dim3((unsigned)(atom_end - atom_begin)), dim3(64), lds, st, A);
-        hipLaunchKernelGGL(k_frame_sum, dim3(P.n_frames, d_virials ? 7 : 1), dim3(256), 0, st, A.e_atom, A.virial,
+        for (int attempt = 0; ; attempt++) {
+            if (fuse) {
+                rc = n3_alloc(c, P.natoms, c->n3_cap, A.n3);
+                if (rc) return rc;
+                A.fuse_n3 = 1;
+                A.n3_need = c->flags.as<int>() + 1;
+                HIPCHK(c, hipMemsetAsync(A.n3_need, 0, sizeof(int), st));
+            }
+            const size_t cap = (size_t)A.n3.cap;
+            // own list (32 + 20 B per entry), queue of bonds, force on the entries (24), walk-order entries + keys (48)
+            const size_t lds = cap * 32 + (5 * cap + 2) * 4 + 16 + 2 * WAVE * EVAL_Q * sizeof(double) + cap * 24 + cap * 48;
+            if ((int)lds > c->lds_max) return fail(c, UF3_EOVERFLOW, "3-body neighbour list does not fit in LDS");
+            if (two_pass) {
+                HIPCHK(c, c->nbr_f.ensure(24 * (size_t)P.natoms * cap));
+                A.nbr_f = c->nbr_f.as<double>();
+                hipLaunchKernelGGL(k_eval<false>, dim3((unsigned)P.natoms), dim3(64), lds, st, A);
+                if (fuse && !deferred_cap) {             // the lists are part of this launch: did they fit?
+                    int fl[4] = {0, 0, 0, 0};
+                    HIPCHK(c, hipMemcpyAsync(fl, c->flags.p, sizeof(fl), hipMemcpyDeviceToHost, st));
+                    HIPCHK(c, hipStreamSynchronize(st));
+                    if (fl[0]) return check_flags(c);
+                    if (fl[1] > (int)cap) {
+                        if (attempt >= 5) return fail(c, UF3_EOVERFLOW, "3-body neighbour capacity did not converge");
+                        c->n3_cap = (fl[1] + 8 + 7) / 8 * 8;
+                        continue;
+                    }
+                }
+                if (fuse && deferred_cap) *deferred_cap = (int)cap;
+                hipLaunchKernelGGL(k_eval_collect, dim3((unsigned)((P.natoms + 15) / 16)), dim3(256), 0, st, A);
+            } else if (atom_end > atom_begin)
+                hipLaunchKernelGGL(k_eval<true>, dim3((unsigned)(atom_end - atom_begin)), dim3(64), lds, st, A);
+            break;
+        }
+        // (one workgroup per frame and component: wide for big frames, the loop is a latency chain)
+        const int sum_threads = P.natoms / P.n_frames >= 2048 ? 1024 : 256;
+        hipLaunchKernelGGL(k_frame_sum, dim3(P.n_frames, d_virials ? 7 : 1), dim3(sum_threads), 0, st, A.e_atom, A.virial,
                            P.d_offsets, d_energies, d_virials);
     }
     HIPCHK(c, hipGetLastError());

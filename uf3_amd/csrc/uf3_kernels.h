@@ -1238,6 +1238,8 @@ struct EvalArgs {
     double *forces;               // [natoms][3] or null
     double *virial;               // [natoms][6] dE/d(strain) shares (xx,yy,zz,yz,xz,xy) or null
     double *nbr_f;                // [natoms * cap][3] force each centre's triplets put on its list entries (two-pass route)
+    int *n3_need;                 // fused list build: longest list seen when one overflowed `cap`
+    int fuse_n3;                  // !GATHER: build the atom's 3-body list from the candidates of the pair walk
     int natoms;
     int atom_lo;                  // first atom of this launch (blocks cover [atom_lo, natoms_end))
     int atom_hi;
@@ -1298,6 +1300,12 @@ k_eval(EvalArgs A) {
         *ooff = ospec + cap;
     double *queue = (double *)(ooff + cap + 1 + ((cap + 1) & 1));          // [128][EVAL_Q]: dx, dy, dz, d, species
     double *gx = queue + 2 * WAVE * EVAL_Q, *gy = gx + cap, *gz = gy + cap;  // !GATHER: force on the list entries
+    // fused list build: entries in walk order (sorted into ox.. afterwards) and their (species, supercell index) keys
+    double *ux = gz + cap, *uy = ux + cap, *uz = uy + cap, *ur = uz + cap;
+    unsigned long long *ukey = (unsigned long long *)(ur + cap);
+    int *uparent = (int *)(ukey + cap), *ushift = uparent + cap;
+    const bool fuse = !GATHER && A.fuse_n3;
+    int count3 = 0;
     int m = A.atom_lo + blockIdx.x;
     if (m >= A.atom_hi) return;
     int lane = lane_id();
@@ -1311,6 +1319,7 @@ k_eval(EvalArgs A) {
     // 2-body: bonds inside their pair's range are queued in LDS and evaluated 64 at a time (about one candidate in
     // five survives the range test: evaluating in place would leave most lanes idle in the spline code)
     int queued = 0;
+    const double rmin3 = B->rmin3, rmax3 = B->rmax3;
     auto drain = [&](int count) {
         const double *c = queue + (size_t)lane * EVAL_Q;
         if (lane < count) {
@@ -1337,12 +1346,27 @@ k_eval(EvalArgs A) {
     };
     for_each_candidate(g, A.cl, m, [&](bool ok, const SlotRec &sr, int sj, int s0, int s1, int s2) {
         double dx = 0, dy = 0, dz = 0, d = 0;
+        bool ok3 = false;
         if (ok) {
             const PairDev &pd = B->pairs[B->pair_of[sm * UF3_MAX_SPECIES + sj]];
             const double rmin = pd.rmin, rmax = pd.rmax;
             image_delta(g, sr, s0, s1, s2, pm, dx, dy, dz);
             d = norm3_rn(dx, dy, dz);
+            ok3 = fuse & (d > rmin3) & (d <= rmax3);                 // angles.py:340: lower strict, upper inclusive
             ok = (d > rmin) & (d < rmax);
+        }
+        if (fuse) {
+            const unsigned long long mask3 = __ballot(ok3);
+            if (ok3) {
+                const int slot = count3 + mbcnt(mask3);
+                if (slot < cap) {
+                    const int sidx = supercell_index(g, s0, s1, s2, sr.atom - g.atom_lo);
+                    ux[slot] = dx; uy[slot] = dy; uz[slot] = dz; ur[slot] = d;
+                    uparent[slot] = sr.atom; ushift[slot] = pack3(s0, s1, s2);
+                    ukey[slot] = ((unsigned long long)sj << 32) | (unsigned)sidx;
+                }
+            }
+            count3 += __popcll(mask3);
         }
         const unsigned long long mask = __ballot(ok);
         if (ok) {
@@ -1367,13 +1391,35 @@ k_eval(EvalArgs A) {
     });
     drain(queued);
     if (B->T > 0) {
-        int n = A.n3.cnt[m];
         size_t base = (size_t)m * cap;
-        for (int q = lane; q < n; q += WAVE) {
-            const N3Entry en = A.n3.ent[base + q];
-            ox[q] = en.dx; oy[q] = en.dy; oz[q] = en.dz; orr[q] = en.r;
-            oparent[q] = en.parent; oshift[q] = en.shiftc; osidx[q] = en.sidx; ospec[q] = en.spec;
-            if (!GATHER) { gx[q] = 0.0; gy[q] = 0.0; gz[q] = 0.0; }
+        int n;
+        if (fuse) {
+            // the list of this atom from the walk above, rank-sorted by (species, supercell index) like k_build_n3's:
+            // into LDS for the loops below and into the batch's list array for k_eval_collect
+            __syncthreads();
+            if (count3 > cap) { if (lane == 0) atomicMax(A.n3_need, count3); count3 = cap; }
+            n = count3;
+            if (lane == 0) A.n3.cnt[m] = n;
+            for (int q = lane; q < n; q += WAVE) {
+                const unsigned long long k = ukey[q];
+                int rank = 0;
+                for (int f = 0; f < n; f++) rank += ukey[f] < k;
+                N3Entry en;
+                en.dx = ux[q]; en.dy = uy[q]; en.dz = uz[q]; en.r = ur[q];
+                en.parent = uparent[q]; en.shiftc = ushift[q]; en.sidx = (int)(unsigned)k; en.spec = (int)(k >> 32);
+                A.n3.ent[base + rank] = en;
+                ox[rank] = en.dx; oy[rank] = en.dy; oz[rank] = en.dz; orr[rank] = en.r;
+                oparent[rank] = en.parent; oshift[rank] = en.shiftc; osidx[rank] = en.sidx; ospec[rank] = en.spec;
+                gx[rank] = 0.0; gy[rank] = 0.0; gz[rank] = 0.0;
+            }
+        } else {
+            n = A.n3.cnt[m];
+            for (int q = lane; q < n; q += WAVE) {
+                const N3Entry en = A.n3.ent[base + q];
+                ox[q] = en.dx; oy[q] = en.dy; oz[q] = en.dz; orr[q] = en.r;
+                oparent[q] = en.parent; oshift[q] = en.shiftc; osidx[q] = en.sidx; ospec[q] = en.spec;
+                if (!GATHER) { gx[q] = 0.0; gy[q] = 0.0; gz[q] = 0.0; }
+            }
         }
         __syncthreads();
         int n_pairs = n * (n - 1) / 2;
@@ -1503,7 +1549,7 @@ k_eval_collect(EvalArgs A) {
 // given); deterministic tree
 __global__ void k_frame_sum(const double *e_atom, const double *v_atom, const int64_t *atom_offsets, double *e_out,
                             double *v_out) {
-    __shared__ double part[256];
+    __shared__ double part[1024];
     const int f = blockIdx.x, comp = (int)blockIdx.y - 1;
     const double *src = comp < 0 ? e_atom : v_atom + comp;
     const int width = comp < 0 ? 1 : 6;
