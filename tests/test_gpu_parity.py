@@ -545,6 +545,31 @@ def test_evaluator_list_capacity_regrows_between_calls():
     assert abs(e[0] - e_ref) <= 1e-10 * abs(e_ref) and rel_err(f, f_ref) < 1e-10
 
 
+def test_evaluator_list_capacity_regrows_in_big_batches():
+    """Same as above for batches whose results do not go through the pinned staging block (the flags are then read
+    at the end of the launch sequence and the whole sequence repeated), on a fresh context so that the remembered
+    capacity is the small one of the first call."""
+    saved = dict(_lib._contexts)
+    _lib._contexts.clear()
+    try:
+        basis = synthetic.notebook_basis(['W'])
+        model = ls.WeightedLinearModel(basis)
+        coeff = np.random.default_rng(9).normal(0, 0.05, basis.n_feats)
+        coeff[basis.col_idx] = 0.0
+        model.coefficients = coeff
+        calc = calculator.UFCalculator(model)
+        calc.evaluate_frames([synthetic.lattice_frame("bcc", (3, 3, 4), 3.6, [74], seed=1)])     # tunes a small capacity
+        dense = [synthetic.lattice_frame("bcc", (3, 3, 4), 2.6, [74], seed=100 + k) for k in range(320)]
+        e, f, off = calc.evaluate_frames(dense)                     # 23 040 atoms: 553 KB of forces
+        ob = O.OracleBasis(basis)
+        for k in (0, 319):
+            e_ref, f_ref = O.evaluate(ob, dense[k], coeff)
+            assert abs(e[k] - e_ref) <= 1e-10 * abs(e_ref) and rel_err(f[off[k]:off[k + 1]], f_ref) < 1e-10
+    finally:
+        _lib._contexts.clear()
+        _lib._contexts.update(saved)
+
+
 def test_featurize_frames_into_caller_buffers():
     atoms, basis = synthetic.config_c2()
     fz = process.BasisFeaturizer(basis)

@@ -976,27 +976,29 @@ static int eval_impl(uf3_basis *b, const uf3_frames *fr, const double *d_pos, co
                 HIPCHK(c, c->nbr_f.ensure(24 * (size_t)P.natoms * cap));
                 A.nbr_f = c->nbr_f.as<double>();
                 hipLaunchKernelGGL(k_eval<false>, dim3((unsigned)P.natoms), dim3(64), lds, st, A);
-                if (fuse && !deferred_cap) {             // the lists are part of this launch: did they fit?
-                    int fl[4] = {0, 0, 0, 0};
-                    HIPCHK(c, hipMemcpyAsync(fl, c->flags.p, sizeof(fl), hipMemcpyDeviceToHost, st));
-                    HIPCHK(c, hipStreamSynchronize(st));
-                    if (fl[0]) return check_flags(c);
-                    if (fl[1] > (int)cap) {
-                        if (attempt >= 5) return fail(c, UF3_EOVERFLOW, "3-body neighbour capacity did not converge");
-                        c->n3_cap = (fl[1] + 8 + 7) / 8 * 8;
-                        continue;
-                    }
-                }
                 if (fuse && deferred_cap) *deferred_cap = (int)cap;
                 hipLaunchKernelGGL(k_eval_collect, dim3((unsigned)((P.natoms + 15) / 16)), dim3(256), 0, st, A);
             } else if (atom_end > atom_begin)
                 hipLaunchKernelGGL(k_eval<true>, dim3((unsigned)(atom_end - atom_begin)), dim3(64), lds, st, A);
+            // (one workgroup per frame and component: wide for big frames, the loop is a latency chain)
+            const int sum_threads = P.natoms / P.n_frames >= 2048 ? 1024 : 256;
+            hipLaunchKernelGGL(k_frame_sum, dim3(P.n_frames, d_virials ? 7 : 1), dim3(sum_threads), 0, st, A.e_atom,
+                               A.virial, P.d_offsets, d_energies, d_virials);
+            if (fuse && !deferred_cap) {
+                // the lists were part of this launch: did they fit?  (Asked after everything is queued -- all kernels
+                // are safe on clipped lists -- so that the GPU does not idle while the host looks.)
+                int fl[4] = {0, 0, 0, 0};
+                HIPCHK(c, hipMemcpyAsync(fl, c->flags.p, sizeof(fl), hipMemcpyDeviceToHost, st));
+                HIPCHK(c, hipStreamSynchronize(st));
+                if (fl[0]) return check_flags(c);
+                if (fl[1] > (int)cap) {
+                    if (attempt >= 5) return fail(c, UF3_EOVERFLOW, "3-body neighbour capacity did not converge");
+                    c->n3_cap = (fl[1] + 8 + 7) / 8 * 8;
+                    continue;
+                }
+            }
             break;
         }
-        // (one workgroup per frame and component: wide for big frames, the loop is a latency chain)
-        const int sum_threads = P.natoms / P.n_frames >= 2048 ? 1024 : 256;
-        hipLaunchKernelGGL(k_frame_sum, dim3(P.n_frames, d_virials ? 7 : 1), dim3(sum_threads), 0, st, A.e_atom, A.virial,
-                           P.d_offsets, d_energies, d_virials);
     }
     HIPCHK(c, hipGetLastError());
     return UF3_OK;
