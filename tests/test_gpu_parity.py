@@ -570,6 +570,39 @@ def test_evaluator_list_capacity_regrows_in_big_batches():
         _lib._contexts.update(saved)
 
 
+def test_degenerate_frames_in_a_batch():
+    """Frames with nothing to do next to a normal one: a lone atom, two atoms beyond every cut-off, an empty frame.
+    Their energy rows hold the composition only, their force rows and forces are zero, and the normal frame is not
+    disturbed (its rows equal those of a batch of its own)."""
+    basis = synthetic.notebook_basis(['Mo', 'W'])
+    fz = process.BasisFeaturizer(basis)
+    big = 40.0 * np.eye(3)
+    lone = Atoms('W', positions=[[1.0, 2.0, 3.0]], cell=big, pbc=True)
+    apart = Atoms('MoW', positions=[[0, 0, 0], [15.0, 0, 0]], cell=big, pbc=True)
+    empty = Atoms(numbers=[], positions=np.zeros((0, 3)), cell=big, pbc=True)
+    normal = synthetic.lattice_frame("bcc", (2, 2, 3), 3.165, [42, 74], seed=6)
+    frames = [lone, apart, empty, normal, lone]
+    x_e, x_f, off = fz.featurize_frames(frames)
+    assert list(np.diff(off)) == [1, 2, 0, len(normal), 1]
+    expect = np.zeros((5, x_e.shape[1]))
+    expect[0, 1] = expect[4, 1] = 1.0                    # columns 0, 1: n_Mo, n_W
+    expect[1, 0] = expect[1, 1] = 1.0
+    x_e1, x_f1, _ = fz.featurize_frames([normal])
+    expect[3] = x_e1[0]
+    assert rel_err(x_e, expect) < 1e-13
+    assert not x_f[:3].any() and not x_f[-1:].any() and rel_err(x_f[off[3]:off[4]], x_f1) < 1e-13
+    model = ls.WeightedLinearModel(basis)
+    coeff = np.random.default_rng(2).normal(0, 0.05, basis.n_feats)
+    coeff[basis.col_idx] = 0.0
+    model.coefficients = coeff
+    calc = calculator.UFCalculator(model)
+    e, f, off_e, v = calc.evaluate_frames(frames, virial=True)
+    e1, f1, _, v1 = calc.evaluate_frames([normal], virial=True)
+    assert np.allclose(e, x_e @ coeff, rtol=1e-12, atol=1e-12) and e[2] == 0.0
+    assert not f[:3].any() and not f[-1:].any() and not v[:3].any()
+    assert rel_err(f[off_e[3]:off_e[4]], f1) < 1e-13 and rel_err(v[3], v1[0]) < 1e-13
+
+
 def test_featurize_frames_into_caller_buffers():
     atoms, basis = synthetic.config_c2()
     fz = process.BasisFeaturizer(basis)
