@@ -603,6 +603,43 @@ def test_degenerate_frames_in_a_batch():
     assert rel_err(f[off_e[3]:off_e[4]], f1) < 1e-13 and rel_err(v[3], v1[0]) < 1e-13
 
 
+def test_atoms_outside_the_cell():
+    """Positions are not wrapped by the reference (geometry.py:108-149 tiles them as given): an atom a few lattice
+    vectors away keeps only the neighbours the finite image range reaches.  Energy rows and 2-body force rows follow
+    the reference (oracle) in that.  The reference's 3-body FORCE rows additionally lose the terms of ghost-centred
+    triplets whose third atom its shrunken supercell does not hold, so they stop being the gradient of its own
+    energy row; the kernels keep those terms (known deviation): their rows are checked against
+    the numerical gradient of the energy row instead.  An atom hundreds of cells away is refused."""
+    basis = synthetic.notebook_basis(['W'])
+    fz = process.BasisFeaturizer(basis)
+    atoms = synthetic.lattice_frame("bcc", (2, 2, 2), 3.165, [74], seed=12)
+    pos = atoms.get_positions().copy()
+    cell = np.array(atoms.get_cell()).reshape(3, 3)
+    pos[3] += 1.0 * cell[0] - 2.0 * cell[2]
+    pos[7] -= 1.0 * cell[1]
+
+    def rows(p):
+        return fz.featurize_frames([Atoms(numbers=atoms.get_atomic_numbers(), positions=p, cell=cell, pbc=True)])
+
+    x_e, x_f, _ = rows(pos)
+    ref = O.featurize(O.OracleBasis(basis), Atoms(numbers=atoms.get_atomic_numbers(), positions=pos, cell=cell, pbc=True))
+    n2 = basis.n_feats - basis.partition_sizes[-1]                       # one-body + pair columns
+    assert rel_err(x_e[0], ref["xe"]) < TOL and rel_err(x_f[:, :, :n2], ref["xf"][:, :, :n2]) < TOL
+    h = 1e-5
+    for a in (0, 3, 7, 9):
+        for c in range(3):
+            up, dn = pos.copy(), pos.copy()
+            up[a, c] += h
+            dn[a, c] -= h
+            grad = -(rows(up)[0][0] - rows(dn)[0][0]) / (2 * h)
+            assert np.abs(grad - x_f[a, c]).max() < 1e-6 * np.abs(x_f).max(), (a, c)
+    far = pos.copy()
+    far[5] += 300.0 * cell[0]
+    with pytest.raises(RuntimeError, match="outside the periodic cell"):
+        rows(far)
+    assert rel_err(rows(pos)[1], x_f) < 1e-13                             # the context is usable afterwards
+
+
 def test_featurize_frames_into_caller_buffers():
     atoms, basis = synthetic.config_c2()
     fz = process.BasisFeaturizer(basis)
