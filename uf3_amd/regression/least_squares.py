@@ -43,16 +43,15 @@ class VarianceRecorder:
         return self.mean, self.std, self.n
 
     def update_with_components(self, df, keys=None):
-        """Force components spread over columns (default fx, fy, fz), rows holding NaN skipped (:55-67)."""
-        keys = ["fx", "fy", "fz"] if keys is None else keys
-        batch = []
-        for _, *components in df[keys].itertuples():
-            if any(component is np.nan for component in components):
+        """One update from force components spread over columns (default fx, fy, fz): every row contributes the
+        concatenation of its cells (scalars or per-atom lists); rows with a missing cell are left out (:55-67)."""
+        columns = ["fx", "fy", "fz"] if keys is None else list(keys)
+        values = []
+        for cells in df[columns].itertuples(index=False, name=None):
+            if any(cell is np.nan for cell in cells):
                 continue
-            if np.ndim(components) > 1:
-                components = list(np.concatenate(components))
-            batch.extend(components)
-        self.update(batch)
+            values.extend(np.ravel(np.concatenate([np.atleast_1d(cell) for cell in cells])).tolist())
+        self.update(values)
         return self.mean, self.std, self.n
 
 
