@@ -100,7 +100,7 @@ def main():
         for name, els in (("fit_accumulate_10k_W", ['W']), ("fit_accumulate_10k_WMo", ['Mo', 'W'])):
             basis = synthetic.notebook_basis(els)
             zs = [74] if els == ['W'] else [42, 74]
-            frames = [synthetic.lattice_frame("bcc", (10, 20, 25), 3.165, zs, 5000 + k) for k in range(16)]
+            frames = [synthetic.lattice_frame("bcc", (10, 20, 25), 3.165, zs, 5000 + k) for k in range(64)]
             rng = np.random.default_rng(3)
             energies = rng.normal(-8.9 * 10000, 5.0, len(frames))
             forces = [rng.normal(0, 0.5, (len(f), 3)) for f in frames]

@@ -18,7 +18,7 @@ from uf3_amd.regression import least_squares as ls
 
 
 class DeviceFitAccumulator:
-    def __init__(self, model, featurizer, device=None, max_atoms_per_chunk=80000):
+    def __init__(self, model, featurizer, device=None, max_atoms_per_chunk=320000):
         import torch
         self.torch = torch
         self.model, self.fz = model, featurizer
@@ -58,18 +58,22 @@ class DeviceFitAccumulator:
                    if forces is not None else None)
             self.fz.featurize_device(batch.struct, d_pos.data_ptr(), d_z.data_ptr(), x_e.data_ptr(),
                                      x_f.data_ptr() if x_f is not None else None)
-            n_atoms = x_e[:, :self.n_el].sum(dim=1)
-            x_e = (x_e / n_atoms[:, None]).contiguous()
-            y_e = torch.from_numpy(np.asarray(energies[start:stop], dtype=np.float64)).to(self.dev) / n_atoms
+            # per-atom normalisation of the energy rows and targets (least_squares.py:697-700); the atom counts are
+            # known on the host (= the sum of the composition columns), so nothing is read back inside the loop and
+            # the host packs the next chunk while this one is still on the GPU (one stream: buffers handed back to
+            # torch's allocator here are not reused before the kernels queued above have run)
+            counts = np.diff(batch.offsets).astype(np.float64)
+            y_e_host = np.asarray(energies[start:stop], dtype=np.float64) / counts
+            x_e = (x_e / torch.from_numpy(counts).to(self.dev)[:, None]).contiguous()
+            y_e = torch.from_numpy(y_e_host).to(self.dev)
             self._gram(x_e, y_e, self.gram_e, self.ord_e)
-            self.m_e += ls.moments(y_e.cpu().numpy())
+            self.m_e += ls.moments(y_e_host)
             if forces is not None:
                 y_host = np.concatenate([np.asarray(f, dtype=np.float64).reshape(-1, 3) for f in forces[start:stop]]).reshape(-1)
                 y_f = torch.from_numpy(y_host).to(self.dev)
                 self._gram(x_f, y_f, self.gram_f, self.ord_f)
                 self.m_f += ls.moments(y_host)
                 self.with_forces = True
-            torch.cuda.current_stream(self.dev).synchronize()      # buffers of this chunk are released next
             start = stop
 
     def pieces(self):
