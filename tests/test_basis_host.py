@@ -102,3 +102,22 @@ def test_regularizer_shapes():
     assert m3.shape == (24, 24) and np.all(m3.sum(axis=1) == 0)
     full = regularize.combine_regularizer_matrices([np.eye(2), np.ones((3, 4))])
     assert full.shape == (5, 6) and full[2:, 2:].sum() == 12
+
+
+def test_szudzik_hash_helpers_against_reference_values():
+    """literal values produced by the reference's composition.py (:252-376) in the build container"""
+    from uf3_amd.data import composition as cp
+    assert cp.symbols_to_hash(['W', 'W']) == 5624 and cp.symbols_to_hash(['Mo', 'W']) == 5592
+    assert cp.symbols_to_hash(['W', 'Mo', 'W']) == 30448398 and cp.symbols_to_hash(['H', 'O', 'O']) == 5337
+    assert cp.hash_to_symbols(5592, 2) == ('Mo', 'W') and cp.hash_to_symbols(30448398, 3) == ('W', 'Mo', 'W')
+    triples = np.array([[1, 8, 8], [74, 42, 74], [6, 1, 1]])
+    h = cp.get_szudzik_hash(triples)
+    assert h.tolist() == [5337, 30448398, 1370]
+    assert np.array_equal(cp.unpack_szudzik_hash(h, 3), triples.astype(float))
+    assert cp.szudzik_unpair(np.array([0, 1, 2, 3, 4, 5, 8, 9, 5550])).tolist() == [
+        [0, 0], [1, 0], [0, 1], [1, 1], [2, 0], [2, 1], [2, 2], [3, 0], [0, 74]]
+    rng = np.random.default_rng(0)
+    pairs = rng.integers(0, 119, (500, 2))
+    assert np.array_equal(cp.szudzik_unpair(cp.szudzik_pair(pairs)), pairs.astype(float))
+    gathered = cp.hash_gather(np.array([1.0, 2.0, 3.0, 4.0]), np.array([7, 3, 7, 3]))
+    assert list(gathered) == [3, 7] and gathered[7].tolist() == [1.0, 3.0] and gathered[3].tolist() == [2.0, 4.0]

@@ -67,6 +67,42 @@ def get_szudzik_hash(array):
     return h
 
 
+def szudzik_unpair(hash_list):
+    """Inverse of ``szudzik_pair`` (composition.py:272-290): with s = floor(sqrt(h)) and t = h - s^2,
+    (x, y) = (s, t) where t < s and (t - s, s) otherwise.  Returns an (n, 2) float array like the reference."""
+    h = np.asarray(hash_list)
+    s = np.sqrt(h).astype(int)
+    t = h - s * s
+    first = t < s
+    return np.stack([np.where(first, s, t - s), np.where(first, t, s)], axis=1).astype(float)
+
+
+def unpack_szudzik_hash(hash_list, n_iter):
+    """Undo the left fold of ``get_szudzik_hash``: n_iter columns per hash (composition.py:311-328)."""
+    rest = np.asarray(hash_list)
+    columns = []
+    for _ in range(n_iter - 1):
+        pair = szudzik_unpair(rest)
+        columns.append(pair[:, 1])
+        rest = pair[:, 0]
+    columns.append(rest)
+    return np.stack(columns[::-1], axis=1)
+
+
+def symbols_to_hash(symbols):
+    return get_szudzik_hash(np.array([[atomic_numbers[el] for el in symbols]]))[0]
+
+
+def hash_to_symbols(hash_, n=2):
+    return tuple(chemical_symbols[int(z)] for z in unpack_szudzik_hash([hash_], n)[0])
+
+
+def hash_gather(values, hashes):
+    """{hash: the values carrying it}, hashes ascending (composition.py:350-359)."""
+    values, hashes = np.asarray(values), np.asarray(hashes)
+    return {int(h): values[hashes == h] for h in np.unique(hashes)}
+
+
 def get_element_combinations(element_list, n=3):
     """(centre, n1<=n2, ...) tuples, centre-major, each unique tuple once."""
     elements = sort_elements([_symbol(e) for e in element_list])
