@@ -707,25 +707,29 @@ def _resolution_basis(res3, lead3=3, elements=('Mo', 'W')):
         leading_trim={2: 0, 3: lead3}, trailing_trim={2: 3, 3: 3})
 
 
-@pytest.mark.parametrize("which,bit", [("notebook_binary", 6), ("asymmetric_window", 6), ("h2o_golden", 6), ("w16_sym1", 6),
-                                       ("w16_sym3", 6), ("four_row_tiles", 8), ("eight_row_tiles", 9),
-                                       ("eight_row_tiles_unary", 9)])
+@pytest.mark.parametrize("which,bit", [("notebook_binary", 7), ("asymmetric_window", 9), ("h2o_golden", None), ("w16_sym1", None),
+                                       ("w16_sym3", None), ("default_resolution", 6), ("four_by_four", 8), ("six_by_six", 9),
+                                       ("five_by_five_unary", 9)])
 def test_matrix_core_and_generic_trio_kernels_agree(which, bit):
-    """The fp64 MFMA specialisations (mode bits 6 / 8 / 9: two / four / eight 16-row tiles) against the
-    output-stationary kernels on the same inputs, and both against the oracle."""
+    """The fp64 MFMA specialisations (mode bits 6 / 7 / 8 / 9: windows of (row tiles, column tiles) = (1,1), (1,2),
+    (1,<=4), (<=2,<=6) with rows (component, l) and columns (m, n)) against the output-stationary kernels on the same
+    inputs, and both against the oracle."""
     if which == "notebook_binary":
         frames = [synthetic.lattice_frame("bcc", (3, 3, 4), 3.165, [42, 74], 11 + k) for k in range(2)]
         basis = synthetic.notebook_basis(['Mo', 'W'])
     elif which == "asymmetric_window":
         frames = [synthetic.lattice_frame("bcc", (3, 4, 3), 3.2, [42, 74], 5, rattle=0.12)]
         basis = _asymmetric_window_basis()
-    elif which == "four_row_tiles":            # 4 x 4 x 11 kept bins: 48 rows
+    elif which == "default_resolution":        # 2 x 2 x 7 kept bins (the reference's default 3-body resolution [5, 5, 10])
+        frames = [synthetic.lattice_frame("bcc", (3, 3, 4), 3.165, [42, 74], 30, rattle=0.1)]
+        basis = _resolution_basis([5, 5, 10])
+    elif which == "four_by_four":              # 4 x 4 x 11 kept bins: 16 rows, 44 columns
         frames = [synthetic.lattice_frame("bcc", (3, 3, 4), 3.165, [42, 74], 31, rattle=0.1)]
         basis = _resolution_basis([7, 7, 14])
-    elif which == "eight_row_tiles":           # 6 x 6 x 12 kept bins (no leading trim): 108 rows, 3 energy tiles
+    elif which == "six_by_six":                # 6 x 6 x 12 kept bins (no leading trim): 24 rows, 72 columns
         frames = [synthetic.lattice_frame("bcc", (3, 4, 3), 3.165, [42, 74], 32, rattle=0.1)]
         basis = synthetic.notebook_basis(['Mo', 'W'], lead3=0)
-    elif which == "eight_row_tiles_unary":     # 5 x 5 x 13 kept bins, symmetry 2 fold
+    elif which == "five_by_five_unary":        # 5 x 5 x 13 kept bins, symmetry 2 fold: 20 rows, 65 columns
         frames = [synthetic.lattice_frame("bcc", (3, 3, 3), 3.165, [74], 33, rattle=0.1)]
         basis = _resolution_basis([8, 8, 16], elements=('W',))
     else:
@@ -737,8 +741,8 @@ def test_matrix_core_and_generic_trio_kernels_agree(which, bit):
         frames, basis = [atoms], basis_from_meta(meta)
     xe_m, xf_m, modes_m = _fresh_rows(basis, frames)
     xe_g, xf_g, modes_g = _fresh_rows(basis, frames, UF3_NO_MFMA_FEAT="1")
-    assert modes_m & (1 << bit), f"expected featurizer mode bit {bit} for this basis, got {modes_m:#x}"
-    assert not (modes_g & 0x340) and (modes_g & 0x3e)
+    assert modes_m & (0x3c0 if bit is None else 1 << bit), f"expected featurizer mode bit {bit} for this basis, got {modes_m:#x}"
+    assert not (modes_g & 0x3c0) and (modes_g & 0x3e)
     assert rel_err(xe_m, xe_g) < 1e-12 and rel_err(xf_m, xf_g) < 1e-12
     ob = O.OracleBasis(basis)
     off = 0
@@ -754,14 +758,15 @@ def test_matrix_core_and_generic_trio_kernels_agree(which, bit):
 
 
 def test_windows_too_wide_for_the_tiles_stay_on_generic_kernels():
-    """More than 16 kept n bins (or more than 128 rows): output-stationary kernels; default trims: matrix cores."""
+    """More than 96 (m, n) columns (or more than 32 (component, l) rows): output-stationary kernels; default trims:
+    matrix cores."""
     fz = process.BasisFeaturizer(_resolution_basis([6, 6, 20], lead3=0, elements=('W',)))     # 6 x 6 x 20 kept bins
     modes = fz._dev()[1].featurizer_modes
-    assert not (modes & 0x340) and (modes & 0x3e)
+    assert not (modes & 0x3c0) and (modes & 0x3e)
     atoms = synthetic.lattice_frame("bcc", (3, 3, 3), 3.165, [74], 35, rattle=0.1)
     _check_against_oracle(fz.bspline_config, [atoms])
-    # the reference's default trims (3 leading, 3 trailing) give 3 x 3 x 9: matrix cores, two row tiles
-    assert process.BasisFeaturizer(synthetic.config_c3()[1])._dev()[1].featurizer_modes & (1 << 6)
+    # the reference's default trims (3 leading, 3 trailing) give 3 x 3 x 9: matrix cores, one row tile x two column tiles
+    assert process.BasisFeaturizer(synthetic.config_c3()[1])._dev()[1].featurizer_modes & (1 << 7)
 
 
 def _lj_like_model():

@@ -1,0 +1,26 @@
+#!/bin/bash
+# Per-phase instruction budget of the matrix-core featurizer launch: PMC passes with UF3_DEBUG_SKIP ablations
+# (1 two-body, 2 centre role, 4 neighbour role, 8 MFMA steps, 16 leg evaluation + staging, 32 row stores).
+#     gpurun --timeout 900 -- 'bash tools/ablate_counters.sh gpurun_out/abl "0 8 16 24 6"'
+set -u
+RUN=${1:?output directory}; SKIPS=${2:-"0 8 16 24 6"}
+mkdir -p "$RUN"; export TMPDIR=/tmp UF3_BENCH_NOCHECK=1
+for s in $SKIPS; do
+  UF3_DEBUG_SKIP=$s timeout 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_MFMA SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAVE_CYCLES SQ_WAIT_INST_ANY \
+    -d $RUN/s$s -o p --output-format csv -- python bench.py --no-cpu-baseline --steps 2 --warmup 1 > $RUN/s$s.json 2>/dev/null
+done
+python - "$RUN" $SKIPS <<'PY'
+import csv, glob, sys, collections
+run, skips = sys.argv[1], sys.argv[2:]
+for s in skips:
+    acc = collections.defaultdict(float); n = collections.Counter()
+    for f in glob.glob(f"{run}/s{s}/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            k = r["Kernel_Name"]
+            if "k_featurize" not in k or ", 0>" in k: continue
+            acc[r["Counter_Name"]] += float(r["Counter_Value"]); n[r["Counter_Name"]] += 1
+    if not acc: print(s, "no data"); continue
+    launches = max(n.values())
+    per_atom = {k: v / launches / 320000 for k, v in acc.items()}
+    print(f"skip {s:>3}: " + "  ".join(f"{k[3:]} {per_atom[k]:.0f}" for k in sorted(per_atom)))
+PY

@@ -87,7 +87,8 @@ struct uf3_basis {
     std::vector<int> block_bounds;   // column boundaries of interaction blocks (for column windows)
     size_t c2_len = 0, c3_len = 0, n_recs = 0;
     size_t n_pair_recs = 0;
-    int dense_stride = 24;           // largest staged-record stride (doubles) among the dense trios
+    int dense_stride[16] = {0};      // per featurizer mode: largest staged-record stride (doubles) among its trios
+    int dense_dump[16] = {0};        // ... smallest stage (doubles) the fold of its widest window needs
     int modes = 1;                   // bit m set: some trio block is handled by featurizer specialisation m
     double r_cut = 0;
 };
@@ -351,20 +352,22 @@ extern "C" int uf3_basis_create(uf3_ctx *c, const uf3_basis_spec *s, uf3_basis *
         }
         td.dense = 0;
         for (int a = 0; a < 3; a++) { td.lo[a] = hi[a] < 0 ? 0 : lo[a]; td.ext[a] = hi[a] < 0 ? 1 : hi[a] - lo[a] + 1; }
-        // 16-row tiles the (c, l, m) rows of the window need: 2, 4 or 8 (wider windows stay on the generic kernels)
-        const int rows3 = 3 * td.ext[0] * td.ext[1];
-        const int tiles = rows3 <= 32 ? 2 : (rows3 <= 64 ? 4 : (rows3 <= 128 ? 8 : 0));
-        if (tiles && td.ext[2] <= 16 && !getenv("UF3_NO_MFMA_FEAT") && (tiles == 2 || !getenv("UF3_NO_WIDE_MFMA"))) {
-            td.dense = tiles;
-            DenseLayout dl = dense_layout(td.ext[0], td.ext[1], td.ext[2]);
-            b->dense_stride = std::max(b->dense_stride, dl.stride);
+        // rows (c, l) x columns (m, n) of the window in 16 x 16 tiles: (1,1) (1,2) (1,<=4) (<=2,<=6) have a matrix-core
+        // specialisation (modes 6-9); wider windows stay on the generic kernels
+        DenseLayout dl = dense_layout(td.ext[0], td.ext[1], td.ext[2]);
+        const int dmode = dense_mode_for(td.ext[0], td.ext[1], td.ext[2]);
+        if (dmode && !getenv("UF3_NO_MFMA_FEAT") && (dmode <= 7 || !getenv("UF3_NO_WIDE_MFMA"))) {
+            td.dense = dmode;
+            b->dense_stride[dmode] = std::max(b->dense_stride[dmode], dl.stride);
+            b->dense_dump[dmode] = std::max(b->dense_dump[dmode], td.ext[0] * dl.cw);
         }
-        b->modes |= 1 << (td.dense == 2 ? 6 : td.dense == 4 ? 8 : td.dense == 8 ? 9 : td.nsrc == 1 ? (td.ncol > WAVE ? 2 : 1) : (td.nsrc == 2 ? (td.ncol > WAVE ? 4 : 3) : 5));
+        b->modes |= 1 << (td.dense ? td.dense : td.nsrc == 1 ? (td.ncol > WAVE ? 2 : 1) : (td.nsrc == 2 ? (td.ncol > WAVE ? 4 : 3) : 5));
         for (auto &v : per_col) for (int k = 0; k < td.nsrc; k++) {
             int sp = k < (int)v.size() ? v[k] : -1;
             colsrc.push_back(sp);
+            // offset inside one component's dumped rows: row l (width cw), column (m, n)
             dsrc.push_back(sp < 0 || !td.dense ? -1
-                           : (((sp & 255) - td.lo[0]) * td.ext[1] + (((sp >> 8) & 255) - td.lo[1])) * 16 + (((sp >> 16) & 255) - td.lo[2]));
+                           : ((sp & 255) - td.lo[0]) * dl.cw + (((sp >> 8) & 255) - td.lo[1]) * td.ext[2] + (((sp >> 16) & 255) - td.lo[2]));
         }
     }
     std::sort(bounds.begin(), bounds.end());
@@ -695,7 +698,7 @@ static size_t feat_lds_bytes(int F, int S, int cap, int cand_cap, bool want_e, s
     size_t stage_d = mode == 0 ? cand_d + pair_buf_d
                      : (dense ? (size_t)dense_stage : (size_t)NSTAGE * ITEM_STRIDE);
     size_t list_d = mode == 0 ? 0 : 5 * (size_t)cap + ((5 * cap) & 1);
-    size_t geo_d = dense ? (size_t)3 * dense_nrec * GEO_STRIDE : 0;
+    size_t geo_d = dense ? (size_t)7 * GEO_N : 0;
     size_t per_wave_d = list_d + stage_d + (stage_d & 1) + geo_d;
     size_t per_wave_i = mode == 0 ? 0 : 3 * (size_t)cap + 2 * ((size_t)cap + 1) + (UF3_MAX_SPECIES + 2) +
                                         (size_t)cap * (S + 1);
@@ -727,9 +730,9 @@ extern "C" int uf3_featurize_dev(uf3_basis *b, const uf3_frames *fr, const doubl
     FeatArgs A;
     A.B = b->dev; A.trios = b->d_trios; A.recs = b->d_recs; A.colsrc = b->d_colsrc;
     A.frag = nullptr;
-    A.dense_stage = DENSE_DUMP; A.dense_nrec = DENSE_NREC;
+    A.dense_stage = 0; A.dense_nrec = DENSE_NREC;
     A.dsrc = b->d_dsrc; A.n_dsrc = (int)b->n_dsrc;
-    const int dense_modes = (1 << 6) | (1 << 8) | (1 << 9);
+    const int dense_modes = (1 << 6) | (1 << 7) | (1 << 8) | (1 << 9);
     const bool dsrc_ok = (b->modes & dense_modes) && b->n_dsrc * sizeof(int) <= 8192 && !getenv("UF3_NO_LDS_DSRC");
     A.dsrc_lds = dsrc_ok;
     if (b->modes & dense_modes) { rc = ensure_frag(c); if (rc) return rc; A.frag = c->frag.as<int>(); }
@@ -761,52 +764,51 @@ extern "C" int uf3_featurize_dev(uf3_basis *b, const uf3_frames *fr, const doubl
         {
             Timed tm(c, T_FEAT);
             for (int mode = 0; mode <= 9; mode++) {
-                if (mode == 7 || !(b->modes & (1 << mode))) continue;             // (7 = mode 6 at 3 waves/SIMD)
-                const bool dense_mode = mode == 6 || mode >= 8;
+                if (!(b->modes & (1 << mode))) continue;
+                const bool dense_mode = mode >= 6;
                 // knot records go to LDS when the block then still reaches the occupancy its registers allow
                 size_t n_rec_mode = mode == 0 ? b->n_pair_recs : b->n_recs;
                 const int S = b->host.S;
                 const size_t cu_lds = 160 * 1024 - 1024;
                 if (dense_mode) A.dsrc_lds = dsrc_ok;
                 size_t lds_extra = (dense_mode && A.dsrc_lds) ? sizeof(int) * b->n_dsrc : 0;
-                int launch_mode = mode;
                 bool recs_lds = false;
                 size_t lds = 0, lds_plain = 0, lds_recs = 0;
-                if (mode == 6) {
-                    // records per staging pass: as many as the stage allows; fewer (smaller stage and geometry
-                    // buffer) if that lets a third workgroup onto the CU -- the kernel is latency-bound
-                    const int nrec_max = std::max(4, std::min(DENSE_NREC, 1056 / b->dense_stride));
-                    const int tries[3] = {nrec_max, std::min(nrec_max, 18), std::min(nrec_max, 15)};
-                    // three workgroups per CU need <= 52 KB each (LDS is granted in coarse granules: 53 KB did not fit)
-                    const size_t budget = 52 * 1024;
-                    const bool dsrc_allowed = A.dsrc_lds;
-                    bool found = false;
-                    // candidates in order of preference: more records per pass first, tables in LDS before tables in HBM
-                    const bool recs_allowed = !getenv("UF3_NO_LDS_RECS");
-                    for (int q = 0; q < 12 && !found && !getenv("UF3_NO_OCC3"); q++) {
-                        const int nr = tries[q / 4];
-                        const bool with_recs = (q & 2) == 0, with_dsrc = (q & 1) == 0;
-                        if ((with_recs && !recs_allowed) || (with_dsrc && !dsrc_allowed)) continue;
-                        int stage = std::max(DENSE_DUMP, nr * b->dense_stride);
-                        size_t need = feat_lds_bytes(F, S, cap, A.cand_cap, want_e && !A.e_direct, with_recs ? n_rec_mode : 0, 6, stage, nr,
-                                                     A.n_pair_cols) + (with_dsrc ? sizeof(int) * b->n_dsrc : 0);
-                        if (need <= budget) {
-                            found = true; launch_mode = 7; recs_lds = with_recs; lds = lds_recs = need;
-                            A.dense_nrec = nr; A.dense_stage = stage; A.dsrc_lds = with_dsrc;
+                bool found = false;
+                if (dense_mode) {
+                    const int stride = b->dense_stride[mode], dump = b->dense_dump[mode];
+                    const int nrec_max = std::max(4, std::min(DENSE_NREC, 1200 / stride));
+                    auto stage_for = [&](int nr) { return std::max(dump, nr * stride); };
+                    A.dense_nrec = nrec_max; A.dense_stage = stage_for(nrec_max);
+                    if (mode <= 7 && !getenv("UF3_NO_OCC3")) {
+                        // records per staging pass: as many as the stage allows; fewer (smaller stage) if that lets a third
+                        // workgroup onto the CU -- the kernel is latency-bound.  Three workgroups per CU need <= 52 KB each
+                        // (LDS is granted in coarse granules: 53 KB did not fit).  Candidates in order of preference: more
+                        // records per pass first, tables in LDS before tables in HBM
+                        const int tries[3] = {nrec_max, std::min(nrec_max, 18), std::min(nrec_max, 15)};
+                        const size_t budget = 52 * 1024;
+                        const bool dsrc_allowed = A.dsrc_lds, recs_allowed = !getenv("UF3_NO_LDS_RECS");
+                        for (int q = 0; q < 12 && !found; q++) {
+                            const int nr = tries[q / 4];
+                            const bool with_recs = (q & 2) == 0, with_dsrc = (q & 1) == 0;
+                            if ((with_recs && !recs_allowed) || (with_dsrc && !dsrc_allowed)) continue;
+                            size_t need = feat_lds_bytes(F, S, cap, A.cand_cap, want_e && !A.e_direct, with_recs ? n_rec_mode : 0, mode,
+                                                         stage_for(nr), nr, A.n_pair_cols) + (with_dsrc ? sizeof(int) * b->n_dsrc : 0);
+                            if (need <= budget) {
+                                found = true; recs_lds = with_recs; lds = lds_recs = need;
+                                A.dense_nrec = nr; A.dense_stage = stage_for(nr); A.dsrc_lds = with_dsrc;
+                            }
                         }
                     }
-                    if (!found) { A.dense_nrec = nrec_max; A.dense_stage = std::max(DENSE_DUMP, nrec_max * b->dense_stride); }
-                } else if (dense_mode) {
-                    A.dense_nrec = std::max(4, std::min(DENSE_NREC, 1056 / b->dense_stride));
-                    A.dense_stage = std::max(DENSE_DUMP, A.dense_nrec * b->dense_stride);
                 }
-                if (launch_mode != 7) {
+                if (!found) {
                     lds_plain = feat_lds_bytes(F, S, cap, A.cand_cap, want_e && !A.e_direct, 0, mode, A.dense_stage, A.dense_nrec, A.n_pair_cols) + lds_extra;
                     lds_recs = feat_lds_bytes(F, S, cap, A.cand_cap, want_e && !A.e_direct, n_rec_mode, mode, A.dense_stage, A.dense_nrec, A.n_pair_cols) + lds_extra;
                     const size_t lds_target = cu_lds / (mode == 0 ? 4 : 2);
                     recs_lds = lds_recs <= lds_target && !getenv("UF3_NO_LDS_RECS");
                     lds = recs_lds ? lds_recs : lds_plain;
                 }
+                const int launch_mode = mode;
                 if (lds > 160 * 1024 - 512) return fail(c, UF3_EOVERFLOW, "featurizer LDS footprint exceeds 160 KB (F or neighbour count too large)");
                 // blocks of WPB waves, each walking a contiguous run of atoms (keeps the shared energy row on
                 // one frame); many more blocks than resident slots (measured: 2 per slot 3400 frames/s, 16-48 per slot

@@ -415,7 +415,7 @@ struct WaveLds {
     int *so;                           // species offsets in the own list [S+1]
     int *ospoff;                       // species offsets of every own neighbour's list [cap][S+1]
     int sp_stride;                     // S + 1
-    double *geo;                       // MFMA specialisation: geometry of the walked triplets [3 * nrec][GEO_STRIDE]
+    double *geo;                       // MFMA specialisation: geometry of the walked triplets, 7 fields of GEO_N
     double *stage;                     // NSTAGE triplet / pair records
     double *cand;                      // 2-body candidates [cand_cap][CAND_STRIDE] (aliases stage)
     double *pstage;                    // 2-body row buffer [4][n_pair_cols] (behind the candidates, inside stage)
@@ -583,161 +583,101 @@ __device__ __forceinline__ void trio_block(const FeatArgs &A, const BasisDev *B,
     }
 }
 
-// ---- MFMA specialisation (MODE 6): dense accumulation of a small raw-bin window on the fp64 matrix cores ----
-// For one atom and trio block the force rows are X_c[l][m][n] = sum over records of
-//     P_c(l,m) * B_n(n) + Q_c(l,m) * B'_n(n),   P_c = B'_l B_m A1_c + B_l B'_m A2_c,   Q_c = B_l B_m A3_c,
-// i.e. a (3*Pk x 2T) * (2T x Nk) product with Pk = ext_l * ext_m window pairs and Nk = ext_n window bins, on
-// v_mfma_f64_16x16x4 (rows (c, l, m) in two 16-row tiles, K = records x {P, Q}).  The accumulators are the raw
-// window; the symmetry fold into columns happens once per (atom, block) through the dsrc table.
-//
-// Records are walked 63 at a time (geometry to LDS), sorted into three classes, and staged 21 at a time by lanes
-// (record, leg) that evaluate one leg each and scatter its four values to their position inside the window, so
-// that every operand address in the MFMA loop is a per-lane constant plus the record stride:
-//   L (B, B') x ext_l | M (B, B') x ext_m | N (B, B') x ext_n | (A1_c, A2_c) c = x,y,z | A3_c c = x,y,z, pad | zero pair
-//   class 0  centre role (A3 = 0: no Q slot)         4 records per step, K index = record; energy tile rides along
-//   class 1  neighbour role, m on leg l (A2 = 0)     2 records per step, P = B'_l B_m A1_c     } single products, 8-byte
-//   class 2  neighbour role, m on leg m (A1 = 0)     2 records per step, P = B_l B'_m A2_c     } operands; ONE loop:
-//            class 1 stores its M pair as (B, B), class 2 its L pair as (B, B), its M pair as (B', B) and its direction
-//            in the A1 slot, so that P lanes read L.y M.x f.x and Q lanes L.x M.y A3 whatever the class
+// ---- dense window on the fp64 matrix cores (MODE 6 - 9) ----------------------------------------------------------
+// For one atom and trio block the rows are a rank-(2 x records) sum of outer products over the window of raw bins that
+// feed the block's columns (ext_l x ext_m x ext_n bins starting at lo):
+//     X_c[l][m][n] = sum over records, two K slots s each, of   A_s[(c, l)] * B_s[(m, n)]
+//   class 0  m centres the triplet       s0:  u1_c B'_l | B_m  B_n      s1:  u2_c B_l | B'_m B_n    energy row: B_l | B_m B_n in s0
+//   class 1  m neighbour, on leg l       s0:  u_c  B'_l | B_m  B_n      s1:  a3_c B_l | B_m  B'_n
+//   class 2  m neighbour, on leg m       s0:  u_c  B_l  | B'_m B_n      s1:  a3_c B_l | B_m  B'_n
+// (u: unit vectors of the legs that end at m, a3: unit vector m -> k; these are -(d r_leg / d R_m)).  On v_mfma_f64_16x16x4:
+// rows (c, l) with c = x, y, z, energy (4 ext_l rows, RT tiles of 16), columns (m, n) (CT tiles), K = 4 slots = 2
+// records per step.  Every operand is ONE product of two 8-byte LDS reads, the same for all classes, because the staging
+// pass arranges each record by its class:
+//   L pairs (LX0[l], LX1[l]) | M pairs (MB0[m], MB1[m]) | N pairs (NB0[n], NB1[n]) | D pairs (D0[c], D1[c]) c = x,y,z,e | 0 0
+//   lane (row (c, l), slot s):  A = L[2l + s] * D[2c + s]   (energy rows: L[2l + 1] * D[6 + s], D[6] = 1 for class 0, else 0)
+//   lane (col (m, n), slot s):  B = M[2m + s] * N[2n + s]
+// Records are walked 63 at a time (geometry to LDS, sorted by class), staged <= 21 at a time by lanes (record, leg) that
+// evaluate one leg each and scatter its four (value, derivative) entries to their place inside the window.  The
+// accumulators are the raw window; the symmetry fold into columns happens once per (atom, block) through dsrc.
+// Energy-only launches stage two records per staged record (K slot = record parity), rows = l only.
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
 struct DenseLayout {
-    int off_m, off_n, off_f, off_z, stride;      // in doubles (L window at 0)
+    int oM, oN, oD, oZ, stride, cw;      // in doubles (L pairs at 0); cw = width of a dumped row
 };
 __host__ __device__ __forceinline__ DenseLayout dense_layout(int ext_l, int ext_m, int ext_n) {
     DenseLayout d;
-    d.off_m = 2 * ext_l; d.off_n = d.off_m + 2 * ext_m; d.off_f = d.off_n + 2 * ext_n;
-    d.off_z = d.off_f + 10; d.stride = d.off_z + 2;
+    d.oM = 2 * ext_l; d.oN = d.oM + 2 * ext_m; d.oD = d.oN + 2 * ext_n; d.oZ = d.oD + 8;
+    d.stride = (d.oZ + 2 + 7) & ~7;
+    d.cw = 16 * ((ext_m * ext_n + 15) / 16);
     return d;
 }
-#define DENSE_DUMP 768    // doubles: 32 force rows + 16 energy rows of 16 bins
+// (row tiles, column tiles) of the four specialisations
+__host__ __device__ constexpr int dense_rt(int mode) { return mode == 9 ? 2 : 1; }
+__host__ __device__ constexpr int dense_ct(int mode) { return mode == 6 ? 1 : (mode == 7 ? 2 : (mode == 8 ? 4 : 6)); }
+// specialisation that serves a window, 0 if none does
+__host__ __device__ __forceinline__ int dense_mode_for(int ext_l, int ext_m, int ext_n) {
+    const int rt = (4 * ext_l + 15) / 16, ct = (ext_m * ext_n + 15) / 16;
+    if (rt == 1) return ct == 1 ? 6 : (ct == 2 ? 7 : (ct <= 4 ? 8 : (ct <= 6 ? 9 : 0)));
+    return (rt == 2 && ct <= 6) ? 9 : 0;
+}
 #define DENSE_NREC 21     // records staged per pass (3 lanes each), upper bound; the launch may use fewer
-#define GEO_STRIDE 8      // doubles per walked triplet: rl, rm, rn | e[3] (neighbour role: m -> k) | packed ints | pad
+#define GEO_N 64          // field stride of the walked triplets' geometry: rl | rm | rn | a3x | a3y | a3z | packed ints
 
-// per-lane operand offsets (doubles, relative to the record of the lane's K slot).  TM = 16-row tiles of the
-// (c, l, m) rows: 2 (windows of <= 10 pairs: the reference's default trims), 4 or 8 (wider windows); the energy rows
-// (c = x, pair < Pk) sit in the first TE = ceil(Pk / 16) tiles.
-template <int TM>
+template <int RT, int CT>
 struct DenseLane {
-    int l[TM], m[TM], f[TM]; // row (c, l, m) of tile tm: L pair, M pair, (A1_c, A2_c) pair
-    int g[TM];               // ... A3_c
-    int q;                   // 1 for K slot "Q" lanes of the two-record steps, else 0
-    int n;                   // N pair of this lane's window bin
-    unsigned e_rows;         // bit te: this lane's row of tile te is an energy row
+    int aL[RT], aD[RT];      // row (c, l) of row tile rt, K slot of this lane: L entry, D entry (doubles inside a record)
+    int bM[CT], bN[CT];      // column (m, n) of column tile ct: M entry, N entry
 };
-__host__ __device__ constexpr int dense_te(int tm) { return tm == 2 ? 1 : (tm == 4 ? 2 : 3); }
 
-template <bool WANT_E, bool MASK, int TM>
-__device__ __forceinline__ void mfma_quad(const double *rec, bool live, const DenseLane<TM> &o, double4_t (&accf)[TM],
-                                          double4_t (&acce)[dense_te(TM)]) {
-    // reads first, then the products, then the MFMAs (see mfma_pair); at most four tiles' operands live at a time
-    constexpr int TE = dense_te(TM);
-    constexpr int TC = TM < 4 ? TM : 4;
-    const double bv = rec[o.n];
-    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+template <bool MASK, int RT, int CT>
+__device__ __forceinline__ void dense_step(const double *rec, bool live, const DenseLane<RT, CT> &o, double4_t (&acc)[RT][CT]) {
+    // all operand reads go out before anything waits on them
+    double la[RT], da[RT], mb[CT], nb[CT];
 #pragma unroll
-    for (int t0 = 0; t0 < TM; t0 += TC) {
-        double2 L[TC], M[TC], Fv[TC];
+    for (int rt = 0; rt < RT; rt++) { la[rt] = rec[o.aL[rt]]; da[rt] = rec[o.aD[rt]]; }
 #pragma unroll
-        for (int u = 0; u < TC; u++) {
-            L[u] = *(const double2 *)(rec + o.l[t0 + u]); M[u] = *(const double2 *)(rec + o.m[t0 + u]);
-            Fv[u] = *(const double2 *)(rec + o.f[t0 + u]);
-        }
-        __builtin_amdgcn_sched_group_barrier(0x100, 3 * TC, 0);
-        double a[TC], ae[TC];
+    for (int ct = 0; ct < CT; ct++) { mb[ct] = rec[o.bM[ct]]; nb[ct] = rec[o.bN[ct]]; }
+    __builtin_amdgcn_sched_group_barrier(0x100, 2 * (RT + CT), 0);                        // DS reads
+    double a[RT], b[CT];
 #pragma unroll
-        for (int u = 0; u < TC; u++) {
-            a[u] = fma(L[u].y * M[u].x, Fv[u].x, (L[u].x * M[u].y) * Fv[u].y);
-            if (MASK) a[u] = live ? a[u] : 0.0;
-            ae[u] = (WANT_E && t0 + u < TE && ((o.e_rows >> (t0 + u)) & 1u)) ? L[u].x * M[u].x : 0.0;
-            if (MASK) ae[u] = live ? ae[u] : 0.0;
-        }
+    for (int rt = 0; rt < RT; rt++) { a[rt] = la[rt] * da[rt]; if (MASK) a[rt] = live ? a[rt] : 0.0; }
 #pragma unroll
-        for (int u = 0; u < TC; u++) accf[t0 + u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], bv, accf[t0 + u], 0, 0, 0);
-        if (WANT_E)
+    for (int ct = 0; ct < CT; ct++) { b[ct] = mb[ct] * nb[ct]; if (MASK) b[ct] = live ? b[ct] : 0.0; }
 #pragma unroll
-            for (int u = 0; u < TC; u++)
-                if (t0 + u < TE) acce[t0 + u] = __builtin_amdgcn_mfma_f64_16x16x4f64(ae[u], bv, acce[t0 + u], 0, 0, 0);
-    }
+    for (int rt = 0; rt < RT; rt++)
+#pragma unroll
+        for (int ct = 0; ct < CT; ct++) acc[rt][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[rt], b[ct], acc[rt][ct], 0, 0, 0);
 }
 
-// two neighbour-role records per step; x/y/z: this lane's three factors (B or B' of leg l, of leg m, direction)
-template <bool MASK, int TM>
-__device__ __forceinline__ void mfma_pair(const double *rec, bool live, const DenseLane<TM> &o, int dx, int dy, int bn,
-                                          double4_t (&accf)[TM]) {
-    // all operand reads (of up to four tiles) go out before anything waits on them (left alone, the scheduler keeps
-    // the register count minimal and waits after every read: one LDS round trip per read instead of one per step)
-    constexpr int TC = TM < 4 ? TM : 4;
-    const double bv = rec[bn];
-    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+// n_staged records (two K slots each) of the stage into the accumulators, two records per step.  STRIDE != 0: the
+// record stride is a compile-time constant, so the unrolled steps address their operands with immediate offsets
+// (one address update per operand and trip instead of one per operand and step).
+template <int RT, int CT, int STRIDE>
+__device__ __forceinline__ void dense_accumulate(const double *stage, int rt_stride, int n_staged, const DenseLane<RT, CT> &o,
+                                                 double4_t (&acc)[RT][CT]) {
+    const int stride = STRIDE ? STRIDE : rt_stride;
+    const int half = lane_id() >> 5;                          // which record of the step this lane's K slot belongs to
+    const double *rec = stage + (size_t)half * stride;
+    const int n_full = n_staged & ~1;
+    int q = 0;
+    if (STRIDE) {
+        for (; q + 8 <= n_full; q += 8, rec += 8 * stride) {
 #pragma unroll
-    for (int t0 = 0; t0 < TM; t0 += TC) {
-        double xv[TC], yv[TC], zv[TC];
-#pragma unroll
-        for (int u = 0; u < TC; u++) {
-            xv[u] = rec[o.l[t0 + u] + dx]; yv[u] = rec[o.m[t0 + u] + dy]; zv[u] = rec[o.q ? o.g[t0 + u] : o.f[t0 + u]];
-        }
-        __builtin_amdgcn_sched_group_barrier(0x100, 3 * TC, 0);                           // DS reads
-        double a[TC];
-#pragma unroll
-        for (int u = 0; u < TC; u++) {
-            a[u] = (xv[u] * yv[u]) * zv[u];
-            if (MASK) a[u] = live ? a[u] : 0.0;
-        }
-        __builtin_amdgcn_sched_group_barrier(0x2, (MASK ? 4 : 2) * TC, 0);                // VALU
-#pragma unroll
-        for (int u = 0; u < TC; u++) accf[t0 + u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], bv, accf[t0 + u], 0, 0, 0);
-        __builtin_amdgcn_sched_group_barrier(0x8, TC, 0);                                 // MFMA
-    }
-}
-
-template <bool WANT_E, bool WANT_F, int TM>
-__device__ __forceinline__ void mfma_records(const double *stage, int stride, int n0, int n1, int n2, const DenseLane<TM> &o,
-                                             double4_t (&accf)[TM], double4_t (&acce)[dense_te(TM)]) {
-    constexpr int TE = dense_te(TM);
-    const int ks = lane_id() >> 4;
-    if (WANT_F) {
-        {   // class 0: four records per step
-            const double *rec = stage + (size_t)ks * stride;
-            const int n_full = n0 & ~3;
-            int q = 0;
-            for (; q < n_full; q += 4, rec += 4 * stride) mfma_quad<WANT_E, false, TM>(rec, true, o, accf, acce);
-            // (lanes past the end read record 0: whatever lies behind the stage need not be finite)
-            if (q < n0) mfma_quad<WANT_E, true, TM>(q + ks < n0 ? rec : stage, q + ks < n0, o, accf, acce);
-        }
-        // neighbour-role records, two per step (K slots: record 0 P, record 0 Q, record 1 P, record 1 Q).  The staging
-        // pass arranged their (L, M) pairs by class so that both classes read the same slots: P lanes L.y * M.x * f.x
-        // (the derivative of the leg that joins the centre and m, the other leg's value, that leg's direction),
-        // Q lanes L.x * M.y * A3
-        {
-            const int pl = 1 - o.q;
-            const int bn = o.n + o.q;                  // B operand: B_n for P slots, B'_n for Q slots
-            const int cnt = n1 + n2;
-            const double *rec = stage + (size_t)(n0 + (ks >> 1)) * stride;
-            const int n_full = cnt & ~1;
-            int q = 0;
-            for (; q < n_full; q += 2, rec += 2 * stride) mfma_pair<false, TM>(rec, true, o, pl, o.q, bn, accf);
-            if (q < cnt) mfma_pair<true, TM>((ks >> 1) == 0 ? rec : stage, (ks >> 1) == 0, o, pl, o.q, bn, accf);
-        }
-    } else if (WANT_E) {
-        const double *rec = stage + (size_t)ks * stride;
-        for (int q = 0; q < n0; q += 4, rec += 4 * stride) {
-            const double *r = q + ks < n0 ? rec : stage;
-            const double bv = r[o.n];
-#pragma unroll
-            for (int te = 0; te < TE; te++) {
-                const double av = (q + ks < n0 && ((o.e_rows >> te) & 1u)) ? r[o.l[te]] * r[o.m[te]] : 0.0;
-                acce[te] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acce[te], 0, 0, 0);
-            }
+            for (int u = 0; u < 4; u++) dense_step<false, RT, CT>(rec + 2 * u * stride, true, o, acc);
         }
     }
+    for (; q < n_full; q += 2, rec += 2 * stride) dense_step<false, RT, CT>(rec, true, o, acc);
+    // odd count: the lanes of the missing record read record 0 (whatever lies behind the stage need not be finite)
+    if (q < n_staged) dense_step<true, RT, CT>(half == 0 ? rec : stage, half == 0, o, acc);
 }
 
-template <bool WANT_E, bool WANT_F, int TM>
+template <bool WANT_E, bool WANT_F, int MODE>
 __device__ __forceinline__ void trio_block_mfma(const FeatArgs &A, const BasisDev *B, const KnotRec *recs, const FrameGeom &g,
                                                 const WaveLds &w, int m, int sm, int t, const ESink &es,
                                                 const int (&fragp)[4], const int *dsrc) {
-    constexpr int TE = dense_te(TM);
+    constexpr int RT = dense_rt(MODE), CT = dense_ct(MODE);
     const int lane = lane_id();
     // the descriptor through the constant address space: scalar loads into SGPRs (the tables never change while a
     // kernel runs; through a plain global pointer every field read is a vector load the compiler cannot hoist)
@@ -749,28 +689,34 @@ __device__ __forceinline__ void trio_block_mfma(const FeatArgs &A, const BasisDe
     const int ncol = td->ncol, F = B->F;
     const int lo_l = td->lo[0], lo_m = td->lo[1], lo_n = td->lo[2];
     const int ext_l = td->ext[0], ext_m = td->ext[1], ext_n = td->ext[2];
-    const int Pk = ext_l * ext_m;
     const DenseLayout dl = dense_layout(ext_l, ext_m, ext_n);
-    const int r16 = lane & 15;
-    // per-lane operand offsets; small quotients by multiply-shift (exact for < 64)
-    const int inv_pk = (65536 + Pk - 1) / Pk, inv_em = (65536 + ext_m - 1) / ext_m;      // wave-uniform
-    DenseLane<TM> o;
-    o.e_rows = 0;
+    const int r16 = lane & 15, slot = (lane >> 4) & 1;
+    // per-lane operand offsets (small quotients by multiply-shift, exact for dividends < 4096 and divisors <= 64)
+    const int inv_l = (65536 + ext_l - 1) / ext_l, inv_n = (65536 + ext_n - 1) / ext_n;      // wave-uniform
+    DenseLane<RT, CT> o;
 #pragma unroll
-    for (int tm = 0; tm < TM; tm++) {
-        const int row = tm * 16 + r16;
-        const int c = (row * inv_pk) >> 16, p = row - c * Pk;
-        const int pl = (p * inv_em) >> 16, pm = p - pl * ext_m;
-        const bool ok = row < 3 * Pk;
-        o.l[tm] = ok ? 2 * pl : dl.off_z;
-        o.m[tm] = ok ? dl.off_m + 2 * pm : dl.off_z;
-        o.f[tm] = ok ? dl.off_f + 2 * c : dl.off_z;
-        o.g[tm] = ok ? dl.off_f + 6 + c : dl.off_z;
-        if (tm < TE && row < Pk) o.e_rows |= 1u << tm;
+    for (int rt = 0; rt < RT; rt++) {
+        const int row = rt * 16 + r16;
+        if (WANT_F) {
+            const int c = (row * inv_l) >> 16, pl = row - c * ext_l;
+            const bool ok = c < 3 || (c == 3 && WANT_E);
+            o.aL[rt] = ok ? 2 * pl + (c == 3 ? 1 : slot) : dl.oZ;
+            o.aD[rt] = ok ? dl.oD + 2 * c + slot : dl.oZ;
+        } else {
+            const bool ok = row < ext_l;
+            o.aL[rt] = ok ? 2 * row + slot : dl.oZ;
+            o.aD[rt] = ok ? dl.oD + 6 + slot : dl.oZ;
+        }
     }
-    o.q = (lane >> 4) & 1;
-    o.n = r16 < ext_n ? dl.off_n + 2 * r16 : dl.off_z;
-    // staging role of this lane: leg `leg` of staged record `li` (lanes 3*li .. 3*li+2)
+#pragma unroll
+    for (int ct = 0; ct < CT; ct++) {
+        const int col = ct * 16 + r16;
+        const int pm = (col * inv_n) >> 16, pn = col - pm * ext_n;
+        const bool ok = pm < ext_m;
+        o.bM[ct] = ok ? dl.oM + 2 * pm + slot : dl.oZ;
+        o.bN[ct] = ok ? dl.oN + 2 * pn + slot : dl.oZ;
+    }
+    // staging role of this lane: leg `leg` of record `li` of the pass (lanes 3*li .. 3*li+2)
     const int li = (lane * 21846) >> 16, leg = lane - 3 * li;
     LegDev lg;
     lg.rec_off = leg == 0 ? td->leg[0].rec_off : (leg == 1 ? td->leg[1].rec_off : td->leg[2].rec_off);
@@ -778,21 +724,21 @@ __device__ __forceinline__ void trio_block_mfma(const FeatArgs &A, const BasisDe
     lg.t0 = leg == 0 ? td->leg[0].t0 : (leg == 1 ? td->leg[1].t0 : td->leg[2].t0);
     lg.tlast = leg == 0 ? td->leg[0].tlast : (leg == 1 ? td->leg[1].tlast : td->leg[2].tlast);
     lg.inv_h = leg == 0 ? td->leg[0].inv_h : (leg == 1 ? td->leg[1].inv_h : td->leg[2].inv_h);
-    const int w_off = leg == 0 ? 0 : (leg == 1 ? dl.off_m : dl.off_n);
+    const int w_off = leg == 0 ? 0 : (leg == 1 ? dl.oM : dl.oN);
     const int w_ext = leg == 0 ? ext_l : (leg == 1 ? ext_m : ext_n), w_lo = leg == 0 ? lo_l : (leg == 1 ? lo_m : lo_n);
-    const int n_clear = (dl.off_f / 2 + 2) / 3;                          // window pairs each of a record's lanes clears
-    double4_t accf[TM], acce[TE];
+    const int n_clear = (dl.oD / 2 + 2) / 3;                             // window pairs each of a record's lanes clears
+    double4_t acc[RT][CT];
 #pragma unroll
-    for (int tm = 0; tm < TM; tm++) accf[tm] = double4_t{0, 0, 0, 0};
+    for (int rt = 0; rt < RT; rt++)
 #pragma unroll
-    for (int te = 0; te < TE; te++) acce[te] = double4_t{0, 0, 0, 0};
+        for (int ct = 0; ct < CT; ct++) acc[rt][ct] = double4_t{0, 0, 0, 0};
     pc.lap(1);
     const int nrec = A.dense_nrec, batch = 3 * nrec;
     const double lo_r[3] = {td->leg[0].t0, td->leg[1].t0, td->leg[2].t0};
     const double hi_r[3] = {td->leg[0].tlast, td->leg[1].tlast, td->leg[2].tlast};
     for (int p0 = 0; p0 < k.n_items; p0 += batch) {
         // ---- walk: one triplet per lane, geometry to LDS sorted by class ------------------------------------
-        int n0, n1, n2;
+        int n_valid;
         {
             TripletGeom tg;
             bool valid = lane < batch && p0 + lane < k.n_items;
@@ -803,85 +749,110 @@ __device__ __forceinline__ void trio_block_mfma(const FeatArgs &A, const BasisDe
                         (tg.rn > lo_r[2]) & (tg.rn < hi_r[2]);
             const bool is0 = valid && tg.centre, is1 = valid && !tg.centre && tg.first, is2 = valid && !tg.centre && !tg.first;
             const unsigned long long m0 = __ballot(is0), m1 = __ballot(is1), m2 = __ballot(is2);
-            n0 = __popcll(m0); n1 = __popcll(m1); n2 = __popcll(m2);
+            const int n0 = __popcll(m0), n1 = __popcll(m1);
+            n_valid = n0 + n1 + __popcll(m2);
             if (valid) {
                 const int rank = is0 ? mbcnt(m0) : (is1 ? n0 + mbcnt(m1) : n0 + n1 + mbcnt(m2));
-                double *ge = w.geo + (size_t)rank * GEO_STRIDE;
-                *(double2 *)(ge) = double2{tg.rl, tg.rm};
+                double *gq = w.geo + rank;
+                gq[0] = tg.rl; gq[GEO_N] = tg.rm; gq[2 * GEO_N] = tg.rn;
                 if (WANT_F) {
-                    *(double2 *)(ge + 2) = double2{tg.rn, tg.a3[0]};
-                    *(double2 *)(ge + 4) = double2{tg.a3[1], tg.a3[2]};
-                    *(int2 *)(ge + 6) = make_int2(tg.i1 | (tg.i2 << 16), is0 ? 0 : (is1 ? 1 : 2));
-                } else ge[2] = tg.rn;
+                    gq[3 * GEO_N] = tg.a3[0]; gq[4 * GEO_N] = tg.a3[1]; gq[5 * GEO_N] = tg.a3[2];
+                    ((int2 *)(w.geo + 6 * GEO_N))[rank] = make_int2(tg.i1 | (tg.i2 << 16), is0 ? 0 : (is1 ? 1 : 2));
+                }
             }
         }
         wave_sync();
         pc.lap(2);
         // ---- staging passes: lane (record li, leg) evaluates one leg and scatters it into the window ---------
-        const int n_valid = n0 + n1 + n2;
         for (int base = 0; base < n_valid; base += nrec) {
             const int n_part = min(nrec, n_valid - base);
             if (li < n_part && !(A.skip & 16)) {
-                const double *ge = w.geo + (size_t)(base + li) * GEO_STRIDE;
-                const double x = ge[leg];
+                const int gi = base + li;
+                const double x = w.geo[leg * GEO_N + gi];
                 KnotRec kr;
                 double v[4], d[4];
                 const int first = load_interval(recs, lg, x, kr) - 3;
                 bspline4<WANT_F>(kr, x, v, d);
-                double *rec = w.stage + (size_t)li * dl.stride;
                 const double2 zz = {0.0, 0.0};
-                // the three lanes of a record clear its windows together (LDS writes of a wave stay in program
-                // order, so every clear lands before any lane's scatter below)
-                for (int q = 0; q < n_clear; q++) {
-                    const int slot = leg * n_clear + q;
-                    if (2 * slot < dl.off_f) *(double2 *)(rec + 2 * slot) = zz;
-                }
-                const int2 pk = WANT_F ? *(const int2 *)(ge + 6) : make_int2(0, 0);
-                const int cls = pk.y;
-                // (value, derivative) pairs; neighbour-role records store the pair of the leg that does not carry the
-                // derivative as (value, value) and class 2 swaps its M pair, so that one MFMA loop serves both classes
-                const bool dup = WANT_F && ((cls == 1 && leg == 1) || (cls == 2 && leg == 0));
-                const bool swp = WANT_F && cls == 2 && leg == 1;
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const unsigned ws = (unsigned)(first + q - w_lo);
-                    const double dq = WANT_F ? d[q] : 0.0;
-                    if (ws < (unsigned)w_ext)
-                        *(double2 *)(rec + w_off + 2 * ws) = double2{swp ? dq : v[q], (dup | swp) ? v[q] : dq};
-                }
                 if (WANT_F) {
-                    // component `leg` of the three direction vectors: unit vectors of own-list entries, and e
+                    double *rec = w.stage + (size_t)li * dl.stride;
+                    // the three lanes of a record clear its windows together (LDS writes of a wave stay in program
+                    // order, so every clear lands before any lane's scatter below)
+                    for (int q = 0; q < n_clear; q++) {
+                        const int sl = leg * n_clear + q;
+                        if (2 * sl < dl.oD) *(double2 *)(rec + 2 * sl) = zz;
+                    }
+                    const int2 pk = ((const int2 *)(w.geo + 6 * GEO_N))[gi];
+                    const int cls = pk.y;
+                    // which of (value, derivative) goes to K slot 0 / 1 (table in the header of this section)
+                    const bool d0 = leg == 0 ? cls != 2 : (leg == 1 ? cls == 2 : false);
+                    const bool d1 = leg == 0 ? false : (leg == 1 ? cls == 0 : cls != 0);
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const unsigned ws = (unsigned)(first + q - w_lo);
+                        if (ws < (unsigned)w_ext)
+                            *(double2 *)(rec + w_off + 2 * ws) = double2{d0 ? d[q] : v[q], d1 ? d[q] : v[q]};
+                    }
+                    // component `leg` of the two direction vectors: unit vectors of own-list entries, and m -> k
                     const int i1 = pk.x & 0xffff, i2 = pk.x >> 16;
                     const double *oc = w.ox + (size_t)leg * A.n3.cap;           // ox | oy | oz are consecutive [cap] arrays
-                    const double v1 = oc[i1] * w.oir[i1];
-                    const double v2c = oc[i2] * w.oir[i2], v2n = ge[3 + leg];   // both fetched: no divergent round trip
-                    const double v2 = cls == 0 ? v2c : v2n;
-                    const double a1 = v1;                                  // neighbour role: the one direction, in .x
-                    const double a2 = cls == 0 ? v2 : 0.0;
-                    const double a3 = cls == 0 ? 0.0 : v2;
-                    *(double2 *)(rec + dl.off_f + 2 * leg) = double2{a1, a2};
-                    rec[dl.off_f + 6 + leg] = a3;
+                    const double u1 = oc[i1] * w.oir[i1];
+                    const double u2 = oc[i2] * w.oir[i2], a3 = w.geo[(3 + leg) * GEO_N + gi];   // both fetched: no divergence
+                    *(double2 *)(rec + dl.oD + 2 * leg) = double2{u1, cls == 0 ? u2 : a3};
+                    if (leg == 0) *(double2 *)(rec + dl.oD + 6) = double2{cls == 0 ? 1.0 : 0.0, 0.0};
+                    if (leg == 1) *(double2 *)(rec + dl.oZ) = zz;
+                } else {
+                    double *rec = w.stage + (size_t)(li >> 1) * dl.stride;
+                    const int s = li & 1;
+                    for (int q = 0; q < n_clear; q++) {      // (both records of the pair clear: all clears precede the scatters)
+                        const int sl = leg * n_clear + q;
+                        if (2 * sl < dl.oD) *(double2 *)(rec + 2 * sl) = zz;
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const unsigned ws = (unsigned)(first + q - w_lo);
+                        if (ws < (unsigned)w_ext) rec[w_off + 2 * ws + s] = v[q];
+                    }
+                    if (leg == 0) rec[dl.oD + 6 + s] = 1.0;
+                    if (leg == 1 && s == 0) *(double2 *)(rec + dl.oZ) = zz;
                 }
-                if (leg == 0) *(double2 *)(rec + dl.off_z) = zz;
             }
             wave_sync();
             pc.lap(4);
-            // class counts inside this pass
-            const int c0 = max(0, min(n_part, n0 - base)), c01 = max(0, min(n_part, n0 + n1 - base));
-            if (!(A.skip & 8)) mfma_records<WANT_E, WANT_F, TM>(w.stage, dl.stride, c0, c01 - c0, n_part - c01, o, accf, acce);
+            if (!(A.skip & 8)) {
+                const int n_staged = WANT_F ? n_part : (n_part + 1) >> 1;
+                switch (dl.stride) {       // wave-uniform
+                    case (MODE == 6 ? 32 : (MODE == 7 ? 40 : (MODE == 8 ? 48 : 56))):
+                        dense_accumulate<RT, CT, (MODE == 6 ? 32 : (MODE == 7 ? 40 : (MODE == 8 ? 48 : 56)))>(w.stage, dl.stride, n_staged, o, acc);
+                        break;
+                    default:
+                        dense_accumulate<RT, CT, 0>(w.stage, dl.stride, n_staged, o, acc);
+                }
+            }
             wave_sync();
             pc.lap(5);
         }
     }
     // accumulator window -> LDS, then lanes <-> columns fold the symmetry images and write the rows
     double *dump = w.stage;
-    const int nsrc = td->nsrc;
-    if (TM == 2) {
-        // rows: 32 force rows (c, l, m), then 16 energy rows (l, m); 16 n bins each: one pass
+    const int nsrc = td->nsrc, cw = dl.cw;
+    const int comp_rows = WANT_F ? ext_l : 0;                    // rows per force component (energy rows follow them)
+    const bool whole = RT * 16 * cw <= A.dense_stage;            // the whole window fits the stage: one pass
+    const int c_first = WANT_F ? 0 : 3, c_last = WANT_E ? 3 : 2;
+    for (int comp = whole ? -1 : c_first; comp <= (whole ? -1 : c_last); comp++) {
+        wave_sync();
 #pragma unroll
         for (int v = 0; v < 4; v++) {
-            if (WANT_F) { dump[fragp[v]] = accf[0][v]; dump[256 + fragp[v]] = accf[1][v]; }
-            if (WANT_E) dump[512 + fragp[v]] = acce[0][v];
+            const int fr = fragp[v] >> 4, fc = fragp[v] & 15;
+#pragma unroll
+            for (int rt = 0; rt < RT; rt++) {
+                int row = rt * 16 + fr;
+                bool ok = true;
+                if (!whole) { row -= (WANT_F ? comp : 0) * ext_l; ok = row >= 0 && row < ext_l; }
+#pragma unroll
+                for (int ct = 0; ct < CT; ct++)
+                    if (ok && ct * 16 < cw) dump[row * cw + ct * 16 + fc] = acc[rt][ct][v];
+            }
         }
         wave_sync();
         for (int col = lane; col < ncol; col += WAVE) {
@@ -889,46 +860,20 @@ __device__ __forceinline__ void trio_block_mfma(const FeatArgs &A, const BasisDe
             for (int q = 0; q < nsrc; q++) {
                 const int off = dsrc[td->src_off + col * nsrc + q];
                 if (off < 0) continue;
-                if (WANT_F) { fx += dump[off]; fy += dump[Pk * 16 + off]; fz += dump[2 * Pk * 16 + off]; }
-                if (WANT_E) en += dump[512 + off];
+                if (whole) {
+                    if (WANT_F) { fx += dump[off]; fy += dump[comp_rows * cw + off]; fz += dump[2 * comp_rows * cw + off]; }
+                    if (WANT_E) en += dump[3 * comp_rows * cw + off];
+                } else fx += dump[off];
             }
-            if (WANT_F && !(A.skip & 32)) {
-                double *dst = A.x_f + (size_t)m * 3 * F + td->col + col;
-                dst[0] = fx; dst[F] = fy; dst[2 * (size_t)F] = fz;
-            }
-            if (WANT_E) es.add(td->col + col, en);
-        }
-    } else {
-        // wider windows do not fit the stage at once: one pass per component (x, y, z, energy), Pk rows each
-        for (int comp = WANT_F ? 0 : 3; comp < (WANT_E ? 4 : 3); comp++) {
-            wave_sync();
-#pragma unroll
-            for (int v = 0; v < 4; v++) {
-                const int fr = fragp[v] >> 4, fc = fragp[v] & 15;
-                if (comp < 3) {
-#pragma unroll
-                    for (int tm = 0; tm < TM; tm++) {
-                        const int p = tm * 16 + fr - comp * Pk;
-                        if (p >= 0 && p < Pk) dump[p * 16 + fc] = accf[tm][v];
-                    }
-                } else {
-#pragma unroll
-                    for (int te = 0; te < TE; te++) {
-                        const int p = te * 16 + fr;
-                        if (p < Pk) dump[p * 16 + fc] = acce[te][v];
-                    }
+            if (whole) {
+                if (WANT_F && !(A.skip & 32)) {
+                    double *dst = A.x_f + (size_t)m * 3 * F + td->col + col;
+                    dst[0] = fx; dst[F] = fy; dst[2 * (size_t)F] = fz;
                 }
-            }
-            wave_sync();
-            for (int col = lane; col < ncol; col += WAVE) {
-                double sum = 0;
-                for (int q = 0; q < nsrc; q++) {
-                    const int off = dsrc[td->src_off + col * nsrc + q];
-                    if (off >= 0) sum += dump[off];
-                }
-                if (comp < 3) { if (!(A.skip & 32)) A.x_f[(size_t)m * 3 * F + (size_t)comp * F + td->col + col] = sum; }
-                else es.add(td->col + col, sum);
-            }
+                if (WANT_E) es.add(td->col + col, en);
+            } else if (comp < 3) {
+                if (!(A.skip & 32)) A.x_f[(size_t)m * 3 * F + (size_t)comp * F + td->col + col] = fx;
+            } else es.add(td->col + col, fx);
         }
     }
     wave_sync();
@@ -1042,17 +987,18 @@ __device__ __forceinline__ void zero_rows(double *x_f, int m, int F, int col, in
 
 // MODE selects the column blocks a launch is responsible for, so that each specialisation carries only the
 // registers of its own path: 0 = one-body + pair blocks; 1..5 = trio blocks whose (nsrc, 64-column chunks
-// per walk) is (1,1), (1,2), (2,1), (2,2), (6,1); 6 = trio blocks with a small dense window, accumulated on the
-// matrix cores (trio_block_mfma).  Every block is written by exactly one launch.
-// (MODE 7 = MODE 6 compiled for three waves per SIMD; launched when its LDS footprint allows three workgroups per CU.)
+// per walk) is (1,1), (1,2), (2,1), (2,2), (6,1); 6..9 = trio blocks with a dense window accumulated on the matrix
+// cores (trio_block_mfma) in (row tiles, column tiles) = (1,1), (1,2), (1,4), (2,6).  Every block is written by
+// exactly one launch.  (6 and 7 are compiled for three waves per SIMD; whether three workgroups fit a CU is the
+// launch's LDS footprint.)
 __device__ __forceinline__ int trio_mode(const TrioDev *td) {
-    if (td->dense) return td->dense == 2 ? 6 : (td->dense == 4 ? 8 : 9);
+    if (td->dense) return td->dense;
     const bool wide = td->ncol > WAVE;
     return td->nsrc == 1 ? (wide ? 2 : 1) : (td->nsrc == 2 ? (wide ? 4 : 3) : 5);
 }
 
 template <bool WANT_E, bool WANT_F, bool RECS_LDS, int MODE>
-__global__ void __launch_bounds__(WPB * WAVE, MODE == 0 ? 4 : (MODE == 7 ? 3 : 2))
+__global__ void __launch_bounds__(WPB * WAVE, MODE == 0 ? 4 : ((MODE == 6 || MODE == 7) ? 3 : 2))
 k_featurize(FeatArgs A) {
     extern __shared__ __align__(16) unsigned char smem[];
     const BasisDev *B = A.B;
@@ -1070,7 +1016,7 @@ k_featurize(FeatArgs A) {
     const size_t stage_d = MODE == 0 ? cand_d + pair_buf_d
                            : (DENSE ? (size_t)A.dense_stage : (size_t)NSTAGE * ITEM_STRIDE);
     const size_t list_d = MODE == 0 ? 0 : 5 * (size_t)cap + ((5 * cap) & 1);
-    const size_t geo_d = DENSE ? (size_t)3 * A.dense_nrec * GEO_STRIDE : 0;
+    const size_t geo_d = DENSE ? (size_t)7 * GEO_N : 0;
     const size_t per_wave_d = list_d + stage_d + (stage_d & 1) + geo_d;
     const size_t per_wave_i = MODE == 0 ? 0 : 3 * (size_t)cap + 2 * ((size_t)cap + 1) + (UF3_MAX_SPECIES + 2) +
                                                   (size_t)cap * (S + 1);
@@ -1198,8 +1144,8 @@ k_featurize(FeatArgs A) {
             for (int t = 0; t < n_trios; t++) {
                 const TrioDev *td = A.trios + t;
                 const int t_dense = load_const(&td->dense), t_nsrc = load_const(&td->nsrc), t_ncol = load_const(&td->ncol);
-                const int t_mode = t_dense ? (t_dense == 2 ? 6 : (t_dense == 4 ? 8 : 9)) : (t_nsrc == 1 ? (t_ncol > WAVE ? 2 : 1) : (t_nsrc == 2 ? (t_ncol > WAVE ? 4 : 3) : 5));
-                if (t_mode != (MODE == 7 ? 6 : MODE)) continue;
+                const int t_mode = t_dense ? t_dense : (t_nsrc == 1 ? (t_ncol > WAVE ? 2 : 1) : (t_nsrc == 2 ? (t_ncol > WAVE ? 4 : 3) : 5));
+                if (t_mode != MODE) continue;
                 const int t_sc = load_const(&td->sc), t_sa = load_const(&td->sa), t_sb = load_const(&td->sb);
                 const bool touches = (t_sc == sm) || (WANT_F && (t_sa == sm || t_sb == sm));
                 if (!touches) { if (WANT_F && !(A.skip & 32)) zero_rows(A.x_f, m, F, load_const(&td->col), t_ncol); continue; }
@@ -1208,7 +1154,7 @@ k_featurize(FeatArgs A) {
                 else if (MODE == 3) trio_block<WANT_E, WANT_F, 2, 1>(A, B, recs, g, w, m, sm, t, es);
                 else if (MODE == 4) trio_block<WANT_E, WANT_F, 2, 2>(A, B, recs, g, w, m, sm, t, es);
                 else if (MODE == 5) trio_block<WANT_E, WANT_F, 6, 1>(A, B, recs, g, w, m, sm, t, es);
-                else trio_block_mfma<WANT_E, WANT_F, (MODE == 8 ? 4 : (MODE == 9 ? 8 : 2))>(A, B, recs, g, w, m, sm, t, es, fragp, dsrc);
+                else trio_block_mfma<WANT_E, WANT_F, (MODE >= 6 ? MODE : 6)>(A, B, recs, g, w, m, sm, t, es, fragp, dsrc);
             }
         }
     }
