@@ -5,6 +5,8 @@ There is deliberately no CPU fallback: if the HIP library is missing or no
 MI355X is visible, every call that needs arithmetic raises ``HipUnavailable``.
 """
 import ctypes as C
+import sys
+import importlib.util
 import os
 import threading
 
@@ -54,6 +56,30 @@ _lib = None
 _lock = threading.Lock()
 
 
+def _share_hip_runtime_with_torch():
+    """One HIP runtime per process, whichever of torch / uf3_amd is imported first.
+
+    PyTorch-ROCm wheels bundle their own ``libamdhip64.so``.  If this library (linked against the system ROCm) has
+    initialised the system runtime before torch is imported, torch's libraries bind to the already loaded system
+    runtime and then find no device (``No HIP GPUs are available``).  With torch imported first everything binds to the
+    bundled runtime, which works -- so when a torch wheel with a bundled runtime is installed, that runtime is
+    loaded here first.  torch itself is not imported."""
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        return
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def load():
     """dlopen libuf3hip.so (built in-tree by ``__graft_entry__.build()``)."""
     global _lib
@@ -65,6 +91,7 @@ def load():
                 f"{LIB_PATH} not found: build it with `make -C uf3_amd/csrc` "
                 "(or `python -c 'import __graft_entry__ as g; g.build()'`). "
                 "uf3_amd has no CPU fallback.")
+        _share_hip_runtime_with_torch()
         lib = C.CDLL(LIB_PATH)
         vp, i32, i64, dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_double
         lib.uf3_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]

@@ -40,9 +40,12 @@ struct TrioDev {
     int dim_l;
     int sc, sa, sb;    // species indices: centre, neighbours sa <= sb
     int nsrc, src_off; // symmetry images per column (1, 2, 6) and offset into the colsrc table
-    // dense accumulation window = bounding box of the raw bins that feed a column.  dense != 0: the box is
-    // small enough (3 * ext[0] * ext[1] <= 32 rows, ext[2] <= 16) for the MFMA specialisation of the featurizer
+    // dense accumulation window = bounding box of the raw bins that feed a column.  dense = featurizer mode (6-9) of
+    // the matrix-core specialisation that serves the box, 0 if none does
     int dense, lo[3], ext[3];
+    // two column tiles (n-major columns): a record with r_n <= thr0 touches tile 0 only, with r_n > thr2 tile 1 only
+    // (knot values of leg n, so the classes are exact for any knot sequence)
+    double thr0, thr2;
 };
 
 struct BasisDev {

@@ -284,6 +284,7 @@ extern "C" int uf3_basis_create(uf3_ctx *c, const uf3_basis_spec *s, uf3_basis *
     }
     b->n_pair_recs = recs.size();
     std::vector<TrioDev> trios(h.T);
+    std::vector<const double *> legn_knots(h.T, nullptr);        // knots of leg n of every trio
     const double *tp = s->trio_knots;
     double lo3 = 1e300, hi3 = -1e300;
     size_t lut_len = 0;
@@ -298,6 +299,7 @@ extern "C" int uf3_basis_create(uf3_ctx *c, const uf3_basis_spec *s, uf3_basis *
             int nk = s->trio_nk[3 * t + d];
             if (nk < 8) { delete b; return fail(c, UF3_EINVAL, "trio knot vector too short"); }
             fill_leg(td.leg[d], tp, nk, recs);
+            if (d == 2) legn_knots[t] = tp;
             for (int q = 0; q < nk; q++) {
                 lo3 = std::min(lo3, tp[q]);
                 if (d < 2) hi3 = std::max(hi3, tp[q]);     // angles.py:322-325: centre legs only
@@ -361,13 +363,29 @@ extern "C" int uf3_basis_create(uf3_ctx *c, const uf3_basis_spec *s, uf3_basis *
             b->dense_stride[dmode] = std::max(b->dense_stride[dmode], dl.stride);
             b->dense_dump[dmode] = std::max(b->dense_dump[dmode], td.ext[0] * dl.cw);
         }
+        td.thr0 = -1e300; td.thr2 = 1e300;
+        if (td.dense && dense_ct(td.dense) == 2) {
+            // intervals of leg n in order: tile 0 only, ..., tile 1 only (an interval i holds t_i < r <= t_{i+1})
+            const double *tn = legn_knots[t];
+            auto tiles_of = [&](int i) {
+                const int f = i - 3 - td.lo[2], n0 = std::max(f, 0), n1 = std::min(f + 3, td.ext[2] - 1);
+                if (n0 > n1) return 0;
+                return ((n0 * td.ext[1]) < 16 ? 1 : 0) | (((n1 + 1) * td.ext[1] - 1) >= 16 ? 2 : 0);
+            };
+            const int i_lo = 3, i_hi = td.leg[2].nk - 5;
+            int i0 = i_lo - 1, i2 = i_hi + 1;
+            while (i0 + 1 <= i_hi && !(tiles_of(i0 + 1) & 2)) i0++;      // last interval of the leading run without tile 1
+            while (i2 - 1 >= i_lo && !(tiles_of(i2 - 1) & 1)) i2--;      // first interval of the trailing run without tile 0
+            if (i0 >= i_lo) td.thr0 = tn[i0 + 1];
+            if (i2 <= i_hi) td.thr2 = tn[i2];
+        }
         b->modes |= 1 << (td.dense ? td.dense : td.nsrc == 1 ? (td.ncol > WAVE ? 2 : 1) : (td.nsrc == 2 ? (td.ncol > WAVE ? 4 : 3) : 5));
         for (auto &v : per_col) for (int k = 0; k < td.nsrc; k++) {
             int sp = k < (int)v.size() ? v[k] : -1;
             colsrc.push_back(sp);
-            // offset inside one component's dumped rows: row l (width cw), column (m, n)
+            // offset inside one component's dumped rows: row l (width cw), columns n-major (n * ext_m + m)
             dsrc.push_back(sp < 0 || !td.dense ? -1
-                           : ((sp & 255) - td.lo[0]) * dl.cw + (((sp >> 8) & 255) - td.lo[1]) * td.ext[2] + (((sp >> 16) & 255) - td.lo[2]));
+                           : ((sp & 255) - td.lo[0]) * dl.cw + (((sp >> 16) & 255) - td.lo[2]) * td.ext[1] + (((sp >> 8) & 255) - td.lo[1]));
         }
     }
     std::sort(bounds.begin(), bounds.end());
@@ -777,7 +795,7 @@ extern "C" int uf3_featurize_dev(uf3_basis *b, const uf3_frames *fr, const doubl
                 bool found = false;
                 if (dense_mode) {
                     const int stride = b->dense_stride[mode], dump = b->dense_dump[mode];
-                    const int nrec_max = std::max(4, std::min(DENSE_NREC, 1200 / stride));
+                    const int nrec_max = std::max(4, std::min(DENSE_NREC, 1200 / stride)) & ~1;     // even: a step is two records
                     auto stage_for = [&](int nr) { return std::max(dump, nr * stride); };
                     A.dense_nrec = nrec_max; A.dense_stage = stage_for(nrec_max);
                     if (mode <= 7 && !getenv("UF3_NO_OCC3")) {
@@ -785,7 +803,7 @@ extern "C" int uf3_featurize_dev(uf3_basis *b, const uf3_frames *fr, const doubl
                         // workgroup onto the CU -- the kernel is latency-bound.  Three workgroups per CU need <= 52 KB each
                         // (LDS is granted in coarse granules: 53 KB did not fit).  Candidates in order of preference: more
                         // records per pass first, tables in LDS before tables in HBM
-                        const int tries[3] = {nrec_max, std::min(nrec_max, 18), std::min(nrec_max, 15)};
+                        const int tries[3] = {nrec_max, std::min(nrec_max, 18), std::min(nrec_max, 14)};
                         const size_t budget = 52 * 1024;
                         const bool dsrc_allowed = A.dsrc_lds, recs_allowed = !getenv("UF3_NO_LDS_RECS");
                         for (int q = 0; q < 12 && !found; q++) {

@@ -631,46 +631,52 @@ struct DenseLane {
     int bM[CT], bN[CT];      // column (m, n) of column tile ct: M entry, N entry
 };
 
-template <bool MASK, int RT, int CT>
-__device__ __forceinline__ void dense_step(const double *rec, bool live, const DenseLane<RT, CT> &o, double4_t (&acc)[RT][CT]) {
+// one step = two staged records (four K slots); TMASK: the column tiles the records of this step can touch
+template <int TMASK, int RT, int CT>
+__device__ __forceinline__ void dense_step(const double *rec, const DenseLane<RT, CT> &o, double4_t (&acc)[RT][CT]) {
     // all operand reads go out before anything waits on them
     double la[RT], da[RT], mb[CT], nb[CT];
+    constexpr int N_READS = 2 * (RT + __builtin_popcount(TMASK));
 #pragma unroll
     for (int rt = 0; rt < RT; rt++) { la[rt] = rec[o.aL[rt]]; da[rt] = rec[o.aD[rt]]; }
 #pragma unroll
-    for (int ct = 0; ct < CT; ct++) { mb[ct] = rec[o.bM[ct]]; nb[ct] = rec[o.bN[ct]]; }
-    __builtin_amdgcn_sched_group_barrier(0x100, 2 * (RT + CT), 0);                        // DS reads
+    for (int ct = 0; ct < CT; ct++)
+        if ((TMASK >> ct) & 1) { mb[ct] = rec[o.bM[ct]]; nb[ct] = rec[o.bN[ct]]; }
+    __builtin_amdgcn_sched_group_barrier(0x100, N_READS, 0);                              // DS reads
     double a[RT], b[CT];
 #pragma unroll
-    for (int rt = 0; rt < RT; rt++) { a[rt] = la[rt] * da[rt]; if (MASK) a[rt] = live ? a[rt] : 0.0; }
+    for (int rt = 0; rt < RT; rt++) a[rt] = la[rt] * da[rt];
 #pragma unroll
-    for (int ct = 0; ct < CT; ct++) { b[ct] = mb[ct] * nb[ct]; if (MASK) b[ct] = live ? b[ct] : 0.0; }
+    for (int ct = 0; ct < CT; ct++) if ((TMASK >> ct) & 1) b[ct] = mb[ct] * nb[ct];
 #pragma unroll
     for (int rt = 0; rt < RT; rt++)
 #pragma unroll
-        for (int ct = 0; ct < CT; ct++) acc[rt][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[rt], b[ct], acc[rt][ct], 0, 0, 0);
+        for (int ct = 0; ct < CT; ct++)
+            if ((TMASK >> ct) & 1) acc[rt][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[rt], b[ct], acc[rt][ct], 0, 0, 0);
 }
 
-// n_staged records (two K slots each) of the stage into the accumulators, two records per step.  STRIDE != 0: the
+// staged records [r0, r1) (both even; two K slots each) into the accumulators, two records per step.  STRIDE != 0: the
 // record stride is a compile-time constant, so the unrolled steps address their operands with immediate offsets
 // (one address update per operand and trip instead of one per operand and step).
-template <int RT, int CT, int STRIDE>
-__device__ __forceinline__ void dense_accumulate(const double *stage, int rt_stride, int n_staged, const DenseLane<RT, CT> &o,
+template <int TMASK, int RT, int CT, int STRIDE>
+__device__ __forceinline__ void dense_accumulate(const double *stage, int rt_stride, int r0, int r1, const DenseLane<RT, CT> &o,
                                                  double4_t (&acc)[RT][CT]) {
     const int stride = STRIDE ? STRIDE : rt_stride;
     const int half = lane_id() >> 5;                          // which record of the step this lane's K slot belongs to
-    const double *rec = stage + (size_t)half * stride;
-    const int n_full = n_staged & ~1;
-    int q = 0;
+    const double *rec = stage + (size_t)(r0 + half) * stride;
+    int q = r0;
     if (STRIDE) {
-        for (; q + 8 <= n_full; q += 8, rec += 8 * stride) {
+        for (; q + 8 <= r1; q += 8, rec += 8 * stride) {
 #pragma unroll
-            for (int u = 0; u < 4; u++) dense_step<false, RT, CT>(rec + 2 * u * stride, true, o, acc);
+            for (int u = 0; u < 4; u++) dense_step<TMASK, RT, CT>(rec + 2 * u * stride, o, acc);
+        }
+        if (q + 4 <= r1) {
+#pragma unroll
+            for (int u = 0; u < 2; u++) dense_step<TMASK, RT, CT>(rec + 2 * u * stride, o, acc);
+            q += 4; rec += 4 * stride;
         }
     }
-    for (; q < n_full; q += 2, rec += 2 * stride) dense_step<false, RT, CT>(rec, true, o, acc);
-    // odd count: the lanes of the missing record read record 0 (whatever lies behind the stage need not be finite)
-    if (q < n_staged) dense_step<true, RT, CT>(half == 0 ? rec : stage, half == 0, o, acc);
+    for (; q < r1; q += 2, rec += 2 * stride) dense_step<TMASK, RT, CT>(rec, o, acc);
 }
 
 template <bool WANT_E, bool WANT_F, int MODE>
@@ -692,7 +698,7 @@ __device__ __forceinline__ void trio_block_mfma(const FeatArgs &A, const BasisDe
     const DenseLayout dl = dense_layout(ext_l, ext_m, ext_n);
     const int r16 = lane & 15, slot = (lane >> 4) & 1;
     // per-lane operand offsets (small quotients by multiply-shift, exact for dividends < 4096 and divisors <= 64)
-    const int inv_l = (65536 + ext_l - 1) / ext_l, inv_n = (65536 + ext_n - 1) / ext_n;      // wave-uniform
+    const int inv_l = (65536 + ext_l - 1) / ext_l, inv_m = (65536 + ext_m - 1) / ext_m;      // wave-uniform
     DenseLane<RT, CT> o;
 #pragma unroll
     for (int rt = 0; rt < RT; rt++) {
@@ -710,9 +716,9 @@ __device__ __forceinline__ void trio_block_mfma(const FeatArgs &A, const BasisDe
     }
 #pragma unroll
     for (int ct = 0; ct < CT; ct++) {
-        const int col = ct * 16 + r16;
-        const int pm = (col * inv_n) >> 16, pn = col - pm * ext_n;
-        const bool ok = pm < ext_m;
+        const int col = ct * 16 + r16;                       // columns n-major: col = n * ext_m + m
+        const int pn = (col * inv_m) >> 16, pm = col - pn * ext_m;
+        const bool ok = pn < ext_n;
         o.bM[ct] = ok ? dl.oM + 2 * pm + slot : dl.oZ;
         o.bN[ct] = ok ? dl.oN + 2 * pn + slot : dl.oZ;
     }
@@ -727,6 +733,13 @@ __device__ __forceinline__ void trio_block_mfma(const FeatArgs &A, const BasisDe
     const int w_off = leg == 0 ? 0 : (leg == 1 ? dl.oM : dl.oN);
     const int w_ext = leg == 0 ? ext_l : (leg == 1 ? ext_m : ext_n), w_lo = leg == 0 ? lo_l : (leg == 1 ? lo_m : lo_n);
     const int n_clear = (dl.oD / 2 + 2) / 3;                             // window pairs each of a record's lanes clears
+    const int n_clear_pad = ((dl.oZ + 2) / 2 + 2) / 3;                   // ... of a padding record (the whole record)
+    // Two column tiles (the reference's default trims): a record touches 4 consecutive n bins, i.e. only tile 0, only
+    // tile 1 or both (columns are n-major), decided by the knot interval of r_n: r_n <= thr0 / r_n > thr2 / else.  The
+    // walk sorts its triplets by that class, and the steps of a pass that hold only records of class 0 (2) skip the MFMA
+    // of tile 1 (0).
+    constexpr bool SPLIT = WANT_F && CT == 2;
+    const double thr0 = td->thr0, thr2 = td->thr2;
     double4_t acc[RT][CT];
 #pragma unroll
     for (int rt = 0; rt < RT; rt++)
@@ -737,8 +750,8 @@ __device__ __forceinline__ void trio_block_mfma(const FeatArgs &A, const BasisDe
     const double lo_r[3] = {td->leg[0].t0, td->leg[1].t0, td->leg[2].t0};
     const double hi_r[3] = {td->leg[0].tlast, td->leg[1].tlast, td->leg[2].tlast};
     for (int p0 = 0; p0 < k.n_items; p0 += batch) {
-        // ---- walk: one triplet per lane, geometry to LDS sorted by class ------------------------------------
-        int n_valid;
+        // ---- walk: one triplet per lane, geometry to LDS (sorted by tile class) ---------------------------------
+        int n_valid, n_cls0 = 0, n_cls01 = 0;
         {
             TripletGeom tg;
             bool valid = lane < batch && p0 + lane < k.n_items;
@@ -747,17 +760,24 @@ __device__ __forceinline__ void trio_block_mfma(const FeatArgs &A, const BasisDe
             if (valid)                   // (bounds hoisted; `&`, not `&&`: no branch, no memory access per clause)
                 valid = (tg.rl > lo_r[0]) & (tg.rl < hi_r[0]) & (tg.rm > lo_r[1]) & (tg.rm < hi_r[1]) &
                         (tg.rn > lo_r[2]) & (tg.rn < hi_r[2]);
-            const bool is0 = valid && tg.centre, is1 = valid && !tg.centre && tg.first, is2 = valid && !tg.centre && !tg.first;
-            const unsigned long long m0 = __ballot(is0), m1 = __ballot(is1), m2 = __ballot(is2);
-            const int n0 = __popcll(m0), n1 = __popcll(m1);
-            n_valid = n0 + n1 + __popcll(m2);
+            int rank;
+            if (SPLIT) {
+                const bool is0 = valid && tg.rn <= thr0, is2 = valid && tg.rn > thr2, is1 = valid && !is0 && !is2;
+                const unsigned long long m0 = __ballot(is0), m1 = __ballot(is1), m2 = __ballot(is2);
+                n_cls0 = __popcll(m0); n_cls01 = n_cls0 + __popcll(m1);
+                n_valid = n_cls01 + __popcll(m2);
+                rank = is0 ? mbcnt(m0) : (is1 ? n_cls0 + mbcnt(m1) : n_cls01 + mbcnt(m2));
+            } else {
+                const unsigned long long mv = __ballot(valid);
+                n_valid = __popcll(mv);
+                rank = mbcnt(mv);
+            }
             if (valid) {
-                const int rank = is0 ? mbcnt(m0) : (is1 ? n0 + mbcnt(m1) : n0 + n1 + mbcnt(m2));
                 double *gq = w.geo + rank;
                 gq[0] = tg.rl; gq[GEO_N] = tg.rm; gq[2 * GEO_N] = tg.rn;
                 if (WANT_F) {
                     gq[3 * GEO_N] = tg.a3[0]; gq[4 * GEO_N] = tg.a3[1]; gq[5 * GEO_N] = tg.a3[2];
-                    ((int2 *)(w.geo + 6 * GEO_N))[rank] = make_int2(tg.i1 | (tg.i2 << 16), is0 ? 0 : (is1 ? 1 : 2));
+                    ((int2 *)(w.geo + 6 * GEO_N))[rank] = make_int2(tg.i1 | (tg.i2 << 16), tg.centre ? 0 : (tg.first ? 1 : 2));
                 }
             }
         }
@@ -766,7 +786,11 @@ __device__ __forceinline__ void trio_block_mfma(const FeatArgs &A, const BasisDe
         // ---- staging passes: lane (record li, leg) evaluates one leg and scatters it into the window ---------
         for (int base = 0; base < n_valid; base += nrec) {
             const int n_part = min(nrec, n_valid - base);
-            if (li < n_part && !(A.skip & 16)) {
+            // staged records, padded with an all-zero record to an even count (a step is two records)
+            const int n_real = WANT_F ? n_part : (n_part + 1) >> 1, n_staged = n_real + (n_real & 1);
+            const bool mine = li < n_part && !(A.skip & 16);
+            const bool pad = (n_real & 1) && (WANT_F ? li == n_part : ((li >> 1) == n_real && li >= n_part)) && li < nrec + 1;
+            if (mine) {
                 const int gi = base + li;
                 const double x = w.geo[leg * GEO_N + gi];
                 KnotRec kr;
@@ -803,7 +827,7 @@ __device__ __forceinline__ void trio_block_mfma(const FeatArgs &A, const BasisDe
                     if (leg == 1) *(double2 *)(rec + dl.oZ) = zz;
                 } else {
                     double *rec = w.stage + (size_t)(li >> 1) * dl.stride;
-                    const int s = li & 1;
+                    const int sl2 = li & 1;
                     for (int q = 0; q < n_clear; q++) {      // (both records of the pair clear: all clears precede the scatters)
                         const int sl = leg * n_clear + q;
                         if (2 * sl < dl.oD) *(double2 *)(rec + 2 * sl) = zz;
@@ -811,23 +835,38 @@ __device__ __forceinline__ void trio_block_mfma(const FeatArgs &A, const BasisDe
 #pragma unroll
                     for (int q = 0; q < 4; q++) {
                         const unsigned ws = (unsigned)(first + q - w_lo);
-                        if (ws < (unsigned)w_ext) rec[w_off + 2 * ws + s] = v[q];
+                        if (ws < (unsigned)w_ext) rec[w_off + 2 * ws + sl2] = v[q];
                     }
-                    if (leg == 0) rec[dl.oD + 6 + s] = 1.0;
-                    if (leg == 1 && s == 0) *(double2 *)(rec + dl.oZ) = zz;
+                    if (leg == 0) rec[dl.oD + 6 + sl2] = 1.0;
+                    if (leg == 1 && sl2 == 0) *(double2 *)(rec + dl.oZ) = zz;
+                }
+            } else if (pad && !(A.skip & 16)) {
+                double *rec = w.stage + (size_t)(WANT_F ? li : li >> 1) * dl.stride;
+                const double2 zz = {0.0, 0.0};
+                for (int q = 0; q < n_clear_pad; q++) {
+                    const int sl = leg * n_clear_pad + q;
+                    if (2 * sl < dl.oZ + 2) *(double2 *)(rec + 2 * sl) = zz;
                 }
             }
+            // steps (two records) of class 0 only: [0, e_a); of class 2 only: [s_c, n_staged) (the padding record is neutral)
+            const int e_a = SPLIT ? max(0, min(n_part, n_cls0 - base)) & ~1 : 0;
+            const int s_c = SPLIT ? (max(0, min(n_part, n_cls01 - base)) + 1) & ~1 : n_staged;
             wave_sync();
             pc.lap(4);
             if (!(A.skip & 8)) {
-                const int n_staged = WANT_F ? n_part : (n_part + 1) >> 1;
-                switch (dl.stride) {       // wave-uniform
-                    case (MODE == 6 ? 32 : (MODE == 7 ? 40 : (MODE == 8 ? 48 : 56))):
-                        dense_accumulate<RT, CT, (MODE == 6 ? 32 : (MODE == 7 ? 40 : (MODE == 8 ? 48 : 56)))>(w.stage, dl.stride, n_staged, o, acc);
-                        break;
-                    default:
-                        dense_accumulate<RT, CT, 0>(w.stage, dl.stride, n_staged, o, acc);
-                }
+                constexpr int S0 = MODE == 6 ? 32 : (MODE == 7 ? 40 : (MODE == 8 ? 48 : 56));    // the usual stride of the mode
+                constexpr int ALL = (1 << CT) - 1;
+                if (dl.stride == S0) {       // wave-uniform
+                    if (SPLIT) {
+                        dense_accumulate<1, RT, CT, S0>(w.stage, S0, 0, e_a, o, acc);
+                        dense_accumulate<ALL, RT, CT, S0>(w.stage, S0, e_a, s_c, o, acc);
+                        dense_accumulate<(CT == 2 ? 2 : ALL), RT, CT, S0>(w.stage, S0, s_c, n_staged, o, acc);
+                    } else dense_accumulate<ALL, RT, CT, S0>(w.stage, S0, 0, n_staged, o, acc);
+                } else if (SPLIT) {
+                    dense_accumulate<1, RT, CT, 0>(w.stage, dl.stride, 0, e_a, o, acc);
+                    dense_accumulate<ALL, RT, CT, 0>(w.stage, dl.stride, e_a, s_c, o, acc);
+                    dense_accumulate<(CT == 2 ? 2 : ALL), RT, CT, 0>(w.stage, dl.stride, s_c, n_staged, o, acc);
+                } else dense_accumulate<ALL, RT, CT, 0>(w.stage, dl.stride, 0, n_staged, o, acc);
             }
             wave_sync();
             pc.lap(5);
