@@ -24,7 +24,12 @@
  *   - "_dev" entries take HBM pointers for the bulk arrays and enqueue on the ctx
  *     stream without synchronising; the plain entries take host pointers, copy in
  *     and out, and synchronise before returning.  Frame metadata (offsets, cells,
- *     pbc) is always host memory: it is a few hundred bytes per frame;
+ *     pbc) is always host memory: it is a few hundred bytes per frame.
+ *     uf3_featurize_dev synchronises only while a context is still learning its
+ *     neighbour capacities (the first calls); afterwards the kernels' status words
+ *     travel to pinned host memory behind the launches and are looked at by the next
+ *     call on the context and by uf3_ctx_synchronize, which then report
+ *     UF3_ESPECIES / UF3_EINVAL / UF3_ERETRY for the EARLIER call;
  *   - all floating point data is IEEE double, C-contiguous; positions in Angstrom.
  */
 #ifndef UF3_HIP_H
@@ -46,7 +51,10 @@ enum {
     UF3_ESPECIES = 2,   /* a frame contains an element outside the basis (process.py:321-330) */
     UF3_EHIP = 3,       /* HIP runtime error */
     UF3_ENOMEM = 4,
-    UF3_EOVERFLOW = 5   /* internal capacity exceeded after retries */
+    UF3_EOVERFLOW = 5,  /* internal capacity exceeded after retries */
+    UF3_ERETRY = 6      /* an earlier asynchronous uf3_featurize_dev call ran with neighbour capacities that turned
+                           out too small: its outputs (and whatever was derived from them) are invalid; the
+                           capacities have been raised -- repeat the work since the last uf3_ctx_synchronize */
 };
 
 /* Flat description of a BSplineBasis (host memory, copied by uf3_basis_create). */
@@ -87,6 +95,8 @@ void uf3_ctx_destroy(uf3_ctx *ctx);
  * default).  Until this is called the ctx uses a private non-blocking stream, which is NOT ordered with
  * work the caller enqueues elsewhere: callers of the _dev entries should always set their stream. */
 int uf3_ctx_set_stream(uf3_ctx *ctx, void *hip_stream);
+/* back to the ctx's private stream (what a temporary user of uf3_ctx_set_stream does when it is done) */
+int uf3_ctx_use_own_stream(uf3_ctx *ctx);
 int uf3_ctx_synchronize(uf3_ctx *ctx);
 const char *uf3_last_error(const uf3_ctx *ctx);
 /* timing of the dominant kernel: (re)start / read accumulated HIP-event time in ms and launches */

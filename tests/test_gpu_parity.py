@@ -169,7 +169,7 @@ def test_oracle_parity_mid_size_configs():
 
 
 def test_full_size_properties_10k_atoms():
-    """configs[3]-sized frame: size-independent properties instead of the (slow) oracle."""
+    """configs[3]-sized frame (the bench workload): size-independent properties and the oracle on every row."""
     atoms, basis = synthetic.config_c4(binary=True)
     assert len(atoms) == 10000
     fz = process.BasisFeaturizer(basis)
@@ -198,9 +198,10 @@ def test_full_size_properties_10k_atoms():
                                         forces=False)[0][0])
     fd = -(rows[0] - rows[1]) / (2 * h)
     assert np.abs(fd - x_f[1234, 0]).max() < 1e-5 * max(1.0, np.abs(x_f[1234, 0]).max())
-    # oracle on a sample: energy row of the whole frame (cheap) matches
-    ref = O.featurize(O.OracleBasis(basis), atoms, forces=False)["xe"]
-    assert rel_err(x_e[0], ref) < TOL
+    # the whole frame against the oracle: energy row and all 30 000 force rows (2.4 s of CPU)
+    ref = O.featurize(O.OracleBasis(basis), atoms)
+    assert rel_err(x_e[0], ref["xe"]) < TOL
+    assert rel_err(x_f, ref["xf"].reshape(x_f.shape)) < TOL
 
 
 def test_unknown_species_raises():
@@ -236,6 +237,112 @@ def test_device_resident_fit_pipeline_matches_host_rows():
     # the planted model is recovered wherever the data reach (short-range pair columns see no data)
     pred, true = x_f.reshape(-1, basis.n_feats) @ model.coefficients, x_f.reshape(-1, basis.n_feats) @ c_true
     assert np.abs(pred - true).max() < 2e-2 * np.abs(true).max()
+
+
+def test_config4_fit_in_chunks_10k_atom_tungsten_frames():
+    """BASELINE config 4 on one GPU's share: 10 000-atom W frames (F = 73) x 66 through the device-resident
+    accumulator in three chunks == the oracle's fit on the downloaded rows (least_squares.py:274-321)."""
+    from uf3_amd import pipeline
+    basis = synthetic.notebook_basis(['W'])
+    n_frames = 66
+    frames = [synthetic.config_c4(frame=k, binary=False)[0] for k in range(n_frames)]
+    assert len(frames[0]) == 10000 and basis.n_feats == 73
+    fz = process.BasisFeaturizer(basis)
+    reg = basis.get_regularization_matrix(ridge_1b=1e-8, ridge_2b=0.0, ridge_3b=1e-8, curvature_2b=1e-8, curvature_3b=0.0)
+    x_e, x_f, off = fz.featurize_frames(frames)
+    x_f = x_f.reshape(-1, basis.n_feats)
+    rng = np.random.default_rng(7)
+    c_true = rng.normal(0, 1, basis.n_feats)
+    c_true[basis.col_idx] = 0
+    energies = x_e @ c_true + rng.normal(0, 1e-3, n_frames)
+    forces_flat = x_f @ c_true + rng.normal(0, 1e-3, len(x_f))
+    forces = [forces_flat[3 * off[k]:3 * off[k + 1]].reshape(-1, 3) for k in range(n_frames)]
+    model = ls.WeightedLinearModel(basis, regularizer=reg)
+    acc = pipeline.DeviceFitAccumulator(model, fz, max_atoms_per_chunk=250000)
+    acc.add_frames(frames, energies, forces)
+    assert acc.n_chunks == 3
+    pieces = acc.pieces()
+    model.fit_from_pieces(pieces, weight=0.3)
+    n = x_e[:, :1].sum(axis=1)
+    ref = O.fit(basis, reg, x_e / n[:, None], energies / n, x_f, forces_flat, weight=0.3)
+    for key in ("gram_e", "gram_f", "ord_e", "ord_f"):
+        assert rel_err(pieces[key], ref[key]) < 1e-9, key
+    pred = model.predict(x_f)
+    assert rel_err(pred, x_f @ ref["coefficients"]) < 1e-6
+    assert np.abs(pred - x_f @ c_true).max() < 2e-2 * np.abs(x_f @ c_true).max()
+
+
+def test_ragged_batch_of_large_frames_equals_per_frame_calls():
+    """32 frames of 1 000 - 10 000 atoms (mixed sizes, W/Mo) in one batch == one call per frame."""
+    basis = synthetic.notebook_basis(['Mo', 'W'])
+    shapes = [(5, 10, 10), (8, 8, 8), (10, 20, 25), (6, 9, 14), (10, 10, 13), (7, 7, 11), (9, 12, 17), (10, 15, 20)]
+    frames = [synthetic.lattice_frame("bcc", shapes[k % len(shapes)], 3.165, [42, 74], 800 + k) for k in range(32)]
+    assert min(len(f) for f in frames) >= 1000 and max(len(f) for f in frames) == 10000
+    fz = process.BasisFeaturizer(basis)
+    x_e, x_f, off = fz.featurize_frames(frames, max_bytes=12 << 30)
+    for k in (0, 2, 5, 13, 31):
+        y_e, y_f, _ = fz.featurize_frames([frames[k]])
+        assert rel_err(x_e[k], y_e[0]) < 1e-12 and rel_err(x_f[off[k]:off[k + 1]], y_f) < 1e-12
+    ref = O.featurize(O.OracleBasis(basis), frames[3])
+    assert rel_err(x_e[3], ref["xe"]) < TOL and rel_err(x_f[off[3]:off[4]], ref["xf"].reshape(-1, 3, basis.n_feats)) < TOL
+
+
+def test_bases_and_featurizers_stay_picklable_and_follow_basis_updates():
+    """Device tables live outside the objects: pickling / deep copies work after GPU use, and a change of
+    the knots retires the tables built for the old ones."""
+    import copy
+    import pickle
+    atoms, basis = synthetic.config_c2()
+    fz = process.BasisFeaturizer(basis)
+    x_e, _, _ = fz.featurize_frames([atoms], forces=False)
+    fz2 = pickle.loads(pickle.dumps(fz))
+    fz3 = copy.deepcopy(fz)
+    assert rel_err(fz2.featurize_frames([atoms], forces=False)[0], x_e) < 1e-13
+    assert rel_err(fz3.featurize_frames([atoms], forces=False)[0], x_e) < 1e-13
+    # same object, new knots: the rows must be those of a basis built with the new knots from scratch
+    pair = basis.interactions_map[2][0]
+    basis.update_knots(r_max_map={pair: 4.8})
+    basis.update_basis_functions()
+    fresh = synthetic.notebook_basis(['W'])
+    fresh.update_knots(r_max_map={pair: 4.8})
+    fresh.update_basis_functions()
+    y_e = fz.featurize_frames([atoms], forces=False)[0]
+    z_e = process.BasisFeaturizer(fresh).featurize_frames([atoms], forces=False)[0]
+    assert rel_err(y_e, z_e) < 1e-13 and rel_err(y_e, x_e) > 1e-3
+
+
+def test_asynchronous_featurize_reports_a_capacity_overflow_afterwards():
+    """``uf3_featurize_dev`` does not wait once a context knows its capacities; a batch that needs longer lists than
+    any before is flagged by the next synchronisation (UF3_ERETRY) and succeeds when repeated."""
+    import ctypes as C
+    import torch
+    dev = torch.device("cuda", 0)
+    ctx = _lib.Context(0)                                   # a context of its own: capacities start from scratch
+    basis = synthetic.notebook_basis(['W'])
+    db = _lib.DeviceBasis(basis, ctx)
+    ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+
+    def run(frames):
+        batch = _lib.FrameBatch(frames)
+        d_pos, d_z = torch.from_numpy(batch.pos).to(dev), torch.from_numpy(batch.z).to(dev)
+        x_e = torch.empty((batch.n_frames, db.n_feat), dtype=torch.float64, device=dev)
+        x_f = torch.empty((batch.n_atoms, 3, db.n_feat), dtype=torch.float64, device=dev)
+        ctx.check(ctx.lib.uf3_featurize_dev(db.handle, C.byref(batch.struct), C.c_void_p(d_pos.data_ptr()),
+                                            C.c_void_p(d_z.data_ptr()), C.c_void_p(x_e.data_ptr()), C.c_void_p(x_f.data_ptr())))
+        return x_e, x_f
+
+    sparse = [synthetic.lattice_frame("bcc", (4, 4, 4), 3.165, [74], 90 + k) for k in range(2)]
+    dense = [synthetic.lattice_frame("bcc", (5, 5, 5), 2.4, [74], 95, rattle=0.05)]         # third shell inside the 3-body range
+    run(sparse); ctx.synchronize()                          # learns the capacities (synchronous calls)
+    run(sparse); ctx.synchronize()
+    run(dense)                                              # asynchronous, lists too short
+    with pytest.raises(_lib.RetryError):
+        ctx.synchronize()
+    x_e, x_f = run(dense)                                   # capacities were raised: now it fits
+    ctx.synchronize()
+    ref = O.featurize(O.OracleBasis(basis), dense[0])
+    assert rel_err(x_e[0].cpu().numpy(), ref["xe"]) < TOL
+    assert rel_err(x_f.cpu().numpy().reshape(ref["xf"].shape), ref["xf"]) < TOL
 
 
 def test_device_entries_follow_the_callers_stream():
@@ -665,7 +772,7 @@ def _fresh_rows(basis, frames, **env):
     old = {k: os.environ.get(k) for k in env}
     os.environ.update(env)
     try:
-        basis.__dict__.pop("_device_cache", None)
+        _lib.drop_device_basis(basis)
         fz = process.BasisFeaturizer(basis)
         _, db = fz._dev()
         modes = db.featurizer_modes
@@ -676,7 +783,7 @@ def _fresh_rows(basis, frames, **env):
                 os.environ.pop(k, None)
             else:
                 os.environ[k] = v
-        basis.__dict__.pop("_device_cache", None)
+        _lib.drop_device_basis(basis)
     return x_e, x_f, modes
 
 

@@ -4,6 +4,7 @@ import os
 import socket
 
 import numpy as np
+import pytest
 import torch.multiprocessing as mp
 
 from _util import GOLDEN, basis_from_meta
@@ -90,6 +91,73 @@ def test_two_rank_decomposed_frame_evaluation(tmp_path):
         assert abs(d["e"] - d["e_ref"]) < 1e-12
         assert np.array_equal(d["f"], d["f_ref"])                # each row comes from exactly one rank (+ zeros)
         assert np.allclose(d["v"], d["v_ref"], rtol=1e-12, atol=1e-12)
+
+
+def _uneven_worker(rank, world, port, out_dir):
+    """rank 1 holds no force rows (as a rank with an empty shard would): every rank must still solve the E + F system"""
+    import torch
+    import torch.distributed as dist
+    from uf3_amd import parallel
+    from uf3_amd.regression import least_squares as ls
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    d = np.load(os.path.join(GOLDEN, "fit_case.npz"))
+    basis = basis_from_meta(json.loads(str(d["meta"])))
+    model = ls.WeightedLinearModel(basis, regularizer=d["regularizer"])
+    mask, fc, ci = model.mask, model.frozen_c, model.col_idx
+    n_cols = model.n_feats - len(ci)
+    pieces = {}
+    if rank == 0:
+        pieces = model_pieces_numpy(ls, d, mask, fc, ci, slice(None), slice(None))
+    else:
+        z = np.zeros
+        pieces = dict(gram_e=z((n_cols, n_cols)), ord_e=z(n_cols), m_e=z(3))        # no force keys at all
+    total = parallel.allreduce_pieces(pieces, n_cols)
+    assert "gram_f" in total
+    model.fit_from_pieces(total, weight=float(d["kappa"][0]))
+    # the packed flavour (what pipeline.fit_frames reduces): a host tensor under gloo
+    flat = parallel.allreduce_packed(torch.from_numpy(parallel.pack_pieces(pieces, n_cols)))
+    assert np.allclose(parallel.unpack_pieces(flat.numpy(), n_cols)["gram_f"], total["gram_f"])
+    np.save(os.path.join(out_dir, f"uneven_{rank}.npy"), model.coefficients)
+    dist.destroy_process_group()
+
+
+def model_pieces_numpy(ls, d, mask, fc, ci, rows_e, rows_f):
+    xe, ye = ls.freeze_columns(d["x_e"][rows_e], d["y_e"][rows_e], mask, fc, ci)
+    xf, yf = ls.freeze_columns(d["x_f"][rows_f], d["y_f"][rows_f], mask, fc, ci)
+    return dict(gram_e=xe.T @ xe, ord_e=xe.T @ ye, gram_f=xf.T @ xf, ord_f=xf.T @ yf,
+                m_e=ls.moments(ye), m_f=ls.moments(d["y_f"][rows_f]))
+
+
+def test_a_rank_without_force_rows_solves_the_same_system(tmp_path):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_uneven_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    d = np.load(os.path.join(GOLDEN, "fit_case.npz"))
+    c0, c1 = np.load(tmp_path / "uneven_0.npy"), np.load(tmp_path / "uneven_1.npy")
+    assert np.array_equal(c0, c1)
+    assert np.allclose(c0, d["coefficients"], rtol=1e-6, atol=1e-8)
+
+
+def test_balanced_shards():
+    from uf3_amd import parallel
+    from uf3_amd.data.atoms import Atoms
+    w = [1, 1, 1, 1, 8, 1, 1, 1, 1]
+    parts = [parallel.shard_balanced(w, r, 2) for r in range(2)]
+    assert parts[0][0] == 0 and parts[0][1] == parts[1][0] and parts[1][1] == len(w)
+    assert abs(sum(w[parts[0][0]:parts[0][1]]) - sum(w[parts[1][0]:parts[1][1]])) <= 8
+    # every item goes to exactly one rank, blocks are contiguous and in rank order, empty weights fall back to counts
+    for world in (1, 3, 4, 8):
+        cuts = [parallel.shard_balanced(w, r, world) for r in range(world)]
+        assert cuts[0][0] == 0 and cuts[-1][1] == len(w) and all(a[1] == b[0] for a, b in zip(cuts, cuts[1:]))
+    assert parallel.shard_balanced([0, 0, 0, 0], 1, 2) == parallel.shard_range(4, 1, 2)
+    big = Atoms(numbers=[74] * 2000, positions=np.zeros((2000, 3)), cell=np.eye(3) * 31.65, pbc=True)
+    small = Atoms(numbers=[74] * 250, positions=np.zeros((250, 3)), cell=np.eye(3) * 15.825, pbc=True)
+    assert parallel.frame_work(big, 3.5) == pytest.approx(8 * parallel.frame_work(small, 3.5))     # same density
+    assert parallel.frame_work(small) == 250.0
 
 
 def test_shard_range_and_packing():

@@ -9,6 +9,7 @@ import sys
 import importlib.util
 import os
 import threading
+import weakref
 
 import numpy as np
 
@@ -17,7 +18,7 @@ LIB_PATH = os.environ.get("UF3_LIB_PATH", os.path.join(_HERE, "csrc", "libuf3hip
 
 EXPORTS = ["uf3_ctx_create", "uf3_ctx_destroy", "uf3_ctx_set_stream", "uf3_ctx_synchronize",
            "uf3_last_error", "uf3_ctx_timing_reset", "uf3_ctx_timing_read",
-           "uf3_basis_create", "uf3_basis_destroy", "uf3_basis_featurizer_modes",
+           "uf3_ctx_use_own_stream", "uf3_basis_create", "uf3_basis_destroy", "uf3_basis_featurizer_modes",
            "uf3_featurize", "uf3_featurize_dev", "uf3_gram", "uf3_gram_dev",
            "uf3_eval", "uf3_eval_dev", "uf3_eval_virial", "uf3_eval_virial_dev", "uf3_eval_atoms", "uf3_eval_atoms_dev",
            "uf3_neighbors_debug"]
@@ -35,6 +36,11 @@ class UF3Error(RuntimeError):
 
 class SpeciesError(UF3Error):
     """A frame contains an element outside the basis (UF3_ESPECIES)."""
+
+
+class RetryError(UF3Error):
+    """UF3_ERETRY: an earlier asynchronous ``uf3_featurize_dev`` call overflowed its neighbour capacities; its
+    outputs are invalid, the capacities have been raised: repeat the work since the last synchronisation."""
 
 
 class BasisSpec(C.Structure):
@@ -98,6 +104,7 @@ def load():
         lib.uf3_ctx_destroy.argtypes = [vp]
         lib.uf3_ctx_destroy.restype = None
         lib.uf3_ctx_set_stream.argtypes = [vp, vp]
+        lib.uf3_ctx_use_own_stream.argtypes = [vp]
         lib.uf3_ctx_synchronize.argtypes = [vp]
         lib.uf3_last_error.argtypes = [vp]
         lib.uf3_last_error.restype = C.c_char_p
@@ -144,10 +151,25 @@ class Context:
     def check(self, rc):
         if rc:
             msg = self.lib.uf3_last_error(self.handle).decode()
-            raise (SpeciesError if rc == 2 else UF3Error)(rc, msg)
+            raise {2: SpeciesError, 6: RetryError}.get(rc, UF3Error)(rc, msg)
 
     def set_stream(self, stream_ptr):
+        """Bind the context to a HIP stream (0 / None: the null stream); returns the stream bound before, so that
+        temporary users can put it back (``None`` before the first call = the context's own stream)."""
+        prev = getattr(self, "_stream", None)
         self.check(self.lib.uf3_ctx_set_stream(self.handle, C.c_void_p(stream_ptr or 0)))
+        self._stream = stream_ptr or 0
+        return prev
+
+    def use_own_stream(self):
+        self.check(self.lib.uf3_ctx_use_own_stream(self.handle))
+        self._stream = None
+
+    def restore_stream(self, prev):
+        if prev is None:
+            self.use_own_stream()
+        else:
+            self.set_stream(prev)
 
     def synchronize(self):
         self.check(self.lib.uf3_ctx_synchronize(self.handle))
@@ -258,14 +280,30 @@ class DeviceBasis:
             pass
 
 
+# Device tables are cached OUTSIDE the basis objects (ctypes handles cannot be pickled or deep-copied, and the
+# reference's objects travel through multiprocessing / joblib).  Weak keys: a table set dies with its basis.  A basis
+# bumps ``_tables_version`` whenever its knots / trims / templates change (BSplineBasis.update_knots,
+# update_basis_functions), which retires the tables built for the old state.
+_device_tables = weakref.WeakKeyDictionary()
+
+
 def device_basis(basis, ctx=None):
-    """Cached DeviceBasis of a BSplineBasis (re-created after fork / unpickling)."""
+    """Cached DeviceBasis of a BSplineBasis (re-created after fork, unpickling or a change of the basis)."""
     ctx = ctx or get_context()
-    cache = basis.__dict__.setdefault("_device_cache", {})
+    per_basis = _device_tables.get(basis)
+    if per_basis is None:
+        per_basis = _device_tables[basis] = {}
     key = (os.getpid(), ctx.device)
-    if key not in cache:
-        cache[key] = DeviceBasis(basis, ctx)
-    return cache[key]
+    version = getattr(basis, "_tables_version", 0)
+    hit = per_basis.get(key)
+    if hit is None or hit[0] != version:
+        hit = per_basis[key] = (version, DeviceBasis(basis, ctx))
+    return hit[1]
+
+
+def drop_device_basis(basis):
+    """Forget the device tables of a basis (they are rebuilt on the next use)."""
+    _device_tables.pop(basis, None)
 
 
 class FrameBatch:

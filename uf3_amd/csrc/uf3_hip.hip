@@ -60,6 +60,13 @@ struct uf3_ctx {
         gram_tiles, frag, dbg;
     int n3_cap = 0, cand_cap = 0;
     bool n3_tuned = false;           // capacity re-sized once to the lists actually seen
+    bool cand_tuned = false;         // a featurizer call has completed with the current candidate capacity
+    // status words of asynchronous featurizer calls: copied to pinned slots behind the launches, looked at later
+    struct Pending { hipEvent_t ev = nullptr; int cap = 0, cand = 0; bool has3 = false, live = false; };
+    enum { N_PENDING = 16 };
+    Pending pending_chk[N_PENDING];
+    PinBuf pin_flags;                // [N_PENDING][4] ints
+    int pending_head = 0;
     bool frag_ready = false;
     int32_t *d_stage_z = nullptr;       // species of the staged batch (tail of stage_pos)
     PinBuf pin_in, pin_geo, pin_out;    // positions + species | frame geometry + offsets | results
@@ -143,7 +150,8 @@ extern "C" void uf3_ctx_destroy(uf3_ctx *c) {
                   &c->key_out, &c->val_in, &c->val_out, &c->sort_tmp, &c->bin_start, &c->slots, &c->flags, &c->n3_cnt, &c->n3_int, &c->n3_dbl, &c->e_atom, &c->nbr_f, &c->coeff,
                   &c->stage_pos, &c->stage_z, &c->stage_out, &c->stage_out2, &c->gram_tiles, &c->frag, &c->dbg};
     for (Buf *b : all) b->release();
-    c->pin_in.release(); c->pin_geo.release(); c->pin_out.release();
+    c->pin_in.release(); c->pin_geo.release(); c->pin_out.release(); c->pin_flags.release();
+    for (auto &pd : c->pending_chk) if (pd.ev) hipEventDestroy(pd.ev);
     if (c->pin_in_done) hipEventDestroy(c->pin_in_done);
     if (c->pin_geo_done) hipEventDestroy(c->pin_geo_done);
     for (auto &v : c->pending) for (auto &p : v) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
@@ -157,12 +165,21 @@ extern "C" int uf3_ctx_set_stream(uf3_ctx *c, void *s) {
     return UF3_OK;
 }
 
+extern "C" int uf3_ctx_use_own_stream(uf3_ctx *c) {
+    if (!c) return fail(nullptr, UF3_EINVAL, "null ctx");
+    c->stream = c->own_stream;
+    return UF3_OK;
+}
+
 static int check_flags(uf3_ctx *c);
+static int poll_pending(uf3_ctx *c, bool wait);
 
 extern "C" int uf3_ctx_synchronize(uf3_ctx *c) {
     if (!c) return fail(nullptr, UF3_EINVAL, "null ctx");
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    int rc = poll_pending(c, true);
+    if (rc) return rc;
     return check_flags(c);
 }
 
@@ -561,6 +578,30 @@ static int check_flags(uf3_ctx *c) {
     return UF3_OK;
 }
 
+// Status words of earlier asynchronous featurizer calls (error flag | 3-body list length needed | candidates needed).
+// wait = false: only the slots whose copy has completed are looked at.  Returns the first problem found, once.
+static int poll_pending(uf3_ctx *c, bool wait) {
+    int rc = UF3_OK;
+    for (int q = 0; q < uf3_ctx::N_PENDING; q++) {
+        uf3_ctx::Pending &p = c->pending_chk[(c->pending_head + q) % uf3_ctx::N_PENDING];
+        if (!p.live) continue;
+        if (wait) { HIPCHK(c, hipEventSynchronize(p.ev)); }
+        else if (hipEventQuery(p.ev) != hipSuccess) continue;
+        p.live = false;
+        const int *fl = (const int *)c->pin_flags.p + 4 * ((c->pending_head + q) % uf3_ctx::N_PENDING);
+        if (fl[0] == 2 && !rc) rc = fail(c, UF3_ESPECIES, "frame contains an element outside the basis (earlier asynchronous call)");
+        else if (fl[0] == 1 && !rc) rc = fail(c, UF3_EINVAL, "atom too far outside the periodic cell (|wrap| > 250) (earlier asynchronous call)");
+        bool grown = false;
+        if (p.has3 && fl[1] > p.cap) { c->n3_cap = std::max(c->n3_cap, (fl[1] + 8 + 7) / 8 * 8); grown = true; }
+        if (fl[2] > p.cand) { c->cand_cap = std::max(c->cand_cap, (fl[2] + 16 + 7) / 8 * 8); grown = true; }
+        if (grown && !rc)
+            rc = fail(c, UF3_ERETRY, "an earlier asynchronous featurizer call overflowed its neighbour capacities: its outputs are "
+                                     "invalid; the capacities have been raised, repeat the work since the last synchronisation");
+    }
+    if (rc && c->flags.p) hipMemsetAsync(c->flags.p, 0, sizeof(int), c->stream);
+    return rc;
+}
+
 static int n3_alloc(uf3_ctx *c, int natoms, int cap, N3Lists &n3) {
     HIPCHK(c, c->n3_cnt.ensure(sizeof(int) * (size_t)natoms * (UF3_MAX_SPECIES + 2)));
     HIPCHK(c, c->n3_dbl.ensure(sizeof(N3Entry) * (size_t)natoms * cap));
@@ -730,6 +771,7 @@ extern "C" int uf3_featurize_dev(uf3_basis *b, const uf3_frames *fr, const doubl
     uf3_ctx *c = b->ctx;
     if (!d_pos || !d_z) return fail(c, UF3_EINVAL, "null positions / species");
     if (!d_xe && !d_xf) return UF3_OK;
+    { int rc0 = poll_pending(c, false); if (rc0) return rc0; }     // verdicts on earlier asynchronous calls that have arrived
     Prepared P;
     const bool old_n3 = getenv("UF3_SEPARATE_N3") != nullptr;     // debugging: lists from k_build_n3 instead
     int rc = prepare(b, fr, d_pos, d_z, old_n3, P);       // cell list only: MODE 0 builds the 3-body lists itself
@@ -868,6 +910,26 @@ extern "C" int uf3_featurize_dev(uf3_basis *b, const uf3_frames *fr, const doubl
             }
         }
         HIPCHK(c, hipGetLastError());
+        if ((!has3 || c->n3_tuned) && c->cand_tuned && !old_n3 && !getenv("UF3_SYNC_FEATURIZE")) {
+            // capacities known from earlier calls: do not wait.  The status words follow the launches into a pinned
+            // slot; the next call on this context / uf3_ctx_synchronize looks at them (UF3_ERETRY if they overflowed)
+            int slot = -1;
+            for (int q = 0; q < uf3_ctx::N_PENDING && slot < 0; q++)
+                if (!c->pending_chk[(c->pending_head + q) % uf3_ctx::N_PENDING].live) slot = (c->pending_head + q) % uf3_ctx::N_PENDING;
+            if (slot < 0) {        // all slots in flight: wait for the oldest
+                int rcw = poll_pending(c, true);
+                if (rcw) return rcw;
+                slot = c->pending_head;
+            }
+            HIPCHK(c, c->pin_flags.ensure(sizeof(int) * 4 * uf3_ctx::N_PENDING));
+            uf3_ctx::Pending &pd = c->pending_chk[slot];
+            if (!pd.ev) HIPCHK(c, hipEventCreateWithFlags(&pd.ev, hipEventDisableTiming));
+            HIPCHK(c, hipMemcpyAsync((int *)c->pin_flags.p + 4 * slot, c->flags.p, 4 * sizeof(int), hipMemcpyDeviceToHost, st));
+            HIPCHK(c, hipEventRecord(pd.ev, st));
+            pd.cap = cap; pd.cand = c->cand_cap; pd.has3 = has3; pd.live = true;
+            c->pending_head = (slot + 1) % uf3_ctx::N_PENDING;
+            return UF3_OK;
+        }
         int fl[3] = {0, 0, 0};                                               // error flag, n3 need, candidate need
         HIPCHK(c, hipMemcpyAsync(fl, c->flags.p, sizeof(fl), hipMemcpyDeviceToHost, st));
         HIPCHK(c, hipStreamSynchronize(st));
@@ -877,6 +939,7 @@ extern "C" int uf3_featurize_dev(uf3_basis *b, const uf3_frames *fr, const doubl
         if (fl[2] > c->cand_cap) { c->cand_cap = (fl[2] + 16 + 7) / 8 * 8; redo = true; }
         if (redo) continue;
         if (has3 && !c->n3_tuned) { rc = n3_tune(c, A.n3, P.natoms); if (rc) return rc; }
+        c->cand_tuned = true;
         return UF3_OK;
     }
     return fail(c, UF3_EOVERFLOW, "neighbour capacities did not converge");
@@ -918,12 +981,17 @@ extern "C" int uf3_featurize(uf3_basis *b, const uf3_frames *fr, const double *p
     size_t be = xe ? 8 * F * fr->n_frames : 0, bf = xf ? 8 * F * 3 * (size_t)natoms : 0;
     if (be) HIPCHK(c, c->stage_out.ensure(be));
     if (bf) HIPCHK(c, c->stage_out2.ensure(bf));
-    rc = uf3_featurize_dev(b, fr, c->stage_pos.as<double>(), c->d_stage_z,
-                           be ? c->stage_out.as<double>() : nullptr, bf ? c->stage_out2.as<double>() : nullptr);
-    if (rc) return rc;
-    if (be) HIPCHK(c, hipMemcpyAsync(xe, c->stage_out.p, be, hipMemcpyDeviceToHost, c->stream));
-    if (bf) HIPCHK(c, hipMemcpyAsync(xf, c->stage_out2.p, bf, hipMemcpyDeviceToHost, c->stream));
-    return uf3_ctx_synchronize(c);
+    for (int attempt = 0; attempt < 6; attempt++) {
+        rc = uf3_featurize_dev(b, fr, c->stage_pos.as<double>(), c->d_stage_z,
+                               be ? c->stage_out.as<double>() : nullptr, bf ? c->stage_out2.as<double>() : nullptr);
+        if (rc == UF3_ERETRY) continue;      // (verdict on an EARLIER asynchronous call: this one has not run)
+        if (rc) return rc;
+        if (be) HIPCHK(c, hipMemcpyAsync(xe, c->stage_out.p, be, hipMemcpyDeviceToHost, c->stream));
+        if (bf) HIPCHK(c, hipMemcpyAsync(xf, c->stage_out2.p, bf, hipMemcpyDeviceToHost, c->stream));
+        rc = uf3_ctx_synchronize(c);
+        if (rc != UF3_ERETRY) return rc;     // the lists of this very call overflowed: repeat it with the raised capacities
+    }
+    return fail(c, UF3_EOVERFLOW, "neighbour capacities did not converge");
 }
 
 // ------------------------------------------------------------------------------ eval

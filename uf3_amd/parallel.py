@@ -22,6 +22,45 @@ def shard_range(n_items, rank, world_size):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def frame_work(atoms, r_max3=None):
+    """Relative featurizer work of a frame ~ atoms x triplets per atom (shards balanced by sum N*T).
+    T grows with the square of the 3-body neighbour count q = 4/3 pi r^3 rho; without a volume (clusters) or a
+    3-body range the atom count is all there is."""
+    n = len(atoms)
+    if not n:
+        return 0.0
+    vol = 0.0
+    try:
+        cell = np.asarray(atoms.get_cell(), dtype=float).reshape(3, 3)
+        if np.all(np.asarray(atoms.get_pbc() if hasattr(atoms, "get_pbc") else atoms.pbc)):
+            vol = abs(float(np.linalg.det(cell)))
+    except Exception:  # noqa: BLE001 - an estimate only
+        vol = 0.0
+    if not r_max3 or vol <= 0.0:
+        return float(n)
+    q = 4.18879 * r_max3 ** 3 * n / vol
+    return float(n) * (1.0 + 0.5 * q * q)
+
+
+def shard_balanced(weights, rank, world_size):
+    """Contiguous block [lo, hi) of rank such that the blocks' summed weights are as even as contiguity allows:
+    block r ends at the first item where the running weight reaches (r + 1) / world of the total."""
+    w = np.asarray(weights, dtype=float)
+    n = len(w)
+    if n == 0 or w.sum() <= 0:
+        return shard_range(n, rank, world_size)
+    cum = np.concatenate([[0.0], np.cumsum(w)])
+    cuts = [0]
+    for r in range(1, world_size):
+        target = cum[-1] * r / world_size
+        k = int(np.searchsorted(cum, target, side="left"))
+        if k > 0 and (target - cum[k - 1]) < (cum[k] - target):      # nearest boundary
+            k -= 1
+        cuts.append(min(max(k, cuts[-1]), n))
+    cuts.append(n)
+    return cuts[rank], cuts[rank + 1]
+
+
 PIECE_KEYS = ("gram_e", "gram_f", "ord_e", "ord_f", "m_e", "m_f")
 
 
@@ -48,44 +87,67 @@ def unpack_pieces(buf, n_cols, with_forces=True):
     return out
 
 
-def allreduce_pieces(pieces, n_cols, device=None):
+def allreduce_packed(flat):
     """
-    Sum the pieces over all ranks of the default process group (no-op when
-    torch.distributed is not initialised).  With the "nccl" backend the packed
-    buffer is reduced on the GPU by RCCL; with "gloo" on the host.
+    Sum a packed piece buffer (torch tensor, device or host) over all ranks of the default process group, in place
+    where the backend allows: with "nccl" (= RCCL over xGMI) the DEVICE buffer goes straight into the collective;
+    with "gloo" (CPU tests) a host copy is reduced.  No-op without a process group.
+    """
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return flat
+    if dist.get_backend() == "nccl":
+        if not flat.is_cuda:
+            raise ValueError("the nccl backend reduces device buffers")
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        return flat
+    host = flat.cpu()
+    dist.all_reduce(host, op=dist.ReduceOp.SUM)
+    return host
+
+
+def allreduce_pieces(pieces, n_cols, device=None, with_forces=None):
+    """
+    Host-dict flavour of ``allreduce_packed``.  ``with_forces`` is a property of the fit and must be the same on
+    every rank (default: decided AFTER the reduction, from the global number of force targets m_f[0], so that a
+    rank whose shard had no forces -- or no frames -- ends up with the same system as the others).
     """
     import torch
     import torch.distributed as dist
-    with_forces = "gram_f" in pieces
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return pieces
     flat = torch.from_numpy(pack_pieces(pieces, n_cols))
     if dist.get_backend() == "nccl":
-        dev = torch.device("cuda", torch.cuda.current_device() if device is None else device)
-        t = flat.to(dev)
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        flat = t.cpu()
-    else:
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-    # every rank must agree on whether forces were present
-    return unpack_pieces(flat.numpy(), n_cols, with_forces=with_forces)
+        flat = flat.to(torch.device("cuda", torch.cuda.current_device() if device is None else device))
+    flat = allreduce_packed(flat).cpu().numpy()
+    if with_forces is None:
+        with_forces = unpack_pieces(flat, n_cols)["m_f"][0] > 0
+    return unpack_pieces(flat, n_cols, with_forces=with_forces)
 
 
-def sharded_fit(model, featurizer, frames, energies, forces=None, weight=0.5):
+def sharded_fit(model, featurizer, frames, energies, forces=None, weight=0.5, balance=True):
     """
-    Data-parallel ``WeightedLinearModel`` fit over ALL frames: this rank takes its contiguous block,
-    featurizes it and accumulates the Gram pieces on its GPU without the rows leaving HBM
-    (``pipeline.DeviceFitAccumulator``), all ranks sum-reduce once and every rank solves the same
-    small system.  Energy rows / targets are per-atom normalised as in the reference's from-file
-    path (least_squares.py:697-700).
+    Data-parallel ``WeightedLinearModel`` fit over ALL frames: this rank takes a contiguous block (balanced by the
+    estimated work sum N*T when ``balance``), featurizes it and accumulates the Gram pieces on its GPU without the
+    rows leaving it (``pipeline.DeviceFitAccumulator``), all ranks sum-reduce the packed device buffer once and every
+    rank solves the same small system.  Energy rows / targets are per-atom normalised as in the reference's
+    from-file path (least_squares.py:697-700).
     """
     import torch.distributed as dist
     from uf3_amd import pipeline
     on = dist.is_available() and dist.is_initialized()
     rank, world = (dist.get_rank(), dist.get_world_size()) if on else (0, 1)
-    lo, hi = shard_range(len(frames), rank, world)
+    if balance and world > 1:
+        basis = model.bspline_config
+        r3 = 0.0
+        for trio in basis.interactions_map.get(3, []) if basis.degree > 2 else []:
+            r3 = max(r3, float(np.max(np.asarray(basis.r_max_map[trio])[:2])))
+        lo, hi = shard_balanced([frame_work(a, r3) for a in frames], rank, world)
+    else:
+        lo, hi = shard_range(len(frames), rank, world)
     return pipeline.fit_frames(model, featurizer, frames[lo:hi], energies[lo:hi],
-                               None if forces is None else forces[lo:hi], weight=weight)
+                               None if forces is None else forces[lo:hi], weight=weight,
+                               with_forces=forces is not None)
 
 
 def sharded_evaluate(calculator, atoms, forces=True, virial=False, device=None):

@@ -1,11 +1,18 @@
 """
 Device-resident fit pipeline: frames -> feature rows -> normal-equation pieces, without the rows
-ever leaving HBM (BASELINE config 4: per-GPU X^T X accumulate, one reduce, host solve).
+ever leaving the GPU (BASELINE config 4: per-GPU X^T X accumulate, one reduce, host solve).
 
 Replaces the reference's ``batched_to_hdf`` + ``fit_from_file`` round trip
 (``uf3/representation/process.py:256-291``, ``uf3/regression/least_squares.py:355-483``): per-atom
 normalisation of the energy rows and targets (``dataframe_to_tuples``, :697-700), Gram pieces of
-energy and force rows, target moments for the E/F weights (``VarianceRecorder``, :19-67).
+energy and force rows, target moments for the E/F weights (``VarianceRecorder``, :19-67; the energy
+moments are those of the FROZEN targets, the force moments of the raw ones, as ``fit`` does, :296-304).
+
+Everything additive lives in ONE flat fp64 device buffer
+    [ G_e (F x F) | G_f (F x F) | o_e (F) | o_f (F) | m_e (3) | m_f (3) ]
+over all F columns; the frozen columns are folded out on the device when the pieces are asked for, and the
+packed buffer of the unfrozen columns (2 F'^2 + 2 F' + 6 doubles) is what ``parallel.allreduce_packed`` sums
+over the ranks -- no host copy before the collective.
 
 PyTorch is used only as the owner of the device buffers and of the stream.
 """
@@ -14,96 +21,141 @@ import ctypes as C
 import numpy as np
 
 from uf3_amd import _lib
-from uf3_amd.regression import least_squares as ls
 
 
 class DeviceFitAccumulator:
-    def __init__(self, model, featurizer, device=None, max_atoms_per_chunk=320000):
+    def __init__(self, model, featurizer, device=None, max_atoms_per_chunk=80000, with_forces=True):
+        """with_forces: whether force rows take part in the fit.  It is a property of the FIT, not of the frames a
+        rank happens to hold: a rank with an empty shard still contributes (zero) force pieces."""
         import torch
         self.torch = torch
         self.model, self.fz = model, featurizer
         self.ctx, self.db = featurizer._dev()
         self.dev = torch.device("cuda", self.ctx.device if device is None else device)
-        self.ctx.set_stream(torch.cuda.current_stream(self.dev).cuda_stream)
-        F = self.db.n_feat
-        z = lambda *s: torch.zeros(s, dtype=torch.float64, device=self.dev)  # noqa: E731
-        self.gram_e, self.gram_f, self.ord_e, self.ord_f = z(F, F), z(F, F), z(F), z(F)
-        self.m_e, self.m_f = np.zeros(3), np.zeros(3)
+        F = self.n_feat = self.db.n_feat
+        self.with_forces = bool(with_forces)
+        self.flat = torch.zeros(2 * F * F + 2 * F + 6, dtype=torch.float64, device=self.dev)
+        o = 0
+        self.gram_e = self.flat[o:o + F * F].view(F, F); o += F * F
+        self.gram_f = self.flat[o:o + F * F].view(F, F); o += F * F
+        self.ord_e = self.flat[o:o + F]; o += F
+        self.ord_f = self.flat[o:o + F]; o += F
+        self.m_e = self.flat[o:o + 3]; o += 3
+        self.m_f = self.flat[o:o + 3]
         self.max_atoms = int(max_atoms_per_chunk)
-        self.n_feat = F
-        self.n_el = len(model.bspline_config.element_list)
-        self.with_forces = False
+        self.n_chunks = 0
+        mask = np.asarray(model.mask)
+        self._keep = torch.from_numpy(np.flatnonzero(mask) if mask.dtype == bool else mask.astype(np.int64)).to(self.dev)
+        self._frozen = torch.from_numpy(np.asarray(model.col_idx, dtype=np.int64)).to(self.dev)
+        self._frozen_c = torch.from_numpy(np.asarray(model.frozen_c, dtype=np.float64).reshape(-1)).to(self.dev)
+
+    def reset(self):
+        self.flat.zero_()
+        self.n_chunks = 0
 
     def _gram(self, x, y, gram, ordn):
-        rows = x.shape[0]
         self.ctx.check(self.ctx.lib.uf3_gram_dev(self.ctx.handle, C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr()),
-                                                 rows, self.n_feat, self.n_feat, 1, C.c_void_p(gram.data_ptr()),
+                                                 x.shape[0], self.n_feat, self.n_feat, 1, C.c_void_p(gram.data_ptr()),
                                                  C.c_void_p(ordn.data_ptr())))
 
-    def add_frames(self, frames, energies, forces=None):
-        """frames: list of Atoms; energies [n]; forces: list of (N_i, 3) arrays or None."""
+    def _moments(self, y, into):
         torch = self.torch
-        start = 0
-        while start < len(frames):           # chunks bounded by the row buffer 3*atoms*F*8 bytes
-            stop, atoms = start, 0
-            while stop < len(frames) and (stop == start or atoms + len(frames[stop]) <= self.max_atoms):
-                atoms += len(frames[stop])
-                stop += 1
-            chunk = frames[start:stop]
-            batch = _lib.FrameBatch(chunk)
-            d_pos = torch.from_numpy(batch.pos).to(self.dev)
-            d_z = torch.from_numpy(batch.z).to(self.dev)
-            x_e = torch.empty((batch.n_frames, self.n_feat), dtype=torch.float64, device=self.dev)
-            x_f = (torch.empty((batch.n_atoms * 3, self.n_feat), dtype=torch.float64, device=self.dev)
-                   if forces is not None else None)
-            self.fz.featurize_device(batch.struct, d_pos.data_ptr(), d_z.data_ptr(), x_e.data_ptr(),
-                                     x_f.data_ptr() if x_f is not None else None)
-            # per-atom normalisation of the energy rows and targets (least_squares.py:697-700); the atom counts are
-            # known on the host (= the sum of the composition columns), so nothing is read back inside the loop and
-            # the host packs the next chunk while this one is still on the GPU (one stream: buffers handed back to
-            # torch's allocator here are not reused before the kernels queued above have run)
-            counts = np.diff(batch.offsets).astype(np.float64)
-            y_e_host = np.asarray(energies[start:stop], dtype=np.float64) / counts
-            x_e = (x_e / torch.from_numpy(counts).to(self.dev)[:, None]).contiguous()
-            y_e = torch.from_numpy(y_e_host).to(self.dev)
-            self._gram(x_e, y_e, self.gram_e, self.ord_e)
-            self.m_e += ls.moments(y_e_host)
-            if forces is not None:
-                y_host = np.concatenate([np.asarray(f, dtype=np.float64).reshape(-1, 3) for f in forces[start:stop]]).reshape(-1)
-                y_f = torch.from_numpy(y_host).to(self.dev)
-                self._gram(x_f, y_f, self.gram_f, self.ord_f)
-                self.m_f += ls.moments(y_host)
-                self.with_forces = True
-            start = stop
+        into += torch.stack([torch.tensor(float(y.numel()), dtype=torch.float64, device=self.dev), y.sum(), (y * y).sum()])
+
+    def add_frames(self, frames, energies, forces=None):
+        """frames: list of Atoms; energies [n]; forces: list of (N_i, 3) arrays (required when with_forces).
+
+        Asynchronous: the host packs and uploads the next chunk while the GPU works on the current one (nothing is
+        read back here; ``uf3_featurize_dev`` does not synchronise once the context knows its neighbour capacities).
+        A capacity overflow in an earlier chunk surfaces as ``_lib.RetryError`` from a later call or from ``pieces``:
+        the accumulated sums are then invalid (``fit_frames`` starts over once)."""
+        torch = self.torch
+        if self.with_forces and forces is None and len(frames):
+            raise ValueError("this accumulator was set up with forces: pass them")
+        prev = self.ctx.set_stream(torch.cuda.current_stream(self.dev).cuda_stream)
+        try:
+            start = 0
+            while start < len(frames):           # chunks bounded by the row buffer 3*atoms*F*8 bytes
+                stop, atoms = start, 0
+                while stop < len(frames) and (stop == start or atoms + len(frames[stop]) <= self.max_atoms):
+                    atoms += len(frames[stop])
+                    stop += 1
+                batch = _lib.FrameBatch(frames[start:stop])
+                d_pos = torch.from_numpy(batch.pos).to(self.dev, non_blocking=True)
+                d_z = torch.from_numpy(batch.z).to(self.dev, non_blocking=True)
+                x_e = torch.empty((batch.n_frames, self.n_feat), dtype=torch.float64, device=self.dev)
+                x_f = (torch.empty((batch.n_atoms * 3, self.n_feat), dtype=torch.float64, device=self.dev)
+                       if self.with_forces else None)
+                self.fz.featurize_device(batch.struct, d_pos.data_ptr(), d_z.data_ptr(), x_e.data_ptr(),
+                                         x_f.data_ptr() if x_f is not None else None)
+                # per-atom normalisation of the energy rows and targets (least_squares.py:697-700); the atom counts
+                # are known on the host (= the sum of the composition columns)
+                counts = torch.from_numpy(np.diff(batch.offsets).astype(np.float64)).to(self.dev)
+                y_e = torch.from_numpy(np.asarray(energies[start:stop], dtype=np.float64)).to(self.dev) / counts
+                x_e = (x_e / counts[:, None]).contiguous()
+                self._gram(x_e, y_e, self.gram_e, self.ord_e)
+                # moments of the FROZEN energies (least_squares.py:296-304)
+                y_fro = y_e - x_e.index_select(1, self._frozen) @ self._frozen_c if self._frozen.numel() else y_e
+                self._moments(y_fro, self.m_e)
+                if self.with_forces:
+                    y_host = np.concatenate([np.asarray(f, dtype=np.float64).reshape(-1, 3)
+                                             for f in forces[start:stop]]).reshape(-1)
+                    y_f = torch.from_numpy(y_host).to(self.dev)
+                    self._gram(x_f, y_f, self.gram_f, self.ord_f)
+                    self._moments(y_f, self.m_f)
+                self.n_chunks += 1
+                start = stop
+        finally:
+            self.ctx.restore_stream(prev)
+
+    def packed(self):
+        """Device tensor [G_e | G_f | o_e | o_f | m_e | m_f] on the UNFROZEN columns (F' of them): the additive
+        pieces of this rank, ready for ``parallel.allreduce_packed``.  Frozen columns are folded out on the
+        Gram level: X_m^T (y - X_f c_f) = o_m - G[m, f] c_f."""
+        torch = self.torch
+        self.ctx.synchronize()                  # verdicts on the asynchronous featurizer calls (RetryError)
+        keep, fro, c_f = self._keep, self._frozen, self._frozen_c
+
+        def fold(gram, ordn):
+            rows = gram.index_select(0, keep)
+            o = ordn.index_select(0, keep)
+            if fro.numel():
+                o = o - rows.index_select(1, fro) @ c_f
+            return rows.index_select(1, keep).reshape(-1), o
+
+        ge, oe = fold(self.gram_e, self.ord_e)
+        gf, of = fold(self.gram_f, self.ord_f)
+        return torch.cat([ge, gf, oe, of, self.m_e, self.m_f])
 
     def pieces(self):
-        """Additive pieces on the unfrozen columns (what ``parallel.allreduce_pieces`` sums)."""
-        model = self.model
-        mask, col_idx, frozen_c = model.mask, model.col_idx, np.asarray(model.frozen_c, dtype=float)
-
-        def reduce(gram, ordn):
-            g, o = gram.cpu().numpy(), ordn.cpu().numpy()
-            # freeze_columns on the Gram level: X_m^T (y - X_f c_f) = o_m - G[m, f] c_f
-            return g[np.ix_(mask, mask)], o[mask] - g[np.ix_(mask, col_idx)] @ frozen_c
-
-        out = dict(m_e=self.m_e.copy())
-        out["gram_e"], out["ord_e"] = reduce(self.gram_e, self.ord_e)
-        if self.with_forces:
-            out["m_f"] = self.m_f.copy()
-            out["gram_f"], out["ord_f"] = reduce(self.gram_f, self.ord_f)
-        return out
+        """Additive pieces of this rank as host arrays (what ``WeightedLinearModel.fit_from_pieces`` takes)."""
+        from uf3_amd import parallel
+        return parallel.unpack_pieces(self.packed().cpu().numpy(), int(self._keep.numel()), with_forces=self.with_forces)
 
 
-def fit_frames(model, featurizer, frames, energies, forces=None, weight=0.5, reduce=True):
+def fit_frames(model, featurizer, frames, energies, forces=None, weight=0.5, reduce=True, with_forces=None,
+               max_atoms_per_chunk=80000):
     """
-    Featurize + accumulate on this rank's GPU, sum-reduce the pieces across ranks (if a process group
-    is initialised), solve on every rank.  ``frames`` is THIS rank's shard.
+    Featurize + accumulate on this rank's GPU, sum-reduce the packed pieces across ranks on the device (if a
+    process group is initialised), solve on every rank.  ``frames`` is THIS rank's shard; ``with_forces`` must be
+    the same on every rank (default: whether forces were passed) -- a rank with an empty shard passes it explicitly.
     """
     from uf3_amd import parallel
-    acc = DeviceFitAccumulator(model, featurizer)
-    acc.add_frames(frames, energies, forces)
-    pieces = acc.pieces()
+    if with_forces is None:
+        with_forces = forces is not None
+    acc = DeviceFitAccumulator(model, featurizer, with_forces=with_forces, max_atoms_per_chunk=max_atoms_per_chunk)
+    for attempt in range(2):
+        try:
+            acc.add_frames(frames, energies, forces)
+            flat = acc.packed()
+            break
+        except _lib.RetryError:          # a neighbour capacity grew under an asynchronous chunk: the sums are invalid
+            if attempt:
+                raise
+            acc.reset()
+    n_cols = int(acc._keep.numel())
     if reduce:
-        pieces = parallel.allreduce_pieces(pieces, model.n_feats - len(model.col_idx))
+        flat = parallel.allreduce_packed(flat)
+    pieces = parallel.unpack_pieces(flat.cpu().numpy(), n_cols, with_forces=with_forces)
     model.fit_from_pieces(pieces, weight=weight)
     return pieces

@@ -235,8 +235,9 @@ class WeightedLinearModel(BasicLinearModel):
     def gram_pieces(self, x_e, y_e, x_f=None, y_f=None):
         """Additive pieces of one shard: Gram/ordinate of the frozen system + target moments."""
         x_e, y_e = np.asarray(x_e, dtype=float), np.asarray(y_e, dtype=float)
-        pieces = dict(m_e=moments(y_e))
         xe, ye = freeze_columns(x_e, y_e, self.mask, self.frozen_c, self.col_idx)
+        # the energy weight comes from the FROZEN targets, the force weight from the raw ones (least_squares.py:296-304)
+        pieces = dict(m_e=moments(ye))
         pieces["gram_e"], pieces["ord_e"] = gram_device(xe, ye)
         if x_f is not None:
             x_f, y_f = np.asarray(x_f, dtype=float), np.asarray(y_f, dtype=float)
@@ -262,7 +263,8 @@ class WeightedLinearModel(BasicLinearModel):
         gram, ordinate = gram_device(xe, ye)
         if x_f is not None:
             y_f = np.asarray(y_f, dtype=float)
-            w_e, w_f = calc_E_F_weights(len(y_e), len(y_f), np.std(y_e), np.std(y_f))
+            # std of the frozen energies, of the raw forces (least_squares.py:296-304)
+            w_e, w_f = calc_E_F_weights(len(ye), len(y_f), np.std(ye), np.std(y_f))
             xf, yf = freeze_columns(np.asarray(x_f, dtype=float), y_f, self.mask, self.frozen_c, self.col_idx)
             gram_f, ord_f = gram_device(xf, yf)
             gram, ordinate = self.combine_weighted_gram(gram, gram_f, ordinate, ord_f, w_e, w_f, weight)

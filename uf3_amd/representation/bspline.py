@@ -399,6 +399,7 @@ class BSplineBasis:
         return max(values)
 
     def update_knots(self, r_max_map=None, r_min_map=None, resolution_map=None, knots_map=None):
+        self._tables_version = getattr(self, "_tables_version", 0) + 1      # device tables of the old knots are stale
         r_min_map = composition.sort_interaction_map(r_min_map or {})
         r_max_map = composition.sort_interaction_map(r_max_map or {})
         resolution_map = composition.sort_interaction_map(resolution_map or {})
@@ -458,6 +459,7 @@ class BSplineBasis:
             self.resolution_map[trio] = [len(s) - 7 for s in lmn]
 
     def update_basis_functions(self):
+        self._tables_version = getattr(self, "_tables_version", 0) + 1      # (uf3_amd._lib.device_basis)
         self._basis_functions = None
         for pair in self.interactions_map.get(2, []):
             if pair not in self.knots_map:

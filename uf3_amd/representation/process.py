@@ -57,10 +57,6 @@ class BasisFeaturizer:
         return "\n".join(["BasisFeaturizer:", f"    Fit forces: {self.fit_forces}",
                           f"    Column prefix: {self.prefix}", repr(self.bspline_config)])
 
-    def __getstate__(self):  # device handles are per process; rebuilt lazily after unpickling
-        state = dict(self.__dict__)
-        return state
-
     # ------------------------------------------------------------------ device plumbing
     def _dev(self):
         ctx = _lib.get_context(self.device)
