@@ -13,13 +13,20 @@ N > 1: launched by torch.distributed.run, one rank per GPU.  Frames are independ
 the data path has no collective (weak scaling: every rank featurizes its own batch); the
 barrier and the MAX-reduce of the elapsed time go over RCCL.
 
+--mode fit (BASELINE config 4: W 2+3-body, 10k-atom frames, F = 73 unless --workload says otherwise): a step =
+featurize one batch of frames into HBM rows + accumulate X^T X / X^T y of the energy and force rows on the fp64
+matrix cores (the rows never leave the GPU); for N > 1 the timed region ends with the ONE all_reduce of the packed
+pieces over RCCL.  --workload lead0 (2-element, no leading trim, F = 1798) is the bandwidth-heavier featurize case.
+
 Extra objects on the JSON line:
-  roofline      achieved = algorithmic bytes per k_featurize launch (28N+75+8F(3N+1)
-                per frame x frames per launch) / mean launch duration measured with HIP events
-                on the launch stream, against the 8 TB/s HBM3E peak.  The path is FP64-ALU/LDS
-                bound at this F, so the fp64 fraction is reported beside it.
-  cpu_baseline  the oracle (oracle/uf3_oracle.c, "port", 1 thread) timed on rank 0 on one frame
-                of the same workload.
+  roofline      the dominant kernel launch group of a step, timed with HIP events on the launch stream.  Both
+                ceilings are reported: `hbm` = algorithmic bytes (28N+75+8F(3N+1) per frame x frames per
+                launch) against 8 TB/s, and `fp64` = algorithmic flops against 78.6 TF.  `bound` names the measured
+                limiter: on MI355X an fp64 MFMA holds the SIMD's vector issue while it runs
+                (tools/experiments/dp_pipe_bench.hip), so matrix and vector fp64 work add up -- the launch is bound by
+                fp64 issue ("mfma" in the contract's vocabulary), not by HBM, at these F.  `traffic` comes from the
+                committed PMC passes of the same command (profiles/), labelled as such.
+  cpu_baseline  the oracle (oracle/uf3_oracle.c, "port") timed on rank 0 on frames of the same workload.
 """
 import argparse
 import ctypes as C
@@ -45,6 +52,11 @@ def main():
                     help="frames per step and rank (32 x 10k atoms: 3.3 GB of rows in HBM); smaller batches leave a "
                          "few per cent on the table to workgroup tail effects")
     ap.add_argument("--atoms", type=int, default=10000, help="10000 = north-star; smaller = debug only")
+    ap.add_argument("--mode", choices=["featurize", "fit"], default="featurize",
+                    help="featurize = BASELINE metric (rows into HBM); fit = config 4 (rows -> X^T X / X^T y on the device)")
+    ap.add_argument("--workload", choices=["c4", "w", "lead0"], default=None,
+                    help="c4 = W/Mo notebook basis F=434 (featurize default); w = W only, F=73 (fit default); "
+                         "lead0 = W/Mo without leading trim, F=1798 (bandwidth-heavier)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -72,9 +84,17 @@ def main():
     else:
         n = max(2, round((args.atoms / 2) ** (1 / 3)))
         reps, workload = (n, n, n), f"debug: {2 * n ** 3}-atom bcc, W/Mo"
-    basis = synthetic.notebook_basis(['Mo', 'W'])
+    wl = args.workload or ("w" if args.mode == "fit" else "c4")
+    elements, numbers, lead3 = (['W'], [74], 3) if wl == "w" else (['Mo', 'W'], [42, 74], 0 if wl == "lead0" else 3)
+    if wl == "w":
+        workload = workload.replace("C4-metric", "C4-fit").replace("W/Mo Bernoulli(0.5)", "W")
+    elif wl == "lead0":
+        workload = workload.replace("C4-metric", "C4-cells").replace("notebook basis", "notebook basis without leading trim")
+    basis = synthetic.notebook_basis(elements, lead3=lead3)
     B = args.frames_per_step
-    frames = [synthetic.lattice_frame("bcc", reps, 3.165, [42, 74], 3000 + rank * 1000 + k) for k in range(B)]
+    if wl == "lead0" and B > 8:
+        B = 8                     # 432 MB of rows per frame
+    frames = [synthetic.lattice_frame("bcc", reps, 3.165, numbers, 3000 + rank * 1000 + k) for k in range(B)]
     batch = _lib.FrameBatch(frames)
     n_atoms = len(frames[0])
     fz = process.BasisFeaturizer(basis, device=dev.index)
@@ -85,9 +105,26 @@ def main():
     d_xe = torch.empty((B, F), dtype=torch.float64, device=dev)
     d_xf = torch.empty((batch.n_atoms, 3, F), dtype=torch.float64, device=dev)
     ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+    fit = args.mode == "fit"
+    acc = flat = None
+    if fit:
+        # targets of the batch (synthetic: any numbers do for the arithmetic; the parity of the fit is a test), already
+        # in HBM like the positions; energies per-atom normalised as the pipeline does
+        from uf3_amd import pipeline
+        from uf3_amd.regression import least_squares as ls
+        model = ls.WeightedLinearModel(basis, regularizer=basis.get_regularization_matrix(
+            ridge_1b=1e-8, ridge_2b=0.0, ridge_3b=1e-8, curvature_2b=1e-8, curvature_3b=0.0))
+        acc = pipeline.DeviceFitAccumulator(model, fz, with_forces=True)
+        g = torch.Generator(device=dev).manual_seed(7 + rank)
+        d_counts = torch.from_numpy(np.diff(batch.offsets).astype(np.float64)).to(dev)
+        d_ye = torch.randn((B,), dtype=torch.float64, device=dev, generator=g)
+        d_yf = torch.randn((3 * batch.n_atoms,), dtype=torch.float64, device=dev, generator=g)
 
     def step():
-        fz.featurize_device(batch.struct, d_pos.data_ptr(), d_z.data_ptr(), d_xe.data_ptr(), d_xf.data_ptr())
+        if fit:
+            acc.add_device_batch(batch.struct, B, batch.n_atoms, d_pos, d_z, d_counts, d_ye, d_yf, x_e=d_xe, x_f=d_xf)
+        else:
+            fz.featurize_device(batch.struct, d_pos.data_ptr(), d_z.data_ptr(), d_xe.data_ptr(), d_xf.data_ptr())
 
     def fence():
         if distributed:
@@ -97,10 +134,17 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
+    ctx.synchronize()
+    if fit:
+        acc.reset()
     ctx.timing_reset(True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    if fit:
+        # the pieces of this rank, frozen columns folded out on the device, and the ONE collective of the fit
+        from uf3_amd import parallel
+        flat = parallel.allreduce_packed(acc.packed())
     fence()
     elapsed = time.perf_counter() - t0
     timing = ctx.timing_read()
@@ -114,69 +158,106 @@ def main():
     # ---- sanity of what was timed: rows are finite and obey translation invariance -------------
     xf_sum = d_xf[:n_atoms].sum(dim=0).abs().max().item()
     assert os.environ.get("UF3_BENCH_NOCHECK") or np.isfinite(xf_sum) and xf_sum < 1e-6 * d_xf[:n_atoms].abs().max().item(), xf_sum
+    if fit:
+        assert bool(torch.isfinite(flat).all())
 
     out = None
     if rank == 0:
         launches = max(1, timing["featurize_launches"])
         launch_ms = timing["featurize_ms"] / launches
         bytes_per_launch = synthetic.algorithmic_bytes(n_atoms, F) * B
-        achieved = bytes_per_launch / (launch_ms * 1e-3) / 1e9
-        # algorithmic fp64 work: ~100 flop per directed pair, ~3.1 kflop per triplet
+        hbm_gbs = bytes_per_launch / (launch_ms * 1e-3) / 1e9
+        # algorithmic fp64 work of the featurizer: ~100 flop per directed pair, ~3.1 kflop per triplet
         pairs_per_atom, trip_per_atom = 58.0, 91.0
         flops_frame = n_atoms * (100.0 * pairs_per_atom + 3100.0 * trip_per_atom)
+        feat_tf = flops_frame * B / (launch_ms * 1e-3) / 1e12
         # HBM bytes per launch from the PMC passes of this same command (separate rocprofv3 --pmc FETCH_SIZE /
         # WRITE_SIZE runs, summary committed under profiles/); null when the workload differs
-        traffic = None
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "round1_hbm_counters.json")))
-            if pmc["workload"] == dict(atoms_per_frame=n_atoms, n_feat=F, frames_per_step=B):
-                traffic = pmc["hbm_bytes_per_launch_raw"]
-        except (OSError, KeyError, ValueError):
-            pass
-        roofline = dict(bound="hbm", achieved=round(achieved, 2), peak=8000.0, unit="GB/s",
-                        frac=round(achieved / 8000.0, 5), traffic=traffic,
-                        kernel="k_featurize<E,F,R,MODE> launch group of one step: MODE 0 (one-body + pairs + 3-body list "
-                               "build) + MODE 7 (3-body windows on the fp64 matrix cores, 3 waves/SIMD)",
-                        launch_ms=round(launch_ms, 4), launches=launches,
-                        algorithmic_bytes_per_launch=bytes_per_launch,
-                        fp64_tflops=round(flops_frame * B / (launch_ms * 1e-3) / 1e12, 3), fp64_peak_tflops=78.6,
-                        neighbor_ms_per_step=round(timing["neighbor_ms"] / args.steps, 4))
+        traffic, traffic_source = None, None
+        for name in ("round2_hbm_counters.json", "round1_hbm_counters.json"):
+            try:
+                pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
+                if pmc["workload"] == dict(atoms_per_frame=n_atoms, n_feat=F, frames_per_step=B):
+                    traffic, traffic_source = pmc["hbm_bytes_per_launch_raw"], "profiles/" + name + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, not measured in this run)"
+                    break
+            except (OSError, KeyError, ValueError):
+                pass
+        feat_kernel = ("k_featurize<E,F,R,MODE> launch group of one step: MODE 0 (one-body + pairs + 3-body list build) + "
+                       "the matrix-core launch of the 3-body windows (MODE 7 at the default trims)")
+        hbm = dict(achieved=round(hbm_gbs, 2), peak=8000.0, unit="GB/s", frac=round(hbm_gbs / 8000.0, 5),
+                   algorithmic_bytes_per_launch=bytes_per_launch)
+        if not fit:
+            roofline = dict(bound="mfma", achieved=round(feat_tf, 3), peak=78.6, unit="TFLOP/s", frac=round(feat_tf / 78.6, 5),
+                            traffic=traffic, traffic_source=traffic_source, hbm=hbm,
+                            bound_note="fp64 issue: an fp64 MFMA holds the SIMD's vector issue for its 64 cycles on MI355X "
+                                       "(tools/experiments/dp_pipe_bench.hip), so the 216 MFMA + ~6100 vector instructions "
+                                       "per atom add up; achieved = ALGORITHMIC flops (SURVEY 8d), the HBM view is in `hbm`",
+                            kernel=feat_kernel, launch_ms=round(launch_ms, 4), launches=launches,
+                            algorithmic_flops_per_launch=flops_frame * B,
+                            neighbor_ms_per_step=round(timing["neighbor_ms"] / args.steps, 4))
+        else:
+            n_keep = int(acc._keep.numel())
+            gram_flops = 2.0 * (3 * n_atoms + 1) * n_keep * n_keep * B          # SURVEY 8d, per step
+            gram_ms = timing["gram_ms"] / args.steps
+            gram_tf = gram_flops / (gram_ms * 1e-3) / 1e12
+            step_tf = (flops_frame * B + gram_flops) / (1e-3 * 1e3 * elapsed / args.steps) / 1e12
+            roofline = dict(bound="mfma", achieved=round(step_tf, 3), peak=78.6, unit="TFLOP/s", frac=round(step_tf / 78.6, 5),
+                            traffic=None, hbm=hbm,
+                            bound_note="whole step (featurizer + X^T X): algorithmic fp64 flops (featurizer: SURVEY 8d per pair / "
+                                       "triplet; Gram: 2 (3N+1) F'^2 per frame) / step time; the rows stay in HBM / Infinity Cache",
+                            kernel="k_featurize launch group + k_gram_mfma (energy and force rows) + k_ordinate",
+                            featurize_ms_per_step=round(launch_ms, 4), gram_ms_per_step=round(gram_ms, 4),
+                            gram_tflops=round(gram_tf, 3), gram_flops_per_step=gram_flops, n_unfrozen_columns=n_keep,
+                            neighbor_ms_per_step=round(timing["neighbor_ms"] / args.steps, 4))
         cpu = None
         if not args.no_cpu_baseline and world == 1:      # reported at N=1 only
             from oracle import oracle as O
             ob = O.OracleBasis(basis)
+            step()
+            torch.cuda.synchronize(dev)
             t1 = time.perf_counter()
             ref = O.featurize(ob, frames[0])
             dt = time.perf_counter() - t1
-            got_e = d_xe[0].cpu().numpy()
+            got_e = d_xe[0].cpu().numpy() * (n_atoms if fit else 1.0)        # (the fit step leaves per-atom rows)
             got_f = d_xf[:n_atoms].cpu().numpy()
             err = max(np.abs(got_e - ref["xe"]).max() / np.abs(ref["xe"]).max(),
                       np.abs(got_f - ref["xf"]).max() / np.abs(ref["xf"]).max())
             assert err < 1e-9, err
+            dt_fit = 0.0
+            if fit:       # the oracle's normal equations on this frame's rows (NumPy, least_squares.py:716-760)
+                t2 = time.perf_counter()
+                xf = ref["xf"].reshape(-1, F)
+                _ = xf.T @ xf, xf.T @ np.ones(len(xf)), np.outer(ref["xe"], ref["xe"])
+                dt_fit = time.perf_counter() - t2
             # the reference fans frames out over a process pool (process.py:196-254): one frame per process on all
-            # host cores (at most 32, one frame each: ~2.5 s per frame), wall clock from the first start to the last end
+            # host cores (at most 32, one frame each), wall clock from the first start to the last end
             import multiprocessing as mp
             workers = max(1, min(args.cpu_workers or (os.cpu_count() or 1), 32, B))
-            value_cpu, cores, how = 1.0 / dt, 1, "single thread"
+            value_cpu, cores, how = 1.0 / (dt + dt_fit), 1, "single thread"
             if workers > 1:
                 try:
                     with mp.get_context("spawn").Pool(workers) as pool:
-                        spans = pool.map_async(_cpu_worker, [(reps, 3000 + k) for k in range(workers)]).get(timeout=240)
+                        spans = pool.map_async(_cpu_worker, [(reps, 3000 + k, elements, numbers, lead3, fit) for k in range(workers)]).get(timeout=400)
                     wall = max(t[1] for t in spans) - min(t[0] for t in spans)
                     value_cpu, cores = workers / wall, workers
-                    how = f"{workers} processes x 1 frame each in {wall:.1f} s (one process alone: {dt:.1f} s per frame)"
+                    how = f"{workers} processes x 1 frame each in {wall:.1f} s (one process alone: {dt + dt_fit:.1f} s per frame)"
                 except Exception as exc:  # noqa: BLE001 - the pool is a convenience; the single-thread figure stands
                     how = f"single thread (process pool failed: {type(exc).__name__})"
+            what = "energy + force rows" + (" + X^T X / X^T y of the rows (NumPy)" if fit else "")
             cpu = dict(value=round(value_cpu, 5), unit="frames/s", cores=cores, kind="port",
-                       sample=f"frames of the same workload ({n_atoms} atoms, F={F}), energy + force rows, "
+                       sample=f"frames of the same workload ({n_atoms} atoms, F={F}), {what}, "
                               f"oracle/uf3_oracle.c, {how}; GPU rows matched frame 0 to {err:.1e}")
-        out = dict(metric="featurized frames/sec (10k-atom, 2-elem, 2+3-body)", value=round(value, 3),
+        metric = ("featurized frames/sec (10k-atom, 2-elem, 2+3-body)" if not fit else
+                  "fitted frames/sec (featurize + X^T X / X^T y accumulate, 10k-atom frames)")
+        out = dict(metric=metric, value=round(value, 3),
                    unit="frames/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
                    ms_per_step=round(1e3 * elapsed / args.steps, 4), higher_is_better=True, scaling="weak",
                    vs_baseline=None, dtype="f64", data="synthetic",
-                   config=dict(workload=workload, atoms_per_frame=n_atoms, n_feat=F, frames_per_step=B,
-                               outputs="energy row + 3N force rows per frame, resident in HBM",
-                               sharding=f"frames x{world}, no data-path collective"),
+                   config=dict(workload=workload, mode=args.mode, atoms_per_frame=n_atoms, n_feat=F, frames_per_step=B,
+                               outputs=("energy row + 3N force rows per frame, resident in HBM" if not fit else
+                                        "packed {G_e, G_f, o_e, o_f, moments} of the unfrozen columns"),
+                               sharding=(f"frames x{world}, no data-path collective" if not fit else
+                                         f"frames x{world}, one all_reduce(SUM) of 2F'^2+2F'+6 doubles at the end")),
                    roofline=roofline, cpu_baseline=cpu)
         print(json.dumps(out), flush=True)
     if distributed:
@@ -187,13 +268,16 @@ def main():
 
 def _cpu_worker(job):
     """one frame of the workload through the CPU restatement (a process of the cpu_baseline pool)"""
-    reps, seed = job
+    reps, seed, elements, numbers, lead3, fit = job
     from oracle import oracle as O
     from uf3_amd import synthetic
-    ob = O.OracleBasis(synthetic.notebook_basis(['Mo', 'W']))
-    frame = synthetic.lattice_frame("bcc", reps, 3.165, [42, 74], seed)
+    ob = O.OracleBasis(synthetic.notebook_basis(elements, lead3=lead3))
+    frame = synthetic.lattice_frame("bcc", reps, 3.165, numbers, seed)
     t0 = time.time()
-    O.featurize(ob, frame)
+    ref = O.featurize(ob, frame)
+    if fit:
+        xf = ref["xf"].reshape(-1, ref["xf"].shape[-1])
+        _ = xf.T @ xf, xf.T @ np.ones(len(xf))
     return t0, time.time()
 
 

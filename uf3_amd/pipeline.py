@@ -44,6 +44,7 @@ class DeviceFitAccumulator:
         self.m_f = self.flat[o:o + 3]
         self.max_atoms = int(max_atoms_per_chunk)
         self.n_chunks = 0
+        self._counts = [0.0, 0.0]
         mask = np.asarray(model.mask)
         self._keep = torch.from_numpy(np.flatnonzero(mask) if mask.dtype == bool else mask.astype(np.int64)).to(self.dev)
         self._frozen = torch.from_numpy(np.asarray(model.col_idx, dtype=np.int64)).to(self.dev)
@@ -52,15 +53,17 @@ class DeviceFitAccumulator:
     def reset(self):
         self.flat.zero_()
         self.n_chunks = 0
+        self._counts = [0.0, 0.0]
 
     def _gram(self, x, y, gram, ordn):
         self.ctx.check(self.ctx.lib.uf3_gram_dev(self.ctx.handle, C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr()),
                                                  x.shape[0], self.n_feat, self.n_feat, 1, C.c_void_p(gram.data_ptr()),
                                                  C.c_void_p(ordn.data_ptr())))
 
-    def _moments(self, y, into):
-        torch = self.torch
-        into += torch.stack([torch.tensor(float(y.numel()), dtype=torch.float64, device=self.dev), y.sum(), (y * y).sum()])
+    def _moments(self, y, into, which):
+        # sums on the device, the count on the host (no scalar upload inside the loop)
+        into[1:] += self.torch.stack([y.sum(), (y * y).sum()])
+        self._counts[which] += float(y.numel())
 
     def add_frames(self, frames, energies, forces=None):
         """frames: list of Atoms; energies [n]; forces: list of (N_i, 3) arrays (required when with_forces).
@@ -83,30 +86,40 @@ class DeviceFitAccumulator:
                 batch = _lib.FrameBatch(frames[start:stop])
                 d_pos = torch.from_numpy(batch.pos).to(self.dev, non_blocking=True)
                 d_z = torch.from_numpy(batch.z).to(self.dev, non_blocking=True)
-                x_e = torch.empty((batch.n_frames, self.n_feat), dtype=torch.float64, device=self.dev)
-                x_f = (torch.empty((batch.n_atoms * 3, self.n_feat), dtype=torch.float64, device=self.dev)
-                       if self.with_forces else None)
-                self.fz.featurize_device(batch.struct, d_pos.data_ptr(), d_z.data_ptr(), x_e.data_ptr(),
-                                         x_f.data_ptr() if x_f is not None else None)
                 # per-atom normalisation of the energy rows and targets (least_squares.py:697-700); the atom counts
                 # are known on the host (= the sum of the composition columns)
                 counts = torch.from_numpy(np.diff(batch.offsets).astype(np.float64)).to(self.dev)
                 y_e = torch.from_numpy(np.asarray(energies[start:stop], dtype=np.float64)).to(self.dev) / counts
-                x_e = (x_e / counts[:, None]).contiguous()
-                self._gram(x_e, y_e, self.gram_e, self.ord_e)
-                # moments of the FROZEN energies (least_squares.py:296-304)
-                y_fro = y_e - x_e.index_select(1, self._frozen) @ self._frozen_c if self._frozen.numel() else y_e
-                self._moments(y_fro, self.m_e)
+                y_f = None
                 if self.with_forces:
                     y_host = np.concatenate([np.asarray(f, dtype=np.float64).reshape(-1, 3)
                                              for f in forces[start:stop]]).reshape(-1)
                     y_f = torch.from_numpy(y_host).to(self.dev)
-                    self._gram(x_f, y_f, self.gram_f, self.ord_f)
-                    self._moments(y_f, self.m_f)
+                self.add_device_batch(batch.struct, batch.n_frames, batch.n_atoms, d_pos, d_z, counts, y_e, y_f)
                 self.n_chunks += 1
                 start = stop
         finally:
             self.ctx.restore_stream(prev)
+
+    def add_device_batch(self, frames_struct, n_frames, n_atoms, d_pos, d_z, d_counts, d_ye, d_yf=None, x_e=None, x_f=None):
+        """One batch whose inputs already live in HBM (torch tensors; ``d_ye`` per-atom normalised, ``d_yf`` flat):
+        featurize -> rows (in ``x_e`` / ``x_f`` if given, else fresh buffers) -> Gram pieces and moments.  Nothing
+        synchronises; the context must be on the caller's stream."""
+        torch = self.torch
+        if x_e is None:
+            x_e = torch.empty((n_frames, self.n_feat), dtype=torch.float64, device=self.dev)
+        if x_f is None and self.with_forces:
+            x_f = torch.empty((n_atoms * 3, self.n_feat), dtype=torch.float64, device=self.dev)
+        self.fz.featurize_device(frames_struct, d_pos.data_ptr(), d_z.data_ptr(), x_e.data_ptr(),
+                                 x_f.data_ptr() if self.with_forces else None)
+        x_e.div_(d_counts[:, None])
+        self._gram(x_e, d_ye, self.gram_e, self.ord_e)
+        # moments of the FROZEN energies (least_squares.py:296-304)
+        y_fro = d_ye - x_e.index_select(1, self._frozen) @ self._frozen_c if self._frozen.numel() else d_ye
+        self._moments(y_fro, self.m_e, 0)
+        if self.with_forces:
+            self._gram(x_f.view(-1, self.n_feat), d_yf, self.gram_f, self.ord_f)
+            self._moments(d_yf, self.m_f, 1)
 
     def packed(self):
         """Device tensor [G_e | G_f | o_e | o_f | m_e | m_f] on the UNFROZEN columns (F' of them): the additive
@@ -125,7 +138,10 @@ class DeviceFitAccumulator:
 
         ge, oe = fold(self.gram_e, self.ord_e)
         gf, of = fold(self.gram_f, self.ord_f)
-        return torch.cat([ge, gf, oe, of, self.m_e, self.m_f])
+        n = torch.tensor(self._counts, dtype=torch.float64).to(self.dev)
+        m_e = torch.cat([n[0:1], self.m_e[1:]])
+        m_f = torch.cat([n[1:2], self.m_f[1:]])
+        return torch.cat([ge, gf, oe, of, m_e, m_f])
 
     def pieces(self):
         """Additive pieces of this rank as host arrays (what ``WeightedLinearModel.fit_from_pieces`` takes)."""
