@@ -837,15 +837,15 @@ extern "C" int uf3_featurize_dev(uf3_basis *b, const uf3_frames *fr, const doubl
                 bool found = false;
                 if (dense_mode) {
                     const int stride = b->dense_stride[mode], dump = b->dense_dump[mode];
-                    const int nrec_max = std::max(4, std::min(DENSE_NREC, 1200 / stride)) & ~1;     // even: a step is two records
-                    auto stage_for = [&](int nr) { return std::max(dump, nr * stride); };
+                    const int nrec_max = std::max(4, std::min(DENSE_NREC, 1200 / stride));
+                    auto stage_for = [&](int nr) { return std::max(dump, (nr + (nr & 1)) * stride); };   // (+ the padding record of an odd pass)
                     A.dense_nrec = nrec_max; A.dense_stage = stage_for(nrec_max);
                     if (mode <= 7 && !getenv("UF3_NO_OCC3")) {
                         // records per staging pass: as many as the stage allows; fewer (smaller stage) if that lets a third
                         // workgroup onto the CU -- the kernel is latency-bound.  Three workgroups per CU need <= 52 KB each
                         // (LDS is granted in coarse granules: 53 KB did not fit).  Candidates in order of preference: more
                         // records per pass first, tables in LDS before tables in HBM
-                        const int tries[3] = {nrec_max, std::min(nrec_max, 18), std::min(nrec_max, 14)};
+                        const int tries[3] = {nrec_max, std::min(nrec_max, 18), std::min(nrec_max, 15)};
                         const size_t budget = 52 * 1024;
                         const bool dsrc_allowed = A.dsrc_lds, recs_allowed = !getenv("UF3_NO_LDS_RECS");
                         for (int q = 0; q < 12 && !found; q++) {

@@ -732,8 +732,6 @@ __device__ __forceinline__ void trio_block_mfma(const FeatArgs &A, const BasisDe
     lg.inv_h = leg == 0 ? td->leg[0].inv_h : (leg == 1 ? td->leg[1].inv_h : td->leg[2].inv_h);
     const int w_off = leg == 0 ? 0 : (leg == 1 ? dl.oM : dl.oN);
     const int w_ext = leg == 0 ? ext_l : (leg == 1 ? ext_m : ext_n), w_lo = leg == 0 ? lo_l : (leg == 1 ? lo_m : lo_n);
-    const int n_clear = (dl.oD / 2 + 2) / 3;                             // window pairs each of a record's lanes clears
-    const int n_clear_pad = ((dl.oZ + 2) / 2 + 2) / 3;                   // ... of a padding record (the whole record)
     // Two column tiles (the reference's default trims): a record touches 4 consecutive n bins, i.e. only tile 0, only
     // tile 1 or both (columns are n-major), decided by the knot interval of r_n: r_n <= thr0 / r_n > thr2 / else.  The
     // walk sorts its triplets by that class, and the steps of a pass that hold only records of class 0 (2) skip the MFMA
@@ -789,7 +787,10 @@ __device__ __forceinline__ void trio_block_mfma(const FeatArgs &A, const BasisDe
             // staged records, padded with an all-zero record to an even count (a step is two records)
             const int n_real = WANT_F ? n_part : (n_part + 1) >> 1, n_staged = n_real + (n_real & 1);
             const bool mine = li < n_part && !(A.skip & 16);
-            const bool pad = (n_real & 1) && (WANT_F ? li == n_part : ((li >> 1) == n_real && li >= n_part)) && li < nrec + 1;
+            // the records of this pass (and the padding record) start from zero: one contiguous fill by the whole wave.
+            // LDS writes of a wave stay in program order, so the fill lands before any lane's scatter below
+            if (!(A.skip & 16))
+                for (int q = 2 * lane; q < n_staged * dl.stride; q += 2 * WAVE) *(double2 *)(w.stage + q) = double2{0.0, 0.0};
             if (mine) {
                 const int gi = base + li;
                 const double x = w.geo[leg * GEO_N + gi];
@@ -797,15 +798,8 @@ __device__ __forceinline__ void trio_block_mfma(const FeatArgs &A, const BasisDe
                 double v[4], d[4];
                 const int first = load_interval(recs, lg, x, kr) - 3;
                 bspline4<WANT_F>(kr, x, v, d);
-                const double2 zz = {0.0, 0.0};
                 if (WANT_F) {
                     double *rec = w.stage + (size_t)li * dl.stride;
-                    // the three lanes of a record clear its windows together (LDS writes of a wave stay in program
-                    // order, so every clear lands before any lane's scatter below)
-                    for (int q = 0; q < n_clear; q++) {
-                        const int sl = leg * n_clear + q;
-                        if (2 * sl < dl.oD) *(double2 *)(rec + 2 * sl) = zz;
-                    }
                     const int2 pk = ((const int2 *)(w.geo + 6 * GEO_N))[gi];
                     const int cls = pk.y;
                     // which of (value, derivative) goes to K slot 0 / 1 (table in the header of this section)
@@ -823,29 +817,16 @@ __device__ __forceinline__ void trio_block_mfma(const FeatArgs &A, const BasisDe
                     const double u1 = oc[i1] * w.oir[i1];
                     const double u2 = oc[i2] * w.oir[i2], a3 = w.geo[(3 + leg) * GEO_N + gi];   // both fetched: no divergence
                     *(double2 *)(rec + dl.oD + 2 * leg) = double2{u1, cls == 0 ? u2 : a3};
-                    if (leg == 0) *(double2 *)(rec + dl.oD + 6) = double2{cls == 0 ? 1.0 : 0.0, 0.0};
-                    if (leg == 1) *(double2 *)(rec + dl.oZ) = zz;
+                    if (leg == 0 && cls == 0) rec[dl.oD + 6] = 1.0;
                 } else {
                     double *rec = w.stage + (size_t)(li >> 1) * dl.stride;
                     const int sl2 = li & 1;
-                    for (int q = 0; q < n_clear; q++) {      // (both records of the pair clear: all clears precede the scatters)
-                        const int sl = leg * n_clear + q;
-                        if (2 * sl < dl.oD) *(double2 *)(rec + 2 * sl) = zz;
-                    }
 #pragma unroll
                     for (int q = 0; q < 4; q++) {
                         const unsigned ws = (unsigned)(first + q - w_lo);
                         if (ws < (unsigned)w_ext) rec[w_off + 2 * ws + sl2] = v[q];
                     }
                     if (leg == 0) rec[dl.oD + 6 + sl2] = 1.0;
-                    if (leg == 1 && sl2 == 0) *(double2 *)(rec + dl.oZ) = zz;
-                }
-            } else if (pad && !(A.skip & 16)) {
-                double *rec = w.stage + (size_t)(WANT_F ? li : li >> 1) * dl.stride;
-                const double2 zz = {0.0, 0.0};
-                for (int q = 0; q < n_clear_pad; q++) {
-                    const int sl = leg * n_clear_pad + q;
-                    if (2 * sl < dl.oZ + 2) *(double2 *)(rec + 2 * sl) = zz;
                 }
             }
             // steps (two records) of class 0 only: [0, e_a); of class 2 only: [s_c, n_staged) (the padding record is neutral)
