@@ -48,7 +48,8 @@ def test_reference_api_slices_and_evaluate_configuration():
     assert set(emap) == set(ref)
     for key in emap:                                   # tests/test_representation.py:605-648
         assert np.allclose(emap[key], np.array(ref[key]))
-    sup = object()                                     # any non-None supercell = periodic path
+    from uf3_amd.data import geometry
+    sup = geometry.get_supercell(atoms, r_cut=basis.r_cut)          # what the reference passes (process.py:332-335)
     lo2, hi2 = fz._block(2)
     lo3, hi3 = fz._block(3)
     assert np.allclose(fz.featurize_energy_2B(atoms, sup), d["xe"][lo2:hi2])
@@ -56,6 +57,11 @@ def test_reference_api_slices_and_evaluate_configuration():
     assert np.allclose(fz.featurize_force_2B(atoms, sup), d["xf"][:, :, lo2:hi2])
     assert np.allclose(fz.featurize_force_3B(atoms, sup), d["xf"][:, :, lo3:hi3])
     assert fz.featurize_force_2B(atoms, sup).shape == (11, 3, hi2 - lo2)
+    # no supercell (or the frame itself): an isolated cluster; anything else is refused, not reinterpreted
+    cluster = fz.featurize_frames([atoms], periodic=False)[0][0, lo2:hi2]
+    assert np.allclose(fz.featurize_energy_2B(atoms), cluster) and np.allclose(fz.featurize_energy_2B(atoms, atoms), cluster)
+    with pytest.raises(ValueError):
+        fz.featurize_energy_2B(atoms, geometry.get_supercell(atoms, r_cut=2 * basis.r_cut))
 
 
 def test_2body_force_feature_invariants():
@@ -985,3 +991,52 @@ def test_random_bases_and_cells_against_oracle(seed):
         e, f, _ = calculator.UFCalculator(model).evaluate_frames([atoms])
         e_ref, f_ref = O.evaluate(O.OracleBasis(basis), atoms, coeff)
         assert abs(e[0] - e_ref) <= TOL * max(1.0, abs(e_ref)) and rel_err(f, f_ref) < TOL
+
+
+def _nccl_fit_worker(rank, world, port, out_dir):
+    import torch
+    import torch.distributed as dist
+    from uf3_amd import parallel
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["UF3_DEVICE"] = str(rank)
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    basis = synthetic.notebook_basis(['W'])
+    frames = [synthetic.lattice_frame("bcc", (3, 3, 3 + (k % 3)), 3.165, [74], seed=150 + k) for k in range(9)]
+    rng = np.random.default_rng(11)
+    energies = rng.normal(size=len(frames))
+    forces = [rng.normal(size=(len(f), 3)) for f in frames]
+    fz = process.BasisFeaturizer(basis, device=rank)
+    reg = basis.get_regularization_matrix(ridge_1b=1e-8, ridge_2b=0.0, ridge_3b=1e-8, curvature_2b=1e-8, curvature_3b=0.0)
+    model = ls.WeightedLinearModel(basis, regularizer=reg)
+    parallel.sharded_fit(model, fz, frames, energies, forces, weight=0.4)        # RCCL all_reduce of the device buffer
+    np.save(os.path.join(out_dir, f"nccl_{rank}.npy"), model.coefficients)
+    dist.destroy_process_group()
+
+
+def test_two_gpu_fit_over_rccl_matches_one_gpu(tmp_path):
+    """The N > 1 path on hardware: frames sharded over 2 GPUs, packed pieces summed by RCCL on the device buffers ==
+    the same fit on one GPU.  Skips where the box has a single GPU (the driver's 8-GPU node runs it)."""
+    import socket
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    import torch.multiprocessing as mp
+    from uf3_amd import pipeline
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_nccl_fit_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    basis = synthetic.notebook_basis(['W'])
+    frames = [synthetic.lattice_frame("bcc", (3, 3, 3 + (k % 3)), 3.165, [74], seed=150 + k) for k in range(9)]
+    rng = np.random.default_rng(11)
+    energies = rng.normal(size=len(frames))
+    forces = [rng.normal(size=(len(f), 3)) for f in frames]
+    reg = basis.get_regularization_matrix(ridge_1b=1e-8, ridge_2b=0.0, ridge_3b=1e-8, curvature_2b=1e-8, curvature_3b=0.0)
+    model = ls.WeightedLinearModel(basis, regularizer=reg)
+    pipeline.fit_frames(model, process.BasisFeaturizer(basis), frames, energies, forces, weight=0.4, reduce=False)
+    c0, c1 = np.load(tmp_path / "nccl_0.npy"), np.load(tmp_path / "nccl_1.npy")
+    assert np.array_equal(c0, c1)
+    assert np.allclose(c0, model.coefficients, rtol=1e-8, atol=1e-10)

@@ -8,8 +8,9 @@ system_changes)`` protocol with ``results['energy'|'free_energy'|'forces'|'stres
 traversal contracted with the coefficients on the fly (``uf3_eval`` in
 ``libuf3hip.so``): pair splines from the pair coefficient vectors, trio splines from
 the decompressed L x M x N grids (``decompress_3B``), as the reference builds its
-``ndsplines`` objects.  Stress is numerical (central differences of the energy), as
-in the reference.  ASE is optional: the class derives from ``ase``'s Calculator when
+``ndsplines`` objects.  Stress is analytic (the strain derivative is accumulated in the same
+pass, ``uf3_eval_virial``; the reference differentiates the energy numerically,
+``calculator.py:399-404``).  ASE is optional: the class derives from ``ase``'s Calculator when
 ASE is importable and is otherwise a duck-typed stand-alone.
 """
 import ctypes as C

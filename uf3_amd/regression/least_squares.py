@@ -144,12 +144,14 @@ def arrange_coefficients(coefficients, bspline_config):
 
 
 class BasicLinearModel:
+    device = None      # HIP device of the Gram products (None: UF3_DEVICE / LOCAL_RANK / 0, like the featurizer)
+
     def __init__(self, regularizer=None):
         self.coefficients = None
         self.regularizer = regularizer
 
     def fit(self, x, y, ridge_penalty=1e-8):
-        gram, ordinate = gram_device(x, y)
+        gram, ordinate = gram_device(x, y, self.device)
         reg = np.eye(len(gram)) * ridge_penalty if self.regularizer is None else self.regularizer
         self.coefficients = lu_factorization(gram + np.dot(reg.T, reg), ordinate)
 
@@ -238,12 +240,12 @@ class WeightedLinearModel(BasicLinearModel):
         xe, ye = freeze_columns(x_e, y_e, self.mask, self.frozen_c, self.col_idx)
         # the energy weight comes from the FROZEN targets, the force weight from the raw ones (least_squares.py:296-304)
         pieces = dict(m_e=moments(ye))
-        pieces["gram_e"], pieces["ord_e"] = gram_device(xe, ye)
+        pieces["gram_e"], pieces["ord_e"] = gram_device(xe, ye, self.device)
         if x_f is not None:
             x_f, y_f = np.asarray(x_f, dtype=float), np.asarray(y_f, dtype=float)
             pieces["m_f"] = moments(y_f)
             xf, yf = freeze_columns(x_f, y_f, self.mask, self.frozen_c, self.col_idx)
-            pieces["gram_f"], pieces["ord_f"] = gram_device(xf, yf)
+            pieces["gram_f"], pieces["ord_f"] = gram_device(xf, yf, self.device)
         return pieces
 
     def fit_from_pieces(self, pieces, weight=0.5):
@@ -260,13 +262,13 @@ class WeightedLinearModel(BasicLinearModel):
         """Energies (+ forces) -> coefficients (least_squares.py:274-321)."""
         x_e, y_e = np.asarray(x_e, dtype=float), np.asarray(y_e, dtype=float)
         xe, ye = freeze_columns(x_e, y_e, self.mask, self.frozen_c, self.col_idx)
-        gram, ordinate = gram_device(xe, ye)
+        gram, ordinate = gram_device(xe, ye, self.device)
         if x_f is not None:
             y_f = np.asarray(y_f, dtype=float)
             # std of the frozen energies, of the raw forces (least_squares.py:296-304)
             w_e, w_f = calc_E_F_weights(len(ye), len(y_f), np.std(ye), np.std(y_f))
             xf, yf = freeze_columns(np.asarray(x_f, dtype=float), y_f, self.mask, self.frozen_c, self.col_idx)
-            gram_f, ord_f = gram_device(xf, yf)
+            gram_f, ord_f = gram_device(xf, yf, self.device)
             gram, ordinate = self.combine_weighted_gram(gram, gram_f, ordinate, ord_f, w_e, w_f, weight)
         self.fit_with_gram(gram, ordinate)
 
@@ -291,8 +293,8 @@ class WeightedLinearModel(BasicLinearModel):
         if e_variance is not None and f_variance is not None:
             e_variance.update(y_e)
             f_variance.update(y_f)
-        gram_e, ord_e = gram_device(x_e, y_e)
-        gram_f, ord_f = gram_device(x_f, y_f)
+        gram_e, ord_e = gram_device(x_e, y_e, self.device)
+        gram_f, ord_f = gram_device(x_f, y_f, self.device)
         return gram_e, gram_f, ord_e, ord_f
 
     def fit_from_tables(self, tables, subset, weight=0.5, batch_size=2500, sample_weights=None, energy_key="energy",

@@ -8,9 +8,12 @@ Surface follows the reference's ``uf3/representation/process.py`` (class :20-536
 :619-630).  Differences in mechanism, not in results:
 
 * no supercell is materialised: periodic images come from a cell list with image
-  shifts on the device.  The optional ``supercell`` argument of ``featurize_*`` is
-  only inspected for ``None`` (None -> treat ``geom`` as an isolated cluster, as
-  the reference does when no supercell is passed);
+  shifts on the device.  The optional ``supercell`` argument of ``featurize_*`` selects the
+  boundary conditions like in the reference: ``None`` (or ``geom`` itself) -> ``geom`` is an
+  isolated cluster; the supercell the reference builds for ``geom``
+  (``geometry.get_supercell(geom, r_cut=basis.r_cut)``) -> the periodic frame.  Any other
+  atom set (a hand-made supercell, another cut-off) is refused rather than silently
+  replaced by the frame's own periodicity;
 * frames are processed in batches (``featurize_frames``); ``evaluate_parallel`` needs
   no worker pool -- the whole batch goes to the GPU of this process.
 
@@ -138,8 +141,28 @@ class BasisFeaturizer:
         return lo, hi
 
     def _rows(self, geom, supercell, energy, forces):
-        periodic = None if supercell is not None else False
+        periodic = self._supercell_means_periodic(geom, supercell)
         return self.featurize_frames([geom], energy=energy, forces=forces, periodic=periodic)
+
+    def _supercell_means_periodic(self, geom, supercell):
+        """None (= periodic images from the frame's own cell) or False (cluster); see the module docstring."""
+        if supercell is None or supercell is geom:
+            return False
+        from uf3_amd.data import geometry
+        got = np.asarray(supercell.get_positions(), dtype=float).reshape(-1, 3)
+        own = np.asarray(geom.get_positions(), dtype=float).reshape(-1, 3)
+        z_got, z_own = np.asarray(supercell.get_atomic_numbers()), np.asarray(geom.get_atomic_numbers())
+        if got.shape == own.shape and np.array_equal(z_got, z_own) and np.allclose(got, own, rtol=0, atol=1e-9):
+            return False                                             # a copy of the frame: no images
+        want = geometry.get_supercell(geom, r_cut=self.r_cut)
+        pos = np.asarray(want.get_positions(), dtype=float).reshape(-1, 3)
+        if (got.shape == pos.shape and np.array_equal(z_got, np.asarray(want.get_atomic_numbers()))
+                and np.allclose(got, pos, rtol=0, atol=1e-9)):
+            return None
+        raise ValueError(
+            "supercell is neither the frame itself nor get_supercell(geom, r_cut=basis.r_cut): "
+            f"{len(got)} atoms given, {len(pos)} expected; the GPU featurizer takes its periodic images from "
+            "the frame's own cell and cannot honour an arbitrary atom set")
 
     def featurize_energy_2B(self, geom, supercell=None):
         lo, hi = self._block(2)
