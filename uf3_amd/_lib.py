@@ -310,21 +310,31 @@ class FrameBatch:
     """Host-side frame metadata + concatenated positions / species of a list of Atoms."""
 
     def __init__(self, atoms_list, periodic=None):
-        n = [len(a) for a in atoms_list]
         self.n_frames = len(atoms_list)
-        self.offsets = np.concatenate([[0], np.cumsum(n)]).astype(np.int64)
-        self.pos = np.ascontiguousarray(np.concatenate(
-            [np.asarray(a.get_positions(), dtype=np.float64).reshape(-1, 3) for a in atoms_list]))
-        self.z = np.ascontiguousarray(np.concatenate(
-            [np.asarray(a.get_atomic_numbers(), dtype=np.int32) for a in atoms_list]))
-        self.cells = np.ascontiguousarray(np.array(
-            [np.array(a.get_cell(), dtype=np.float64).reshape(3, 3) for a in atoms_list]))
-        pbc = np.zeros((self.n_frames, 3), dtype=np.uint8)
-        for k, a in enumerate(atoms_list):
-            pbc[k, :] = np.asarray(a.get_pbc() if hasattr(a, "get_pbc") else a.pbc)
-        if periodic is False:
-            pbc[:] = 0
-        self.pbc = pbc
+        if self.n_frames == 1:          # an MD step: no concatenations
+            a = atoms_list[0]
+            self.pos = np.ascontiguousarray(a.get_positions(), dtype=np.float64).reshape(-1, 3)
+            self.z = np.ascontiguousarray(a.get_atomic_numbers(), dtype=np.int32)
+            self.offsets = np.array([0, len(self.z)], dtype=np.int64)
+            self.cells = np.ascontiguousarray(a.get_cell(), dtype=np.float64).reshape(1, 3, 3)
+            self.pbc = np.zeros((1, 3), dtype=np.uint8)
+            if periodic is not False:
+                self.pbc[0, :] = a.get_pbc() if hasattr(a, "get_pbc") else a.pbc
+        else:
+            n = [len(a) for a in atoms_list]
+            self.offsets = np.concatenate([[0], np.cumsum(n)]).astype(np.int64)
+            self.pos = np.ascontiguousarray(np.concatenate(
+                [np.asarray(a.get_positions(), dtype=np.float64).reshape(-1, 3) for a in atoms_list]))
+            self.z = np.ascontiguousarray(np.concatenate(
+                [np.asarray(a.get_atomic_numbers(), dtype=np.int32) for a in atoms_list]))
+            self.cells = np.ascontiguousarray(np.array(
+                [np.array(a.get_cell(), dtype=np.float64).reshape(3, 3) for a in atoms_list]))
+            pbc = np.zeros((self.n_frames, 3), dtype=np.uint8)
+            for k, a in enumerate(atoms_list):
+                pbc[k, :] = np.asarray(a.get_pbc() if hasattr(a, "get_pbc") else a.pbc)
+            if periodic is False:
+                pbc[:] = 0
+            self.pbc = pbc
         self.n_atoms = int(self.offsets[-1])
         self.struct = make_frames(self.offsets, self.cells, self.pbc)
 

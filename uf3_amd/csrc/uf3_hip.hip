@@ -69,6 +69,8 @@ struct uf3_ctx {
     int pending_head = 0;
     bool frag_ready = false;
     int32_t *d_stage_z = nullptr;       // species of the staged batch (tail of stage_pos)
+    size_t pin_in_pending = 0;          // small batch: bytes of positions | species waiting in pin_in; the cell-list
+                                        // stage appends the frame geometry and sends everything in ONE copy
     PinBuf pin_in, pin_geo, pin_out;    // positions + species | frame geometry + offsets | results
     hipEvent_t pin_in_done = nullptr, pin_geo_done = nullptr;   // the copies out of pin_in / pin_geo have executed
     std::vector<double> coeff_shadow;   // host copy of the model last uploaded by uf3_eval (c1 | c2 | c3)
@@ -567,6 +569,7 @@ struct Prepared {
     const signed char *spec = nullptr;
     const int64_t *d_offsets = nullptr;
     bool deferred = false;      // the list-capacity / error flags of this build have not been read yet
+    bool flags_zeroed = false;  // the cell-list stage has already zeroed the n3 / candidate status words
 };
 
 static int check_flags(uf3_ctx *c) {
@@ -669,14 +672,29 @@ static int prepare(uf3_basis *b, const uf3_frames *fr, const double *d_pos, cons
     // frame geometry | atom offsets: one block, staged in pinned memory (the copy is asynchronous; the event tells
     // the next call when the staging block may be overwritten)
     const size_t geo_bytes = (sizeof(FrameGeom) * nf + 15) / 16 * 16, off_bytes = sizeof(int64_t) * (nf + 1);
-    HIPCHK(c, c->geoms.ensure(geo_bytes + off_bytes));
-    HIPCHK(c, hipEventSynchronize(c->pin_geo_done));
-    HIPCHK(c, c->pin_geo.ensure(geo_bytes + off_bytes));
-    std::memcpy(c->pin_geo.p, geoms.data(), sizeof(FrameGeom) * nf);
-    std::memcpy((char *)c->pin_geo.p + geo_bytes, fr->atom_offsets, off_bytes);
-    HIPCHK(c, hipMemcpyAsync(c->geoms.p, c->pin_geo.p, geo_bytes + off_bytes, hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipEventRecord(c->pin_geo_done, st));
-    const int64_t *d_offsets = (const int64_t *)((const char *)c->geoms.p + geo_bytes);
+    const FrameGeom *d_geoms;
+    const int64_t *d_offsets;
+    if (c->pin_in_pending && d_pos == c->stage_pos.as<double>()) {
+        // small batch staged by upload_frames: positions | species | geometry | offsets leave pin_in in one copy
+        const size_t at = c->pin_in_pending;
+        std::memcpy((char *)c->pin_in.p + at, geoms.data(), sizeof(FrameGeom) * nf);
+        std::memcpy((char *)c->pin_in.p + at + geo_bytes, fr->atom_offsets, off_bytes);
+        HIPCHK(c, hipMemcpyAsync(c->stage_pos.p, c->pin_in.p, at + geo_bytes + off_bytes, hipMemcpyHostToDevice, st));
+        HIPCHK(c, hipEventRecord(c->pin_in_done, st));
+        c->pin_in_pending = 0;
+        d_geoms = (const FrameGeom *)((const char *)c->stage_pos.p + at);
+        d_offsets = (const int64_t *)((const char *)c->stage_pos.p + at + geo_bytes);
+    } else {
+        HIPCHK(c, c->geoms.ensure(geo_bytes + off_bytes));
+        HIPCHK(c, hipEventSynchronize(c->pin_geo_done));
+        HIPCHK(c, c->pin_geo.ensure(geo_bytes + off_bytes));
+        std::memcpy(c->pin_geo.p, geoms.data(), sizeof(FrameGeom) * nf);
+        std::memcpy((char *)c->pin_geo.p + geo_bytes, fr->atom_offsets, off_bytes);
+        HIPCHK(c, hipMemcpyAsync(c->geoms.p, c->pin_geo.p, geo_bytes + off_bytes, hipMemcpyHostToDevice, st));
+        HIPCHK(c, hipEventRecord(c->pin_geo_done, st));
+        d_geoms = c->geoms.as<FrameGeom>();
+        d_offsets = (const int64_t *)((const char *)c->geoms.p + geo_bytes);
+    }
     size_t na = (size_t)natoms;
     HIPCHK(c, c->frame_of.ensure(4 * na)); HIPCHK(c, c->atom_bin.ensure(4 * na)); HIPCHK(c, c->atom_wrap.ensure(4 * na));
     HIPCHK(c, c->spec.ensure(na)); HIPCHK(c, c->key_in.ensure(4 * na)); HIPCHK(c, c->key_out.ensure(4 * na));
@@ -688,7 +706,14 @@ static int prepare(uf3_basis *b, const uf3_frames *fr, const double *d_pos, cons
 
     Timed tm(c, T_NBR);
     int tb = 256, gb = (natoms + tb - 1) / tb;
-    hipLaunchKernelGGL(k_frame_bins, dim3(gb), dim3(tb), 0, st, b->dev, c->geoms.as<FrameGeom>(),
+    if (natoms <= UF3_SMALL_ATOMS && !getenv("UF3_NO_SMALL_PREPARE")) {
+        // an MD step: the whole cell-list stage in one workgroup (and the status words of the launches that follow zeroed)
+        hipLaunchKernelGGL(k_prepare_small, dim3(1), dim3(1024), 0, st, b->dev, d_geoms, d_offsets, nf,
+                           natoms, nbins, d_pos, d_z, c->frame_of.as<int>(), c->atom_bin.as<int>(), c->atom_wrap.as<int>(),
+                           c->spec.as<signed char>(), c->bin_start.as<int>(), c->slots.as<SlotRec>(), flags, 2);
+        P.flags_zeroed = true;
+    } else {
+    hipLaunchKernelGGL(k_frame_bins, dim3(gb), dim3(tb), 0, st, b->dev, d_geoms,
                        d_offsets, nf, natoms, d_pos, d_z, c->frame_of.as<int>(), c->atom_bin.as<int>(),
                        c->atom_wrap.as<int>(), c->spec.as<signed char>(), c->key_in.as<int>(), c->val_in.as<int>(), flags);
     int bits = 1;
@@ -703,10 +728,11 @@ static int prepare(uf3_basis *b, const uf3_frames *fr, const double *d_pos, cons
                        nbins, c->bin_start.as<int>());
     hipLaunchKernelGGL(k_gather_sorted, dim3(gb), dim3(tb), 0, st, c->val_out.as<int>(), natoms, d_pos,
                        c->atom_wrap.as<int>(), c->spec.as<signed char>(), c->slots.as<SlotRec>());
+    }
     HIPCHK(c, hipGetLastError());
 
     P.natoms = natoms; P.n_frames = nf; P.nbins = nbins; P.max_density = dens;
-    P.geoms = c->geoms.as<FrameGeom>();
+    P.geoms = d_geoms;
     P.frame_of = c->frame_of.as<int>();
     P.spec = c->spec.as<signed char>();
     P.d_offsets = d_offsets;
@@ -946,7 +972,8 @@ extern "C" int uf3_featurize_dev(uf3_basis *b, const uf3_frames *fr, const doubl
 }
 
 // host-buffer helpers
-static int upload_frames(uf3_ctx *c, const uf3_frames *fr, const double *pos, const int32_t *z, int &natoms) {
+static int upload_frames(uf3_ctx *c, const uf3_frames *fr, const double *pos, const int32_t *z, int &natoms,
+                         bool defer_small = false) {
     if (!fr || fr->n_frames < 1 || !fr->atom_offsets) return fail(c, UF3_EINVAL, "bad uf3_frames");
     int64_t total = fr->atom_offsets[fr->n_frames];
     if (total < 1 || total >= (1LL << 28)) return fail(c, UF3_EINVAL, "batch must hold 1 .. 2^28 atoms");
@@ -954,13 +981,17 @@ static int upload_frames(uf3_ctx *c, const uf3_frames *fr, const double *pos, co
     natoms = (int)total;
     HIPCHK(c, hipSetDevice(c->device));
     const size_t bp = 24 * (size_t)natoms, bz = 4 * (size_t)natoms;
-    HIPCHK(c, c->stage_pos.ensure(bp + bz));                       // positions | species, one block
+    // (room behind positions | species for the frame geometry: see pin_in_pending)
+    const size_t geo_room = 64 + sizeof(FrameGeom) * (size_t)fr->n_frames + 8 * ((size_t)fr->n_frames + 1);
+    HIPCHK(c, c->stage_pos.ensure(bp + bz + geo_room));            // positions | species, one block
     c->d_stage_z = (int32_t *)((char *)c->stage_pos.p + bp);
+    c->pin_in_pending = 0;
     if (bp + bz <= UF3_PIN_LIMIT) {
         HIPCHK(c, hipEventSynchronize(c->pin_in_done));
-        HIPCHK(c, c->pin_in.ensure(bp + bz));
+        HIPCHK(c, c->pin_in.ensure(bp + bz + geo_room));
         std::memcpy(c->pin_in.p, pos, bp);
         std::memcpy((char *)c->pin_in.p + bp, z, bz);
+        if (defer_small && bp + bz + geo_room <= UF3_PIN_LIMIT) { c->pin_in_pending = (bp + bz + 15) / 16 * 16; return UF3_OK; }
         HIPCHK(c, hipMemcpyAsync(c->stage_pos.p, c->pin_in.p, bp + bz, hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipEventRecord(c->pin_in_done, c->stream));
     } else {
@@ -997,7 +1028,7 @@ extern "C" int uf3_featurize(uf3_basis *b, const uf3_frames *fr, const double *p
 // ------------------------------------------------------------------------------ eval
 static int eval_impl(uf3_basis *b, const uf3_frames *fr, const double *d_pos, const int32_t *d_z, const double *c1,
                      const double *c2, const double *c3, double *d_energies, double *d_forces, double *d_virials,
-                     int64_t atom_begin = 0, int64_t atom_end = -1, int *deferred_cap = nullptr) {
+                     int64_t atom_begin = 0, int64_t atom_end = -1, int *deferred_cap = nullptr, int *flags_tail = nullptr) {
     uf3_ctx *c = b->ctx;
     if (!d_pos || !d_z || !c1 || !d_energies) return fail(c, UF3_EINVAL, "uf3_eval: null argument");
     if ((b->c2_len && !c2) || (b->c3_len && !c3)) return fail(c, UF3_EINVAL, "uf3_eval: missing coefficients");
@@ -1054,7 +1085,7 @@ static int eval_impl(uf3_basis *b, const uf3_frames *fr, const double *d_pos, co
                 if (rc) return rc;
                 A.fuse_n3 = 1;
                 A.n3_need = c->flags.as<int>() + 1;
-                HIPCHK(c, hipMemsetAsync(A.n3_need, 0, sizeof(int), st));
+                if (!P.flags_zeroed || attempt) HIPCHK(c, hipMemsetAsync(A.n3_need, 0, sizeof(int), st));
             }
             const size_t cap = (size_t)A.n3.cap;
             // own list (32 + 20 B per entry), queue of bonds, force on the entries (24), walk-order entries + keys (48)
@@ -1071,7 +1102,7 @@ static int eval_impl(uf3_basis *b, const uf3_frames *fr, const double *d_pos, co
             // (one workgroup per frame and component: wide for big frames, the loop is a latency chain)
             const int sum_threads = P.natoms / P.n_frames >= 2048 ? 1024 : 256;
             hipLaunchKernelGGL(k_frame_sum, dim3(P.n_frames, d_virials ? 7 : 1), dim3(sum_threads), 0, st, A.e_atom,
-                               A.virial, P.d_offsets, d_energies, d_virials);
+                               A.virial, P.d_offsets, d_energies, d_virials, (const int *)c->flags.as<int>(), flags_tail);
             if (fuse && !deferred_cap) {
                 // the lists were part of this launch: did they fit?  (Asked after everything is queued -- all kernels
                 // are safe on clipped lists -- so that the GPU does not idle while the host looks.)
@@ -1111,33 +1142,33 @@ static int eval_host(uf3_basis *b, const uf3_frames *fr, const double *pos, cons
     uf3_ctx *c = b->ctx;
     if (!energies) return fail(c, UF3_EINVAL, "uf3_eval: null energies");
     int natoms = 0;
-    int rc = upload_frames(c, fr, pos, z, natoms);
+    int rc = upload_frames(c, fr, pos, z, natoms, true);
     if (rc) return rc;
     // results in one block: energies [nf] | virials [nf][6] | forces [natoms][3]
     const size_t nf = (size_t)fr->n_frames, bf = forces ? 24 * (size_t)natoms : 0, total = 8 * nf * 7 + bf;
-    HIPCHK(c, c->stage_out.ensure(total));
+    HIPCHK(c, c->stage_out.ensure(total + 16));
     double *d_e = c->stage_out.as<double>(), *d_v = d_e + nf, *d_f = d_e + 7 * nf;
     if (forces && (atom_begin != 0 || (atom_end >= 0 && atom_end != natoms)))   // rows of other ranks' atoms: zero
         HIPCHK(c, hipMemsetAsync(d_f, 0, bf, c->stream));
     if (total + 16 <= UF3_PIN_LIMIT) {
-        // small batch (an MD step): results and the neighbour stage's flags come back in ONE wait -- the lists are
-        // built at the remembered capacity and the evaluation runs on them right away; if they overflowed (or a
-        // species / wrap error was flagged) the results are discarded and the call repeated / failed
+        // small batch (an MD step): results and the neighbour stage's status words come back in ONE download and ONE
+        // wait -- the lists are built at the remembered capacity and the evaluation runs on them right away; if they
+        // overflowed (or a species / wrap error was flagged) the results are discarded and the call repeated / failed
         HIPCHK(c, c->pin_out.ensure(total + 16));
+        int *d_flags_tail = (int *)((char *)c->stage_out.p + total);
         for (int attempt = 0; attempt < 6; attempt++) {
             int cap_used = 0;
             rc = eval_impl(b, fr, c->stage_pos.as<double>(), c->d_stage_z, c1, c2, c3, d_e, forces ? d_f : nullptr,
-                           virials ? d_v : nullptr, atom_begin, atom_end, &cap_used);
+                           virials ? d_v : nullptr, atom_begin, atom_end, &cap_used, d_flags_tail);
             if (rc) return rc;
-            HIPCHK(c, hipMemcpyAsync(c->pin_out.p, d_e, total, hipMemcpyDeviceToHost, c->stream));
-            if (cap_used)
-                HIPCHK(c, hipMemcpyAsync((char *)c->pin_out.p + total, c->flags.p, 16, hipMemcpyDeviceToHost, c->stream));
-            rc = uf3_ctx_synchronize(c);
+            HIPCHK(c, hipMemcpyAsync(c->pin_out.p, d_e, total + 16, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            rc = poll_pending(c, true);
             if (rc) return rc;
-            if (cap_used) {
+            {
                 const int *fl = (const int *)((const char *)c->pin_out.p + total);
                 if (fl[0]) return check_flags(c);
-                if (fl[1] > cap_used) { c->n3_cap = (fl[1] + 8 + 7) / 8 * 8; continue; }
+                if (cap_used && fl[1] > cap_used) { c->n3_cap = (fl[1] + 8 + 7) / 8 * 8; continue; }
             }
             const double *h = (const double *)c->pin_out.p;
             std::memcpy(energies, h, 8 * nf);

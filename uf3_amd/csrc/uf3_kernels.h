@@ -91,6 +91,88 @@ __global__ void k_gather_sorted(const int *sorted_val, int natoms, const double 
     slots[s] = r;
 }
 
+// The whole cell-list stage of a SMALL batch (<= UF3_SMALL_ATOMS atoms: an MD step) in one workgroup: frame / bin /
+// wrap / species per atom, a bitonic sort of (global bin << 32 | atom) in LDS -- the keys are distinct, so the order is
+// the stable radix sort's -- then bin starts and slot records.  One launch instead of seven.
+#define UF3_SMALL_ATOMS 2048
+__global__ void __launch_bounds__(1024)
+k_prepare_small(const BasisDev *B, const FrameGeom *geoms, const int64_t *atom_offsets, int n_frames, int natoms,
+                int nbins, const double *pos, const int32_t *z, int *frame_of, int *atom_bin, int *atom_wrap,
+                signed char *spec, int *bin_start, SlotRec *slots, int *flags, int n_zero_flags) {
+    __shared__ unsigned long long keys[UF3_SMALL_ATOMS];
+    const int tid = threadIdx.x;
+    if (tid < n_zero_flags) flags[1 + tid] = 0;                   // (n3_need, cand_need of the launches that follow)
+    int n_pow2 = 64;
+    while (n_pow2 < natoms) n_pow2 <<= 1;
+    for (int a = tid; a < n_pow2; a += 1024) {
+        unsigned long long key = ~0ull;
+        if (a < natoms) {
+            int lo = 0, hi = n_frames - 1;                // frame with atom_offsets[f] <= a < atom_offsets[f+1]
+            while (lo < hi) {
+                int mid = (lo + hi + 1) >> 1;
+                if (atom_offsets[mid] <= a) lo = mid; else hi = mid - 1;
+            }
+            const FrameGeom &g = geoms[lo];
+            frame_of[a] = lo;
+            int zz = z[a];
+            int s = (zz >= 0 && zz < 120) ? B->z2s[zz] : -1;
+            if (s < 0) { atomicExch(flags, 2); s = 0; }
+            spec[a] = (signed char)s;
+            double x = pos[3 * (size_t)a], y = pos[3 * (size_t)a + 1], w = pos[3 * (size_t)a + 2];
+            int bin[3], wrap[3];
+            for (int k = 0; k < 3; k++) {
+                double f = x * g.inv[k] + y * g.inv[3 + k] + w * g.inv[6 + k];
+                if (g.per[k]) {
+                    double fl = floor(f);
+                    int b = (int)((f - fl) * g.nb[k]);
+                    bin[k] = b >= g.nb[k] ? g.nb[k] - 1 : (b < 0 ? 0 : b);
+                    wrap[k] = (int)fl;
+                    if (wrap[k] < -250 || wrap[k] > 250) { atomicExch(flags, 1); wrap[k] = 0; }
+                } else {
+                    long long q = (long long)floor(f / g.binw[k]);
+                    int b = (int)(q % g.nb[k]);
+                    bin[k] = b < 0 ? b + g.nb[k] : b;
+                    wrap[k] = 0;
+                }
+            }
+            int lb = (bin[0] * g.nb[1] + bin[1]) * g.nb[2] + bin[2];
+            atom_bin[a] = lb;
+            atom_wrap[a] = pack3(wrap[0], wrap[1], wrap[2]);
+            key = ((unsigned long long)(unsigned)(g.bin_base + lb) << 32) | (unsigned)a;
+        }
+        keys[a] = key;
+    }
+    __syncthreads();
+    for (int size = 2; size <= n_pow2; size <<= 1)
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int t = tid; t < n_pow2 / 2; t += 1024) {
+                const int i = 2 * t - (t & (stride - 1)), j = i + stride;          // the pair (i, i + stride) of this stage
+                const bool up = (i & size) == 0;
+                const unsigned long long a = keys[i], b = keys[j];
+                if ((a > b) == up) { keys[i] = b; keys[j] = a; }
+            }
+            __syncthreads();
+        }
+    for (int sidx = tid; sidx < natoms; sidx += 1024) {
+        const int a = (int)(unsigned)keys[sidx];
+        SlotRec r;
+        r.x = pos[3 * (size_t)a]; r.y = pos[3 * (size_t)a + 1]; r.z = pos[3 * (size_t)a + 2];
+        r.atom = a;
+        int w0, w1, w2;
+        unpack3(atom_wrap[a], w0, w1, w2);                 // (written by this thread block above; same-block visibility
+        r.ws = pack_ws(w0, w1, w2, spec[a]);               //  through the barriers)
+        slots[sidx] = r;
+    }
+    for (int b = tid; b <= nbins; b += 1024) {             // first slot with bin >= b
+        int lo = 0, hi = natoms;
+        while (lo < hi) {
+            int mid = (lo + hi) >> 1;
+            if ((int)(keys[mid] >> 32) < b) lo = mid + 1; else hi = mid;
+        }
+        bin_start[b] = lo;
+    }
+}
+
 // vector from atom m (original position pm) to the image (slot, shift) of a neighbour
 __device__ __forceinline__ void image_delta(const FrameGeom &g, const SlotRec &sr, int s0, int s1, int s2,
                                             const double *pm, double &dx, double &dy, double &dz) {
@@ -1513,10 +1595,13 @@ k_eval_collect(EvalArgs A) {
 
 // per-frame sums of per-atom quantities: blockIdx.y = 0 energy (width 1), 1..6 virial components (width 6, if
 // given); deterministic tree
+// (flags_dst: the status words of the launches before it ride along behind the results, so that a small batch needs
+// one download)
 __global__ void k_frame_sum(const double *e_atom, const double *v_atom, const int64_t *atom_offsets, double *e_out,
-                            double *v_out) {
+                            double *v_out, const int *flags_src, int *flags_dst) {
     __shared__ double part[1024];
     const int f = blockIdx.x, comp = (int)blockIdx.y - 1;
+    if (flags_dst && f == 0 && comp < 0 && threadIdx.x < 4) flags_dst[threadIdx.x] = flags_src[threadIdx.x];
     const double *src = comp < 0 ? e_atom : v_atom + comp;
     const int width = comp < 0 ? 1 : 6;
     double s = 0.0;
