@@ -1,7 +1,7 @@
 #!/bin/bash
 # Everything profiles/<prefix>_* is condensed from (run on the MI355X box from the repository root):
-#     gpurun --timeout 1500 -- 'bash tools/profile_round.sh gpurun_out/r1j'
-#     python tools/summarize_profiles.py gpurun_out/r1j profiles/round1
+#     gpurun --timeout 1500 -- 'bash tools/profile_round.sh gpurun_out/r2z'
+#     python tools/summarize_profiles.py gpurun_out/r2z profiles/round2
 # Counter passes are separate rocprofv3 runs (--pmc never together with a trace); every command is bounded.
 set -u
 RUN=${1:?run directory under gpurun_out/}
@@ -20,4 +20,7 @@ $T rocprofv3 --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOP
     -d $RUN/pmc3 -o p3 --output-format csv -- $B --steps 4 --warmup 2 > /dev/null 2>&1
 $T python tools/bench_kernels.py > $RUN/kernels.json 2> $RUN/kernels.err
 $T python bench.py > $RUN/bench_default.json 2> $RUN/bench_default.err
+$T python bench.py --mode fit > $RUN/bench_fit.json 2> $RUN/bench_fit.err
+$T python bench.py --mode fit --workload c4 --no-cpu-baseline > $RUN/bench_fit_c4.json 2> $RUN/bench_fit_c4.err
+$T python bench.py --workload lead0 --no-cpu-baseline > $RUN/bench_lead0.json 2> $RUN/bench_lead0.err
 cut -c1-200 $RUN/bench_default.json

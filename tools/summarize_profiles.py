@@ -56,6 +56,8 @@ def main(run, prefix):
     steps = max(int(r["Calls"]) for r in feat)
     rocprof_group_ms = sum(float(r["TotalDurationNs"]) for r in feat) / steps / 1e6
     bench = json.load(open(os.path.join(run, "bench_default.json")))
+    roof = bench["roofline"]
+    alg_bytes = roof["hbm"]["algorithmic_bytes_per_launch"] if "hbm" in roof else roof["algorithmic_bytes_per_launch"]
 
     fetch = featurize_counters(os.path.join(run, "pmc_fetch"))["FETCH_SIZE"]
     write = featurize_counters(os.path.join(run, "pmc_write"))["WRITE_SIZE"]
@@ -73,10 +75,9 @@ def main(run, prefix):
         "WRITE_SIZE_KiB_per_launch": write_kib,
         "hbm_bytes_per_launch_raw": (fetch_kib + write_kib) * 1024,
         "hbm_bytes_per_launch_fetch_x2": (2 * fetch_kib + write_kib) * 1024,
-        "algorithmic_bytes_per_launch": bench["roofline"]["algorithmic_bytes_per_launch"],
+        "algorithmic_bytes_per_launch": alg_bytes,
         "known_write_bytes_per_launch (rows + 3-body lists at capacity 16)":
-            bench["roofline"]["algorithmic_bytes_per_launch"]
-            + 48 * 16 * bench["config"]["atoms_per_frame"] * bench["config"]["frames_per_step"],
+            alg_bytes + 48 * 16 * bench["config"]["atoms_per_frame"] * bench["config"]["frames_per_step"],
         "kernel_time_agreement": {
             "hip_events_ms_per_step (bench.py, live)": bench["roofline"]["launch_ms"],
             "rocprofv3_kernel_stats_ms_per_step": rocprof_group_ms,

@@ -57,7 +57,8 @@ struct uf3_ctx {
     Buf geoms, offsets, frame_of, atom_bin, atom_wrap, spec, key_in, key_out, val_in, val_out, sort_tmp,
         bin_start, slots, flags,
         n3_cnt, n3_int, n3_dbl, e_atom, nbr_f, coeff, stage_pos, stage_z, stage_out, stage_out2,
-        gram_tiles, frag, dbg;
+        gram_tiles, frag, dbg,
+        halo;                           // marks + index list of the halo atoms of a decomposed frame
     int n3_cap = 0, cand_cap = 0;
     bool n3_tuned = false;           // capacity re-sized once to the lists actually seen
     bool cand_tuned = false;         // a featurizer call has completed with the current candidate capacity
@@ -150,7 +151,7 @@ extern "C" void uf3_ctx_destroy(uf3_ctx *c) {
     hipStreamSynchronize(c->stream);
     Buf *all[] = {&c->geoms, &c->offsets, &c->frame_of, &c->atom_bin, &c->atom_wrap, &c->spec, &c->key_in,
                   &c->key_out, &c->val_in, &c->val_out, &c->sort_tmp, &c->bin_start, &c->slots, &c->flags, &c->n3_cnt, &c->n3_int, &c->n3_dbl, &c->e_atom, &c->nbr_f, &c->coeff,
-                  &c->stage_pos, &c->stage_z, &c->stage_out, &c->stage_out2, &c->gram_tiles, &c->frag, &c->dbg};
+                  &c->stage_pos, &c->stage_z, &c->stage_out, &c->stage_out2, &c->gram_tiles, &c->frag, &c->dbg, &c->halo};
     for (Buf *b : all) b->release();
     c->pin_in.release(); c->pin_geo.release(); c->pin_out.release(); c->pin_flags.release();
     for (auto &pd : c->pending_chk) if (pd.ev) hipEventDestroy(pd.ev);
@@ -639,8 +640,10 @@ static int n3_tune(uf3_ctx *c, const N3Lists &n3, int natoms) {
 // cell list + 3-body neighbour lists for a batch (positions / species already in HBM)
 // defer_check: once the list capacity is tuned, do not wait for the build's flags; the caller reads them together
 // with its results and repeats the call if the lists overflowed (all kernels are safe on clipped lists)
+// n3_lo / n3_hi: build the 3-body lists only for the atoms [n3_lo, n3_hi) and for their halo (the atoms in their
+// lists): what a rank of a decomposed frame needs (n3_hi < 0: every atom)
 static int prepare(uf3_basis *b, const uf3_frames *fr, const double *d_pos, const int32_t *d_z, bool need_n3,
-                   Prepared &P, bool defer_check = false) {
+                   Prepared &P, bool defer_check = false, int64_t n3_lo = 0, int64_t n3_hi = -1) {
     uf3_ctx *c = b->ctx;
     if (!fr || fr->n_frames < 1 || !fr->atom_offsets || !fr->cells || !fr->pbc)
         return fail(c, UF3_EINVAL, "bad uf3_frames");
@@ -749,8 +752,25 @@ static int prepare(uf3_basis *b, const uf3_frames *fr, const double *d_pos, cons
             HIPCHK(c, hipMemsetAsync(flags + 1, 0, sizeof(int), st));
             size_t lds = (size_t)cap * (8 + 32 + 16);
             if ((int)lds > c->lds_max) return fail(c, UF3_EOVERFLOW, "3-body neighbour list does not fit in LDS");
-            hipLaunchKernelGGL(k_build_n3, dim3(natoms), dim3(64), lds, st, b->dev, P.geoms, P.frame_of, P.cl, P.n3,
-                               d_pos, natoms, flags + 1);
+            const bool block_only = n3_hi >= 0 && !(n3_lo == 0 && n3_hi == natoms) && !getenv("UF3_NO_HALO");
+            if (!block_only)
+                hipLaunchKernelGGL(k_build_n3, dim3(natoms), dim3(64), lds, st, b->dev, P.geoms, P.frame_of, P.cl, P.n3,
+                                   d_pos, natoms, flags + 1, 0, (const int *)nullptr, (const int *)nullptr);
+            else if (n3_hi > n3_lo) {
+                // the block, then the atoms its lists mention (marked and collected on the device), nothing else
+                const int nb_ = (int)(n3_hi - n3_lo);
+                HIPCHK(c, c->halo.ensure(sizeof(int) * (2 * (size_t)natoms + 4)));
+                int *mark = c->halo.as<int>(), *which = mark + natoms, *n_which = which + natoms;
+                HIPCHK(c, hipMemsetAsync(mark, 0, sizeof(int) * (size_t)natoms, st));
+                HIPCHK(c, hipMemsetAsync(n_which, 0, sizeof(int), st));
+                HIPCHK(c, hipMemsetAsync(P.n3.cnt, 0, sizeof(int) * (size_t)natoms, st));      // lists not built: empty
+                hipLaunchKernelGGL(k_build_n3, dim3(nb_), dim3(64), lds, st, b->dev, P.geoms, P.frame_of, P.cl, P.n3,
+                                   d_pos, natoms, flags + 1, (int)n3_lo, (const int *)nullptr, (const int *)nullptr);
+                hipLaunchKernelGGL(k_mark_halo, dim3(nb_), dim3(64), 0, st, P.n3, (int)n3_lo, (int)n3_hi, mark, which, n_which);
+                // (the halo's size is known on the device only: a grid of the worst case, surplus workgroups leave at once)
+                hipLaunchKernelGGL(k_build_n3, dim3(natoms - nb_), dim3(64), lds, st, b->dev, P.geoms, P.frame_of, P.cl,
+                                   P.n3, d_pos, natoms, flags + 1, 0, (const int *)which, (const int *)n_which);
+            }
             HIPCHK(c, hipGetLastError());
             if (defer_check && c->n3_tuned) { P.deferred = true; return UF3_OK; }
             int fl[4] = {0, 0, 0, 0};                                   // error flag | list length needed | .. | ..
@@ -1041,7 +1061,7 @@ static int eval_impl(uf3_basis *b, const uf3_frames *fr, const double *d_pos, co
     const bool two_pass = whole && d_forces && b->host.T > 0 && !getenv("UF3_EVAL_GATHER");
     const bool fuse = two_pass && c->n3_tuned && c->n3_cap > 0 && !getenv("UF3_SEPARATE_N3");
     Prepared P;
-    int rc = prepare(b, fr, d_pos, d_z, !fuse, P, deferred_cap != nullptr);
+    int rc = prepare(b, fr, d_pos, d_z, !fuse, P, deferred_cap != nullptr, atom_begin, whole ? -1 : atom_end);
     if (rc) return rc;
     if (deferred_cap) *deferred_cap = P.deferred ? P.n3.cap : 0;
     hipStream_t st = c->stream;

@@ -187,16 +187,19 @@ __device__ __forceinline__ void image_delta(const FrameGeom &g, const SlotRec &s
 // ---------------------------------------------------------------------------------
 // 3-body neighbour lists: one wave per atom
 // ---------------------------------------------------------------------------------
+// atom of workgroup blockIdx.x: first + blockIdx.x, or which[blockIdx.x] when an index list is given (the halo of a
+// block of atoms: its length is read on the device, the grid is an upper bound)
 __global__ void __launch_bounds__(64)
 k_build_n3(const BasisDev *B, const FrameGeom *geoms, const int *frame_of, CellList cl, N3Lists n3,
-           const double *pos, int natoms, int *overflow_need) {
+           const double *pos, int natoms, int *overflow_need, int first, const int *which, const int *n_which) {
     extern __shared__ __align__(16) unsigned char smem[];
     int cap = n3.cap;
     unsigned long long *key = (unsigned long long *)smem;
     double *ex = (double *)(key + cap), *ey = ex + cap, *ez = ey + cap, *er = ez + cap;
     int *eparent = (int *)(er + cap), *eshift = eparent + cap, *esidx = eshift + cap, *espec = esidx + cap;
 
-    int m = blockIdx.x;
+    int m = first + blockIdx.x;
+    if (which) { if ((int)blockIdx.x >= *n_which) return; m = which[blockIdx.x]; }
     if (m >= natoms) return;
     int lane = lane_id();
     const FrameGeom g = geoms[frame_of[m]];
@@ -244,6 +247,19 @@ k_build_n3(const BasisDev *B, const FrameGeom *geoms, const int *frame_of, CellL
     }
 }
 
+
+// Halo of a block of atoms [lo, hi) for the gather route of the evaluator: the atoms outside the block that appear in
+// a block atom's 3-body list (their own lists are walked by the block's atoms).  mark[] must be zero on entry; the
+// order of `which` does not matter (it only decides which workgroup builds which list).
+__global__ void k_mark_halo(N3Lists n3, int lo, int hi, int *mark, int *which, int *n_which) {
+    const int m = lo + blockIdx.x;
+    if (m >= hi) return;
+    const int n = min(n3.cnt[m], n3.cap);
+    for (int e = threadIdx.x; e < n; e += blockDim.x) {
+        const int p = n3.ent[(size_t)m * n3.cap + e].parent;
+        if ((p < lo || p >= hi) && atomicExch(mark + p, 1) == 0) which[atomicAdd(n_which, 1)] = p;
+    }
+}
 
 // largest list length of a batch (capacity tuning after the first build of a context)
 __global__ void k_max_count(const int *cnt, int n, int *out) {
