@@ -763,7 +763,7 @@ __device__ __forceinline__ void dense_accumulate(const double *stage, int rt_str
     const int half = lane_id() >> 5;                          // which record of the step this lane's K slot belongs to
     const double *rec = stage + (size_t)(r0 + half) * stride;
     int q = r0;
-    if (STRIDE) {
+    if (STRIDE && RT * CT <= 4) {      // (a step of a wide window is 8-12 MFMAs: nothing to gain, registers to lose)
         for (; q + 8 <= r1; q += 8, rec += 8 * stride) {
 #pragma unroll
             for (int u = 0; u < 4; u++) dense_step<TMASK, RT, CT>(rec + 2 * u * stride, o, acc);
