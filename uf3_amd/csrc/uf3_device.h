@@ -46,6 +46,11 @@ struct TrioDev {
     // two column tiles (n-major columns): a record with r_n <= thr0 touches tile 0 only, with r_n > thr2 tile 1 only
     // (knot values of leg n, so the classes are exact for any knot sequence)
     double thr0, thr2;
+    // grouped != 0 (3 x 3 x <=9 windows): the n bins are covered by three overlapping groups of five, [0,4] [2,6] [4,8];
+    // a record's four n bins lie inside ONE group -- r_n <= gthr0: group 0, r_n > gthr2: group 2, else group 1 -- so
+    // every step is a single MFMA into its group's accumulator tile (columns (n - group base, m): 15 of 16)
+    double gthr0, gthr2;
+    int grouped;
 };
 
 struct BasisDev {

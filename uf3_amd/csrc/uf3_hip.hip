@@ -383,6 +383,16 @@ extern "C" int uf3_basis_create(uf3_ctx *c, const uf3_basis_spec *s, uf3_basis *
             b->dense_stride[dmode] = std::max(b->dense_stride[dmode], dl.stride);
             b->dense_dump[dmode] = std::max(b->dense_dump[dmode], td.ext[0] * dl.cw);
         }
+        td.grouped = 0; td.gthr0 = -1e300; td.gthr2 = 1e300;
+        if (td.dense == 7 && td.ext[1] == 3 && td.ext[0] <= 3 && td.ext[2] >= 6 && td.ext[2] <= 9 && !getenv("UF3_NO_NGROUP")) {
+            // first window bin f = interval - 3 - lo_n: f <= 1 -> group 0 (bins 0..4), f >= 4 -> group 2 (bins 4..8)
+            const double *tn = legn_knots[t];
+            const int nk = td.leg[2].nk, i_lo = 3, i_hi = nk - 5;
+            const int i0 = td.lo[2] + 4, i2 = td.lo[2] + 7;       // last interval of group 0, first of group 2
+            td.grouped = 1;
+            if (i0 >= i_lo) td.gthr0 = tn[std::min(i0, i_hi) + 1];
+            if (i2 <= i_hi) td.gthr2 = tn[std::max(i2, i_lo)];
+        }
         td.thr0 = -1e300; td.thr2 = 1e300;
         if (td.dense && dense_ct(td.dense) == 2) {
             // intervals of leg n in order: tile 0 only, ..., tile 1 only (an interval i holds t_i < r <= t_{i+1})

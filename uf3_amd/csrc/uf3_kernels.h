@@ -999,6 +999,187 @@ __device__ __forceinline__ void trio_block_mfma(const FeatArgs &A, const BasisDe
     // the dump left window values in the stage: stale slots must stay finite (they are multiplied by 0), which they are
 }
 
+// ---- grouped n windows: the 3 x 3 x 9 blocks of the reference's default trims ------------------------------------
+// The 27 columns (n, m) of such a window need two 16-column tiles, but a record touches four consecutive n bins only.
+// Cover the n bins by three overlapping groups of five ([0,4], [2,6], [4,8]: 15 columns each = ONE tile): every record
+// falls into exactly one group (TrioDev::gthr0 / gthr2), the walk sorts its triplets by group, a step of two records
+// of one group is a single MFMA into that group's accumulator, and the step at a group boundary runs once per group
+// with the other record's B operand zeroed.  137 steps -> ~165 MFMA per atom instead of 222 (two tiles with skipping),
+// a staged record shrinks from 40 to 32 doubles.  The three accumulator tiles are added into the usual dumped window
+// (rows (c, l), columns n-major) before the symmetry fold.
+template <bool WANT_E>
+__device__ __forceinline__ void trio_block_grouped(const FeatArgs &A, const BasisDev *B, const KnotRec *recs, const FrameGeom &g,
+                                                   const WaveLds &w, int m, int sm, int t, const ESink &es,
+                                                   const int (&fragp)[4], const int *dsrc) {
+    constexpr int STRIDE = 32, GW = 5, NG = 3;
+    constexpr bool WANT_F = true;
+    const int lane = lane_id();
+    const TrioDev td_copy = load_const(A.trios + t);
+    const TrioDev *td = &td_copy;
+    TrioWalk k;
+    trio_walk_setup<WANT_F>(A, w, td, sm, k);
+    const int ncol = td->ncol, F = B->F;
+    const int lo_l = td->lo[0], lo_m = td->lo[1], lo_n = td->lo[2];
+    const int ext_l = td->ext[0], ext_m = td->ext[1], ext_n = td->ext[2];
+    const int oM = 2 * ext_l, oN = oM + 2 * ext_m, oD = oN + 2 * GW, oZ = oD + 8;       // (oZ + 2 <= STRIDE: ext_l, ext_m <= 3)
+    const int r16 = lane & 15, slot = (lane >> 4) & 1;
+    const int inv_l = (65536 + ext_l - 1) / ext_l, inv_m = (65536 + ext_m - 1) / ext_m;
+    DenseLane<1, 1> o;
+    {
+        const int c = (r16 * inv_l) >> 16, pl = r16 - c * ext_l;
+        const bool ok = c < 3 || (c == 3 && WANT_E);
+        o.aL[0] = ok ? 2 * pl + (c == 3 ? 1 : slot) : oZ;
+        o.aD[0] = ok ? oD + 2 * c + slot : oZ;
+        const int nl = (r16 * inv_m) >> 16, pm = r16 - nl * ext_m;         // column = (n - group base) * ext_m + m
+        o.bM[0] = nl < GW ? oM + 2 * pm + slot : oZ;
+        o.bN[0] = nl < GW ? oN + 2 * nl + slot : oZ;
+    }
+    const int li = (lane * 21846) >> 16, leg = lane - 3 * li;
+    LegDev lg;
+    lg.rec_off = leg == 0 ? td->leg[0].rec_off : (leg == 1 ? td->leg[1].rec_off : td->leg[2].rec_off);
+    lg.nk = leg == 0 ? td->leg[0].nk : (leg == 1 ? td->leg[1].nk : td->leg[2].nk);
+    lg.t0 = leg == 0 ? td->leg[0].t0 : (leg == 1 ? td->leg[1].t0 : td->leg[2].t0);
+    lg.tlast = leg == 0 ? td->leg[0].tlast : (leg == 1 ? td->leg[1].tlast : td->leg[2].tlast);
+    lg.inv_h = leg == 0 ? td->leg[0].inv_h : (leg == 1 ? td->leg[1].inv_h : td->leg[2].inv_h);
+    const int w_off = leg == 0 ? 0 : (leg == 1 ? oM : oN);
+    const double gthr0 = td->gthr0, gthr2 = td->gthr2;
+    double4_t acc[NG][1][1];
+#pragma unroll
+    for (int q = 0; q < NG; q++) acc[q][0][0] = double4_t{0, 0, 0, 0};
+    const int nrec = A.dense_nrec, batch = 3 * nrec;
+    const double lo_r[3] = {td->leg[0].t0, td->leg[1].t0, td->leg[2].t0};
+    const double hi_r[3] = {td->leg[0].tlast, td->leg[1].tlast, td->leg[2].tlast};
+    // records [r0, r1) (even bounds) of one group into its tile: two steps per trip, then at most one more
+    auto range = [&](int r0, int r1, double4_t (&acc_g)[1][1]) {
+        const double *rec = w.stage + (size_t)(r0 + (lane >> 5)) * STRIDE;
+        int q = r0;
+        for (; q + 4 <= r1; q += 4, rec += 4 * STRIDE) {
+            dense_step<1, 1, 1>(rec, o, acc_g);
+            dense_step<1, 1, 1>(rec + 2 * STRIDE, o, acc_g);
+        }
+        if (q < r1) dense_step<1, 1, 1>(rec, o, acc_g);
+    };
+    // the step of records (2s, 2s + 1) that belong to groups ga < gb: once per group, the other record's B zeroed
+    auto straddle = [&](int s2, double4_t (&acc_a)[1][1], double4_t (&acc_b)[1][1]) {
+        const int half = lane >> 5;
+        const double *rec = w.stage + (size_t)(s2 + half) * STRIDE;
+        const double la = rec[o.aL[0]], da = rec[o.aD[0]], mb = rec[o.bM[0]], nb = rec[o.bN[0]];
+        const double a = la * da, b = mb * nb;
+        acc_a[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, half == 0 ? b : 0.0, acc_a[0][0], 0, 0, 0);
+        acc_b[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, half == 1 ? b : 0.0, acc_b[0][0], 0, 0, 0);
+    };
+    for (int p0 = 0; p0 < k.n_items; p0 += batch) {
+        int n_valid, n_g0, n_g01;
+        {
+            TripletGeom tg;
+            bool valid = lane < batch && p0 + lane < k.n_items;
+            if (valid) valid = trio_walk_geom<WANT_F>(A, g, w, td, k, m, sm, p0 + lane, tg);
+            if (valid)
+                valid = (tg.rl > lo_r[0]) & (tg.rl < hi_r[0]) & (tg.rm > lo_r[1]) & (tg.rm < hi_r[1]) &
+                        (tg.rn > lo_r[2]) & (tg.rn < hi_r[2]);
+            const bool is0 = valid && tg.rn <= gthr0, is2 = valid && tg.rn > gthr2, is1 = valid && !is0 && !is2;
+            const unsigned long long m0 = __ballot(is0), m1 = __ballot(is1), m2 = __ballot(is2);
+            n_g0 = __popcll(m0); n_g01 = n_g0 + __popcll(m1);
+            n_valid = n_g01 + __popcll(m2);
+            if (valid) {
+                const int rank = is0 ? mbcnt(m0) : (is1 ? n_g0 + mbcnt(m1) : n_g01 + mbcnt(m2));
+                double *gq = w.geo + rank;
+                gq[0] = tg.rl; gq[GEO_N] = tg.rm; gq[2 * GEO_N] = tg.rn;
+                gq[3 * GEO_N] = tg.a3[0]; gq[4 * GEO_N] = tg.a3[1]; gq[5 * GEO_N] = tg.a3[2];
+                ((int2 *)(w.geo + 6 * GEO_N))[rank] =
+                    make_int2(tg.i1 | (tg.i2 << 16), (tg.centre ? 0 : (tg.first ? 1 : 2)) | ((is0 ? 0 : (is1 ? 1 : 2)) << 2));
+            }
+        }
+        wave_sync();
+        for (int base = 0; base < n_valid; base += nrec) {
+            const int n_part = min(nrec, n_valid - base);
+            const int n_staged = n_part + (n_part & 1);
+            const bool mine = li < n_part && !(A.skip & 16);
+            if (!(A.skip & 16))
+                for (int q = 2 * lane; q < n_staged * STRIDE; q += 2 * WAVE) *(double2 *)(w.stage + q) = double2{0.0, 0.0};
+            if (mine) {
+                const int gi = base + li;
+                const double x = w.geo[leg * GEO_N + gi];
+                KnotRec kr;
+                double v[4], d[4];
+                const int first = load_interval(recs, lg, x, kr) - 3;
+                bspline4<WANT_F>(kr, x, v, d);
+                double *rec = w.stage + (size_t)li * STRIDE;
+                const int2 pk = ((const int2 *)(w.geo + 6 * GEO_N))[gi];
+                const int cls = pk.y & 3, grp = pk.y >> 2;
+                // leg n: window = the record's group; legs l, m: the block's window
+                const int w_lo = leg == 0 ? lo_l : (leg == 1 ? lo_m : lo_n + 2 * grp);
+                const int w_ext = leg == 0 ? ext_l : (leg == 1 ? ext_m : min(GW, ext_n - 2 * grp));
+                const bool d0 = leg == 0 ? cls != 2 : (leg == 1 ? cls == 2 : false);
+                const bool d1 = leg == 0 ? false : (leg == 1 ? cls == 0 : cls != 0);
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const unsigned ws = (unsigned)(first + q - w_lo);
+                    if (ws < (unsigned)w_ext)
+                        *(double2 *)(rec + w_off + 2 * ws) = double2{d0 ? d[q] : v[q], d1 ? d[q] : v[q]};
+                }
+                const int i1 = pk.x & 0xffff, i2 = pk.x >> 16;
+                const double *oc = w.ox + (size_t)leg * A.n3.cap;
+                const double u1 = oc[i1] * w.oir[i1];
+                const double u2 = oc[i2] * w.oir[i2], a3 = w.geo[(3 + leg) * GEO_N + gi];
+                *(double2 *)(rec + oD + 2 * leg) = double2{u1, cls == 0 ? u2 : a3};
+                if (leg == 0 && cls == 0) rec[oD + 6] = 1.0;
+            }
+            // group boundaries inside this pass (records are sorted by group): [0, b0) group 0, [b0, b1) group 1, rest 2
+            const int b0 = max(0, min(n_part, n_g0 - base)), b1 = max(0, min(n_part, n_g01 - base));
+            wave_sync();
+            if (!(A.skip & 8)) {
+                // (a loop per group, not one loop that picks the accumulator per step: the compiler copies every
+                // accumulator tile at each control-flow merge -- per-step selection cost 6500 vector instructions per atom)
+                range(0, b0 & ~1, acc[0]);
+                int start1 = b0;
+                if (b0 & 1) {      // record b0 - 1 is the last of group 0; its partner belongs to group 1, 2 or is the padding
+                    if (b1 > b0) straddle(b0 - 1, acc[0], acc[1]); else straddle(b0 - 1, acc[0], acc[2]);
+                    start1 = b0 + 1;
+                }
+                int start2 = max(b1, start1);
+                if (b1 > start1) {
+                    range(start1, start1 + ((b1 - start1) & ~1), acc[1]);
+                    if ((b1 - start1) & 1) { straddle(b1 - 1, acc[1], acc[2]); start2 = b1 + 1; }
+                }
+                if (start2 < n_staged) range(start2, n_staged, acc[2]);
+            }
+            wave_sync();
+        }
+    }
+    // the three group tiles into the dumped window: rows (c, l) of width cw, columns n-major (n * ext_m + m)
+    double *dump = w.stage;
+    const int cw = 16 * ((ext_m * ext_n + 15) / 16), nsrc = td->nsrc;
+    for (int q = 2 * lane; q < 16 * cw; q += 2 * WAVE) *(double2 *)(dump + q) = double2{0.0, 0.0};
+    wave_sync();
+#pragma unroll
+    for (int grp = 0; grp < NG; grp++) {
+#pragma unroll
+        for (int v = 0; v < 4; v++) {
+            const int fr = fragp[v] >> 4, fc = fragp[v] & 15;
+            const int nl = (fc * inv_m) >> 16, pm = fc - nl * ext_m;
+            if (nl < GW && nl + 2 * grp < ext_n) dump[fr * cw + (nl + 2 * grp) * ext_m + pm] += acc[grp][0][0][v];
+        }
+        wave_sync();
+    }
+    const int comp = ext_l * cw;                                 // doubles per component (x, y, z, then energy)
+    for (int col = lane; col < ncol; col += WAVE) {
+        double fx = 0, fy = 0, fz = 0, en = 0;
+        for (int q = 0; q < nsrc; q++) {
+            const int off = dsrc[td->src_off + col * nsrc + q];
+            if (off < 0) continue;
+            fx += dump[off]; fy += dump[comp + off]; fz += dump[2 * comp + off];
+            if (WANT_E) en += dump[3 * comp + off];
+        }
+        if (!(A.skip & 32)) {
+            double *dst = A.x_f + (size_t)m * 3 * F + td->col + col;
+            dst[0] = fx; dst[F] = fy; dst[2 * (size_t)F] = fz;
+        }
+        if (WANT_E) es.add(td->col + col, en);
+    }
+    wave_sync();
+}
+
 // 2-body columns of atom m: lanes <-> neighbour images (the candidates collected in LDS).  Each lane evaluates its
 // bond once and adds its four basis values / derivatives into a per-wave row buffer in LDS (native ds_add_f64;
 // bonds of one shell hit the same four columns, the LDS serialises those); the buffer then leaves as coalesced
@@ -1272,6 +1453,8 @@ k_featurize(FeatArgs A) {
                 else if (MODE == 3) trio_block<WANT_E, WANT_F, 2, 1>(A, B, recs, g, w, m, sm, t, es);
                 else if (MODE == 4) trio_block<WANT_E, WANT_F, 2, 2>(A, B, recs, g, w, m, sm, t, es);
                 else if (MODE == 5) trio_block<WANT_E, WANT_F, 6, 1>(A, B, recs, g, w, m, sm, t, es);
+                else if (MODE == 7 && WANT_F && load_const(&td->grouped))
+                    trio_block_grouped<WANT_E>(A, B, recs, g, w, m, sm, t, es, fragp, dsrc);
                 else trio_block_mfma<WANT_E, WANT_F, (MODE >= 6 ? MODE : 6)>(A, B, recs, g, w, m, sm, t, es, fragp, dsrc);
             }
         }
