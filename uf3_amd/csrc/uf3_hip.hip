@@ -98,6 +98,7 @@ struct uf3_basis {
     size_t c2_len = 0, c3_len = 0, n_recs = 0;
     size_t n_pair_recs = 0;
     int dense_stride[16] = {0};      // per featurizer mode: largest staged-record stride (doubles) among its trios
+    int dense_stride_f[16] = {0};    // ... when force rows are wanted (grouped 3 x 3 x 9 windows stage 32-double records)
     int dense_dump[16] = {0};        // ... smallest stage (doubles) the fold of its widest window needs
     int modes = 1;                   // bit m set: some trio block is handled by featurizer specialisation m
     double r_cut = 0;
@@ -393,6 +394,7 @@ extern "C" int uf3_basis_create(uf3_ctx *c, const uf3_basis_spec *s, uf3_basis *
             if (i0 >= i_lo) td.gthr0 = tn[std::min(i0, i_hi) + 1];
             if (i2 <= i_hi) td.gthr2 = tn[std::max(i2, i_lo)];
         }
+        if (td.dense) b->dense_stride_f[td.dense] = std::max(b->dense_stride_f[td.dense], td.grouped ? 32 : dl.stride);
         td.thr0 = -1e300; td.thr2 = 1e300;
         if (td.dense && dense_ct(td.dense) == 2) {
             // intervals of leg n in order: tile 0 only, ..., tile 1 only (an interval i holds t_i < r <= t_{i+1})
@@ -892,7 +894,8 @@ extern "C" int uf3_featurize_dev(uf3_basis *b, const uf3_frames *fr, const doubl
                 size_t lds = 0, lds_plain = 0, lds_recs = 0;
                 bool found = false;
                 if (dense_mode) {
-                    const int stride = b->dense_stride[mode], dump = b->dense_dump[mode];
+                    const int stride = want_f ? b->dense_stride_f[mode] : b->dense_stride[mode];
+                    const int dump = want_f && stride == 32 ? std::max(512, b->dense_dump[mode]) : b->dense_dump[mode];
                     const int nrec_max = std::max(4, std::min(DENSE_NREC, 1200 / stride));
                     auto stage_for = [&](int nr) { return std::max(dump, (nr + (nr & 1)) * stride); };   // (+ the padding record of an odd pass)
                     A.dense_nrec = nrec_max; A.dense_stage = stage_for(nrec_max);
