@@ -99,6 +99,7 @@ struct uf3_basis {
     size_t n_pair_recs = 0;
     int dense_stride[16] = {0};      // per featurizer mode: largest staged-record stride (doubles) among its trios
     int dense_stride_f[16] = {0};    // ... when force rows are wanted (grouped 3 x 3 x 9 windows stage 32-double records)
+    bool dense_grouped[16] = {false}; // a trio of the mode stages grouped n windows (even-aligned groups: up to two padding records per pass)
     int dense_dump[16] = {0};        // ... smallest stage (doubles) the fold of its widest window needs
     int modes = 1;                   // bit m set: some trio block is handled by featurizer specialisation m
     double r_cut = 0;
@@ -395,6 +396,7 @@ extern "C" int uf3_basis_create(uf3_ctx *c, const uf3_basis_spec *s, uf3_basis *
             if (i2 <= i_hi) td.gthr2 = tn[std::max(i2, i_lo)];
         }
         if (td.dense) b->dense_stride_f[td.dense] = std::max(b->dense_stride_f[td.dense], td.grouped ? 32 : dl.stride);
+        if (td.dense && td.grouped) b->dense_grouped[td.dense] = true;
         td.thr0 = -1e300; td.thr2 = 1e300;
         if (td.dense && dense_ct(td.dense) == 2) {
             // intervals of leg n in order: tile 0 only, ..., tile 1 only (an interval i holds t_i < r <= t_{i+1})
@@ -896,8 +898,10 @@ extern "C" int uf3_featurize_dev(uf3_basis *b, const uf3_frames *fr, const doubl
                 if (dense_mode) {
                     const int stride = want_f ? b->dense_stride_f[mode] : b->dense_stride[mode];
                     const int dump = want_f && stride == 32 ? std::max(512, b->dense_dump[mode]) : b->dense_dump[mode];
-                    const int nrec_max = std::max(4, std::min(DENSE_NREC, 1200 / stride));
-                    auto stage_for = [&](int nr) { return std::max(dump, (nr + (nr & 1)) * stride); };   // (+ the padding record of an odd pass)
+                    const bool grouped = want_f && b->dense_grouped[mode];
+                    const int nrec_max = std::max(4, std::min(grouped ? 20 : DENSE_NREC, 1200 / stride));
+                    // (+ the padding record of an odd pass; grouped windows: one per odd group, at most 2 + (nr odd))
+                    auto stage_for = [&](int nr) { return std::max(dump, (nr + (nr & 1) + (grouped ? 2 : 0)) * stride); };
                     A.dense_nrec = nrec_max; A.dense_stage = stage_for(nrec_max);
                     if (mode <= 7 && !getenv("UF3_NO_OCC3")) {
                         // records per staging pass: as many as the stage allows; fewer (smaller stage) if that lets a third

@@ -1007,6 +1007,74 @@ __device__ __forceinline__ void trio_block_mfma(const FeatArgs &A, const BasisDe
 // with the other record's B operand zeroed.  137 steps -> ~165 MFMA per atom instead of 222 (two tiles with skipping),
 // a staged record shrinks from 40 to 32 doubles.  The three accumulator tiles are added into the usual dumped window
 // (rows (c, l), columns n-major) before the symmetry fold.
+// The MFMA steps of one staged pass of the grouped windows, written out by hand: records of group g fill the even-aligned
+// slot range that follows group g - 1 (an odd group is padded with a zero record), so one set of four operand addresses
+// runs through the stage and group g's steps accumulate into its own tile.  Why assembly: with three accumulator tiles
+// alive across three loops the compiler copies whole tiles at every loop boundary (about 100 v_mov per pass, 1400 per
+// atom).  Inside one asm statement the tiles stay where they are: per step 4 LDS reads, 2 products, 2 address updates
+// (two steps per trip share them through the immediate offset) and the MFMA.
+// Spacing: a VALU result needs two issue slots before an MFMA may read it as A / B (the compiler's s_nop 1); MFMAs that
+// chain through the accumulator need none; 18 wait states after the last MFMA before other code may read a tile.
+#define UF3_GROUP_STEPS(G)                                                                      \
+    "s_cmp_lt_u32 %[n" G "], 2\n"                                                               \
+    "s_cbranch_scc1 1f\n"                                                                       \
+    "0:\n"                                                                                      \
+    "ds_read_b64 %[la], %[va]\n"                                                                \
+    "ds_read_b64 %[da], %[vd]\n"                                                                \
+    "ds_read_b64 %[mb], %[vm]\n"                                                                \
+    "ds_read_b64 %[nb], %[vn]\n"                                                                \
+    "ds_read_b64 %[la2], %[va] offset:512\n"                                                    \
+    "ds_read_b64 %[da2], %[vd] offset:512\n"                                                    \
+    "ds_read_b64 %[mb2], %[vm] offset:512\n"                                                    \
+    "ds_read_b64 %[nb2], %[vn] offset:512\n"                                                    \
+    "s_sub_u32 %[n" G "], %[n" G "], 2\n"                                                       \
+    "v_add_u32 %[va], 0x400, %[va]\n"                                                           \
+    "v_add_u32 %[vd], 0x400, %[vd]\n"                                                           \
+    "v_add_u32 %[vm], 0x400, %[vm]\n"                                                           \
+    "v_add_u32 %[vn], 0x400, %[vn]\n"                                                           \
+    "s_waitcnt lgkmcnt(4)\n"                                                                    \
+    "v_mul_f64 %[la], %[la], %[da]\n"                                                           \
+    "v_mul_f64 %[mb], %[mb], %[nb]\n"                                                           \
+    "s_waitcnt lgkmcnt(0)\n"                                                                    \
+    "v_mul_f64 %[la2], %[la2], %[da2]\n"                                                        \
+    "v_mul_f64 %[mb2], %[mb2], %[nb2]\n"                                                        \
+    "v_mfma_f64_16x16x4_f64 %[acc" G "], %[la], %[mb], %[acc" G "]\n"                           \
+    "s_cmp_lt_u32 %[n" G "], 2\n"                                                               \
+    "v_mfma_f64_16x16x4_f64 %[acc" G "], %[la2], %[mb2], %[acc" G "]\n"                         \
+    "s_cbranch_scc0 0b\n"                                                                       \
+    "1:\n"                                                                                      \
+    "s_cmp_eq_u32 %[n" G "], 0\n"                                                               \
+    "s_cbranch_scc1 2f\n"                                                                       \
+    "ds_read_b64 %[la], %[va]\n"                                                                \
+    "ds_read_b64 %[da], %[vd]\n"                                                                \
+    "ds_read_b64 %[mb], %[vm]\n"                                                                \
+    "ds_read_b64 %[nb], %[vn]\n"                                                                \
+    "v_add_u32 %[va], 0x200, %[va]\n"                                                           \
+    "v_add_u32 %[vd], 0x200, %[vd]\n"                                                           \
+    "v_add_u32 %[vm], 0x200, %[vm]\n"                                                           \
+    "v_add_u32 %[vn], 0x200, %[vn]\n"                                                           \
+    "s_waitcnt lgkmcnt(2)\n"                                                                    \
+    "v_mul_f64 %[la], %[la], %[da]\n"                                                           \
+    "s_waitcnt lgkmcnt(0)\n"                                                                    \
+    "v_mul_f64 %[mb], %[mb], %[nb]\n"                                                           \
+    "s_nop 1\n"                                                                                 \
+    "v_mfma_f64_16x16x4_f64 %[acc" G "], %[la], %[mb], %[acc" G "]\n"                           \
+    "2:\n"
+
+__device__ __forceinline__ void grouped_pass_steps(unsigned va, unsigned vd, unsigned vm, unsigned vn, int n0, int n1, int n2,
+                                                   double4_t &acc0, double4_t &acc1, double4_t &acc2) {
+    double la, da, mb, nb, la2, da2, mb2, nb2;
+    asm volatile(UF3_GROUP_STEPS("0") UF3_GROUP_STEPS("1") UF3_GROUP_STEPS("2")
+                 "s_nop 15\n"
+                 "s_nop 3\n"
+                 : [acc0] "+v"(acc0), [acc1] "+v"(acc1), [acc2] "+v"(acc2), [va] "+v"(va), [vd] "+v"(vd), [vm] "+v"(vm),
+                   [vn] "+v"(vn), [n0] "+s"(n0), [n1] "+s"(n1), [n2] "+s"(n2), [la] "=&v"(la), [da] "=&v"(da), [mb] "=&v"(mb),
+                   [nb] "=&v"(nb), [la2] "=&v"(la2), [da2] "=&v"(da2), [mb2] "=&v"(mb2), [nb2] "=&v"(nb2)
+                 :
+                 : "scc", "memory");
+}
+#undef UF3_GROUP_STEPS
+
 template <bool WANT_E>
 __device__ __forceinline__ void trio_block_grouped(const FeatArgs &A, const BasisDev *B, const KnotRec *recs, const FrameGeom &g,
                                                    const WaveLds &w, int m, int sm, int t, const ESink &es,
@@ -1049,25 +1117,10 @@ __device__ __forceinline__ void trio_block_grouped(const FeatArgs &A, const Basi
     const int nrec = A.dense_nrec, batch = 3 * nrec;
     const double lo_r[3] = {td->leg[0].t0, td->leg[1].t0, td->leg[2].t0};
     const double hi_r[3] = {td->leg[0].tlast, td->leg[1].tlast, td->leg[2].tlast};
-    // records [r0, r1) (even bounds) of one group into its tile: two steps per trip, then at most one more
-    auto range = [&](int r0, int r1, double4_t (&acc_g)[1][1]) {
-        const double *rec = w.stage + (size_t)(r0 + (lane >> 5)) * STRIDE;
-        int q = r0;
-        for (; q + 4 <= r1; q += 4, rec += 4 * STRIDE) {
-            dense_step<1, 1, 1>(rec, o, acc_g);
-            dense_step<1, 1, 1>(rec + 2 * STRIDE, o, acc_g);
-        }
-        if (q < r1) dense_step<1, 1, 1>(rec, o, acc_g);
-    };
-    // the step of records (2s, 2s + 1) that belong to groups ga < gb: once per group, the other record's B zeroed
-    auto straddle = [&](int s2, double4_t (&acc_a)[1][1], double4_t (&acc_b)[1][1]) {
-        const int half = lane >> 5;
-        const double *rec = w.stage + (size_t)(s2 + half) * STRIDE;
-        const double la = rec[o.aL[0]], da = rec[o.aD[0]], mb = rec[o.bM[0]], nb = rec[o.bN[0]];
-        const double a = la * da, b = mb * nb;
-        acc_a[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, half == 0 ? b : 0.0, acc_a[0][0], 0, 0, 0);
-        acc_b[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, half == 1 ? b : 0.0, acc_b[0][0], 0, 0, 0);
-    };
+    // LDS byte addresses of this lane's four operands in record (lane >> 5) of the stage
+    const unsigned stage_lds = (unsigned)(size_t)(__attribute__((address_space(3))) double *)w.stage + (lane >> 5) * (STRIDE * 8);
+    const unsigned a_va = stage_lds + 8 * o.aL[0], a_vd = stage_lds + 8 * o.aD[0], a_vm = stage_lds + 8 * o.bM[0],
+                   a_vn = stage_lds + 8 * o.bN[0];
     for (int p0 = 0; p0 < k.n_items; p0 += batch) {
         int n_valid, n_g0, n_g01;
         {
@@ -1093,7 +1146,11 @@ __device__ __forceinline__ void trio_block_grouped(const FeatArgs &A, const Basi
         wave_sync();
         for (int base = 0; base < n_valid; base += nrec) {
             const int n_part = min(nrec, n_valid - base);
-            const int n_staged = n_part + (n_part & 1);
+            // group boundaries inside this pass (records are sorted by group): [0, b0) group 0, [b0, b1) group 1, rest 2;
+            // every group starts on an even slot (its steps never share a record pair with another group's)
+            const int b0 = max(0, min(n_part, n_g0 - base)), b1 = max(0, min(n_part, n_g01 - base));
+            const int st0 = (b0 + 1) >> 1, st1 = (b1 - b0 + 1) >> 1, st2 = (n_part - b1 + 1) >> 1;
+            const int n_staged = 2 * (st0 + st1 + st2);
             const bool mine = li < n_part && !(A.skip & 16);
             if (!(A.skip & 16))
                 for (int q = 2 * lane; q < n_staged * STRIDE; q += 2 * WAVE) *(double2 *)(w.stage + q) = double2{0.0, 0.0};
@@ -1104,7 +1161,7 @@ __device__ __forceinline__ void trio_block_grouped(const FeatArgs &A, const Basi
                 double v[4], d[4];
                 const int first = load_interval(recs, lg, x, kr) - 3;
                 bspline4<WANT_F>(kr, x, v, d);
-                double *rec = w.stage + (size_t)li * STRIDE;
+                double *rec = w.stage + (size_t)(li + (li >= b0 ? (b0 & 1) : 0) + (li >= b1 ? ((b1 - b0) & 1) : 0)) * STRIDE;
                 const int2 pk = ((const int2 *)(w.geo + 6 * GEO_N))[gi];
                 const int cls = pk.y & 3, grp = pk.y >> 2;
                 // leg n: window = the record's group; legs l, m: the block's window
@@ -1125,25 +1182,8 @@ __device__ __forceinline__ void trio_block_grouped(const FeatArgs &A, const Basi
                 *(double2 *)(rec + oD + 2 * leg) = double2{u1, cls == 0 ? u2 : a3};
                 if (leg == 0 && cls == 0) rec[oD + 6] = 1.0;
             }
-            // group boundaries inside this pass (records are sorted by group): [0, b0) group 0, [b0, b1) group 1, rest 2
-            const int b0 = max(0, min(n_part, n_g0 - base)), b1 = max(0, min(n_part, n_g01 - base));
             wave_sync();
-            if (!(A.skip & 8)) {
-                // (a loop per group, not one loop that picks the accumulator per step: the compiler copies every
-                // accumulator tile at each control-flow merge -- per-step selection cost 6500 vector instructions per atom)
-                range(0, b0 & ~1, acc[0]);
-                int start1 = b0;
-                if (b0 & 1) {      // record b0 - 1 is the last of group 0; its partner belongs to group 1, 2 or is the padding
-                    if (b1 > b0) straddle(b0 - 1, acc[0], acc[1]); else straddle(b0 - 1, acc[0], acc[2]);
-                    start1 = b0 + 1;
-                }
-                int start2 = max(b1, start1);
-                if (b1 > start1) {
-                    range(start1, start1 + ((b1 - start1) & ~1), acc[1]);
-                    if ((b1 - start1) & 1) { straddle(b1 - 1, acc[1], acc[2]); start2 = b1 + 1; }
-                }
-                if (start2 < n_staged) range(start2, n_staged, acc[2]);
-            }
+            if (!(A.skip & 8)) grouped_pass_steps(a_va, a_vd, a_vm, a_vn, st0, st1, st2, acc[0][0][0], acc[1][0][0], acc[2][0][0]);
             wave_sync();
         }
     }
