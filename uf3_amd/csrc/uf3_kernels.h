@@ -1081,6 +1081,7 @@ __device__ __forceinline__ void trio_block_grouped(const FeatArgs &A, const Basi
                                                    const int (&fragp)[4], const int *dsrc) {
     constexpr int STRIDE = 32, GW = 5, NG = 3;
     constexpr bool WANT_F = true;
+    PhaseClock pc;
     const int lane = lane_id();
     const TrioDev td_copy = load_const(A.trios + t);
     const TrioDev *td = &td_copy;
@@ -1121,6 +1122,7 @@ __device__ __forceinline__ void trio_block_grouped(const FeatArgs &A, const Basi
     const unsigned stage_lds = (unsigned)(size_t)(__attribute__((address_space(3))) double *)w.stage + (lane >> 5) * (STRIDE * 8);
     const unsigned a_va = stage_lds + 8 * o.aL[0], a_vd = stage_lds + 8 * o.aD[0], a_vm = stage_lds + 8 * o.bM[0],
                    a_vn = stage_lds + 8 * o.bN[0];
+    pc.lap(1);
     for (int p0 = 0; p0 < k.n_items; p0 += batch) {
         int n_valid, n_g0, n_g01;
         {
@@ -1144,6 +1146,7 @@ __device__ __forceinline__ void trio_block_grouped(const FeatArgs &A, const Basi
             }
         }
         wave_sync();
+        pc.lap(2);
         for (int base = 0; base < n_valid; base += nrec) {
             const int n_part = min(nrec, n_valid - base);
             // group boundaries inside this pass (records are sorted by group): [0, b0) group 0, [b0, b1) group 1, rest 2;
@@ -1183,7 +1186,9 @@ __device__ __forceinline__ void trio_block_grouped(const FeatArgs &A, const Basi
                 if (leg == 0 && cls == 0) rec[oD + 6] = 1.0;
             }
             wave_sync();
+            pc.lap(4);
             if (!(A.skip & 8)) grouped_pass_steps(a_va, a_vd, a_vm, a_vn, st0, st1, st2, acc[0][0][0], acc[1][0][0], acc[2][0][0]);
+            pc.lap(5);
             wave_sync();
         }
     }
@@ -1218,6 +1223,7 @@ __device__ __forceinline__ void trio_block_grouped(const FeatArgs &A, const Basi
         if (WANT_E) es.add(td->col + col, en);
     }
     wave_sync();
+    pc.lap(6);
 }
 
 // 2-body columns of atom m: lanes <-> neighbour images (the candidates collected in LDS).  Each lane evaluates its
@@ -1950,6 +1956,171 @@ k_gram_mfma(const double *x, int64_t n_rows, int n_feat, int64_t ld, int rows_pe
             if (vals[q] != 0.0) unsafeAtomicAdd(gram + (size_t)gi * n_feat + gj, vals[q]);
         }
     }
+}
+
+// X^T X, LDS-tiled.  G's upper triangle is cut into 64 x 64 patches (4 x 4 MFMA tiles = 128 accumulator registers, one
+// wave each): FULL patches above the diagonal, DIAG patches on it (tiles i <= j only).  A workgroup of four waves takes up
+// to four patches that touch at most four 64-column ranges (2 x 2 neighbours, four diagonal patches, or leftovers packed
+// by the host: GramBlock) over a chunk of rows.  Slabs of GT_KS rows of those ranges go through LDS once per workgroup
+// (coalesced 8-byte loads; the next slab is in flight in registers while the current one is multiplied), so a k-step of
+// 16 MFMAs costs a wave 8 LDS operand reads and no global traffic -- against one wave per 32 x 32 tile with direct loads
+// (k_gram_mfma) a quarter of the cache reads per MFMA and a third of the re-fetch between sibling tiles.  Waves of one
+// workgroup carry the same kind of patch wherever the packing allows, so none idles at the slab barriers.  The
+// workgroups that hold a range's diagonal patch also accumulate X^T y for it while staging.
+#define GT_KS 16
+#define GT_LDW 80         // slab row stride (doubles) of one 64-column range: rows k, k + 1 of an operand read fall into
+                          // different halves of the banks
+struct GramBlock {
+    int range[4];         // 64-column ranges staged by the workgroup (unused slots repeat a used one)
+    int wa[4], wb[4];     // per wave: slot of its A range, of its B range
+    int kind[4];          // per wave: 0 none, 1 FULL, 2 DIAG
+    int ord_mask;         // bit q: this workgroup accumulates X^T y for range[q]
+    int pad[3];
+};
+
+template <int KIND>       // 1: all 16 tiles, 2: tiles (i <= j) of a diagonal patch (A and B are the same columns)
+__device__ __forceinline__ void gram_slab_steps(const double *sa, const double *sb, double4_t (&acc)[4][4], int lane) {
+    const int lo = (lane >> 4) * GT_LDW + (lane & 15);
+#pragma unroll
+    for (int kk = 0; kk < GT_KS / 4; kk++) {
+        double a[4], b[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) a[u] = sa[lo + kk * 4 * GT_LDW + 16 * u];
+#pragma unroll
+        for (int u = 0; u < 4; u++) b[u] = KIND == 2 ? a[u] : sb[lo + kk * 4 * GT_LDW + 16 * u];
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                if (KIND == 1 || j >= i) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+}
+
+__global__ void __launch_bounds__(256, 2)
+k_gram_tiled(const double *x, const double *y, int64_t n_rows, int n_feat, int64_t ld, int rows_per_chunk, int blocks_per_chunk,
+             const GramBlock *blocks, const int *frag_rowcol, double *gram, double *ord) {
+    __shared__ double slab[4][GT_KS * GT_LDW];
+    const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+    // all workgroups of one row chunk run on the same XCD, back to back (one L2 serves their re-reads)
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int chunk = xcd + 8 * (slot / blocks_per_chunk);
+    const GramBlock gb = load_const(blocks + slot % blocks_per_chunk);
+    const int64_t r0 = (int64_t)chunk * rows_per_chunk;
+    if (r0 >= n_rows) return;
+    const int64_t r1 = min(n_rows, r0 + rows_per_chunk);
+    const int kind = wave == 0 ? gb.kind[0] : (wave == 1 ? gb.kind[1] : (wave == 2 ? gb.kind[2] : gb.kind[3]));
+    const int wa = wave == 0 ? gb.wa[0] : (wave == 1 ? gb.wa[1] : (wave == 2 ? gb.wa[2] : gb.wa[3]));
+    const int wb = wave == 0 ? gb.wb[0] : (wave == 1 ? gb.wb[1] : (wave == 2 ? gb.wb[2] : gb.wb[3]));
+    // staging role of this thread: column (t & 63) of every range, rows (t >> 6) + 4 j of the slab
+    const int sc = t & 63, sr = t >> 6;
+    // Nothing conditional inside the slab loop: at every control-flow merge the compiler copies the 64 accumulator pairs, and
+    // a guarded load is a branch.  Columns past n_feat are read from column 0 and multiplied by zero on the way into LDS;
+    // the loop runs over whole slabs (the prefetch of the last trip re-reads the last slab), a ragged tail follows it.
+    const double *pq[4];
+    double mq[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int col = gb.range[q] * 64 + sc;
+        pq[q] = x + (col < n_feat ? col : 0);
+        mq[q] = col < n_feat ? 1.0 : 0.0;
+    }
+    const bool want_ord = gb.ord_mask != 0 && ord && y;
+    double gq[4][GT_KS / 4], oq[4] = {0.0, 0.0, 0.0, 0.0};
+    auto store = [&]() {
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+#pragma unroll
+            for (int j = 0; j < GT_KS / 4; j++) slab[q][(sr + 4 * j) * GT_LDW + sc] = gq[q][j] * mq[q];
+    };
+    double4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = double4_t{0, 0, 0, 0};
+    const double *sa = slab[wa], *sb = slab[wb];
+    const int n_full = (int)((r1 - r0) / GT_KS);
+    const int64_t r_tail = r0 + (int64_t)n_full * GT_KS;
+    // one loop per (patch kind, with / without X^T y)
+    auto run = [&](auto kind_c, auto ord_c) {
+        constexpr int KIND = decltype(kind_c)::value;
+        constexpr bool ORD = decltype(ord_c)::value;
+        auto fetch = [&](int64_t rs, double yscale) {
+#pragma unroll
+            for (int j = 0; j < GT_KS / 4; j++) {
+                const int64_t row = rs + sr + 4 * j;
+                const double yr = ORD ? y[row] * yscale : 0.0;
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    gq[q][j] = pq[q][row * ld];
+                    if (ORD) oq[q] += gq[q][j] * yr;
+                }
+            }
+        };
+        if (n_full > 0) {
+            fetch(r0, 1.0);
+            store();
+            __syncthreads();
+            for (int s = 0; s < n_full; s++) {
+                const bool last = s + 1 >= n_full;
+                fetch(r0 + (int64_t)(last ? s : s + 1) * GT_KS, last ? 0.0 : 1.0);
+                if (KIND) gram_slab_steps<KIND ? KIND : 1>(sa, sb, acc, lane);
+                __syncthreads();
+                store();
+                __syncthreads();
+            }
+        }
+        if (r_tail < r1) {                          // ragged end of the last chunk: rows past it are zeros
+#pragma unroll
+            for (int j = 0; j < GT_KS / 4; j++) {
+                const int64_t row = r_tail + sr + 4 * j;
+#pragma unroll
+                for (int q = 0; q < 4; q++) gq[q][j] = 0.0;
+                if (row < r1) {
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        gq[q][j] = pq[q][row * ld];
+                        if (ORD) oq[q] += gq[q][j] * y[row];
+                    }
+                }
+            }
+            store();
+            __syncthreads();
+            if (KIND) gram_slab_steps<KIND ? KIND : 1>(sa, sb, acc, lane);
+        }
+    };
+    using std::integral_constant;
+    if (want_ord) {
+        if (kind == 1) run(integral_constant<int, 1>{}, integral_constant<bool, true>{});
+        else if (kind == 2) run(integral_constant<int, 2>{}, integral_constant<bool, true>{});
+        else run(integral_constant<int, 0>{}, integral_constant<bool, true>{});
+    } else {
+        if (kind == 1) run(integral_constant<int, 1>{}, integral_constant<bool, false>{});
+        else if (kind == 2) run(integral_constant<int, 2>{}, integral_constant<bool, false>{});
+        else run(integral_constant<int, 0>{}, integral_constant<bool, false>{});
+    }
+    if (want_ord) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int col = gb.range[q] * 64 + sc;
+            if (((gb.ord_mask >> q) & 1) && col < n_feat && oq[q] != 0.0) unsafeAtomicAdd(ord + col, oq[q]);
+        }
+    }
+    if (kind == 0) return;
+    const int a0 = (wa == 0 ? gb.range[0] : (wa == 1 ? gb.range[1] : (wa == 2 ? gb.range[2] : gb.range[3]))) * 64;
+    const int b0 = (wb == 0 ? gb.range[0] : (wb == 1 ? gb.range[1] : (wb == 2 ? gb.range[2] : gb.range[3]))) * 64;
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if (kind == 2 && j < i) continue;
+#pragma unroll
+            for (int v = 0; v < 4; v++) {
+                const int gi = a0 + 16 * i + frag_rowcol[(lane * 4 + v) * 2];
+                const int gj = b0 + 16 * j + frag_rowcol[(lane * 4 + v) * 2 + 1];
+                const double val = acc[i][j][v];
+                if (gi < n_feat && gj < n_feat && gj >= gi && val != 0.0) unsafeAtomicAdd(gram + (size_t)gi * n_feat + gj, val);
+            }
+        }
 }
 
 __global__ void k_gram_mirror(double *gram, int n_feat) {
