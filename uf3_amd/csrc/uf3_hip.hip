@@ -1349,6 +1349,7 @@ extern "C" int uf3_gram_dev(uf3_ctx *c, const double *dx, const double *dy, int6
         }
         // row chunks: about two rounds of workgroups over the chip's resident slots (two per CU)
         const int bpc = c->gram_plan_blocks;
+        // (measured flat between two and twelve workgroups per CU)
         const int want_chunks = std::max(8, (c->n_cu * 4 + bpc - 1) / bpc / 8 * 8);
         int64_t rpc = (n_rows + want_chunks - 1) / want_chunks;
         rpc = std::max<int64_t>(256, (rpc + GT_KS - 1) / GT_KS * GT_KS);

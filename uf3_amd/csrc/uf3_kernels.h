@@ -2025,12 +2025,17 @@ k_gram_tiled(const double *x, const double *y, int64_t n_rows, int n_feat, int64
         mq[q] = col < n_feat ? 1.0 : 0.0;
     }
     const bool want_ord = gb.ord_mask != 0 && ord && y;
-    double gq[4][GT_KS / 4], oq[4] = {0.0, 0.0, 0.0, 0.0};
-    auto store = [&]() {
+    double gq[4][GT_KS / 4], yq[GT_KS / 4], ysc = 0.0, oq[4] = {0.0, 0.0, 0.0, 0.0};
+    // (X^T y is accumulated here, when the prefetched values are consumed anyway -- at fetch time it would wait for the
+    // loads before the slab's MFMAs instead of after them)
+    auto store = [&](bool with_ord) {
 #pragma unroll
         for (int q = 0; q < 4; q++)
 #pragma unroll
-            for (int j = 0; j < GT_KS / 4; j++) slab[q][(sr + 4 * j) * GT_LDW + sc] = gq[q][j] * mq[q];
+            for (int j = 0; j < GT_KS / 4; j++) {
+                slab[q][(sr + 4 * j) * GT_LDW + sc] = gq[q][j] * mq[q];
+                if (with_ord) oq[q] += gq[q][j] * (yq[j] * ysc);
+            }
     };
     double4_t acc[4][4];
 #pragma unroll
@@ -2045,27 +2050,25 @@ k_gram_tiled(const double *x, const double *y, int64_t n_rows, int n_feat, int64
         constexpr int KIND = decltype(kind_c)::value;
         constexpr bool ORD = decltype(ord_c)::value;
         auto fetch = [&](int64_t rs, double yscale) {
+            ysc = yscale;
 #pragma unroll
             for (int j = 0; j < GT_KS / 4; j++) {
                 const int64_t row = rs + sr + 4 * j;
-                const double yr = ORD ? y[row] * yscale : 0.0;
+                if (ORD) yq[j] = y[row];
 #pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    gq[q][j] = pq[q][row * ld];
-                    if (ORD) oq[q] += gq[q][j] * yr;
-                }
+                for (int q = 0; q < 4; q++) gq[q][j] = pq[q][row * ld];
             }
         };
         if (n_full > 0) {
             fetch(r0, 1.0);
-            store();
+            store(ORD);
             __syncthreads();
             for (int s = 0; s < n_full; s++) {
                 const bool last = s + 1 >= n_full;
                 fetch(r0 + (int64_t)(last ? s : s + 1) * GT_KS, last ? 0.0 : 1.0);
                 if (KIND) gram_slab_steps<KIND ? KIND : 1>(sa, sb, acc, lane);
                 __syncthreads();
-                store();
+                store(ORD);
                 __syncthreads();
             }
         }
@@ -2083,7 +2086,7 @@ k_gram_tiled(const double *x, const double *y, int64_t n_rows, int n_feat, int64
                     }
                 }
             }
-            store();
+            store(false);
             __syncthreads();
             if (KIND) gram_slab_steps<KIND ? KIND : 1>(sa, sb, acc, lane);
         }
