@@ -175,6 +175,27 @@ __device__ __forceinline__ int load_interval(const KnotRec *recs, const LegDev &
     return i;
 }
 
+// The two halves of load_interval, for callers that look up several legs at once: every leg's record at its guessed
+// interval goes out first (load_interval_guess), the rare corrections follow (load_interval_fix) -- three dependent
+// memory round trips become one.
+__device__ __forceinline__ int load_interval_guess(const KnotRec *recs, const LegDev &leg, double x, KnotRec &k) {
+    const int hi = leg.nk - 5;
+    int i = 3 + (int)((x - leg.t0) * leg.inv_h);
+    i = i < 3 ? 3 : (i > hi ? hi : i);
+    load_knot_rec(recs + leg.rec_off + i, k);
+    return i;
+}
+__device__ __forceinline__ int load_interval_fix(const KnotRec *recs, const LegDev &leg, double x, int i, KnotRec &k) {
+    const int hi = leg.nk - 5;
+    const KnotRec *base = recs + leg.rec_off;
+    if (__builtin_expect(x > k.t[3] && i < hi, 0)) {
+        do { ++i; load_knot_rec(base + i, k); } while (x > k.t[3] && i < hi);
+    } else if (__builtin_expect(x <= k.t[2] && i > 3, 0)) {
+        do { --i; load_knot_rec(base + i, k); } while (x <= k.t[2] && i > 3);
+    }
+    return i;
+}
+
 // values v[0..3] and first derivatives d[0..3] of basis functions i-3 .. i at x
 template <bool DERIV>
 __device__ __forceinline__ void bspline4(const KnotRec &k, double x, double *v, double *d) {

@@ -1538,6 +1538,10 @@ struct EvalArgs {
     int atom_hi;
 };
 
+#ifndef EVAL_CGROUP
+#define EVAL_CGROUP 4     // coefficient rows (32 bytes each) in flight per lane (8 / 16 need a fourth of the registers more:
+                          // 2 waves per SIMD, 0.58 against 0.50 ms on the 50 k-atom ternary frame)
+#endif
 // V and its three leg partials at (rl, rm, rn) from the full coefficient grid of a trio
 __device__ __forceinline__ bool trio_value(const BasisDev *B, const double *c3, int trio, double rl, double rm, double rn,
                                            bool want_grad, double &val, double *grad) {
@@ -1548,24 +1552,40 @@ __device__ __forceinline__ bool trio_value(const BasisDev *B, const double *c3, 
     const LegDev l0 = td->leg[0], l1 = td->leg[1], l2 = td->leg[2];
     const int dim_m = td->dim_m, dim_n = td->dim_n, lut_off = td->lut_off;
     if (!((rl > l0.t0) & (rl < l0.tlast) & (rm > l1.t0) & (rm < l1.tlast) & (rn > l2.t0) & (rn < l2.tlast))) return false;
+    // Memory round trips, not arithmetic, bound this function (the compiler had serialised it into ~20 dependent loads):
+    // the three legs' knot records go out together, then -- the coefficient block only needs the interval indices -- the
+    // coefficient rows, EVAL_CGROUP at a time, ahead of the arithmetic that consumes them.
     KnotRec kl, km, kn;
-    int il = load_interval(recs, l0, rl, kl), im = load_interval(recs, l1, rm, km), in = load_interval(recs, l2, rn, kn);
+    int il = load_interval_guess(recs, l0, rl, kl), im = load_interval_guess(recs, l1, rm, km), in = load_interval_guess(recs, l2, rn, kn);
+    il = load_interval_fix(recs, l0, rl, il, kl); im = load_interval_fix(recs, l1, rm, im, km); in = load_interval_fix(recs, l2, rn, in, kn);
+    int mn = dim_m * dim_n;
+    const double *c = c3 + lut_off + (il - 3) * mn + (im - 3) * dim_n + (in - 3);
+    typedef double coeff4 __attribute__((ext_vector_type(4), aligned(8)));
+    coeff4 cc[EVAL_CGROUP];
+#pragma unroll
+    for (int q = 0; q < EVAL_CGROUP; q++) cc[q] = *(const coeff4 *)(c + (q >> 2) * mn + (q & 3) * dim_n);   // four consecutive n bins per request
+    asm volatile("" ::: "memory");
     double vl[4], vm[4], vn[4], dl[4], dm[4], dn[4];
     bspline4<true>(kl, rl, vl, dl);
     bspline4<true>(km, rm, vm, dm);
     bspline4<true>(kn, rn, vn, dn);
-    int mn = dim_m * dim_n;
-    const double *c = c3 + lut_off + (il - 3) * mn + (im - 3) * dim_n + (in - 3);
     double v = 0, g0 = 0, g1 = 0, g2 = 0;
-    for (int a = 0; a < 4; a++)
-        for (int b = 0; b < 4; b++) {
-            typedef double coeff4 __attribute__((ext_vector_type(4), aligned(8)));
-            const coeff4 cc = *(const coeff4 *)(c + a * mn + b * dim_n);       // four consecutive n bins in one request
-            const double s = cc[0] * vn[0] + cc[1] * vn[1] + cc[2] * vn[2] + cc[3] * vn[3];
-            const double sd = cc[0] * dn[0] + cc[1] * dn[1] + cc[2] * dn[2] + cc[3] * dn[3];
+#pragma unroll
+    for (int q0 = 0; q0 < 16; q0 += EVAL_CGROUP) {
+        if (q0 > 0) {
+#pragma unroll
+            for (int q = 0; q < EVAL_CGROUP; q++) cc[q] = *(const coeff4 *)(c + ((q0 + q) >> 2) * mn + ((q0 + q) & 3) * dim_n);
+            asm volatile("" ::: "memory");
+        }
+#pragma unroll
+        for (int q = 0; q < EVAL_CGROUP; q++) {
+            const int a = (q0 + q) >> 2, b = (q0 + q) & 3;
+            const double s = cc[q][0] * vn[0] + cc[q][1] * vn[1] + cc[q][2] * vn[2] + cc[q][3] * vn[3];
+            const double sd = cc[q][0] * dn[0] + cc[q][1] * dn[1] + cc[q][2] * dn[2] + cc[q][3] * dn[3];
             v += vl[a] * vm[b] * s;
             if (want_grad) { g0 += dl[a] * vm[b] * s; g1 += vl[a] * dm[b] * s; g2 += vl[a] * vm[b] * sd; }
         }
+    }
     val = v; grad[0] = g0; grad[1] = g1; grad[2] = g2;
     return true;
 }
@@ -1580,9 +1600,12 @@ __device__ __forceinline__ double wave_sum(double v) {
 // what a block of atoms of a decomposed frame needs).  !GATHER: each triplet once, at its centre, which also sums the
 // force it puts on each of its list entries (nbr_f, in LDS first); k_eval_collect then adds to every atom what its
 // neighbours' triplets put on it.  One wave owns a centre and LDS adds of a wave keep their order: deterministic.
-// (158 registers = 3 waves per SIMD; bounding it to 4 or 5 spills: 0.51 -> 0.60 / 1.19 ms on the 50 k-atom ternary frame)
+// (3 waves per SIMD; bounding it to 4 or 5 spills: 0.51 -> 0.60 / 1.19 ms on the 50 k-atom ternary frame)
+#ifndef EVAL_MINW
+#define EVAL_MINW 3
+#endif
 template <bool GATHER>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64, EVAL_MINW)
 k_eval(EvalArgs A) {
     extern __shared__ __align__(16) unsigned char smem[];
     const BasisDev *B = A.B;
