@@ -190,7 +190,7 @@ def main():
             roofline = dict(bound="mfma", achieved=round(feat_tf, 3), peak=78.6, unit="TFLOP/s", frac=round(feat_tf / 78.6, 5),
                             traffic=traffic, traffic_source=traffic_source, hbm=hbm,
                             bound_note="fp64 issue: an fp64 MFMA holds the SIMD's vector issue for its 64 cycles on MI355X "
-                                       "(tools/experiments/dp_pipe_bench.hip), so the 153 MFMA + ~6800 vector instructions "
+                                       "(tools/experiments/dp_pipe_bench.hip), so the 141 MFMA + ~6000 vector instructions "
                                        "per atom add up; achieved = ALGORITHMIC flops (SURVEY 8d), the HBM view is in `hbm`",
                             kernel=feat_kernel, launch_ms=round(launch_ms, 4), launches=launches,
                             algorithmic_flops_per_launch=flops_frame * B,

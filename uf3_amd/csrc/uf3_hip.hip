@@ -1287,7 +1287,8 @@ extern "C" int uf3_gram_dev(uf3_ctx *c, const double *dx, const double *dy, int6
     if (n_rows == 0) return UF3_OK;
     // (up to two column ranges the patches are mostly padding: one wave per 32 x 32 tile with direct loads is faster there --
     // measured 0.62 against 0.81 ms at F = 73, 960 k rows)
-    if (n_feat > 128 && !getenv("UF3_GRAM_DIRECT")) {
+    // (and below ~64 k rows the row chunks get too short for the slab pipeline: 0.24 against 0.21 ms at 30 001 x 425)
+    if (n_feat > 128 && n_rows >= 65536 && !getenv("UF3_GRAM_DIRECT")) {
         // LDS-tiled kernel: patches of 64 x 64 packed into workgroups (at most four patches on at most four column ranges)
         if (c->gram_plan_feat != n_feat) {
             const int np = (n_feat + 63) / 64;
@@ -1361,17 +1362,23 @@ extern "C" int uf3_gram_dev(uf3_ctx *c, const double *dx, const double *dy, int6
         HIPCHK(c, hipGetLastError());
         return UF3_OK;
     }
-    c->gram_plan_feat = -1;                                            // (the direct kernel reuses the plan buffer)
-    int nt = (n_feat + 31) / 32;
-    std::vector<int> ti, tj;
-    for (int i = 0; i < nt; i++) for (int j = i; j < nt; j++) { ti.push_back(i); tj.push_back(j); }
-    while (ti.size() % 4) { ti.push_back(-1); tj.push_back(-1); }
-    size_t np = ti.size();
-    HIPCHK(c, c->gram_tiles.ensure(8 * np));
+    // tile-pair table of the direct kernel: built and uploaded when n_feat changes (the buffer is shared with the tiled
+    // kernel's plan; negative feature counts mark "holds the direct table for -n_feat")
+    const int nt = (n_feat + 31) / 32;
+    size_t np = (size_t)nt * (nt + 1) / 2;
+    np = (np + 3) / 4 * 4;
+    if (c->gram_plan_feat != -n_feat) {
+        std::vector<int> tij;
+        for (int i = 0; i < nt; i++) for (int j = i; j < nt; j++) tij.push_back(i);
+        while (tij.size() < np) tij.push_back(-1);
+        for (int i = 0; i < nt; i++) for (int j = i; j < nt; j++) tij.push_back(j);
+        while (tij.size() < 2 * np) tij.push_back(-1);
+        HIPCHK(c, c->gram_tiles.ensure(8 * np));
+        HIPCHK(c, hipMemcpyAsync(c->gram_tiles.p, tij.data(), 8 * np, hipMemcpyHostToDevice, st));
+        HIPCHK(c, hipStreamSynchronize(st));                           // (tij is a local)
+        c->gram_plan_feat = -n_feat;
+    }
     int *d_ti = c->gram_tiles.as<int>(), *d_tj = d_ti + np;
-    HIPCHK(c, hipMemcpyAsync(d_ti, ti.data(), 4 * np, hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipMemcpyAsync(d_tj, tj.data(), 4 * np, hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipStreamSynchronize(st));
     // enough row chunks to fill the chip, each a multiple of 4 rows
     int blocks_xy = (int)(np / 4);
     int want_chunks = std::max(1, (c->n_cu * 8 + blocks_xy - 1) / blocks_xy);
