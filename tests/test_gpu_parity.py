@@ -160,6 +160,20 @@ def test_gram_kernel_ragged_shapes(shape):
     assert np.array_equal(g, g.T)
 
 
+@pytest.mark.parametrize("shape", [(65536, 129), (70013, 257), (66001, 434), (65551, 333)])
+def test_tiled_gram_kernel_ragged_shapes(shape):
+    """The LDS-tiled kernel (more than 128 columns, at least 64 k rows): column counts that end inside a 64-column range /
+    inside a 16-column tile, an odd number of ranges, row counts that are no multiple of the 16-row slab; X^T y is
+    accumulated by the workgroups of the diagonal patches."""
+    rng = np.random.default_rng(shape[1])
+    x, y = rng.normal(size=shape), rng.normal(size=shape[0])
+    g, o = ls.gram_device(x, y)
+    ref = x.T @ x
+    assert np.allclose(g, ref, rtol=1e-11, atol=1e-9 * np.abs(ref).max())
+    assert np.allclose(o, x.T @ y, rtol=1e-11, atol=1e-9 * np.abs(ref).max())
+    assert np.array_equal(g, g.T)
+
+
 def test_oracle_parity_mid_size_configs():
     """configs[1] (1024-atom W) fully, configs[2] (4096-atom Ne-Xe) on the energy row + sampled atoms."""
     atoms, basis = synthetic.config_c2()
