@@ -205,7 +205,7 @@ def main():
                             traffic=None, hbm=hbm,
                             bound_note="whole step (featurizer + X^T X): algorithmic fp64 flops (featurizer: SURVEY 8d per pair / "
                                        "triplet; Gram: 2 (3N+1) F'^2 per frame) / step time; the rows stay in HBM / Infinity Cache",
-                            kernel="k_featurize launch group + k_gram_tiled / k_gram_mfma (energy and force rows, X^T y fused or k_ordinate)",
+                            kernel="k_featurize launch group + k_gram_tiled / k_gram_mfma (energy and force rows, X^T y fused)",
                             featurize_ms_per_step=round(launch_ms, 4), gram_ms_per_step=round(gram_ms, 4),
                             gram_tflops=round(gram_tf, 3), gram_flops_per_step=gram_flops, n_unfrozen_columns=n_keep,
                             neighbor_ms_per_step=round(timing["neighbor_ms"] / args.steps, 4))

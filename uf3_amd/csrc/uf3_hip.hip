@@ -1388,16 +1388,9 @@ extern "C" int uf3_gram_dev(uf3_ctx *c, const double *dx, const double *dy, int6
     {
         Timed tm(c, T_GRAM);
         const int chunks8 = (chunks + 7) / 8 * 8;                  // whole rounds over the 8 XCDs
-        hipLaunchKernelGGL(k_gram_mfma, dim3(blocks_xy * chunks8), dim3(256), 0, st, dx, n_rows, n_feat, ld, (int)rpc,
-                           blocks_xy, d_ti, d_tj, c->frag.as<int>(), d_gram);
+        hipLaunchKernelGGL(k_gram_mfma, dim3(blocks_xy * chunks8), dim3(256), 0, st, dx, (d_ord && dy) ? dy : nullptr, n_rows, n_feat, ld,
+                           (int)rpc, blocks_xy, d_ti, d_tj, c->frag.as<int>(), d_gram, d_ord);
         hipLaunchKernelGGL(k_gram_mirror, dim3((n_feat + 255) / 256, n_feat), dim3(256), 0, st, d_gram, n_feat);
-        if (d_ord && dy) {
-            int ochunks = (int)std::min<int64_t>(4096, (n_rows + 63) / 64);
-            int64_t orpc = (n_rows + ochunks - 1) / ochunks;
-            ochunks = (int)((n_rows + orpc - 1) / orpc);
-            hipLaunchKernelGGL(k_ordinate, dim3((n_feat + 255) / 256, ochunks), dim3(256), 0, st, dx, dy, n_rows, n_feat,
-                               ld, (int)orpc, d_ord);
-        }
     }
     HIPCHK(c, hipGetLastError());
     return UF3_OK;

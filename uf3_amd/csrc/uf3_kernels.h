@@ -12,7 +12,7 @@
 //   k_eval<GATHER>    energy + forces (+ virial) of a fitted model        one wave / atom: every triplet once at its
 //                     centre + k_eval_collect (whole batch), or gathered at its three atoms (a block of atoms)
 //   k_frame_sum       per-frame sums of the per-atom energies / virial shares
-//   k_gram_mfma       X^T X on the fp64 matrix cores;  k_ordinate  X^T y
+//   k_gram_tiled / k_gram_mfma   X^T X on the fp64 matrix cores, X^T y riding along in the diagonal workgroups / waves
 //
 // Formulation: every atom m GATHERS all pair terms and all triplet terms it takes part in --
 // as centre, or as one of the two neighbours of a centre c in N3(m) -- so its three force-feature rows are complete
@@ -1917,8 +1917,8 @@ __global__ void k_mfma_probe(int *rowcol) {
 // (min 4 waves/SIMD: with the default target of 8 the accumulators are shuttled between VGPRs and AGPRs around
 // every MFMA group -- 64 v_accvgpr moves per 4 MFMAs)
 __global__ void __launch_bounds__(256, 4)
-k_gram_mfma(const double *x, int64_t n_rows, int n_feat, int64_t ld, int rows_per_chunk, int blocks_xy,
-            const int *tile_i, const int *tile_j, const int *frag_rowcol, double *gram) {
+k_gram_mfma(const double *x, const double *y, int64_t n_rows, int n_feat, int64_t ld, int rows_per_chunk, int blocks_xy,
+            const int *tile_i, const int *tile_j, const int *frag_rowcol, double *gram, double *ord) {
     int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     // XCD-aware order: workgroups are dealt to the 8 XCDs round-robin by their linear id, and each XCD has its own
     // L2.  All tile pairs of one row chunk go to the same XCD, back to back, so that the chunk (rows x n_feat
@@ -1938,19 +1938,26 @@ k_gram_mfma(const double *x, int64_t n_rows, int n_feat, int64_t ld, int rows_pe
     // load is a branch, and four branches per step keep only one step's loads in flight)
     const double *pa0 = x + (va0 ? ca0 : 0), *pa1 = x + (va1 ? ca1 : 0), *pb0 = x + (vb0 ? cb0 : 0), *pb1 = x + (vb1 ? cb1 : 0);
     double4_t acc00 = {0, 0, 0, 0}, acc01 = {0, 0, 0, 0}, acc10 = {0, 0, 0, 0}, acc11 = {0, 0, 0, 0};
+    // X^T y rides along in the waves of the diagonal tile pairs: the lane already holds X[row k][column i] of its two
+    // 16-column halves; the four k groups of a column meet in a cross-lane sum at the end (other waves: weight 0)
+    const bool want_ord = ord && y && ti == tj;
+    const double *py = want_ord ? y : x;                            // (any readable address when unused)
+    const double yw = want_ord ? 1.0 : 0.0;
+    double oy0 = 0.0, oy1 = 0.0;
     int64_t r = r0;
     constexpr int KU = 4;                                           // k-steps per trip: 4 * KU loads in flight
     for (; r + 4 * KU <= r1; r += 4 * KU) {
-        double a0[KU], a1[KU], b0[KU], b1[KU];
+        double a0[KU], a1[KU], b0[KU], b1[KU], yv[KU];
 #pragma unroll
         for (int u = 0; u < KU; u++) {
             const int64_t o = (r + 4 * u + k) * ld;
-            a0[u] = pa0[o]; a1[u] = pa1[o]; b0[u] = pb0[o]; b1[u] = pb1[o];
+            a0[u] = pa0[o]; a1[u] = pa1[o]; b0[u] = pb0[o]; b1[u] = pb1[o]; yv[u] = py[r + 4 * u + k];
         }
-        __builtin_amdgcn_sched_group_barrier(0x20, 4 * KU, 0);      // all VMEM reads first
+        __builtin_amdgcn_sched_group_barrier(0x20, 5 * KU, 0);      // all VMEM reads first
 #pragma unroll
         for (int u = 0; u < KU; u++) {
             const double x0 = va0 ? a0[u] : 0.0, x1 = va1 ? a1[u] : 0.0, y0 = vb0 ? b0[u] : 0.0, y1 = vb1 ? b1[u] : 0.0;
+            oy0 += x0 * (yv[u] * yw); oy1 += x1 * (yv[u] * yw);
             acc00 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, y0, acc00, 0, 0, 0);
             acc01 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, y1, acc01, 0, 0, 0);
             acc10 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, y0, acc10, 0, 0, 0);
@@ -1963,10 +1970,20 @@ k_gram_mfma(const double *x, int64_t n_rows, int n_feat, int64_t ld, int rows_pe
         const int64_t o0 = (vr ? row : r0) * ld;
         double a0 = pa0[o0], a1 = pa1[o0], b0 = pb0[o0], b1 = pb1[o0];
         a0 = (vr && va0) ? a0 : 0.0; a1 = (vr && va1) ? a1 : 0.0; b0 = (vr && vb0) ? b0 : 0.0; b1 = (vr && vb1) ? b1 : 0.0;
+        const double yr = py[vr ? row : r0] * yw;
+        oy0 += a0 * yr; oy1 += a1 * yr;
         acc00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc00, 0, 0, 0);
         acc01 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc01, 0, 0, 0);
         acc10 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc10, 0, 0, 0);
         acc11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc11, 0, 0, 0);
+    }
+    if (want_ord) {
+        oy0 += __shfl_xor(oy0, 16); oy0 += __shfl_xor(oy0, 32);
+        oy1 += __shfl_xor(oy1, 16); oy1 += __shfl_xor(oy1, 32);
+        if (k == 0) {
+            if (va0 && oy0 != 0.0) unsafeAtomicAdd(ord + ca0, oy0);
+            if (va1 && oy1 != 0.0) unsafeAtomicAdd(ord + ca1, oy1);
+        }
     }
     for (int v = 0; v < 4; v++) {
         int fr = frag_rowcol[(lane * 4 + v) * 2], fc = frag_rowcol[(lane * 4 + v) * 2 + 1];
@@ -2155,16 +2172,6 @@ __global__ void k_gram_mirror(double *gram, int n_feat) {
     if (j < n_feat && j < i) gram[(size_t)i * n_feat + j] = gram[(size_t)j * n_feat + i];
 }
 
-__global__ void k_ordinate(const double *x, const double *y, int64_t n_rows, int n_feat, int64_t ld,
-                           int rows_per_chunk, double *ord) {
-    int col = blockIdx.x * blockDim.x + threadIdx.x;
-    int64_t r0 = (int64_t)blockIdx.y * rows_per_chunk, r1 = r0 + rows_per_chunk;
-    if (r1 > n_rows) r1 = n_rows;
-    if (col >= n_feat) return;
-    double s = 0.0;
-    for (int64_t r = r0; r < r1; r++) s += x[r * ld + col] * y[r];
-    if (s != 0.0) unsafeAtomicAdd(ord + col, s);
-}
 
 // ---------------------------------------------------------------------------------
 // neighbour index dump (debug / parity): unsorted tuples, the host sorts them
