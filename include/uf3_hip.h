@@ -53,8 +53,10 @@ enum {
     UF3_ENOMEM = 4,
     UF3_EOVERFLOW = 5,  /* internal capacity exceeded after retries */
     UF3_ERETRY = 6      /* an earlier asynchronous uf3_featurize_dev call ran with neighbour capacities that turned
-                           out too small: its outputs (and whatever was derived from them) are invalid; the
-                           capacities have been raised -- repeat the work since the last uf3_ctx_synchronize */
+                           out too small, or met atoms given far outside their periodic cell (their 3-body force
+                           rows need the launches that carry the reference's image-range rule): its outputs (and
+                           whatever was derived from them) are invalid; the context has adapted -- repeat the work
+                           since the last uf3_ctx_synchronize */
 };
 
 /* Flat description of a BSplineBasis (host memory, copied by uf3_basis_create). */

@@ -730,13 +730,13 @@ def test_degenerate_frames_in_a_batch():
     assert rel_err(f[off_e[3]:off_e[4]], f1) < 1e-13 and rel_err(v[3], v1[0]) < 1e-13
 
 
-def test_atoms_outside_the_cell():
+def test_atoms_outside_the_cell(monkeypatch):
     """Positions are not wrapped by the reference (geometry.py:108-149 tiles them as given): an atom a few lattice
-    vectors away keeps only the neighbours the finite image range reaches.  Energy rows and 2-body force rows follow
-    the reference (oracle) in that.  The reference's 3-body FORCE rows additionally lose the terms of ghost-centred
-    triplets whose third atom its shrunken supercell does not hold, so they stop being the gradient of its own
-    energy row; the kernels keep those terms (known deviation): their rows are checked against
-    the numerical gradient of the energy row instead.  An atom hundreds of cells away is refused."""
+    vectors away keeps only the neighbours the finite image range reaches, and the 3-body FORCE rows additionally lose
+    the terms of ghost-centred triplets whose third atom that supercell does not hold (so they stop being the gradient
+    of the energy row).  The kernels reproduce all of it: every row equals the oracle's.  With UF3_KEEP_GHOST_TERMS the
+    dropped terms are kept instead and the rows are the numerical gradient of the energy row again.  An atom hundreds
+    of cells away is refused."""
     basis = synthetic.notebook_basis(['W'])
     fz = process.BasisFeaturizer(basis)
     atoms = synthetic.lattice_frame("bcc", (2, 2, 2), 3.165, [74], seed=12)
@@ -750,8 +750,17 @@ def test_atoms_outside_the_cell():
 
     x_e, x_f, _ = rows(pos)
     ref = O.featurize(O.OracleBasis(basis), Atoms(numbers=atoms.get_atomic_numbers(), positions=pos, cell=cell, pbc=True))
+    assert rel_err(x_e[0], ref["xe"]) < TOL and rel_err(x_f, ref["xf"]) < TOL
+    # the same through the batched path (several frames per call, one of them with every atom inside its cell)
+    inside = Atoms(numbers=atoms.get_atomic_numbers(), positions=atoms.get_positions(), cell=cell, pbc=True)
+    y_e, y_f, off = fz.featurize_frames([inside, Atoms(numbers=atoms.get_atomic_numbers(), positions=pos, cell=cell, pbc=True)])
+    ref_in = O.featurize(O.OracleBasis(basis), inside)
+    assert rel_err(y_f[off[1]:off[2]], ref["xf"]) < TOL and rel_err(y_f[off[0]:off[1]], ref_in["xf"]) < TOL
+    monkeypatch.setenv("UF3_KEEP_GHOST_TERMS", "1")
+    k_e, k_f, _ = rows(pos)
     n2 = basis.n_feats - basis.partition_sizes[-1]                       # one-body + pair columns
-    assert rel_err(x_e[0], ref["xe"]) < TOL and rel_err(x_f[:, :, :n2], ref["xf"][:, :, :n2]) < TOL
+    assert rel_err(k_e[0], ref["xe"]) < TOL and rel_err(k_f[:, :, :n2], ref["xf"][:, :, :n2]) < TOL
+    assert rel_err(k_f, ref["xf"]) > 1e-6                                # (this frame does lose terms in the reference)
     h = 1e-5
     for a in (0, 3, 7, 9):
         for c in range(3):
@@ -759,7 +768,31 @@ def test_atoms_outside_the_cell():
             up[a, c] += h
             dn[a, c] -= h
             grad = -(rows(up)[0][0] - rows(dn)[0][0]) / (2 * h)
-            assert np.abs(grad - x_f[a, c]).max() < 1e-6 * np.abs(x_f).max(), (a, c)
+            assert np.abs(grad - k_f[a, c]).max() < 1e-6 * np.abs(k_f).max(), (a, c)
+    monkeypatch.delenv("UF3_KEEP_GHOST_TERMS")
+    # asynchronous entry: the ordinary 3-body launches leave such a batch to the image-range ones -- the verdict arrives
+    # with the next synchronisation (RetryError), the repeated call is right, and a batch of wrapped atoms afterwards
+    # brings the context back to the ordinary launches
+    import torch
+    ctx, db = fz._dev()
+    dev = torch.device("cuda", ctx.device)
+    wrapped = Atoms(numbers=atoms.get_atomic_numbers(), positions=atoms.get_positions(), cell=cell, pbc=True)
+    rows(atoms.get_positions())                                           # (ordinary launches again)
+    batch = _lib.FrameBatch([Atoms(numbers=atoms.get_atomic_numbers(), positions=pos, cell=cell, pbc=True)])
+    d_pos, d_z = torch.from_numpy(batch.pos).to(dev), torch.from_numpy(batch.z).to(dev)
+    d_xe = torch.zeros((1, db.n_feat), dtype=torch.float64, device=dev)
+    d_xf = torch.zeros((batch.n_atoms, 3, db.n_feat), dtype=torch.float64, device=dev)
+    prev = ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+    try:
+        fz.featurize_device(batch.struct, d_pos.data_ptr(), d_z.data_ptr(), d_xe.data_ptr(), d_xf.data_ptr())
+        with pytest.raises(_lib.RetryError):
+            ctx.synchronize()
+        fz.featurize_device(batch.struct, d_pos.data_ptr(), d_z.data_ptr(), d_xe.data_ptr(), d_xf.data_ptr())
+        ctx.synchronize()
+    finally:
+        ctx.restore_stream(prev)
+    assert rel_err(d_xf.cpu().numpy(), ref["xf"]) < TOL
+    assert rel_err(fz.featurize_frames([wrapped])[1], ref_in["xf"]) < TOL
     far = pos.copy()
     far[5] += 300.0 * cell[0]
     with pytest.raises(RuntimeError, match="outside the periodic cell"):

@@ -78,6 +78,8 @@ struct FrameGeom {
     int per[3];         // periodic flag
     int fac[3];         // reference image range per axis (0 when not periodic)
     int cnt[3];         // images per axis in the reference supercell (2*fac+1 or 1)
+    double win_lo[3], win_hi[3];   // fractional window around the cell: while every atom of the frame lies inside it, any two
+                                   // atoms within r_cut of each other are images -fac .. fac of one another (TrioWalk::img_check)
     int bin_base;       // first global bin
     int atom_lo, atom_hi;
 };
@@ -118,6 +120,11 @@ struct N3Lists {
     int *cnt;       // [natoms]
     int *spoff;     // [natoms][UF3_MAX_SPECIES+1] first entry of each species in the list
     N3Entry *ent;   // [natoms*cap]
+    // extension (batches with atoms outside their cell only, k_build_n3_ext): neighbours whose image index lies beyond
+    // the reference's range as seen from the atom, but inside it as seen from one of the atom's ghost images
+    int xcap;
+    int *xoff;      // [natoms][UF3_MAX_SPECIES+1]
+    N3Entry *xent;  // [natoms*xcap]
 };
 
 __device__ __forceinline__ int pack3(int a, int b, int c) { return (a + 512) | ((b + 512) << 10) | ((c + 512) << 20); }
@@ -252,7 +259,7 @@ __device__ __forceinline__ int mbcnt(unsigned long long mask) {
 // (unwrapped) positions; images outside the reference's range (|s| > fac) are skipped, so the
 // candidate set is exactly the reference's supercell (geometry.py:131-149).
 template <class F>
-__device__ __forceinline__ void for_each_candidate(const FrameGeom &g, const CellList &cl, int m, F f) {
+__device__ __forceinline__ void for_each_candidate(const FrameGeom &g, const CellList &cl, int m, F f, int range_mult = 1) {
     const int lane = lane_id();
     const int lb = cl.atom_bin[m];
     const int b2 = lb % g.nb[2], b1 = (lb / g.nb[2]) % g.nb[1], b0 = lb / (g.nb[2] * g.nb[1]);
@@ -311,7 +318,7 @@ __device__ __forceinline__ void for_each_candidate(const FrameGeom &g, const Cel
                 int v0, v1, v2;
                 unpack_ws(sr.ws, v0, v1, v2, sj);
                 s0 = sh0 - v0 + w0; s1 = sh1 - v1 + w1; s2 = sh2 - v2 + w2;
-                ok = (abs(s0) <= g.fac[0]) && (abs(s1) <= g.fac[1]) && (abs(s2) <= g.fac[2]);
+                ok = (abs(s0) <= range_mult * g.fac[0]) && (abs(s1) <= range_mult * g.fac[1]) && (abs(s2) <= range_mult * g.fac[2]);
                 if (ok && sr.atom == m && s0 == 0 && s1 == 0 && s2 == 0) ok = false;
             }
             f(ok, sr, sj, s0, s1, s2);

@@ -58,16 +58,19 @@ struct uf3_ctx {
         bin_start, slots, flags,
         n3_cnt, n3_int, n3_dbl, e_atom, nbr_f, coeff, stage_pos, stage_z, stage_out, stage_out2,
         gram_tiles, frag, dbg,
-        halo;                           // marks + index list of the halo atoms of a decomposed frame
+        halo,                           // marks + index list of the halo atoms of a decomposed frame
+        n3x_ent, n3x_off;               // extension lists (batches with atoms outside their cell; see N3Lists)
     int n3_cap = 0, cand_cap = 0;
+    int n3x_cap = 0;                 // capacity of the extension lists (0 until a batch needed them)
+    bool img_mode = false;           // a batch with atoms far outside their cell has been seen: 3-body launches with the image-range rule
     int gram_plan_feat = -1, gram_plan_blocks = 0;   // workgroup plan of k_gram_tiled held in gram_tiles (for this n_feat)
     bool n3_tuned = false;           // capacity re-sized once to the lists actually seen
     bool cand_tuned = false;         // a featurizer call has completed with the current candidate capacity
     // status words of asynchronous featurizer calls: copied to pinned slots behind the launches, looked at later
-    struct Pending { hipEvent_t ev = nullptr; int cap = 0, cand = 0; bool has3 = false, live = false; };
+    struct Pending { hipEvent_t ev = nullptr; int cap = 0, cand = 0, xcap = 0; bool has3 = false, img = true, img_launch = false, live = false; };
     enum { N_PENDING = 16 };
     Pending pending_chk[N_PENDING];
-    PinBuf pin_flags;                // [N_PENDING][4] ints
+    PinBuf pin_flags;                // [N_PENDING][8] ints
     int pending_head = 0;
     bool frag_ready = false;
     int32_t *d_stage_z = nullptr;       // species of the staged batch (tail of stage_pos)
@@ -154,7 +157,7 @@ extern "C" void uf3_ctx_destroy(uf3_ctx *c) {
     hipStreamSynchronize(c->stream);
     Buf *all[] = {&c->geoms, &c->offsets, &c->frame_of, &c->atom_bin, &c->atom_wrap, &c->spec, &c->key_in,
                   &c->key_out, &c->val_in, &c->val_out, &c->sort_tmp, &c->bin_start, &c->slots, &c->flags, &c->n3_cnt, &c->n3_int, &c->n3_dbl, &c->e_atom, &c->nbr_f, &c->coeff,
-                  &c->stage_pos, &c->stage_z, &c->stage_out, &c->stage_out2, &c->gram_tiles, &c->frag, &c->dbg, &c->halo};
+                  &c->stage_pos, &c->stage_z, &c->stage_out, &c->stage_out2, &c->gram_tiles, &c->frag, &c->dbg, &c->halo, &c->n3x_ent, &c->n3x_off};
     for (Buf *b : all) b->release();
     c->pin_in.release(); c->pin_geo.release(); c->pin_out.release(); c->pin_flags.release();
     for (auto &pd : c->pending_chk) if (pd.ev) hipEventDestroy(pd.ev);
@@ -559,7 +562,12 @@ static int make_geom(uf3_ctx *c, const uf3_basis *b, const uf3_frames *fr, int f
             if (g.rad[k] < 1) g.rad[k] = 1;
             g.binw[k] = 1.0 / nb;
             if (g.fac[k] > 400) return fail(c, UF3_EINVAL, "cell is too small relative to the cutoff");
+            // atoms inside a window of fractional width fac + 1 - r_cut / h around the cell (>= 1: the cell itself always
+            // is) are at most fac images apart whenever they are within r_cut of each other
+            const double w = g.fac[k] + 1.0 - b->r_cut / h - 1e-9;
+            g.win_lo[k] = 0.5 - 0.5 * w; g.win_hi[k] = 0.5 + 0.5 * w;
         } else {
+            g.win_lo[k] = -1e300; g.win_hi[k] = 1e300;
             g.nb[k] = nb_np;
             g.rad[k] = 1;
             g.binw[k] = rs / h;      // fractional width of a bin of real width rs
@@ -607,12 +615,15 @@ static int poll_pending(uf3_ctx *c, bool wait) {
         if (wait) { HIPCHK(c, hipEventSynchronize(p.ev)); }
         else if (hipEventQuery(p.ev) != hipSuccess) continue;
         p.live = false;
-        const int *fl = (const int *)c->pin_flags.p + 4 * ((c->pending_head + q) % uf3_ctx::N_PENDING);
+        const int *fl = (const int *)c->pin_flags.p + 8 * ((c->pending_head + q) % uf3_ctx::N_PENDING);
         if (fl[0] == 2 && !rc) rc = fail(c, UF3_ESPECIES, "frame contains an element outside the basis (earlier asynchronous call)");
         else if (fl[0] == 1 && !rc) rc = fail(c, UF3_EINVAL, "atom too far outside the periodic cell (|wrap| > 250) (earlier asynchronous call)");
         bool grown = false;
         if (p.has3 && fl[1] > p.cap) { c->n3_cap = std::max(c->n3_cap, (fl[1] + 8 + 7) / 8 * 8); grown = true; }
         if (fl[2] > p.cand) { c->cand_cap = std::max(c->cand_cap, (fl[2] + 16 + 7) / 8 * 8); grown = true; }
+        if (fl[3] > p.xcap) { c->n3x_cap = std::max(c->n3x_cap, std::min(248, (fl[3] + 8 + 7) / 8 * 8)); grown = true; }
+        if (fl[4] && !p.img) { c->img_mode = true; grown = true; }      // (its 3-body launches left without writing rows)
+        else if (!fl[4] && p.img_launch) c->img_mode = false;            // back to the ordinary launches
         if (grown && !rc)
             rc = fail(c, UF3_ERETRY, "an earlier asynchronous featurizer call overflowed its neighbour capacities: its outputs are "
                                      "invalid; the capacities have been raised, repeat the work since the last synchronisation");
@@ -643,10 +654,10 @@ static int n3_tune(uf3_ctx *c, const N3Lists &n3, int natoms) {
     hipStream_t st = c->stream;
     int *flags = c->flags.as<int>();
     c->n3_tuned = true;
-    HIPCHK(c, hipMemsetAsync(flags + 3, 0, sizeof(int), st));
-    hipLaunchKernelGGL(k_max_count, dim3(64), dim3(256), 0, st, n3.cnt, natoms, flags + 3);
+    HIPCHK(c, hipMemsetAsync(flags + 6, 0, sizeof(int), st));
+    hipLaunchKernelGGL(k_max_count, dim3(64), dim3(256), 0, st, n3.cnt, natoms, flags + 6);
     int seen = 0;
-    HIPCHK(c, hipMemcpyAsync(&seen, flags + 3, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipMemcpyAsync(&seen, flags + 6, sizeof(int), hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipStreamSynchronize(st));
     c->n3_cap = std::max(8, (seen + 7) / 8 * 8);
     return UF3_OK;
@@ -731,6 +742,7 @@ static int prepare(uf3_basis *b, const uf3_frames *fr, const double *d_pos, cons
                            c->spec.as<signed char>(), c->bin_start.as<int>(), c->slots.as<SlotRec>(), flags, 2);
         P.flags_zeroed = true;
     } else {
+    HIPCHK(c, hipMemsetAsync(flags + 3, 0, 2 * sizeof(int), st));         // extension-list need | "some atom outside its cell" (k_frame_bins)
     hipLaunchKernelGGL(k_frame_bins, dim3(gb), dim3(tb), 0, st, b->dev, d_geoms,
                        d_offsets, nf, natoms, d_pos, d_z, c->frame_of.as<int>(), c->atom_bin.as<int>(),
                        c->atom_wrap.as<int>(), c->spec.as<signed char>(), c->key_in.as<int>(), c->val_in.as<int>(), flags);
@@ -867,6 +879,9 @@ extern "C" int uf3_featurize_dev(uf3_basis *b, const uf3_frames *fr, const doubl
     A.n3_need = c->flags.as<int>() + 1;
     A.pos = d_pos; A.spec = P.spec; A.x_e = d_xe; A.x_f = d_xf; A.natoms = P.natoms;
     A.cand_need = c->flags.as<int>() + 2;
+    // (UF3_KEEP_GHOST_TERMS: keep the force terms of ghost-centred triplets whose third atom the reference's image range
+    // does not reach -- rows of unwrapped atoms are then the exact gradient of the energy row instead of the reference's)
+    A.outside = getenv("UF3_KEEP_GHOST_TERMS") ? nullptr : c->flags.as<int>() + 4;
     { const char *e = getenv("UF3_DEBUG_SKIP"); A.skip = e ? atoi(e) : 0; }
     for (int attempt = 0; attempt < 6; attempt++) {
         A.cand_cap = c->cand_cap;
@@ -882,6 +897,21 @@ extern "C" int uf3_featurize_dev(uf3_basis *b, const uf3_frames *fr, const doubl
         }
         if (want_e) HIPCHK(c, hipMemsetAsync(d_xe, 0, sizeof(double) * (size_t)P.n_frames * F, st));
         HIPCHK(c, hipMemsetAsync(A.n3_need, 0, 2 * sizeof(int), st));       // n3_need, cand_need
+        const bool img_launch = c->img_mode && has3 && want_f && A.outside;
+        const bool ext_lists = img_launch;
+        if (ext_lists) {
+            // extension lists for batches with atoms outside their cell (the kernel leaves at once otherwise); storage only
+            // once a batch has asked for it (flags[3], through the same retry path as the other capacities)
+            const int xcap = c->n3x_cap;
+            A.n3.xcap = xcap; A.n3.xent = nullptr; A.n3.xoff = nullptr;
+            if (xcap > 0) {
+                HIPCHK(c, c->n3x_ent.ensure(sizeof(N3Entry) * (size_t)P.natoms * xcap));
+                HIPCHK(c, c->n3x_off.ensure(sizeof(int) * (size_t)P.natoms * (UF3_MAX_SPECIES + 1)));
+                A.n3.xent = c->n3x_ent.as<N3Entry>(); A.n3.xoff = c->n3x_off.as<int>();
+            }
+            hipLaunchKernelGGL(k_build_n3_ext, dim3(std::min(P.natoms, 2048)), dim3(64), (size_t)xcap * (8 + 32 + 12) + 16, st,
+                               b->dev, P.geoms, P.frame_of, P.cl, A.n3, d_pos, P.natoms, c->flags.as<int>());
+        }
         {
             Timed tm(c, T_FEAT);
             for (int mode = 0; mode <= 9; mode++) {
@@ -911,7 +941,7 @@ extern "C" int uf3_featurize_dev(uf3_basis *b, const uf3_frames *fr, const doubl
                         // records per pass first, tables in LDS before tables in HBM
                         const int tries[3] = {nrec_max, std::min(nrec_max, 18), std::min(nrec_max, 15)};
                         const size_t budget = 52 * 1024;
-                        const bool dsrc_allowed = A.dsrc_lds, recs_allowed = !getenv("UF3_NO_LDS_RECS");
+                        const bool dsrc_allowed = A.dsrc_lds, recs_allowed = !getenv("UF3_NO_LDS_RECS") && !(img_launch && mode != 0);
                         for (int q = 0; q < 12 && !found; q++) {
                             const int nr = tries[q / 4];
                             const bool with_recs = (q & 2) == 0, with_dsrc = (q & 1) == 0;
@@ -929,7 +959,7 @@ extern "C" int uf3_featurize_dev(uf3_basis *b, const uf3_frames *fr, const doubl
                     lds_plain = feat_lds_bytes(F, S, cap, A.cand_cap, want_e && !A.e_direct, 0, mode, A.dense_stage, A.dense_nrec, A.n_pair_cols) + lds_extra;
                     lds_recs = feat_lds_bytes(F, S, cap, A.cand_cap, want_e && !A.e_direct, n_rec_mode, mode, A.dense_stage, A.dense_nrec, A.n_pair_cols) + lds_extra;
                     const size_t lds_target = cu_lds / (mode == 0 ? 4 : 2);
-                    recs_lds = lds_recs <= lds_target && !getenv("UF3_NO_LDS_RECS");
+                    recs_lds = lds_recs <= lds_target && !getenv("UF3_NO_LDS_RECS") && !(img_launch && mode != 0);
                     lds = recs_lds ? lds_recs : lds_plain;
                 }
                 const int launch_mode = mode;
@@ -946,16 +976,19 @@ extern "C" int uf3_featurize_dev(uf3_basis *b, const uf3_frames *fr, const doubl
                     fprintf(stderr, "uf3 featurize mode %d: lds %zu B (plain %zu, with recs %zu), recs_lds %d, cap %d, cand_cap %d, "
                             "blocks %d x %d atoms, n_recs %zu, dense nrec %d stage %d\n", launch_mode, lds, lds_plain, lds_recs,
                             (int)recs_lds, cap, A.cand_cap, n_blocks, apb, n_rec_mode, A.dense_nrec, A.dense_stage);
-#define UF3_LAUNCH1(E, Fo, R, M)                                                                                      \
+#define UF3_LAUNCH1(E, Fo, R, M, I)                                                                                   \
     do {                                                                                                            \
-        HIPCHK(c, hipFuncSetAttribute((const void *)k_featurize<E, Fo, R, M>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        hipLaunchKernelGGL((k_featurize<E, Fo, R, M>), dim3(n_blocks), dim3(WPB * WAVE), lds, st, A);                \
+        HIPCHK(c, hipFuncSetAttribute((const void *)k_featurize<E, Fo, R, M, I>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL((k_featurize<E, Fo, R, M, I>), dim3(n_blocks), dim3(WPB * WAVE), lds, st, A);             \
     } while (0)
 #define UF3_LAUNCH(M)                                                                                               \
     do {                                                                                                            \
-        if (want_e && want_f) { if (recs_lds) UF3_LAUNCH1(true, true, true, M); else UF3_LAUNCH1(true, true, false, M); }      \
-        else if (want_f) { if (recs_lds) UF3_LAUNCH1(false, true, true, M); else UF3_LAUNCH1(false, true, false, M); }       \
-        else { if (recs_lds) UF3_LAUNCH1(true, false, true, M); else UF3_LAUNCH1(true, false, false, M); }                  \
+        if (img_launch && M != 0) {   /* (the image-range variants exist with the knot records in HBM only) */       \
+            if (want_e) UF3_LAUNCH1(true, true, false, (M == 0 ? 1 : M), true); else UF3_LAUNCH1(false, true, false, (M == 0 ? 1 : M), true); \
+        }                                                                                                           \
+        else if (want_e && want_f) { if (recs_lds) UF3_LAUNCH1(true, true, true, M, false); else UF3_LAUNCH1(true, true, false, M, false); }   \
+        else if (want_f) { if (recs_lds) UF3_LAUNCH1(false, true, true, M, false); else UF3_LAUNCH1(false, true, false, M, false); }    \
+        else { if (recs_lds) UF3_LAUNCH1(true, false, true, M, false); else UF3_LAUNCH1(true, false, false, M, false); }               \
     } while (0)
                 switch (launch_mode) {
                     case 0: UF3_LAUNCH(0); break;
@@ -985,20 +1018,26 @@ extern "C" int uf3_featurize_dev(uf3_basis *b, const uf3_frames *fr, const doubl
                 if (rcw) return rcw;
                 slot = c->pending_head;
             }
-            HIPCHK(c, c->pin_flags.ensure(sizeof(int) * 4 * uf3_ctx::N_PENDING));
+            HIPCHK(c, c->pin_flags.ensure(sizeof(int) * 8 * uf3_ctx::N_PENDING));
             uf3_ctx::Pending &pd = c->pending_chk[slot];
             if (!pd.ev) HIPCHK(c, hipEventCreateWithFlags(&pd.ev, hipEventDisableTiming));
-            HIPCHK(c, hipMemcpyAsync((int *)c->pin_flags.p + 4 * slot, c->flags.p, 4 * sizeof(int), hipMemcpyDeviceToHost, st));
+            HIPCHK(c, hipMemcpyAsync((int *)c->pin_flags.p + 8 * slot, c->flags.p, 8 * sizeof(int), hipMemcpyDeviceToHost, st));
             HIPCHK(c, hipEventRecord(pd.ev, st));
-            pd.cap = cap; pd.cand = c->cand_cap; pd.has3 = has3; pd.live = true;
+            pd.cap = cap; pd.cand = c->cand_cap; pd.has3 = has3; pd.xcap = ext_lists ? c->n3x_cap : (1 << 30); pd.img = img_launch || !(has3 && want_f && A.outside); pd.img_launch = img_launch; pd.live = true;
             c->pending_head = (slot + 1) % uf3_ctx::N_PENDING;
             return UF3_OK;
         }
-        int fl[3] = {0, 0, 0};                                               // error flag, n3 need, candidate need
+        int fl[8] = {0, 0, 0, 0, 0, 0, 0, 0};            // error flag, n3 need, candidate need, extension need, atoms far outside
         HIPCHK(c, hipMemcpyAsync(fl, c->flags.p, sizeof(fl), hipMemcpyDeviceToHost, st));
         HIPCHK(c, hipStreamSynchronize(st));
         if (fl[0]) return check_flags(c);
         bool redo = false;
+        if (has3 && want_f && A.outside && fl[4] && !c->img_mode) { c->img_mode = true; redo = true; }
+        else if (img_launch && !fl[4]) c->img_mode = false;                 // (valid all the same) back to the ordinary launches
+        if (ext_lists && fl[3] > c->n3x_cap) {
+            if (fl[3] > 248) return fail(c, UF3_EOVERFLOW, "extension neighbour lists of atoms far outside their cell exceed 248 entries");
+            c->n3x_cap = (fl[3] + 8 + 7) / 8 * 8; redo = true;
+        }
         if (has3 && fl[1] > cap) { c->n3_cap = (fl[1] + 8 + 7) / 8 * 8; c->n3_tuned = true; redo = true; }
         if (fl[2] > c->cand_cap) { c->cand_cap = (fl[2] + 16 + 7) / 8 * 8; redo = true; }
         if (redo) continue;

@@ -44,8 +44,10 @@ __global__ void k_frame_bins(const BasisDev *B, const FrameGeom *geoms, const in
     spec[a] = (signed char)s;
     double x = pos[3 * (size_t)a], y = pos[3 * (size_t)a + 1], w = pos[3 * (size_t)a + 2];
     int bin[3], wrap[3];
+    bool far_out = false;
     for (int k = 0; k < 3; k++) {
         double f = x * g.inv[k] + y * g.inv[3 + k] + w * g.inv[6 + k];
+        far_out |= f < g.win_lo[k] || f > g.win_hi[k];
         if (g.per[k]) {
             double fl = floor(f);
             int b = (int)((f - fl) * g.nb[k]);
@@ -62,6 +64,7 @@ __global__ void k_frame_bins(const BasisDev *B, const FrameGeom *geoms, const in
     int lb = (bin[0] * g.nb[1] + bin[1]) * g.nb[2] + bin[2];
     atom_bin[a] = lb;
     atom_wrap[a] = pack3(wrap[0], wrap[1], wrap[2]);
+    if (far_out) err_flag[4] = 1;                                   // an atom far outside its cell (see TrioWalk::img_check)
     sort_key[a] = g.bin_base + lb;
     sort_val[a] = a;
 }
@@ -102,6 +105,8 @@ k_prepare_small(const BasisDev *B, const FrameGeom *geoms, const int64_t *atom_o
     __shared__ unsigned long long keys[UF3_SMALL_ATOMS];
     const int tid = threadIdx.x;
     if (tid < n_zero_flags) flags[1 + tid] = 0;                   // (n3_need, cand_need of the launches that follow)
+    if (tid == 0) { flags[3] = 0; flags[4] = 0; }                 // (extension-list need, "some atom outside its cell")
+    bool outside = false;
     int n_pow2 = 64;
     while (n_pow2 < natoms) n_pow2 <<= 1;
     for (int a = tid; a < n_pow2; a += 1024) {
@@ -122,6 +127,7 @@ k_prepare_small(const BasisDev *B, const FrameGeom *geoms, const int64_t *atom_o
             int bin[3], wrap[3];
             for (int k = 0; k < 3; k++) {
                 double f = x * g.inv[k] + y * g.inv[3 + k] + w * g.inv[6 + k];
+                outside |= f < g.win_lo[k] || f > g.win_hi[k];
                 if (g.per[k]) {
                     double fl = floor(f);
                     int b = (int)((f - fl) * g.nb[k]);
@@ -143,6 +149,7 @@ k_prepare_small(const BasisDev *B, const FrameGeom *geoms, const int64_t *atom_o
         keys[a] = key;
     }
     __syncthreads();
+    if (outside) flags[4] = 1;                                    // (after the barrier: thread 0 has zeroed it)
     for (int size = 2; size <= n_pow2; size <<= 1)
         for (int stride = size >> 1; stride > 0; stride >>= 1) {
             for (int t = tid; t < n_pow2 / 2; t += 1024) {
@@ -248,6 +255,70 @@ k_build_n3(const BasisDev *B, const FrameGeom *geoms, const int *frame_of, CellL
 }
 
 
+// Extension lists (see N3Lists): for a batch that holds atoms outside their cell, the 3-body neighbours of every atom
+// whose image index lies in (fac, 2 fac] on some axis.  A ghost image c + s_c of the atom takes its neighbours from the
+// reference's supercell, i.e. by ABSOLUTE image index |s_c + s_k| <= fac: entries of the atom's own list can fall out of
+// that range (TrioWalk::img_check drops them) and entries beyond the atom's own range can fall into it -- these.  Leaves at
+// once when no atom of the batch lies outside its cell (flags[4] == 0: every batch in practice).  Sorted by (species,
+// image, atom); flags[3] reports the capacity needed.
+__global__ void __launch_bounds__(64)
+k_build_n3_ext(const BasisDev *B, const FrameGeom *geoms, const int *frame_of, CellList cl, N3Lists n3,
+               const double *pos, int natoms, int *flags) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    if (flags[4] == 0) return;
+    const int cap = n3.xcap;
+    unsigned long long *key = (unsigned long long *)smem;
+    double *ex = (double *)(key + cap), *ey = ex + cap, *ez = ey + cap, *er = ez + cap;
+    int *eparent = (int *)(er + cap), *eshift = eparent + cap, *espec = eshift + cap;
+    const int lane = lane_id();
+    const double rmin3 = B->rmin3, rmax3 = B->rmax3;
+    for (int m = blockIdx.x; m < natoms; m += gridDim.x) {
+        const FrameGeom g = geoms[frame_of[m]];
+        double pm[3] = {pos[3 * (size_t)m], pos[3 * (size_t)m + 1], pos[3 * (size_t)m + 2]};
+        int count = 0;
+        for_each_candidate(g, cl, m, [&](bool ok, const SlotRec &sr, int sj, int s0, int s1, int s2) {
+            double dx = 0, dy = 0, dz = 0, d = 0;
+            ok = ok && (abs(s0) > g.fac[0] || abs(s1) > g.fac[1] || abs(s2) > g.fac[2]);
+            if (ok) {
+                image_delta(g, sr, s0, s1, s2, pm, dx, dy, dz);
+                d = norm3_rn(dx, dy, dz);
+                ok = (d > rmin3) && (d <= rmax3);
+            }
+            unsigned long long mask = __ballot(ok);
+            if (ok) {
+                int e = count + mbcnt(mask);
+                if (e < cap) {
+                    key[e] = ((unsigned long long)sj << 58) | ((unsigned long long)(unsigned)pack3(s0, s1, s2) << 28) |
+                             (unsigned)(sr.atom - g.atom_lo);
+                    ex[e] = dx; ey[e] = dy; ez[e] = dz; er[e] = d;
+                    eparent[e] = sr.atom; eshift[e] = pack3(s0, s1, s2); espec[e] = sj;
+                }
+            }
+            count += __popcll(mask);
+        }, 2);
+        __syncthreads();
+        if (count > cap) { if (lane == 0) atomicMax(flags + 3, count); count = cap; }
+        if (cap > 0) {
+            for (int sp = lane; sp <= UF3_MAX_SPECIES; sp += WAVE) {
+                int below = 0;
+                for (int f = 0; f < count; f++) below += espec[f] < sp;
+                n3.xoff[(size_t)m * (UF3_MAX_SPECIES + 1) + sp] = below;
+            }
+            for (int e = lane; e < count; e += WAVE) {
+                unsigned long long k = key[e];
+                int rank = 0;
+                for (int f = 0; f < count; f++) rank += key[f] < k;
+                N3Entry out;
+                out.dx = ex[e]; out.dy = ey[e]; out.dz = ez[e]; out.r = er[e];
+                out.parent = eparent[e]; out.shiftc = eshift[e]; out.sidx = -1; out.spec = espec[e];
+                n3.xent[(size_t)m * cap + rank] = out;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+
 // Halo of a block of atoms [lo, hi) for the gather route of the evaluator: the atoms outside the block that appear in
 // a block atom's 3-body list (their own lists are walked by the block's atoms).  mark[] must be zero on entry; the
 // order of `which` does not matter (it only decides which workgroup builds which list).
@@ -349,6 +420,7 @@ struct FeatArgs {
     double *x_e;        // [n_frames][F] or null
     double *x_f;        // [natoms][3][F] or null
     int *cand_need;     // overflow report of the 2-body candidate stage
+    const int *outside; // != 0: some atom of the batch lies outside its cell (null: the image-range rule is switched off)
     int *n3_need;       // ... of the 3-body neighbour lists (MODE 0 builds them when build_n3 != 0)
     int build_n3;
     int e_direct;       // energy row too long for LDS: every contribution goes straight to HBM (global atomics)
@@ -526,12 +598,22 @@ struct TrioWalk {
     int cnt_c, ra_lo, rb_lo, nb_;
     int total_n, rc_lo, ncen, sx;
     int n_items;
+    // The reference tiles the positions AS GIVEN with images -fac .. fac per axis (geometry.py:108-149) and takes the third
+    // atom of a ghost-centred triplet from that supercell (angles.py:424-514): an image beyond the range does not exist
+    // there and the triplet's force terms are absent from its rows.  With every atom inside its cell this never happens
+    // (two 3-body legs reach no further than r_cut); a batch with unwrapped atoms (k_frame_bins marks it) checks the
+    // third atom's absolute image index.
+    int img_check;
 };
 
-template <bool WANT_F>
+template <bool WANT_F, bool IMG>
 __device__ __forceinline__ void trio_walk_setup(const FeatArgs &A, const WaveLds &w, const TrioDev *td, int sm, TrioWalk &k) {
     const int lane = lane_id();
     const int sc = td->sc, sa = td->sa, sb = td->sb;
+    // (compiled into the IMG launches only: the ordinary ones leave at once when the batch has such atoms and the host repeats
+    // the call with these)
+    k.img_check = (IMG && WANT_F && A.outside) ? __builtin_amdgcn_readfirstlane(A.outside[0]) : 0;   // 0 off, 1 range rule, 2 + extension lists
+    if (k.img_check && A.n3.xcap > 0) k.img_check = 2;
     k.cnt_c = 0; k.ra_lo = 0; k.rb_lo = 0; k.nb_ = 1;
     if (sm == sc && !(A.skip & 2)) {          // m is the centre: own neighbours of species sa x sb
         k.ra_lo = w.so[sa]; k.rb_lo = w.so[sb];
@@ -552,6 +634,12 @@ __device__ __forceinline__ void trio_walk_setup(const FeatArgs &A, const WaveLds
                 if (e < k.ncen) {
                     const int *sp = w.ospoff + (size_t)(k.rc_lo + e) * w.sp_stride;
                     base = sp[k.sx]; cnt = sp[k.sx + 1] - base;
+                    if (IMG && k.img_check > 1) {     // + the centre's extension entries: base | own count << 8 | first extension << 16
+                        const int *xo = A.n3.xoff + (size_t)w.oparent[k.rc_lo + e] * (UF3_MAX_SPECIES + 1);
+                        const int xb = xo[k.sx], xn = xo[k.sx + 1] - xb;
+                        base |= (cnt << 8) | (xb << 16);
+                        cnt += xn;
+                    }
                 }
                 const int incl = wave_scan_incl(cnt);
                 if (e < k.ncen) { w.noff[e] = k.total_n + incl - cnt; w.nbase[e] = base; }
@@ -570,7 +658,7 @@ __device__ __forceinline__ void trio_walk_setup(const FeatArgs &A, const WaveLds
 }
 
 // geometry of item p of the walk; false when the item is void (p out of range, or the third atom is m itself)
-template <bool WANT_F>
+template <bool WANT_F, bool IMG>
 __device__ __forceinline__ bool trio_walk_geom(const FeatArgs &A, const FrameGeom &g, const WaveLds &w, const TrioDev *td,
                                                const TrioWalk &k, int m, int sm, int p, TripletGeom &tg) {
     const int sa = td->sa, sb = td->sb, cap = A.n3.cap;
@@ -604,12 +692,22 @@ __device__ __forceinline__ bool trio_walk_geom(const FeatArgs &A, const FrameGeo
         while (lo < hi) { int mid = (lo + hi + 1) >> 1; if (w.noff[mid] <= q) lo = mid; else hi = mid - 1; }
         int e = k.rc_lo + lo, kk = w.nbase[lo] + (q - w.noff[lo]);
         int pc = w.oparent[e];
-        size_t kb = (size_t)pc * cap + kk;
+        const N3Entry *kp = A.n3.ent + (size_t)pc * cap + kk;
+        if (IMG && k.img_check > 1) {                   // (packed by trio_walk_setup)
+            const int nb = w.nbase[lo], rel = q - w.noff[lo], own = (nb >> 8) & 0xff;
+            kp = rel < own ? A.n3.ent + (size_t)pc * cap + (nb & 0xff) + rel
+                           : A.n3.xent + (size_t)pc * A.n3.xcap + (nb >> 16) + (rel - own);
+        }
         int s0, s1, s2;
         unpack3(w.oshift[e], s0, s1, s2);
-        const N3Entry ke = A.n3.ent[kb];
+        const N3Entry ke = *kp;
         int kparent = ke.parent, kshift = ke.shiftc;
         valid = !(kparent == m && kshift == pack3(-s0, -s1, -s2));       // k is m itself
+        if (IMG && k.img_check) {                                        // k's image as the reference numbers it
+            int t0, t1, t2;
+            unpack3(kshift, t0, t1, t2);
+            valid = valid && abs(s0 + t0) <= g.fac[0] && abs(s1 + t1) <= g.fac[1] && abs(s2 + t2) <= g.fac[2];
+        }
         if (valid) {
             int ksidx = ke.sidx;
             int msidx = supercell_index(g, -s0, -s1, -s2, m_local);      // m as numbered from c
@@ -635,14 +733,14 @@ __device__ __forceinline__ bool trio_walk_geom(const FeatArgs &A, const FrameGeo
     return valid;
 }
 
-template <bool WANT_E, bool WANT_F, int NSRC, int NCH>
+template <bool WANT_E, bool WANT_F, int NSRC, int NCH, bool IMG>
 __device__ __forceinline__ void trio_block(const FeatArgs &A, const BasisDev *B, const KnotRec *recs, const FrameGeom &g,
                                            const WaveLds &w, int m, int sm, int t, const ESink &es) {
     const int lane = lane_id();
     const TrioDev td_copy = load_const(A.trios + t);          // scalar loads (see load_const)
     const TrioDev *td = &td_copy;
     TrioWalk k;
-    trio_walk_setup<WANT_F>(A, w, td, sm, k);
+    trio_walk_setup<WANT_F, IMG>(A, w, td, sm, k);
     const int ncol = td->ncol, F = B->F;
     for (int c0 = 0; c0 < ncol; c0 += NCH * WAVE) {
         ColSrc src[NCH][NSRC];
@@ -663,7 +761,7 @@ __device__ __forceinline__ void trio_block(const FeatArgs &A, const BasisDev *B,
         for (int p0 = 0; p0 < k.n_items; p0 += WAVE) {
             TripletGeom tg;
             TripletRec r;
-            bool valid = trio_walk_geom<WANT_F>(A, g, w, td, k, m, sm, p0 + lane, tg);
+            bool valid = trio_walk_geom<WANT_F, IMG>(A, g, w, td, k, m, sm, p0 + lane, tg);
             valid = eval_triplet<WANT_F>(recs, td, tg, valid, r);
             stage_and_gather<WANT_E, WANT_F, NSRC, NCH>(tg, r, valid, w.stage, src, acc);
         }
@@ -777,7 +875,7 @@ __device__ __forceinline__ void dense_accumulate(const double *stage, int rt_str
     for (; q < r1; q += 2, rec += 2 * stride) dense_step<TMASK, RT, CT>(rec, o, acc);
 }
 
-template <bool WANT_E, bool WANT_F, int MODE>
+template <bool WANT_E, bool WANT_F, int MODE, bool IMG>
 __device__ __forceinline__ void trio_block_mfma(const FeatArgs &A, const BasisDev *B, const KnotRec *recs, const FrameGeom &g,
                                                 const WaveLds &w, int m, int sm, int t, const ESink &es,
                                                 const int (&fragp)[4], const int *dsrc) {
@@ -789,7 +887,7 @@ __device__ __forceinline__ void trio_block_mfma(const FeatArgs &A, const BasisDe
     const TrioDev *td = &td_copy;
     PhaseClock pc;
     TrioWalk k;
-    trio_walk_setup<WANT_F>(A, w, td, sm, k);
+    trio_walk_setup<WANT_F, IMG>(A, w, td, sm, k);
     const int ncol = td->ncol, F = B->F;
     const int lo_l = td->lo[0], lo_m = td->lo[1], lo_n = td->lo[2];
     const int ext_l = td->ext[0], ext_m = td->ext[1], ext_n = td->ext[2];
@@ -851,7 +949,7 @@ __device__ __forceinline__ void trio_block_mfma(const FeatArgs &A, const BasisDe
         {
             TripletGeom tg;
             bool valid = lane < batch && p0 + lane < k.n_items;
-            if (valid) valid = trio_walk_geom<WANT_F>(A, g, w, td, k, m, sm, p0 + lane, tg);
+            if (valid) valid = trio_walk_geom<WANT_F, IMG>(A, g, w, td, k, m, sm, p0 + lane, tg);
             // leg masks t[0] <= r <= t[-1] (angles.py:502-508); both ends contribute nothing (see eval_triplet)
             if (valid)                   // (bounds hoisted; `&`, not `&&`: no branch, no memory access per clause)
                 valid = (tg.rl > lo_r[0]) & (tg.rl < hi_r[0]) & (tg.rm > lo_r[1]) & (tg.rm < hi_r[1]) &
@@ -1075,7 +1173,7 @@ __device__ __forceinline__ void grouped_pass_steps(unsigned va, unsigned vd, uns
 }
 #undef UF3_GROUP_STEPS
 
-template <bool WANT_E>
+template <bool WANT_E, bool IMG>
 __device__ __forceinline__ void trio_block_grouped(const FeatArgs &A, const BasisDev *B, const KnotRec *recs, const FrameGeom &g,
                                                    const WaveLds &w, int m, int sm, int t, const ESink &es,
                                                    const int (&fragp)[4], const int *dsrc) {
@@ -1086,7 +1184,7 @@ __device__ __forceinline__ void trio_block_grouped(const FeatArgs &A, const Basi
     const TrioDev td_copy = load_const(A.trios + t);
     const TrioDev *td = &td_copy;
     TrioWalk k;
-    trio_walk_setup<WANT_F>(A, w, td, sm, k);
+    trio_walk_setup<WANT_F, IMG>(A, w, td, sm, k);
     const int ncol = td->ncol, F = B->F;
     const int lo_l = td->lo[0], lo_m = td->lo[1], lo_n = td->lo[2];
     const int ext_l = td->ext[0], ext_m = td->ext[1], ext_n = td->ext[2];
@@ -1128,7 +1226,7 @@ __device__ __forceinline__ void trio_block_grouped(const FeatArgs &A, const Basi
         {
             TripletGeom tg;
             bool valid = lane < batch && p0 + lane < k.n_items;
-            if (valid) valid = trio_walk_geom<WANT_F>(A, g, w, td, k, m, sm, p0 + lane, tg);
+            if (valid) valid = trio_walk_geom<WANT_F, IMG>(A, g, w, td, k, m, sm, p0 + lane, tg);
             if (valid)
                 valid = (tg.rl > lo_r[0]) & (tg.rl < hi_r[0]) & (tg.rm > lo_r[1]) & (tg.rm < hi_r[1]) &
                         (tg.rn > lo_r[2]) & (tg.rn < hi_r[2]);
@@ -1342,12 +1440,15 @@ __device__ __forceinline__ int trio_mode(const TrioDev *td) {
     return td->nsrc == 1 ? (wide ? 2 : 1) : (td->nsrc == 2 ? (wide ? 4 : 3) : 5);
 }
 
-template <bool WANT_E, bool WANT_F, bool RECS_LDS, int MODE>
+template <bool WANT_E, bool WANT_F, bool RECS_LDS, int MODE, bool IMG>
 __global__ void __launch_bounds__(WPB * WAVE, MODE == 0 ? 4 : ((MODE == 6 || MODE == 7) ? 3 : 2))
 k_featurize(FeatArgs A) {
     extern __shared__ __align__(16) unsigned char smem[];
     const BasisDev *B = A.B;
     const int F = load_const(&B->F), S = load_const(&B->S), n_trios = load_const(&B->T), cap = A.n3.cap;
+    // a batch with atoms far outside their cell needs the reference's image-range rule in the 3-body force rows (TrioWalk::
+    // img_check): the ordinary launches leave it to the IMG ones (the host sees the same flag and repeats the call)
+    if (!IMG && WANT_F && MODE != 0 && A.outside && A.outside[0]) return;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);           // wave-uniform: LDS pointers and atom indices in SGPRs
     double *erow = (double *)smem;                                         // [F] shared by the block (WANT_E)
@@ -1494,14 +1595,14 @@ k_featurize(FeatArgs A) {
                 const int t_sc = load_const(&td->sc), t_sa = load_const(&td->sa), t_sb = load_const(&td->sb);
                 const bool touches = (t_sc == sm) || (WANT_F && (t_sa == sm || t_sb == sm));
                 if (!touches) { if (WANT_F && !(A.skip & 32)) zero_rows(A.x_f, m, F, load_const(&td->col), t_ncol); continue; }
-                if (MODE == 1) trio_block<WANT_E, WANT_F, 1, 1>(A, B, recs, g, w, m, sm, t, es);
-                else if (MODE == 2) trio_block<WANT_E, WANT_F, 1, 2>(A, B, recs, g, w, m, sm, t, es);
-                else if (MODE == 3) trio_block<WANT_E, WANT_F, 2, 1>(A, B, recs, g, w, m, sm, t, es);
-                else if (MODE == 4) trio_block<WANT_E, WANT_F, 2, 2>(A, B, recs, g, w, m, sm, t, es);
-                else if (MODE == 5) trio_block<WANT_E, WANT_F, 6, 1>(A, B, recs, g, w, m, sm, t, es);
+                if (MODE == 1) trio_block<WANT_E, WANT_F, 1, 1, IMG>(A, B, recs, g, w, m, sm, t, es);
+                else if (MODE == 2) trio_block<WANT_E, WANT_F, 1, 2, IMG>(A, B, recs, g, w, m, sm, t, es);
+                else if (MODE == 3) trio_block<WANT_E, WANT_F, 2, 1, IMG>(A, B, recs, g, w, m, sm, t, es);
+                else if (MODE == 4) trio_block<WANT_E, WANT_F, 2, 2, IMG>(A, B, recs, g, w, m, sm, t, es);
+                else if (MODE == 5) trio_block<WANT_E, WANT_F, 6, 1, IMG>(A, B, recs, g, w, m, sm, t, es);
                 else if (MODE == 7 && WANT_F && load_const(&td->grouped))
-                    trio_block_grouped<WANT_E>(A, B, recs, g, w, m, sm, t, es, fragp, dsrc);
-                else trio_block_mfma<WANT_E, WANT_F, (MODE >= 6 ? MODE : 6)>(A, B, recs, g, w, m, sm, t, es, fragp, dsrc);
+                    trio_block_grouped<WANT_E, IMG>(A, B, recs, g, w, m, sm, t, es, fragp, dsrc);
+                else trio_block_mfma<WANT_E, WANT_F, (MODE >= 6 ? MODE : 6), IMG>(A, B, recs, g, w, m, sm, t, es, fragp, dsrc);
             }
         }
     }
