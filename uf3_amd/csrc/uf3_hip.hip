@@ -59,7 +59,8 @@ struct uf3_ctx {
         n3_cnt, n3_int, n3_dbl, e_atom, nbr_f, coeff, stage_pos, stage_z, stage_out, stage_out2,
         gram_tiles, frag, dbg,
         halo,                           // marks + index list of the halo atoms of a decomposed frame
-        n3x_ent, n3x_off;               // extension lists (batches with atoms outside their cell; see N3Lists)
+        n3x_ent, n3x_off,               // extension lists (batches with atoms outside their cell; see N3Lists)
+        bin_cnt;                        // atoms per cell-list bin (counting sort)
     int n3_cap = 0, cand_cap = 0;
     int n3x_cap = 0;                 // capacity of the extension lists (0 until a batch needed them)
     bool img_mode = false;           // a batch with atoms far outside their cell has been seen: 3-body launches with the image-range rule
@@ -157,7 +158,7 @@ extern "C" void uf3_ctx_destroy(uf3_ctx *c) {
     hipStreamSynchronize(c->stream);
     Buf *all[] = {&c->geoms, &c->offsets, &c->frame_of, &c->atom_bin, &c->atom_wrap, &c->spec, &c->key_in,
                   &c->key_out, &c->val_in, &c->val_out, &c->sort_tmp, &c->bin_start, &c->slots, &c->flags, &c->n3_cnt, &c->n3_int, &c->n3_dbl, &c->e_atom, &c->nbr_f, &c->coeff,
-                  &c->stage_pos, &c->stage_z, &c->stage_out, &c->stage_out2, &c->gram_tiles, &c->frag, &c->dbg, &c->halo, &c->n3x_ent, &c->n3x_off};
+                  &c->stage_pos, &c->stage_z, &c->stage_out, &c->stage_out2, &c->gram_tiles, &c->frag, &c->dbg, &c->halo, &c->n3x_ent, &c->n3x_off, &c->bin_cnt};
     for (Buf *b : all) b->release();
     c->pin_in.release(); c->pin_geo.release(); c->pin_out.release(); c->pin_flags.release();
     for (auto &pd : c->pending_chk) if (pd.ev) hipEventDestroy(pd.ev);
@@ -726,8 +727,7 @@ static int prepare(uf3_basis *b, const uf3_frames *fr, const double *d_pos, cons
     }
     size_t na = (size_t)natoms;
     HIPCHK(c, c->frame_of.ensure(4 * na)); HIPCHK(c, c->atom_bin.ensure(4 * na)); HIPCHK(c, c->atom_wrap.ensure(4 * na));
-    HIPCHK(c, c->spec.ensure(na)); HIPCHK(c, c->key_in.ensure(4 * na)); HIPCHK(c, c->key_out.ensure(4 * na));
-    HIPCHK(c, c->val_in.ensure(4 * na)); HIPCHK(c, c->val_out.ensure(4 * na));
+    HIPCHK(c, c->spec.ensure(na)); HIPCHK(c, c->key_in.ensure(4 * na)); HIPCHK(c, c->val_out.ensure(4 * na));
     HIPCHK(c, c->bin_start.ensure(4 * ((size_t)nbins + 2)));
     HIPCHK(c, c->slots.ensure(sizeof(SlotRec) * na));
     if (!c->flags.p) { HIPCHK(c, c->flags.ensure(64)); HIPCHK(c, hipMemsetAsync(c->flags.p, 0, 64, st)); }
@@ -743,21 +743,22 @@ static int prepare(uf3_basis *b, const uf3_frames *fr, const double *d_pos, cons
         P.flags_zeroed = true;
     } else {
     HIPCHK(c, hipMemsetAsync(flags + 3, 0, 2 * sizeof(int), st));         // extension-list need | "some atom outside its cell" (k_frame_bins)
+    // counting sort by global bin: counts (k_frame_bins) -> exclusive scan = bin starts -> fill -> per-bin order + slot records
+    HIPCHK(c, c->bin_cnt.ensure(4 * ((size_t)nbins + 2)));
+    HIPCHK(c, hipMemsetAsync(c->bin_cnt.p, 0, 4 * ((size_t)nbins + 1), st));
     hipLaunchKernelGGL(k_frame_bins, dim3(gb), dim3(tb), 0, st, b->dev, d_geoms,
                        d_offsets, nf, natoms, d_pos, d_z, c->frame_of.as<int>(), c->atom_bin.as<int>(),
-                       c->atom_wrap.as<int>(), c->spec.as<signed char>(), c->key_in.as<int>(), c->val_in.as<int>(), flags);
-    int bits = 1;
-    while ((1LL << bits) < (long long)nbins + 1) bits++;
+                       c->atom_wrap.as<int>(), c->spec.as<signed char>(), c->key_in.as<int>(), c->bin_cnt.as<int>(), flags);
     size_t tmp_bytes = 0;
-    HIPCHK(c, rocprim::radix_sort_pairs(nullptr, tmp_bytes, c->key_in.as<int>(), c->key_out.as<int>(),
-                                         c->val_in.as<int>(), c->val_out.as<int>(), na, 0, bits, st));
+    HIPCHK(c, rocprim::exclusive_scan(nullptr, tmp_bytes, c->bin_cnt.as<int>(), c->bin_start.as<int>(), 0, (size_t)nbins + 1,
+                                       rocprim::plus<int>(), st));
     HIPCHK(c, c->sort_tmp.ensure(tmp_bytes));
-    HIPCHK(c, rocprim::radix_sort_pairs(c->sort_tmp.p, tmp_bytes, c->key_in.as<int>(), c->key_out.as<int>(),
-                                         c->val_in.as<int>(), c->val_out.as<int>(), na, 0, bits, st));
-    hipLaunchKernelGGL(k_bin_start, dim3((nbins + 1 + tb - 1) / tb), dim3(tb), 0, st, c->key_out.as<int>(), natoms,
-                       nbins, c->bin_start.as<int>());
-    hipLaunchKernelGGL(k_gather_sorted, dim3(gb), dim3(tb), 0, st, c->val_out.as<int>(), natoms, d_pos,
-                       c->atom_wrap.as<int>(), c->spec.as<signed char>(), c->slots.as<SlotRec>());
+    HIPCHK(c, rocprim::exclusive_scan(c->sort_tmp.p, tmp_bytes, c->bin_cnt.as<int>(), c->bin_start.as<int>(), 0, (size_t)nbins + 1,
+                                       rocprim::plus<int>(), st));
+    hipLaunchKernelGGL(k_bin_fill, dim3(gb), dim3(tb), 0, st, c->key_in.as<int>(), natoms, c->bin_start.as<int>(),
+                       c->bin_cnt.as<int>(), c->val_out.as<int>());
+    hipLaunchKernelGGL(k_bin_finish, dim3((nbins + tb - 1) / tb), dim3(tb), 0, st, nbins, c->bin_start.as<int>(),
+                       c->val_out.as<int>(), d_pos, c->atom_wrap.as<int>(), c->spec.as<signed char>(), c->slots.as<SlotRec>());
     }
     HIPCHK(c, hipGetLastError());
 
