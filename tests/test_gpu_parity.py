@@ -292,6 +292,39 @@ def test_config4_fit_in_chunks_10k_atom_tungsten_frames():
     assert np.abs(pred - x_f @ c_true).max() < 2e-2 * np.abs(x_f @ c_true).max()
 
 
+def test_two_element_fit_in_chunks_through_the_tiled_gram_kernel():
+    """The metric variant of config 4 (W/Mo, F = 434) through the device-resident accumulator: chunks of three 10 000-atom
+    frames = 90 003 force rows, i.e. the LDS-tiled X^T X kernel in its accumulating form with X^T y riding along,
+    twice; pieces == the oracle's on the downloaded rows."""
+    from uf3_amd import pipeline
+    basis = synthetic.notebook_basis(['Mo', 'W'])
+    n_frames = 6
+    frames = [synthetic.config_c4(frame=k)[0] for k in range(n_frames)]
+    assert len(frames[0]) == 10000 and basis.n_feats == 434
+    fz = process.BasisFeaturizer(basis)
+    reg = basis.get_regularization_matrix(ridge_1b=1e-8, ridge_2b=0.0, ridge_3b=1e-8, curvature_2b=1e-8, curvature_3b=0.0)
+    x_e, x_f, off = fz.featurize_frames(frames)
+    x_f = x_f.reshape(-1, basis.n_feats)
+    rng = np.random.default_rng(17)
+    c_true = rng.normal(0, 1, basis.n_feats)
+    c_true[basis.col_idx] = 0
+    energies = x_e @ c_true + rng.normal(0, 1e-3, n_frames)
+    forces_flat = x_f @ c_true + rng.normal(0, 1e-3, len(x_f))
+    forces = [forces_flat[3 * off[k]:3 * off[k + 1]].reshape(-1, 3) for k in range(n_frames)]
+    model = ls.WeightedLinearModel(basis, regularizer=reg)
+    acc = pipeline.DeviceFitAccumulator(model, fz, max_atoms_per_chunk=30000)
+    acc.add_frames(frames, energies, forces)
+    assert acc.n_chunks == 2
+    pieces = acc.pieces()
+    n = x_e[:, :2].sum(axis=1)
+    ref = O.fit(basis, reg, x_e / n[:, None], energies / n, x_f, forces_flat, weight=0.3)
+    for key in ("gram_e", "gram_f", "ord_e", "ord_f"):
+        assert rel_err(pieces[key], ref[key]) < 1e-9, key
+    model.fit_from_pieces(pieces, weight=0.3)
+    pred = model.predict(x_f)
+    assert rel_err(pred, x_f @ ref["coefficients"]) < 1e-6
+
+
 def test_ragged_batch_of_large_frames_equals_per_frame_calls():
     """32 frames of 1 000 - 10 000 atoms (mixed sizes, W/Mo) in one batch == one call per frame."""
     basis = synthetic.notebook_basis(['Mo', 'W'])
