@@ -1,10 +1,12 @@
 // uf3_kernels.h -- the gfx950 kernels of the UF3 hot path.
 //
 //   k_frame_bins      atom -> (frame, wrapped fractional bin)            [HBM-trivial]
-//   k_bin_start / k_gather_sorted   cell list over radix-sorted atoms (32-B slot records in bin order)
+//   k_bin_fill / k_bin_finish   cell list: counting sort of the atoms by bin (32-B slot records in bin order);
+//                     k_prepare_small: the whole stage of an MD-step batch in one workgroup
 //   k_build_n3        per-atom 3-body neighbour lists with image shifts, sorted by
 //                     (species, reference supercell index)               one wave / atom (evaluator path)
-//   k_featurize<E, F, R, MODE>   energy row + 3 force rows per atom      one wave / atom, one launch per block family:
+//   k_build_n3_ext    extension lists for batches with atoms far outside their cell (reference's image range)
+//   k_featurize<E, F, R, MODE, IMG>   energy row + 3 force rows per atom   one wave / atom, one launch per block family:
 //                     MODE 0      one-body + pair columns; also builds the 3-body lists from its candidates
 //                     MODE 6 / 7  3-body windows of <= 32 rows on the fp64 matrix cores (7: three waves / SIMD)
 //                     MODE 8 / 9  ... of <= 64 / <= 128 rows
