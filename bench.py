@@ -48,9 +48,9 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--cpu-workers", type=int, default=0, help="processes of the cpu_baseline pool (0: all cores, <= 32)")
-    ap.add_argument("--frames-per-step", type=int, default=32,
-                    help="frames per step and rank (32 x 10k atoms: 3.3 GB of rows in HBM); smaller batches leave a "
-                         "few per cent on the table to workgroup tail effects")
+    ap.add_argument("--frames-per-step", type=int, default=128,
+                    help="frames per step and rank (128 x 10k atoms: 13.4 GB of rows in HBM, sized for 288 GB); smaller "
+                         "batches leave a few per cent on the table to launch tails (32: -2.5 %%)")
     ap.add_argument("--atoms", type=int, default=10000, help="10000 = north-star; smaller = debug only")
     ap.add_argument("--mode", choices=["featurize", "fit"], default="featurize",
                     help="featurize = BASELINE metric (rows into HBM); fit = config 4 (rows -> X^T X / X^T y on the device)")
