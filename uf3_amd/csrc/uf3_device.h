@@ -304,8 +304,17 @@ __device__ __forceinline__ void for_each_candidate(const FrameGeom &g, const Cel
         const int last = min(WAVE, n_runs - r0) - 1;
         for (int base = 0; base < total; base += WAVE) {
             const int idx = base + lane;
-            int run = 0;
-            for (int rr = 0; rr < last; rr++) run += idx >= __builtin_amdgcn_readlane(incl, rr);
+            // the run of candidate idx = the first run whose inclusive end lies beyond idx: binary search over the lanes' prefix
+            // sums (six shuffles; a linear count over up to 49 runs cost 75-150 vector instructions per step)
+            int run = 0, run_hi = last;
+#pragma unroll
+            for (int it = 0; it < 6; it++) {
+                const int mid = (run + run_hi) >> 1;
+                const bool right = __shfl(incl, mid) <= idx;
+                run = right ? mid + 1 : run;
+                run_hi = right ? run_hi : mid;
+            }
+            run = min(run, last);
             const int slot = __shfl(rel, run) + idx;
             int sh0, sh1, sh2;
             unpack3(__shfl(shp, run), sh0, sh1, sh2);
