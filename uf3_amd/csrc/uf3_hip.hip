@@ -941,7 +941,7 @@ extern "C" int uf3_featurize_dev(uf3_basis *b, const uf3_frames *fr, const doubl
                         // (LDS is granted in coarse granules: 53 KB did not fit).  Candidates in order of preference: more
                         // records per pass first, tables in LDS before tables in HBM
                         const int tries[3] = {nrec_max, std::min(nrec_max, 18), std::min(nrec_max, 15)};
-                        const size_t budget = 52 * 1024;
+                        const size_t budget = (WPB == 4 ? 52 : 13 * WPB) * 1024;      // (12 waves per CU: 3 x 4 or 2 x 6)
                         const bool dsrc_allowed = A.dsrc_lds, recs_allowed = !getenv("UF3_NO_LDS_RECS") && !(img_launch && mode != 0);
                         for (int q = 0; q < 12 && !found; q++) {
                             const int nr = tries[q / 4];

@@ -374,7 +374,9 @@ __device__ __forceinline__ bool neighbour_is_first(const FrameGeom &g, int sm, i
 // ---------------------------------------------------------------------------------
 // featurizer
 // ---------------------------------------------------------------------------------
+#ifndef WPB
 #define WPB 4             // independent waves per workgroup (they share only the energy row)
+#endif
 #define NSTAGE 32         // records staged in LDS per wave at a time
 #define CAND_STRIDE 6     // doubles per 2-body candidate: dx, dy, dz, d | species | int2 {atom, packed image shift}
 #define ITEM_STRIDE 38    // doubles per staged triplet record (16-B aligned)
