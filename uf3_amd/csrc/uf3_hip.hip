@@ -977,10 +977,11 @@ extern "C" int uf3_featurize_dev(uf3_basis *b, const uf3_frames *fr, const doubl
                     fprintf(stderr, "uf3 featurize mode %d: lds %zu B (plain %zu, with recs %zu), recs_lds %d, cap %d, cand_cap %d, "
                             "blocks %d x %d atoms, n_recs %zu, dense nrec %d stage %d\n", launch_mode, lds, lds_plain, lds_recs,
                             (int)recs_lds, cap, A.cand_cap, n_blocks, apb, n_rec_mode, A.dense_nrec, A.dense_stage);
+#define UF3_GRID(n) (((n) + 7) / 8 * 8)      /* whole rounds over the XCDs (surplus workgroups find no atoms) */
 #define UF3_LAUNCH1(E, Fo, R, M, I)                                                                                   \
     do {                                                                                                            \
         HIPCHK(c, hipFuncSetAttribute((const void *)k_featurize<E, Fo, R, M, I>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        hipLaunchKernelGGL((k_featurize<E, Fo, R, M, I>), dim3(n_blocks), dim3(WPB * WAVE), lds, st, A);             \
+        hipLaunchKernelGGL((k_featurize<E, Fo, R, M, I>), dim3(UF3_GRID(n_blocks)), dim3(WPB * WAVE), lds, st, A);   \
     } while (0)
 #define UF3_LAUNCH(M)                                                                                               \
     do {                                                                                                            \

@@ -1519,7 +1519,11 @@ k_featurize(FeatArgs A) {
     if (e_lds) { for (int q = tid; q < F; q += WPB * WAVE) erow[q] = 0.0; }
     if (DENSE) for (int q = lane; q < (int)stage_d; q += WAVE) w.stage[q] = 0.0;   // masked operands read stale slots
     __syncthreads();
-    const int block_first = blockIdx.x * A.atoms_per_block;
+    // workgroups go to the 8 XCDs round-robin by their linear id, each XCD has its own L2: give every XCD one contiguous
+    // eighth of the atoms (atoms are in cell order, a neighbour's list is then mostly in the same L2: +1 % on the clock).
+    // The grid is a multiple of 8; surplus workgroups find no atoms.
+    const int bid = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    const int block_first = bid * A.atoms_per_block;
     const int block_end = min(block_first + A.atoms_per_block, A.natoms);
     int erow_frame = -1;
     for (int m0 = block_first; m0 < block_end; m0 += WPB) {      // the block's waves take consecutive atoms
