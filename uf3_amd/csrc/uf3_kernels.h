@@ -1742,7 +1742,8 @@ k_eval(EvalArgs A) {
     int *uparent = (int *)(ukey + cap), *ushift = uparent + cap;
     const bool fuse = !GATHER && A.fuse_n3;
     int count3 = 0;
-    int m = A.atom_lo + blockIdx.x;
+    // (one contiguous eighth of the atoms per XCD, as in k_featurize; the grid is a multiple of 8)
+    int m = A.atom_lo + (int)((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3));
     if (m >= A.atom_hi) return;
     int lane = lane_id();
     const FrameGeom g = A.geoms[A.frame_of[m]];
@@ -1953,7 +1954,7 @@ k_eval(EvalArgs A) {
 // on it; fixed lane order + a fixed shuffle tree: deterministic
 __global__ void __launch_bounds__(256)
 k_eval_collect(EvalArgs A) {
-    const int m = blockIdx.x * 16 + (threadIdx.x >> 4), sub = threadIdx.x & 15;
+    const int m = (int)((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3)) * 16 + (threadIdx.x >> 4), sub = threadIdx.x & 15;
     if (m >= A.natoms) return;
     const int cap = A.n3.cap, n = A.n3.cnt[m];
     const N3Entry *mine = A.n3.ent + (size_t)m * cap;
