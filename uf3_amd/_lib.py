@@ -39,8 +39,9 @@ class SpeciesError(UF3Error):
 
 
 class RetryError(UF3Error):
-    """UF3_ERETRY: an earlier asynchronous ``uf3_featurize_dev`` call overflowed its neighbour capacities; its
-    outputs are invalid, the capacities have been raised: repeat the work since the last synchronisation."""
+    """UF3_ERETRY: an earlier asynchronous ``uf3_featurize_dev`` call overflowed its neighbour capacities (or met atoms
+    far outside their cell, whose 3-body force rows need the launches with the reference's image-range rule); its outputs
+    are invalid, the context has adapted: repeat the work since the last synchronisation."""
 
 
 class BasisSpec(C.Structure):

@@ -160,13 +160,13 @@ def fit_frames(model, featurizer, frames, energies, forces=None, weight=0.5, red
     if with_forces is None:
         with_forces = forces is not None
     acc = DeviceFitAccumulator(model, featurizer, with_forces=with_forces, max_atoms_per_chunk=max_atoms_per_chunk)
-    for attempt in range(2):
+    for attempt in range(4):
         try:
             acc.add_frames(frames, energies, forces)
             flat = acc.packed()
             break
-        except _lib.RetryError:          # a neighbour capacity grew under an asynchronous chunk: the sums are invalid
-            if attempt:
+        except _lib.RetryError:          # a neighbour capacity grew under an asynchronous chunk (or the context switched to
+            if attempt == 3:             # the image-range launches for atoms far outside their cell): the sums are invalid
                 raise
             acc.reset()
     n_cols = int(acc._keep.numel())
