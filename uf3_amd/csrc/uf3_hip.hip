@@ -391,7 +391,8 @@ extern "C" int uf3_basis_create(uf3_ctx *c, const uf3_basis_spec *s, uf3_basis *
             b->dense_dump[dmode] = std::max(b->dense_dump[dmode], td.ext[0] * dl.cw);
         }
         td.grouped = 0; td.gthr0 = -1e300; td.gthr2 = 1e300;
-        if (td.dense == 7 && td.ext[1] == 3 && td.ext[0] <= 3 && td.ext[2] >= 6 && td.ext[2] <= 9 && !getenv("UF3_NO_NGROUP")) {
+        if (td.dense == 7 && td.ext[1] == 3 && td.ext[0] <= 3 && td.ext[2] >= 6 && td.ext[2] <= 9 && td.nsrc <= 2 && td.ncol <= 128 &&
+            !getenv("UF3_NO_NGROUP")) {
             // first window bin f = interval - 3 - lo_n: f <= 1 -> group 0 (bins 0..4), f >= 4 -> group 2 (bins 4..8)
             const double *tn = legn_knots[t];
             const int nk = td.leg[2].nk, i_lo = 3, i_hi = nk - 5;
@@ -929,7 +930,8 @@ extern "C" int uf3_featurize_dev(uf3_basis *b, const uf3_frames *fr, const doubl
                 bool found = false;
                 if (dense_mode) {
                     const int stride = want_f ? b->dense_stride_f[mode] : b->dense_stride[mode];
-                    const int dump = want_f && stride == 32 ? std::max(512, b->dense_dump[mode]) : b->dense_dump[mode];
+                    // (grouped windows fold from three 12 x 16 tiles side by side: 704 doubles)
+                    const int dump = want_f && b->dense_grouped[mode] ? std::max(704, b->dense_dump[mode]) : b->dense_dump[mode];
                     const bool grouped = want_f && b->dense_grouped[mode];
                     const int nrec_max = std::max(4, std::min(grouped ? 20 : DENSE_NREC, 1200 / stride));
                     // (+ the padding record of an odd pass; grouped windows: one per odd group, at most 2 + (nr odd))
