@@ -1329,20 +1329,22 @@ __device__ __forceinline__ void trio_block_grouped(const FeatArgs &A, const Basi
         const int col = lane + it * WAVE;
         if (col >= ncol) break;
         double fx = 0, fy = 0, fz = 0, en = 0;
+        // (no branches around the reads: every (source, group) combination is read -- from the tile's first entry when it does
+        // not apply -- and weighted 0 or 1, so that all reads of a column are in flight together)
 #pragma unroll
         for (int q = 0; q < 2; q++) {
             const int off = offs[it][q];
-            if (off < 0) continue;
             // window offset -> (l, n, m) relative to the window; bin n sits in the groups g with 0 <= n - 2 g <= 4
-            const int l_rel = off >> cw_shift, rem = off & (cw - 1);
+            const int offc = max(off, 0), l_rel = offc >> cw_shift, rem = offc & (cw - 1);
             const int n_rel = (rem * inv_m) >> 16, m_rel = rem - n_rel * ext_m;
 #pragma unroll
             for (int grp = 0; grp < NG; grp++) {
                 const int nl = n_rel - 2 * grp;
-                if (nl < 0 || nl >= GW) continue;
-                const double *t = tiles + grp * 256 + l_rel * 16 + nl * ext_m + m_rel;
-                fx += t[0]; fy += t[ext_l * 16]; fz += t[2 * ext_l * 16];
-                if (WANT_E) en += t[3 * ext_l * 16];
+                const bool use = off >= 0 && nl >= 0 && nl < GW;
+                const double wgt = use ? 1.0 : 0.0;
+                const double *t = tiles + (use ? grp * 256 + l_rel * 16 + nl * ext_m + m_rel : 0);
+                fx += wgt * t[0]; fy += wgt * t[ext_l * 16]; fz += wgt * t[2 * ext_l * 16];
+                if (WANT_E) en += wgt * t[3 * ext_l * 16];
             }
         }
         if (!(A.skip & 32)) {
