@@ -1330,7 +1330,9 @@ __device__ __forceinline__ void trio_block_grouped(const FeatArgs &A, const Basi
         if (col >= ncol) break;
         double fx = 0, fy = 0, fz = 0, en = 0;
         // (no branches around the reads: every (source, group) combination is read -- from the tile's first entry when it does
-        // not apply -- and weighted 0 or 1, so that all reads of a column are in flight together)
+        // not apply -- and weighted 0 or 1; all reads of a column go out before the first sum waits for one: left alone the
+        // compiler serialised them into 24 round trips)
+        double tv[2][NG][4], wgt[2][NG];
 #pragma unroll
         for (int q = 0; q < 2; q++) {
             const int off = offs[it][q];
@@ -1341,12 +1343,20 @@ __device__ __forceinline__ void trio_block_grouped(const FeatArgs &A, const Basi
             for (int grp = 0; grp < NG; grp++) {
                 const int nl = n_rel - 2 * grp;
                 const bool use = off >= 0 && nl >= 0 && nl < GW;
-                const double wgt = use ? 1.0 : 0.0;
+                wgt[q][grp] = use ? 1.0 : 0.0;
                 const double *t = tiles + (use ? grp * 256 + l_rel * 16 + nl * ext_m + m_rel : 0);
-                fx += wgt * t[0]; fy += wgt * t[ext_l * 16]; fz += wgt * t[2 * ext_l * 16];
-                if (WANT_E) en += wgt * t[3 * ext_l * 16];
+                tv[q][grp][0] = t[0]; tv[q][grp][1] = t[ext_l * 16]; tv[q][grp][2] = t[2 * ext_l * 16];
+                tv[q][grp][3] = WANT_E ? t[3 * ext_l * 16] : 0.0;
             }
         }
+        __builtin_amdgcn_sched_group_barrier(0x100, WANT_E ? 24 : 18, 0);       // all DS reads first
+#pragma unroll
+        for (int q = 0; q < 2; q++)
+#pragma unroll
+            for (int grp = 0; grp < NG; grp++) {
+                fx += wgt[q][grp] * tv[q][grp][0]; fy += wgt[q][grp] * tv[q][grp][1]; fz += wgt[q][grp] * tv[q][grp][2];
+                if (WANT_E) en += wgt[q][grp] * tv[q][grp][3];
+            }
         if (!(A.skip & 32)) {
             double *dst = A.x_f + (size_t)m * 3 * F + td->col + col;
             dst[0] = fx; dst[F] = fy; dst[2 * (size_t)F] = fz;
