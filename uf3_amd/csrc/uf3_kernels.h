@@ -1271,13 +1271,21 @@ __device__ __forceinline__ void trio_block_grouped(const FeatArgs &A, const Basi
                 for (int q = 2 * lane; q < n_staged * STRIDE; q += 2 * WAVE) *(double2 *)(w.stage + q) = double2{0.0, 0.0};
             if (mine) {
                 const int gi = base + li;
+                // the LDS round trips of a pass in two waves instead of seven: everything that hangs on gi alone first, then
+                // the knot record together with the direction components (left alone the compiler reads them one by one, each
+                // behind its own wait)
                 const double x = w.geo[leg * GEO_N + gi];
+                const int2 pk = ((const int2 *)(w.geo + 6 * GEO_N))[gi];
+                const double a3 = w.geo[(3 + leg) * GEO_N + gi];
+                __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+                const int i1 = pk.x & 0xffff, i2 = pk.x >> 16;
+                const double *oc = w.ox + (size_t)leg * A.n3.cap;
+                const double oc1 = oc[i1], oi1 = w.oir[i1], oc2 = oc[i2], oi2 = w.oir[i2];
                 KnotRec kr;
                 double v[4], d[4];
                 const int first = load_interval(recs, lg, x, kr) - 3;
                 bspline4<WANT_F>(kr, x, v, d);
                 double *rec = w.stage + (size_t)(li + (li >= b0 ? (b0 & 1) : 0) + (li >= b1 ? ((b1 - b0) & 1) : 0)) * STRIDE;
-                const int2 pk = ((const int2 *)(w.geo + 6 * GEO_N))[gi];
                 const int cls = pk.y & 3, grp = pk.y >> 2;
                 // leg n: window = the record's group; legs l, m: the block's window
                 const int w_lo = leg == 0 ? lo_l : (leg == 1 ? lo_m : lo_n + 2 * grp);
@@ -1290,10 +1298,7 @@ __device__ __forceinline__ void trio_block_grouped(const FeatArgs &A, const Basi
                     if (ws < (unsigned)w_ext)
                         *(double2 *)(rec + w_off + 2 * ws) = double2{d0 ? d[q] : v[q], d1 ? d[q] : v[q]};
                 }
-                const int i1 = pk.x & 0xffff, i2 = pk.x >> 16;
-                const double *oc = w.ox + (size_t)leg * A.n3.cap;
-                const double u1 = oc[i1] * w.oir[i1];
-                const double u2 = oc[i2] * w.oir[i2], a3 = w.geo[(3 + leg) * GEO_N + gi];
+                const double u1 = oc1 * oi1, u2 = oc2 * oi2;
                 *(double2 *)(rec + oD + 2 * leg) = double2{u1, cls == 0 ? u2 : a3};
                 if (leg == 0 && cls == 0) rec[oD + 6] = 1.0;
             }
