@@ -714,7 +714,11 @@ __device__ __forceinline__ bool trio_walk_geom(const FeatArgs &A, const FrameGeo
         }
         int s0, s1, s2;
         unpack3(w.oshift[e], s0, s1, s2);
+        // the centre's own-list fields go out together with the entry's global load (requested after it they would each wait
+        // behind it: this chain is the walk's critical path)
+        const double oex = w.ox[e], oey = w.oy[e], oez = w.oz[e], oer = w.orr[e], oie = w.oir[e];
         const N3Entry ke = *kp;
+        asm volatile("" ::: "memory");
         int kparent = ke.parent, kshift = ke.shiftc;
         valid = !(kparent == m && kshift == pack3(-s0, -s1, -s2));       // k is m itself
         if (IMG && k.img_check) {                                        // k's image as the reference numbers it
@@ -726,20 +730,20 @@ __device__ __forceinline__ bool trio_walk_geom(const FeatArgs &A, const FrameGeo
             int ksidx = ke.sidx;
             int msidx = supercell_index(g, -s0, -s1, -s2, m_local);      // m as numbered from c
             double vx = ke.dx, vy = ke.dy, vz = ke.dz, rk = ke.r;
-            double ex = w.ox[e] + vx, ey = w.oy[e] + vy, ez = w.oz[e] + vz;   // m -> k
+            double ex = oex + vx, ey = oey + vy, ez = oez + vz;              // m -> k
             tg.rn = norm3_rn(ex, ey, ez);
             bool m_first = neighbour_is_first(g, sm, k.sx, s0, s1, s2, m_local, msidx, ksidx, kshift,
                                               kparent - g.atom_lo);
             tg.i1 = e; tg.i2 = e;
-            double ie = w.oir[e], in = 1.0 / tg.rn;
-            double ue[3] = {w.ox[e] * ie, w.oy[e] * ie, w.oz[e] * ie};
+            double ie = oie, in = 1.0 / tg.rn;
+            double ue[3] = {oex * ie, oey * ie, oez * ie};
             tg.a3[0] = ex * in; tg.a3[1] = ey * in; tg.a3[2] = ez * in;
             tg.first = m_first;
             if (m_first) {
-                tg.rl = w.orr[e]; tg.rm = rk;
+                tg.rl = oer; tg.rm = rk;
                 for (int u = 0; u < 3; u++) { tg.a1[u] = ue[u]; tg.a2[u] = 0.0; }
             } else {
-                tg.rl = rk; tg.rm = w.orr[e];
+                tg.rl = rk; tg.rm = oer;
                 for (int u = 0; u < 3; u++) { tg.a1[u] = 0.0; tg.a2[u] = ue[u]; }
             }
         }
