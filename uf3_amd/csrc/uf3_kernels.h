@@ -1007,14 +1007,21 @@ __device__ __forceinline__ void trio_block_mfma(const FeatArgs &A, const BasisDe
                 for (int q = 2 * lane; q < n_staged * dl.stride; q += 2 * WAVE) *(double2 *)(w.stage + q) = double2{0.0, 0.0};
             if (mine) {
                 const int gi = base + li;
+                // (the LDS reads of a pass in two waves, as in trio_block_grouped)
                 const double x = w.geo[leg * GEO_N + gi];
+                const int2 pk = WANT_F ? ((const int2 *)(w.geo + 6 * GEO_N))[gi] : make_int2(0, 0);
+                const double a3 = WANT_F ? w.geo[(3 + leg) * GEO_N + gi] : 0.0;
+                __builtin_amdgcn_sched_group_barrier(0x100, WANT_F ? 3 : 1, 0);
+                const int i1 = pk.x & 0xffff, i2 = pk.x >> 16;
+                const double *oc = w.ox + (size_t)leg * A.n3.cap;               // ox | oy | oz are consecutive [cap] arrays
+                const double oc1 = WANT_F ? oc[i1] : 0.0, oi1 = WANT_F ? w.oir[i1] : 0.0, oc2 = WANT_F ? oc[i2] : 0.0,
+                             oi2 = WANT_F ? w.oir[i2] : 0.0;
                 KnotRec kr;
                 double v[4], d[4];
                 const int first = load_interval(recs, lg, x, kr) - 3;
                 bspline4<WANT_F>(kr, x, v, d);
                 if (WANT_F) {
                     double *rec = w.stage + (size_t)li * dl.stride;
-                    const int2 pk = ((const int2 *)(w.geo + 6 * GEO_N))[gi];
                     const int cls = pk.y;
                     // which of (value, derivative) goes to K slot 0 / 1 (table in the header of this section)
                     const bool d0 = leg == 0 ? cls != 2 : (leg == 1 ? cls == 2 : false);
@@ -1026,10 +1033,7 @@ __device__ __forceinline__ void trio_block_mfma(const FeatArgs &A, const BasisDe
                             *(double2 *)(rec + w_off + 2 * ws) = double2{d0 ? d[q] : v[q], d1 ? d[q] : v[q]};
                     }
                     // component `leg` of the two direction vectors: unit vectors of own-list entries, and m -> k
-                    const int i1 = pk.x & 0xffff, i2 = pk.x >> 16;
-                    const double *oc = w.ox + (size_t)leg * A.n3.cap;           // ox | oy | oz are consecutive [cap] arrays
-                    const double u1 = oc[i1] * w.oir[i1];
-                    const double u2 = oc[i2] * w.oir[i2], a3 = w.geo[(3 + leg) * GEO_N + gi];   // both fetched: no divergence
+                    const double u1 = oc1 * oi1, u2 = oc2 * oi2;
                     *(double2 *)(rec + dl.oD + 2 * leg) = double2{u1, cls == 0 ? u2 : a3};
                     if (leg == 0 && cls == 0) rec[dl.oD + 6] = 1.0;
                 } else {
