@@ -1095,6 +1095,25 @@ __device__ __forceinline__ void trio_block_mfma(const FeatArgs &A, const BasisDe
         wave_sync();
         for (int col = lane; col < ncol; col += WAVE) {
             double fx = 0, fy = 0, fz = 0, en = 0;
+            if (nsrc <= 2) {
+                // at most two sources per column (the usual case): both table entries, then all their window reads, go out
+                // together, weighted 0 / 1 -- no branch around a read (the compiler serialises guarded reads into round trips)
+                const int o0 = dsrc[td->src_off + col * nsrc], o1 = nsrc > 1 ? dsrc[td->src_off + col * nsrc + 1] : -1;
+                const double w0 = o0 >= 0 ? 1.0 : 0.0, w1 = o1 >= 0 ? 1.0 : 0.0;
+                const double *p0 = dump + max(o0, 0), *p1 = dump + max(o1, 0);
+                double t0[4], t1[4];
+                t0[0] = p0[0]; t1[0] = p1[0];
+                if (whole && WANT_F) {
+                    t0[1] = p0[comp_rows * cw]; t1[1] = p1[comp_rows * cw];
+                    t0[2] = p0[2 * comp_rows * cw]; t1[2] = p1[2 * comp_rows * cw];
+                }
+                if (whole && WANT_E) { t0[3] = p0[3 * comp_rows * cw]; t1[3] = p1[3 * comp_rows * cw]; }
+                asm volatile("" ::: "memory");                    // (all reads requested before the first sum)
+                if (whole) {
+                    if (WANT_F) { fx = w0 * t0[0] + w1 * t1[0]; fy = w0 * t0[1] + w1 * t1[1]; fz = w0 * t0[2] + w1 * t1[2]; }
+                    if (WANT_E) en = w0 * t0[3] + w1 * t1[3];
+                } else fx = w0 * t0[0] + w1 * t1[0];
+            } else
             for (int q = 0; q < nsrc; q++) {
                 const int off = dsrc[td->src_off + col * nsrc + q];
                 if (off < 0) continue;
