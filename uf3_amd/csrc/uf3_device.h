@@ -32,7 +32,12 @@ struct PairDev {
     double rmin, rmax; // strict range: max(r_min,0) < d < r_max
 };
 
+// what the per-(atom, trio) dispatch of k_featurize looks at, in one 32-byte block at the head of TrioDev: ONE scalar load per
+// trio and atom (read field by field, each behind its own branch, it was eight dependent scalar round trips)
+struct TrioHead { int dense, nsrc, ncol, sc, sa, sb, col, grouped; };
+
 struct TrioDev {
+    TrioHead head;     // copies of the fields below (filled by uf3_basis_create once they are final)
     LegDev leg[3];     // l (ij), m (ik), n (jk)
     int col, ncol;
     int lut_off;       // into BasisDev::lut (also offset of the full grid in c3)

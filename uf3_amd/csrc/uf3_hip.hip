@@ -443,6 +443,7 @@ extern "C" int uf3_basis_create(uf3_ctx *c, const uf3_basis_spec *s, uf3_basis *
     HIPCHK(c, hipMalloc(&b->d_dsrc, sizeof(int) * std::max<size_t>(1, dsrc.size())));
     if (!dsrc.empty()) HIPCHK(c, hipMemcpy(b->d_dsrc, dsrc.data(), sizeof(int) * dsrc.size(), hipMemcpyHostToDevice));
     b->n_dsrc = dsrc.size();
+    for (auto &td : trios) td.head = TrioHead{td.dense, td.nsrc, td.ncol, td.sc, td.sa, td.sb, td.col, td.grouped};
     HIPCHK(c, hipMalloc(&b->d_trios, sizeof(TrioDev) * std::max<size_t>(1, trios.size())));
     if (!trios.empty())
         HIPCHK(c, hipMemcpy(b->d_trios, trios.data(), sizeof(TrioDev) * trios.size(), hipMemcpyHostToDevice));

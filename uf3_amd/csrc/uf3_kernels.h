@@ -1668,18 +1668,22 @@ k_featurize(FeatArgs A) {
             pcl.lap(0);
             for (int t = 0; t < n_trios; t++) {
                 const TrioDev *td = A.trios + t;
-                const int t_dense = load_const(&td->dense), t_nsrc = load_const(&td->nsrc), t_ncol = load_const(&td->ncol);
+                // one 32-byte scalar load (see TrioHead; as eight ints the compiler sinks every field's load to its branch)
+                typedef int int8_v __attribute__((ext_vector_type(8)));
+                const int8_v hv = *(const __attribute__((address_space(4))) int8_v *)(unsigned long long)&td->head;
+                const TrioHead th = {hv[0], hv[1], hv[2], hv[3], hv[4], hv[5], hv[6], hv[7]};
+                const int t_dense = th.dense, t_nsrc = th.nsrc, t_ncol = th.ncol;
                 const int t_mode = t_dense ? t_dense : (t_nsrc == 1 ? (t_ncol > WAVE ? 2 : 1) : (t_nsrc == 2 ? (t_ncol > WAVE ? 4 : 3) : 5));
                 if (t_mode != MODE) continue;
-                const int t_sc = load_const(&td->sc), t_sa = load_const(&td->sa), t_sb = load_const(&td->sb);
+                const int t_sc = th.sc, t_sa = th.sa, t_sb = th.sb;
                 const bool touches = (t_sc == sm) || (WANT_F && (t_sa == sm || t_sb == sm));
-                if (!touches) { if (WANT_F && !(A.skip & 32)) zero_rows(A.x_f, m, F, load_const(&td->col), t_ncol); continue; }
+                if (!touches) { if (WANT_F && !(A.skip & 32)) zero_rows(A.x_f, m, F, th.col, t_ncol); continue; }
                 if (MODE == 1) trio_block<WANT_E, WANT_F, 1, 1, IMG>(A, B, recs, g, w, m, sm, t, es);
                 else if (MODE == 2) trio_block<WANT_E, WANT_F, 1, 2, IMG>(A, B, recs, g, w, m, sm, t, es);
                 else if (MODE == 3) trio_block<WANT_E, WANT_F, 2, 1, IMG>(A, B, recs, g, w, m, sm, t, es);
                 else if (MODE == 4) trio_block<WANT_E, WANT_F, 2, 2, IMG>(A, B, recs, g, w, m, sm, t, es);
                 else if (MODE == 5) trio_block<WANT_E, WANT_F, 6, 1, IMG>(A, B, recs, g, w, m, sm, t, es);
-                else if (MODE == 7 && WANT_F && load_const(&td->grouped))
+                else if (MODE == 7 && WANT_F && th.grouped)
                     trio_block_grouped<WANT_E, IMG>(A, B, recs, g, w, m, sm, t, es, fragp, dsrc);
                 else trio_block_mfma<WANT_E, WANT_F, (MODE >= 6 ? MODE : 6), IMG>(A, B, recs, g, w, m, sm, t, es, fragp, dsrc);
             }
