@@ -7,7 +7,7 @@ RUN=${1:?output directory}; SKIPS=${2:-"0 8 16 24 6"}
 mkdir -p "$RUN"; export TMPDIR=/tmp UF3_BENCH_NOCHECK=1
 for s in $SKIPS; do
   UF3_DEBUG_SKIP=$s timeout 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_MFMA SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAVE_CYCLES SQ_WAIT_INST_ANY \
-    -d $RUN/s$s -o p --output-format csv -- python bench.py --no-cpu-baseline --steps 2 --warmup 1 > $RUN/s$s.json 2>/dev/null
+    -d $RUN/s$s -o p --output-format csv -- python bench.py --no-cpu-baseline --steps 2 --warmup 1 --frames-per-step 32 > $RUN/s$s.json 2>/dev/null
 done
 python - "$RUN" $SKIPS <<'PY'
 import csv, glob, sys, collections
@@ -17,7 +17,7 @@ for s in skips:
     for f in glob.glob(f"{run}/s{s}/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"]
-            if "k_featurize" not in k or ", 0>" in k: continue
+            if "k_featurize" not in k or ", 0, " in k: continue      # (the pair launch: MODE 0)
             acc[r["Counter_Name"]] += float(r["Counter_Value"]); n[r["Counter_Name"]] += 1
     if not acc: print(s, "no data"); continue
     launches = max(n.values())
