@@ -307,10 +307,10 @@ __device__ __forceinline__ void for_each_candidate(const FrameGeom &g, const Cel
         const int total = __builtin_amdgcn_readlane(incl, WAVE - 1);
         const int rel = slot0 - (incl - len);                 // slot = rel + flat index, inside this run
         const int last = min(WAVE, n_runs - r0) - 1;
-        for (int base = 0; base < total; base += WAVE) {
-            const int idx = base + lane;
-            // the run of candidate idx = the first run whose inclusive end lies beyond idx: binary search over the lanes' prefix
-            // sums (six shuffles; a linear count over up to 49 runs cost 75-150 vector instructions per step)
+        // slot record and packed image shift of flat candidate idx.  The run of idx = the first run whose inclusive end lies
+        // beyond idx: binary search over the lanes' prefix sums (six shuffles; a linear count over up to 49 runs cost 75-150
+        // vector instructions per step).  Indices past the end read slot 0 (never used).
+        auto fetch = [&](int idx, SlotRec &sr, int &shpk) {
             int run = 0, run_hi = last;
 #pragma unroll
             for (int it = 0; it < 6; it++) {
@@ -321,20 +321,29 @@ __device__ __forceinline__ void for_each_candidate(const FrameGeom &g, const Cel
             }
             run = min(run, last);
             const int slot = __shfl(rel, run) + idx;
+            shpk = __shfl(shp, run);
+            sr = cl.slots[idx < total ? slot : 0];
+        };
+        // the records of step i + 1 are requested before step i is handed to f (its global round trip hides behind f's work)
+        SlotRec sr_next;
+        int shp_next;
+        if (total > 0) fetch(lane, sr_next, shp_next);
+        for (int base = 0; base < total; base += WAVE) {
+            const int idx = base + lane;
+            SlotRec sr = sr_next;
+            const int shpk = shp_next;
+            if (base + WAVE < total) fetch(idx + WAVE, sr_next, shp_next);
             int sh0, sh1, sh2;
-            unpack3(__shfl(shp, run), sh0, sh1, sh2);
+            unpack3(shpk, sh0, sh1, sh2);
             bool ok = idx < total;
             int s0 = 0, s1 = 0, s2 = 0, sj = 0;
-            SlotRec sr;
-            sr.x = sr.y = sr.z = 0.0; sr.atom = 0; sr.ws = 0;
             if (ok) {
-                sr = cl.slots[slot];
                 int v0, v1, v2;
                 unpack_ws(sr.ws, v0, v1, v2, sj);
                 s0 = sh0 - v0 + w0; s1 = sh1 - v1 + w1; s2 = sh2 - v2 + w2;
                 ok = (abs(s0) <= range_mult * g.fac[0]) && (abs(s1) <= range_mult * g.fac[1]) && (abs(s2) <= range_mult * g.fac[2]);
                 if (ok && sr.atom == m && s0 == 0 && s1 == 0 && s2 == 0) ok = false;
-            }
+            } else { sr.x = sr.y = sr.z = 0.0; sr.atom = 0; sr.ws = 0; }
             f(ok, sr, sj, s0, s1, s2);
         }
     }
