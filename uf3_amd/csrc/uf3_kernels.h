@@ -2034,9 +2034,14 @@ k_eval_collect(EvalArgs A) {
         const int back = pack3(-s0, -s1, -s2), nc = A.n3.cnt[c];
         const N3Entry *theirs = A.n3.ent + (size_t)c * cap;
         int hit = -1;
-        for (int r = 0; r < nc; r++) {
-            const int2 key = *(const int2 *)&theirs[r].parent;
-            if (key.x == m && key.y == back) hit = r;
+        for (int r0 = 0; r0 < nc; r0 += 8) {                // eight entries' keys in flight together (a plain loop waits for each)
+            int2 key[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) key[u] = *(const int2 *)&theirs[min(r0 + u, nc - 1)].parent;
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                if (r0 + u < nc && key[u].x == m && key[u].y == back) hit = r0 + u;
         }
         if (hit >= 0) {
             const double *f = A.nbr_f + 3 * ((size_t)c * cap + hit);
