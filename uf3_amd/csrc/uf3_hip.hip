@@ -1176,11 +1176,13 @@ static int eval_impl(uf3_basis *b, const uf3_frames *fr, const double *d_pos, co
             if (two_pass) {
                 HIPCHK(c, c->nbr_f.ensure(24 * (size_t)P.natoms * cap));
                 A.nbr_f = c->nbr_f.as<double>();
-                hipLaunchKernelGGL(k_eval<false>, dim3((unsigned)((P.natoms + 7) / 8 * 8)), dim3(64), lds, st, A);
+                if (A.virial) hipLaunchKernelGGL((k_eval<false, true>), dim3((unsigned)((P.natoms + 7) / 8 * 8)), dim3(64), lds, st, A);
+                else hipLaunchKernelGGL((k_eval<false, false>), dim3((unsigned)((P.natoms + 7) / 8 * 8)), dim3(64), lds, st, A);
                 if (fuse && deferred_cap) *deferred_cap = (int)cap;
                 hipLaunchKernelGGL(k_eval_collect, dim3((unsigned)(((P.natoms + 15) / 16 + 7) / 8 * 8)), dim3(256), 0, st, A);
             } else if (atom_end > atom_begin)
-                hipLaunchKernelGGL(k_eval<true>, dim3((unsigned)((atom_end - atom_begin + 7) / 8 * 8)), dim3(64), lds, st, A);
+                if (A.virial) hipLaunchKernelGGL((k_eval<true, true>), dim3((unsigned)((atom_end - atom_begin + 7) / 8 * 8)), dim3(64), lds, st, A);
+                else hipLaunchKernelGGL((k_eval<true, false>), dim3((unsigned)((atom_end - atom_begin + 7) / 8 * 8)), dim3(64), lds, st, A);
             // (one workgroup per frame and component: wide for big frames, the loop is a latency chain)
             const int sum_threads = P.natoms / P.n_frames >= 2048 ? 1024 : 256;
             hipLaunchKernelGGL(k_frame_sum, dim3(P.n_frames, d_virials ? 7 : 1), dim3(sum_threads), 0, st, A.e_atom,

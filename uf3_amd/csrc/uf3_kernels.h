@@ -11,7 +11,7 @@
 //                     MODE 6 / 7  3-body windows of <= 32 rows on the fp64 matrix cores (7: three waves / SIMD)
 //                     MODE 8 / 9  ... of <= 64 / <= 128 rows
 //                     MODE 1-5    generic output-stationary 3-body kernels (wider windows)
-//   k_eval<GATHER>    energy + forces (+ virial) of a fitted model        one wave / atom: every triplet once at its
+//   k_eval<GATHER, VIR>   energy + forces (+ virial) of a fitted model        one wave / atom: every triplet once at its
 //                     centre + k_eval_collect (whole batch), or gathered at its three atoms (a block of atoms)
 //   k_frame_sum       per-frame sums of the per-atom energies / virial shares
 //   k_gram_tiled / k_gram_mfma   X^T X on the fp64 matrix cores, X^T y riding along in the diagonal workgroups / waves
@@ -1788,7 +1788,7 @@ __device__ __forceinline__ double wave_sum(double v) {
 #ifndef EVAL_MINW
 #define EVAL_MINW 3
 #endif
-template <bool GATHER>
+template <bool GATHER, bool VIR>
 __global__ void __launch_bounds__(64, EVAL_MINW)
 k_eval(EvalArgs A) {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -1813,7 +1813,7 @@ k_eval(EvalArgs A) {
     int lane = lane_id();
     const FrameGeom g = A.geoms[A.frame_of[m]];
     const int sm = A.spec[m];
-    const bool want_f = A.forces != nullptr, want_v = A.virial != nullptr;
+    const bool want_f = A.forces != nullptr, want_v = VIR && A.virial != nullptr;   // (VIR: compiled out of the usual launches)
     double vir[6] = {0, 0, 0, 0, 0, 0};
     double pm[3] = {A.pos[3 * (size_t)m], A.pos[3 * (size_t)m + 1], A.pos[3 * (size_t)m + 2]};
     double e = 0.0, fx = 0.0, fy = 0.0, fz = 0.0;
