@@ -27,6 +27,11 @@ Extra objects on the JSON line:
                 fp64 issue ("mfma" in the contract's vocabulary), not by HBM, at these F.  `traffic` comes from the
                 committed PMC passes of the same command (profiles/), labelled as such.
   cpu_baseline  the oracle (oracle/uf3_oracle.c, "port") timed on rank 0 on frames of the same workload.
+  extra         (N = 1, default mode only; measured AFTER the headline's timed region) one sub-line per other BASELINE
+                configuration, each with ms_per_step and its own roofline: fit_w (config 4: W, F = 73, featurize + X^T X /
+                X^T y), fit_c4 (the same at F = 434), lead0 (F = 1798: the bandwidth-heavier featurize case), eval_50k
+                (config 5: ternary 50k-atom frame, uf3_eval_dev loop, with the oracle's evaluator as cpu_baseline) and
+                eval_128 (latency of one 128-atom UFCalculator call).  --no-extra skips them.
 """
 import argparse
 import ctypes as C
@@ -58,6 +63,7 @@ def main():
                     help="c4 = W/Mo notebook basis F=434 (featurize default); w = W only, F=73 (fit default); "
                          "lead0 = W/Mo without leading trim, F=1798 (bandwidth-heavier)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the sub-lines of the other BASELINE configurations")
     args = ap.parse_args()
 
     import torch
@@ -259,10 +265,227 @@ def main():
                                sharding=(f"frames x{world}, no data-path collective" if not fit else
                                          f"frames x{world}, one all_reduce(SUM) of 2F'^2+2F'+6 doubles at the end")),
                    roofline=roofline, cpu_baseline=cpu)
+        if world == 1 and not fit and wl == "c4" and args.atoms == 10000 and not args.no_extra:
+            out["extra"] = extra_lines(dev, ctx, fz, frames, batch, d_pos, d_z, d_xe, d_xf,
+                                       cpu=not args.no_cpu_baseline)
         print(json.dumps(out), flush=True)
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# sub-lines of the other BASELINE configurations (rank 0, N = 1, after the headline)
+# ---------------------------------------------------------------------------------------------------------------
+PAIRS_PER_ATOM, TRIPLETS_PER_ATOM = 58.0, 91.0        # realised on the rattled bcc cells
+PEAK_FP64_TF, PEAK_HBM_GBS = 78.6, 8000.0
+
+
+def _featurizer_flops(n_atoms):
+    """~100 flop per directed pair, ~3.1 kflop per triplet"""
+    return n_atoms * (100.0 * PAIRS_PER_ATOM + 3100.0 * TRIPLETS_PER_ATOM)
+
+
+def _roof(flops, bytes_, seconds, bound, **more):
+    tf, gbs = flops / seconds / 1e12, bytes_ / seconds / 1e9
+    main = (dict(bound="mfma", achieved=round(tf, 3), peak=PEAK_FP64_TF, unit="TFLOP/s", frac=round(tf / PEAK_FP64_TF, 5))
+            if bound == "mfma" else
+            dict(bound="hbm", achieved=round(gbs, 2), peak=PEAK_HBM_GBS, unit="GB/s", frac=round(gbs / PEAK_HBM_GBS, 5)))
+    main.update(fp64=dict(achieved=round(tf, 3), peak=PEAK_FP64_TF, unit="TFLOP/s", frac=round(tf / PEAK_FP64_TF, 5),
+                          algorithmic_flops_per_step=flops),
+                hbm=dict(achieved=round(gbs, 2), peak=PEAK_HBM_GBS, unit="GB/s", frac=round(gbs / PEAK_HBM_GBS, 5),
+                         algorithmic_bytes_per_step=bytes_), traffic=None)
+    main.update(more)
+    return main
+
+
+def _timed(torch, dev, ctx, step, steps, warmup):
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize(dev)
+    ctx.synchronize()
+    ctx.timing_reset(True)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize(dev)
+    dt = (time.perf_counter() - t0) / steps
+    timing = ctx.timing_read()
+    ctx.timing_reset(False)
+    return dt, {k: v / steps for k, v in timing.items()}
+
+
+def extra_fit(torch, dev, basis, frames, batch, d_pos, d_z, d_xe, d_xf, steps=5, warmup=2):
+    """BASELINE config 4 on one GPU: featurize a batch into HBM rows + X^T X / X^T y of energy and force rows (+ the packed,
+    frozen-folded pieces once at the end, as `bench.py --mode fit` does)."""
+    from uf3_amd import pipeline
+    from uf3_amd.regression import least_squares as ls
+    from uf3_amd.representation import process
+    fz = process.BasisFeaturizer(basis, device=dev.index)
+    ctx, db = fz._dev()
+    F, B, n_atoms = db.n_feat, batch.n_frames, len(frames[0])
+    model = ls.WeightedLinearModel(basis, regularizer=basis.get_regularization_matrix(
+        ridge_1b=1e-8, ridge_2b=0.0, ridge_3b=1e-8, curvature_2b=1e-8, curvature_3b=0.0))
+    acc = pipeline.DeviceFitAccumulator(model, fz, with_forces=True)
+    g = torch.Generator(device=dev).manual_seed(7)
+    d_counts = torch.from_numpy(np.diff(batch.offsets).astype(np.float64)).to(dev)
+    d_ye = torch.randn((B,), dtype=torch.float64, device=dev, generator=g)
+    d_yf = torch.randn((3 * batch.n_atoms,), dtype=torch.float64, device=dev, generator=g)
+    xe, xf = d_xe.view(-1)[:B * F].view(B, F), d_xf.view(-1)[:3 * batch.n_atoms * F].view(batch.n_atoms, 3, F)
+
+    def step():
+        acc.add_device_batch(batch.struct, B, batch.n_atoms, d_pos, d_z, d_counts, d_ye, d_yf, x_e=xe, x_f=xf)
+
+    dt, t = _timed(torch, dev, ctx, step, steps, warmup)
+    flat = acc.packed()
+    assert bool(torch.isfinite(flat).all())
+    n_keep = int(acc._keep.numel())
+    tiles = (n_keep + 15) // 16
+    # executed Gram flops: the 16 x 16 tiles of the upper triangle (the kernels skip the lower one), force + energy rows
+    gram_tri = 2.0 * (3 * n_atoms + 1) * 256.0 * (tiles * (tiles + 1) / 2) * B
+    gram_full = 2.0 * (3 * n_atoms + 1) * n_keep * n_keep * B
+    flops = _featurizer_flops(n_atoms) * B + gram_tri
+    bytes_ = (52 * n_atoms + 75) * B                               # fused-Gram mode (SURVEY 8d): inputs + targets
+    return dict(metric="fitted frames/sec (featurize + X^T X / X^T y accumulate)", value=round(B / dt, 2), unit="frames/s",
+                ms_per_step=round(dt * 1e3, 4), steps=steps, frames_per_step=B, atoms_per_frame=n_atoms, n_feat=F,
+                n_unfrozen_columns=n_keep,
+                roofline=_roof(flops, bytes_, dt, "mfma", featurize_ms_per_step=round(t["featurize_ms"], 4),
+                               gram_ms_per_step=round(t["gram_ms"], 4),
+                               gram_tflops_executed_triangle=round(gram_tri / max(t["gram_ms"], 1e-9) / 1e9, 3),
+                               gram_flops_full_matrix=gram_full,
+                               note="fp64 flops = featurizer (SURVEY 8d) + the upper-triangle tiles the Gram kernels execute; "
+                                    "hbm = SURVEY 8d's fused-Gram bytes (52 N per frame), information only: the rows "
+                                    "themselves stay in HBM between the two kernels"))
+
+
+def extra_lead0(torch, dev, frames, d_xf, steps=5, warmup=2):
+    """the bandwidth-heavier featurize case: W/Mo without the leading 3-body trim, F = 1798 (432 MB of rows per frame)"""
+    from uf3_amd import _lib, synthetic
+    from uf3_amd.representation import process
+    basis = synthetic.notebook_basis(['Mo', 'W'], lead3=0)
+    fz = process.BasisFeaturizer(basis, device=dev.index)
+    ctx, db = fz._dev()
+    B = 8
+    batch = _lib.FrameBatch(frames[:B])
+    F, n_atoms = db.n_feat, len(frames[0])
+    d_pos = torch.from_numpy(batch.pos).to(dev)
+    d_z = torch.from_numpy(batch.z).to(dev)
+    xe = torch.empty((B, F), dtype=torch.float64, device=dev)
+    xf = d_xf.view(-1)[:3 * batch.n_atoms * F].view(batch.n_atoms, 3, F)       # (13.4 GB buffer of the headline: 10.4 GB used)
+
+    def step():
+        fz.featurize_device(batch.struct, d_pos.data_ptr(), d_z.data_ptr(), xe.data_ptr(), xf.data_ptr())
+
+    dt, t = _timed(torch, dev, ctx, step, steps, warmup)
+    s = xf[:n_atoms].sum(dim=0).abs().max().item()
+    assert np.isfinite(s) and s < 1e-6 * xf[:n_atoms].abs().max().item(), s           # translation invariance of the rows
+    bytes_ = synthetic.algorithmic_bytes(n_atoms, F) * B
+    return dict(metric="featurized frames/sec (10k-atom, 2-elem, 2+3-body, no leading trim)", value=round(B / dt, 2),
+                unit="frames/s", ms_per_step=round(dt * 1e3, 4), steps=steps, frames_per_step=B, atoms_per_frame=n_atoms,
+                n_feat=F, roofline=_roof(_featurizer_flops(n_atoms) * B, bytes_, dt, "hbm",
+                                         featurize_ms_per_step=round(t["featurize_ms"], 4),
+                                         note="6.7 flop/B: the one workload SURVEY 8d calls HBM-bound on paper"))
+
+
+def _random_model(basis, seed):
+    from uf3_amd.forcefield import calculator
+    from uf3_amd.regression import least_squares as ls
+    model = ls.WeightedLinearModel(basis)
+    coeff = np.random.default_rng(seed).normal(0, 0.05, basis.n_feats)
+    coeff[basis.col_idx] = 0.0
+    model.coefficients = coeff
+    return model, calculator.UFCalculator(model)
+
+
+def extra_eval_50k(torch, dev, cpu=True, steps=20, warmup=3):
+    """BASELINE config 5 on one GPU: energy + forces of a 50 000-atom ternary frame per step (uf3_eval_dev, inputs and outputs in HBM)"""
+    from uf3_amd import _lib, synthetic
+    basis = synthetic.notebook_basis(['V', 'Mo', 'W'])
+    atoms = synthetic.lattice_frame("bcc", (25, 25, 40), 3.165, [23, 42, 74], 4000)
+    model, calc = _random_model(basis, 11)
+    ctx = _lib.get_context(dev.index)
+    db = _lib.device_basis(basis, ctx)
+    batch = _lib.FrameBatch([atoms])
+    n = batch.n_atoms
+    d_pos = torch.from_numpy(batch.pos).to(dev)
+    d_z = torch.from_numpy(batch.z).to(dev)
+    d_e = torch.empty((1,), dtype=torch.float64, device=dev)
+    d_f = torch.empty((n, 3), dtype=torch.float64, device=dev)
+
+    def step():
+        ctx.check(ctx.lib.uf3_eval_dev(db.handle, C.byref(batch.struct), C.c_void_p(d_pos.data_ptr()),
+                                       C.c_void_p(d_z.data_ptr()), _lib._p(calc._c1), _lib._p(calc._c2), _lib._p(calc._c3),
+                                       C.c_void_p(d_e.data_ptr()), C.c_void_p(d_f.data_ptr())))
+
+    dt, t = _timed(torch, dev, ctx, step, steps, warmup)
+    f = d_f.cpu().numpy()
+    out = dict(metric="evaluated atom-steps/sec (50k-atom ternary frame, energy + forces)", value=round(n / dt), unit="atom-steps/s",
+               ms_per_step=round(dt * 1e3, 4), steps=steps, atoms_per_frame=n, n_feat=int(basis.n_feats),
+               roofline=_roof(n * (100.0 * PAIRS_PER_ATOM + 700.0 * TRIPLETS_PER_ATOM), 52.0 * n + 75 + 8.0 * len(calc._c3), dt, "mfma",
+                              eval_kernels_ms_per_step=round(t["eval_ms"], 4), neighbor_ms_per_step=round(t["neighbor_ms"], 4),
+                              note="flops = N (100 p + 700 T): every triplet once at its centre (3 legs x ~60 + 64-term "
+                                   "contraction with value and 3 partials ~450 + forces); bytes = 52 N + the coefficient grids"))
+    if cpu:
+        from oracle import oracle as O
+        ob = O.OracleBasis(basis)
+        t0 = time.perf_counter()
+        ref = O.evaluate(ob, atoms, model.coefficients)
+        dt_cpu = time.perf_counter() - t0
+        e_ref, f_ref = ref[0], ref[1]
+        err = max(abs(float(d_e.item()) - e_ref) / abs(e_ref), np.abs(f - f_ref).max() / np.abs(f_ref).max())
+        assert err < 1e-9, err
+        out["cpu_baseline"] = dict(value=round(n / dt_cpu), unit="atom-steps/s", cores=1, kind="port",
+                                   sample=f"the same frame once through oracle/uf3_oracle.c's evaluator, single thread, "
+                                          f"{dt_cpu:.1f} s; GPU energy / forces matched to {err:.1e}")
+    return out
+
+
+def extra_eval_128(calls=300):
+    """latency of one MD-step call on a small cell: UFCalculator.evaluate_frames (host arrays in and out), 128-atom W frame"""
+    from uf3_amd import synthetic
+    basis = synthetic.notebook_basis(['W'])
+    atoms = synthetic.lattice_frame("bcc", (4, 4, 4), 3.165, [74], seed=3)
+    _, calc = _random_model(basis, 1)
+    for _ in range(10):
+        calc.evaluate_frames([atoms])
+    t0 = time.perf_counter()
+    for _ in range(calls):
+        calc.evaluate_frames([atoms])
+    dt = (time.perf_counter() - t0) / calls
+    n = len(atoms)
+    return dict(metric="latency of one energy + force call (128-atom W frame, host arrays in and out)", value=round(dt * 1e6, 2),
+                unit="us/call", higher_is_better=False, ms_per_step=round(dt * 1e3, 5), steps=calls, atoms_per_frame=n,
+                roofline=_roof(n * (100.0 * PAIRS_PER_ATOM + 700.0 * TRIPLETS_PER_ATOM), 52.0 * n + 75, dt, "mfma",
+                               note="launch / latency bound: one dependent chain upload -> cell list -> evaluation -> download"))
+
+
+def extra_lines(dev, ctx, fz, frames, batch, d_pos, d_z, d_xe, d_xf, cpu=True):
+    import torch
+    from uf3_amd import _lib, synthetic
+    out = {}
+
+    def guarded(name, fn):
+        t0 = time.perf_counter()
+        try:
+            out[name] = fn()
+        except Exception as exc:  # noqa: BLE001 - a failing sub-line must not take the headline with it
+            out[name] = dict(error=f"{type(exc).__name__}: {exc}"[:300])
+        out[name]["wall_s"] = round(time.perf_counter() - t0, 2)
+        ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+
+    guarded("fit_c4", lambda: extra_fit(torch, dev, fz.bspline_config, frames, batch, d_pos, d_z, d_xe, d_xf))
+
+    def fit_w():
+        frames_w = [synthetic.lattice_frame("bcc", (10, 20, 25), 3.165, [74], 3000 + k) for k in range(len(frames))]
+        batch_w = _lib.FrameBatch(frames_w)
+        pos_w, z_w = torch.from_numpy(batch_w.pos).to(dev), torch.from_numpy(batch_w.z).to(dev)
+        return extra_fit(torch, dev, synthetic.notebook_basis(['W']), frames_w, batch_w, pos_w, z_w, d_xe, d_xf)
+
+    guarded("fit_w", fit_w)
+    guarded("lead0", lambda: extra_lead0(torch, dev, frames, d_xf))
+    guarded("eval_50k", lambda: extra_eval_50k(torch, dev, cpu=cpu))
+    guarded("eval_128", extra_eval_128)
     return out
 
 

@@ -50,3 +50,14 @@ FEATURE_CASES = ["case_steel", "case_h2o", "case_h2o_lead0", "case_ch4", "case_c
 def rel_err(a, b):
     a, b = np.asarray(a, float), np.asarray(b, float)
     return float(np.abs(a - b).max() / max(1.0, np.abs(b).max())) if a.size else 0.0
+
+
+def worst_elementwise(a, b, rtol=1e-9, floor=1e-12):
+    """north_star's "within 1e-6 relative", literally: max over entries of |a - b| / (rtol |b| + floor max|b|); <= 1 passes.
+    Every entry is held to ``rtol`` of ITS OWN magnitude; ``floor`` (relative to the largest entry) only covers entries that
+    are sums of cancelling terms around zero.  (``rel_err`` above is the max-norm and lets small columns hide behind large
+    ones.)"""
+    a, b = np.asarray(a, float), np.asarray(b, float)
+    if not a.size:
+        return 0.0
+    return float((np.abs(a - b) / (rtol * np.abs(b) + floor * max(np.abs(b).max(), 1e-300))).max())

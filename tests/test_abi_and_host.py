@@ -97,3 +97,39 @@ def test_unknown_element_warns_and_returns_empty():
     other = Atoms("Ar2", positions=[[0, 0, 0], [3, 0, 0]])
     with pytest.warns(RuntimeWarning):
         assert fz.evaluate_configuration(other, energy=1.0) == {}
+
+
+def test_supercell_argument_accepts_lattice_tilings_only():
+    """``featurize_*(geom, supercell)``: the reference takes any supercell; features only depend on it through the images
+    inside the cut-off, so every tiling by whole lattice images covering ``r_cut`` is accepted (larger r_cut, sorted
+    images), anything else is refused (host logic, no GPU involved)."""
+    import numpy as np
+    import pytest
+    from uf3_amd import synthetic
+    from uf3_amd.data import geometry
+    from uf3_amd.data.atoms import Atoms
+    from uf3_amd.representation import process
+    atoms = synthetic.lattice_frame("bcc", (2, 2, 2), 3.165, [74], seed=4)
+    fz = process.BasisFeaturizer(synthetic.notebook_basis(['W']))
+    check = fz._supercell_means_periodic
+    assert check(atoms, None) is False and check(atoms, atoms) is False and check(atoms, atoms.copy()) is False
+    ref = geometry.get_supercell(atoms, r_cut=fz.r_cut)
+    assert check(atoms, ref) is None
+    assert check(atoms, geometry.get_supercell(atoms)) is None                                  # r_cut = 10
+    assert check(atoms, geometry.get_supercell(atoms, r_cut=fz.r_cut, sort_indices=True)) is None
+    n = len(atoms)
+    with pytest.raises(ValueError):                                                              # too few images
+        check(atoms, Atoms(numbers=ref.get_atomic_numbers()[:5 * n], positions=ref.get_positions()[:5 * n]))
+    with pytest.raises(ValueError):
+        check(atoms, Atoms(numbers=ref.get_atomic_numbers()[:-1], positions=ref.get_positions()[:-1]))
+    moved = ref.get_positions().copy()
+    moved[len(atoms) + 3] += 0.01                                                                # not a rigid image
+    with pytest.raises(ValueError):
+        check(atoms, Atoms(numbers=ref.get_atomic_numbers(), positions=moved))
+    # atoms outside the cell: the reference's rows depend on the image range, so only its own range is accepted
+    pos = atoms.get_positions().copy()
+    pos[0] += np.array(atoms.get_cell())[0] * 1.5
+    out = Atoms(numbers=atoms.get_atomic_numbers(), positions=pos, cell=atoms.get_cell(), pbc=True)
+    assert check(out, geometry.get_supercell(out, r_cut=fz.r_cut)) is None
+    with pytest.raises(ValueError):
+        check(out, geometry.get_supercell(out, r_cut=3 * fz.r_cut))

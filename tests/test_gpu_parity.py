@@ -17,7 +17,7 @@ from uf3_amd.data.atoms import Atoms, read_extxyz
 from uf3_amd.forcefield import calculator
 from uf3_amd.regression import least_squares as ls
 from uf3_amd.representation import process
-from _util import GOLDEN, FEATURE_CASES, basis_from_meta, load_case, rel_err
+from _util import GOLDEN, FEATURE_CASES, basis_from_meta, load_case, rel_err, worst_elementwise
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-9
@@ -30,8 +30,10 @@ def test_feature_rows_against_reference_capture(name):
     fz = process.BasisFeaturizer(basis)
     x_e, x_f, _ = fz.featurize_frames([atoms], energy=True, forces="xf" in d)
     assert rel_err(x_e[0], d["xe"]) < TOL
+    assert worst_elementwise(x_e[0], d["xe"]) <= 1.0          # entry by entry, 1e-9 of each entry's own magnitude
     if "xf" in d:
         assert rel_err(x_f, d["xf"]) < TOL
+        assert worst_elementwise(x_f, d["xf"]) <= 1.0
     pairs, n3 = fz.neighbor_indices(atoms)
     for p, pair in enumerate(basis.interactions_map[2]):
         assert np.array_equal(pairs[pair], d[f"pair{p}_ij"])        # bit-exact neighbour indices
@@ -60,8 +62,16 @@ def test_reference_api_slices_and_evaluate_configuration():
     # no supercell (or the frame itself): an isolated cluster; anything else is refused, not reinterpreted
     cluster = fz.featurize_frames([atoms], periodic=False)[0][0, lo2:hi2]
     assert np.allclose(fz.featurize_energy_2B(atoms), cluster) and np.allclose(fz.featurize_energy_2B(atoms, atoms), cluster)
-    with pytest.raises(ValueError):
-        fz.featurize_energy_2B(atoms, geometry.get_supercell(atoms, r_cut=2 * basis.r_cut))
+    # any tiling by whole lattice images that covers the cut-off is the reference's supercell as far as the features go
+    # (get_supercell's default r_cut = 10, sort_indices=True); an arbitrary atom set is refused, not reinterpreted
+    for sup2 in (geometry.get_supercell(atoms, r_cut=2 * basis.r_cut), geometry.get_supercell(atoms),
+                 geometry.get_supercell(atoms, r_cut=basis.r_cut, sort_indices=True)):
+        assert np.allclose(fz.featurize_energy_2B(atoms, sup2), d["xe"][lo2:hi2])
+    assert np.allclose(fz.featurize_force_3B(atoms, geometry.get_supercell(atoms)), d["xf"][:, :, lo3:hi3])
+    with pytest.raises(ValueError):                                  # (too few images for the cut-off)
+        fz.featurize_energy_2B(atoms, Atoms(numbers=sup.get_atomic_numbers()[:3 * len(atoms)], positions=sup.get_positions()[:3 * len(atoms)]))
+    with pytest.raises(ValueError):                                  # (one atom short of whole images)
+        fz.featurize_energy_2B(atoms, Atoms(numbers=sup.get_atomic_numbers()[:-1], positions=sup.get_positions()[:-1]))
 
 
 def test_2body_force_feature_invariants():
@@ -222,6 +232,9 @@ def test_full_size_properties_10k_atoms():
     ref = O.featurize(O.OracleBasis(basis), atoms)
     assert rel_err(x_e[0], ref["xe"]) < TOL
     assert rel_err(x_f, ref["xf"].reshape(x_f.shape)) < TOL
+    # ... and entry by entry: each of the 13 M entries within 1e-9 of ITS OWN magnitude (small outer-shell columns included)
+    assert worst_elementwise(x_e[0], ref["xe"]) <= 1.0
+    assert worst_elementwise(x_f, ref["xf"].reshape(x_f.shape)) <= 1.0
 
 
 def test_unknown_species_raises():
@@ -396,6 +409,49 @@ def test_asynchronous_featurize_reports_a_capacity_overflow_afterwards():
     ref = O.featurize(O.OracleBasis(basis), dense[0])
     assert rel_err(x_e[0].cpu().numpy(), ref["xe"]) < TOL
     assert rel_err(x_f.cpu().numpy().reshape(ref["xf"].shape), ref["xf"]) < TOL
+
+
+def test_asynchronous_verdict_waits_for_the_synchronize_of_its_owner():
+    """A capacity overflow of an asynchronous call is reported by the next ``uf3_ctx_synchronize`` even when other entries
+    of the same context (a host-buffer featurize, an evaluator call) ran in between and met the verdict first."""
+    import ctypes as C
+    import torch
+    dev = torch.device("cuda", 0)
+    ctx = _lib.Context(0)
+    basis = synthetic.notebook_basis(['W'])
+    db = _lib.DeviceBasis(basis, ctx)
+    ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+    keep = []
+
+    def run_async(frames):
+        batch = _lib.FrameBatch(frames)
+        d_pos, d_z = torch.from_numpy(batch.pos).to(dev), torch.from_numpy(batch.z).to(dev)
+        x_f = torch.empty((batch.n_atoms, 3, db.n_feat), dtype=torch.float64, device=dev)
+        keep.append((batch, d_pos, d_z, x_f))
+        ctx.check(ctx.lib.uf3_featurize_dev(db.handle, C.byref(batch.struct), C.c_void_p(d_pos.data_ptr()),
+                                            C.c_void_p(d_z.data_ptr()), None, C.c_void_p(x_f.data_ptr())))
+
+    def run_host(frames):
+        batch = _lib.FrameBatch(frames)
+        x_e = np.empty((batch.n_frames, db.n_feat))
+        ctx.check(ctx.lib.uf3_featurize(db.handle, C.byref(batch.struct), _lib._p(batch.pos), _lib._p(batch.z), _lib._p(x_e), None))
+        return x_e
+
+    sparse = [synthetic.lattice_frame("bcc", (4, 4, 4), 3.165, [74], 90 + k) for k in range(2)]
+    dense = [synthetic.lattice_frame("bcc", (5, 5, 5), 2.4, [74], 95, rattle=0.05)]
+    run_async(sparse); ctx.synchronize()
+    run_async(sparse); ctx.synchronize()
+    run_async(dense)                                        # asynchronous, lists too short: its rows are invalid
+    torch.cuda.synchronize(dev)
+    x_e = run_host(sparse)                                  # an unrelated synchronous call meets the verdict first ...
+    ref = O.featurize(O.OracleBasis(basis), sparse[0], forces=False)
+    assert rel_err(x_e[0], ref["xe"]) < TOL                 # ... and is not disturbed by it
+    with pytest.raises(_lib.RetryError):                    # the owner still learns about it
+        ctx.synchronize()
+    ctx.synchronize()                                       # reported once
+    run_async(dense); ctx.synchronize()                     # capacities were raised: now it fits
+    ref = O.featurize(O.OracleBasis(basis), dense[0])
+    assert rel_err(keep[-1][3].cpu().numpy().reshape(ref["xf"].shape), ref["xf"]) < TOL
 
 
 def test_device_entries_follow_the_callers_stream():
@@ -646,7 +702,15 @@ def test_atom_range_shares_add_up_to_the_frame():
     calc = calculator.UFCalculator(model)
     e, f, _, v = calc.evaluate_frames([atoms], virial=True)
     n, world = len(atoms), 3
+    assert n == 420
     shares = [calc.evaluate_atom_range(atoms, *parallel.shard_range(n, r, world), virial=True) for r in range(world)]
+    # the shares against the ORACLE's evaluator directly (not only against the product's other route)
+    e_ref, f_ref = O.evaluate(O.OracleBasis(basis), atoms, coeff)
+    assert abs(sum(s[0] for s in shares) - e_ref) <= 1e-10 * abs(e_ref)
+    assert rel_err(sum(s[1] for s in shares), f_ref) < 1e-10 and worst_elementwise(sum(s[1] for s in shares), f_ref) <= 1.0
+    for r, (_, fs, _) in enumerate(shares):
+        lo, hi = parallel.shard_range(n, r, world)
+        assert rel_err(fs[lo:hi], f_ref[lo:hi]) < 1e-10
     assert abs(sum(s[0] for s in shares) - e[0]) <= 1e-12 * abs(e[0])
     assert rel_err(sum(s[2] for s in shares), v[0]) < 1e-12
     for r, (_, fs, _) in enumerate(shares):

@@ -57,14 +57,15 @@ struct uf3_ctx {
     Buf geoms, offsets, frame_of, atom_bin, atom_wrap, spec, key_in, key_out, val_in, val_out, sort_tmp,
         bin_start, slots, flags,
         n3_cnt, n3_int, n3_dbl, e_atom, nbr_f, coeff, stage_pos, stage_z, stage_out, stage_out2,
-        gram_tiles, frag, dbg,
+        gram_tiles, gram_tij, frag, dbg,
         halo,                           // marks + index list of the halo atoms of a decomposed frame
         n3x_ent, n3x_off,               // extension lists (batches with atoms outside their cell; see N3Lists)
         bin_cnt;                        // atoms per cell-list bin (counting sort)
     int n3_cap = 0, cand_cap = 0;
     int n3x_cap = 0;                 // capacity of the extension lists (0 until a batch needed them)
     bool img_mode = false;           // a batch with atoms far outside their cell has been seen: 3-body launches with the image-range rule
-    int gram_plan_feat = -1, gram_plan_blocks = 0;   // workgroup plan of k_gram_tiled held in gram_tiles (for this n_feat)
+    int gram_plan_feat = 0, gram_plan_blocks = 0;    // workgroup plan of k_gram_tiled held in gram_tiles (for this n_feat; 0: none)
+    int gram_direct_feat = 0;                        // tile-pair table of k_gram_mfma held in gram_tij (for this n_feat; 0: none)
     bool n3_tuned = false;           // capacity re-sized once to the lists actually seen
     bool cand_tuned = false;         // a featurizer call has completed with the current candidate capacity
     // status words of asynchronous featurizer calls: copied to pinned slots behind the launches, looked at later
@@ -73,6 +74,11 @@ struct uf3_ctx {
     Pending pending_chk[N_PENDING];
     PinBuf pin_flags;                // [N_PENDING][8] ints
     int pending_head = 0;
+    // A bad verdict on an asynchronous call belongs to whoever synchronises the context next, not to whichever entry happens to
+    // poll first: it is remembered here until uf3_ctx_synchronize has reported it (the entries that meet it on the way still
+    // return it once, so an asynchronous loop stops early).
+    int async_bad = 0;
+    std::string async_msg;
     bool frag_ready = false;
     int32_t *d_stage_z = nullptr;       // species of the staged batch (tail of stage_pos)
     size_t pin_in_pending = 0;          // small batch: bytes of positions | species waiting in pin_in; the cell-list
@@ -158,7 +164,7 @@ extern "C" void uf3_ctx_destroy(uf3_ctx *c) {
     hipStreamSynchronize(c->stream);
     Buf *all[] = {&c->geoms, &c->offsets, &c->frame_of, &c->atom_bin, &c->atom_wrap, &c->spec, &c->key_in,
                   &c->key_out, &c->val_in, &c->val_out, &c->sort_tmp, &c->bin_start, &c->slots, &c->flags, &c->n3_cnt, &c->n3_int, &c->n3_dbl, &c->e_atom, &c->nbr_f, &c->coeff,
-                  &c->stage_pos, &c->stage_z, &c->stage_out, &c->stage_out2, &c->gram_tiles, &c->frag, &c->dbg, &c->halo, &c->n3x_ent, &c->n3x_off, &c->bin_cnt};
+                  &c->stage_pos, &c->stage_z, &c->stage_out, &c->stage_out2, &c->gram_tiles, &c->gram_tij, &c->frag, &c->dbg, &c->halo, &c->n3x_ent, &c->n3x_off, &c->bin_cnt};
     for (Buf *b : all) b->release();
     c->pin_in.release(); c->pin_geo.release(); c->pin_out.release(); c->pin_flags.release();
     for (auto &pd : c->pending_chk) if (pd.ev) hipEventDestroy(pd.ev);
@@ -182,13 +188,27 @@ extern "C" int uf3_ctx_use_own_stream(uf3_ctx *c) {
 }
 
 static int check_flags(uf3_ctx *c);
-static int poll_pending(uf3_ctx *c, bool wait);
+static int poll_pending(uf3_ctx *c, bool wait, bool remember = true);
 
 extern "C" int uf3_ctx_synchronize(uf3_ctx *c) {
     if (!c) return fail(nullptr, UF3_EINVAL, "null ctx");
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    int rc = poll_pending(c, true);
+    poll_pending(c, true);                           // (whatever it finds is remembered in async_bad)
+    if (c->async_bad) {
+        const int rc = c->async_bad;
+        const std::string msg = c->async_msg;
+        c->async_bad = 0; c->async_msg.clear();
+        return fail(c, rc, msg);
+    }
+    return check_flags(c);
+}
+
+// what the synchronous host entries do at their end: wait for the stream and look at the verdict of THEIR OWN call (verdicts on
+// earlier asynchronous calls were drained into async_bad before the call started and stay there for uf3_ctx_synchronize)
+static int sync_own_call(uf3_ctx *c) {
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    int rc = poll_pending(c, true, false);
     if (rc) return rc;
     return check_flags(c);
 }
@@ -610,7 +630,7 @@ static int check_flags(uf3_ctx *c) {
 
 // Status words of earlier asynchronous featurizer calls (error flag | 3-body list length needed | candidates needed).
 // wait = false: only the slots whose copy has completed are looked at.  Returns the first problem found, once.
-static int poll_pending(uf3_ctx *c, bool wait) {
+static int poll_pending(uf3_ctx *c, bool wait, bool remember) {
     int rc = UF3_OK;
     for (int q = 0; q < uf3_ctx::N_PENDING; q++) {
         uf3_ctx::Pending &p = c->pending_chk[(c->pending_head + q) % uf3_ctx::N_PENDING];
@@ -622,8 +642,9 @@ static int poll_pending(uf3_ctx *c, bool wait) {
         if (fl[0] == 2 && !rc) rc = fail(c, UF3_ESPECIES, "frame contains an element outside the basis (earlier asynchronous call)");
         else if (fl[0] == 1 && !rc) rc = fail(c, UF3_EINVAL, "atom too far outside the periodic cell (|wrap| > 250) (earlier asynchronous call)");
         bool grown = false;
-        if (p.has3 && fl[1] > p.cap) { c->n3_cap = std::max(c->n3_cap, (fl[1] + 8 + 7) / 8 * 8); grown = true; }
-        if (fl[2] > p.cand) { c->cand_cap = std::max(c->cand_cap, (fl[2] + 16 + 7) / 8 * 8); grown = true; }
+        // (with headroom: a data set ordered by increasing density would otherwise overflow chunk after chunk)
+        if (p.has3 && fl[1] > p.cap) { c->n3_cap = std::max(c->n3_cap, (std::max(fl[1] + 8, p.cap + p.cap / 4) + 7) / 8 * 8); grown = true; }
+        if (fl[2] > p.cand) { c->cand_cap = std::max(c->cand_cap, (std::max(fl[2] + 16, p.cand + p.cand / 4) + 7) / 8 * 8); grown = true; }
         if (fl[3] > p.xcap) { c->n3x_cap = std::max(c->n3x_cap, std::min(248, (fl[3] + 8 + 7) / 8 * 8)); grown = true; }
         if (fl[4] && !p.img) { c->img_mode = true; grown = true; }      // (its 3-body launches left without writing rows)
         else if (!fl[4] && p.img_launch) c->img_mode = false;            // back to the ordinary launches
@@ -632,6 +653,7 @@ static int poll_pending(uf3_ctx *c, bool wait) {
                                      "invalid; the capacities have been raised, repeat the work since the last synchronisation");
     }
     if (rc && c->flags.p) hipMemsetAsync(c->flags.p, 0, sizeof(int), c->stream);
+    if (rc && remember && !c->async_bad) { c->async_bad = rc; c->async_msg = c->err; }
     return rc;
 }
 
@@ -1088,6 +1110,7 @@ extern "C" int uf3_featurize(uf3_basis *b, const uf3_frames *fr, const double *p
     if (!b) return fail(nullptr, UF3_EINVAL, "null basis");
     uf3_ctx *c = b->ctx;
     int natoms = 0;
+    poll_pending(c, true);                   // verdicts on earlier asynchronous calls: remembered for uf3_ctx_synchronize, not ours
     int rc = upload_frames(c, fr, pos, z, natoms);
     if (rc) return rc;
     size_t F = (size_t)b->host.F;
@@ -1097,11 +1120,10 @@ extern "C" int uf3_featurize(uf3_basis *b, const uf3_frames *fr, const double *p
     for (int attempt = 0; attempt < 6; attempt++) {
         rc = uf3_featurize_dev(b, fr, c->stage_pos.as<double>(), c->d_stage_z,
                                be ? c->stage_out.as<double>() : nullptr, bf ? c->stage_out2.as<double>() : nullptr);
-        if (rc == UF3_ERETRY) continue;      // (verdict on an EARLIER asynchronous call: this one has not run)
         if (rc) return rc;
         if (be) HIPCHK(c, hipMemcpyAsync(xe, c->stage_out.p, be, hipMemcpyDeviceToHost, c->stream));
         if (bf) HIPCHK(c, hipMemcpyAsync(xf, c->stage_out2.p, bf, hipMemcpyDeviceToHost, c->stream));
-        rc = uf3_ctx_synchronize(c);
+        rc = sync_own_call(c);
         if (rc != UF3_ERETRY) return rc;     // the lists of this very call overflowed: repeat it with the raised capacities
     }
     return fail(c, UF3_EOVERFLOW, "neighbour capacities did not converge");
@@ -1119,6 +1141,8 @@ static int eval_impl(uf3_basis *b, const uf3_frames *fr, const double *d_pos, co
     // Two-pass route, list capacity known: the centre pass builds each atom's 3-body list from the candidates of
     // its own pair walk (no k_build_n3 launch, one neighbourhood scan less).
     const int64_t total = (fr && fr->atom_offsets && fr->n_frames >= 1) ? fr->atom_offsets[fr->n_frames] : -1;
+    if (total >= 0 && (atom_begin < 0 || (atom_end >= 0 && (atom_begin > atom_end || atom_end > total))))
+        return fail(c, UF3_EINVAL, "uf3_eval_atoms: atom range outside the batch");
     const bool whole = atom_begin == 0 && (atom_end < 0 || atom_end == total);
     const bool two_pass = whole && d_forces && b->host.T > 0 && !getenv("UF3_EVAL_GATHER");
     const bool fuse = two_pass && c->n3_tuned && c->n3_cap > 0 && !getenv("UF3_SEPARATE_N3");
@@ -1180,9 +1204,10 @@ static int eval_impl(uf3_basis *b, const uf3_frames *fr, const double *d_pos, co
                 else hipLaunchKernelGGL((k_eval<false, false>), dim3((unsigned)((P.natoms + 7) / 8 * 8)), dim3(64), lds, st, A);
                 if (fuse && deferred_cap) *deferred_cap = (int)cap;
                 hipLaunchKernelGGL(k_eval_collect, dim3((unsigned)(((P.natoms + 15) / 16 + 7) / 8 * 8)), dim3(256), 0, st, A);
-            } else if (atom_end > atom_begin)
+            } else if (atom_end > atom_begin) {
                 if (A.virial) hipLaunchKernelGGL((k_eval<true, true>), dim3((unsigned)((atom_end - atom_begin + 7) / 8 * 8)), dim3(64), lds, st, A);
                 else hipLaunchKernelGGL((k_eval<true, false>), dim3((unsigned)((atom_end - atom_begin + 7) / 8 * 8)), dim3(64), lds, st, A);
+            }
             // (one workgroup per frame and component: wide for big frames, the loop is a latency chain)
             const int sum_threads = P.natoms / P.n_frames >= 2048 ? 1024 : 256;
             hipLaunchKernelGGL(k_frame_sum, dim3(P.n_frames, d_virials ? 7 : 1), dim3(sum_threads), 0, st, A.e_atom,
@@ -1226,6 +1251,7 @@ static int eval_host(uf3_basis *b, const uf3_frames *fr, const double *pos, cons
     uf3_ctx *c = b->ctx;
     if (!energies) return fail(c, UF3_EINVAL, "uf3_eval: null energies");
     int natoms = 0;
+    poll_pending(c, false);                  // (arrived verdicts on asynchronous featurizer calls: for uf3_ctx_synchronize, not for us)
     int rc = upload_frames(c, fr, pos, z, natoms, true);
     if (rc) return rc;
     // results in one block: energies [nf] | virials [nf][6] | forces [natoms][3]
@@ -1247,8 +1273,7 @@ static int eval_host(uf3_basis *b, const uf3_frames *fr, const double *pos, cons
             if (rc) return rc;
             HIPCHK(c, hipMemcpyAsync(c->pin_out.p, d_e, total + 16, hipMemcpyDeviceToHost, c->stream));
             HIPCHK(c, hipStreamSynchronize(c->stream));
-            rc = poll_pending(c, true);
-            if (rc) return rc;
+            poll_pending(c, true);           // (remembered, see above)
             {
                 const int *fl = (const int *)((const char *)c->pin_out.p + total);
                 if (fl[0]) return check_flags(c);
@@ -1268,7 +1293,9 @@ static int eval_host(uf3_basis *b, const uf3_frames *fr, const double *pos, cons
     HIPCHK(c, hipMemcpyAsync(energies, d_e, 8 * nf, hipMemcpyDeviceToHost, c->stream));
     if (virials) HIPCHK(c, hipMemcpyAsync(virials, d_v, 48 * nf, hipMemcpyDeviceToHost, c->stream));
     if (forces) HIPCHK(c, hipMemcpyAsync(forces, d_f, bf, hipMemcpyDeviceToHost, c->stream));
-    return uf3_ctx_synchronize(c);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    poll_pending(c, true);
+    return check_flags(c);
 }
 
 extern "C" int uf3_eval(uf3_basis *b, const uf3_frames *fr, const double *pos, const int32_t *z, const double *c1,
@@ -1389,6 +1416,7 @@ extern "C" int uf3_gram_dev(uf3_ctx *c, const double *dx, const double *dy, int6
             for (auto &g : open) plan.push_back(g);
             for (auto &g : plan)
                 for (int q = 0; q < 4; q++) if (g.range[q] < 0) g.range[q] = g.range[0];
+            c->gram_plan_feat = 0;
             HIPCHK(c, c->gram_tiles.ensure(sizeof(GramBlock) * plan.size()));
             HIPCHK(c, hipMemcpyAsync(c->gram_tiles.p, plan.data(), sizeof(GramBlock) * plan.size(), hipMemcpyHostToDevice, st));
             HIPCHK(c, hipStreamSynchronize(st));
@@ -1408,23 +1436,24 @@ extern "C" int uf3_gram_dev(uf3_ctx *c, const double *dx, const double *dy, int6
         HIPCHK(c, hipGetLastError());
         return UF3_OK;
     }
-    // tile-pair table of the direct kernel: built and uploaded when n_feat changes (the buffer is shared with the tiled
-    // kernel's plan; negative feature counts mark "holds the direct table for -n_feat")
+    // tile-pair table of the direct kernel: built and uploaded when n_feat changes (its own buffer and key: a fit that sends
+    // its energy rows here and its force rows to the tiled kernel keeps both plans)
     const int nt = (n_feat + 31) / 32;
     size_t np = (size_t)nt * (nt + 1) / 2;
     np = (np + 3) / 4 * 4;
-    if (c->gram_plan_feat != -n_feat) {
+    if (c->gram_direct_feat != n_feat) {
         std::vector<int> tij;
         for (int i = 0; i < nt; i++) for (int j = i; j < nt; j++) tij.push_back(i);
         while (tij.size() < np) tij.push_back(-1);
         for (int i = 0; i < nt; i++) for (int j = i; j < nt; j++) tij.push_back(j);
         while (tij.size() < 2 * np) tij.push_back(-1);
-        HIPCHK(c, c->gram_tiles.ensure(8 * np));
-        HIPCHK(c, hipMemcpyAsync(c->gram_tiles.p, tij.data(), 8 * np, hipMemcpyHostToDevice, st));
+        c->gram_direct_feat = 0;
+        HIPCHK(c, c->gram_tij.ensure(8 * np));
+        HIPCHK(c, hipMemcpyAsync(c->gram_tij.p, tij.data(), 8 * np, hipMemcpyHostToDevice, st));
         HIPCHK(c, hipStreamSynchronize(st));                           // (tij is a local)
-        c->gram_plan_feat = -n_feat;
+        c->gram_direct_feat = n_feat;
     }
-    int *d_ti = c->gram_tiles.as<int>(), *d_tj = d_ti + np;
+    int *d_ti = c->gram_tij.as<int>(), *d_tj = d_ti + np;
     // enough row chunks to fill the chip, each a multiple of 4 rows
     int blocks_xy = (int)(np / 4);
     int want_chunks = std::max(1, (c->n_cu * 8 + blocks_xy - 1) / blocks_xy);

@@ -87,14 +87,19 @@ def unpack_pieces(buf, n_cols, with_forces=True):
     return out
 
 
-def allreduce_packed(flat):
+def allreduce_packed(flat, force=None):
     """
     Sum a packed piece buffer (torch tensor, device or host) over all ranks of the default process group, in place
     where the backend allows: with "nccl" (= RCCL over xGMI) the DEVICE buffer goes straight into the collective;
-    with "gloo" (CPU tests) a host copy is reduced.  No-op without a process group.
+    with "gloo" (CPU tests) a host copy is reduced.  No-op without a process group, and -- unless ``force`` (default:
+    the environment variable UF3_FORCE_COLLECTIVE) -- in a group of one rank: forcing it runs the collective itself on
+    a one-GPU box (a sum over one rank: the buffer is unchanged).
     """
+    import os
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if force is None:
+        force = bool(os.environ.get("UF3_FORCE_COLLECTIVE"))
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not force):
         return flat
     if dist.get_backend() == "nccl":
         if not flat.is_cuda:

@@ -160,15 +160,26 @@ def fit_frames(model, featurizer, frames, energies, forces=None, weight=0.5, red
     if with_forces is None:
         with_forces = forces is not None
     acc = DeviceFitAccumulator(model, featurizer, with_forces=with_forces, max_atoms_per_chunk=max_atoms_per_chunk)
-    for attempt in range(4):
+    attempt = 0
+    while True:
         try:
             acc.add_frames(frames, energies, forces)
             flat = acc.packed()
             break
-        except _lib.RetryError:          # a neighbour capacity grew under an asynchronous chunk (or the context switched to
-            if attempt == 3:             # the image-range launches for atoms far outside their cell): the sums are invalid
-                raise
+        except _lib.UF3Error as exc:
+            # Chunks queued before the verdict arrived are still in flight with the old capacities: wait for them and
+            # drop their verdicts (they would otherwise fail the next attempt, or the next user of the shared context),
+            # then start over.  A capacity overflow (or the switch to the image-range launches for atoms far outside
+            # their cell) is repeated until the context has converged -- capacities only grow, geometrically --; any
+            # other error is the caller's.
+            try:
+                acc.ctx.synchronize()
+            except _lib.UF3Error:
+                pass
             acc.reset()
+            attempt += 1
+            if not isinstance(exc, _lib.RetryError) or attempt >= 16:
+                raise
     n_cols = int(acc._keep.numel())
     if reduce:
         flat = parallel.allreduce_packed(flat)

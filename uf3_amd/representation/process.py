@@ -154,14 +154,51 @@ class BasisFeaturizer:
         z_got, z_own = np.asarray(supercell.get_atomic_numbers()), np.asarray(geom.get_atomic_numbers())
         if got.shape == own.shape and np.array_equal(z_got, z_own) and np.allclose(got, own, rtol=0, atol=1e-9):
             return False                                             # a copy of the frame: no images
-        want = geometry.get_supercell(geom, r_cut=self.r_cut)
-        pos = np.asarray(want.get_positions(), dtype=float).reshape(-1, 3)
-        if (got.shape == pos.shape and np.array_equal(z_got, np.asarray(want.get_atomic_numbers()))
-                and np.allclose(got, pos, rtol=0, atol=1e-9)):
+        # Any tiling of the frame by whole lattice images (blocks of N atoms, each the frame shifted by an integer
+        # combination of the cell vectors) that covers at least the reference's image range gives the reference's
+        # features: a supercell built with a larger r_cut (get_supercell's default is 10) or with sort_indices=True is as
+        # good as get_supercell(geom, basis.r_cut).  The images themselves come from the frame's own cell on the device.
+        n = len(own)
+        cell = np.array(geom.get_cell(), dtype=float).reshape(3, 3)
+        pbc = np.asarray(geom.get_pbc() if hasattr(geom, "get_pbc") else geom.pbc, dtype=bool)
+        problem = None
+        if n == 0 or len(got) % n or not np.array_equal(z_got, np.tile(z_own, len(got) // max(n, 1))):
+            problem = f"{len(got)} atoms given: not whole images of the frame's {n} atoms"
+        else:
+            blocks = got.reshape(-1, n, 3)
+            delta = blocks[:, 0, :] - own[0]
+            if not np.allclose(blocks - own[None], delta[:, None, :], rtol=0, atol=1e-8):
+                problem = "its blocks are not rigid translations of the frame"
+            else:
+                with np.errstate(all="ignore"):
+                    frac = np.linalg.lstsq(cell.T, delta.T, rcond=None)[0].T if np.any(cell) else np.zeros_like(delta)
+                shifts = np.rint(frac).astype(int)
+                if not np.allclose(shifts @ cell, delta, rtol=0, atol=1e-8) or np.any(shifts[:, ~pbc] != 0):
+                    problem = "its blocks are not shifted by whole lattice vectors along the periodic axes"
+                else:
+                    have = {tuple(v) for v in shifts}
+                    need = {tuple(v) for v in geometry.image_shifts(cell, pbc, self.r_cut)}
+                    if len(have) != len(shifts) or not need <= have:
+                        problem = (f"it holds {len(have)} distinct images, the cut-off {self.r_cut} needs the "
+                                   f"{len(need)} images of get_supercell(geom, r_cut=basis.r_cut)")
+                    elif have != need:
+                        # more images than the reference's range: the same features as long as no atom sits FAR outside
+                        # its cell (for those the reference's rows depend on the image range, geometry.py:131-149).  The
+                        # window is the device's (make_geom in uf3_hip.hip): inside a fractional width fac + 1 - r_cut / h
+                        # around the cell, atoms within r_cut of each other are at most fac images apart.
+                        fr_own = own @ np.linalg.inv(cell) if abs(np.linalg.det(cell)) > 0 else np.zeros_like(own)
+                        normals = [np.cross(cell[1], cell[2]), np.cross(cell[2], cell[0]), np.cross(cell[0], cell[1])]
+                        for k in np.flatnonzero(pbc):
+                            h = abs(np.dot(cell[k], normals[k])) / max(np.linalg.norm(normals[k]), 1e-300)
+                            w = np.ceil(self.r_cut / h) + 1.0 - self.r_cut / h - 1e-9
+                            if np.any((fr_own[:, k] < 0.5 - 0.5 * w) | (fr_own[:, k] > 0.5 + 0.5 * w)):
+                                problem = ("it holds more images than get_supercell(geom, r_cut=basis.r_cut) and the frame has "
+                                           "atoms far outside its cell, whose reference rows depend on the image range")
+        if problem is None:
             return None
         raise ValueError(
-            "supercell is neither the frame itself nor get_supercell(geom, r_cut=basis.r_cut): "
-            f"{len(got)} atoms given, {len(pos)} expected; the GPU featurizer takes its periodic images from "
+            "supercell is neither the frame itself nor a tiling of it by lattice images that covers "
+            f"get_supercell(geom, r_cut=basis.r_cut): {problem}; the GPU featurizer takes its periodic images from "
             "the frame's own cell and cannot honour an arbitrary atom set")
 
     def featurize_energy_2B(self, geom, supercell=None):
