@@ -108,6 +108,7 @@ struct uf3_basis {
     std::vector<int> block_bounds;   // column boundaries of interaction blocks (for column windows)
     size_t c2_len = 0, c3_len = 0, n_recs = 0;
     size_t n_pair_recs = 0;
+    size_t trio_rec_lo = 0;          // first knot record a trio leg refers to
     int dense_stride[16] = {0};      // per featurizer mode: largest staged-record stride (doubles) among its trios
     int dense_stride_f[16] = {0};    // ... when force rows are wanted (grouped 3 x 3 x 9 windows stage 32-double records)
     bool dense_grouped[16] = {false}; // a trio of the mode stages grouped n windows (even-aligned groups: up to two padding records per pass)
@@ -454,6 +455,8 @@ extern "C" int uf3_basis_create(uf3_ctx *c, const uf3_basis_spec *s, uf3_basis *
     b->block_bounds = bounds;
 
     b->n_recs = recs.size();
+    b->trio_rec_lo = recs.size();
+    for (auto &td : trios) for (int d = 0; d < 3; d++) b->trio_rec_lo = std::min(b->trio_rec_lo, (size_t)td.leg[d].rec_off);
     HIPCHK(c, hipMalloc(&b->d_recs, sizeof(KnotRec) * std::max<size_t>(1, recs.size())));
     HIPCHK(c, hipMemcpy(b->d_recs, recs.data(), sizeof(KnotRec) * recs.size(), hipMemcpyHostToDevice));
     HIPCHK(c, hipMalloc(&b->d_lut, sizeof(int) * lut.size()));
@@ -912,6 +915,7 @@ extern "C" int uf3_featurize_dev(uf3_basis *b, const uf3_frames *fr, const doubl
         A.cand_cap = c->cand_cap;
         A.n_recs = (int)b->n_recs;
         A.n_pair_recs = (int)b->n_pair_recs;
+        A.trio_rec_lo = (int)b->trio_rec_lo;
         A.n_pair_cols = 0;
         for (int p = 0; p < b->host.P; p++) A.n_pair_cols += b->host.pairs[p].nb;
         if (old_n3) cap = A.n3.cap;
@@ -943,7 +947,7 @@ extern "C" int uf3_featurize_dev(uf3_basis *b, const uf3_frames *fr, const doubl
                 if (!(b->modes & (1 << mode))) continue;
                 const bool dense_mode = mode >= 6;
                 // knot records go to LDS when the block then still reaches the occupancy its registers allow
-                size_t n_rec_mode = mode == 0 ? b->n_pair_recs : b->n_recs;
+                size_t n_rec_mode = mode == 0 ? b->n_pair_recs : b->n_recs - b->trio_rec_lo;
                 const int S = b->host.S;
                 const size_t cu_lds = 160 * 1024 - 1024;
                 if (dense_mode) A.dsrc_lds = dsrc_ok;
@@ -956,16 +960,17 @@ extern "C" int uf3_featurize_dev(uf3_basis *b, const uf3_frames *fr, const doubl
                     // (grouped windows fold from three 12 x 16 tiles side by side: 704 doubles)
                     const int dump = want_f && b->dense_grouped[mode] ? std::max(704, b->dense_dump[mode]) : b->dense_dump[mode];
                     const bool grouped = want_f && b->dense_grouped[mode];
-                    const int nrec_max = std::max(4, std::min(grouped ? 20 : DENSE_NREC, 1200 / stride));
+                    const int nrec_max = std::max(4, std::min(DENSE_NREC, 1200 / stride));
                     // (+ the padding record of an odd pass; grouped windows: one per odd group, at most 2 + (nr odd))
                     auto stage_for = [&](int nr) { return std::max(dump, (nr + (nr & 1) + (grouped ? 2 : 0)) * stride); };
+                    // (21 records = 63 staging lanes = one walk step: a block of <= 63 items is one step and three passes)
                     A.dense_nrec = nrec_max; A.dense_stage = stage_for(nrec_max);
                     if (mode <= 7 && !getenv("UF3_NO_OCC3")) {
                         // records per staging pass: as many as the stage allows; fewer (smaller stage) if that lets a third
                         // workgroup onto the CU -- the kernel is latency-bound.  Three workgroups per CU need <= 52 KB each
                         // (LDS is granted in coarse granules: 53 KB did not fit).  Candidates in order of preference: more
                         // records per pass first, tables in LDS before tables in HBM
-                        const int tries[3] = {nrec_max, std::min(nrec_max, 18), std::min(nrec_max, 15)};
+                        const int tries[3] = {nrec_max, std::min(nrec_max, 20), std::min(nrec_max, 15)};
                         const size_t budget = (WPB == 4 ? 52 : 13 * WPB) * 1024;      // (12 waves per CU: 3 x 4 or 2 x 6)
                         const bool dsrc_allowed = A.dsrc_lds, recs_allowed = !getenv("UF3_NO_LDS_RECS") && !(img_launch && mode != 0);
                         for (int q = 0; q < 12 && !found; q++) {

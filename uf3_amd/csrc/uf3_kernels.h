@@ -442,6 +442,7 @@ struct FeatArgs {
     int cand_cap;       // 2-body candidates staged per atom
     int n_recs;         // KnotRec count (for the LDS copy)
     int n_pair_recs;    // ... of which belong to the pair blocks (they come first)
+    int trio_rec_lo;    // first record a trio leg refers to (>= n_pair_recs unless a trio leg shares a pair's knot sequence)
     int n_pair_cols;    // columns of all pair blocks together (they follow the S one-body columns)
     int dense_stage;    // doubles of per-wave stage the MFMA specialisation needs (max over dense trios)
     int dense_nrec;     // records staged per pass by the MFMA specialisation (<= DENSE_NREC)
@@ -610,6 +611,7 @@ struct WaveLds {
 // species sc (one of m's own neighbours e), enumerated through that centre's list.
 struct TrioWalk {
     int cnt_c, ra_lo, rb_lo, nb_;
+    float rcp_nb;          // 1 / nb_ (item index -> (p / nb_, p % nb_) without an integer division)
     int total_n, rc_lo, ncen, sx;
     int n_items;
     // The reference tiles the positions AS GIVEN with images -fac .. fac per axis (geometry.py:108-149) and takes the third
@@ -669,6 +671,7 @@ __device__ __forceinline__ void trio_walk_setup(const FeatArgs &A, const WaveLds
     k.total_n = __builtin_amdgcn_readfirstlane(k.total_n); k.rc_lo = __builtin_amdgcn_readfirstlane(k.rc_lo);
     k.ncen = __builtin_amdgcn_readfirstlane(k.ncen); k.sx = __builtin_amdgcn_readfirstlane(k.sx);
     k.n_items = k.cnt_c + k.total_n;
+    k.rcp_nb = __builtin_amdgcn_rcpf((float)k.nb_);
 }
 
 // geometry of item p of the walk; false when the item is void (p out of range, or the third atom is m itself)
@@ -684,12 +687,19 @@ __device__ __forceinline__ bool trio_walk_geom(const FeatArgs &A, const FrameGeo
     if (valid && tg.centre) {
         int aa, bb;
         if (sa == sb) {
-            bb = (int)((1.0f + sqrtf(1.0f + 8.0f * (float)p)) * 0.5f);
-            while (bb * (bb - 1) / 2 > p) --bb;
-            while ((bb + 1) * bb / 2 <= p) ++bb;
+            // pair index -> (aa < bb): bb = floor((1 + sqrt(1 + 8 p)) / 2).  In single precision the root of a non-square
+            // 1 + 8 p < 2^15 stays >= 0.004 away from the next integer, far more than the hardware root's error; one
+            // branch-free correction each way is kept as a guard.
+            bb = (int)((1.0f + __builtin_amdgcn_sqrtf(fmaf(8.0f, (float)p, 1.0f))) * 0.5f);
+            bb -= (bb * (bb - 1) / 2 > p) ? 1 : 0;
+            bb += ((bb + 1) * bb / 2 <= p) ? 1 : 0;
             aa = p - bb * (bb - 1) / 2;
             aa += k.ra_lo; bb += k.ra_lo;
-        } else { aa = k.ra_lo + p / k.nb_; bb = k.rb_lo + p % k.nb_; }
+        } else {
+            // p / nb_ by a reciprocal (p < 4096, nb_ <= 64: (p + 0.5) / nb_ is at least 0.5 / nb_ away from an integer)
+            const int q = (int)(((float)p + 0.5f) * k.rcp_nb);
+            aa = k.ra_lo + q; bb = k.rb_lo + (p - q * k.nb_);
+        }
         tg.rl = w.orr[aa]; tg.rm = w.orr[bb];
         tg.i1 = aa; tg.i2 = bb;
         double ex = w.ox[bb] - w.ox[aa], ey = w.oy[bb] - w.oy[aa], ez = w.oz[bb] - w.oz[aa];
@@ -735,7 +745,11 @@ __device__ __forceinline__ bool trio_walk_geom(const FeatArgs &A, const FrameGeo
             bool m_first = neighbour_is_first(g, sm, k.sx, s0, s1, s2, m_local, msidx, ksidx, kshift,
                                               kparent - g.atom_lo);
             tg.i1 = e; tg.i2 = e;
-            double ie = oie, in = 1.0 / tg.rn;
+            // 1 / rn: hardware reciprocal + two Newton steps (the unit vector needs no correctly rounded quotient)
+            double in = __builtin_amdgcn_rcp(tg.rn);
+            in = fma(fma(-tg.rn, in, 1.0), in, in);
+            in = fma(fma(-tg.rn, in, 1.0), in, in);
+            const double ie = oie;
             double ue[3] = {oex * ie, oey * ie, oez * ie};
             tg.a3[0] = ex * in; tg.a3[1] = ey * in; tg.a3[2] = ez * in;
             tg.first = m_first;
@@ -1560,19 +1574,20 @@ k_featurize(FeatArgs A) {
         size_t ints_total = ((size_t)WPB * per_wave_i + 3) & ~(size_t)3;   // 16-B alignment
         recs_lds = (KnotRec *)((int *)(erow + e_d + (size_t)WPB * per_wave_d) + ints_total);
     }
+    // (pair records come first: the pair launch copies those, a trio launch only the records its legs refer to)
+    const int rec_first = MODE == 0 ? 0 : A.trio_rec_lo, rec_end = MODE == 0 ? A.n_pair_recs : A.n_recs;
     if (RECS_LDS) {
-        const int n_copy = MODE == 0 ? A.n_pair_recs : A.n_recs;            // pair records come first
-        const double *srcp = (const double *)A.recs;
+        const double *srcp = (const double *)(A.recs + rec_first);
         double *dstp = (double *)recs_lds;
-        for (int q = tid; q < n_copy * 12; q += WPB * WAVE) dstp[q] = srcp[q];
+        for (int q = tid; q < (rec_end - rec_first) * 12; q += WPB * WAVE) dstp[q] = srcp[q];
     }
-    const KnotRec *recs = RECS_LDS ? recs_lds : A.recs;
+    const KnotRec *recs = RECS_LDS ? recs_lds - rec_first : A.recs;
     int fragp[4] = {0, 0, 0, 0};
     const int *dsrc = A.dsrc;
     if (DENSE) {
         for (int v = 0; v < 4; v++) fragp[v] = A.frag[(lane * 4 + v) * 2] * 16 + A.frag[(lane * 4 + v) * 2 + 1];
         if (A.dsrc_lds) {
-            int *dl = (int *)(recs_lds + (RECS_LDS ? A.n_recs : 0));
+            int *dl = (int *)(recs_lds + (RECS_LDS ? rec_end - rec_first : 0));
             for (int q = tid; q < A.n_dsrc; q += WPB * WAVE) dl[q] = A.dsrc[q];
             dsrc = dl;
         }
