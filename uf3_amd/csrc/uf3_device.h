@@ -34,6 +34,7 @@ struct PairDev {
 
 // what the per-(atom, trio) dispatch of k_featurize looks at, in one 32-byte block at the head of TrioDev: ONE scalar load per
 // trio and atom (read field by field, each behind its own branch, it was eight dependent scalar round trips)
+// grouped: 0, or (layout + 1) | offset of the block's fold table in FeatArgs::gsrc << 8
 struct TrioHead { int dense, nsrc, ncol, sc, sa, sb, col, grouped; };
 
 struct TrioDev {
@@ -56,6 +57,8 @@ struct TrioDev {
     // every step is a single MFMA into its group's accumulator tile (columns (n - group base, m): 15 of 16)
     double gthr0, gthr2;
     int grouped;
+    int layout;        // grouped windows: number of this trio's window layout (legs' knot sequences, window box, thresholds)
+    int gsrc_off;      // ... and where its fold table starts in FeatArgs::gsrc
 };
 
 struct BasisDev {

@@ -104,6 +104,9 @@ struct uf3_basis {
     int *d_lut = nullptr;
     int *d_colsrc = nullptr;
     int *d_dsrc = nullptr;           // colsrc as offsets into the dumped dense window (MFMA specialisation)
+    unsigned short *d_gsrc = nullptr; // grouped windows: fold tables (FeatArgs::gsrc)
+    size_t n_gsrc = 0;
+    bool all_grouped7 = false;       // every mode-7 trio stages grouped windows (its force launches do not touch dsrc)
     size_t n_dsrc = 0;
     std::vector<int> block_bounds;   // column boundaries of interaction blocks (for column windows)
     size_t c2_len = 0, c3_len = 0, n_recs = 0;
@@ -423,6 +426,7 @@ extern "C" int uf3_basis_create(uf3_ctx *c, const uf3_basis_spec *s, uf3_basis *
             if (i2 <= i_hi) td.gthr2 = tn[std::max(i2, i_lo)];
         }
         if (td.dense) b->dense_stride_f[td.dense] = std::max(b->dense_stride_f[td.dense], td.grouped ? 32 : dl.stride);
+        if (td.grouped && (td.leg[0].nk > 255 || td.leg[1].nk > 255 || td.leg[2].nk > 255 || recs.size() > 65535)) td.grouped = 0;   // (GroupedLayout packs them)
         if (td.dense && td.grouped) b->dense_grouped[td.dense] = true;
         td.thr0 = -1e300; td.thr2 = 1e300;
         if (td.dense && dense_ct(td.dense) == 2) {
@@ -449,6 +453,52 @@ extern "C" int uf3_basis_create(uf3_ctx *c, const uf3_basis_spec *s, uf3_basis *
                            : ((sp & 255) - td.lo[0]) * dl.cw + (((sp >> 16) & 255) - td.lo[2]) * td.ext[1] + (((sp >> 8) & 255) - td.lo[1]));
         }
     }
+    // grouped windows: number the distinct window layouts and write the fold tables -- per column, for (source 0 | 1) x
+    // (group 0 | 1 | 2), the double index of the source bin inside the dumped group tiles ([group][row 4 c + l][16 columns],
+    // component 0) or 15, an entry no record touches
+    std::vector<unsigned short> gsrc;
+    {
+        std::vector<int> layout_rep;                 // first trio of every layout
+        for (int t = 0; t < h.T; t++) {
+            TrioDev &td = trios[t];
+            td.layout = -1; td.gsrc_off = 0;
+            if (!td.grouped) continue;
+            auto same_leg = [](const LegDev &a, const LegDev &b2) {
+                return a.rec_off == b2.rec_off && a.nk == b2.nk && a.t0 == b2.t0 && a.tlast == b2.tlast && a.inv_h == b2.inv_h;
+            };
+            for (size_t q = 0; q < layout_rep.size() && td.layout < 0; q++) {
+                const TrioDev &o = trios[layout_rep[q]];
+                bool same = o.gthr0 == td.gthr0 && o.gthr2 == td.gthr2;
+                for (int a = 0; a < 3; a++) same = same && o.lo[a] == td.lo[a] && o.ext[a] == td.ext[a] && same_leg(o.leg[a], td.leg[a]);
+                if (same) td.layout = (int)q;
+            }
+            if (td.layout < 0) { td.layout = (int)layout_rep.size(); layout_rep.push_back(t); }
+            if (td.layout > 254) { td.grouped = 0; td.layout = -1; continue; }     // (never in practice: the ordinary two-tile path)
+            std::vector<unsigned short> mine;
+            for (int col = 0; col < td.ncol; col++)
+                for (int q = 0; q < 2; q++) {
+                    const int sp = q < td.nsrc ? colsrc[td.src_off + col * td.nsrc + q] : -1;
+                    for (int grp = 0; grp < 3; grp++) {
+                        unsigned short a = 15;
+                        if (sp >= 0) {
+                            const int l_rel = (sp & 255) - td.lo[0], m_rel = ((sp >> 8) & 255) - td.lo[1], n_rel = ((sp >> 16) & 255) - td.lo[2];
+                            const int nl = n_rel - 2 * grp;
+                            if (nl >= 0 && nl < 5) a = (unsigned short)(grp * 256 + l_rel * 16 + nl * td.ext[1] + m_rel);
+                        }
+                        mine.push_back(a);
+                    }
+                }
+            // (identical tables -- the same symmetry on the same layout -- are stored once: small enough for LDS)
+            td.gsrc_off = -1;
+            for (size_t off = 0; off + mine.size() <= gsrc.size() && td.gsrc_off < 0; off += 2)
+                if (std::equal(mine.begin(), mine.end(), gsrc.begin() + off)) td.gsrc_off = (int)off;
+            if (td.gsrc_off < 0) {
+                td.gsrc_off = (int)gsrc.size();
+                gsrc.insert(gsrc.end(), mine.begin(), mine.end());
+                while (gsrc.size() & 1) gsrc.push_back(15);      // (blocks start on a 4-byte boundary)
+            }
+        }
+    }
     std::sort(bounds.begin(), bounds.end());
     bounds.erase(std::unique(bounds.begin(), bounds.end()), bounds.end());
     if (bounds.back() != h.F) { delete b; return fail(c, UF3_EINVAL, "column blocks do not add up to n_feat"); }
@@ -466,7 +516,13 @@ extern "C" int uf3_basis_create(uf3_ctx *c, const uf3_basis_spec *s, uf3_basis *
     HIPCHK(c, hipMalloc(&b->d_dsrc, sizeof(int) * std::max<size_t>(1, dsrc.size())));
     if (!dsrc.empty()) HIPCHK(c, hipMemcpy(b->d_dsrc, dsrc.data(), sizeof(int) * dsrc.size(), hipMemcpyHostToDevice));
     b->n_dsrc = dsrc.size();
-    for (auto &td : trios) td.head = TrioHead{td.dense, td.nsrc, td.ncol, td.sc, td.sa, td.sb, td.col, td.grouped};
+    b->n_gsrc = gsrc.size();
+    b->all_grouped7 = true;
+    for (auto &td : trios) if (td.dense == 7 && !td.grouped) b->all_grouped7 = false;
+    HIPCHK(c, hipMalloc(&b->d_gsrc, sizeof(unsigned short) * std::max<size_t>(8, gsrc.size() + 8)));
+    if (!gsrc.empty()) HIPCHK(c, hipMemcpy(b->d_gsrc, gsrc.data(), sizeof(unsigned short) * gsrc.size(), hipMemcpyHostToDevice));
+    for (auto &td : trios)
+        td.head = TrioHead{td.dense, td.nsrc, td.ncol, td.sc, td.sa, td.sb, td.col, td.grouped ? ((td.layout + 1) | (td.gsrc_off << 8)) : 0};
     HIPCHK(c, hipMalloc(&b->d_trios, sizeof(TrioDev) * std::max<size_t>(1, trios.size())));
     if (!trios.empty())
         HIPCHK(c, hipMemcpy(b->d_trios, trios.data(), sizeof(TrioDev) * trios.size(), hipMemcpyHostToDevice));
@@ -487,7 +543,7 @@ extern "C" void uf3_basis_destroy(uf3_basis *b) {
     if (!b) return;
     hipSetDevice(b->ctx->device);
     hipStreamSynchronize(b->ctx->stream);
-    hipFree(b->dev); hipFree(b->d_trios); hipFree(b->d_recs); hipFree(b->d_lut); hipFree(b->d_colsrc); hipFree(b->d_dsrc);
+    hipFree(b->dev); hipFree(b->d_trios); hipFree(b->d_recs); hipFree(b->d_lut); hipFree(b->d_colsrc); hipFree(b->d_dsrc); hipFree(b->d_gsrc);
     delete b;
 }
 
@@ -893,6 +949,7 @@ extern "C" int uf3_featurize_dev(uf3_basis *b, const uf3_frames *fr, const doubl
     A.frag = nullptr;
     A.dense_stage = 0; A.dense_nrec = DENSE_NREC;
     A.dsrc = b->d_dsrc; A.n_dsrc = (int)b->n_dsrc;
+    A.gsrc = b->d_gsrc; A.n_gsrc = (int)b->n_gsrc; A.gsrc_lds = 0;
     const int dense_modes = (1 << 6) | (1 << 7) | (1 << 8) | (1 << 9);
     const bool dsrc_ok = (b->modes & dense_modes) && b->n_dsrc * sizeof(int) <= 8192 && !getenv("UF3_NO_LDS_DSRC");
     A.dsrc_lds = dsrc_ok;
@@ -950,15 +1007,18 @@ extern "C" int uf3_featurize_dev(uf3_basis *b, const uf3_frames *fr, const doubl
                 size_t n_rec_mode = mode == 0 ? b->n_pair_recs : b->n_recs - b->trio_rec_lo;
                 const int S = b->host.S;
                 const size_t cu_lds = 160 * 1024 - 1024;
-                if (dense_mode) A.dsrc_lds = dsrc_ok;
-                size_t lds_extra = (dense_mode && A.dsrc_lds) ? sizeof(int) * b->n_dsrc : 0;
+                if (dense_mode) A.dsrc_lds = dsrc_ok && !(mode == 7 && want_f && b->all_grouped7);
+                const bool gsrc_wanted = mode == 7 && want_f && b->dense_grouped[7] && b->n_gsrc > 0 && b->n_gsrc * 2 <= 4096 && !getenv("UF3_NO_LDS_GSRC");
+                const size_t gsrc_bytes = gsrc_wanted ? b->n_gsrc * 2 : 0;
+                A.gsrc_lds = gsrc_wanted;
+                size_t lds_extra = ((dense_mode && A.dsrc_lds) ? sizeof(int) * b->n_dsrc : 0) + gsrc_bytes;
                 bool recs_lds = false;
                 size_t lds = 0, lds_plain = 0, lds_recs = 0;
                 bool found = false;
                 if (dense_mode) {
                     const int stride = want_f ? b->dense_stride_f[mode] : b->dense_stride[mode];
-                    // (grouped windows fold from three 12 x 16 tiles side by side: 704 doubles)
-                    const int dump = want_f && b->dense_grouped[mode] ? std::max(704, b->dense_dump[mode]) : b->dense_dump[mode];
+                    // (grouped windows fold from three 16 x 16 tiles side by side: 768 doubles)
+                    const int dump = want_f && b->dense_grouped[mode] ? std::max(768, b->dense_dump[mode]) : b->dense_dump[mode];
                     const bool grouped = want_f && b->dense_grouped[mode];
                     const int nrec_max = std::max(4, std::min(DENSE_NREC, 1200 / stride));
                     // (+ the padding record of an odd pass; grouped windows: one per odd group, at most 2 + (nr odd))
@@ -978,7 +1038,7 @@ extern "C" int uf3_featurize_dev(uf3_basis *b, const uf3_frames *fr, const doubl
                             const bool with_recs = (q & 2) == 0, with_dsrc = (q & 1) == 0;
                             if ((with_recs && !recs_allowed) || (with_dsrc && !dsrc_allowed)) continue;
                             size_t need = feat_lds_bytes(F, S, cap, A.cand_cap, want_e && !A.e_direct, with_recs ? n_rec_mode : 0, mode,
-                                                         stage_for(nr), nr, A.n_pair_cols) + (with_dsrc ? sizeof(int) * b->n_dsrc : 0);
+                                                         stage_for(nr), nr, A.n_pair_cols) + (with_dsrc ? sizeof(int) * b->n_dsrc : 0) + gsrc_bytes;
                             if (need <= budget) {
                                 found = true; recs_lds = with_recs; lds = lds_recs = need;
                                 A.dense_nrec = nr; A.dense_stage = stage_for(nr); A.dsrc_lds = with_dsrc;
@@ -993,7 +1053,8 @@ extern "C" int uf3_featurize_dev(uf3_basis *b, const uf3_frames *fr, const doubl
                     recs_lds = lds_recs <= lds_target && !getenv("UF3_NO_LDS_RECS") && !(img_launch && mode != 0);
                     lds = recs_lds ? lds_recs : lds_plain;
                 }
-                const int launch_mode = mode;
+                // (10: mode 7 with grouped windows only -- the force launches of a basis whose mode-7 blocks are all grouped)
+                const int launch_mode = (mode == 7 && want_f && b->all_grouped7 && !img_launch && !getenv("UF3_NO_GROUPED_ONLY")) ? 10 : mode;
                 if (lds > 160 * 1024 - 512) return fail(c, UF3_EOVERFLOW, "featurizer LDS footprint exceeds 160 KB (F or neighbour count too large)");
                 // blocks of WPB waves, each walking a contiguous run of atoms (keeps the shared energy row on
                 // one frame); many more blocks than resident slots (measured: 2 per slot 3400 frames/s, 16-48 per slot
@@ -1032,6 +1093,9 @@ extern "C" int uf3_featurize_dev(uf3_basis *b, const uf3_frames *fr, const doubl
                     case 6: UF3_LAUNCH(6); break;
                     case 7: UF3_LAUNCH(7); break;
                     case 8: UF3_LAUNCH(8); break;
+                    case 10: if (want_e) { if (recs_lds) UF3_LAUNCH1(true, true, true, 10, false); else UF3_LAUNCH1(true, true, false, 10, false); }
+                             else { if (recs_lds) UF3_LAUNCH1(false, true, true, 10, false); else UF3_LAUNCH1(false, true, false, 10, false); }
+                             break;
                     default: UF3_LAUNCH(9); break;
                 }
 #undef UF3_LAUNCH

@@ -425,6 +425,10 @@ struct FeatArgs {
     const int *frag;          // v_mfma_f64_16x16x4 accumulator layout: [lane][4] -> (row, col), from k_mfma_probe
     const int *dsrc;          // dense trios: colsrc entries as offsets (pair * 16 + n bin) into the dumped window, -1 pad
     int n_dsrc, dsrc_lds;     // table length; staged in LDS by the MFMA specialisation when dsrc_lds != 0
+    const unsigned short *gsrc;   // grouped windows: per column six double indices into the dumped group tiles, (source 0 | 1) x
+                                  // (group 0 | 1 | 2), 15 (a zero) where the combination does not apply; block offset in
+                                  // TrioHead::grouped >> 8
+    int n_gsrc, gsrc_lds;         // table length (shorts); copied to LDS by the matrix-core launch when gsrc_lds != 0
     const FrameGeom *geoms;
     const int *frame_of;
     CellList cl;
@@ -623,9 +627,8 @@ struct TrioWalk {
 };
 
 template <bool WANT_F, bool IMG>
-__device__ __forceinline__ void trio_walk_setup(const FeatArgs &A, const WaveLds &w, const TrioDev *td, int sm, TrioWalk &k) {
+__device__ __forceinline__ void trio_walk_setup(const FeatArgs &A, const WaveLds &w, int sc, int sa, int sb, int sm, TrioWalk &k) {
     const int lane = lane_id();
-    const int sc = td->sc, sa = td->sa, sb = td->sb;
     // (compiled into the IMG launches only: the ordinary ones leave at once when the batch has such atoms and the host repeats
     // the call with these)
     k.img_check = (IMG && WANT_F && A.outside) ? __builtin_amdgcn_readfirstlane(A.outside[0]) : 0;   // 0 off, 1 range rule, 2 + extension lists
@@ -676,9 +679,9 @@ __device__ __forceinline__ void trio_walk_setup(const FeatArgs &A, const WaveLds
 
 // geometry of item p of the walk; false when the item is void (p out of range, or the third atom is m itself)
 template <bool WANT_F, bool IMG>
-__device__ __forceinline__ bool trio_walk_geom(const FeatArgs &A, const FrameGeom &g, const WaveLds &w, const TrioDev *td,
+__device__ __forceinline__ bool trio_walk_geom(const FeatArgs &A, const FrameGeom &g, const WaveLds &w, int sa, int sb,
                                                const TrioWalk &k, int m, int sm, int p, TripletGeom &tg) {
-    const int sa = td->sa, sb = td->sb, cap = A.n3.cap;
+    const int cap = A.n3.cap;
     const int m_local = m - g.atom_lo;
     bool valid = p < k.n_items;
     tg.centre = p < k.cnt_c;
@@ -772,7 +775,7 @@ __device__ __forceinline__ void trio_block(const FeatArgs &A, const BasisDev *B,
     const TrioDev td_copy = load_const(A.trios + t);          // scalar loads (see load_const)
     const TrioDev *td = &td_copy;
     TrioWalk k;
-    trio_walk_setup<WANT_F, IMG>(A, w, td, sm, k);
+    trio_walk_setup<WANT_F, IMG>(A, w, td->sc, td->sa, td->sb, sm, k);
     const int ncol = td->ncol, F = B->F;
     for (int c0 = 0; c0 < ncol; c0 += NCH * WAVE) {
         ColSrc src[NCH][NSRC];
@@ -793,7 +796,7 @@ __device__ __forceinline__ void trio_block(const FeatArgs &A, const BasisDev *B,
         for (int p0 = 0; p0 < k.n_items; p0 += WAVE) {
             TripletGeom tg;
             TripletRec r;
-            bool valid = trio_walk_geom<WANT_F, IMG>(A, g, w, td, k, m, sm, p0 + lane, tg);
+            bool valid = trio_walk_geom<WANT_F, IMG>(A, g, w, td->sa, td->sb, k, m, sm, p0 + lane, tg);
             valid = eval_triplet<WANT_F>(recs, td, tg, valid, r);
             stage_and_gather<WANT_E, WANT_F, NSRC, NCH>(tg, r, valid, w.stage, src, acc);
         }
@@ -919,7 +922,7 @@ __device__ __forceinline__ void trio_block_mfma(const FeatArgs &A, const BasisDe
     const TrioDev *td = &td_copy;
     PhaseClock pc;
     TrioWalk k;
-    trio_walk_setup<WANT_F, IMG>(A, w, td, sm, k);
+    trio_walk_setup<WANT_F, IMG>(A, w, td->sc, td->sa, td->sb, sm, k);
     const int ncol = td->ncol, F = B->F;
     const int lo_l = td->lo[0], lo_m = td->lo[1], lo_n = td->lo[2];
     const int ext_l = td->ext[0], ext_m = td->ext[1], ext_n = td->ext[2];
@@ -981,7 +984,7 @@ __device__ __forceinline__ void trio_block_mfma(const FeatArgs &A, const BasisDe
         {
             TripletGeom tg;
             bool valid = lane < batch && p0 + lane < k.n_items;
-            if (valid) valid = trio_walk_geom<WANT_F, IMG>(A, g, w, td, k, m, sm, p0 + lane, tg);
+            if (valid) valid = trio_walk_geom<WANT_F, IMG>(A, g, w, td->sa, td->sb, k, m, sm, p0 + lane, tg);
             // leg masks t[0] <= r <= t[-1] (angles.py:502-508); both ends contribute nothing (see eval_triplet)
             if (valid)                   // (bounds hoisted; `&`, not `&&`: no branch, no memory access per clause)
                 valid = (tg.rl > lo_r[0]) & (tg.rl < hi_r[0]) & (tg.rm > lo_r[1]) & (tg.rm < hi_r[1]) &
@@ -1228,64 +1231,102 @@ __device__ __forceinline__ void grouped_pass_steps(unsigned va, unsigned vd, uns
 }
 #undef UF3_GROUP_STEPS
 
+// What the lanes of a grouped window need that depends only on the window's LAYOUT -- knot sequences of the three legs, window
+// box, group thresholds: TrioDev::layout numbers the distinct ones, a basis built with one set of per-interaction settings
+// has a single one --, not on the block or the atom.  Computed when a block of another layout comes along (in practice once
+// per wave and launch) instead of at every (atom, block): the per-block set-up was 220 vector instructions, a quarter of
+// them spills of the descriptor's scalars.
+struct GroupedLayout {
+    int id;                               // TrioDev::layout this was computed for (-1: none yet)
+    int ext_l, ext_n, lo_l, lo_m, lo_n;   // (ext_m == 3)
+    double lo_r[3], hi_r[3], gthr0, gthr2;
+    // per lane, packed (they stay in registers across blocks and atoms):
+    unsigned ops;                         // byte offsets of the four MFMA operands inside a staged record: va | vd << 8 | vm << 16 | vn << 24
+    unsigned legpack;                     // staging role (li, leg): first knot record of the leg | knots << 16 | first pair of its window inside a record << 24
+    double leg_t0, leg_inv_h;             // ... and its support start / interval guess
+    unsigned tiles01, tiles23;            // accumulator element v -> double index inside a dumped group tile (16 bits each, 0xffff: none)
+};
+
+template <bool WANT_E>
+__device__ __forceinline__ void grouped_layout_setup(const FeatArgs &A, int t, const int (&fragp)[4], GroupedLayout &L) {
+    constexpr int GW = 5;
+    const int lane = lane_id();
+    const TrioDev td_copy = load_const(A.trios + t);
+    const TrioDev *td = &td_copy;
+    L.id = td->layout;
+    L.ext_l = td->ext[0]; L.ext_n = td->ext[2];
+    L.lo_l = td->lo[0]; L.lo_m = td->lo[1]; L.lo_n = td->lo[2];
+    for (int q = 0; q < 3; q++) { L.lo_r[q] = td->leg[q].t0; L.hi_r[q] = td->leg[q].tlast; }
+    L.gthr0 = td->gthr0; L.gthr2 = td->gthr2;
+    const int ext_l = L.ext_l, ext_m = 3;
+    const int oM = 2 * ext_l, oN = oM + 2 * ext_m, oD = oN + 2 * GW, oZ = oD + 8;       // (oZ + 2 <= 32: ext_l, ext_m <= 3)
+    const int r16 = lane & 15, slot = (lane >> 4) & 1;
+    const int inv_l = (65536 + ext_l - 1) / ext_l, inv_m = (65536 + ext_m - 1) / ext_m;
+    {
+        const int c = (r16 * inv_l) >> 16, pl = r16 - c * ext_l;
+        const bool ok = c < 3 || (c == 3 && WANT_E);
+        const unsigned va = 8 * (ok ? 2 * pl + (c == 3 ? 1 : slot) : oZ), vd = 8 * (ok ? oD + 2 * c + slot : oZ);
+        const int nl = (r16 * inv_m) >> 16, pm = r16 - nl * ext_m;         // column = (n - group base) * ext_m + m
+        const unsigned vm = 8 * (nl < GW ? oM + 2 * pm + slot : oZ), vn = 8 * (nl < GW ? oN + 2 * nl + slot : oZ);
+        L.ops = va | (vd << 8) | (vm << 16) | (vn << 24);                   // (a record is 256 bytes)
+    }
+    const int li = (lane * 21846) >> 16, leg = lane - 3 * li;
+    const int rec_off = leg == 0 ? td->leg[0].rec_off : (leg == 1 ? td->leg[1].rec_off : td->leg[2].rec_off);
+    const int nk = leg == 0 ? td->leg[0].nk : (leg == 1 ? td->leg[1].nk : td->leg[2].nk);
+    L.leg_t0 = leg == 0 ? td->leg[0].t0 : (leg == 1 ? td->leg[1].t0 : td->leg[2].t0);
+    L.leg_inv_h = leg == 0 ? td->leg[0].inv_h : (leg == 1 ? td->leg[1].inv_h : td->leg[2].inv_h);
+    L.legpack = (unsigned)rec_off | ((unsigned)nk << 16) | ((unsigned)(leg == 0 ? 0 : (leg == 1 ? oM : oN)) << 24);   // (host: rec_off < 65536, nk < 256)
+    // dumped tiles: [group][row 4 c + l][16 columns] -- component c always 4 rows on, whatever ext_l, so that the fold reads a
+    // column's four components at fixed distances
+    unsigned ts[4];
+#pragma unroll
+    for (int v = 0; v < 4; v++) {
+        const int row = fragp[v] >> 4, col = fragp[v] & 15;
+        const int c = (row * inv_l) >> 16, pl = row - c * ext_l;
+        ts[v] = row < 4 * ext_l ? (unsigned)((4 * c + pl) * 16 + col) : 0xffffu;
+    }
+    L.tiles01 = ts[0] | (ts[1] << 16); L.tiles23 = ts[2] | (ts[3] << 16);
+}
+
+// th: the block's dispatch header; gsrc: its fold table (see FeatArgs::gsrc), gsrc_off = th.grouped >> 8
 template <bool WANT_E, bool IMG>
 __device__ __forceinline__ void trio_block_grouped(const FeatArgs &A, const BasisDev *B, const KnotRec *recs, const FrameGeom &g,
-                                                   const WaveLds &w, int m, int sm, int t, const ESink &es,
-                                                   const int (&fragp)[4], const int *dsrc) {
+                                                   const WaveLds &w, int m, int sm, const TrioHead &th, const ESink &es,
+                                                   const GroupedLayout &L, const unsigned short *gsrc) {
     constexpr int STRIDE = 32, GW = 5, NG = 3;
     constexpr bool WANT_F = true;
     PhaseClock pc;
     const int lane = lane_id();
-    const TrioDev td_copy = load_const(A.trios + t);
-    const TrioDev *td = &td_copy;
     TrioWalk k;
-    trio_walk_setup<WANT_F, IMG>(A, w, td, sm, k);
-    const int ncol = td->ncol, F = B->F;
-    const int lo_l = td->lo[0], lo_m = td->lo[1], lo_n = td->lo[2];
-    const int ext_l = td->ext[0], ext_m = td->ext[1], ext_n = td->ext[2];
-    const int oM = 2 * ext_l, oN = oM + 2 * ext_m, oD = oN + 2 * GW, oZ = oD + 8;       // (oZ + 2 <= STRIDE: ext_l, ext_m <= 3)
-    const int r16 = lane & 15, slot = (lane >> 4) & 1;
-    const int inv_l = (65536 + ext_l - 1) / ext_l, inv_m = (65536 + ext_m - 1) / ext_m;
-    DenseLane<1, 1> o;
-    {
-        const int c = (r16 * inv_l) >> 16, pl = r16 - c * ext_l;
-        const bool ok = c < 3 || (c == 3 && WANT_E);
-        o.aL[0] = ok ? 2 * pl + (c == 3 ? 1 : slot) : oZ;
-        o.aD[0] = ok ? oD + 2 * c + slot : oZ;
-        const int nl = (r16 * inv_m) >> 16, pm = r16 - nl * ext_m;         // column = (n - group base) * ext_m + m
-        o.bM[0] = nl < GW ? oM + 2 * pm + slot : oZ;
-        o.bN[0] = nl < GW ? oN + 2 * nl + slot : oZ;
-    }
+    trio_walk_setup<WANT_F, IMG>(A, w, th.sc, th.sa, th.sb, sm, k);
+    const int ncol = th.ncol, F = B->F;
+    const unsigned short *gsrc_blk = gsrc + (th.grouped >> 8);      // the block's fold table (LDS when it fits)
+    const int ext_l = L.ext_l, ext_m = 3, ext_n = L.ext_n;
+    const int oM = 2 * ext_l, oN = oM + 2 * ext_m, oD = oN + 2 * GW;
     const int li = (lane * 21846) >> 16, leg = lane - 3 * li;
-    LegDev lg;
-    lg.rec_off = leg == 0 ? td->leg[0].rec_off : (leg == 1 ? td->leg[1].rec_off : td->leg[2].rec_off);
-    lg.nk = leg == 0 ? td->leg[0].nk : (leg == 1 ? td->leg[1].nk : td->leg[2].nk);
-    lg.t0 = leg == 0 ? td->leg[0].t0 : (leg == 1 ? td->leg[1].t0 : td->leg[2].t0);
-    lg.tlast = leg == 0 ? td->leg[0].tlast : (leg == 1 ? td->leg[1].tlast : td->leg[2].tlast);
-    lg.inv_h = leg == 0 ? td->leg[0].inv_h : (leg == 1 ? td->leg[1].inv_h : td->leg[2].inv_h);
-    const int w_off = leg == 0 ? 0 : (leg == 1 ? oM : oN);
-    const double gthr0 = td->gthr0, gthr2 = td->gthr2;
     double4_t acc[NG][1][1];
 #pragma unroll
     for (int q = 0; q < NG; q++) acc[q][0][0] = double4_t{0, 0, 0, 0};
     const int nrec = A.dense_nrec, batch = 3 * nrec;
-    const double lo_r[3] = {td->leg[0].t0, td->leg[1].t0, td->leg[2].t0};
-    const double hi_r[3] = {td->leg[0].tlast, td->leg[1].tlast, td->leg[2].tlast};
     // LDS byte addresses of this lane's four operands in record (lane >> 5) of the stage
     const unsigned stage_lds = (unsigned)(size_t)(__attribute__((address_space(3))) double *)w.stage + (lane >> 5) * (STRIDE * 8);
-    const unsigned a_va = stage_lds + 8 * o.aL[0], a_vd = stage_lds + 8 * o.aD[0], a_vm = stage_lds + 8 * o.bM[0],
-                   a_vn = stage_lds + 8 * o.bN[0];
+    const unsigned a_va = stage_lds + (L.ops & 0xffu), a_vd = stage_lds + ((L.ops >> 8) & 0xffu),
+                   a_vm = stage_lds + ((L.ops >> 16) & 0xffu), a_vn = stage_lds + (L.ops >> 24);
+    LegDev lg;                                                  // (what load_interval looks at)
+    lg.rec_off = (int)(L.legpack & 0xffffu); lg.nk = (int)((L.legpack >> 16) & 0xffu); lg.t0 = L.leg_t0; lg.inv_h = L.leg_inv_h;
+    lg.tlast = 0.0;
+    const int w_off = (int)(L.legpack >> 24);
     pc.lap(1);
     for (int p0 = 0; p0 < k.n_items; p0 += batch) {
         int n_valid, n_g0, n_g01;
         {
             TripletGeom tg;
             bool valid = lane < batch && p0 + lane < k.n_items;
-            if (valid) valid = trio_walk_geom<WANT_F, IMG>(A, g, w, td, k, m, sm, p0 + lane, tg);
+            if (valid) valid = trio_walk_geom<WANT_F, IMG>(A, g, w, th.sa, th.sb, k, m, sm, p0 + lane, tg);
             if (valid)
-                valid = (tg.rl > lo_r[0]) & (tg.rl < hi_r[0]) & (tg.rm > lo_r[1]) & (tg.rm < hi_r[1]) &
-                        (tg.rn > lo_r[2]) & (tg.rn < hi_r[2]);
-            const bool is0 = valid && tg.rn <= gthr0, is2 = valid && tg.rn > gthr2, is1 = valid && !is0 && !is2;
+                valid = (tg.rl > L.lo_r[0]) & (tg.rl < L.hi_r[0]) & (tg.rm > L.lo_r[1]) & (tg.rm < L.hi_r[1]) &
+                        (tg.rn > L.lo_r[2]) & (tg.rn < L.hi_r[2]);
+            const bool is0 = valid && tg.rn <= L.gthr0, is2 = valid && tg.rn > L.gthr2, is1 = valid && !is0 && !is2;
             const unsigned long long m0 = __ballot(is0), m1 = __ballot(is1), m2 = __ballot(is2);
             n_g0 = __popcll(m0); n_g01 = n_g0 + __popcll(m1);
             n_valid = n_g01 + __popcll(m2);
@@ -1329,7 +1370,7 @@ __device__ __forceinline__ void trio_block_grouped(const FeatArgs &A, const Basi
                 double *rec = w.stage + (size_t)(li + (li >= b0 ? (b0 & 1) : 0) + (li >= b1 ? ((b1 - b0) & 1) : 0)) * STRIDE;
                 const int cls = pk.y & 3, grp = pk.y >> 2;
                 // leg n: window = the record's group; legs l, m: the block's window
-                const int w_lo = leg == 0 ? lo_l : (leg == 1 ? lo_m : lo_n + 2 * grp);
+                const int w_lo = leg == 0 ? L.lo_l : (leg == 1 ? L.lo_m : L.lo_n + 2 * grp);
                 const int w_ext = leg == 0 ? ext_l : (leg == 1 ? ext_m : min(GW, ext_n - 2 * grp));
                 const bool d0 = leg == 0 ? cls != 2 : (leg == 1 ? cls == 2 : false);
                 const bool d1 = leg == 0 ? false : (leg == 1 ? cls == 0 : cls != 0);
@@ -1350,64 +1391,46 @@ __device__ __forceinline__ void trio_block_grouped(const FeatArgs &A, const Basi
             wave_sync();
         }
     }
-    // Fold.  The three group tiles go to LDS side by side with plain stores ([group][row (c, l)][16 columns]: no zero fill, no
+    // Fold.  The three group tiles go to LDS side by side with plain stores ([group][row 4 c + l][16 columns]: no zero fill, no
     // read-modify-write of a shared window) and every column of the block then sums its source bins over the one to three
-    // groups that hold them: three dependent LDS round trips per block instead of nine (this phase is a latency chain: it
-    // took 12 % of the launch for 8 % of its instructions).
-    double *tiles = w.stage;                                     // rows < 12 of 3 x 16 x 16 doubles: 704 doubles, the host's minimum
-    const int cw = 16 * ((ext_m * ext_n + 15) / 16), nsrc = td->nsrc, cw_shift = cw == 32 ? 5 : 4;
-    int offs[2][2];                                              // the fold table's entries of this lane's (at most two) columns
+    // groups that hold them.  Where each (source, group) sits inside the tiles is a table made by the host (FeatArgs::gsrc: six
+    // addresses per column; a combination that does not apply points at column 15 of tile 0, which no record ever touches and
+    // is therefore zero): 24 reads at fixed component distances and their sum, no address arithmetic, no weights.
+    double *tiles = w.stage;                                     // 3 x 16 x 16 doubles = the host's minimum stage
+    // the fold table's entries of this lane's (at most two) columns: six tile addresses each
+    int3 fs[2];
 #pragma unroll
-    for (int it = 0; it < 2; it++)
-#pragma unroll
-        for (int q = 0; q < 2; q++) {
-            const int col = lane + it * WAVE;
-            offs[it][q] = (col < ncol && q < nsrc) ? dsrc[td->src_off + col * nsrc + q] : -1;
-        }
+    for (int it = 0; it < 2; it++) fs[it] = *(const int3 *)(gsrc_blk + 6 * min(lane + it * WAVE, ncol - 1));
+    const unsigned ts[4] = {L.tiles01 & 0xffffu, L.tiles01 >> 16, L.tiles23 & 0xffffu, L.tiles23 >> 16};
 #pragma unroll
     for (int grp = 0; grp < NG; grp++)
 #pragma unroll
-        for (int v = 0; v < 4; v++)                                                          // fragp = row << 4 | column
-            if ((fragp[v] >> 4) < 4 * ext_l) tiles[grp * 256 + fragp[v]] = acc[grp][0][0][v];  // (rows (c, l): 4 ext_l <= 12)
+        for (int v = 0; v < 4; v++)
+            if (ts[v] != 0xffffu) tiles[grp * 256 + ts[v]] = acc[grp][0][0][v];
     wave_sync();
 #pragma unroll
     for (int it = 0; it < 2; it++) {
         const int col = lane + it * WAVE;
-        if (col >= ncol) break;
-        double fx = 0, fy = 0, fz = 0, en = 0;
-        // (no branches around the reads: every (source, group) combination is read -- from the tile's first entry when it does
-        // not apply -- and weighted 0 or 1; all reads of a column go out before the first sum waits for one: left alone the
-        // compiler serialised them into 24 round trips)
-        double tv[2][NG][4], wgt[2][NG];
+        if (it * WAVE >= ncol) break;                              // (wave-uniform: blocks of <= 64 columns fold in one round)
+        if (col >= ncol) continue;
+        const unsigned a[6] = {(unsigned)fs[it].x & 0xffffu, (unsigned)fs[it].x >> 16, (unsigned)fs[it].y & 0xffffu,
+                               (unsigned)fs[it].y >> 16, (unsigned)fs[it].z & 0xffffu, (unsigned)fs[it].z >> 16};
+        double tv[6][4];
 #pragma unroll
-        for (int q = 0; q < 2; q++) {
-            const int off = offs[it][q];
-            // window offset -> (l, n, m) relative to the window; bin n sits in the groups g with 0 <= n - 2 g <= 4
-            const int offc = max(off, 0), l_rel = offc >> cw_shift, rem = offc & (cw - 1);
-            const int n_rel = (rem * inv_m) >> 16, m_rel = rem - n_rel * ext_m;
-#pragma unroll
-            for (int grp = 0; grp < NG; grp++) {
-                const int nl = n_rel - 2 * grp;
-                const bool use = off >= 0 && nl >= 0 && nl < GW;
-                wgt[q][grp] = use ? 1.0 : 0.0;
-                const double *t = tiles + (use ? grp * 256 + l_rel * 16 + nl * ext_m + m_rel : 0);
-                tv[q][grp][0] = t[0]; tv[q][grp][1] = t[ext_l * 16]; tv[q][grp][2] = t[2 * ext_l * 16];
-                tv[q][grp][3] = WANT_E ? t[3 * ext_l * 16] : 0.0;
-            }
+        for (int q = 0; q < 6; q++) {
+            const double *tp = tiles + a[q];
+            tv[q][0] = tp[0]; tv[q][1] = tp[64]; tv[q][2] = tp[128];
+            tv[q][3] = WANT_E ? tp[192] : 0.0;
         }
         __builtin_amdgcn_sched_group_barrier(0x100, WANT_E ? 24 : 18, 0);       // all DS reads first
+        double sum[4];
 #pragma unroll
-        for (int q = 0; q < 2; q++)
-#pragma unroll
-            for (int grp = 0; grp < NG; grp++) {
-                fx += wgt[q][grp] * tv[q][grp][0]; fy += wgt[q][grp] * tv[q][grp][1]; fz += wgt[q][grp] * tv[q][grp][2];
-                if (WANT_E) en += wgt[q][grp] * tv[q][grp][3];
-            }
+        for (int c = 0; c < 4; c++) sum[c] = ((tv[0][c] + tv[1][c]) + (tv[2][c] + tv[3][c])) + (tv[4][c] + tv[5][c]);
         if (!(A.skip & 32)) {
-            double *dst = A.x_f + (size_t)m * 3 * F + td->col + col;
-            dst[0] = fx; dst[F] = fy; dst[2 * (size_t)F] = fz;
+            double *dst = A.x_f + (size_t)m * 3 * F + th.col + col;
+            dst[0] = sum[0]; dst[F] = sum[1]; dst[2 * (size_t)F] = sum[2];
         }
-        if (WANT_E) es.add(td->col + col, en);
+        if (WANT_E) es.add(th.col + col, sum[3]);
     }
     wave_sync();
     pc.lap(6);
@@ -1529,9 +1552,13 @@ __device__ __forceinline__ int trio_mode(const TrioDev *td) {
     return td->nsrc == 1 ? (wide ? 2 : 1) : (td->nsrc == 2 ? (wide ? 4 : 3) : 5);
 }
 
-template <bool WANT_E, bool WANT_F, bool RECS_LDS, int MODE, bool IMG>
-__global__ void __launch_bounds__(WPB * WAVE, MODE == 0 ? 4 : ((MODE == 6 || MODE == 7) ? 3 : 2))
+// MODE_ 10 = MODE 7 for a basis whose mode-7 blocks all stage grouped windows (the launch then carries no code and no
+// registers of the ordinary two-tile path).
+template <bool WANT_E, bool WANT_F, bool RECS_LDS, int MODE_, bool IMG>
+__global__ void __launch_bounds__(WPB * WAVE, MODE_ == 0 ? 4 : ((MODE_ == 6 || MODE_ == 7 || MODE_ == 10) ? 3 : 2))
 k_featurize(FeatArgs A) {
+    constexpr int MODE = MODE_ == 10 ? 7 : MODE_;
+    constexpr bool GROUPED_ONLY = MODE_ == 10;
     extern __shared__ __align__(16) unsigned char smem[];
     const BasisDev *B = A.B;
     const int F = load_const(&B->F), S = load_const(&B->S), n_trios = load_const(&B->T), cap = A.n3.cap;
@@ -1584,12 +1611,18 @@ k_featurize(FeatArgs A) {
     const KnotRec *recs = RECS_LDS ? recs_lds - rec_first : A.recs;
     int fragp[4] = {0, 0, 0, 0};
     const int *dsrc = A.dsrc;
+    const unsigned short *gsrc = A.gsrc;
     if (DENSE) {
         for (int v = 0; v < 4; v++) fragp[v] = A.frag[(lane * 4 + v) * 2] * 16 + A.frag[(lane * 4 + v) * 2 + 1];
+        int *dl = (int *)(recs_lds + (RECS_LDS ? rec_end - rec_first : 0));
         if (A.dsrc_lds) {
-            int *dl = (int *)(recs_lds + (RECS_LDS ? rec_end - rec_first : 0));
             for (int q = tid; q < A.n_dsrc; q += WPB * WAVE) dl[q] = A.dsrc[q];
             dsrc = dl;
+            dl += A.n_dsrc;
+        }
+        if (A.gsrc_lds) {                                          // (n_gsrc is even)
+            for (int q = tid; q < A.n_gsrc / 2; q += WPB * WAVE) dl[q] = ((const int *)A.gsrc)[q];
+            gsrc = (const unsigned short *)dl;
         }
     }
     if (e_lds) { for (int q = tid; q < F; q += WPB * WAVE) erow[q] = 0.0; }
@@ -1602,6 +1635,8 @@ k_featurize(FeatArgs A) {
     const int block_first = bid * A.atoms_per_block;
     const int block_end = min(block_first + A.atoms_per_block, A.natoms);
     int erow_frame = -1;
+    GroupedLayout GL;
+    GL.id = -1;
     for (int m0 = block_first; m0 < block_end; m0 += WPB) {      // the block's waves take consecutive atoms
         const int m = m0 + wave;
         const bool active = m < block_end;
@@ -1698,9 +1733,12 @@ k_featurize(FeatArgs A) {
                 else if (MODE == 3) trio_block<WANT_E, WANT_F, 2, 1, IMG>(A, B, recs, g, w, m, sm, t, es);
                 else if (MODE == 4) trio_block<WANT_E, WANT_F, 2, 2, IMG>(A, B, recs, g, w, m, sm, t, es);
                 else if (MODE == 5) trio_block<WANT_E, WANT_F, 6, 1, IMG>(A, B, recs, g, w, m, sm, t, es);
-                else if (MODE == 7 && WANT_F && th.grouped)
-                    trio_block_grouped<WANT_E, IMG>(A, B, recs, g, w, m, sm, t, es, fragp, dsrc);
-                else trio_block_mfma<WANT_E, WANT_F, (MODE >= 6 ? MODE : 6), IMG>(A, B, recs, g, w, m, sm, t, es, fragp, dsrc);
+                else if (MODE == 7 && WANT_F && th.grouped) {
+                    if (__builtin_expect((th.grouped & 0xff) - 1 != GL.id, 0)) grouped_layout_setup<WANT_E>(A, t, fragp, GL);
+                    trio_block_grouped<WANT_E, IMG>(A, B, recs, g, w, m, sm, th, es, GL, gsrc);
+                }
+                else if (!GROUPED_ONLY)
+                    trio_block_mfma<WANT_E, WANT_F, (MODE >= 6 ? MODE : 6), IMG>(A, B, recs, g, w, m, sm, t, es, fragp, dsrc);
             }
         }
     }
