@@ -57,6 +57,8 @@ struct TrioDev {
     // every step is a single MFMA into its group's accumulator tile (columns (n - group base, m): 15 of 16)
     double gthr0, gthr2;
     int grouped;
+    int banded;        // MODE 9 force launches: the leg-n intervals fall into <= 3 bands of <= 3 column tiles each (gthr0 / gthr2
+    int band_tile[3];  // separate them, band_tile[b] = first column tile of band b); TrioHead::grouped = 1
     int layout;        // grouped windows: number of this trio's window layout (legs' knot sequences, window box, thresholds)
     int gsrc_off;      // ... and where its fold table starts in FeatArgs::gsrc
 };

@@ -106,7 +106,8 @@ struct uf3_basis {
     int *d_dsrc = nullptr;           // colsrc as offsets into the dumped dense window (MFMA specialisation)
     unsigned short *d_gsrc = nullptr; // grouped windows: fold tables (FeatArgs::gsrc)
     size_t n_gsrc = 0;
-    bool all_grouped7 = false;       // every mode-7 trio stages grouped windows (its force launches do not touch dsrc)
+    bool all_grouped7 = false;
+    bool all_banded9 = false;        // every mode-9 trio runs banded (trio_block_banded)       // every mode-7 trio stages grouped windows (its force launches do not touch dsrc)
     size_t n_dsrc = 0;
     std::vector<int> block_bounds;   // column boundaries of interaction blocks (for column windows)
     size_t c2_len = 0, c3_len = 0, n_recs = 0;
@@ -425,6 +426,38 @@ extern "C" int uf3_basis_create(uf3_ctx *c, const uf3_basis_spec *s, uf3_basis *
             if (i0 >= i_lo) td.gthr0 = tn[std::min(i0, i_hi) + 1];
             if (i2 <= i_hi) td.gthr2 = tn[std::max(i2, i_lo)];
         }
+        // wide windows (mode 9, two row tiles): cut the intervals of leg n into at most three bands whose records touch at most
+        // three neighbouring column tiles (trio_block_banded); windows that do not fit keep the dense loop
+        td.banded = 0; td.band_tile[0] = td.band_tile[1] = td.band_tile[2] = 0;
+        if (td.dense == 9 && dl.stride == 64 && (4 * td.ext[0] + 15) / 16 == 2 && !getenv("UF3_NO_BANDS")) {
+            const double *tn = legn_knots[t];
+            const int i_lo = 3, i_hi = td.leg[2].nk - 5, n_ct = (td.ext[1] * td.ext[2] + 15) / 16;
+            auto tiles_of = [&](int i, int &t0, int &t1) {
+                const int f = i - 3 - td.lo[2], n0 = std::max(f, 0), n1 = std::min(f + 3, td.ext[2] - 1);
+                if (n0 > n1) return false;
+                t0 = (n0 * td.ext[1]) / 16; t1 = ((n1 + 1) * td.ext[1] - 1) / 16;
+                return true;
+            };
+            int band_first[4] = {i_lo, -1, -1, -1}, band_lo[3] = {-1, -1, -1}, nb = 0;
+            bool ok = true;
+            for (int i = i_lo; i <= i_hi && ok; i++) {
+                int t0, t1;
+                if (!tiles_of(i, t0, t1)) continue;                       // (an interval outside the window: any band)
+                if (band_lo[nb] < 0) band_lo[nb] = t0;
+                if (t1 - band_lo[nb] + 1 > 3) {                           // does not fit the open band: start the next one
+                    if (++nb > 2) { ok = false; break; }
+                    band_first[nb] = i; band_lo[nb] = t0;
+                    if (t1 - t0 + 1 > 3) ok = false;
+                }
+            }
+            if (ok) {
+                td.banded = 1;
+                td.gthr0 = nb >= 1 ? tn[band_first[1]] : 1e300;           // r_n <= t_i: interval < i
+                td.gthr2 = nb >= 2 ? tn[band_first[2]] : 1e300;
+                for (int q = 0; q < 3; q++) td.band_tile[q] = std::max(0, std::min(band_lo[q] < 0 ? 0 : band_lo[q], std::max(0, n_ct - 3)));
+                b->dense_grouped[9] = true;
+            }
+        }
         if (td.dense) b->dense_stride_f[td.dense] = std::max(b->dense_stride_f[td.dense], td.grouped ? 32 : dl.stride);
         if (td.grouped && (td.leg[0].nk > 255 || td.leg[1].nk > 255 || td.leg[2].nk > 255 || recs.size() > 65535)) td.grouped = 0;   // (GroupedLayout packs them)
         if (td.dense && td.grouped) b->dense_grouped[td.dense] = true;
@@ -519,10 +552,13 @@ extern "C" int uf3_basis_create(uf3_ctx *c, const uf3_basis_spec *s, uf3_basis *
     b->n_gsrc = gsrc.size();
     b->all_grouped7 = true;
     for (auto &td : trios) if (td.dense == 7 && !td.grouped) b->all_grouped7 = false;
+    b->all_banded9 = true;
+    for (auto &td : trios) if (td.dense == 9 && !td.banded) b->all_banded9 = false;
     HIPCHK(c, hipMalloc(&b->d_gsrc, sizeof(unsigned short) * std::max<size_t>(8, gsrc.size() + 8)));
     if (!gsrc.empty()) HIPCHK(c, hipMemcpy(b->d_gsrc, gsrc.data(), sizeof(unsigned short) * gsrc.size(), hipMemcpyHostToDevice));
     for (auto &td : trios)
-        td.head = TrioHead{td.dense, td.nsrc, td.ncol, td.sc, td.sa, td.sb, td.col, td.grouped ? ((td.layout + 1) | (td.gsrc_off << 8)) : 0};
+        td.head = TrioHead{td.dense, td.nsrc, td.ncol, td.sc, td.sa, td.sb, td.col,
+                           td.grouped ? ((td.layout + 1) | (td.gsrc_off << 8)) : (td.banded ? 1 : 0)};
     HIPCHK(c, hipMalloc(&b->d_trios, sizeof(TrioDev) * std::max<size_t>(1, trios.size())));
     if (!trios.empty())
         HIPCHK(c, hipMemcpy(b->d_trios, trios.data(), sizeof(TrioDev) * trios.size(), hipMemcpyHostToDevice));
@@ -1054,7 +1090,8 @@ extern "C" int uf3_featurize_dev(uf3_basis *b, const uf3_frames *fr, const doubl
                     lds = recs_lds ? lds_recs : lds_plain;
                 }
                 // (10: mode 7 with grouped windows only -- the force launches of a basis whose mode-7 blocks are all grouped)
-                const int launch_mode = (mode == 7 && want_f && b->all_grouped7 && !img_launch && !getenv("UF3_NO_GROUPED_ONLY")) ? 10 : mode;
+                const int launch_mode = (mode == 7 && want_f && b->all_grouped7 && !img_launch && !getenv("UF3_NO_GROUPED_ONLY")) ? 10
+                                        : ((mode == 9 && want_f && b->all_banded9 && !img_launch && !getenv("UF3_NO_GROUPED_ONLY")) ? 11 : mode);
                 if (lds > 160 * 1024 - 512) return fail(c, UF3_EOVERFLOW, "featurizer LDS footprint exceeds 160 KB (F or neighbour count too large)");
                 // blocks of WPB waves, each walking a contiguous run of atoms (keeps the shared energy row on
                 // one frame); many more blocks than resident slots (measured: 2 per slot 3400 frames/s, 16-48 per slot
@@ -1095,6 +1132,9 @@ extern "C" int uf3_featurize_dev(uf3_basis *b, const uf3_frames *fr, const doubl
                     case 8: UF3_LAUNCH(8); break;
                     case 10: if (want_e) { if (recs_lds) UF3_LAUNCH1(true, true, true, 10, false); else UF3_LAUNCH1(true, true, false, 10, false); }
                              else { if (recs_lds) UF3_LAUNCH1(false, true, true, 10, false); else UF3_LAUNCH1(false, true, false, 10, false); }
+                             break;
+                    case 11: if (want_e) { if (recs_lds) UF3_LAUNCH1(true, true, true, 11, false); else UF3_LAUNCH1(true, true, false, 11, false); }
+                             else { if (recs_lds) UF3_LAUNCH1(false, true, true, 11, false); else UF3_LAUNCH1(false, true, false, 11, false); }
                              break;
                     default: UF3_LAUNCH(9); break;
                 }

@@ -910,6 +910,76 @@ __device__ __forceinline__ void dense_accumulate(const double *stage, int rt_str
     for (; q < r1; q += 2, rec += 2 * stride) dense_step<TMASK, RT, CT>(rec, o, acc);
 }
 
+// accumulator window -> LDS, then lanes <-> columns fold the symmetry images and write the rows (the end of a block of the
+// matrix-core specialisations that keep the raw window in registers)
+template <bool WANT_E, bool WANT_F, int RT, int CT>
+__device__ __forceinline__ void dense_fold(const FeatArgs &A, const WaveLds &w, const TrioDev *td, const DenseLayout &dl, int m, int F,
+                                           const ESink &es, const int (&fragp)[4], const int *dsrc, double4_t (&acc)[RT][CT]) {
+    const int lane = lane_id();
+    const int ncol = td->ncol, ext_l = td->ext[0];
+    double *dump = w.stage;
+    const int nsrc = td->nsrc, cw = dl.cw;
+    const int comp_rows = WANT_F ? ext_l : 0;                    // rows per force component (energy rows follow them)
+    const bool whole = RT * 16 * cw <= A.dense_stage;            // the whole window fits the stage: one pass
+    const int c_first = WANT_F ? 0 : 3, c_last = WANT_E ? 3 : 2;
+    for (int comp = whole ? -1 : c_first; comp <= (whole ? -1 : c_last); comp++) {
+        wave_sync();
+#pragma unroll
+        for (int v = 0; v < 4; v++) {
+            const int fr = fragp[v] >> 4, fc = fragp[v] & 15;
+#pragma unroll
+            for (int rt = 0; rt < RT; rt++) {
+                int row = rt * 16 + fr;
+                bool ok = true;
+                if (!whole) { row -= (WANT_F ? comp : 0) * ext_l; ok = row >= 0 && row < ext_l; }
+#pragma unroll
+                for (int ct = 0; ct < CT; ct++)
+                    if (ok && ct * 16 < cw) dump[row * cw + ct * 16 + fc] = acc[rt][ct][v];
+            }
+        }
+        wave_sync();
+        for (int col = lane; col < ncol; col += WAVE) {
+            double fx = 0, fy = 0, fz = 0, en = 0;
+            if (nsrc <= 2) {
+                // at most two sources per column (the usual case): both table entries, then all their window reads, go out
+                // together, weighted 0 / 1 -- no branch around a read (the compiler serialises guarded reads into round trips)
+                const int o0 = dsrc[td->src_off + col * nsrc], o1 = nsrc > 1 ? dsrc[td->src_off + col * nsrc + 1] : -1;
+                const double w0 = o0 >= 0 ? 1.0 : 0.0, w1 = o1 >= 0 ? 1.0 : 0.0;
+                const double *p0 = dump + max(o0, 0), *p1 = dump + max(o1, 0);
+                double t0[4], t1[4];
+                t0[0] = p0[0]; t1[0] = p1[0];
+                if (whole && WANT_F) {
+                    t0[1] = p0[comp_rows * cw]; t1[1] = p1[comp_rows * cw];
+                    t0[2] = p0[2 * comp_rows * cw]; t1[2] = p1[2 * comp_rows * cw];
+                }
+                if (whole && WANT_E) { t0[3] = p0[3 * comp_rows * cw]; t1[3] = p1[3 * comp_rows * cw]; }
+                asm volatile("" ::: "memory");                    // (all reads requested before the first sum)
+                if (whole) {
+                    if (WANT_F) { fx = w0 * t0[0] + w1 * t1[0]; fy = w0 * t0[1] + w1 * t1[1]; fz = w0 * t0[2] + w1 * t1[2]; }
+                    if (WANT_E) en = w0 * t0[3] + w1 * t1[3];
+                } else fx = w0 * t0[0] + w1 * t1[0];
+            } else
+            for (int q = 0; q < nsrc; q++) {
+                const int off = dsrc[td->src_off + col * nsrc + q];
+                if (off < 0) continue;
+                if (whole) {
+                    if (WANT_F) { fx += dump[off]; fy += dump[comp_rows * cw + off]; fz += dump[2 * comp_rows * cw + off]; }
+                    if (WANT_E) en += dump[3 * comp_rows * cw + off];
+                } else fx += dump[off];
+            }
+            if (whole) {
+                if (WANT_F && !(A.skip & 32)) {
+                    double *dst = A.x_f + (size_t)m * 3 * F + td->col + col;
+                    dst[0] = fx; dst[F] = fy; dst[2 * (size_t)F] = fz;
+                }
+                if (WANT_E) es.add(td->col + col, en);
+            } else if (comp < 3) {
+                if (!(A.skip & 32)) A.x_f[(size_t)m * 3 * F + (size_t)comp * F + td->col + col] = fx;
+            } else es.add(td->col + col, fx);
+        }
+    }
+}
+
 template <bool WANT_E, bool WANT_F, int MODE, bool IMG>
 __device__ __forceinline__ void trio_block_mfma(const FeatArgs &A, const BasisDev *B, const KnotRec *recs, const FrameGeom &g,
                                                 const WaveLds &w, int m, int sm, int t, const ESink &es,
@@ -1088,71 +1158,223 @@ __device__ __forceinline__ void trio_block_mfma(const FeatArgs &A, const BasisDe
             pc.lap(5);
         }
     }
-    // accumulator window -> LDS, then lanes <-> columns fold the symmetry images and write the rows
-    double *dump = w.stage;
-    const int nsrc = td->nsrc, cw = dl.cw;
-    const int comp_rows = WANT_F ? ext_l : 0;                    // rows per force component (energy rows follow them)
-    const bool whole = RT * 16 * cw <= A.dense_stage;            // the whole window fits the stage: one pass
-    const int c_first = WANT_F ? 0 : 3, c_last = WANT_E ? 3 : 2;
-    for (int comp = whole ? -1 : c_first; comp <= (whole ? -1 : c_last); comp++) {
-        wave_sync();
-#pragma unroll
-        for (int v = 0; v < 4; v++) {
-            const int fr = fragp[v] >> 4, fc = fragp[v] & 15;
-#pragma unroll
-            for (int rt = 0; rt < RT; rt++) {
-                int row = rt * 16 + fr;
-                bool ok = true;
-                if (!whole) { row -= (WANT_F ? comp : 0) * ext_l; ok = row >= 0 && row < ext_l; }
-#pragma unroll
-                for (int ct = 0; ct < CT; ct++)
-                    if (ok && ct * 16 < cw) dump[row * cw + ct * 16 + fc] = acc[rt][ct][v];
-            }
-        }
-        wave_sync();
-        for (int col = lane; col < ncol; col += WAVE) {
-            double fx = 0, fy = 0, fz = 0, en = 0;
-            if (nsrc <= 2) {
-                // at most two sources per column (the usual case): both table entries, then all their window reads, go out
-                // together, weighted 0 / 1 -- no branch around a read (the compiler serialises guarded reads into round trips)
-                const int o0 = dsrc[td->src_off + col * nsrc], o1 = nsrc > 1 ? dsrc[td->src_off + col * nsrc + 1] : -1;
-                const double w0 = o0 >= 0 ? 1.0 : 0.0, w1 = o1 >= 0 ? 1.0 : 0.0;
-                const double *p0 = dump + max(o0, 0), *p1 = dump + max(o1, 0);
-                double t0[4], t1[4];
-                t0[0] = p0[0]; t1[0] = p1[0];
-                if (whole && WANT_F) {
-                    t0[1] = p0[comp_rows * cw]; t1[1] = p1[comp_rows * cw];
-                    t0[2] = p0[2 * comp_rows * cw]; t1[2] = p1[2 * comp_rows * cw];
-                }
-                if (whole && WANT_E) { t0[3] = p0[3 * comp_rows * cw]; t1[3] = p1[3 * comp_rows * cw]; }
-                asm volatile("" ::: "memory");                    // (all reads requested before the first sum)
-                if (whole) {
-                    if (WANT_F) { fx = w0 * t0[0] + w1 * t1[0]; fy = w0 * t0[1] + w1 * t1[1]; fz = w0 * t0[2] + w1 * t1[2]; }
-                    if (WANT_E) en = w0 * t0[3] + w1 * t1[3];
-                } else fx = w0 * t0[0] + w1 * t1[0];
-            } else
-            for (int q = 0; q < nsrc; q++) {
-                const int off = dsrc[td->src_off + col * nsrc + q];
-                if (off < 0) continue;
-                if (whole) {
-                    if (WANT_F) { fx += dump[off]; fy += dump[comp_rows * cw + off]; fz += dump[2 * comp_rows * cw + off]; }
-                    if (WANT_E) en += dump[3 * comp_rows * cw + off];
-                } else fx += dump[off];
-            }
-            if (whole) {
-                if (WANT_F && !(A.skip & 32)) {
-                    double *dst = A.x_f + (size_t)m * 3 * F + td->col + col;
-                    dst[0] = fx; dst[F] = fy; dst[2 * (size_t)F] = fz;
-                }
-                if (WANT_E) es.add(td->col + col, en);
-            } else if (comp < 3) {
-                if (!(A.skip & 32)) A.x_f[(size_t)m * 3 * F + (size_t)comp * F + td->col + col] = fx;
-            } else es.add(td->col + col, fx);
-        }
-    }
+    dense_fold<WANT_E, WANT_F, RT, CT>(A, w, td, dl, m, F, es, fragp, dsrc, acc);
     wave_sync();
     pc.lap(6);
     // the dump left window values in the stage: stale slots must stay finite (they are multiplied by 0), which they are
+}
+
+// ---- banded wide windows (MODE 9 force launches): the untrimmed / higher-resolution blocks -----------------------------
+// A window of 6 x 6 x 12 bins is 2 row tiles x 5 column tiles; the dense loop above spends 10 MFMAs on every step although a
+// record touches four consecutive n bins, i.e. at most three neighbouring column tiles (columns are n-major).  The leg-n
+// intervals are cut into three BANDS (TrioDev::gthr0 / gthr2 again: knot values of leg n), every band's records touch only
+// the column tiles band_tile[b] .. band_tile[b] + 2; the walk sorts the triplets by band, every band starts on an even slot
+// of the stage, and a step is 2 x 3 = 6 MFMAs into the band's six accumulator tiles.  As with the grouped windows the steps of
+// a band are ONE asm statement (three per pass, straight-line between them): in C++ the compiler copies the twelve accumulator
+// tiles at every loop boundary and spills ~130 registers; here they stay where they are.
+#define UF3_BAND_STEP_BYTES "0x400"       /* two records of 64 doubles */
+__device__ __forceinline__ void banded_steps(unsigned va0, unsigned vd0, unsigned va1, unsigned vd1, unsigned vm0, unsigned vn0,
+                                             unsigned vm1, unsigned vn1, unsigned vm2, unsigned vn2, int n_steps,
+                                             double4_t &c00, double4_t &c01, double4_t &c02, double4_t &c10, double4_t &c11,
+                                             double4_t &c12) {
+    double la0, da0, la1, da1, mb0, nb0, mb1, nb1, mb2, nb2;
+    asm volatile(
+        "s_cmp_eq_u32 %[n], 0\n"
+        "s_cbranch_scc1 1f\n"
+        "0:\n"
+        "ds_read_b64 %[la0], %[va0]\n"
+        "ds_read_b64 %[da0], %[vd0]\n"
+        "ds_read_b64 %[la1], %[va1]\n"
+        "ds_read_b64 %[da1], %[vd1]\n"
+        "ds_read_b64 %[mb0], %[vm0]\n"
+        "ds_read_b64 %[nb0], %[vn0]\n"
+        "ds_read_b64 %[mb1], %[vm1]\n"
+        "ds_read_b64 %[nb1], %[vn1]\n"
+        "ds_read_b64 %[mb2], %[vm2]\n"
+        "ds_read_b64 %[nb2], %[vn2]\n"
+        "s_sub_u32 %[n], %[n], 1\n"
+        "v_add_u32 %[va0], " UF3_BAND_STEP_BYTES ", %[va0]\n"
+        "v_add_u32 %[vd0], " UF3_BAND_STEP_BYTES ", %[vd0]\n"
+        "v_add_u32 %[va1], " UF3_BAND_STEP_BYTES ", %[va1]\n"
+        "v_add_u32 %[vd1], " UF3_BAND_STEP_BYTES ", %[vd1]\n"
+        "v_add_u32 %[vm0], " UF3_BAND_STEP_BYTES ", %[vm0]\n"
+        "v_add_u32 %[vn0], " UF3_BAND_STEP_BYTES ", %[vn0]\n"
+        "v_add_u32 %[vm1], " UF3_BAND_STEP_BYTES ", %[vm1]\n"
+        "v_add_u32 %[vn1], " UF3_BAND_STEP_BYTES ", %[vn1]\n"
+        "v_add_u32 %[vm2], " UF3_BAND_STEP_BYTES ", %[vm2]\n"
+        "v_add_u32 %[vn2], " UF3_BAND_STEP_BYTES ", %[vn2]\n"
+        "s_waitcnt lgkmcnt(6)\n"
+        "v_mul_f64 %[la0], %[la0], %[da0]\n"
+        "v_mul_f64 %[la1], %[la1], %[da1]\n"
+        "s_waitcnt lgkmcnt(4)\n"
+        "v_mul_f64 %[mb0], %[mb0], %[nb0]\n"
+        "s_waitcnt lgkmcnt(2)\n"
+        "v_mul_f64 %[mb1], %[mb1], %[nb1]\n"
+        "s_waitcnt lgkmcnt(0)\n"
+        "v_mul_f64 %[mb2], %[mb2], %[nb2]\n"
+        "v_mfma_f64_16x16x4_f64 %[c00], %[la0], %[mb0], %[c00]\n"
+        "v_mfma_f64_16x16x4_f64 %[c10], %[la1], %[mb0], %[c10]\n"
+        "v_mfma_f64_16x16x4_f64 %[c01], %[la0], %[mb1], %[c01]\n"
+        "v_mfma_f64_16x16x4_f64 %[c11], %[la1], %[mb1], %[c11]\n"
+        "s_cmp_eq_u32 %[n], 0\n"
+        "v_mfma_f64_16x16x4_f64 %[c02], %[la0], %[mb2], %[c02]\n"
+        "v_mfma_f64_16x16x4_f64 %[c12], %[la1], %[mb2], %[c12]\n"
+        "s_cbranch_scc0 0b\n"
+        "s_nop 15\n"
+        "s_nop 3\n"
+        "1:\n"
+        : [c00] "+v"(c00), [c01] "+v"(c01), [c02] "+v"(c02), [c10] "+v"(c10), [c11] "+v"(c11), [c12] "+v"(c12),
+          [va0] "+v"(va0), [vd0] "+v"(vd0), [va1] "+v"(va1), [vd1] "+v"(vd1), [vm0] "+v"(vm0), [vn0] "+v"(vn0),
+          [vm1] "+v"(vm1), [vn1] "+v"(vn1), [vm2] "+v"(vm2), [vn2] "+v"(vn2), [n] "+s"(n_steps),
+          [la0] "=&v"(la0), [da0] "=&v"(da0), [la1] "=&v"(la1), [da1] "=&v"(da1), [mb0] "=&v"(mb0), [nb0] "=&v"(nb0),
+          [mb1] "=&v"(mb1), [nb1] "=&v"(nb1), [mb2] "=&v"(mb2), [nb2] "=&v"(nb2)
+        :
+        : "scc", "memory");
+}
+#undef UF3_BAND_STEP_BYTES
+
+template <bool WANT_E, bool IMG>
+__device__ __forceinline__ void trio_block_banded(const FeatArgs &A, const BasisDev *B, const KnotRec *recs, const FrameGeom &g,
+                                                  const WaveLds &w, int m, int sm, int t, const ESink &es,
+                                                  const int (&fragp)[4], const int *dsrc) {
+    constexpr int RT = 2, CT = 6, STRIDE = 64;
+    constexpr bool WANT_F = true;
+    const int lane = lane_id();
+    const TrioDev td_copy = load_const(A.trios + t);
+    const TrioDev *td = &td_copy;
+    PhaseClock pc;
+    TrioWalk k;
+    trio_walk_setup<WANT_F, IMG>(A, w, td->sc, td->sa, td->sb, sm, k);
+    const int F = B->F;
+    const int lo_l = td->lo[0], lo_m = td->lo[1], lo_n = td->lo[2];
+    const int ext_l = td->ext[0], ext_m = td->ext[1], ext_n = td->ext[2];
+    const DenseLayout dl = dense_layout(ext_l, ext_m, ext_n);          // (dl.stride == STRIDE: the host sends no other window here)
+    const int r16 = lane & 15, slot = (lane >> 4) & 1;
+    const int inv_l = (65536 + ext_l - 1) / ext_l, inv_m = (65536 + ext_m - 1) / ext_m;
+    // LDS byte addresses of this lane's operands in record (lane >> 5) of the stage
+    const unsigned stage_lds = (unsigned)(size_t)(__attribute__((address_space(3))) double *)w.stage + (lane >> 5) * (STRIDE * 8);
+    unsigned aL[RT], aD[RT], bM[CT], bN[CT];
+#pragma unroll
+    for (int rt = 0; rt < RT; rt++) {
+        const int row = rt * 16 + r16;
+        const int c = (row * inv_l) >> 16, pl = row - c * ext_l;
+        const bool ok = c < 3 || (c == 3 && WANT_E);
+        aL[rt] = stage_lds + 8 * (ok ? 2 * pl + (c == 3 ? 1 : slot) : dl.oZ);
+        aD[rt] = stage_lds + 8 * (ok ? dl.oD + 2 * c + slot : dl.oZ);
+    }
+#pragma unroll
+    for (int ct = 0; ct < CT; ct++) {
+        const int col = ct * 16 + r16;                       // columns n-major: col = n * ext_m + m
+        const int pn = (col * inv_m) >> 16, pm = col - pn * ext_m;
+        const bool ok = pn < ext_n;
+        bM[ct] = stage_lds + 8 * (ok ? dl.oM + 2 * pm + slot : dl.oZ);
+        bN[ct] = stage_lds + 8 * (ok ? dl.oN + 2 * pn + slot : dl.oZ);
+    }
+    const int li = (lane * 21846) >> 16, leg = lane - 3 * li;
+    LegDev lg;
+    lg.rec_off = leg == 0 ? td->leg[0].rec_off : (leg == 1 ? td->leg[1].rec_off : td->leg[2].rec_off);
+    lg.nk = leg == 0 ? td->leg[0].nk : (leg == 1 ? td->leg[1].nk : td->leg[2].nk);
+    lg.t0 = leg == 0 ? td->leg[0].t0 : (leg == 1 ? td->leg[1].t0 : td->leg[2].t0);
+    lg.tlast = leg == 0 ? td->leg[0].tlast : (leg == 1 ? td->leg[1].tlast : td->leg[2].tlast);
+    lg.inv_h = leg == 0 ? td->leg[0].inv_h : (leg == 1 ? td->leg[1].inv_h : td->leg[2].inv_h);
+    const int w_off = leg == 0 ? 0 : (leg == 1 ? dl.oM : dl.oN);
+    const int w_ext = leg == 0 ? ext_l : (leg == 1 ? ext_m : ext_n), w_lo = leg == 0 ? lo_l : (leg == 1 ? lo_m : lo_n);
+    const double thr0 = td->gthr0, thr2 = td->gthr2;
+    const int bt0 = td->band_tile[0], bt1 = td->band_tile[1], bt2 = td->band_tile[2];     // wave-uniform
+    double4_t acc[RT][CT];
+#pragma unroll
+    for (int rt = 0; rt < RT; rt++)
+#pragma unroll
+        for (int ct = 0; ct < CT; ct++) acc[rt][ct] = double4_t{0, 0, 0, 0};
+    pc.lap(1);
+    const int nrec = A.dense_nrec, batch = 3 * nrec;
+    const double lo_r[3] = {td->leg[0].t0, td->leg[1].t0, td->leg[2].t0};
+    const double hi_r[3] = {td->leg[0].tlast, td->leg[1].tlast, td->leg[2].tlast};
+    for (int p0 = 0; p0 < k.n_items; p0 += batch) {
+        int n_valid, n_g0, n_g01;
+        {
+            TripletGeom tg;
+            bool valid = lane < batch && p0 + lane < k.n_items;
+            if (valid) valid = trio_walk_geom<WANT_F, IMG>(A, g, w, td->sa, td->sb, k, m, sm, p0 + lane, tg);
+            if (valid)
+                valid = (tg.rl > lo_r[0]) & (tg.rl < hi_r[0]) & (tg.rm > lo_r[1]) & (tg.rm < hi_r[1]) &
+                        (tg.rn > lo_r[2]) & (tg.rn < hi_r[2]);
+            const bool is0 = valid && tg.rn <= thr0, is2 = valid && tg.rn > thr2, is1 = valid && !is0 && !is2;
+            const unsigned long long m0 = __ballot(is0), m1 = __ballot(is1), m2 = __ballot(is2);
+            n_g0 = __popcll(m0); n_g01 = n_g0 + __popcll(m1);
+            n_valid = n_g01 + __popcll(m2);
+            if (valid) {
+                const int rank = is0 ? mbcnt(m0) : (is1 ? n_g0 + mbcnt(m1) : n_g01 + mbcnt(m2));
+                double *gq = w.geo + rank;
+                gq[0] = tg.rl; gq[GEO_N] = tg.rm; gq[2 * GEO_N] = tg.rn;
+                gq[3 * GEO_N] = tg.a3[0]; gq[4 * GEO_N] = tg.a3[1]; gq[5 * GEO_N] = tg.a3[2];
+                ((int2 *)(w.geo + 6 * GEO_N))[rank] = make_int2(tg.i1 | (tg.i2 << 16), tg.centre ? 0 : (tg.first ? 1 : 2));
+            }
+        }
+        wave_sync();
+        pc.lap(2);
+        for (int base = 0; base < n_valid; base += nrec) {
+            const int n_part = min(nrec, n_valid - base);
+            // band boundaries inside this pass (records are sorted by band); every band starts on an even slot
+            const int b0 = max(0, min(n_part, n_g0 - base)), b1 = max(0, min(n_part, n_g01 - base));
+            const int st0 = (b0 + 1) >> 1, st1 = (b1 - b0 + 1) >> 1, st2 = (n_part - b1 + 1) >> 1;
+            const int n_staged = 2 * (st0 + st1 + st2);
+            const bool mine = li < n_part && !(A.skip & 16);
+            if (!(A.skip & 16))
+                for (int q = 2 * lane; q < n_staged * STRIDE; q += 2 * WAVE) *(double2 *)(w.stage + q) = double2{0.0, 0.0};
+            if (mine) {
+                const int gi = base + li;
+                const double x = w.geo[leg * GEO_N + gi];
+                const int2 pk = ((const int2 *)(w.geo + 6 * GEO_N))[gi];
+                const double a3 = w.geo[(3 + leg) * GEO_N + gi];
+                __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+                const int i1 = pk.x & 0xffff, i2 = pk.x >> 16;
+                const double *oc = w.ox + (size_t)leg * A.n3.cap;
+                const double oc1 = oc[i1], oi1 = w.oir[i1], oc2 = oc[i2], oi2 = w.oir[i2];
+                KnotRec kr;
+                double v[4], d[4];
+                const int first = load_interval(recs, lg, x, kr) - 3;
+                bspline4<WANT_F>(kr, x, v, d);
+                double *rec = w.stage + (size_t)(li + (li >= b0 ? (b0 & 1) : 0) + (li >= b1 ? ((b1 - b0) & 1) : 0)) * STRIDE;
+                const int cls = pk.y;
+                const bool d0 = leg == 0 ? cls != 2 : (leg == 1 ? cls == 2 : false);
+                const bool d1 = leg == 0 ? false : (leg == 1 ? cls == 0 : cls != 0);
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const unsigned ws = (unsigned)(first + q - w_lo);
+                    if (ws < (unsigned)w_ext)
+                        *(double2 *)(rec + w_off + 2 * ws) = double2{d0 ? d[q] : v[q], d1 ? d[q] : v[q]};
+                }
+                const double u1 = oc1 * oi1, u2 = oc2 * oi2;
+                *(double2 *)(rec + dl.oD + 2 * leg) = double2{u1, cls == 0 ? u2 : a3};
+                if (leg == 0 && cls == 0) rec[dl.oD + 6] = 1.0;
+            }
+            wave_sync();
+            pc.lap(4);
+            if (!(A.skip & 8)) {
+                // band b's steps go to the column tiles band_tile[b] .. + 2 (wave-uniform switches: the tiles are registers)
+                const unsigned off1 = (unsigned)(2 * st0) * (STRIDE * 8), off2 = off1 + (unsigned)(2 * st1) * (STRIDE * 8);
+#define UF3_BAND(BT, OFF, NST)                                                                                                    \
+    if ((BT) == 0) banded_steps(aL[0] + (OFF), aD[0] + (OFF), aL[1] + (OFF), aD[1] + (OFF), bM[0] + (OFF), bN[0] + (OFF), bM[1] + (OFF), bN[1] + (OFF), \
+                                bM[2] + (OFF), bN[2] + (OFF), NST, acc[0][0], acc[0][1], acc[0][2], acc[1][0], acc[1][1], acc[1][2]);   \
+    else if ((BT) == 1) banded_steps(aL[0] + (OFF), aD[0] + (OFF), aL[1] + (OFF), aD[1] + (OFF), bM[1] + (OFF), bN[1] + (OFF), bM[2] + (OFF), bN[2] + (OFF), \
+                                     bM[3] + (OFF), bN[3] + (OFF), NST, acc[0][1], acc[0][2], acc[0][3], acc[1][1], acc[1][2], acc[1][3]); \
+    else if ((BT) == 2) banded_steps(aL[0] + (OFF), aD[0] + (OFF), aL[1] + (OFF), aD[1] + (OFF), bM[2] + (OFF), bN[2] + (OFF), bM[3] + (OFF), bN[3] + (OFF), \
+                                     bM[4] + (OFF), bN[4] + (OFF), NST, acc[0][2], acc[0][3], acc[0][4], acc[1][2], acc[1][3], acc[1][4]); \
+    else banded_steps(aL[0] + (OFF), aD[0] + (OFF), aL[1] + (OFF), aD[1] + (OFF), bM[3] + (OFF), bN[3] + (OFF), bM[4] + (OFF), bN[4] + (OFF),       \
+                      bM[5] + (OFF), bN[5] + (OFF), NST, acc[0][3], acc[0][4], acc[0][5], acc[1][3], acc[1][4], acc[1][5]);
+                UF3_BAND(bt0, 0u, st0)
+                UF3_BAND(bt1, off1, st1)
+                UF3_BAND(bt2, off2, st2)
+#undef UF3_BAND
+            }
+            pc.lap(5);
+            wave_sync();
+        }
+    }
+    dense_fold<WANT_E, WANT_F, RT, CT>(A, w, td, dl, m, F, es, fragp, dsrc, acc);
+    wave_sync();
+    pc.lap(6);
 }
 
 // ---- grouped n windows: the 3 x 3 x 9 blocks of the reference's default trims ------------------------------------
@@ -1553,12 +1775,12 @@ __device__ __forceinline__ int trio_mode(const TrioDev *td) {
 }
 
 // MODE_ 10 = MODE 7 for a basis whose mode-7 blocks all stage grouped windows (the launch then carries no code and no
-// registers of the ordinary two-tile path).
+// registers of the ordinary two-tile path); MODE_ 11 = MODE 9 with banded windows only, likewise.
 template <bool WANT_E, bool WANT_F, bool RECS_LDS, int MODE_, bool IMG>
 __global__ void __launch_bounds__(WPB * WAVE, MODE_ == 0 ? 4 : ((MODE_ == 6 || MODE_ == 7 || MODE_ == 10) ? 3 : 2))
 k_featurize(FeatArgs A) {
-    constexpr int MODE = MODE_ == 10 ? 7 : MODE_;
-    constexpr bool GROUPED_ONLY = MODE_ == 10;
+    constexpr int MODE = MODE_ == 10 ? 7 : (MODE_ == 11 ? 9 : MODE_);
+    constexpr bool GROUPED_ONLY = MODE_ == 10 || MODE_ == 11;      // (11: mode 9, banded windows only)
     extern __shared__ __align__(16) unsigned char smem[];
     const BasisDev *B = A.B;
     const int F = load_const(&B->F), S = load_const(&B->S), n_trios = load_const(&B->T), cap = A.n3.cap;
@@ -1737,6 +1959,8 @@ k_featurize(FeatArgs A) {
                     if (__builtin_expect((th.grouped & 0xff) - 1 != GL.id, 0)) grouped_layout_setup<WANT_E>(A, t, fragp, GL);
                     trio_block_grouped<WANT_E, IMG>(A, B, recs, g, w, m, sm, th, es, GL, gsrc);
                 }
+                else if (MODE == 9 && WANT_F && th.grouped)
+                    trio_block_banded<WANT_E, IMG>(A, B, recs, g, w, m, sm, t, es, fragp, dsrc);
                 else if (!GROUPED_ONLY)
                     trio_block_mfma<WANT_E, WANT_F, (MODE >= 6 ? MODE : 6), IMG>(A, B, recs, g, w, m, sm, t, es, fragp, dsrc);
             }
