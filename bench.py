@@ -98,8 +98,8 @@ def main():
         workload = workload.replace("C4-metric", "C4-cells").replace("notebook basis", "notebook basis without leading trim")
     basis = synthetic.notebook_basis(elements, lead3=lead3)
     B = args.frames_per_step
-    if wl == "lead0" and B > 8:
-        B = 8                     # 432 MB of rows per frame
+    if wl == "lead0" and B > 24:
+        B = 24                    # 432 MB of rows per frame
     frames = [synthetic.lattice_frame("bcc", reps, 3.165, numbers, 3000 + rank * 1000 + k) for k in range(B)]
     batch = _lib.FrameBatch(frames)
     n_atoms = len(frames[0])
@@ -366,13 +366,13 @@ def extra_lead0(torch, dev, frames, d_xf, steps=5, warmup=2):
     basis = synthetic.notebook_basis(['Mo', 'W'], lead3=0)
     fz = process.BasisFeaturizer(basis, device=dev.index)
     ctx, db = fz._dev()
-    B = 8
+    B = 24                                                      # 432 MB of rows per frame: 10.4 GB of the headline's 13.4 GB buffer
     batch = _lib.FrameBatch(frames[:B])
     F, n_atoms = db.n_feat, len(frames[0])
     d_pos = torch.from_numpy(batch.pos).to(dev)
     d_z = torch.from_numpy(batch.z).to(dev)
     xe = torch.empty((B, F), dtype=torch.float64, device=dev)
-    xf = d_xf.view(-1)[:3 * batch.n_atoms * F].view(batch.n_atoms, 3, F)       # (13.4 GB buffer of the headline: 10.4 GB used)
+    xf = d_xf.view(-1)[:3 * batch.n_atoms * F].view(batch.n_atoms, 3, F)
 
     def step():
         fz.featurize_device(batch.struct, d_pos.data_ptr(), d_z.data_ptr(), xe.data_ptr(), xf.data_ptr())

@@ -16,7 +16,7 @@ print("frames/s", d["value"], "ms/step", d["ms_per_step"], "launch_ms", d["roofl
 PY
 if [ "$PMC" = "pmc" ]; then
   UF3_BENCH_NOCHECK=1 timeout 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_MFMA SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAVE_CYCLES SQ_WAIT_INST_ANY \
-    -d $RUN/pmc -o p --output-format csv -- python bench.py --no-cpu-baseline --no-extra --steps 2 --warmup 1 --frames-per-step 32 "$@" > /dev/null 2>&1
+    -d $RUN/pmc -o p --output-format csv -- python bench.py --no-cpu-baseline --no-extra --steps 2 --warmup 1 --frames-per-step ${UF3_PMC_FRAMES:-32} "$@" > /dev/null 2>&1
   python - "$RUN" <<'PY'
 import csv, glob, sys, collections
 run = sys.argv[1]
@@ -29,6 +29,7 @@ for f in glob.glob(f"{run}/pmc/**/*counter_collection.csv", recursive=True):
         acc[mode][r["Counter_Name"]] += float(r["Counter_Value"]); n[mode][r["Counter_Name"]] += 1
 for mode in acc:
     launches = max(n[mode].values())
-    print(mode, "per atom:", "  ".join(f"{k[3:]} {v / launches / 320000:.0f}" for k, v in sorted(acc[mode].items())))
+    atoms = float(__import__("os").environ.get("UF3_PMC_ATOMS", "320000"))      # (32 frames of 10 k atoms per launch)
+    print(mode, "per atom:", "  ".join(f"{k[3:]} {v / launches / atoms:.0f}" for k, v in sorted(acc[mode].items())))
 PY
 fi

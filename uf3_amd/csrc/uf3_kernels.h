@@ -911,71 +911,82 @@ __device__ __forceinline__ void dense_accumulate(const double *stage, int rt_str
 }
 
 // accumulator window -> LDS, then lanes <-> columns fold the symmetry images and write the rows (the end of a block of the
-// matrix-core specialisations that keep the raw window in registers)
+// matrix-core specialisations that keep the raw window in registers).  As many components (x, y, z, energy) per dump as the
+// stage holds; the fold table's entries of a lane's columns are fetched once, before the first dump (they were re-read from
+// HBM for every component: a third of the wide windows' vector instructions went into this function).
 template <bool WANT_E, bool WANT_F, int RT, int CT>
 __device__ __forceinline__ void dense_fold(const FeatArgs &A, const WaveLds &w, const TrioDev *td, const DenseLayout &dl, int m, int F,
                                            const ESink &es, const int (&fragp)[4], const int *dsrc, double4_t (&acc)[RT][CT]) {
+    constexpr int MAXIT = RT * CT <= 2 ? 2 : 8;                  // 64-column rounds whose table entries stay in registers
     const int lane = lane_id();
-    const int ncol = td->ncol, ext_l = td->ext[0];
+    const int ncol = td->ncol, ext_l = td->ext[0], nsrc = td->nsrc, cw = dl.cw;
     double *dump = w.stage;
-    const int nsrc = td->nsrc, cw = dl.cw;
-    const int comp_rows = WANT_F ? ext_l : 0;                    // rows per force component (energy rows follow them)
-    const bool whole = RT * 16 * cw <= A.dense_stage;            // the whole window fits the stage: one pass
     const int c_first = WANT_F ? 0 : 3, c_last = WANT_E ? 3 : 2;
-    for (int comp = whole ? -1 : c_first; comp <= (whole ? -1 : c_last); comp++) {
+    const int rows_c = ext_l * cw;                               // doubles of one component's rows
+    const int cpp = max(1, min(c_last - c_first + 1, A.dense_stage / rows_c));      // components per dump
+    const int inv_l = (65536 + ext_l - 1) / ext_l;
+    const bool in_regs = nsrc <= 2 && ncol <= MAXIT * WAVE;      // wave-uniform
+    int o0[MAXIT], o1[MAXIT];
+    if (in_regs) {
+#pragma unroll
+        for (int it = 0; it < MAXIT; it++) {
+            const int col = lane + it * WAVE;
+            o0[it] = col < ncol ? dsrc[td->src_off + col * nsrc] : -1;
+            o1[it] = (col < ncol && nsrc > 1) ? dsrc[td->src_off + col * nsrc + 1] : -1;
+        }
+    }
+    for (int c0 = c_first; c0 <= c_last; c0 += cpp) {
+        const int nc = min(cpp, c_last - c0 + 1);
         wave_sync();
 #pragma unroll
         for (int v = 0; v < 4; v++) {
             const int fr = fragp[v] >> 4, fc = fragp[v] & 15;
 #pragma unroll
             for (int rt = 0; rt < RT; rt++) {
-                int row = rt * 16 + fr;
-                bool ok = true;
-                if (!whole) { row -= (WANT_F ? comp : 0) * ext_l; ok = row >= 0 && row < ext_l; }
+                const int row = rt * 16 + fr;
+                // rows are (component, l) with force rows wanted, l alone (the energy) without
+                const int c = WANT_F ? (row * inv_l) >> 16 : 3, pl = WANT_F ? row - c * ext_l : row;
+                const bool ok = c >= c0 && c < c0 + nc && pl < ext_l;
 #pragma unroll
                 for (int ct = 0; ct < CT; ct++)
-                    if (ok && ct * 16 < cw) dump[row * cw + ct * 16 + fc] = acc[rt][ct][v];
+                    if (ok && ct * 16 < cw) dump[((c - c0) * ext_l + pl) * cw + ct * 16 + fc] = acc[rt][ct][v];
             }
         }
         wave_sync();
-        for (int col = lane; col < ncol; col += WAVE) {
-            double fx = 0, fy = 0, fz = 0, en = 0;
-            if (nsrc <= 2) {
-                // at most two sources per column (the usual case): both table entries, then all their window reads, go out
-                // together, weighted 0 / 1 -- no branch around a read (the compiler serialises guarded reads into round trips)
-                const int o0 = dsrc[td->src_off + col * nsrc], o1 = nsrc > 1 ? dsrc[td->src_off + col * nsrc + 1] : -1;
-                const double w0 = o0 >= 0 ? 1.0 : 0.0, w1 = o1 >= 0 ? 1.0 : 0.0;
-                const double *p0 = dump + max(o0, 0), *p1 = dump + max(o1, 0);
+        if (in_regs) {
+#pragma unroll
+            for (int it = 0; it < MAXIT; it++) {
+                if (it * WAVE >= ncol) break;                    // (wave-uniform)
+                const int col = lane + it * WAVE;
+                if (col >= ncol) continue;
+                // both sources of a column are read whether they exist or not and weighted 0 / 1: no branch around a read
+                const double w0 = o0[it] >= 0 ? 1.0 : 0.0, w1 = o1[it] >= 0 ? 1.0 : 0.0;
+                const double *p0 = dump + max(o0[it], 0), *p1 = dump + max(o1[it], 0);
                 double t0[4], t1[4];
-                t0[0] = p0[0]; t1[0] = p1[0];
-                if (whole && WANT_F) {
-                    t0[1] = p0[comp_rows * cw]; t1[1] = p1[comp_rows * cw];
-                    t0[2] = p0[2 * comp_rows * cw]; t1[2] = p1[2 * comp_rows * cw];
+#pragma unroll
+                for (int q = 0; q < 4; q++) { const int qq = q < nc ? q : 0; t0[q] = p0[qq * rows_c]; t1[q] = p1[qq * rows_c]; }
+                asm volatile("" ::: "memory");                   // (all reads requested before the first sum)
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    if (q >= nc) break;
+                    const double val = w0 * t0[q] + w1 * t1[q];
+                    const int comp = c0 + q;
+                    if (comp < 3) { if (!(A.skip & 32)) A.x_f[(size_t)m * 3 * F + (size_t)comp * F + td->col + col] = val; }
+                    else es.add(td->col + col, val);
                 }
-                if (whole && WANT_E) { t0[3] = p0[3 * comp_rows * cw]; t1[3] = p1[3 * comp_rows * cw]; }
-                asm volatile("" ::: "memory");                    // (all reads requested before the first sum)
-                if (whole) {
-                    if (WANT_F) { fx = w0 * t0[0] + w1 * t1[0]; fy = w0 * t0[1] + w1 * t1[1]; fz = w0 * t0[2] + w1 * t1[2]; }
-                    if (WANT_E) en = w0 * t0[3] + w1 * t1[3];
-                } else fx = w0 * t0[0] + w1 * t1[0];
-            } else
-            for (int q = 0; q < nsrc; q++) {
-                const int off = dsrc[td->src_off + col * nsrc + q];
-                if (off < 0) continue;
-                if (whole) {
-                    if (WANT_F) { fx += dump[off]; fy += dump[comp_rows * cw + off]; fz += dump[2 * comp_rows * cw + off]; }
-                    if (WANT_E) en += dump[3 * comp_rows * cw + off];
-                } else fx += dump[off];
             }
-            if (whole) {
-                if (WANT_F && !(A.skip & 32)) {
-                    double *dst = A.x_f + (size_t)m * 3 * F + td->col + col;
-                    dst[0] = fx; dst[F] = fy; dst[2 * (size_t)F] = fz;
+        } else {
+            for (int col = lane; col < ncol; col += WAVE)
+                for (int q = 0; q < nc; q++) {
+                    double val = 0.0;
+                    for (int sidx = 0; sidx < nsrc; sidx++) {
+                        const int off = dsrc[td->src_off + col * nsrc + sidx];
+                        if (off >= 0) val += dump[q * rows_c + off];
+                    }
+                    const int comp = c0 + q;
+                    if (comp < 3) { if (!(A.skip & 32)) A.x_f[(size_t)m * 3 * F + (size_t)comp * F + td->col + col] = val; }
+                    else es.add(td->col + col, val);
                 }
-                if (WANT_E) es.add(td->col + col, en);
-            } else if (comp < 3) {
-                if (!(A.skip & 32)) A.x_f[(size_t)m * 3 * F + (size_t)comp * F + td->col + col] = fx;
-            } else es.add(td->col + col, fx);
         }
     }
 }
@@ -1172,57 +1183,73 @@ __device__ __forceinline__ void trio_block_mfma(const FeatArgs &A, const BasisDe
 // of the stage, and a step is 2 x 3 = 6 MFMAs into the band's six accumulator tiles.  As with the grouped windows the steps of
 // a band are ONE asm statement (three per pass, straight-line between them): in C++ the compiler copies the twelve accumulator
 // tiles at every loop boundary and spills ~130 registers; here they stay where they are.
-#define UF3_BAND_STEP_BYTES "0x400"       /* two records of 64 doubles */
+// one step (two records of 64 doubles = 0x400 bytes) at byte offset OFF from the running addresses
+#define UF3_BAND_STEP(OFF)                                                                      \
+        "ds_read_b64 %[la0], %[va0] offset:" OFF "\n"                                           \
+        "ds_read_b64 %[da0], %[vd0] offset:" OFF "\n"                                           \
+        "ds_read_b64 %[la1], %[va1] offset:" OFF "\n"                                           \
+        "ds_read_b64 %[da1], %[vd1] offset:" OFF "\n"                                           \
+        "ds_read_b64 %[mb0], %[vm0] offset:" OFF "\n"                                           \
+        "ds_read_b64 %[nb0], %[vn0] offset:" OFF "\n"                                           \
+        "ds_read_b64 %[mb1], %[vm1] offset:" OFF "\n"                                           \
+        "ds_read_b64 %[nb1], %[vn1] offset:" OFF "\n"                                           \
+        "ds_read_b64 %[mb2], %[vm2] offset:" OFF "\n"                                           \
+        "ds_read_b64 %[nb2], %[vn2] offset:" OFF "\n"                                           \
+        "s_waitcnt lgkmcnt(6)\n"                                                                \
+        "v_mul_f64 %[la0], %[la0], %[da0]\n"                                                    \
+        "v_mul_f64 %[la1], %[la1], %[da1]\n"                                                    \
+        "s_waitcnt lgkmcnt(4)\n"                                                                \
+        "v_mul_f64 %[mb0], %[mb0], %[nb0]\n"                                                    \
+        "s_waitcnt lgkmcnt(2)\n"                                                                \
+        "v_mul_f64 %[mb1], %[mb1], %[nb1]\n"                                                    \
+        "s_waitcnt lgkmcnt(0)\n"                                                                \
+        "v_mul_f64 %[mb2], %[mb2], %[nb2]\n"                                                    \
+        "v_mfma_f64_16x16x4_f64 %[c00], %[la0], %[mb0], %[c00]\n"                               \
+        "v_mfma_f64_16x16x4_f64 %[c10], %[la1], %[mb0], %[c10]\n"                               \
+        "v_mfma_f64_16x16x4_f64 %[c01], %[la0], %[mb1], %[c01]\n"                               \
+        "v_mfma_f64_16x16x4_f64 %[c11], %[la1], %[mb1], %[c11]\n"                               \
+        "v_mfma_f64_16x16x4_f64 %[c02], %[la0], %[mb2], %[c02]\n"                               \
+        "v_mfma_f64_16x16x4_f64 %[c12], %[la1], %[mb2], %[c12]\n"
+#define UF3_BAND_ADVANCE(BYTES)                                                                 \
+        "v_add_u32 %[va0], " BYTES ", %[va0]\n"                                                 \
+        "v_add_u32 %[vd0], " BYTES ", %[vd0]\n"                                                 \
+        "v_add_u32 %[va1], " BYTES ", %[va1]\n"                                                 \
+        "v_add_u32 %[vd1], " BYTES ", %[vd1]\n"                                                 \
+        "v_add_u32 %[vm0], " BYTES ", %[vm0]\n"                                                 \
+        "v_add_u32 %[vn0], " BYTES ", %[vn0]\n"                                                 \
+        "v_add_u32 %[vm1], " BYTES ", %[vm1]\n"                                                 \
+        "v_add_u32 %[vn1], " BYTES ", %[vn1]\n"                                                 \
+        "v_add_u32 %[vm2], " BYTES ", %[vm2]\n"                                                 \
+        "v_add_u32 %[vn2], " BYTES ", %[vn2]\n"
 __device__ __forceinline__ void banded_steps(unsigned va0, unsigned vd0, unsigned va1, unsigned vd1, unsigned vm0, unsigned vn0,
                                              unsigned vm1, unsigned vn1, unsigned vm2, unsigned vn2, int n_steps,
                                              double4_t &c00, double4_t &c01, double4_t &c02, double4_t &c10, double4_t &c11,
                                              double4_t &c12) {
     double la0, da0, la1, da1, mb0, nb0, mb1, nb1, mb2, nb2;
+    // four steps per trip share one advance of the ten operand addresses (the steps reach their records through the
+    // instruction's offset field), single steps finish the band
     asm volatile(
-        "s_cmp_eq_u32 %[n], 0\n"
+        "s_cmp_lt_u32 %[n], 4\n"
         "s_cbranch_scc1 1f\n"
         "0:\n"
-        "ds_read_b64 %[la0], %[va0]\n"
-        "ds_read_b64 %[da0], %[vd0]\n"
-        "ds_read_b64 %[la1], %[va1]\n"
-        "ds_read_b64 %[da1], %[vd1]\n"
-        "ds_read_b64 %[mb0], %[vm0]\n"
-        "ds_read_b64 %[nb0], %[vn0]\n"
-        "ds_read_b64 %[mb1], %[vm1]\n"
-        "ds_read_b64 %[nb1], %[vn1]\n"
-        "ds_read_b64 %[mb2], %[vm2]\n"
-        "ds_read_b64 %[nb2], %[vn2]\n"
-        "s_sub_u32 %[n], %[n], 1\n"
-        "v_add_u32 %[va0], " UF3_BAND_STEP_BYTES ", %[va0]\n"
-        "v_add_u32 %[vd0], " UF3_BAND_STEP_BYTES ", %[vd0]\n"
-        "v_add_u32 %[va1], " UF3_BAND_STEP_BYTES ", %[va1]\n"
-        "v_add_u32 %[vd1], " UF3_BAND_STEP_BYTES ", %[vd1]\n"
-        "v_add_u32 %[vm0], " UF3_BAND_STEP_BYTES ", %[vm0]\n"
-        "v_add_u32 %[vn0], " UF3_BAND_STEP_BYTES ", %[vn0]\n"
-        "v_add_u32 %[vm1], " UF3_BAND_STEP_BYTES ", %[vm1]\n"
-        "v_add_u32 %[vn1], " UF3_BAND_STEP_BYTES ", %[vn1]\n"
-        "v_add_u32 %[vm2], " UF3_BAND_STEP_BYTES ", %[vm2]\n"
-        "v_add_u32 %[vn2], " UF3_BAND_STEP_BYTES ", %[vn2]\n"
-        "s_waitcnt lgkmcnt(6)\n"
-        "v_mul_f64 %[la0], %[la0], %[da0]\n"
-        "v_mul_f64 %[la1], %[la1], %[da1]\n"
-        "s_waitcnt lgkmcnt(4)\n"
-        "v_mul_f64 %[mb0], %[mb0], %[nb0]\n"
-        "s_waitcnt lgkmcnt(2)\n"
-        "v_mul_f64 %[mb1], %[mb1], %[nb1]\n"
-        "s_waitcnt lgkmcnt(0)\n"
-        "v_mul_f64 %[mb2], %[mb2], %[nb2]\n"
-        "v_mfma_f64_16x16x4_f64 %[c00], %[la0], %[mb0], %[c00]\n"
-        "v_mfma_f64_16x16x4_f64 %[c10], %[la1], %[mb0], %[c10]\n"
-        "v_mfma_f64_16x16x4_f64 %[c01], %[la0], %[mb1], %[c01]\n"
-        "v_mfma_f64_16x16x4_f64 %[c11], %[la1], %[mb1], %[c11]\n"
-        "s_cmp_eq_u32 %[n], 0\n"
-        "v_mfma_f64_16x16x4_f64 %[c02], %[la0], %[mb2], %[c02]\n"
-        "v_mfma_f64_16x16x4_f64 %[c12], %[la1], %[mb2], %[c12]\n"
+        UF3_BAND_STEP("0") UF3_BAND_STEP("0x400") UF3_BAND_STEP("0x800") UF3_BAND_STEP("0xc00")
+        "s_sub_u32 %[n], %[n], 4\n"
+        UF3_BAND_ADVANCE("0x1000")
+        "s_cmp_lt_u32 %[n], 4\n"
         "s_cbranch_scc0 0b\n"
+        "1:\n"
+        "s_cmp_lt_u32 %[n], 2\n"
+        "s_cbranch_scc1 2f\n"
+        UF3_BAND_STEP("0") UF3_BAND_STEP("0x400")
+        "s_sub_u32 %[n], %[n], 2\n"
+        UF3_BAND_ADVANCE("0x800")
+        "2:\n"
+        "s_cmp_eq_u32 %[n], 0\n"
+        "s_cbranch_scc1 3f\n"
+        UF3_BAND_STEP("0")
+        "3:\n"
         "s_nop 15\n"
         "s_nop 3\n"
-        "1:\n"
         : [c00] "+v"(c00), [c01] "+v"(c01), [c02] "+v"(c02), [c10] "+v"(c10), [c11] "+v"(c11), [c12] "+v"(c12),
           [va0] "+v"(va0), [vd0] "+v"(vd0), [va1] "+v"(va1), [vd1] "+v"(vd1), [vm0] "+v"(vm0), [vn0] "+v"(vn0),
           [vm1] "+v"(vm1), [vn1] "+v"(vn1), [vm2] "+v"(vm2), [vn2] "+v"(vn2), [n] "+s"(n_steps),
@@ -1231,7 +1258,8 @@ __device__ __forceinline__ void banded_steps(unsigned va0, unsigned vd0, unsigne
         :
         : "scc", "memory");
 }
-#undef UF3_BAND_STEP_BYTES
+#undef UF3_BAND_STEP
+#undef UF3_BAND_ADVANCE
 
 template <bool WANT_E, bool IMG>
 __device__ __forceinline__ void trio_block_banded(const FeatArgs &A, const BasisDev *B, const KnotRec *recs, const FrameGeom &g,
@@ -1363,9 +1391,10 @@ __device__ __forceinline__ void trio_block_banded(const FeatArgs &A, const Basis
                                      bM[4] + (OFF), bN[4] + (OFF), NST, acc[0][2], acc[0][3], acc[0][4], acc[1][2], acc[1][3], acc[1][4]); \
     else banded_steps(aL[0] + (OFF), aD[0] + (OFF), aL[1] + (OFF), aD[1] + (OFF), bM[3] + (OFF), bN[3] + (OFF), bM[4] + (OFF), bN[4] + (OFF),       \
                       bM[5] + (OFF), bN[5] + (OFF), NST, acc[0][3], acc[0][4], acc[0][5], acc[1][3], acc[1][4], acc[1][5]);
-                UF3_BAND(bt0, 0u, st0)
-                UF3_BAND(bt1, off1, st1)
-                UF3_BAND(bt2, off2, st2)
+                // (the records of a walk step are sorted by band: a pass mostly holds one or two of them)
+                if (st0 > 0) { UF3_BAND(bt0, 0u, st0) }
+                if (st1 > 0) { UF3_BAND(bt1, off1, st1) }
+                if (st2 > 0) { UF3_BAND(bt2, off2, st2) }
 #undef UF3_BAND
             }
             pc.lap(5);
