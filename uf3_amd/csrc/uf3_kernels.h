@@ -1600,8 +1600,15 @@ __device__ __forceinline__ void trio_block_grouped(const FeatArgs &A, const Basi
             const int st0 = (b0 + 1) >> 1, st1 = (b1 - b0 + 1) >> 1, st2 = (n_part - b1 + 1) >> 1;
             const int n_staged = 2 * (st0 + st1 + st2);
             const bool mine = li < n_part && !(A.skip & 16);
-            if (!(A.skip & 16))
-                for (int q = 2 * lane; q < n_staged * STRIDE; q += 2 * WAVE) *(double2 *)(w.stage + q) = double2{0.0, 0.0};
+            if (!(A.skip & 16)) {
+                // the pass's records (and its padding records) start from zero.  The usual stage (24 records of 32 doubles) is
+                // cleared whole by six unconditional stores -- cheaper than a loop over the records in use
+                if (A.dense_stage == 768) {
+#pragma unroll
+                    for (int u = 0; u < 6; u++) *(double2 *)(w.stage + 2 * lane + u * 2 * WAVE) = double2{0.0, 0.0};
+                } else
+                    for (int q = 2 * lane; q < n_staged * STRIDE; q += 2 * WAVE) *(double2 *)(w.stage + q) = double2{0.0, 0.0};
+            }
             if (mine) {
                 const int gi = base + li;
                 // the LDS round trips of a pass in two waves instead of seven: everything that hangs on gi alone first, then
