@@ -203,17 +203,22 @@ def main():
                             neighbor_ms_per_step=round(timing["neighbor_ms"] / args.steps, 4))
         else:
             n_keep = int(acc._keep.numel())
-            gram_flops = 2.0 * (3 * n_atoms + 1) * n_keep * n_keep * B          # SURVEY 8d, per step
+            # executed Gram flops: the 16 x 16 tiles of the UPPER triangle over all F columns (the kernels skip the lower one);
+            # SURVEY 8d's full-matrix count 2 (3N+1) F'^2 is kept beside it for reference only
+            tiles = (F + 15) // 16
+            gram_flops = 2.0 * (3 * n_atoms + 1) * 256.0 * (tiles * (tiles + 1) / 2) * B
+            gram_flops_full = 2.0 * (3 * n_atoms + 1) * n_keep * n_keep * B
             gram_ms = timing["gram_ms"] / args.steps
             gram_tf = gram_flops / (gram_ms * 1e-3) / 1e12
             step_tf = (flops_frame * B + gram_flops) / (1e-3 * 1e3 * elapsed / args.steps) / 1e12
             roofline = dict(bound="mfma", achieved=round(step_tf, 3), peak=78.6, unit="TFLOP/s", frac=round(step_tf / 78.6, 5),
                             traffic=None, hbm=hbm,
-                            bound_note="whole step (featurizer + X^T X): algorithmic fp64 flops (featurizer: SURVEY 8d per pair / "
-                                       "triplet; Gram: 2 (3N+1) F'^2 per frame) / step time; the rows stay in HBM / Infinity Cache",
+                            bound_note="whole step (featurizer + X^T X): fp64 flops (featurizer: SURVEY 8d per pair / triplet; Gram: "
+                                       "the upper-triangle tiles the kernels execute) / step time; the rows stay in HBM / Infinity Cache",
                             kernel="k_featurize launch group + k_gram_tiled / k_gram_mfma (energy and force rows, X^T y fused)",
                             featurize_ms_per_step=round(launch_ms, 4), gram_ms_per_step=round(gram_ms, 4),
-                            gram_tflops=round(gram_tf, 3), gram_flops_per_step=gram_flops, n_unfrozen_columns=n_keep,
+                            gram_tflops_executed_triangle=round(gram_tf, 3), gram_flops_per_step=gram_flops,
+                            gram_flops_full_matrix=gram_flops_full, n_unfrozen_columns=n_keep,
                             neighbor_ms_per_step=round(timing["neighbor_ms"] / args.steps, 4))
         cpu = None
         if not args.no_cpu_baseline and world == 1:      # reported at N=1 only
@@ -341,8 +346,8 @@ def extra_fit(torch, dev, basis, frames, batch, d_pos, d_z, d_xe, d_xf, steps=5,
     flat = acc.packed()
     assert bool(torch.isfinite(flat).all())
     n_keep = int(acc._keep.numel())
-    tiles = (n_keep + 15) // 16
-    # executed Gram flops: the 16 x 16 tiles of the upper triangle (the kernels skip the lower one), force + energy rows
+    tiles = (F + 15) // 16
+    # executed Gram flops: the 16 x 16 tiles of the upper triangle over all F columns (the kernels skip the lower one)
     gram_tri = 2.0 * (3 * n_atoms + 1) * 256.0 * (tiles * (tiles + 1) / 2) * B
     gram_full = 2.0 * (3 * n_atoms + 1) * n_keep * n_keep * B
     flops = _featurizer_flops(n_atoms) * B + gram_tri

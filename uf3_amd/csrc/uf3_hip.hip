@@ -823,13 +823,21 @@ static int prepare(uf3_basis *b, const uf3_frames *fr, const double *d_pos, cons
     const size_t geo_bytes = (sizeof(FrameGeom) * nf + 15) / 16 * 16, off_bytes = sizeof(int64_t) * (nf + 1);
     const FrameGeom *d_geoms;
     const int64_t *d_offsets;
+    const int4 *host_block = nullptr;           // != null: k_prepare_small fetches the staged block itself
+    size_t host_block_bytes = 0;
     if (c->pin_in_pending && d_pos == c->stage_pos.as<double>()) {
-        // small batch staged by upload_frames: positions | species | geometry | offsets leave pin_in in one copy
+        // small batch staged by upload_frames: positions | species | geometry | offsets leave pin_in in one piece -- fetched by
+        // the cell-list kernel itself when that is the one-workgroup kernel, by one copy otherwise
         const size_t at = c->pin_in_pending;
         std::memcpy((char *)c->pin_in.p + at, geoms.data(), sizeof(FrameGeom) * nf);
         std::memcpy((char *)c->pin_in.p + at + geo_bytes, fr->atom_offsets, off_bytes);
-        HIPCHK(c, hipMemcpyAsync(c->stage_pos.p, c->pin_in.p, at + geo_bytes + off_bytes, hipMemcpyHostToDevice, st));
-        HIPCHK(c, hipEventRecord(c->pin_in_done, st));
+        if (natoms <= UF3_SMALL_ATOMS && !getenv("UF3_NO_SMALL_PREPARE") && !getenv("UF3_NO_ZERO_COPY")) {
+            host_block = (const int4 *)c->pin_in.p;
+            host_block_bytes = (at + geo_bytes + off_bytes + 15) / 16 * 16;
+        } else {
+            HIPCHK(c, hipMemcpyAsync(c->stage_pos.p, c->pin_in.p, at + geo_bytes + off_bytes, hipMemcpyHostToDevice, st));
+            HIPCHK(c, hipEventRecord(c->pin_in_done, st));
+        }
         c->pin_in_pending = 0;
         d_geoms = (const FrameGeom *)((const char *)c->stage_pos.p + at);
         d_offsets = (const int64_t *)((const char *)c->stage_pos.p + at + geo_bytes);
@@ -856,9 +864,12 @@ static int prepare(uf3_basis *b, const uf3_frames *fr, const double *d_pos, cons
     int tb = 256, gb = (natoms + tb - 1) / tb;
     if (natoms <= UF3_SMALL_ATOMS && !getenv("UF3_NO_SMALL_PREPARE")) {
         // an MD step: the whole cell-list stage in one workgroup (and the status words of the launches that follow zeroed)
-        hipLaunchKernelGGL(k_prepare_small, dim3(1), dim3(1024), 0, st, b->dev, d_geoms, d_offsets, nf,
+        hipLaunchKernelGGL(k_prepare_small, dim3(1), dim3(natoms <= 256 ? 256 : 1024), 0, st, b->dev, d_geoms, d_offsets, nf,
                            natoms, nbins, d_pos, d_z, c->frame_of.as<int>(), c->atom_bin.as<int>(), c->atom_wrap.as<int>(),
-                           c->spec.as<signed char>(), c->bin_start.as<int>(), c->slots.as<SlotRec>(), flags, 2);
+                           c->spec.as<signed char>(), c->bin_start.as<int>(), c->slots.as<SlotRec>(), flags, 2,
+                           host_block, (int4 *)c->stage_pos.p, (int)(host_block_bytes / 16));
+        // (host_block: no event behind the kernel -- a record between two launches costs the next kernel ~5 us of dispatch
+        // latency, and the only caller on this path, the synchronous evaluator entry, waits for the stream before it returns)
         P.flags_zeroed = true;
     } else {
     HIPCHK(c, hipMemsetAsync(flags + 3, 0, 2 * sizeof(int), st));         // extension-list need | "some atom outside its cell" (k_frame_bins)
@@ -1195,7 +1206,7 @@ static int upload_frames(uf3_ctx *c, const uf3_frames *fr, const double *pos, co
     HIPCHK(c, hipSetDevice(c->device));
     const size_t bp = 24 * (size_t)natoms, bz = 4 * (size_t)natoms;
     // (room behind positions | species for the frame geometry: see pin_in_pending)
-    const size_t geo_room = 64 + sizeof(FrameGeom) * (size_t)fr->n_frames + 8 * ((size_t)fr->n_frames + 1);
+    const size_t geo_room = 96 + sizeof(FrameGeom) * (size_t)fr->n_frames + 8 * ((size_t)fr->n_frames + 1);
     HIPCHK(c, c->stage_pos.ensure(bp + bz + geo_room));            // positions | species, one block
     c->d_stage_z = (int32_t *)((char *)c->stage_pos.p + bp);
     c->pin_in_pending = 0;
@@ -1241,7 +1252,8 @@ extern "C" int uf3_featurize(uf3_basis *b, const uf3_frames *fr, const double *p
 // ------------------------------------------------------------------------------ eval
 static int eval_impl(uf3_basis *b, const uf3_frames *fr, const double *d_pos, const int32_t *d_z, const double *c1,
                      const double *c2, const double *c3, double *d_energies, double *d_forces, double *d_virials,
-                     int64_t atom_begin = 0, int64_t atom_end = -1, int *deferred_cap = nullptr, int *flags_tail = nullptr) {
+                     int64_t atom_begin = 0, int64_t atom_end = -1, int *deferred_cap = nullptr, int *flags_tail = nullptr,
+                     double *mirror = nullptr) {
     uf3_ctx *c = b->ctx;
     if (!d_pos || !d_z || !c1 || !d_energies) return fail(c, UF3_EINVAL, "uf3_eval: null argument");
     if ((b->c2_len && !c2) || (b->c3_len && !c3)) return fail(c, UF3_EINVAL, "uf3_eval: missing coefficients");
@@ -1320,7 +1332,8 @@ static int eval_impl(uf3_basis *b, const uf3_frames *fr, const double *d_pos, co
             // (one workgroup per frame and component: wide for big frames, the loop is a latency chain)
             const int sum_threads = P.natoms / P.n_frames >= 2048 ? 1024 : 256;
             hipLaunchKernelGGL(k_frame_sum, dim3(P.n_frames, d_virials ? 7 : 1), dim3(sum_threads), 0, st, A.e_atom,
-                               A.virial, P.d_offsets, d_energies, d_virials, (const int *)c->flags.as<int>(), flags_tail);
+                               A.virial, P.d_offsets, d_energies, d_virials, (const int *)c->flags.as<int>(), flags_tail,
+                               mirror, (const double *)d_forces, d_forces ? 3 * P.natoms : 0);
             if (fuse && !deferred_cap) {
                 // the lists were part of this launch: did they fit?  (Asked after everything is queued -- all kernels
                 // are safe on clipped lists -- so that the GPU does not idle while the host looks.)
@@ -1377,10 +1390,14 @@ static int eval_host(uf3_basis *b, const uf3_frames *fr, const double *pos, cons
         int *d_flags_tail = (int *)((char *)c->stage_out.p + total);
         for (int attempt = 0; attempt < 6; attempt++) {
             int cap_used = 0;
+            // (up to the one-workgroup cell-list limit the last kernel writes the results into the pinned block itself; the
+            // mirror's layout has the forces right behind the 7 nf sums, as d_e does)
+            const bool zero_copy = natoms <= UF3_SMALL_ATOMS && !getenv("UF3_NO_ZERO_COPY");
             rc = eval_impl(b, fr, c->stage_pos.as<double>(), c->d_stage_z, c1, c2, c3, d_e, forces ? d_f : nullptr,
-                           virials ? d_v : nullptr, atom_begin, atom_end, &cap_used, d_flags_tail);
+                           virials ? d_v : nullptr, atom_begin, atom_end, &cap_used, d_flags_tail,
+                           zero_copy ? (double *)c->pin_out.p : nullptr);
             if (rc) return rc;
-            HIPCHK(c, hipMemcpyAsync(c->pin_out.p, d_e, total + 16, hipMemcpyDeviceToHost, c->stream));
+            if (!zero_copy) HIPCHK(c, hipMemcpyAsync(c->pin_out.p, d_e, total + 16, hipMemcpyDeviceToHost, c->stream));
             HIPCHK(c, hipStreamSynchronize(c->stream));
             poll_pending(c, true);           // (remembered, see above)
             {

@@ -113,15 +113,24 @@ __global__ void k_bin_finish(int nbins, const int *bin_start, int *sorted_val, c
 __global__ void __launch_bounds__(1024)
 k_prepare_small(const BasisDev *B, const FrameGeom *geoms, const int64_t *atom_offsets, int n_frames, int natoms,
                 int nbins, const double *pos, const int32_t *z, int *frame_of, int *atom_bin, int *atom_wrap,
-                signed char *spec, int *bin_start, SlotRec *slots, int *flags, int n_zero_flags) {
+                signed char *spec, int *bin_start, SlotRec *slots, int *flags, int n_zero_flags,
+                const int4 *host_block, int4 *dev_block, int block_int4s) {
     __shared__ unsigned long long keys[UF3_SMALL_ATOMS];
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, nt = blockDim.x;        // (256 threads for <= 256 atoms: cheaper barriers; 1024 otherwise)
+    // host_block != null: positions | species | frame geometry | offsets of the batch still sit in the caller's pinned staging
+    // block (device-visible host memory): this workgroup fetches them itself -- a few KB over the link -- instead of waiting for
+    // a copy engine's transfer in front of it (one dependent step of an MD call less).  pos, z, geoms, atom_offsets point into
+    // dev_block, where the later kernels read them.
+    if (host_block) {
+        for (int q = tid; q < block_int4s; q += nt) dev_block[q] = host_block[q];
+        __syncthreads();
+    }
     if (tid < n_zero_flags) flags[1 + tid] = 0;                   // (n3_need, cand_need of the launches that follow)
     if (tid == 0) { flags[3] = 0; flags[4] = 0; }                 // (extension-list need, "some atom outside its cell")
     bool outside = false;
     int n_pow2 = 64;
     while (n_pow2 < natoms) n_pow2 <<= 1;
-    for (int a = tid; a < n_pow2; a += 1024) {
+    for (int a = tid; a < n_pow2; a += nt) {
         unsigned long long key = ~0ull;
         if (a < natoms) {
             int lo = 0, hi = n_frames - 1;                // frame with atom_offsets[f] <= a < atom_offsets[f+1]
@@ -164,7 +173,7 @@ k_prepare_small(const BasisDev *B, const FrameGeom *geoms, const int64_t *atom_o
     if (outside) flags[4] = 1;                                    // (after the barrier: thread 0 has zeroed it)
     for (int size = 2; size <= n_pow2; size <<= 1)
         for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            for (int t = tid; t < n_pow2 / 2; t += 1024) {
+            for (int t = tid; t < n_pow2 / 2; t += nt) {
                 const int i = 2 * t - (t & (stride - 1)), j = i + stride;          // the pair (i, i + stride) of this stage
                 const bool up = (i & size) == 0;
                 const unsigned long long a = keys[i], b = keys[j];
@@ -172,7 +181,7 @@ k_prepare_small(const BasisDev *B, const FrameGeom *geoms, const int64_t *atom_o
             }
             __syncthreads();
         }
-    for (int sidx = tid; sidx < natoms; sidx += 1024) {
+    for (int sidx = tid; sidx < natoms; sidx += nt) {
         const int a = (int)(unsigned)keys[sidx];
         SlotRec r;
         r.x = pos[3 * (size_t)a]; r.y = pos[3 * (size_t)a + 1]; r.z = pos[3 * (size_t)a + 2];
@@ -182,7 +191,7 @@ k_prepare_small(const BasisDev *B, const FrameGeom *geoms, const int64_t *atom_o
         r.ws = pack_ws(w0, w1, w2, spec[a]);               //  through the barriers)
         slots[sidx] = r;
     }
-    for (int b = tid; b <= nbins; b += 1024) {             // first slot with bin >= b
+    for (int b = tid; b <= nbins; b += nt) {             // first slot with bin >= b
         int lo = 0, hi = natoms;
         while (lo < hi) {
             int mid = (lo + hi) >> 1;
@@ -2239,9 +2248,10 @@ k_eval(EvalArgs A) {
         __syncthreads();
         int n_pairs = n * (n - 1) / 2;
         for (int p = lane; p < n_pairs; p += WAVE) {
-            int bb = (int)((1.0f + sqrtf(1.0f + 8.0f * (float)p)) * 0.5f);
-            while (bb * (bb - 1) / 2 > p) --bb;
-            while ((bb + 1) * bb / 2 <= p) ++bb;
+            // (pair index -> (aa < bb) as in trio_walk_geom: hardware root + one guard each way, no loops)
+            int bb = (int)((1.0f + __builtin_amdgcn_sqrtf(fmaf(8.0f, (float)p, 1.0f))) * 0.5f);
+            bb -= (bb * (bb - 1) / 2 > p) ? 1 : 0;
+            bb += ((bb + 1) * bb / 2 <= p) ? 1 : 0;
             int aa = p - bb * (bb - 1) / 2;
             double rl = orr[aa], rm = orr[bb];
             double rn = norm3_rn(ox[bb] - ox[aa], oy[bb] - oy[aa], oz[bb] - oz[aa]);
@@ -2333,47 +2343,56 @@ k_eval(EvalArgs A) {
 __global__ void __launch_bounds__(256)
 k_eval_collect(EvalArgs A) {
     const int m = (int)((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3)) * 16 + (threadIdx.x >> 4), sub = threadIdx.x & 15;
-    if (m >= A.natoms) return;
-    const int cap = A.n3.cap, n = A.n3.cnt[m];
-    const N3Entry *mine = A.n3.ent + (size_t)m * cap;
-    double sx = 0.0, sy = 0.0, sz = 0.0;
-    // lanes <-> own entries; each lane scans its centre's list (independent loads: three dependent round trips per
-    // entry instead of three per list position)
-    for (int q = sub; q < n; q += 16) {
-        const int2 me = *(const int2 *)&mine[q].parent;
-        const int c = me.x;
-        int s0, s1, s2;
-        unpack3(me.y, s0, s1, s2);
-        const int back = pack3(-s0, -s1, -s2), nc = A.n3.cnt[c];
-        const N3Entry *theirs = A.n3.ent + (size_t)c * cap;
-        int hit = -1;
-        for (int r0 = 0; r0 < nc; r0 += 8) {                // eight entries' keys in flight together (a plain loop waits for each)
-            int2 key[8];
+    if (m < A.natoms) {
+        const int cap = A.n3.cap, n = A.n3.cnt[m];
+        const N3Entry *mine = A.n3.ent + (size_t)m * cap;
+        double sx = 0.0, sy = 0.0, sz = 0.0;
+        // lanes <-> own entries; each lane scans its centre's list (independent loads: three dependent round trips per
+        // entry instead of three per list position)
+        for (int q = sub; q < n; q += 16) {
+            const int2 me = *(const int2 *)&mine[q].parent;
+            const int c = me.x;
+            int s0, s1, s2;
+            unpack3(me.y, s0, s1, s2);
+            const int back = pack3(-s0, -s1, -s2), nc = A.n3.cnt[c];
+            const N3Entry *theirs = A.n3.ent + (size_t)c * cap;
+            int hit = -1;
+            for (int r0 = 0; r0 < nc; r0 += 8) {                // eight entries' keys in flight together (a plain loop waits for each)
+                int2 key[8];
 #pragma unroll
-            for (int u = 0; u < 8; u++) key[u] = *(const int2 *)&theirs[min(r0 + u, nc - 1)].parent;
-            asm volatile("" ::: "memory");
+                for (int u = 0; u < 8; u++) key[u] = *(const int2 *)&theirs[min(r0 + u, nc - 1)].parent;
+                asm volatile("" ::: "memory");
 #pragma unroll
-            for (int u = 0; u < 8; u++)
-                if (r0 + u < nc && key[u].x == m && key[u].y == back) hit = r0 + u;
+                for (int u = 0; u < 8; u++)
+                    if (r0 + u < nc && key[u].x == m && key[u].y == back) hit = r0 + u;
+            }
+            if (hit >= 0) {
+                const double *f = A.nbr_f + 3 * ((size_t)c * cap + hit);
+                sx += f[0]; sy += f[1]; sz += f[2];
+            }
         }
-        if (hit >= 0) {
-            const double *f = A.nbr_f + 3 * ((size_t)c * cap + hit);
-            sx += f[0]; sy += f[1]; sz += f[2];
-        }
+        for (int sh = 8; sh > 0; sh >>= 1) { sx += __shfl_xor(sx, sh, 16); sy += __shfl_xor(sy, sh, 16); sz += __shfl_xor(sz, sh, 16); }
+        if (sub == 0) { double *f = A.forces + 3 * (size_t)m; f[0] += sx; f[1] += sy; f[2] += sz; }
     }
-    for (int sh = 8; sh > 0; sh >>= 1) { sx += __shfl_xor(sx, sh, 16); sy += __shfl_xor(sy, sh, 16); sz += __shfl_xor(sz, sh, 16); }
-    if (sub == 0) { double *f = A.forces + 3 * (size_t)m; f[0] += sx; f[1] += sy; f[2] += sz; }
 }
 
 // per-frame sums of per-atom quantities: blockIdx.y = 0 energy (width 1), 1..6 virial components (width 6, if
 // given); deterministic tree
 // (flags_dst: the status words of the launches before it ride along behind the results, so that a small batch needs
 // one download)
+// (mirror: the caller's pinned result block, energies [nf] | virials [nf][6] | forces [n_force] | status words -- device-visible
+// host memory, written here directly so that a small batch needs no copy-engine transfer behind its last kernel)
 __global__ void k_frame_sum(const double *e_atom, const double *v_atom, const int64_t *atom_offsets, double *e_out,
-                            double *v_out, const int *flags_src, int *flags_dst) {
+                            double *v_out, const int *flags_src, int *flags_dst, double *mirror, const double *forces,
+                            int n_force) {
     __shared__ double part[1024];
     const int f = blockIdx.x, comp = (int)blockIdx.y - 1;
     if (flags_dst && f == 0 && comp < 0 && threadIdx.x < 4) flags_dst[threadIdx.x] = flags_src[threadIdx.x];
+    if (mirror && f == 0 && comp < 0) {
+        const int nf = gridDim.x;
+        if (forces) for (int q = threadIdx.x; q < n_force; q += blockDim.x) mirror[7 * (size_t)nf + q] = forces[q];
+        if (threadIdx.x < 4) ((int *)(mirror + 7 * (size_t)nf + n_force))[threadIdx.x] = flags_src[threadIdx.x];
+    }
     const double *src = comp < 0 ? e_atom : v_atom + comp;
     const int width = comp < 0 ? 1 : 6;
     double s = 0.0;
@@ -2384,7 +2403,10 @@ __global__ void k_frame_sum(const double *e_atom, const double *v_atom, const in
         if ((int)threadIdx.x < w) part[threadIdx.x] += part[threadIdx.x + w];
         __syncthreads();
     }
-    if (threadIdx.x == 0) { if (comp < 0) e_out[f] = part[0]; else v_out[(size_t)f * 6 + comp] = part[0]; }
+    if (threadIdx.x == 0) {
+        if (comp < 0) e_out[f] = part[0]; else v_out[(size_t)f * 6 + comp] = part[0];
+        if (mirror) { if (comp < 0) mirror[f] = part[0]; else mirror[gridDim.x + (size_t)f * 6 + comp] = part[0]; }
+    }
 }
 
 // ---------------------------------------------------------------------------------

@@ -78,6 +78,7 @@ class UFCalculator(_Base):
         self._c3 = (np.ascontiguousarray(np.concatenate([self.trio_potentials[t].ravel()
                                                          for t in basis.interactions_map[3]]))
                     if self.trio_potentials else np.zeros(1))
+        self._pc = (_lib._addr(self._c1), _lib._addr(self._c2), _lib._addr(self._c3))     # (the arrays live as long as self)
 
     degree = property(lambda self: self.bspline_config.degree)
     element_list = property(lambda self: self.bspline_config.element_list)
@@ -99,13 +100,18 @@ class UFCalculator(_Base):
         batch = _lib.FrameBatch(atoms_list)
         e = np.empty(batch.n_frames)
         f = np.empty((batch.n_atoms, 3)) if forces else None
-        args = (db.handle, C.byref(batch.struct), _lib._p(batch.pos), _lib._p(batch.z), _lib._p(self._c1),
-                _lib._p(self._c2), _lib._p(self._c3), _lib._p(e), _lib._p(f))
+        addr = _lib._addr                     # (plain ints: the host side of an MD-step call is as long as its kernels)
+        args = (db.handle, C.byref(batch.struct), addr(batch.pos), addr(batch.z), self._pc[0], self._pc[1], self._pc[2],
+                addr(e), addr(f))
         if virial:
             v = np.empty((batch.n_frames, 6))
-            ctx.check(ctx.lib.uf3_eval_virial(*args, _lib._p(v)))
+            rc = ctx.lib.uf3_eval_virial(*args, addr(v))
+            if rc:
+                ctx.check(rc)
             return e, f, batch.offsets, v
-        ctx.check(ctx.lib.uf3_eval(*args))
+        rc = ctx.lib.uf3_eval(*args)
+        if rc:
+            ctx.check(rc)
         return e, f, batch.offsets
 
     def evaluate_atom_range(self, atoms, atom_begin, atom_end, forces=True, virial=False):
