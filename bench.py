@@ -180,7 +180,7 @@ def main():
         # HBM bytes per launch from the PMC passes of this same command (separate rocprofv3 --pmc FETCH_SIZE /
         # WRITE_SIZE runs, summary committed under profiles/); null when the workload differs
         traffic, traffic_source = None, None
-        for name in ("round2_hbm_counters.json", "round1_hbm_counters.json"):
+        for name in ("round3_hbm_counters.json", "round2_hbm_counters.json", "round1_hbm_counters.json"):
             try:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
                 if pmc["workload"] == dict(atoms_per_frame=n_atoms, n_feat=F, frames_per_step=B):

@@ -48,6 +48,9 @@ def main(run, prefix):
     shutil.copy(os.path.join(run, "bench_default.json"), prefix + "_bench_n1.json")
     if os.path.exists(os.path.join(run, "kernels.json")):
         shutil.copy(os.path.join(run, "kernels.json"), prefix + "_secondary_kernels.json")
+    extra = glob.glob(os.path.join(run, "trace_extra", "*_kernel_stats.csv"))
+    if extra:       # kernel statistics of the default run WITH the sub-lines of the other BASELINE configurations
+        shutil.copy(extra[0], prefix + "_kernel_stats_all_configs.csv")
 
     with open(stats, newline="") as fh:
         feat = [r for r in csv.DictReader(fh) if "k_featurize" in r["Name"]]
