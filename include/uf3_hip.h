@@ -108,12 +108,14 @@ int uf3_ctx_timing_read(uf3_ctx *ctx, double *featurize_ms, int64_t *featurize_l
 
 int uf3_basis_create(uf3_ctx *ctx, const uf3_basis_spec *spec, uf3_basis **out);
 void uf3_basis_destroy(uf3_basis *basis);
-/* Diagnostics: which featurizer specialisations the basis uses.  Bit 0: one-body + pair blocks; bits 1..5: 3-body
- * blocks on the generic output-stationary kernels ((symmetry images, 64-column chunks) = (1,1) (1,2) (2,1) (2,2)
- * (6,1)); bit 6: 3-body blocks whose window of non-trimmed bins is small enough (3*ext_l*ext_m <= 32, ext_n <= 16)
- * for the fp64 matrix-core kernel with two 16-row tiles; bits 8 / 9: wider windows (<= 64 / <= 128 rows) on the same
- * kernel with four / eight row tiles.  Setting UF3_NO_MFMA_FEAT in the environment before uf3_basis_create keeps
- * every block on the generic kernels (used by the tests to compare the two paths). */
+/* Diagnostics: which featurizer specialisations the basis uses.  Bit 0: one-body + pair blocks (the launch that also
+ * builds the 3-body neighbour lists); bits 1..5: 3-body blocks on the generic output-stationary kernels ((symmetry images,
+ * 64-column chunks) = (1,1) (1,2) (2,1) (2,2) (6,1)); bits 6..9: 3-body blocks whose window of non-trimmed bins runs on the
+ * fp64 matrix cores, rows (component, l) x columns (n, m) in 16 x 16 tiles: (row tiles, column tiles) = (1,1) (1,2) (1,<=4)
+ * (<=2,<=6).  Within bit 7 the 3 x 3 x <=9 windows of the reference's default trims stage grouped n windows, within bit 9
+ * the wide windows run banded; both are chosen per block by uf3_basis_create.  Setting
+ * UF3_NO_MFMA_FEAT in the environment before uf3_basis_create keeps every block on the generic kernels (used by the tests
+ * to compare the two paths). */
 int uf3_basis_featurizer_modes(const uf3_basis *basis, int32_t *mask);
 
 /*
@@ -134,6 +136,26 @@ int uf3_gram(uf3_ctx *ctx, const double *x, const double *y, int64_t n_rows, int
              int64_t ld, int accumulate, double *gram, double *ord);
 int uf3_gram_dev(uf3_ctx *ctx, const double *d_x, const double *d_y, int64_t n_rows,
                  int32_t n_feat, int64_t ld, int accumulate, double *d_gram, double *d_ord);
+
+/*
+ * The bookkeeping around the Gram pieces of a device-resident fit (what the reference does on the host in
+ * dataframe_to_tuples, least_squares.py:666-713, freeze_columns / VarianceRecorder, :19-67, :296-304, :817-890), on the
+ * context's stream, nothing synchronises:
+ *   uf3_fit_rows_dev   energy rows of a batch divided by their frames' atom counts (per-atom normalisation, :697-700; in
+ *                      place), and the target moments: moments[1..2] += (sum, sum of squares) of the FROZEN energies
+ *                      y_e - x_e[:, frozen] . c_frozen, moments[4..5] += those of the force targets (y_f may be NULL).
+ *                      moments[0] / [3] (the counts) are the caller's.
+ *   uf3_fit_pack_dev   flat [G_e (F x F) | G_f (F x F) | o_e (F) | o_f (F) | m_e (3) | m_f (3)] over all F columns ->
+ *                      the same layout over the n_keep unfrozen columns, frozen columns folded out on the Gram level
+ *                      (o_keep -= G[keep, frozen] . c_frozen): the additive pieces one rank hands to the all-reduce.
+ * keep / frozen are int64 column indices in HBM, c_frozen the frozen coefficients in HBM.
+ */
+int uf3_fit_rows_dev(uf3_ctx *ctx, int32_t n_frames, int32_t n_feat, double *d_x_e, const double *d_atom_counts,
+                     const double *d_y_e, const double *d_y_f, int64_t n_y_f, const int64_t *d_frozen,
+                     const double *d_c_frozen, int32_t n_frozen, double *d_moments /*[6]*/);
+int uf3_fit_pack_dev(uf3_ctx *ctx, int32_t n_feat, const double *d_flat, const int64_t *d_keep, int32_t n_keep,
+                     const int64_t *d_frozen, const double *d_c_frozen, int32_t n_frozen, double n_energy_rows,
+                     double n_force_rows, double *d_packed);
 
 /*
  * Energy and forces of a fitted model on a batch of frames.

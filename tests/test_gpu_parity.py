@@ -338,6 +338,55 @@ def test_two_element_fit_in_chunks_through_the_tiled_gram_kernel():
     assert rel_err(pred, x_f @ ref["coefficients"]) < 1e-6
 
 
+def test_fit_bookkeeping_entries_against_numpy():
+    """uf3_fit_rows_dev / uf3_fit_pack_dev (per-atom normalisation, moments of the frozen energies and of the force targets,
+    frozen columns folded out of the packed pieces) against the reference's host arithmetic restated in NumPy
+    (least_squares.py:697-700, :296-304, :817-890)."""
+    import ctypes as C
+    import torch
+    dev = torch.device("cuda", 0)
+    ctx = _lib.get_context(0)
+    prev = ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+    try:
+        rng = np.random.default_rng(5)
+        nf, F, n_yf = 37, 61, 10007
+        x_e = rng.normal(size=(nf, F)); counts = rng.integers(3, 90, nf).astype(float)
+        y_e = rng.normal(size=nf); y_f = rng.normal(size=n_yf)
+        frozen = np.array([0, 7, 8, 40], dtype=np.int64); c_fro = rng.normal(size=4)
+        keep = np.array([q for q in range(F) if q not in set(frozen.tolist())], dtype=np.int64)
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)          # noqa: E731
+        d_x, d_c, d_ye, d_yf, d_fro, d_cf, d_keep = t(x_e), t(counts), t(y_e), t(y_f), t(frozen), t(c_fro), t(keep)
+        flat = rng.normal(size=2 * F * F + 2 * F + 6)
+        flat[-6:] = 0.0
+        d_flat = t(flat)
+        ctx.check(ctx.lib.uf3_fit_rows_dev(ctx.handle, nf, F, d_x.data_ptr(), d_c.data_ptr(), d_ye.data_ptr(), d_yf.data_ptr(), n_yf,
+                                           d_fro.data_ptr(), d_cf.data_ptr(), 4, d_flat[-6:].data_ptr()))
+        x_n = x_e / counts[:, None]
+        assert np.array_equal(d_x.cpu().numpy(), x_n)                           # one division per entry: the same bits
+        y_fro = y_e - x_n[:, frozen] @ c_fro
+        m = d_flat[-6:].cpu().numpy()
+        assert np.allclose(m[[1, 2, 4, 5]], [y_fro.sum(), (y_fro ** 2).sum(), y_f.sum(), (y_f ** 2).sum()], rtol=1e-12, atol=1e-12)
+        K = len(keep)
+        out = torch.empty(2 * K * K + 2 * K + 6, dtype=torch.float64, device=dev)
+        ctx.check(ctx.lib.uf3_fit_pack_dev(ctx.handle, F, d_flat.data_ptr(), d_keep.data_ptr(), K, d_fro.data_ptr(), d_cf.data_ptr(), 4,
+                                           float(nf), float(n_yf), out.data_ptr()))
+        got = out.cpu().numpy()
+        full = d_flat.cpu().numpy()
+        for which in range(2):
+            G = full[which * F * F:(which + 1) * F * F].reshape(F, F)
+            o = full[2 * F * F + which * F:2 * F * F + (which + 1) * F]
+            assert np.array_equal(got[which * K * K:(which + 1) * K * K].reshape(K, K), G[np.ix_(keep, keep)])
+            assert np.allclose(got[2 * K * K + which * K:2 * K * K + (which + 1) * K], o[keep] - G[np.ix_(keep, frozen)] @ c_fro, rtol=1e-13, atol=1e-13)
+        assert np.array_equal(got[-6:], [nf, m[1], m[2], n_yf, m[4], m[5]])
+        # no frozen columns, no force targets
+        d_flat2 = t(np.zeros(2 * F * F + 2 * F + 6))
+        ctx.check(ctx.lib.uf3_fit_rows_dev(ctx.handle, nf, F, t(x_e).data_ptr(), d_c.data_ptr(), d_ye.data_ptr(), None, 0, None, None, 0,
+                                           d_flat2[-6:].data_ptr()))
+        assert np.allclose(d_flat2[-6:].cpu().numpy(), [0, y_e.sum(), (y_e ** 2).sum(), 0, 0, 0], rtol=1e-12)
+    finally:
+        ctx.restore_stream(prev)
+
+
 def test_ragged_batch_of_large_frames_equals_per_frame_calls():
     """32 frames of 1 000 - 10 000 atoms (mixed sizes, W/Mo) in one batch == one call per frame."""
     basis = synthetic.notebook_basis(['Mo', 'W'])

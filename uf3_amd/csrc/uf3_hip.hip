@@ -1621,6 +1621,37 @@ extern "C" int uf3_gram(uf3_ctx *c, const double *x, const double *y, int64_t n_
     return UF3_OK;
 }
 
+// ------------------------------------------------------------------------------ fit bookkeeping
+extern "C" int uf3_fit_rows_dev(uf3_ctx *c, int32_t n_frames, int32_t n_feat, double *d_x_e, const double *d_counts,
+                                const double *d_y_e, const double *d_y_f, int64_t n_y_f, const int64_t *d_frozen,
+                                const double *d_c_frozen, int32_t n_frozen, double *d_moments) {
+    if (!c) return fail(nullptr, UF3_EINVAL, "null ctx");
+    if (n_frames < 0 || n_feat < 1 || !d_x_e || !d_counts || !d_y_e || !d_moments || n_y_f < 0 || n_frozen < 0 ||
+        (n_frozen && (!d_frozen || !d_c_frozen)))
+        return fail(c, UF3_EINVAL, "uf3_fit_rows_dev: bad argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    const int64_t f_blocks = d_y_f ? (n_y_f + 4095) / 4096 : 0;
+    if (n_frames + f_blocks == 0) return UF3_OK;
+    hipLaunchKernelGGL(k_fit_rows, dim3((unsigned)(n_frames + f_blocks)), dim3(256), 0, c->stream, n_frames, n_feat, d_x_e, d_counts,
+                       d_y_e, d_y_f, n_y_f, d_frozen, d_c_frozen, n_frozen, d_moments);
+    HIPCHK(c, hipGetLastError());
+    return UF3_OK;
+}
+
+extern "C" int uf3_fit_pack_dev(uf3_ctx *c, int32_t n_feat, const double *d_flat, const int64_t *d_keep, int32_t n_keep,
+                                const int64_t *d_frozen, const double *d_c_frozen, int32_t n_frozen, double n_energy_rows,
+                                double n_force_rows, double *d_packed) {
+    if (!c) return fail(nullptr, UF3_EINVAL, "null ctx");
+    if (n_feat < 1 || n_keep < 1 || n_keep > n_feat || !d_flat || !d_keep || !d_packed || n_frozen < 0 ||
+        (n_frozen && (!d_frozen || !d_c_frozen)))
+        return fail(c, UF3_EINVAL, "uf3_fit_pack_dev: bad argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    hipLaunchKernelGGL(k_fit_pack, dim3((unsigned)n_keep, 2), dim3(256), 0, c->stream, n_feat, d_flat, d_keep, n_keep, d_frozen,
+                       d_c_frozen, n_frozen, n_energy_rows, n_force_rows, d_packed);
+    HIPCHK(c, hipGetLastError());
+    return UF3_OK;
+}
+
 // ------------------------------------------------------------------------------ neighbour debug
 extern "C" int uf3_neighbors_debug(uf3_basis *b, const uf3_frames *fr, const double *pos, const int32_t *z,
                                    int64_t *pair_count, int64_t *pair_ij, int64_t pair_cap, int64_t *n3_count,

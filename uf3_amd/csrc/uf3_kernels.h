@@ -2699,6 +2699,71 @@ __global__ void k_gram_mirror(double *gram, int n_feat) {
 
 
 // ---------------------------------------------------------------------------------
+// fit bookkeeping around the Gram pieces (uf3_fit_rows_dev / uf3_fit_pack_dev)
+// ---------------------------------------------------------------------------------
+// block 0 .. n_frames - 1: one energy row each -- per-atom normalisation in place, the frozen energy of the frame; the
+// blocks behind them: chunks of the force targets.  Partial sums meet in moments[] through fp64 atomics.
+__global__ void __launch_bounds__(256)
+k_fit_rows(int n_frames, int n_feat, double *x_e, const double *counts, const double *y_e, const double *y_f, int64_t n_y_f,
+           const int64_t *frozen, const double *c_frozen, int n_frozen, double *moments) {
+    __shared__ double part[2][256];
+    const int tid = threadIdx.x;
+    double s1 = 0.0, s2 = 0.0;
+    if ((int)blockIdx.x < n_frames) {
+        const int f = blockIdx.x;
+        double *row = x_e + (size_t)f * n_feat;
+        const double n_at = counts[f];
+        for (int q = tid; q < n_feat; q += 256) row[q] = row[q] / n_at;
+        __syncthreads();
+        double dot = 0.0;
+        for (int q = tid; q < n_frozen; q += 256) dot += row[frozen[q]] * c_frozen[q];
+        part[0][tid] = dot;
+        __syncthreads();
+        for (int w = 128; w > 0; w >>= 1) { if (tid < w) part[0][tid] += part[0][tid + w]; __syncthreads(); }
+        if (tid == 0) { const double yf = y_e[f] - part[0][0]; unsafeAtomicAdd(moments + 1, yf); unsafeAtomicAdd(moments + 2, yf * yf); }
+        return;
+    }
+    if (!y_f) return;
+    const int64_t chunk = (int64_t)(blockIdx.x - n_frames) * 256 * 16;
+    for (int u = 0; u < 16; u++) {
+        const int64_t q = chunk + (int64_t)u * 256 + tid;
+        if (q < n_y_f) { const double v = y_f[q]; s1 += v; s2 += v * v; }
+    }
+    part[0][tid] = s1; part[1][tid] = s2;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if (tid < w) { part[0][tid] += part[0][tid + w]; part[1][tid] += part[1][tid + w]; }
+        __syncthreads();
+    }
+    if (tid == 0) { unsafeAtomicAdd(moments + 4, part[0][0]); unsafeAtomicAdd(moments + 5, part[1][0]); }
+}
+
+// packed [G_e | G_f | o_e | o_f | m_e | m_f] over the unfrozen columns; blockIdx.y = 0 energy pieces, 1 force pieces;
+// blockIdx.x = row of the packed Gram (the thread block copies the row and folds the frozen columns into the ordinate)
+__global__ void __launch_bounds__(256)
+k_fit_pack(int n_feat, const double *flat, const int64_t *keep, int n_keep, const int64_t *frozen, const double *c_frozen,
+           int n_frozen, double n_e, double n_f, double *packed) {
+    __shared__ double part[256];
+    const int tid = threadIdx.x, which = blockIdx.y, i = blockIdx.x;
+    const size_t F = (size_t)n_feat, K = (size_t)n_keep;
+    const double *gram = flat + which * F * F, *ordn = flat + 2 * F * F + which * F;
+    double *g_out = packed + which * K * K, *o_out = packed + 2 * K * K + which * K;
+    const double *row = gram + (size_t)keep[i] * F;
+    for (int j = tid; j < n_keep; j += 256) g_out[(size_t)i * K + j] = row[keep[j]];
+    double dot = 0.0;
+    for (int q = tid; q < n_frozen; q += 256) dot += row[frozen[q]] * c_frozen[q];
+    part[tid] = dot;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) { if (tid < w) part[tid] += part[tid + w]; __syncthreads(); }
+    if (tid == 0) o_out[i] = ordn[keep[i]] - part[0];
+    if (i == 0 && tid < 3) {
+        const double *m_in = flat + 2 * F * F + 2 * F + 3 * which;
+        double *m_out = packed + 2 * K * K + 2 * K + 3 * which;
+        m_out[tid] = tid == 0 ? (which == 0 ? n_e : n_f) : m_in[tid];
+    }
+}
+
+// ---------------------------------------------------------------------------------
 // neighbour index dump (debug / parity): unsorted tuples, the host sorts them
 // ---------------------------------------------------------------------------------
 __global__ void __launch_bounds__(64)

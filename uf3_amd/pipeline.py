@@ -14,7 +14,9 @@ over all F columns; the frozen columns are folded out on the device when the pie
 packed buffer of the unfrozen columns (2 F'^2 + 2 F' + 6 doubles) is what ``parallel.allreduce_packed`` sums
 over the ranks -- no host copy before the collective.
 
-PyTorch is used only as the owner of the device buffers and of the stream.
+PyTorch is used only as the owner of the device buffers and of the stream: the arithmetic around the Gram kernels
+(normalisation, target moments, the fold of the frozen columns) is the library's (``uf3_fit_rows_dev``,
+``uf3_fit_pack_dev``).
 """
 import ctypes as C
 
@@ -59,11 +61,6 @@ class DeviceFitAccumulator:
         self.ctx.check(self.ctx.lib.uf3_gram_dev(self.ctx.handle, C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr()),
                                                  x.shape[0], self.n_feat, self.n_feat, 1, C.c_void_p(gram.data_ptr()),
                                                  C.c_void_p(ordn.data_ptr())))
-
-    def _moments(self, y, into, which):
-        # sums on the device, the count on the host (no scalar upload inside the loop)
-        into[1:] += self.torch.stack([y.sum(), (y * y).sum()])
-        self._counts[which] += float(y.numel())
 
     def add_frames(self, frames, energies, forces=None):
         """frames: list of Atoms; energies [n]; forces: list of (N_i, 3) arrays (required when with_forces).
@@ -112,14 +109,18 @@ class DeviceFitAccumulator:
             x_f = torch.empty((n_atoms * 3, self.n_feat), dtype=torch.float64, device=self.dev)
         self.fz.featurize_device(frames_struct, d_pos.data_ptr(), d_z.data_ptr(), x_e.data_ptr(),
                                  x_f.data_ptr() if self.with_forces else None)
-        x_e.div_(d_counts[:, None])
+        # per-atom normalisation of the energy rows (least_squares.py:697-700), moments of the FROZEN energies and of the
+        # force targets (:296-304): one kernel of the library (uf3_fit_rows_dev), sums on the device, counts on the host
+        n_yf = int(d_yf.numel()) if self.with_forces else 0
+        self.ctx.check(self.ctx.lib.uf3_fit_rows_dev(
+            self.ctx.handle, n_frames, self.n_feat, x_e.data_ptr(), d_counts.data_ptr(), d_ye.data_ptr(),
+            d_yf.data_ptr() if self.with_forces else None, n_yf, self._frozen.data_ptr() if self._frozen.numel() else None,
+            self._frozen_c.data_ptr() if self._frozen.numel() else None, int(self._frozen.numel()), self.m_e.data_ptr()))
+        self._counts[0] += float(n_frames)
+        self._counts[1] += float(n_yf)
         self._gram(x_e, d_ye, self.gram_e, self.ord_e)
-        # moments of the FROZEN energies (least_squares.py:296-304)
-        y_fro = d_ye - x_e.index_select(1, self._frozen) @ self._frozen_c if self._frozen.numel() else d_ye
-        self._moments(y_fro, self.m_e, 0)
         if self.with_forces:
             self._gram(x_f.view(-1, self.n_feat), d_yf, self.gram_f, self.ord_f)
-            self._moments(d_yf, self.m_f, 1)
 
     def packed(self):
         """Device tensor [G_e | G_f | o_e | o_f | m_e | m_f] on the UNFROZEN columns (F' of them): the additive
@@ -127,21 +128,17 @@ class DeviceFitAccumulator:
         Gram level: X_m^T (y - X_f c_f) = o_m - G[m, f] c_f."""
         torch = self.torch
         self.ctx.synchronize()                  # verdicts on the asynchronous featurizer calls (RetryError)
-        keep, fro, c_f = self._keep, self._frozen, self._frozen_c
-
-        def fold(gram, ordn):
-            rows = gram.index_select(0, keep)
-            o = ordn.index_select(0, keep)
-            if fro.numel():
-                o = o - rows.index_select(1, fro) @ c_f
-            return rows.index_select(1, keep).reshape(-1), o
-
-        ge, oe = fold(self.gram_e, self.ord_e)
-        gf, of = fold(self.gram_f, self.ord_f)
-        n = torch.tensor(self._counts, dtype=torch.float64).to(self.dev)
-        m_e = torch.cat([n[0:1], self.m_e[1:]])
-        m_f = torch.cat([n[1:2], self.m_f[1:]])
-        return torch.cat([ge, gf, oe, of, m_e, m_f])
+        n_keep, n_fro = int(self._keep.numel()), int(self._frozen.numel())
+        out = torch.empty(2 * n_keep * n_keep + 2 * n_keep + 6, dtype=torch.float64, device=self.dev)
+        prev = self.ctx.set_stream(torch.cuda.current_stream(self.dev).cuda_stream)     # (ordered with the caller's use of `out`)
+        try:
+            self.ctx.check(self.ctx.lib.uf3_fit_pack_dev(
+                self.ctx.handle, self.n_feat, self.flat.data_ptr(), self._keep.data_ptr(), n_keep,
+                self._frozen.data_ptr() if n_fro else None, self._frozen_c.data_ptr() if n_fro else None, n_fro,
+                float(self._counts[0]), float(self._counts[1]), out.data_ptr()))
+        finally:
+            self.ctx.restore_stream(prev)
+        return out
 
     def pieces(self):
         """Additive pieces of this rank as host arrays (what ``WeightedLinearModel.fit_from_pieces`` takes)."""
