@@ -197,6 +197,21 @@ int uf3_eval_atoms_dev(uf3_basis *basis, const uf3_frames *frames, const double 
                        int64_t atom_end, double *d_energies, double *d_forces, double *d_virials);
 
 /*
+ * The share of the CENTRES [atom_begin, atom_end): their one-body, pair and centre-role triplet energies and strain
+ * derivative (as above), their pair forces, and what their triplets put on EVERY atom -- each triplet is evaluated once, at
+ * its centre; rows of atoms inside the range or in its halo (the atoms its 3-body lists mention) come back non-zero, all
+ * others zero.  Shares over disjoint ranges add up to uf3_eval_virial's results like those of uf3_eval_atoms, at a third
+ * of the triplet work: what a rank of a decomposed frame computes before the one sum-reduce of
+ * [energy | strain derivative | forces] (uf3_amd/parallel.py: sharded_evaluate).  forces / virials may be NULL.
+ */
+int uf3_eval_centres(uf3_basis *basis, const uf3_frames *frames, const double *pos, const int32_t *z,
+                     const double *c1, const double *c2, const double *c3, int64_t atom_begin, int64_t atom_end,
+                     double *energies, double *forces, double *virials);
+int uf3_eval_centres_dev(uf3_basis *basis, const uf3_frames *frames, const double *d_pos, const int32_t *d_z,
+                         const double *c1, const double *c2, const double *c3 /* host */, int64_t atom_begin,
+                         int64_t atom_end, double *d_energies, double *d_forces, double *d_virials);
+
+/*
  * Neighbour indices in the reference's supercell numbering (ghost index =
  * image_rank * N + atom, geometry.py:108-149), single frame, host buffers.
  *   pair_ij [P][pair_cap][2]  2-body (i, j) per pair block, row-major sorted; pair_count [P]

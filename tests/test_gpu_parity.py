@@ -766,6 +766,23 @@ def test_atom_range_shares_add_up_to_the_frame():
         lo, hi = parallel.shard_range(n, r, world)
         assert rel_err(fs[lo:hi], f[lo:hi]) < 1e-12
         assert not fs[:lo].any() and not fs[hi:].any()
+    # blocks of CENTRES (uf3_eval_centres: every triplet once, at its centre; what it puts on atoms of other blocks comes back
+    # in the same array): the shares add up to the oracle's and to the whole-frame results, rows far from the block are zero
+    for w in (3, 8):
+        cs = [calc.evaluate_centre_range(atoms, *parallel.shard_range(n, r, w), virial=True) for r in range(w)]
+        assert abs(sum(s[0] for s in cs) - e_ref) <= 1e-10 * abs(e_ref) and abs(sum(s[0] for s in cs) - e[0]) <= 1e-12 * abs(e[0])
+        assert rel_err(sum(s[1] for s in cs), f_ref) < 1e-10 and worst_elementwise(sum(s[1] for s in cs), f_ref) <= 1.0
+        assert rel_err(sum(s[1] for s in cs), f) < 1e-12 and rel_err(sum(s[2] for s in cs), v[0]) < 1e-12
+        for r, (es, fs, _) in enumerate(cs):
+            lo, hi = parallel.shard_range(n, r, w)
+            assert abs(es - shares[r][0]) <= 1e-12 * abs(es) if w == 3 else True       # the same centres' energies
+            touched = np.flatnonzero(np.abs(fs).sum(axis=1) > 0)
+            assert set(range(lo, hi)) <= set(touched.tolist())
+            assert len(touched) < n or w == 3                                            # (a halo, not the whole frame)
+    cs2 = [calc.evaluate_centre_range(atoms, *parallel.shard_range(n, r, 3), virial=True) for r in range(3)]   # repeatable
+    assert all(np.array_equal(a[1], b2[1]) and a[0] == b2[0] for a, b2 in zip(cs2, [calc.evaluate_centre_range(atoms, *parallel.shard_range(n, r, 3), virial=True) for r in range(3)]))
+    e0c, f0c, _ = calc.evaluate_centre_range(atoms, 10, 10)
+    assert e0c == 0.0 and not f0c.any()
     os.environ["UF3_EVAL_GATHER"] = "1"                                       # whole frame through the gather route
     try:
         e_g, f_g, _, v_g = calc.evaluate_frames([atoms], virial=True)

@@ -98,15 +98,15 @@ def main():
                          atom_steps_per_s=round(batch.n_atoms / (wall * 1e-3)), energy=float(d_e.item()),
                          net_force=float(np.abs(f.sum(axis=0)).max()), max_force=float(np.abs(f).max()))
     # ---- one large frame decomposed over ranks (N4): what ONE rank of a world of 1 / 2 / 4 / 8 spends on its block of the
-    # 50k-atom ternary frame (uf3_eval_atoms: cell list of the frame, 3-body lists of the block + its halo only, gather
-    # evaluation of the block).  The frame is in lattice order (x slowest), so an index block is a slab.
+    # 50k-atom ternary frame (uf3_eval_centres: cell list of the frame, every triplet centred in the block once, 3-body lists
+    # of the block's halo, collection pass over block + halo).  The frame is in lattice order (x slowest), so an index block is a slab.
     if not args.quick:
         name, atoms, basis = cases[-1]
         d_v = torch.empty((6,), dtype=torch.float64, device=dev)
         dec = {}
         for world in (1, 2, 4, 8):
             lo, hi = 0, (batch.n_atoms + world - 1) // world
-            call = lambda: ctx.check(ctx.lib.uf3_eval_atoms_dev(  # noqa: E731
+            call = lambda: ctx.check(ctx.lib.uf3_eval_centres_dev(  # noqa: E731
                 db.handle, C.byref(batch.struct), C.c_void_p(d_pos.data_ptr()), C.c_void_p(d_z.data_ptr()),
                 _lib._p(calc._c1), _lib._p(calc._c2), _lib._p(calc._c3), lo, hi, C.c_void_p(d_e.data_ptr()),
                 C.c_void_p(d_f.data_ptr()), C.c_void_p(d_v.data_ptr())))

@@ -783,6 +783,25 @@ static int n3_tune(uf3_ctx *c, const N3Lists &n3, int natoms) {
     return UF3_OK;
 }
 
+// 3-body lists of the HALO of the block of atoms [lo, hi), whose own lists exist: the atoms outside the block that those
+// lists mention are marked and collected on the device (c->halo: marks [natoms] | indices [natoms] | count), then built
+static int build_halo_lists(uf3_basis *b, const Prepared &P, const N3Lists &n3, const double *d_pos, int lo, int hi) {
+    uf3_ctx *c = b->ctx;
+    hipStream_t st = c->stream;
+    const int natoms = P.natoms, nb_ = hi - lo;
+    HIPCHK(c, c->halo.ensure(sizeof(int) * ((size_t)natoms + 4)));
+    int *mark = c->halo.as<int>(), *range = mark + natoms;
+    HIPCHK(c, hipMemsetAsync(mark, 0, sizeof(int) * (size_t)natoms, st));
+    if (nb_ <= 0 || natoms - nb_ <= 0) return UF3_OK;
+    const size_t lds = (size_t)n3.cap * (8 + 32 + 16);
+    hipLaunchKernelGGL(k_mark_halo, dim3((nb_ + 3) / 4), dim3(256), 0, st, n3, lo, hi, mark, range);
+    // (one workgroup per atom outside the block; the unmarked ones leave at once)
+    hipLaunchKernelGGL(k_build_n3, dim3(natoms - nb_), dim3(64), lds, st, b->dev, P.geoms, P.frame_of, P.cl, n3, d_pos,
+                       natoms, c->flags.as<int>() + 1, 0, (const int *)mark, (const int *)range);
+    HIPCHK(c, hipGetLastError());
+    return UF3_OK;
+}
+
 // cell list + 3-body neighbour lists for a batch (positions / species already in HBM)
 // defer_check: once the list capacity is tuned, do not wait for the build's flags; the caller reads them together
 // with its results and repeats the call if the lists overflowed (all kernels are safe on clipped lists)
@@ -917,17 +936,11 @@ static int prepare(uf3_basis *b, const uf3_frames *fr, const double *d_pos, cons
             else if (n3_hi > n3_lo) {
                 // the block, then the atoms its lists mention (marked and collected on the device), nothing else
                 const int nb_ = (int)(n3_hi - n3_lo);
-                HIPCHK(c, c->halo.ensure(sizeof(int) * (2 * (size_t)natoms + 4)));
-                int *mark = c->halo.as<int>(), *which = mark + natoms, *n_which = which + natoms;
-                HIPCHK(c, hipMemsetAsync(mark, 0, sizeof(int) * (size_t)natoms, st));
-                HIPCHK(c, hipMemsetAsync(n_which, 0, sizeof(int), st));
                 HIPCHK(c, hipMemsetAsync(P.n3.cnt, 0, sizeof(int) * (size_t)natoms, st));      // lists not built: empty
                 hipLaunchKernelGGL(k_build_n3, dim3(nb_), dim3(64), lds, st, b->dev, P.geoms, P.frame_of, P.cl, P.n3,
                                    d_pos, natoms, flags + 1, (int)n3_lo, (const int *)nullptr, (const int *)nullptr);
-                hipLaunchKernelGGL(k_mark_halo, dim3(nb_), dim3(64), 0, st, P.n3, (int)n3_lo, (int)n3_hi, mark, which, n_which);
-                // (the halo's size is known on the device only: a grid of the worst case, surplus workgroups leave at once)
-                hipLaunchKernelGGL(k_build_n3, dim3(natoms - nb_), dim3(64), lds, st, b->dev, P.geoms, P.frame_of, P.cl,
-                                   P.n3, d_pos, natoms, flags + 1, 0, (const int *)which, (const int *)n_which);
+                int rh = build_halo_lists(b, P, P.n3, d_pos, (int)n3_lo, (int)n3_hi);
+                if (rh) return rh;
             }
             HIPCHK(c, hipGetLastError());
             if (defer_check && c->n3_tuned) { P.deferred = true; return UF3_OK; }
@@ -1253,7 +1266,7 @@ extern "C" int uf3_featurize(uf3_basis *b, const uf3_frames *fr, const double *p
 static int eval_impl(uf3_basis *b, const uf3_frames *fr, const double *d_pos, const int32_t *d_z, const double *c1,
                      const double *c2, const double *c3, double *d_energies, double *d_forces, double *d_virials,
                      int64_t atom_begin = 0, int64_t atom_end = -1, int *deferred_cap = nullptr, int *flags_tail = nullptr,
-                     double *mirror = nullptr) {
+                     double *mirror = nullptr, bool centre_share = false) {
     uf3_ctx *c = b->ctx;
     if (!d_pos || !d_z || !c1 || !d_energies) return fail(c, UF3_EINVAL, "uf3_eval: null argument");
     if ((b->c2_len && !c2) || (b->c3_len && !c3)) return fail(c, UF3_EINVAL, "uf3_eval: missing coefficients");
@@ -1265,7 +1278,11 @@ static int eval_impl(uf3_basis *b, const uf3_frames *fr, const double *d_pos, co
     if (total >= 0 && (atom_begin < 0 || (atom_end >= 0 && (atom_begin > atom_end || atom_end > total))))
         return fail(c, UF3_EINVAL, "uf3_eval_atoms: atom range outside the batch");
     const bool whole = atom_begin == 0 && (atom_end < 0 || atom_end == total);
-    const bool two_pass = whole && d_forces && b->host.T > 0 && !getenv("UF3_EVAL_GATHER");
+    // a block of CENTRES (uf3_eval_centres): the two-pass route on the block -- every triplet once, at its centre inside the
+    // block; the collection pass then serves the block and its halo (the atoms the block's lists mention), whose lists are
+    // built for that purpose.  Rows of all other atoms stay zero; the shares of disjoint blocks add up to the frame.
+    const bool centres = centre_share && !whole && d_forces && b->host.T > 0 && atom_end > atom_begin;
+    const bool two_pass = (whole || centres) && d_forces && b->host.T > 0 && !getenv("UF3_EVAL_GATHER");
     const bool fuse = two_pass && c->n3_tuned && c->n3_cap > 0 && !getenv("UF3_SEPARATE_N3");
     Prepared P;
     int rc = prepare(b, fr, d_pos, d_z, !fuse, P, deferred_cap != nullptr, atom_begin, whole ? -1 : atom_end);
@@ -1293,9 +1310,7 @@ static int eval_impl(uf3_basis *b, const uf3_frames *fr, const double *d_pos, co
     if (atom_end < 0) atom_end = P.natoms;
     if (atom_begin < 0 || atom_begin > atom_end || atom_end > P.natoms)
         return fail(c, UF3_EINVAL, "uf3_eval_atoms: atom range outside the batch");
-    const bool partial = atom_begin != 0 || atom_end != P.natoms;
-    if (partial)    // atoms outside the range contribute zero to the per-frame sums
-        HIPCHK(c, hipMemsetAsync(c->e_atom.p, 0, 8 * (size_t)P.natoms * (d_virials ? 7 : 1), st));
+    // (atoms outside the range: the per-frame sums run over the range only)
     EvalArgs A;
     A.B = b->dev; A.geoms = P.geoms; A.frame_of = P.frame_of; A.cl = P.cl; A.n3 = P.n3;
     if (!A.n3.cap) A.n3.cap = 1;
@@ -1304,6 +1319,9 @@ static int eval_impl(uf3_basis *b, const uf3_frames *fr, const double *d_pos, co
     A.atom_lo = (int)atom_begin; A.atom_hi = (int)atom_end;
     A.virial = d_virials ? A.e_atom + P.natoms : nullptr;
     A.nbr_f = nullptr; A.n3_need = nullptr; A.fuse_n3 = 0;
+    A.halo_mark = nullptr;
+    if (centre_share && !whole && d_forces)      // (rows of atoms that no centre of the block touches: zero)
+        HIPCHK(c, hipMemsetAsync(d_forces, 0, 24 * (size_t)P.natoms, st));
     {
         Timed tm(c, T_EVAL);
         for (int attempt = 0; ; attempt++) {
@@ -1321,9 +1339,17 @@ static int eval_impl(uf3_basis *b, const uf3_frames *fr, const double *d_pos, co
             if (two_pass) {
                 HIPCHK(c, c->nbr_f.ensure(24 * (size_t)P.natoms * cap));
                 A.nbr_f = c->nbr_f.as<double>();
-                if (A.virial) hipLaunchKernelGGL((k_eval<false, true>), dim3((unsigned)((P.natoms + 7) / 8 * 8)), dim3(64), lds, st, A);
-                else hipLaunchKernelGGL((k_eval<false, false>), dim3((unsigned)((P.natoms + 7) / 8 * 8)), dim3(64), lds, st, A);
+                const int64_t n_centres = atom_end - atom_begin;
+                if (centres && fuse) HIPCHK(c, hipMemsetAsync(A.n3.cnt, 0, sizeof(int) * (size_t)P.natoms, st));   // (lists not built: empty)
+                if (A.virial) hipLaunchKernelGGL((k_eval<false, true>), dim3((unsigned)((n_centres + 7) / 8 * 8)), dim3(64), lds, st, A);
+                else hipLaunchKernelGGL((k_eval<false, false>), dim3((unsigned)((n_centres + 7) / 8 * 8)), dim3(64), lds, st, A);
                 if (fuse && deferred_cap) *deferred_cap = (int)cap;
+                if (centres) {
+                    // the block's lists exist now (this launch built them, or prepare did): the halo's, then the collection
+                    // pass over block + halo
+                    if (fuse || getenv("UF3_NO_HALO")) { int rh = build_halo_lists(b, P, A.n3, d_pos, (int)atom_begin, (int)atom_end); if (rh) return rh; }
+                    A.halo_mark = c->halo.as<int>();
+                }
                 hipLaunchKernelGGL(k_eval_collect, dim3((unsigned)(((P.natoms + 15) / 16 + 7) / 8 * 8)), dim3(256), 0, st, A);
             } else if (atom_end > atom_begin) {
                 if (A.virial) hipLaunchKernelGGL((k_eval<true, true>), dim3((unsigned)((atom_end - atom_begin + 7) / 8 * 8)), dim3(64), lds, st, A);
@@ -1333,7 +1359,7 @@ static int eval_impl(uf3_basis *b, const uf3_frames *fr, const double *d_pos, co
             const int sum_threads = P.natoms / P.n_frames >= 2048 ? 1024 : 256;
             hipLaunchKernelGGL(k_frame_sum, dim3(P.n_frames, d_virials ? 7 : 1), dim3(sum_threads), 0, st, A.e_atom,
                                A.virial, P.d_offsets, d_energies, d_virials, (const int *)c->flags.as<int>(), flags_tail,
-                               mirror, (const double *)d_forces, d_forces ? 3 * P.natoms : 0);
+                               mirror, (const double *)d_forces, d_forces ? 3 * P.natoms : 0, (int)atom_begin, (int)atom_end);
             if (fuse && !deferred_cap) {
                 // the lists were part of this launch: did they fit?  (Asked after everything is queued -- all kernels
                 // are safe on clipped lists -- so that the GPU does not idle while the host looks.)
@@ -1369,7 +1395,7 @@ extern "C" int uf3_eval_virial_dev(uf3_basis *b, const uf3_frames *fr, const dou
 
 static int eval_host(uf3_basis *b, const uf3_frames *fr, const double *pos, const int32_t *z, const double *c1,
                      const double *c2, const double *c3, double *energies, double *forces, double *virials,
-                     int64_t atom_begin = 0, int64_t atom_end = -1) {
+                     int64_t atom_begin = 0, int64_t atom_end = -1, bool centre_share = false) {
     uf3_ctx *c = b->ctx;
     if (!energies) return fail(c, UF3_EINVAL, "uf3_eval: null energies");
     int natoms = 0;
@@ -1395,7 +1421,7 @@ static int eval_host(uf3_basis *b, const uf3_frames *fr, const double *pos, cons
             const bool zero_copy = natoms <= UF3_SMALL_ATOMS && !getenv("UF3_NO_ZERO_COPY");
             rc = eval_impl(b, fr, c->stage_pos.as<double>(), c->d_stage_z, c1, c2, c3, d_e, forces ? d_f : nullptr,
                            virials ? d_v : nullptr, atom_begin, atom_end, &cap_used, d_flags_tail,
-                           zero_copy ? (double *)c->pin_out.p : nullptr);
+                           zero_copy ? (double *)c->pin_out.p : nullptr, centre_share);
             if (rc) return rc;
             if (!zero_copy) HIPCHK(c, hipMemcpyAsync(c->pin_out.p, d_e, total + 16, hipMemcpyDeviceToHost, c->stream));
             HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1414,7 +1440,7 @@ static int eval_host(uf3_basis *b, const uf3_frames *fr, const double *pos, cons
         return fail(c, UF3_EOVERFLOW, "3-body neighbour capacity did not converge");
     }
     rc = eval_impl(b, fr, c->stage_pos.as<double>(), c->d_stage_z, c1, c2, c3, d_e, forces ? d_f : nullptr,
-                   virials ? d_v : nullptr, atom_begin, atom_end);
+                   virials ? d_v : nullptr, atom_begin, atom_end, nullptr, nullptr, nullptr, centre_share);
     if (rc) return rc;
     HIPCHK(c, hipMemcpyAsync(energies, d_e, 8 * nf, hipMemcpyDeviceToHost, c->stream));
     if (virials) HIPCHK(c, hipMemcpyAsync(virials, d_v, 48 * nf, hipMemcpyDeviceToHost, c->stream));
@@ -1450,6 +1476,22 @@ extern "C" int uf3_eval_atoms(uf3_basis *b, const uf3_frames *fr, const double *
     if (!b) return fail(nullptr, UF3_EINVAL, "null basis");
     if (atom_end < 0) return fail(b->ctx, UF3_EINVAL, "uf3_eval_atoms: atom range outside the batch");
     return eval_host(b, fr, pos, z, c1, c2, c3, energies, forces, virials, atom_begin, atom_end);
+}
+
+extern "C" int uf3_eval_centres_dev(uf3_basis *b, const uf3_frames *fr, const double *d_pos, const int32_t *d_z,
+                                    const double *c1, const double *c2, const double *c3, int64_t atom_begin,
+                                    int64_t atom_end, double *d_energies, double *d_forces, double *d_virials) {
+    if (!b) return fail(nullptr, UF3_EINVAL, "null basis");
+    if (atom_end < 0) return fail(b->ctx, UF3_EINVAL, "uf3_eval_centres: atom range outside the batch");
+    return eval_impl(b, fr, d_pos, d_z, c1, c2, c3, d_energies, d_forces, d_virials, atom_begin, atom_end, nullptr, nullptr, nullptr, true);
+}
+
+extern "C" int uf3_eval_centres(uf3_basis *b, const uf3_frames *fr, const double *pos, const int32_t *z, const double *c1,
+                                const double *c2, const double *c3, int64_t atom_begin, int64_t atom_end,
+                                double *energies, double *forces, double *virials) {
+    if (!b) return fail(nullptr, UF3_EINVAL, "null basis");
+    if (atom_end < 0) return fail(b->ctx, UF3_EINVAL, "uf3_eval_centres: atom range outside the batch");
+    return eval_host(b, fr, pos, z, c1, c2, c3, energies, forces, virials, atom_begin, atom_end, true);
 }
 
 // ------------------------------------------------------------------------------ gram

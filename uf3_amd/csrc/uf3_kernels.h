@@ -215,8 +215,8 @@ __device__ __forceinline__ void image_delta(const FrameGeom &g, const SlotRec &s
 // ---------------------------------------------------------------------------------
 // 3-body neighbour lists: one wave per atom
 // ---------------------------------------------------------------------------------
-// atom of workgroup blockIdx.x: first + blockIdx.x, or which[blockIdx.x] when an index list is given (the halo of a
-// block of atoms: its length is read on the device, the grid is an upper bound)
+// atom of workgroup blockIdx.x: first + blockIdx.x; or, when marks are given (which [natoms], n_which = {block begin, block
+// end} on the device), the blockIdx.x-th atom outside that block if it is marked: the halo of a block of atoms
 __global__ void __launch_bounds__(64)
 k_build_n3(const BasisDev *B, const FrameGeom *geoms, const int *frame_of, CellList cl, N3Lists n3,
            const double *pos, int natoms, int *overflow_need, int first, const int *which, const int *n_which) {
@@ -227,7 +227,13 @@ k_build_n3(const BasisDev *B, const FrameGeom *geoms, const int *frame_of, CellL
     int *eparent = (int *)(er + cap), *eshift = eparent + cap, *esidx = eshift + cap, *espec = esidx + cap;
 
     int m = first + blockIdx.x;
-    if (which) { if ((int)blockIdx.x >= *n_which) return; m = which[blockIdx.x]; }
+    if (which) {
+        // `which` = halo marks [natoms], n_which = {block begin, block end}: workgroup b takes the b-th atom OUTSIDE the block and
+        // leaves unless the block's lists mention it
+        const int lo = n_which[0], hi = n_which[1];
+        m = (int)blockIdx.x < lo ? (int)blockIdx.x : (int)blockIdx.x + (hi - lo);
+        if (m >= natoms || !which[m]) return;
+    }
     if (m >= natoms) return;
     int lane = lane_id();
     const FrameGeom g = geoms[frame_of[m]];
@@ -340,16 +346,17 @@ k_build_n3_ext(const BasisDev *B, const FrameGeom *geoms, const int *frame_of, C
 }
 
 
-// Halo of a block of atoms [lo, hi) for the gather route of the evaluator: the atoms outside the block that appear in
-// a block atom's 3-body list (their own lists are walked by the block's atoms).  mark[] must be zero on entry; the
-// order of `which` does not matter (it only decides which workgroup builds which list).
-__global__ void k_mark_halo(N3Lists n3, int lo, int hi, int *mark, int *which, int *n_which) {
-    const int m = lo + blockIdx.x;
+// Halo of a block of atoms [lo, hi): the atoms outside the block that appear in a block atom's 3-body list (the gather route
+// walks their lists, the centre route's collection pass serves them).  mark[] must be zero on entry.
+__global__ void __launch_bounds__(256)
+k_mark_halo(N3Lists n3, int lo, int hi, int *mark, int *range) {
+    const int m = lo + blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (blockIdx.x == 0 && threadIdx.x == 0) { range[0] = lo; range[1] = hi; }
     if (m >= hi) return;
     const int n = min(n3.cnt[m], n3.cap);
-    for (int e = threadIdx.x; e < n; e += blockDim.x) {
+    for (int e = threadIdx.x & 63; e < n; e += 64) {
         const int p = n3.ent[(size_t)m * n3.cap + e].parent;
-        if ((p < lo || p >= hi) && atomicExch(mark + p, 1) == 0) which[atomicAdd(n_which, 1)] = p;
+        if (p < lo || p >= hi) mark[p] = 1;                       // (plain stores of the same value: no order to keep)
     }
 }
 
@@ -2042,6 +2049,9 @@ struct EvalArgs {
     int natoms;
     int atom_lo;                  // first atom of this launch (blocks cover [atom_lo, natoms_end))
     int atom_hi;
+    // collection pass of a block of CENTRES (uf3_eval_centres): only the centres [atom_lo, atom_hi) have run, and only the
+    // atoms inside the block or marked as its halo have lists
+    const int *halo_mark;         // [natoms] != 0: a halo atom of the block; null: every atom collects from every centre
 };
 
 #ifndef EVAL_CGROUP
@@ -2343,8 +2353,9 @@ k_eval(EvalArgs A) {
 __global__ void __launch_bounds__(256)
 k_eval_collect(EvalArgs A) {
     const int m = (int)((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3)) * 16 + (threadIdx.x >> 4), sub = threadIdx.x & 15;
-    if (m < A.natoms) {
+    if (m < A.natoms && (!A.halo_mark || (m >= A.atom_lo && m < A.atom_hi) || A.halo_mark[m])) {
         const int cap = A.n3.cap, n = A.n3.cnt[m];
+        const int c_lo = A.halo_mark ? A.atom_lo : 0, c_hi = A.halo_mark ? A.atom_hi : A.natoms;
         const N3Entry *mine = A.n3.ent + (size_t)m * cap;
         double sx = 0.0, sy = 0.0, sz = 0.0;
         // lanes <-> own entries; each lane scans its centre's list (independent loads: three dependent round trips per
@@ -2352,6 +2363,7 @@ k_eval_collect(EvalArgs A) {
         for (int q = sub; q < n; q += 16) {
             const int2 me = *(const int2 *)&mine[q].parent;
             const int c = me.x;
+            if (c < c_lo || c >= c_hi) continue;               // (a centre outside the block: another rank's)
             int s0, s1, s2;
             unpack3(me.y, s0, s1, s2);
             const int back = pack3(-s0, -s1, -s2), nc = A.n3.cnt[c];
@@ -2384,7 +2396,7 @@ k_eval_collect(EvalArgs A) {
 // host memory, written here directly so that a small batch needs no copy-engine transfer behind its last kernel)
 __global__ void k_frame_sum(const double *e_atom, const double *v_atom, const int64_t *atom_offsets, double *e_out,
                             double *v_out, const int *flags_src, int *flags_dst, double *mirror, const double *forces,
-                            int n_force) {
+                            int n_force, int a_lo, int a_hi) {
     __shared__ double part[1024];
     const int f = blockIdx.x, comp = (int)blockIdx.y - 1;
     if (flags_dst && f == 0 && comp < 0 && threadIdx.x < 4) flags_dst[threadIdx.x] = flags_src[threadIdx.x];
@@ -2396,7 +2408,9 @@ __global__ void k_frame_sum(const double *e_atom, const double *v_atom, const in
     const double *src = comp < 0 ? e_atom : v_atom + comp;
     const int width = comp < 0 ? 1 : 6;
     double s = 0.0;
-    for (int64_t a = atom_offsets[f] + threadIdx.x; a < atom_offsets[f + 1]; a += blockDim.x) s += src[a * width];
+    // (a share of a block of atoms: only [a_lo, a_hi) carries values)
+    const int64_t a0 = max(atom_offsets[f], (int64_t)a_lo), a1 = min(atom_offsets[f + 1], (int64_t)a_hi);
+    for (int64_t a = a0 + threadIdx.x; a < a1; a += blockDim.x) s += src[a * width];
     part[threadIdx.x] = s;
     __syncthreads();
     for (int w = blockDim.x / 2; w > 0; w >>= 1) {

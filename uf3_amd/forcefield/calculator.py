@@ -131,6 +131,25 @@ class UFCalculator(_Base):
                                          int(atom_end), _lib._p(e), _lib._p(f), _lib._p(v)))
         return float(e[0]), f, (v[0] if virial else None)
 
+    def evaluate_centre_range(self, atoms, atom_begin, atom_end, forces=True, virial=False):
+        """
+        Share of the CENTRES [atom_begin, atom_end) of one frame: (energy share, forces [N, 3], dE/d(strain) share [6] or
+        None).  Every triplet is evaluated once, at its centre inside the range, so the force array also carries what those
+        triplets put on atoms outside it (the range's halo); all other rows are zero.  Shares over disjoint ranges covering
+        the frame add up to ``evaluate_frames`` at a third of ``evaluate_atom_range``'s triplet work (``uf3_eval_centres``;
+        what ``parallel.sharded_evaluate`` reduces).
+        """
+        ctx = _lib.get_context(self.device)
+        db = _lib.device_basis(self.bspline_config, ctx)
+        batch = _lib.FrameBatch([atoms])
+        e = np.empty(1)
+        f = np.empty((batch.n_atoms, 3)) if forces else None
+        v = np.empty((1, 6)) if virial else None
+        ctx.check(ctx.lib.uf3_eval_centres(db.handle, C.byref(batch.struct), _lib._p(batch.pos), _lib._p(batch.z),
+                                           _lib._p(self._c1), _lib._p(self._c2), _lib._p(self._c3), int(atom_begin),
+                                           int(atom_end), _lib._p(e), _lib._p(f), _lib._p(v)))
+        return float(e[0]), f, (v[0] if virial else None)
+
     def calculate(self, atoms=None, properties=None, system_changes=tuple(all_changes)):
         if properties is None:
             properties = self.implemented_properties

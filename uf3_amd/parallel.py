@@ -158,9 +158,9 @@ def sharded_fit(model, featurizer, frames, energies, forces=None, weight=0.5, ba
 def sharded_evaluate(calculator, atoms, forces=True, virial=False, device=None):
     """
     ONE large frame decomposed over the ranks (the reference's calculator is a
-    single process, calculator.py:124-153).  Every atom gathers its own force row in ``uf3_eval``, so the
-    decomposition needs no halo bookkeeping on the host: each rank holds the whole frame's positions
-    (28 B per atom), evaluates the atoms of its contiguous index block (``uf3_eval_atoms``) and one
+    single process, calculator.py:124-153).  Each rank holds the whole frame's positions (28 B per atom) and
+    evaluates the triplets CENTRED in its contiguous index block once each (``uf3_eval_centres``: the block's pair
+    terms, its triplets, and what they put on the block's halo -- no halo bookkeeping on the host) and one
     ``all_reduce(SUM)`` over [energy | dE/d(strain) (6) | forces (3N)] -- 1.2 MB at 50 k atoms, RCCL over
     xGMI under "nccl" -- gives every rank the full result.  Returns (energy, forces or None, virial or None).
     """
@@ -170,7 +170,10 @@ def sharded_evaluate(calculator, atoms, forces=True, virial=False, device=None):
     on = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
     rank, world = (dist.get_rank(), dist.get_world_size()) if on else (0, 1)
     lo, hi = shard_range(n, rank, world)
-    e, f, v = calculator.evaluate_atom_range(atoms, lo, hi, forces=forces, virial=virial)
+    # (a block of centres: every triplet once, what it puts on atoms of other blocks rides in the same reduce; calculators
+    # without that entry -- the stand-ins of the CPU tests -- give the gather shares, which add up the same way)
+    share = getattr(calculator, "evaluate_centre_range", None) or calculator.evaluate_atom_range
+    e, f, v = share(atoms, lo, hi, forces=forces, virial=virial)
     if not on:
         return e, f, v
     flat = np.concatenate([[e], np.zeros(6) if v is None else v, np.zeros(0) if f is None else f.reshape(-1)])
