@@ -1364,8 +1364,13 @@ __device__ __forceinline__ void trio_block_banded(const FeatArgs &A, const Basis
             const int st0 = (b0 + 1) >> 1, st1 = (b1 - b0 + 1) >> 1, st2 = (n_part - b1 + 1) >> 1;
             const int n_staged = 2 * (st0 + st1 + st2);
             const bool mine = li < n_part && !(A.skip & 16);
-            if (!(A.skip & 16))
-                for (int q = 2 * lane; q < n_staged * STRIDE; q += 2 * WAVE) *(double2 *)(w.stage + q) = double2{0.0, 0.0};
+            if (!(A.skip & 16)) {
+                if (A.dense_stage == 1280) {                   // (the usual stage, 20 records of 64 doubles: cleared whole, no loop)
+#pragma unroll
+                    for (int u = 0; u < 10; u++) *(double2 *)(w.stage + 2 * lane + u * 2 * WAVE) = double2{0.0, 0.0};
+                } else
+                    for (int q = 2 * lane; q < n_staged * STRIDE; q += 2 * WAVE) *(double2 *)(w.stage + q) = double2{0.0, 0.0};
+            }
             if (mine) {
                 const int gi = base + li;
                 const double x = w.geo[leg * GEO_N + gi];
