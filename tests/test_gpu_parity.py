@@ -1080,6 +1080,37 @@ def test_matrix_core_and_generic_trio_kernels_agree(which, bit):
     assert rel_err(fz.featurize_frames(frames, energy=False)[1], xf_m) < 1e-12
 
 
+@pytest.mark.parametrize("lead3", [3, 0])
+def test_trios_with_different_settings_in_one_basis(lead3):
+    """Every trio its own cut-offs / resolution: several window LAYOUTS in one basis (the per-lane layout constants are
+    recomputed when a block of another layout comes along), grouped and two-tile windows side by side in the mode-7 launch
+    (lead3 = 3), banded and dense wide windows side by side in the mode-9 launch (lead3 = 0)."""
+    from uf3_amd.data import composition
+    from uf3_amd.representation import bspline
+    cs = composition.ChemicalSystem(['Mo', 'W'], 3)
+    pairs, trios = cs.interactions_map[2], cs.interactions_map[3]
+    res = [[6, 6, 12], [6, 6, 13], [6, 6, 10], [6, 6, 12], [5, 5, 12], [6, 6, 11]]
+    rmax = [3.5, 3.5, 3.7, 3.9, 3.5, 3.6]
+    basis = bspline.BSplineBasis(
+        cs,
+        r_min_map={**{p: 0.001 for p in pairs}, **{t: [1.5, 1.5, 1.5] for t in trios}},
+        r_max_map={**{p: 5.5 for p in pairs}, **{t: [r, r, 2 * r] for t, r in zip(trios, rmax)}},
+        resolution_map={**{p: 15 for p in pairs}, **{t: r for t, r in zip(trios, res)}},
+        leading_trim={2: 0, 3: lead3}, trailing_trim={2: 3, 3: 3})
+    frames = [synthetic.lattice_frame("bcc", (4, 4, 5), 3.165, [42, 74], 31), synthetic.lattice_frame("bcc", (3, 5, 4), 3.0, [42, 74], 32)]
+    fz = process.BasisFeaturizer(basis)
+    modes = fz._dev()[1].featurizer_modes
+    assert modes & ((1 << 7) if lead3 else (1 << 9)), hex(modes)
+    x_e, x_f, off = fz.featurize_frames(frames)
+    ob = O.OracleBasis(basis)
+    for k, atoms in enumerate(frames):
+        ref = O.featurize(ob, atoms)
+        assert rel_err(x_e[k], ref["xe"]) < TOL and worst_elementwise(x_e[k], ref["xe"]) <= 1.0
+        assert rel_err(x_f[off[k]:off[k + 1]], ref["xf"]) < TOL and worst_elementwise(x_f[off[k]:off[k + 1]], ref["xf"]) <= 1.0
+    xe2 = fz.featurize_frames(frames, forces=False)[0]                 # (energy-only launches: the dense loops)
+    assert rel_err(xe2, x_e) < 1e-12
+
+
 def test_windows_too_wide_for_the_tiles_stay_on_generic_kernels():
     """More than 96 (m, n) columns (or more than 32 (component, l) rows): output-stationary kernels; default trims:
     matrix cores."""
