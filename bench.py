@@ -24,8 +24,10 @@ Extra objects on the JSON line:
                 launch) against 8 TB/s, and `fp64` = algorithmic flops against 78.6 TF.  `bound` names the measured
                 limiter: on MI355X an fp64 MFMA holds the SIMD's vector issue while it runs
                 (tools/experiments/dp_pipe_bench.hip), so matrix and vector fp64 work add up -- the launch is bound by
-                fp64 issue ("mfma" in the contract's vocabulary), not by HBM, at these F.  `traffic` comes from the
-                committed PMC passes of the same command (profiles/), labelled as such.
+                fp64 issue ("mfma" in the contract's vocabulary), not by HBM, at these F.  `traffic` is measured in the run
+                (N = 1, featurize mode): two short child runs of this command under `rocprofv3 --pmc` (FETCH_SIZE, WRITE_SIZE,
+                separate passes), after the timed region; --no-traffic, or a box without the profiler, quotes the committed
+                PMC passes under profiles/ instead, labelled as such.
   cpu_baseline  the oracle (oracle/uf3_oracle.c, "port") timed on rank 0 on frames of the same workload.
   extra         (N = 1, default mode only; measured AFTER the headline's timed region) one sub-line per other BASELINE
                 configuration, each with ms_per_step and its own roofline: fit_w (config 4: W, F = 73, featurize + X^T X /
@@ -64,6 +66,9 @@ def main():
                          "lead0 = W/Mo without leading trim, F=1798 (bandwidth-heavier)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the sub-lines of the other BASELINE configurations")
+    ap.add_argument("--no-traffic", action="store_true",
+                    help="do not measure roofline.traffic in this run (two short child runs under rocprofv3 --pmc); the figure "
+                         "of the committed PMC passes under profiles/ is quoted instead")
     args = ap.parse_args()
 
     import torch
@@ -180,7 +185,9 @@ def main():
         # HBM bytes per launch from the PMC passes of this same command (separate rocprofv3 --pmc FETCH_SIZE /
         # WRITE_SIZE runs, summary committed under profiles/); null when the workload differs
         traffic, traffic_source = None, None
-        for name in ("round3_hbm_counters.json", "round2_hbm_counters.json", "round1_hbm_counters.json"):
+        if world == 1 and not fit and not args.no_traffic:
+            traffic, traffic_source = measure_traffic(B, args.workload, args.atoms)
+        for name in (() if traffic is not None else ("round3_hbm_counters.json", "round2_hbm_counters.json", "round1_hbm_counters.json")):
             try:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
                 if pmc["workload"] == dict(atoms_per_frame=n_atoms, n_feat=F, frames_per_step=B):
@@ -278,6 +285,53 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# roofline.traffic, measured in the run: HBM bytes of one k_featurize launch group from the PMC counters
+# ---------------------------------------------------------------------------------------------------------------
+def measure_traffic(frames_per_step, workload, atoms):
+    """Two short child runs of this script under `rocprofv3 --pmc` -- FETCH_SIZE and WRITE_SIZE in SEPARATE passes, counters
+    only (no trace domains) -- on the same workload and batch; the k_featurize dispatches of a step are summed and averaged
+    over the steps.  Units as in tools/summarize_profiles.py (MI355X_MICROARCH.md: the counters report KiB; on gfx950
+    FETCH_SIZE can come out at half the bytes of wide streaming reads -- the reads here are mostly 48-byte list entries, so the
+    uncorrected sum is what `traffic` quotes and the source string says so).  Returns (bytes per launch group | None, source)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, None
+    totals = {}
+    work = tempfile.mkdtemp(prefix="uf3_pmc_", dir="/tmp")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(work, counter)
+            cmd = [exe, "--pmc", counter, "-d", out, "-o", "p", "--output-format", "csv", "--", sys.executable,
+                   os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--no-extra", "--no-cpu-baseline", "--no-traffic",
+                   "--frames-per-step", str(frames_per_step), "--atoms", str(atoms)] + (["--workload", workload] if workload else [])
+            env = dict(os.environ, TMPDIR="/tmp", UF3_BENCH_NOCHECK="1")
+            subprocess.run(cmd, env=env, cwd=work, timeout=240, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
+            per_kernel = {}
+            for path in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+                with open(path, newline="") as fh:
+                    for row in csv.DictReader(fh):
+                        if "k_featurize" in row["Kernel_Name"] and row["Counter_Name"] == counter:
+                            per_kernel.setdefault(row["Kernel_Name"], []).append(float(row["Counter_Value"]))
+            if not per_kernel:
+                return None, None
+            steps = max(len(v) for v in per_kernel.values())
+            totals[counter] = sum(sum(v) for v in per_kernel.values()) / steps * 1024.0          # KiB -> bytes
+        return (totals["FETCH_SIZE"] + totals["WRITE_SIZE"],
+                f"measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes of this command at "
+                f"--steps 2 (k_featurize launches of a step summed; FETCH {totals['FETCH_SIZE'] / 1e9:.2f} GB + WRITE "
+                f"{totals['WRITE_SIZE'] / 1e9:.2f} GB, uncorrected)")
+    except Exception:  # noqa: BLE001 - no profiler, no counters: the committed figure is quoted instead
+        return None, None
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
 
 
 # ---------------------------------------------------------------------------------------------------------------

@@ -7,7 +7,7 @@ RUN=${1:?output directory}; SKIPS=${2:-"0 8 16 24 6"}
 mkdir -p "$RUN"; export TMPDIR=/tmp UF3_BENCH_NOCHECK=1
 for s in $SKIPS; do
   UF3_DEBUG_SKIP=$s timeout 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_MFMA SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAVE_CYCLES SQ_WAIT_INST_ANY \
-    -d $RUN/s$s -o p --output-format csv -- python bench.py --no-cpu-baseline --no-extra --steps 2 --warmup 1 --frames-per-step 32 > $RUN/s$s.json 2>/dev/null
+    -d $RUN/s$s -o p --output-format csv -- python bench.py --no-cpu-baseline --no-extra --no-traffic --steps 2 --warmup 1 --frames-per-step 32 > $RUN/s$s.json 2>/dev/null
 done
 python - "$RUN" $SKIPS <<'PY'
 import csv, glob, sys, collections

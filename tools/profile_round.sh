@@ -8,7 +8,7 @@ RUN=${1:?run directory under gpurun_out/}
 mkdir -p "$RUN"
 export TMPDIR=/tmp
 T="timeout 280"
-B="python bench.py --no-cpu-baseline --no-extra"
+B="python bench.py --no-cpu-baseline --no-extra --no-traffic"
 $T rocprofv3 --kernel-trace --stats -d $RUN/trace -o r1 --output-format csv -- $B > $RUN/bench_traced.json 2>/dev/null
 $T rocprofv3 --pmc FETCH_SIZE -d $RUN/pmc_fetch -o f --output-format csv -- $B --steps 6 --warmup 2 > /dev/null 2>&1
 $T rocprofv3 --pmc WRITE_SIZE -d $RUN/pmc_write -o w --output-format csv -- $B --steps 6 --warmup 2 > /dev/null 2>&1
@@ -19,7 +19,7 @@ $T rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_
 $T rocprofv3 --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT \
     -d $RUN/pmc3 -o p3 --output-format csv -- $B --steps 4 --warmup 2 > /dev/null 2>&1
 # the same trace over the whole default run: the sub-lines of the other BASELINE configurations (fit, lead-0, evaluator) included
-$T rocprofv3 --kernel-trace --stats -d $RUN/trace_extra -o x --output-format csv -- python bench.py --no-cpu-baseline > $RUN/bench_traced_extra.json 2>/dev/null
+$T rocprofv3 --kernel-trace --stats -d $RUN/trace_extra -o x --output-format csv -- python bench.py --no-cpu-baseline --no-traffic > $RUN/bench_traced_extra.json 2>/dev/null
 $T python tools/bench_kernels.py > $RUN/kernels.json 2> $RUN/kernels.err
 timeout 400 python bench.py --steps 20 --warmup 5 > $RUN/bench_default.json 2> $RUN/bench_default.err
 cut -c1-200 $RUN/bench_default.json

@@ -7,7 +7,7 @@ RUN=${1:?output directory}; PMC=${2:-}; shift; shift || true
 mkdir -p "$RUN"; export TMPDIR=/tmp
 timeout 300 python -m pytest tests/test_gpu_parity.py -x -q -k "reference_capture or full_size_properties or matrix_core_and_generic or random_bases or atoms_outside or mid_size or ragged_batch_of_large" > $RUN/pytest.log 2>&1
 tail -3 $RUN/pytest.log
-UF3_DEBUG_LDS=1 timeout 200 python bench.py --no-cpu-baseline --no-extra --steps 10 --warmup 3 "$@" > $RUN/bench.json 2> $RUN/bench.err
+UF3_DEBUG_LDS=1 timeout 200 python bench.py --no-cpu-baseline --no-extra --no-traffic --steps 10 --warmup 3 "$@" > $RUN/bench.json 2> $RUN/bench.err
 grep "uf3 featurize mode" $RUN/bench.err | sort | uniq -c | head -4
 python - "$RUN" <<'PY'
 import json, sys
@@ -16,7 +16,7 @@ print("frames/s", d["value"], "ms/step", d["ms_per_step"], "launch_ms", d["roofl
 PY
 if [ "$PMC" = "pmc" ]; then
   UF3_BENCH_NOCHECK=1 timeout 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_MFMA SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAVE_CYCLES SQ_WAIT_INST_ANY \
-    -d $RUN/pmc -o p --output-format csv -- python bench.py --no-cpu-baseline --no-extra --steps 2 --warmup 1 --frames-per-step ${UF3_PMC_FRAMES:-32} "$@" > /dev/null 2>&1
+    -d $RUN/pmc -o p --output-format csv -- python bench.py --no-cpu-baseline --no-extra --no-traffic --steps 2 --warmup 1 --frames-per-step ${UF3_PMC_FRAMES:-32} "$@" > /dev/null 2>&1
   python - "$RUN" <<'PY'
 import csv, glob, sys, collections
 run = sys.argv[1]
