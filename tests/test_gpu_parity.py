@@ -170,6 +170,19 @@ def test_gram_kernel_ragged_shapes(shape):
     assert np.array_equal(g, g.T)
 
 
+@pytest.mark.parametrize("shape", [(16384, 73), (20011, 80), (17003, 5), (40001, 33), (16385, 16)])
+def test_slab_gram_kernel_for_narrow_matrices(shape):
+    """k_gram_small (F <= 80, at least 16 k rows): every tile-pair count from 1 to 15, column counts inside a tile, row counts
+    that are no multiple of the 32-row slab or of the rows per workgroup; X^T y from the staging threads; accumulate mode."""
+    rng = np.random.default_rng(shape[1])
+    x, y = rng.normal(size=shape), rng.normal(size=shape[0])
+    g, o = ls.gram_device(x, y)
+    ref = x.T @ x
+    assert np.abs(g - ref).max() < 1e-12 * np.abs(ref).max()
+    assert np.allclose(o, x.T @ y, rtol=1e-11, atol=1e-9)
+    assert np.array_equal(g, g.T)
+
+
 @pytest.mark.parametrize("shape", [(65536, 129), (70013, 257), (66001, 434), (65551, 333)])
 def test_tiled_gram_kernel_ragged_shapes(shape):
     """The LDS-tiled kernel (more than 128 columns, at least 64 k rows): column counts that end inside a 64-column range /

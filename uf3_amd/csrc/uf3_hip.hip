@@ -1604,6 +1604,19 @@ extern "C" int uf3_gram_dev(uf3_ctx *c, const double *dx, const double *dy, int6
         HIPCHK(c, hipGetLastError());
         return UF3_OK;
     }
+    if (n_feat <= GS_LDW && n_rows >= 16384 && !getenv("UF3_GRAM_DIRECT")) {
+        // narrow matrices: slabs of 32 rows through LDS, every row read once (k_gram_small); about eight workgroups per CU
+        const int64_t want_blocks = (int64_t)c->n_cu * 8;
+        int64_t rpb = (n_rows + want_blocks - 1) / want_blocks;
+        rpb = std::max<int64_t>(4 * GS_ROWS, (rpb + GS_ROWS - 1) / GS_ROWS * GS_ROWS);
+        const int64_t blocks = (n_rows + rpb - 1) / rpb;
+        Timed tm(c, T_GRAM);
+        hipLaunchKernelGGL(k_gram_small, dim3((unsigned)blocks), dim3(256), 0, st, dx, (d_ord && dy) ? dy : nullptr, n_rows, n_feat, ld,
+                           rpb, c->frag.as<int>(), d_gram, d_ord);
+        hipLaunchKernelGGL(k_gram_mirror, dim3((n_feat + 255) / 256, n_feat), dim3(256), 0, st, d_gram, n_feat);
+        HIPCHK(c, hipGetLastError());
+        return UF3_OK;
+    }
     // tile-pair table of the direct kernel: built and uploaded when n_feat changes (its own buffer and key: a fit that sends
     // its energy rows here and its force rows to the tiled kernel keeps both plans)
     const int nt = (n_feat + 31) / 32;

@@ -2711,6 +2711,115 @@ k_gram_tiled(const double *x, const double *y, int64_t n_rows, int n_feat, int64
         }
 }
 
+// X^T X for narrow matrices (F <= 80: one-element bases, config 4's F = 73), slabs through LDS.  The direct kernel gives every
+// 32 x 32 tile pair its own wave, which reads its 64 columns of every row itself: at F = 73 six waves read the rows six times
+// (1.5 ms per 3.84 M rows, the L2 carrying it).  Here a workgroup of four waves takes a chunk of rows, brings slabs of 32 rows
+// x F columns into LDS once (coalesced, the next slab in flight in registers while the current one is multiplied) and its
+// waves share the <= 15 tile pairs (16 x 16 tiles, upper triangle) of the WHOLE Gram matrix: every row is read once from HBM.
+// X^T y rides along in the staging threads.
+#define GS_ROWS 32
+#define GS_LDW 80
+template <int NP>         // tile pairs of this wave (1 .. 4): nothing conditional inside the slab loop
+__device__ __forceinline__ void gram_small_steps(const double *slab, int lane, const int (&oa)[4], const int (&ob)[4], double4_t (&acc)[4]) {
+    const double *rowp = slab + (lane >> 4) * GS_LDW + (lane & 15);
+#pragma unroll
+    for (int kk = 0; kk < GS_ROWS / 4; kk++) {
+        double a[NP], b[NP];
+#pragma unroll
+        for (int q = 0; q < NP; q++) { a[q] = rowp[kk * 4 * GS_LDW + oa[q]]; b[q] = rowp[kk * 4 * GS_LDW + ob[q]]; }
+#pragma unroll
+        for (int q = 0; q < NP; q++) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], b[q], acc[q], 0, 0, 0);
+    }
+}
+
+__global__ void __launch_bounds__(256, 2)
+k_gram_small(const double *x, const double *y, int64_t n_rows, int n_feat, int64_t ld, int64_t rows_per_block,
+             const int *frag_rowcol, double *gram, double *ord) {
+    __shared__ double slab[GS_ROWS * GS_LDW];
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block, r1 = min(n_rows, r0 + rows_per_block);
+    if (r0 >= n_rows) return;
+    const int nt = (n_feat + 15) >> 4, n_pairs = nt * (nt + 1) / 2;          // tiles per side, tile pairs (ti <= tj)
+    // this wave's tile pairs: wave, wave + 4, ... (at most four of the fifteen); column offsets of their operands in a slab row
+    int oa[4], ob[4], np_w = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        int p = wave + 4 * q, a = 0;
+        oa[q] = ob[q] = 0;
+        if (p < n_pairs) {
+            while (p >= nt - a) { p -= nt - a; ++a; }                       // row a of the upper triangle holds nt - a pairs
+            oa[q] = 16 * a; ob[q] = 16 * (a + p);
+            np_w = q + 1;
+        }
+    }
+    // staging role: column sc of rows sr, sr + 2, ... of the slab (128 column slots, the first GS_LDW in use); columns past
+    // n_feat are read from column 0 and multiplied by zero, the loads of whole slabs are unconditional
+    const int sc = t & 127, sr = t >> 7;
+    const bool col_ok = sc < n_feat, stage = sc < GS_LDW;
+    const double *px = x + (col_ok ? sc : 0);
+    const double mq = col_ok ? 1.0 : 0.0;
+    const bool want_ord = ord && y;
+    const double *py = want_ord ? y : x;
+    const double yw = want_ord ? mq : 0.0;
+    double4_t acc[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) acc[q] = double4_t{0, 0, 0, 0};
+    double oy = 0.0, nxt[GS_ROWS / 2], ynx[GS_ROWS / 2];
+    const int n_full = (int)((r1 - r0) / GS_ROWS);
+    auto fetch = [&](int64_t rs) {
+#pragma unroll
+        for (int j = 0; j < GS_ROWS / 2; j++) { const int64_t row = rs + sr + 2 * j; nxt[j] = px[row * ld]; ynx[j] = py[row]; }
+    };
+    auto store = [&](double ysc) {
+        if (stage) {
+#pragma unroll
+            for (int j = 0; j < GS_ROWS / 2; j++) { slab[(sr + 2 * j) * GS_LDW + sc] = nxt[j] * mq; oy += nxt[j] * (ynx[j] * ysc); }
+        }
+    };
+    auto steps = [&]() {
+        if (np_w == 4) gram_small_steps<4>(slab, lane, oa, ob, acc);
+        else if (np_w == 3) gram_small_steps<3>(slab, lane, oa, ob, acc);
+        else if (np_w == 2) gram_small_steps<2>(slab, lane, oa, ob, acc);
+        else if (np_w == 1) gram_small_steps<1>(slab, lane, oa, ob, acc);
+    };
+    if (n_full > 0) {
+        fetch(r0);
+        for (int sidx = 0; sidx < n_full; sidx++) {
+            __syncthreads();                                                // (the previous slab has been read)
+            store(yw);
+            __syncthreads();
+            // (the prefetch of the last trip re-reads the last slab: nothing conditional around the loads)
+            fetch(r0 + (int64_t)(sidx + 1 < n_full ? sidx + 1 : sidx) * GS_ROWS);
+            steps();
+        }
+    }
+    const int64_t r_tail = r0 + (int64_t)n_full * GS_ROWS;
+    if (r_tail < r1) {                                                      // ragged end of the chunk: rows past it are zeros
+#pragma unroll
+        for (int j = 0; j < GS_ROWS / 2; j++) {
+            const int64_t row = r_tail + sr + 2 * j;
+            nxt[j] = 0.0; ynx[j] = 0.0;
+            if (row < r1) { nxt[j] = px[row * ld]; ynx[j] = py[row]; }
+        }
+        __syncthreads();
+        store(yw);
+        __syncthreads();
+        steps();
+    }
+    if (want_ord && col_ok && oy != 0.0) unsafeAtomicAdd(ord + sc, oy);
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        if (q >= np_w) break;
+#pragma unroll
+        for (int v = 0; v < 4; v++) {
+            const int gi = oa[q] + frag_rowcol[(lane * 4 + v) * 2], gj = ob[q] + frag_rowcol[(lane * 4 + v) * 2 + 1];
+            const double val = acc[q][v];
+            if (gi < n_feat && gj < n_feat && gj >= gi && val != 0.0) unsafeAtomicAdd(gram + (size_t)gi * n_feat + gj, val);
+        }
+    }
+}
+
 __global__ void k_gram_mirror(double *gram, int n_feat) {
     int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
     if (j < n_feat && j < i) gram[(size_t)i * n_feat + j] = gram[(size_t)j * n_feat + i];
