@@ -620,6 +620,39 @@ def test_evaluate_dataframe_surface():
     assert len(p_e) == 1 and len(p_f) == 9 and np.all(np.isfinite(p_e)) and np.all(np.isfinite(p_f))
 
 
+def test_batched_to_hdf_chunks_and_resume(monkeypatch, tmp_path):
+    """``BasisFeaturizer.batched_to_hdf`` (process.py:256-291): chunk boundaries, table names, skipping the chunks a file already
+    holds.  No PyTables in the image: the writer and the table listing are replaced by an in-memory store."""
+    import pandas as pd
+    basis = synthetic.notebook_basis(['W'])
+    fz = process.BasisFeaturizer(basis)
+    frames = [synthetic.lattice_frame("bcc", (2, 2, 2), 3.165, [74], 40 + k) for k in range(7)]
+    rng = np.random.default_rng(2)
+    df = pd.DataFrame({"geometry": frames, "energy": rng.normal(size=7), "fx": [rng.normal(size=16) for _ in frames],
+                       "fy": [rng.normal(size=16) for _ in frames], "fz": [rng.normal(size=16) for _ in frames]},
+                      index=[f"s{k}" for k in range(7)])
+    store = {}
+    monkeypatch.setattr(process, "save_feature_db", lambda d, filename, table_name="features": store.__setitem__(table_name, d))
+    monkeypatch.setattr(process, "existing_feature_tables", lambda filename: sorted(store))
+    path = tmp_path / "features.h5"
+    fz.batched_to_hdf(str(path), df, batch_size=3)
+    assert sorted(store) == ["features_000", "features_001", "features_002"]
+    whole = fz.evaluate(df, progress=False)
+
+    def same(a, b):      # (energy rows are summed with atomics: the last bits depend on the batch)
+        return a.index.equals(b.index) and list(a.columns) == list(b.columns) and np.allclose(a.to_numpy(), b.to_numpy(), rtol=1e-12, atol=1e-12)
+
+    assert same(pd.concat([store[k] for k in sorted(store)]), whole)
+    assert [len(store[k].index.unique(level=0)) for k in sorted(store)] == [3, 3, 1]
+    path.write_bytes(b"")                                       # the file exists now: chunks it holds are skipped
+    del store["features_001"]
+    kept = store["features_000"]
+    with pytest.warns(RuntimeWarning):
+        fz.batched_to_hdf(str(path), df, batch_size=3)
+    assert sorted(store) == ["features_000", "features_001", "features_002"] and store["features_000"] is kept
+    assert same(pd.concat([store[k] for k in sorted(store)]), whole)
+
+
 def test_batched_evaluate_equals_frame_by_frame_evaluation():
     """``evaluate`` batches the frames of a table; rows, order and skip rules must be those of the reference's
     frame-by-frame loop over ``evaluate_configuration`` (process.py:121-194, 293-367)."""
@@ -720,6 +753,31 @@ def test_fit_from_feature_tables_against_reference_capture():
     sw = np.sqrt(w)
     expect = np.linalg.lstsq(np.vstack([x * sw[:, None], reg]), np.concatenate([y * sw, np.zeros(12)]), rcond=None)[0]
     assert np.allclose(ls.weighted_least_squares(x, y, weights=w, regularizer=reg), expect, rtol=1e-9)
+
+
+def test_file_wrappers_of_the_table_fit(monkeypatch, tmp_path):
+    """``fit_from_file(filename)`` / ``batched_predict(filename)``: the image has neither PyTables nor h5py, so the two
+    functions that touch the file (``hdf_table_names``, ``pd_read_hdf``) are replaced by an in-memory store here; everything
+    the wrappers do themselves -- existence check, table order, hand-over to the table loop -- runs."""
+    t, basis, tables, weights = _table_fit_case()
+    store = {f"features_{k:03d}": df for k, df in enumerate(tables)}
+    path = tmp_path / "features.h5"
+    path.write_bytes(b"")
+    reads = []
+    monkeypatch.setattr(ls, "hdf_table_names", lambda filename: sorted(store) if str(filename) == str(path) else [])
+    monkeypatch.setattr(ls, "pd_read_hdf", lambda filename, name: (reads.append(name), store[name])[1])
+    subset = t["subset"].tolist()
+    model = ls.WeightedLinearModel(basis, regularizer=t["regularizer"])
+    model.fit_from_file(str(path), subset, weight=float(t["kappa"][0]), sample_weights=weights)
+    assert reads == sorted(store)
+    assert np.allclose(model.coefficients, t["coefficients"], rtol=1e-7, atol=1e-9)
+    assert np.array_equal(model.data_coverage, t["data_coverage"])
+    model.coefficients = t["coefficients"]
+    y_e, p_e, y_f, p_f = model.batched_predict(str(path), keys=["a1", "b0", "c2", "c3"], score=False)
+    assert np.array_equal(y_e, t["pred_y_e"]) and np.allclose(p_e, t["pred_p_e"], rtol=1e-13)
+    assert np.array_equal(y_f, t["pred_y_f"]) and np.allclose(p_f, t["pred_p_f"], rtol=1e-13, atol=1e-14)
+    with pytest.raises(FileNotFoundError):
+        model.fit_from_file(str(tmp_path / "missing.h5"), subset)
 
 
 def test_energy_only_and_forces_only_modes_agree():

@@ -320,5 +320,51 @@ class BasisFeaturizer:
         return self.evaluate(df_data, atoms_key=atoms_key, energy_key=energy_key, progress=progress)
 
 
+    def batched_to_hdf(self, filename, df_data, client=None, n_jobs=16, batch_size=50, progress="bar",
+                       table_template="features_{}", **kwargs):
+        """
+        Feature tables of ``df_data`` in chunks of ``batch_size`` frames, each written as table
+        ``features_000``, ``features_001`` ... of one HDF5 file -- the on-disk cache ``fit_from_file`` /
+        ``batched_predict`` stream from (process.py:256-291).  Chunk boundaries, table names (zero-padded to at
+        least three digits) and the skipping of chunks an existing file already holds follow the reference;
+        every chunk is one GPU batch here (``client`` / ``n_jobs`` are accepted and ignored).  Writing goes
+        through ``DataFrame.to_hdf`` (``save_feature_db``) and therefore needs PyTables.
+        """
+        import os
+        idx_all = np.arange(len(df_data))
+        idx_batches = np.array_split(idx_all, idx_all[batch_size::batch_size])
+        idx_magnitude = max(int(np.ceil(np.log10(len(idx_batches)) + 0.1)), 3)
+        chunk_names = []
+        if os.path.isfile(filename):
+            chunk_names = existing_feature_tables(filename)
+            warnings.warn(f"File already exists: contains {len(chunk_names)} chunks.", RuntimeWarning)
+        kwargs.pop("progress", None)
+        kwargs.pop("n_jobs", None)
+        kwargs.pop("shuffle", None)
+        for j, idx_batch in enumerate(idx_batches):
+            table_name = table_template.format(str(j).rjust(idx_magnitude, "0"))
+            if table_name in chunk_names:
+                continue
+            df_features = self.evaluate(df_data.iloc[idx_batch], progress=False, **kwargs)
+            save_feature_db(df_features, filename, table_name=table_name)
+
+
+def save_feature_db(dataframe, filename, table_name='features'):
+    """One feature table into an HDF5 file (process.py:538-547); needs PyTables."""
+    dataframe.to_hdf(filename, key=table_name, mode="a", format='fixed')
+
+
+def load_feature_db(filename, table_name='features'):
+    """... and back (process.py:550-562)."""
+    import pandas as pd
+    return pd.read_hdf(filename, table_name)
+
+
+def existing_feature_tables(filename):
+    """Names of the tables an HDF5 feature file already holds (what io.analyze_hdf_tables reports, io.py:943-970)."""
+    from uf3_amd.regression.least_squares import hdf_table_names
+    return hdf_table_names(filename)
+
+
 def flatten_by_interactions(vector_map, pair_tuples):
     return np.concatenate([vector_map[pair] for pair in pair_tuples], axis=-1)
