@@ -23,7 +23,7 @@ buf = (ctypes.c_ulonglong * 16)()
 ctx.lib.uf3_debug_phase(buf)
 step()
 ctx.lib.uf3_debug_phase(buf)
-names = ["list", "setup", "walk", "eval", "stage", "mfma", "dump"]
-tot = sum(buf[i] for i in range(7))
+names = ["list", "setup", "walk", "eval", "stage", "mfma", "fold: energy adds + end", "fold: tile dump", "fold: reads + sums", "fold: row stores (incl. their completion)"]
+tot = sum(buf[i] for i in range(len(names)))
 for i, n in enumerate(names):
-    print(f"{n:6s} {buf[i]:>14d} {100.0 * buf[i] / tot:5.1f}%")
+    print(f"{n:44s} {buf[i]:>14d} {100.0 * buf[i] / tot:5.1f}%")

@@ -1555,7 +1555,9 @@ __device__ __forceinline__ void grouped_layout_setup(const FeatArgs &A, int t, c
     for (int v = 0; v < 4; v++) {
         const int row = fragp[v] >> 4, col = fragp[v] & 15;
         const int c = (row * inv_l) >> 16, pl = row - c * ext_l;
-        ts[v] = row < 4 * ext_l ? (unsigned)((4 * c + pl) * 16 + col) : 0xffffu;
+        // (accumulator rows past the window -- 4 ext_l .. 15 -- are parked in row 3 of the tile when ext_l < 4, a row the fold
+        // never reads, so that the dump needs no lane mask; with ext_l == 4 every row is in use)
+        ts[v] = row < 4 * ext_l ? (unsigned)((4 * c + pl) * 16 + col) : (ext_l < 4 ? (unsigned)(3 * 16 + col) : 0xffffu);
     }
     L.tiles01 = ts[0] | (ts[1] << 16); L.tiles23 = ts[2] | (ts[3] << 16);
 }
@@ -1676,10 +1678,26 @@ __device__ __forceinline__ void trio_block_grouped(const FeatArgs &A, const Basi
     // addresses per column; a combination that does not apply points at column 15 of tile 0, which no record ever touches and
     // is therefore zero): 24 reads at fixed component distances and their sum, no address arithmetic, no weights.
     double *tiles = w.stage;                                     // 3 x 16 x 16 doubles = the host's minimum stage
+    if (A.skip & 128) return;                                    // (ablation: no fold, no rows)
     // the fold table's entries of this lane's (at most two) columns: six tile addresses each
+    // (through the LDS or the global address space explicitly: as a generic pointer it is a flat load, whose results the
+    // compiler can only wait for with vmcnt(0) -- i.e. together with the row stores of the round before)
     int3 fs[2];
+    if (A.gsrc_lds) {
+        typedef const __attribute__((address_space(3))) int *LdsInts;
 #pragma unroll
-    for (int it = 0; it < 2; it++) fs[it] = *(const int3 *)(gsrc_blk + 6 * min(lane + it * WAVE, ncol - 1));
+        for (int it = 0; it < 2; it++) {
+            LdsInts q = (LdsInts)(const int *)(gsrc_blk + 6 * min(lane + it * WAVE, ncol - 1));
+            fs[it] = make_int3(q[0], q[1], q[2]);
+        }
+    } else {
+        typedef const __attribute__((address_space(1))) int *GlobalInts;
+#pragma unroll
+        for (int it = 0; it < 2; it++) {
+            GlobalInts q = (GlobalInts)(const int *)(gsrc_blk + 6 * min(lane + it * WAVE, ncol - 1));
+            fs[it] = make_int3(q[0], q[1], q[2]);
+        }
+    }
     const unsigned ts[4] = {L.tiles01 & 0xffffu, L.tiles01 >> 16, L.tiles23 & 0xffffu, L.tiles23 >> 16};
 #pragma unroll
     for (int grp = 0; grp < NG; grp++)
@@ -1687,6 +1705,7 @@ __device__ __forceinline__ void trio_block_grouped(const FeatArgs &A, const Basi
         for (int v = 0; v < 4; v++)
             if (ts[v] != 0xffffu) tiles[grp * 256 + ts[v]] = acc[grp][0][0][v];
     wave_sync();
+    pc.lap(7);
 #pragma unroll
     for (int it = 0; it < 2; it++) {
         const int col = lane + it * WAVE;
@@ -1705,10 +1724,12 @@ __device__ __forceinline__ void trio_block_grouped(const FeatArgs &A, const Basi
         double sum[4];
 #pragma unroll
         for (int c = 0; c < 4; c++) sum[c] = ((tv[0][c] + tv[1][c]) + (tv[2][c] + tv[3][c])) + (tv[4][c] + tv[5][c]);
+        pc.lap(8);
         if (!(A.skip & 32)) {
             double *dst = A.x_f + (size_t)m * 3 * F + th.col + col;
             dst[0] = sum[0]; dst[F] = sum[1]; dst[2 * (size_t)F] = sum[2];
         }
+        pc.lap(9);
         if (WANT_E) es.add(th.col + col, sum[3]);
     }
     wave_sync();
