@@ -822,7 +822,8 @@ __device__ __forceinline__ void trio_block(const FeatArgs &A, const BasisDev *B,
             if (col < ncol) {
                 if (WANT_F) {
                     double *dst = A.x_f + (size_t)m * 3 * F + td->col + col;
-                    dst[0] = acc[ch][0]; dst[F] = acc[ch][1]; dst[2 * (size_t)F] = acc[ch][2];
+                    __builtin_nontemporal_store(acc[ch][0], dst); __builtin_nontemporal_store(acc[ch][1], dst + F);
+                    __builtin_nontemporal_store(acc[ch][2], dst + 2 * (size_t)F);
                 }
                 if (WANT_E) es.add(td->col + col, acc[ch][3]);
             }
@@ -987,7 +988,7 @@ __device__ __forceinline__ void dense_fold(const FeatArgs &A, const WaveLds &w, 
                     if (q >= nc) break;
                     const double val = w0 * t0[q] + w1 * t1[q];
                     const int comp = c0 + q;
-                    if (comp < 3) { if (!(A.skip & 32)) A.x_f[(size_t)m * 3 * F + (size_t)comp * F + td->col + col] = val; }
+                    if (comp < 3) { if (!(A.skip & 32)) __builtin_nontemporal_store(val, A.x_f + (size_t)m * 3 * F + (size_t)comp * F + td->col + col); }
                     else es.add(td->col + col, val);
                 }
             }
@@ -1000,7 +1001,7 @@ __device__ __forceinline__ void dense_fold(const FeatArgs &A, const WaveLds &w, 
                         if (off >= 0) val += dump[q * rows_c + off];
                     }
                     const int comp = c0 + q;
-                    if (comp < 3) { if (!(A.skip & 32)) A.x_f[(size_t)m * 3 * F + (size_t)comp * F + td->col + col] = val; }
+                    if (comp < 3) { if (!(A.skip & 32)) __builtin_nontemporal_store(val, A.x_f + (size_t)m * 3 * F + (size_t)comp * F + td->col + col); }
                     else es.add(td->col + col, val);
                 }
         }
@@ -1726,8 +1727,11 @@ __device__ __forceinline__ void trio_block_grouped(const FeatArgs &A, const Basi
         for (int c = 0; c < 4; c++) sum[c] = ((tv[0][c] + tv[1][c]) + (tv[2][c] + tv[3][c])) + (tv[4][c] + tv[5][c]);
         pc.lap(8);
         if (!(A.skip & 32)) {
+            // (streaming stores: the rows are not read again by this launch -- they should not push the neighbour lists, which
+            // are, out of the L2)
             double *dst = A.x_f + (size_t)m * 3 * F + th.col + col;
-            dst[0] = sum[0]; dst[F] = sum[1]; dst[2 * (size_t)F] = sum[2];
+            __builtin_nontemporal_store(sum[0], dst); __builtin_nontemporal_store(sum[1], dst + F);
+            __builtin_nontemporal_store(sum[2], dst + 2 * (size_t)F);
         }
         pc.lap(9);
         if (WANT_E) es.add(th.col + col, sum[3]);
@@ -1777,7 +1781,8 @@ __device__ __forceinline__ void pair_rows(const FeatArgs &A, const BasisDev *B, 
     for (int col = lane; col < n2; col += WAVE) {
         if (WANT_F) {
             double *dst = A.x_f + (size_t)m * 3 * F + S + col;
-            dst[0] = row[n2 + col]; dst[F] = row[2 * n2 + col]; dst[2 * (size_t)F] = row[3 * n2 + col];
+            __builtin_nontemporal_store(row[n2 + col], dst); __builtin_nontemporal_store(row[2 * n2 + col], dst + F);
+            __builtin_nontemporal_store(row[3 * n2 + col], dst + 2 * (size_t)F);
         }
         if (WANT_E) es.add(S + col, row[col]);
     }
@@ -1836,7 +1841,7 @@ __device__ __forceinline__ void build_n3_list(const FeatArgs &A, const BasisDev 
 __device__ __forceinline__ void zero_rows(double *x_f, int m, int F, int col, int n) {
     for (int c = lane_id(); c < n; c += WAVE) {
         double *dst = x_f + (size_t)m * 3 * F + col + c;
-        dst[0] = 0.0; dst[F] = 0.0; dst[2 * (size_t)F] = 0.0;
+        __builtin_nontemporal_store(0.0, dst); __builtin_nontemporal_store(0.0, dst + F); __builtin_nontemporal_store(0.0, dst + 2 * (size_t)F);
     }
 }
 
