@@ -1734,7 +1734,7 @@ __device__ __forceinline__ void trio_block_grouped(const FeatArgs &A, const Basi
             __builtin_nontemporal_store(sum[2], dst + 2 * (size_t)F);
         }
         pc.lap(9);
-        if (WANT_E) es.add(th.col + col, sum[3]);
+        if (WANT_E && !(A.skip & 256)) es.add(th.col + col, sum[3]);
     }
     wave_sync();
     pc.lap(6);
