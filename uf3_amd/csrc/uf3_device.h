@@ -248,6 +248,20 @@ __device__ __forceinline__ double norm3_rn(double dx, double dy, double dz) {
     return sqrt(s);
 }
 
+// |d| for the THIRD leg of a triplet (r_jk): not part of any neighbour-index decision -- it selects knot intervals, where a
+// cubic B-spline is continuous, and is compared with the leg's ends, where the basis functions vanish -- so the last bit does
+// not matter and the root comes from the hardware estimate + one Newton step + one correction (8 instructions; the IEEE
+// library root with its scaling for subnormal arguments is 20, and the walk takes one per triplet role).
+__device__ __forceinline__ double norm3_leg(double dx, double dy, double dz) {
+    const double s = fma(dz, dz, fma(dy, dy, dx * dx));
+    const double y = __builtin_amdgcn_rsq(s);
+    double g = s * y, h = 0.5 * y;
+    const double r = fma(-h, g, 0.5);
+    g = fma(g, r, g); h = fma(h, r, h);
+    g = fma(fma(-g, g, s), h, g);
+    return s > 0.0 ? g : 0.0;
+}
+
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 // inclusive prefix sum over the 64 lanes on the DPP network (row shifts, then row broadcasts): no LDS round trips
 __device__ __forceinline__ int wave_scan_incl(int v) {

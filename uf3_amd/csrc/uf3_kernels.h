@@ -722,7 +722,7 @@ __device__ __forceinline__ bool trio_walk_geom(const FeatArgs &A, const FrameGeo
         tg.rl = w.orr[aa]; tg.rm = w.orr[bb];
         tg.i1 = aa; tg.i2 = bb;
         double ex = w.ox[bb] - w.ox[aa], ey = w.oy[bb] - w.oy[aa], ez = w.oz[bb] - w.oz[aa];
-        tg.rn = norm3_rn(ex, ey, ez);
+        tg.rn = norm3_leg(ex, ey, ez);
         if (WANT_F) {
             double il = w.oir[aa], im = w.oir[bb];
             tg.a1[0] = w.ox[aa] * il; tg.a1[1] = w.oy[aa] * il; tg.a1[2] = w.oz[aa] * il;
@@ -760,7 +760,7 @@ __device__ __forceinline__ bool trio_walk_geom(const FeatArgs &A, const FrameGeo
             int msidx = supercell_index(g, -s0, -s1, -s2, m_local);      // m as numbered from c
             double vx = ke.dx, vy = ke.dy, vz = ke.dz, rk = ke.r;
             double ex = oex + vx, ey = oey + vy, ez = oez + vz;              // m -> k
-            tg.rn = norm3_rn(ex, ey, ez);
+            tg.rn = norm3_leg(ex, ey, ez);
             bool m_first = neighbour_is_first(g, sm, k.sx, s0, s1, s2, m_local, msidx, ksidx, kshift,
                                               kparent - g.atom_lo);
             tg.i1 = e; tg.i2 = e;
@@ -2295,7 +2295,7 @@ k_eval(EvalArgs A) {
             bb += ((bb + 1) * bb / 2 <= p) ? 1 : 0;
             int aa = p - bb * (bb - 1) / 2;
             double rl = orr[aa], rm = orr[bb];
-            double rn = norm3_rn(ox[bb] - ox[aa], oy[bb] - oy[aa], oz[bb] - oz[aa]);
+            double rn = norm3_leg(ox[bb] - ox[aa], oy[bb] - oy[aa], oz[bb] - oz[aa]);
             int trio = B->trio_of[(sm * UF3_MAX_SPECIES + ospec[aa]) * UF3_MAX_SPECIES + ospec[bb]];
             double val, gr[3];
             if (!trio_value(B, A.c3, trio, rl, rm, rn, want_f || want_v, val, gr)) continue;
@@ -2353,7 +2353,7 @@ k_eval(EvalArgs A) {
                 int msidx = supercell_index(g, -s0, -s1, -s2, m_local);
                 double vx = ke.dx, vy = ke.dy, vz = ke.dz, rk = ke.r;
                 double ex = ox[q] + vx, ey = oy[q] + vy, ez = oz[q] + vz;
-                double rn = norm3_rn(vx - (-ox[q]), vy - (-oy[q]), vz - (-oz[q]));
+                double rn = norm3_leg(vx - (-ox[q]), vy - (-oy[q]), vz - (-oz[q]));
                 bool m_first = neighbour_is_first(g, sm, ksp, s0, s1, s2, m_local, msidx, ksidx, ke.shiftc,
                                                   ke.parent - g.atom_lo);
                 int sc = ospec[q];
