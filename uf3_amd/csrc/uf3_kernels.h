@@ -2441,7 +2441,18 @@ __global__ void k_frame_sum(const double *e_atom, const double *v_atom, const in
     double s = 0.0;
     // (a share of a block of atoms: only [a_lo, a_hi) carries values)
     const int64_t a0 = max(atom_offsets[f], (int64_t)a_lo), a1 = min(atom_offsets[f + 1], (int64_t)a_hi);
-    for (int64_t a = a0 + threadIdx.x; a < a1; a += blockDim.x) s += src[a * width];
+    // (eight loads in flight per trip, added in the order a plain loop adds them: the loop was a chain of dependent round trips,
+    // 16 us for a 50 k-atom frame)
+    int64_t a = a0 + threadIdx.x;
+    const int64_t bd = blockDim.x;
+    for (; a + 7 * bd < a1; a += 8 * bd) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = src[(a + u * bd) * width];
+#pragma unroll
+        for (int u = 0; u < 8; u++) s += v[u];
+    }
+    for (; a < a1; a += bd) s += src[a * width];
     part[threadIdx.x] = s;
     __syncthreads();
     for (int w = blockDim.x / 2; w > 0; w >>= 1) {
