@@ -891,10 +891,13 @@ static int prepare(uf3_basis *b, const uf3_frames *fr, const double *d_pos, cons
         // latency, and the only caller on this path, the synchronous evaluator entry, waits for the stream before it returns)
         P.flags_zeroed = true;
     } else {
-    HIPCHK(c, hipMemsetAsync(flags + 3, 0, 2 * sizeof(int), st));         // extension-list need | "some atom outside its cell" (k_frame_bins)
+    // n3 need | candidate need | extension-list need | "some atom outside its cell" (k_frame_bins): one fill for all four (the
+    // launches behind this stage then need none of their own; every fill is a small kernel on the stream)
+    HIPCHK(c, hipMemsetAsync(flags + 1, 0, 4 * sizeof(int), st));
+    P.flags_zeroed = true;
     // counting sort by global bin: counts (k_frame_bins) -> exclusive scan = bin starts -> fill -> per-bin order + slot records
-    HIPCHK(c, c->bin_cnt.ensure(4 * ((size_t)nbins + 2)));
-    HIPCHK(c, hipMemsetAsync(c->bin_cnt.p, 0, 4 * ((size_t)nbins + 1), st));
+    HIPCHK(c, c->bin_cnt.ensure(4 * ((size_t)nbins + 8)));
+    HIPCHK(c, hipMemsetAsync(c->bin_cnt.p, 0, (4 * ((size_t)nbins + 1) + 15) / 16 * 16, st));      // (whole 16-byte pieces: one fill kernel)
     hipLaunchKernelGGL(k_frame_bins, dim3(gb), dim3(tb), 0, st, b->dev, d_geoms,
                        d_offsets, nf, natoms, d_pos, d_z, c->frame_of.as<int>(), c->atom_bin.as<int>(),
                        c->atom_wrap.as<int>(), c->spec.as<signed char>(), c->key_in.as<int>(), c->bin_cnt.as<int>(), flags);
@@ -1042,7 +1045,7 @@ extern "C" int uf3_featurize_dev(uf3_basis *b, const uf3_frames *fr, const doubl
             if (rc) return rc;
         }
         if (want_e) HIPCHK(c, hipMemsetAsync(d_xe, 0, sizeof(double) * (size_t)P.n_frames * F, st));
-        HIPCHK(c, hipMemsetAsync(A.n3_need, 0, 2 * sizeof(int), st));       // n3_need, cand_need
+        if (!P.flags_zeroed || attempt) HIPCHK(c, hipMemsetAsync(A.n3_need, 0, 2 * sizeof(int), st));       // n3_need, cand_need
         const bool img_launch = c->img_mode && has3 && want_f && A.outside;
         const bool ext_lists = img_launch;
         if (ext_lists) {
