@@ -563,6 +563,14 @@ extern "C" int uf3_basis_create(uf3_ctx *c, const uf3_basis_spec *s, uf3_basis *
     if (!trios.empty())
         HIPCHK(c, hipMemcpy(b->d_trios, trios.data(), sizeof(TrioDev) * trios.size(), hipMemcpyHostToDevice));
     h.trios = b->d_trios; h.recs = b->d_recs; h.lut = b->d_lut;
+    h.trio_legs_uniform = h.T > 0 && !getenv("UF3_NO_UNIFORM_LEGS");
+    for (int t = 1; t < h.T && h.trio_legs_uniform; t++) {
+        for (int d = 0; d < 3; d++) {
+            const LegDev &a = trios[0].leg[d], &q = trios[t].leg[d];
+            if (a.rec_off != q.rec_off || a.nk != q.nk || a.t0 != q.t0 || a.tlast != q.tlast || a.inv_h != q.inv_h) h.trio_legs_uniform = 0;
+        }
+        if (trios[t].dim_l != trios[0].dim_l || trios[t].dim_m != trios[0].dim_m || trios[t].dim_n != trios[0].dim_n) h.trio_legs_uniform = 0;
+    }
     HIPCHK(c, hipMalloc(&b->dev, sizeof(BasisDev)));
     HIPCHK(c, hipMemcpy(b->dev, &h, sizeof(BasisDev), hipMemcpyHostToDevice));
     *out = b;

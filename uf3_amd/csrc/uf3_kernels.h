@@ -2095,9 +2095,20 @@ __device__ __forceinline__ bool trio_value(const BasisDev *B, const double *c3, 
     if (trio < 0) return false;
     const TrioDev *td = load_const(&B->trios) + trio;
     const KnotRec *recs = load_const(&B->recs);
-    // all descriptor fields in flight together (per-lane trio: vector loads), then a branch-free range test
-    const LegDev l0 = td->leg[0], l1 = td->leg[1], l2 = td->leg[2];
-    const int dim_m = td->dim_m, dim_n = td->dim_n, lut_off = td->lut_off;
+    // all descriptor fields in flight together (per-lane trio: vector loads), then a branch-free range test.  When every trio
+    // has the same legs and grid (one set of 3-body settings: the usual case) those come from trio 0 through scalar loads and
+    // only the offset of the trio's coefficient grid is per lane.
+    LegDev l0, l1, l2;
+    int dim_m, dim_n;
+    const int lut_off = td->lut_off;
+    if (load_const(&B->trio_legs_uniform)) {
+        const TrioDev *t0 = load_const(&B->trios);
+        l0 = load_const(&t0->leg[0]); l1 = load_const(&t0->leg[1]); l2 = load_const(&t0->leg[2]);
+        dim_m = load_const(&t0->dim_m); dim_n = load_const(&t0->dim_n);
+    } else {
+        l0 = td->leg[0]; l1 = td->leg[1]; l2 = td->leg[2];
+        dim_m = td->dim_m; dim_n = td->dim_n;
+    }
     if (!((rl > l0.t0) & (rl < l0.tlast) & (rm > l1.t0) & (rm < l1.tlast) & (rn > l2.t0) & (rn < l2.tlast))) return false;
     // Memory round trips, not arithmetic, bound this function (the compiler had serialised it into ~20 dependent loads):
     // the three legs' knot records go out together, then -- the coefficient block only needs the interval indices -- the
