@@ -70,7 +70,9 @@ struct BasisDev {
     double rmax2;          // largest pair r_max
     double rsearch;        // cell-list radius = max(rmax2, rmax3) (= BSplineBasis.r_cut)
     int trio_legs_uniform; // every trio has the legs (knot sequences) and grid dimensions of trio 0: the evaluator reads them once,
-    int pad_;              // through scalar loads, instead of per lane and triplet
+                           // through scalar loads, instead of per lane and triplet
+    int pairs_uniform;     // every pair block has the knots, range and size of pair 0 (only its first column differs: pair_col)
+    int pair_col[UF3_MAX_SPECIES * UF3_MAX_SPECIES];   // first column of the pair block of two species
     signed char z2s[120];  // atomic number -> species index or -1
     short pair_of[UF3_MAX_SPECIES * UF3_MAX_SPECIES];
     short trio_of[UF3_MAX_SPECIES * UF3_MAX_SPECIES * UF3_MAX_SPECIES];  // [centre][a][b], a<=b

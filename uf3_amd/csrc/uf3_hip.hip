@@ -563,6 +563,13 @@ extern "C" int uf3_basis_create(uf3_ctx *c, const uf3_basis_spec *s, uf3_basis *
     if (!trios.empty())
         HIPCHK(c, hipMemcpy(b->d_trios, trios.data(), sizeof(TrioDev) * trios.size(), hipMemcpyHostToDevice));
     h.trios = b->d_trios; h.recs = b->d_recs; h.lut = b->d_lut;
+    h.pairs_uniform = !getenv("UF3_NO_UNIFORM_LEGS");
+    for (int a = 0; a < UF3_MAX_SPECIES * UF3_MAX_SPECIES; a++) h.pair_col[a] = h.pair_of[a] >= 0 ? h.pairs[h.pair_of[a]].col : 0;
+    for (int p2 = 1; p2 < h.P && h.pairs_uniform; p2++) {
+        const PairDev &a = h.pairs[0], &q = h.pairs[p2];
+        if (a.leg.rec_off != q.leg.rec_off || a.leg.nk != q.leg.nk || a.leg.t0 != q.leg.t0 || a.leg.tlast != q.leg.tlast ||
+            a.leg.inv_h != q.leg.inv_h || a.rmin != q.rmin || a.rmax != q.rmax || a.nb != q.nb) h.pairs_uniform = 0;
+    }
     h.trio_legs_uniform = h.T > 0 && !getenv("UF3_NO_UNIFORM_LEGS");
     for (int t = 1; t < h.T && h.trio_legs_uniform; t++) {
         for (int d = 0; d < 3; d++) {

@@ -1750,6 +1750,7 @@ __device__ __forceinline__ void pair_rows(const FeatArgs &A, const BasisDev *B, 
     const int lane = lane_id(), F = B->F, S = B->S;
     const int n2 = A.n_pair_cols;                       // pair columns are [S, S + n2)
     double *row = w.pstage;                             // [4][n2]: energy, fx, fy, fz
+    const int pairs_uniform = load_const(&B->pairs_uniform), lead2 = load_const(&B->lead2), trail2 = load_const(&B->trail2);
     for (int q = lane; q < 4 * n2; q += WAVE) row[q] = 0.0;
     wave_sync();
     for (int e0 = 0; e0 < n_cand; e0 += WAVE) {
@@ -1757,19 +1758,32 @@ __device__ __forceinline__ void pair_rows(const FeatArgs &A, const BasisDev *B, 
         if (e < n_cand) {
             const double *c = w.cand + (size_t)e * CAND_STRIDE;
             const double d = c[3];
-            const PairDev &pd = B->pairs[B->pair_of[sm * UF3_MAX_SPECIES + (int)c[4]]];
-            if (!(d > pd.rmin && d < pd.rmax)) continue;              // a 3-body-only neighbour
+            // (one set of 2-body settings: knots, range and size of pair 0 through scalar loads, only the block's first column
+            // per lane -- instead of two dependent vector loads per field)
+            const int pair_idx = sm * UF3_MAX_SPECIES + (int)c[4];
+            LegDev leg;
+            double p_rmin, p_rmax;
+            int p_nb;
+            const int p_col = B->pair_col[pair_idx];
+            if (pairs_uniform) {
+                leg = load_const(&B->pairs[0].leg); p_rmin = load_const(&B->pairs[0].rmin); p_rmax = load_const(&B->pairs[0].rmax);
+                p_nb = load_const(&B->pairs[0].nb);
+            } else {
+                const PairDev &pd = B->pairs[B->pair_of[pair_idx]];
+                leg = pd.leg; p_rmin = pd.rmin; p_rmax = pd.rmax; p_nb = pd.nb;
+            }
+            if (!(d > p_rmin && d < p_rmax)) continue;                // a 3-body-only neighbour
             KnotRec kr;
             double v[4], dv[4];
-            const int first = load_interval(recs, pd.leg, d, kr) - 3;
+            const int first = load_interval(recs, leg, d, kr) - 3;
             bspline4<WANT_F>(kr, d, v, dv);
             const double s = 2.0 / d;                   // both directed images of the bond (distances.py:116-141)
             const double dir[3] = {s * c[0], s * c[1], s * c[2]};
-            const int hi = pd.nb - B->trail2, base = pd.col - S;
+            const int hi = p_nb - trail2, base = p_col - S;
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 const int bf = first + q;
-                if (bf >= B->lead2 && bf < hi) {        // bspline.py:840,880
+                if (bf >= lead2 && bf < hi) {           // bspline.py:840,880
                     double *dst = row + base + bf;
                     if (WANT_E) lds_add(dst, v[q]);
                     if (WANT_F) { lds_add(dst + n2, dv[q] * dir[0]); lds_add(dst + 2 * n2, dv[q] * dir[1]); lds_add(dst + 3 * n2, dv[q] * dir[2]); }
@@ -1973,6 +1987,8 @@ k_featurize(FeatArgs A) {
             int n_cand = 0;
             const bool build3 = A.build_n3 != 0;
             const double rmin3 = load_const(&B->rmin3), rmax3 = load_const(&B->rmax3);
+            const int pairs_uniform0 = load_const(&B->pairs_uniform);
+            const double2 rr0 = double2{load_const(&B->pairs[0].rmin), load_const(&B->pairs[0].rmax)};
             if (!(A.skip & 1)) for_each_candidate(g, A.cl, m, [&](bool ok, const SlotRec &sr, int sj, int s0, int s1, int s2) {
                 double dx = 0, dy = 0, dz = 0, d = 0;
                 if (ok) {
@@ -1980,7 +1996,7 @@ k_featurize(FeatArgs A) {
                     d = norm3_rn(dx, dy, dz);
                     // kept if inside its pair's range (distances.py:66, strict both sides) or a 3-body neighbour;
                     // (r_min, r_max) in one load, no short-circuit: every clause evaluated would be a memory round trip
-                    const double2 rr = *(const double2 *)&B->pairs[B->pair_of[sm * UF3_MAX_SPECIES + sj]].rmin;
+                    const double2 rr = pairs_uniform0 ? rr0 : *(const double2 *)&B->pairs[B->pair_of[sm * UF3_MAX_SPECIES + sj]].rmin;
                     ok = ((d > rr.x) & (d < rr.y)) | (build3 & (d > rmin3) & (d <= rmax3));
                 }
                 unsigned long long mask = __ballot(ok);
@@ -2196,14 +2212,16 @@ k_eval(EvalArgs A) {
     // five survives the range test: evaluating in place would leave most lanes idle in the spline code)
     int queued = 0;
     const double rmin3 = B->rmin3, rmax3 = B->rmax3;
+    const int ev_pairs_uniform = load_const(&B->pairs_uniform);
+    const double ev_rmin0 = load_const(&B->pairs[0].rmin), ev_rmax0 = load_const(&B->pairs[0].rmax);
     auto drain = [&](int count) {
         const double *c = queue + (size_t)lane * EVAL_Q;
         if (lane < count) {
             const double dx = c[0], dy = c[1], dz = c[2], d = c[3];
-            const PairDev &pd = B->pairs[B->pair_of[sm * UF3_MAX_SPECIES + (int)c[4]]];
+            const int pair_idx = sm * UF3_MAX_SPECIES + (int)c[4];
             KnotRec kr;
-            const LegDev leg = pd.leg;
-            const int col = pd.col;
+            const LegDev leg = ev_pairs_uniform ? load_const(&B->pairs[0].leg) : B->pairs[B->pair_of[pair_idx]].leg;
+            const int col = B->pair_col[pair_idx];
             int i = load_interval(recs_g, leg, d, kr);
             double v[4], dv[4];
             bspline4<true>(kr, d, v, dv);
@@ -2224,8 +2242,8 @@ k_eval(EvalArgs A) {
         double dx = 0, dy = 0, dz = 0, d = 0;
         bool ok3 = false;
         if (ok) {
-            const PairDev &pd = B->pairs[B->pair_of[sm * UF3_MAX_SPECIES + sj]];
-            const double rmin = pd.rmin, rmax = pd.rmax;
+            double rmin = ev_rmin0, rmax = ev_rmax0;
+            if (!ev_pairs_uniform) { const PairDev &pd = B->pairs[B->pair_of[sm * UF3_MAX_SPECIES + sj]]; rmin = pd.rmin; rmax = pd.rmax; }
             image_delta(g, sr, s0, s1, s2, pm, dx, dy, dz);
             d = norm3_rn(dx, dy, dz);
             ok3 = fuse & (d > rmin3) & (d <= rmax3);                 // angles.py:340: lower strict, upper inclusive
