@@ -360,19 +360,26 @@ def _roof(flops, bytes_, seconds, bound, **more):
 
 
 def _timed(torch, dev, ctx, step, steps, warmup):
+    """(seconds per step by the wall clock with the library's event timing OFF -- the events cost host time, which shows on
+    sub-millisecond steps --, kernel-class milliseconds per step from a second, shorter loop with it on)"""
     for _ in range(warmup):
         step()
     torch.cuda.synchronize(dev)
     ctx.synchronize()
-    ctx.timing_reset(True)
+    ctx.timing_reset(False)
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
     torch.cuda.synchronize(dev)
     dt = (time.perf_counter() - t0) / steps
+    n2 = max(2, steps // 2)
+    ctx.timing_reset(True)
+    for _ in range(n2):
+        step()
+    torch.cuda.synchronize(dev)
     timing = ctx.timing_read()
     ctx.timing_reset(False)
-    return dt, {k: v / steps for k, v in timing.items()}
+    return dt, {k: v / n2 for k, v in timing.items()}
 
 
 def extra_fit(torch, dev, basis, frames, batch, d_pos, d_z, d_xe, d_xf, steps=5, warmup=2):
