@@ -1714,17 +1714,30 @@ __device__ __forceinline__ void trio_block_grouped(const FeatArgs &A, const Basi
         if (col >= ncol) continue;
         const unsigned a[6] = {(unsigned)fs[it].x & 0xffffu, (unsigned)fs[it].x >> 16, (unsigned)fs[it].y & 0xffffu,
                                (unsigned)fs[it].y >> 16, (unsigned)fs[it].z & 0xffffu, (unsigned)fs[it].z >> 16};
-        double tv[6][4];
-#pragma unroll
-        for (int q = 0; q < 6; q++) {
-            const double *tp = tiles + a[q];
-            tv[q][0] = tp[0]; tv[q][1] = tp[64]; tv[q][2] = tp[128];
-            tv[q][3] = WANT_E ? tp[192] : 0.0;
-        }
-        __builtin_amdgcn_sched_group_barrier(0x100, WANT_E ? 24 : 18, 0);       // all DS reads first
         double sum[4];
+        if (th.nsrc == 1) {                                        // (wave-uniform: no symmetry images -- the second source's
+            double tv[3][4];                                       //  three entries all point at the zero)
 #pragma unroll
-        for (int c = 0; c < 4; c++) sum[c] = ((tv[0][c] + tv[1][c]) + (tv[2][c] + tv[3][c])) + (tv[4][c] + tv[5][c]);
+            for (int q = 0; q < 3; q++) {
+                const double *tp = tiles + a[q];
+                tv[q][0] = tp[0]; tv[q][1] = tp[64]; tv[q][2] = tp[128];
+                tv[q][3] = WANT_E ? tp[192] : 0.0;
+            }
+            __builtin_amdgcn_sched_group_barrier(0x100, WANT_E ? 12 : 9, 0);    // all DS reads first
+#pragma unroll
+            for (int c = 0; c < 4; c++) sum[c] = (tv[0][c] + tv[1][c]) + tv[2][c];
+        } else {
+            double tv[6][4];
+#pragma unroll
+            for (int q = 0; q < 6; q++) {
+                const double *tp = tiles + a[q];
+                tv[q][0] = tp[0]; tv[q][1] = tp[64]; tv[q][2] = tp[128];
+                tv[q][3] = WANT_E ? tp[192] : 0.0;
+            }
+            __builtin_amdgcn_sched_group_barrier(0x100, WANT_E ? 24 : 18, 0);   // all DS reads first
+#pragma unroll
+            for (int c = 0; c < 4; c++) sum[c] = ((tv[0][c] + tv[1][c]) + (tv[2][c] + tv[3][c])) + (tv[4][c] + tv[5][c]);
+        }
         pc.lap(8);
         if (!(A.skip & 32)) {
             // (streaming stores: the rows are not read again by this launch -- they should not push the neighbour lists, which
