@@ -1846,11 +1846,20 @@ __device__ __forceinline__ void build_n3_list(const FeatArgs &A, const BasisDev 
     wave_sync();
     if (count > cap) { if (lane == 0) atomicMax(A.n3_need, count); count = cap; }
     if (lane == 0) A.n3.cnt[m] = count;
-    for (int sp = lane; sp <= UF3_MAX_SPECIES; sp += WAVE) {        // entries are species-sorted: offsets per species
-        int below = 0;
-        for (int f = 0; f < count; f++) below += (int)(key[f] >> 32) < sp;
-        A.n3.spoff[(size_t)m * (UF3_MAX_SPECIES + 1) + sp] = below;
-    }
+    if (count <= WAVE) {                 // entries are species-sorted: offsets per species = entries of a lower species (ballots)
+        const int my_spec = lane < count ? (int)(key[lane] >> 32) : UF3_MAX_SPECIES;
+        int below = count;
+        for (int sp = 0; sp <= load_const(&B->S); sp++) {
+            const int n_lower = __popcll(__ballot(my_spec < sp));
+            if (lane == sp) below = n_lower;
+        }
+        if (lane <= UF3_MAX_SPECIES) A.n3.spoff[(size_t)m * (UF3_MAX_SPECIES + 1) + lane] = below;
+    } else
+        for (int sp = lane; sp <= UF3_MAX_SPECIES; sp += WAVE) {
+            int below = 0;
+            for (int f = 0; f < count; f++) below += (int)(key[f] >> 32) < sp;
+            A.n3.spoff[(size_t)m * (UF3_MAX_SPECIES + 1) + sp] = below;
+        }
     for (int e = lane; e < count; e += WAVE) {                      // rank sort
         const unsigned long long k = key[e];
         int rank = 0;
