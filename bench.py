@@ -210,7 +210,8 @@ def main():
                             neighbor_ms_per_step=round(timing["neighbor_ms"] / args.steps, 4))
         else:
             n_keep = int(acc._keep.numel())
-            # executed Gram flops: the 16 x 16 tiles of the UPPER triangle over all F columns (the kernels skip the lower one);
+            # Gram flops: the 16 x 16 tiles of the UPPER triangle of the dense product over all F columns (the kernels skip the
+            # lower one; with two or more species the force rows are multiplied on their species' columns only -- fewer still);
             # SURVEY 8d's full-matrix count 2 (3N+1) F'^2 is kept beside it for reference only
             tiles = (F + 15) // 16
             gram_flops = 2.0 * (3 * n_atoms + 1) * 256.0 * (tiles * (tiles + 1) / 2) * B
@@ -221,7 +222,8 @@ def main():
             roofline = dict(bound="mfma", achieved=round(step_tf, 3), peak=78.6, unit="TFLOP/s", frac=round(step_tf / 78.6, 5),
                             traffic=None, hbm=hbm,
                             bound_note="whole step (featurizer + X^T X): fp64 flops (featurizer: SURVEY 8d per pair / triplet; Gram: "
-                                       "the upper-triangle tiles the kernels execute) / step time; the rows stay in HBM / Infinity Cache",
+                                       "the upper-triangle tiles of the dense product; the species-wise launches of a multi-element batch execute fewer) / step time; "
+                                       "the rows stay in HBM / Infinity Cache",
                             kernel="k_featurize launch group + k_gram_tiled / k_gram_mfma (energy and force rows, X^T y fused)",
                             featurize_ms_per_step=round(launch_ms, 4), gram_ms_per_step=round(gram_ms, 4),
                             gram_tflops_executed_triangle=round(gram_tf, 3), gram_flops_per_step=gram_flops,
@@ -408,7 +410,8 @@ def extra_fit(torch, dev, basis, frames, batch, d_pos, d_z, d_xe, d_xf, steps=5,
     assert bool(torch.isfinite(flat).all())
     n_keep = int(acc._keep.numel())
     tiles = (F + 15) // 16
-    # executed Gram flops: the 16 x 16 tiles of the upper triangle over all F columns (the kernels skip the lower one)
+    # Gram flops: the 16 x 16 tiles of the upper triangle of the dense product over all F columns (the kernels skip the lower one,
+    # and the species-wise launches of a multi-element batch the blocks a species takes no part in)
     gram_tri = 2.0 * (3 * n_atoms + 1) * 256.0 * (tiles * (tiles + 1) / 2) * B
     gram_full = 2.0 * (3 * n_atoms + 1) * n_keep * n_keep * B
     flops = _featurizer_flops(n_atoms) * B + gram_tri

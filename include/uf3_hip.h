@@ -136,6 +136,15 @@ int uf3_gram(uf3_ctx *ctx, const double *x, const double *y, int64_t n_rows, int
              int64_t ld, int accumulate, double *gram, double *ord);
 int uf3_gram_dev(uf3_ctx *ctx, const double *d_x, const double *d_y, int64_t n_rows,
                  int32_t n_feat, int64_t ld, int accumulate, double *d_gram, double *d_ord);
+/*
+ * The same pieces for the FORCE rows of a featurized batch (d_x_f as uf3_featurize_dev wrote it, [3 n_atoms][ld]; d_z the
+ * atomic numbers the batch was featurized with).  The rows of an atom of species s are zero outside the blocks s takes part
+ * in -- in the reference's dense X^T X (least_squares.py:19-67) those zeros are multiplied like everything else --: with two
+ * or more species the rows are listed by species on the device and each list is multiplied on its own columns only.  The
+ * result equals uf3_gram_dev's up to the order of summation; one species, narrow matrices and small batches go there.
+ */
+int uf3_gram_force_rows_dev(uf3_basis *basis, const double *d_x_f, const double *d_y_f, const int32_t *d_z,
+                            int64_t n_atoms, int64_t ld, int accumulate, double *d_gram, double *d_ord);
 
 /*
  * The bookkeeping around the Gram pieces of a device-resident fit (what the reference does on the host in

@@ -319,12 +319,13 @@ def test_config4_fit_in_chunks_10k_atom_tungsten_frames():
 
 
 def test_two_element_fit_in_chunks_through_the_tiled_gram_kernel():
-    """The metric variant of config 4 (W/Mo, F = 434) through the device-resident accumulator: chunks of three 10 000-atom
-    frames = 90 003 force rows, i.e. the LDS-tiled X^T X kernel in its accumulating form with X^T y riding along,
-    twice; pieces == the oracle's on the downloaded rows."""
+    """The metric variant of config 4 (W/Mo, F = 434) through the device-resident accumulator: a chunk of five 10 000-atom
+    frames (150 000 force rows: listed by species, each list through the LDS-tiled X^T X kernel on its species' columns,
+    X^T y riding along) and one of three (90 000 rows: the plain tiled product, accumulating on top); pieces == the
+    oracle's on the downloaded rows."""
     from uf3_amd import pipeline
     basis = synthetic.notebook_basis(['Mo', 'W'])
-    n_frames = 6
+    n_frames = 8
     frames = [synthetic.config_c4(frame=k)[0] for k in range(n_frames)]
     assert len(frames[0]) == 10000 and basis.n_feats == 434
     fz = process.BasisFeaturizer(basis)
@@ -338,7 +339,7 @@ def test_two_element_fit_in_chunks_through_the_tiled_gram_kernel():
     forces_flat = x_f @ c_true + rng.normal(0, 1e-3, len(x_f))
     forces = [forces_flat[3 * off[k]:3 * off[k + 1]].reshape(-1, 3) for k in range(n_frames)]
     model = ls.WeightedLinearModel(basis, regularizer=reg)
-    acc = pipeline.DeviceFitAccumulator(model, fz, max_atoms_per_chunk=30000)
+    acc = pipeline.DeviceFitAccumulator(model, fz, max_atoms_per_chunk=50000)
     acc.add_frames(frames, energies, forces)
     assert acc.n_chunks == 2
     pieces = acc.pieces()
@@ -349,6 +350,65 @@ def test_two_element_fit_in_chunks_through_the_tiled_gram_kernel():
     model.fit_from_pieces(pieces, weight=0.3)
     pred = model.predict(x_f)
     assert rel_err(pred, x_f @ ref["coefficients"]) < 1e-6
+
+
+@pytest.mark.parametrize("elements,numbers,reps", [(['Mo', 'W'], [42, 74], (10, 20, 25)),
+                                                    (['Mo', 'W'], [42, 74, 74, 74, 74], (10, 20, 25)),
+                                                    (['Mo', 'Nb', 'W'], [41, 42, 74], (12, 22, 25))])
+def test_force_row_gram_by_species_equals_the_dense_product(elements, numbers, reps):
+    """uf3_gram_force_rows_dev (rows listed by species on the device, each list multiplied on the columns of its species'
+    blocks) == uf3_gram_dev on the same rows in HBM, X^T y included; overwrite, then accumulate.  Even and 20 / 80
+    compositions, three species; and the rows really are zero outside the columns the entry multiplies."""
+    import torch
+    from uf3_amd.data import composition
+    dev = torch.device("cuda", 0)
+    basis = synthetic.notebook_basis(elements)
+    fz = process.BasisFeaturizer(basis)
+    ctx, db = fz._dev()
+    F = basis.n_feats
+    frames = [synthetic.lattice_frame("bcc", reps, 3.165, numbers, seed=900 + k) for k in range(5)]
+    batch = _lib.FrameBatch(frames)
+    n_atoms = batch.n_atoms
+    assert 3 * n_atoms // len(elements) >= 65536
+    d_pos, d_z = torch.from_numpy(batch.pos).to(dev), torch.from_numpy(batch.z).to(dev)
+    x_e = torch.empty((len(frames), F), dtype=torch.float64, device=dev)
+    x_f = torch.empty((3 * n_atoms, F), dtype=torch.float64, device=dev)
+    y_f = torch.from_numpy(np.random.default_rng(3).normal(size=3 * n_atoms)).to(dev)
+    prev = ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+    try:
+        fz.featurize_device(batch.struct, d_pos.data_ptr(), d_z.data_ptr(), x_e.data_ptr(), x_f.data_ptr())
+        g_ref, o_ref = torch.empty((F, F), dtype=torch.float64, device=dev), torch.empty(F, dtype=torch.float64, device=dev)
+        g, o = torch.full((F, F), 7.0, dtype=torch.float64, device=dev), torch.full((F,), 7.0, dtype=torch.float64, device=dev)
+        ctx.check(ctx.lib.uf3_gram_dev(ctx.handle, x_f.data_ptr(), y_f.data_ptr(), 3 * n_atoms, F, F, 0, g_ref.data_ptr(),
+                                       o_ref.data_ptr()))
+        ctx.check(ctx.lib.uf3_gram_force_rows_dev(db.handle, x_f.data_ptr(), y_f.data_ptr(), d_z.data_ptr(), n_atoms, F, 0,
+                                                  g.data_ptr(), o.data_ptr()))
+        ctx.synchronize()
+        g1, o1 = g.cpu().numpy(), o.cpu().numpy()
+        ctx.check(ctx.lib.uf3_gram_force_rows_dev(db.handle, x_f.data_ptr(), y_f.data_ptr(), d_z.data_ptr(), n_atoms, F, 1,
+                                                  g.data_ptr(), o.data_ptr()))
+        ctx.synchronize()
+    finally:
+        ctx.restore_stream(prev)
+    g_ref, o_ref = g_ref.cpu().numpy(), o_ref.cpu().numpy()
+    scale = np.abs(g_ref).max()
+    assert np.abs(g1 - g_ref).max() < 1e-12 * scale and np.array_equal(g1, g1.T)
+    assert np.abs(o1 - o_ref).max() < 1e-11 * np.abs(o_ref).max()
+    assert np.abs(g.cpu().numpy() - 2 * g_ref).max() < 2e-12 * scale
+    assert np.abs(o.cpu().numpy() - 2 * o_ref).max() < 2e-11 * np.abs(o_ref).max()
+    # the premise, on the rows themselves: an atom's rows vanish in every block its species takes no part in
+    sizes, offsets = basis.get_interaction_partitions()
+    rows = x_f.view(n_atoms, 3, F)
+    for el in basis.element_list:
+        inside = np.zeros(F, dtype=bool)
+        for inter in sizes:
+            if not isinstance(inter, str) and el in inter:
+                inside[offsets[inter]:offsets[inter] + sizes[inter]] = True
+        assert 0 < inside.sum() < F
+        idx = torch.from_numpy(np.flatnonzero(batch.z == composition.atomic_numbers[el])[:4000]).to(dev)
+        assert len(idx) > 100
+        outside = torch.from_numpy(np.flatnonzero(~inside)).to(dev)
+        assert float(rows[idx][:, :, outside].abs().max()) == 0.0
 
 
 def test_fit_bookkeeping_entries_against_numpy():

@@ -22,7 +22,7 @@ EXPORTS = ["uf3_ctx_create", "uf3_ctx_destroy", "uf3_ctx_set_stream", "uf3_ctx_s
            "uf3_featurize", "uf3_featurize_dev", "uf3_gram", "uf3_gram_dev",
            "uf3_eval", "uf3_eval_dev", "uf3_eval_virial", "uf3_eval_virial_dev", "uf3_eval_atoms", "uf3_eval_atoms_dev",
            "uf3_eval_centres", "uf3_eval_centres_dev",
-           "uf3_neighbors_debug", "uf3_fit_rows_dev", "uf3_fit_pack_dev"]
+           "uf3_neighbors_debug", "uf3_fit_rows_dev", "uf3_fit_pack_dev", "uf3_gram_force_rows_dev"]
 
 
 class HipUnavailable(RuntimeError):
@@ -128,6 +128,7 @@ def load():
         for name in ("uf3_eval_atoms", "uf3_eval_atoms_dev", "uf3_eval_centres", "uf3_eval_centres_dev"):
             getattr(lib, name).argtypes = [vp, C.POINTER(Frames), vp, vp, vp, vp, vp, i64, i64, vp, vp, vp]
         lib.uf3_neighbors_debug.argtypes = [vp, C.POINTER(Frames), vp, vp, vp, vp, i64, vp, vp, i64]
+        lib.uf3_gram_force_rows_dev.argtypes = [vp, vp, vp, vp, i64, i64, i32, vp, vp]
         lib.uf3_fit_rows_dev.argtypes = [vp, i32, i32, vp, vp, vp, vp, i64, vp, vp, i32, vp]
         lib.uf3_fit_pack_dev.argtypes = [vp, i32, vp, vp, i32, vp, vp, i32, dbl, dbl, vp]
         _lib = lib

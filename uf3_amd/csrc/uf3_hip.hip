@@ -57,14 +57,16 @@ struct uf3_ctx {
     Buf geoms, offsets, frame_of, atom_bin, atom_wrap, spec, key_in, key_out, val_in, val_out, sort_tmp,
         bin_start, slots, flags,
         n3_cnt, n3_int, n3_dbl, e_atom, nbr_f, coeff, stage_pos, stage_z, stage_out, stage_out2,
-        gram_tiles, gram_tij, frag, dbg,
+        gram_tiles[4], gram_tij, frag, dbg,
+        sp_rows, sp_seg,                // force rows by species (uf3_gram_force_rows_dev): row lists | segment starts, counts, cursors
         halo,                           // marks + index list of the halo atoms of a decomposed frame
         n3x_ent, n3x_off,               // extension lists (batches with atoms outside their cell; see N3Lists)
         bin_cnt;                        // atoms per cell-list bin (counting sort)
     int n3_cap = 0, cand_cap = 0;
     int n3x_cap = 0;                 // capacity of the extension lists (0 until a batch needed them)
     bool img_mode = false;           // a batch with atoms far outside their cell has been seen: 3-body launches with the image-range rule
-    int gram_plan_feat = 0, gram_plan_blocks = 0;    // workgroup plan of k_gram_tiled held in gram_tiles (for this n_feat; 0: none)
+    int gram_plan_np[4] = {0, 0, 0, 0}, gram_plan_blocks[4] = {0, 0, 0, 0}, gram_plan_next = 0;   // workgroup plans of k_gram_tiled held in
+                                                     // gram_tiles[] (each for this many 64-column ranges; 0: none)
     int gram_direct_feat = 0;                        // tile-pair table of k_gram_mfma held in gram_tij (for this n_feat; 0: none)
     bool n3_tuned = false;           // capacity re-sized once to the lists actually seen
     bool cand_tuned = false;         // a featurizer call has completed with the current candidate capacity
@@ -106,9 +108,11 @@ struct uf3_basis {
     int *d_dsrc = nullptr;           // colsrc as offsets into the dumped dense window (MFMA specialisation)
     unsigned short *d_gsrc = nullptr; // grouped windows: fold tables (FeatArgs::gsrc)
     size_t n_gsrc = 0;
-    bool all_grouped7 = false;
-    bool all_banded9 = false;        // every mode-9 trio runs banded (trio_block_banded)       // every mode-7 trio stages grouped windows (its force launches do not touch dsrc)
+    bool all_grouped7 = false;       // every mode-7 trio stages grouped windows (its force launches do not touch dsrc)
+    bool all_banded9 = false;        // every mode-9 trio runs banded (trio_block_banded)
     size_t n_dsrc = 0;
+    int *d_sp_cols = nullptr;        // [S][F]: the columns of the blocks species s takes part in, ascending (uf3_gram_force_rows_dev)
+    int sp_ncols[UF3_MAX_SPECIES] = {0};
     std::vector<int> block_bounds;   // column boundaries of interaction blocks (for column windows)
     size_t c2_len = 0, c3_len = 0, n_recs = 0;
     size_t n_pair_recs = 0;
@@ -169,7 +173,9 @@ extern "C" void uf3_ctx_destroy(uf3_ctx *c) {
     hipStreamSynchronize(c->stream);
     Buf *all[] = {&c->geoms, &c->offsets, &c->frame_of, &c->atom_bin, &c->atom_wrap, &c->spec, &c->key_in,
                   &c->key_out, &c->val_in, &c->val_out, &c->sort_tmp, &c->bin_start, &c->slots, &c->flags, &c->n3_cnt, &c->n3_int, &c->n3_dbl, &c->e_atom, &c->nbr_f, &c->coeff,
-                  &c->stage_pos, &c->stage_z, &c->stage_out, &c->stage_out2, &c->gram_tiles, &c->gram_tij, &c->frag, &c->dbg, &c->halo, &c->n3x_ent, &c->n3x_off, &c->bin_cnt};
+                  &c->stage_pos, &c->stage_z, &c->stage_out, &c->stage_out2, &c->gram_tiles[0], &c->gram_tiles[1], &c->gram_tiles[2],
+                  &c->gram_tiles[3], &c->sp_rows, &c->sp_seg, &c->gram_tij, &c->frag, &c->dbg, &c->halo, &c->n3x_ent, &c->n3x_off,
+                  &c->bin_cnt};
     for (Buf *b : all) b->release();
     c->pin_in.release(); c->pin_geo.release(); c->pin_out.release(); c->pin_flags.release();
     for (auto &pd : c->pending_chk) if (pd.ev) hipEventDestroy(pd.ev);
@@ -578,6 +584,22 @@ extern "C" int uf3_basis_create(uf3_ctx *c, const uf3_basis_spec *s, uf3_basis *
         }
         if (trios[t].dim_l != trios[0].dim_l || trios[t].dim_m != trios[0].dim_m || trios[t].dim_n != trios[0].dim_n) h.trio_legs_uniform = 0;
     }
+    // the force rows of an atom of species s are zero outside the blocks s takes part in (and in the one-body columns)
+    {
+        std::vector<int> sp_cols((size_t)h.S * h.F, 0);
+        for (int sp = 0; sp < h.S; sp++) {
+            std::vector<char> in(h.F, 0);
+            for (int p2 = 0; p2 < h.P; p2++)
+                if (h.pairs[p2].sa == sp || h.pairs[p2].sb == sp) for (int q = 0; q < h.pairs[p2].nb; q++) in[h.pairs[p2].col + q] = 1;
+            for (auto &td : trios)
+                if (td.sc == sp || td.sa == sp || td.sb == sp) for (int q = 0; q < td.ncol; q++) in[td.col + q] = 1;
+            int n = 0;
+            for (int q = 0; q < h.F; q++) if (in[q]) sp_cols[(size_t)sp * h.F + n++] = q;
+            b->sp_ncols[sp] = n;
+        }
+        HIPCHK(c, hipMalloc(&b->d_sp_cols, sizeof(int) * sp_cols.size()));
+        HIPCHK(c, hipMemcpy(b->d_sp_cols, sp_cols.data(), sizeof(int) * sp_cols.size(), hipMemcpyHostToDevice));
+    }
     HIPCHK(c, hipMalloc(&b->dev, sizeof(BasisDev)));
     HIPCHK(c, hipMemcpy(b->dev, &h, sizeof(BasisDev), hipMemcpyHostToDevice));
     *out = b;
@@ -594,7 +616,7 @@ extern "C" void uf3_basis_destroy(uf3_basis *b) {
     if (!b) return;
     hipSetDevice(b->ctx->device);
     hipStreamSynchronize(b->ctx->stream);
-    hipFree(b->dev); hipFree(b->d_trios); hipFree(b->d_recs); hipFree(b->d_lut); hipFree(b->d_colsrc); hipFree(b->d_dsrc); hipFree(b->d_gsrc);
+    hipFree(b->dev); hipFree(b->d_trios); hipFree(b->d_recs); hipFree(b->d_lut); hipFree(b->d_colsrc); hipFree(b->d_dsrc); hipFree(b->d_gsrc); hipFree(b->d_sp_cols);
     delete b;
 }
 
@@ -1531,6 +1553,109 @@ static int ensure_frag(uf3_ctx *c) {
     return UF3_OK;
 }
 
+// k_gram_tiled over all rows and columns (rowmap == nullptr), or over the rows rowmap[seg[0] .. seg[0] + seg[1]) -- seg on the
+// device -- and the n_cols columns of colmap: n_rows is then the bound the grid covers, n_rows_plan what a segment is expected
+// to hold (the chunks are cut for it; workgroups past the segment leave at once).  Accumulates the upper triangle.
+static int launch_gram_tiled(uf3_ctx *c, const double *dx, const double *dy, int64_t n_rows, int64_t n_rows_plan, int n_feat,
+                             int64_t ld, double *d_gram, double *d_ord, const int *rowmap, const int *seg, const int *colmap,
+                             int n_cols) {
+    hipStream_t st = c->stream;
+    const int np = (n_cols + 63) / 64;
+    // LDS-tiled kernel: patches of 64 x 64 packed into workgroups (at most four patches on at most four column ranges)
+    int ps = -1;
+    for (int q = 0; q < 4; q++) if (c->gram_plan_np[q] == np) ps = q;
+    if (ps < 0) {
+        ps = c->gram_plan_next;
+        c->gram_plan_next = (ps + 1) & 3;
+        std::vector<GramBlock> plan;
+        auto fresh = [&]() { GramBlock g; memset(&g, 0, sizeof g); for (int q = 0; q < 4; q++) g.range[q] = -1; return g; };
+        auto slot_of = [&](GramBlock &g, int r, bool add) {
+            for (int q = 0; q < 4; q++) if (g.range[q] == r) return q;
+            if (add) for (int q = 0; q < 4; q++) if (g.range[q] < 0) { g.range[q] = r; return q; }
+            return -1;
+        };
+        auto n_waves = [&](const GramBlock &g) { int n = 0; for (int w = 0; w < 4; w++) n += g.kind[w] != 0; return n; };
+        auto fits = [&](const GramBlock &g, int pa, int pb) {
+            if (n_waves(g) >= 4) return false;
+            int free_slots = 0, need = 0;
+            bool has_a = false, has_b = false;
+            for (int q = 0; q < 4; q++) { free_slots += g.range[q] < 0; has_a |= g.range[q] == pa; has_b |= g.range[q] == pb; }
+            need = (has_a ? 0 : 1) + ((has_b || pb == pa) ? 0 : 1);
+            return need <= free_slots;
+        };
+        auto add_patch = [&](GramBlock &g, int pa, int pb) {
+            const int w = n_waves(g);
+            g.wa[w] = slot_of(g, pa, true); g.wb[w] = slot_of(g, pb, true);
+            g.kind[w] = pa == pb ? 2 : 1;
+            if (pa == pb) g.ord_mask |= 1 << g.wa[w];
+        };
+        // diagonal patches four at a time (equal work per wave)
+        for (int p0 = 0; p0 < np; p0 += 4) {
+            GramBlock g = fresh();
+            for (int p = p0; p < std::min(np, p0 + 4); p++) add_patch(g, p, p);
+            plan.push_back(g);
+        }
+        // off-diagonal patches four to a workgroup on at most four ranges: greedy (to the patch that opened the workgroup add
+        // the ones that need no new range, then one, then two), over the natural order and a few shuffles of it; the fewest
+        // workgroups win (every workgroup costs the time of a full patch, however many of its waves have one)
+        std::vector<std::pair<int, int>> pairs;
+        for (int pa = 0; pa < np; pa++) for (int pb = pa + 1; pb < np; pb++) pairs.push_back({pa, pb});
+        std::vector<GramBlock> best;
+        unsigned lcg = 12345u;
+        for (int attempt = 0; attempt < 64; attempt++) {
+            std::vector<std::pair<int, int>> left = pairs;
+            if (attempt)
+                for (size_t q = left.size(); q > 1; q--) { lcg = lcg * 1664525u + 1013904223u; std::swap(left[q - 1], left[(lcg >> 8) % q]); }
+            std::vector<GramBlock> blocks;
+            while (!left.empty()) {
+                GramBlock g = fresh();
+                add_patch(g, left[0].first, left[0].second);
+                left.erase(left.begin());
+                while (n_waves(g) < 4 && !left.empty()) {
+                    int pick = -1;
+                    for (int need = 0; need <= 2 && pick < 0; need++)
+                        for (size_t q = 0; q < left.size() && pick < 0; q++) {
+                            const int n_new = (slot_of(g, left[q].first, false) < 0) + (slot_of(g, left[q].second, false) < 0);
+                            if (n_new == need && fits(g, left[q].first, left[q].second)) pick = (int)q;
+                        }
+                    if (pick < 0) break;
+                    add_patch(g, left[pick].first, left[pick].second);
+                    left.erase(left.begin() + pick);
+                }
+                blocks.push_back(g);
+            }
+            if (best.empty() || blocks.size() < best.size()) best = blocks;
+            if (best.size() * 4 < pairs.size() + 4) break;                  // (cannot get better)
+        }
+        for (auto &g : best) plan.push_back(g);
+        for (auto &g : plan)
+            for (int q = 0; q < 4; q++) if (g.range[q] < 0) g.range[q] = g.range[0];
+        c->gram_plan_np[ps] = 0;
+        HIPCHK(c, hipStreamSynchronize(st));                           // (a launch may still be reading the plan this one replaces)
+        HIPCHK(c, c->gram_tiles[ps].ensure(sizeof(GramBlock) * plan.size()));
+        HIPCHK(c, hipMemcpyAsync(c->gram_tiles[ps].p, plan.data(), sizeof(GramBlock) * plan.size(), hipMemcpyHostToDevice, st));
+        HIPCHK(c, hipStreamSynchronize(st));
+        c->gram_plan_np[ps] = np; c->gram_plan_blocks[ps] = (int)plan.size();
+    }
+    // row chunks: about two rounds of workgroups over the chip's resident slots (two per CU)
+    const int bpc = c->gram_plan_blocks[ps];
+    // (measured flat between two and twelve workgroups per CU)
+    const int want_chunks = std::max(8, (c->n_cu * 4 + bpc - 1) / bpc / 8 * 8);
+    int64_t rpc = (n_rows_plan + want_chunks - 1) / want_chunks;
+    rpc = std::max<int64_t>(256, (rpc + GT_KS - 1) / GT_KS * GT_KS);
+    const int chunks = (int)((n_rows + rpc - 1) / rpc), chunks8 = (chunks + 7) / 8 * 8;
+    if (rowmap)
+        hipLaunchKernelGGL(k_gram_tiled<true>, dim3(bpc * chunks8), dim3(256), 0, st, dx, (d_ord && dy) ? dy : nullptr, n_rows, n_feat,
+                           ld, (int)rpc, bpc, (const GramBlock *)c->gram_tiles[ps].p, c->frag.as<int>(), d_gram, d_ord, rowmap, seg, colmap,
+                           n_cols);
+    else
+        hipLaunchKernelGGL(k_gram_tiled<false>, dim3(bpc * chunks8), dim3(256), 0, st, dx, (d_ord && dy) ? dy : nullptr, n_rows, n_feat,
+                           ld, (int)rpc, bpc, (const GramBlock *)c->gram_tiles[ps].p, c->frag.as<int>(), d_gram, d_ord,
+                           (const int *)nullptr, (const int *)nullptr, (const int *)nullptr, n_feat);
+    HIPCHK(c, hipGetLastError());
+    return UF3_OK;
+}
+
 extern "C" int uf3_gram_dev(uf3_ctx *c, const double *dx, const double *dy, int64_t n_rows, int32_t n_feat, int64_t ld,
                             int accumulate, double *d_gram, double *d_ord) {
     if (!c) return fail(nullptr, UF3_EINVAL, "null ctx");
@@ -1549,75 +1674,9 @@ extern "C" int uf3_gram_dev(uf3_ctx *c, const double *dx, const double *dy, int6
     // (and below ~64 k rows the row chunks get too short for the slab pipeline: 0.24 against 0.21 ms at 30 001 x 425)
     if (n_feat > 128 && n_rows >= 65536 && !getenv("UF3_GRAM_DIRECT")) {
         // LDS-tiled kernel: patches of 64 x 64 packed into workgroups (at most four patches on at most four column ranges)
-        if (c->gram_plan_feat != n_feat) {
-            const int np = (n_feat + 63) / 64;
-            std::vector<GramBlock> plan;
-            auto fresh = [&]() { GramBlock g; memset(&g, 0, sizeof g); for (int q = 0; q < 4; q++) g.range[q] = -1; return g; };
-            auto slot_of = [&](GramBlock &g, int r, bool add) {
-                for (int q = 0; q < 4; q++) if (g.range[q] == r) return q;
-                if (add) for (int q = 0; q < 4; q++) if (g.range[q] < 0) { g.range[q] = r; return q; }
-                return -1;
-            };
-            auto n_waves = [&](const GramBlock &g) { int n = 0; for (int w = 0; w < 4; w++) n += g.kind[w] != 0; return n; };
-            auto fits = [&](const GramBlock &g, int pa, int pb) {
-                if (n_waves(g) >= 4) return false;
-                int free_slots = 0, need = 0;
-                bool has_a = false, has_b = false;
-                for (int q = 0; q < 4; q++) { free_slots += g.range[q] < 0; has_a |= g.range[q] == pa; has_b |= g.range[q] == pb; }
-                need = (has_a ? 0 : 1) + ((has_b || pb == pa) ? 0 : 1);
-                return need <= free_slots;
-            };
-            auto add_patch = [&](GramBlock &g, int pa, int pb) {
-                const int w = n_waves(g);
-                g.wa[w] = slot_of(g, pa, true); g.wb[w] = slot_of(g, pb, true);
-                g.kind[w] = pa == pb ? 2 : 1;
-                if (pa == pb) g.ord_mask |= 1 << g.wa[w];
-            };
-            // diagonal patches four at a time (equal work per wave)
-            for (int p0 = 0; p0 < np; p0 += 4) {
-                GramBlock g = fresh();
-                for (int p = p0; p < std::min(np, p0 + 4); p++) add_patch(g, p, p);
-                plan.push_back(g);
-            }
-            // complete 2 x 2 groups of full patches, then the leftovers first-fit
-            std::vector<std::pair<int, int>> left;
-            for (int a = 0; a < np; a += 2)
-                for (int b = a; b < np; b += 2) {
-                    const bool whole = b > a && a + 1 < np && b + 1 < np;
-                    if (whole) {
-                        GramBlock g = fresh();
-                        add_patch(g, a, b); add_patch(g, a, b + 1); add_patch(g, a + 1, b); add_patch(g, a + 1, b + 1);
-                        plan.push_back(g);
-                    } else {
-                        for (int pa = a; pa < std::min(np, a + 2); pa++)
-                            for (int pb = std::max(b, pa + 1); pb < std::min(np, b + 2); pb++) left.push_back({pa, pb});
-                    }
-                }
-            std::vector<GramBlock> open;
-            for (auto &pp : left) {
-                bool placed = false;
-                for (auto &g : open) if (fits(g, pp.first, pp.second)) { add_patch(g, pp.first, pp.second); placed = true; break; }
-                if (!placed) { GramBlock g = fresh(); add_patch(g, pp.first, pp.second); open.push_back(g); }
-            }
-            for (auto &g : open) plan.push_back(g);
-            for (auto &g : plan)
-                for (int q = 0; q < 4; q++) if (g.range[q] < 0) g.range[q] = g.range[0];
-            c->gram_plan_feat = 0;
-            HIPCHK(c, c->gram_tiles.ensure(sizeof(GramBlock) * plan.size()));
-            HIPCHK(c, hipMemcpyAsync(c->gram_tiles.p, plan.data(), sizeof(GramBlock) * plan.size(), hipMemcpyHostToDevice, st));
-            HIPCHK(c, hipStreamSynchronize(st));
-            c->gram_plan_feat = n_feat; c->gram_plan_blocks = (int)plan.size();
-        }
-        // row chunks: about two rounds of workgroups over the chip's resident slots (two per CU)
-        const int bpc = c->gram_plan_blocks;
-        // (measured flat between two and twelve workgroups per CU)
-        const int want_chunks = std::max(8, (c->n_cu * 4 + bpc - 1) / bpc / 8 * 8);
-        int64_t rpc = (n_rows + want_chunks - 1) / want_chunks;
-        rpc = std::max<int64_t>(256, (rpc + GT_KS - 1) / GT_KS * GT_KS);
-        const int chunks = (int)((n_rows + rpc - 1) / rpc), chunks8 = (chunks + 7) / 8 * 8;
         Timed tm(c, T_GRAM);
-        hipLaunchKernelGGL(k_gram_tiled, dim3(bpc * chunks8), dim3(256), 0, st, dx, (d_ord && dy) ? dy : nullptr, n_rows, n_feat,
-                           ld, (int)rpc, bpc, (const GramBlock *)c->gram_tiles.p, c->frag.as<int>(), d_gram, d_ord);
+        rc = launch_gram_tiled(c, dx, dy, n_rows, n_rows, n_feat, ld, d_gram, d_ord, nullptr, nullptr, nullptr, n_feat);
+        if (rc) return rc;
         hipLaunchKernelGGL(k_gram_mirror, dim3((n_feat + 255) / 256, n_feat), dim3(256), 0, st, d_gram, n_feat);
         HIPCHK(c, hipGetLastError());
         return UF3_OK;
@@ -1666,6 +1725,50 @@ extern "C" int uf3_gram_dev(uf3_ctx *c, const double *dx, const double *dy, int6
                            (int)rpc, blocks_xy, d_ti, d_tj, c->frag.as<int>(), d_gram, d_ord);
         hipLaunchKernelGGL(k_gram_mirror, dim3((n_feat + 255) / 256, n_feat), dim3(256), 0, st, d_gram, n_feat);
     }
+    HIPCHK(c, hipGetLastError());
+    return UF3_OK;
+}
+
+extern "C" int uf3_gram_force_rows_dev(uf3_basis *b, const double *d_x_f, const double *d_y_f, const int32_t *d_z, int64_t n_atoms,
+                                       int64_t ld, int accumulate, double *d_gram, double *d_ord) {
+    if (!b) return fail(nullptr, UF3_EINVAL, "null basis");
+    uf3_ctx *c = b->ctx;
+    const int F = b->host.F, S = b->host.S;
+    if (!d_x_f || !d_gram || !d_z || n_atoms < 0 || ld < F || 3 * n_atoms > INT32_MAX)
+        return fail(c, UF3_EINVAL, "uf3_gram_force_rows_dev: bad argument");
+    int widest = 0;
+    for (int sp = 0; sp < S; sp++) widest = std::max(widest, b->sp_ncols[sp]);
+    // One species, a narrow matrix or short segments: the plain product (same result; the zero columns are multiplied).  Also
+    // when no species leaves out at least one 64-column range's worth of columns.
+    if (S < 2 || F <= 128 || 3 * n_atoms / S < 65536 || (widest + 63) / 64 >= (F + 63) / 64 || getenv("UF3_GRAM_DENSE"))
+        return uf3_gram_dev(c, d_x_f, d_y_f, 3 * n_atoms, F, ld, accumulate, d_gram, d_ord);
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = ensure_frag(c);
+    if (rc) return rc;
+    hipStream_t st = c->stream;
+    if (!accumulate) {
+        HIPCHK(c, hipMemsetAsync(d_gram, 0, 8 * (size_t)F * F, st));
+        if (d_ord) HIPCHK(c, hipMemsetAsync(d_ord, 0, 8 * (size_t)F, st));
+    }
+    if (n_atoms == 0) return UF3_OK;
+    // row lists by species (readable two slabs past the end: the kernel fetches row indices a slab ahead)
+    const size_t n_list = 3 * (size_t)n_atoms + 2 * GT_KS + 8;
+    HIPCHK(c, c->sp_rows.ensure(sizeof(int) * n_list));
+    HIPCHK(c, c->sp_seg.ensure(sizeof(int) * 3 * UF3_MAX_SPECIES));
+    int *seg = c->sp_seg.as<int>(), *cursor = seg + 2 * UF3_MAX_SPECIES, *rows = c->sp_rows.as<int>();
+    Timed tm(c, T_GRAM);
+    HIPCHK(c, hipMemsetAsync(seg, 0, sizeof(int) * 3 * UF3_MAX_SPECIES, st));
+    HIPCHK(c, hipMemsetAsync(rows + 3 * n_atoms, 0, sizeof(int) * (n_list - 3 * (size_t)n_atoms), st));
+    const unsigned nblk = (unsigned)((n_atoms + 255) / 256);
+    hipLaunchKernelGGL(k_species_rows, dim3(nblk), dim3(256), 0, st, (const BasisDev *)b->dev, d_z, n_atoms, 0, seg, cursor, rows);
+    hipLaunchKernelGGL(k_species_rows, dim3(nblk), dim3(256), 0, st, (const BasisDev *)b->dev, d_z, n_atoms, 1, seg, cursor, rows);
+    for (int sp = 0; sp < S; sp++) {
+        if (b->sp_ncols[sp] == 0) continue;
+        rc = launch_gram_tiled(c, d_x_f, d_y_f, 3 * n_atoms, 3 * n_atoms / S, F, ld, d_gram, d_ord, rows, seg + 2 * sp,
+                               b->d_sp_cols + (size_t)sp * F, b->sp_ncols[sp]);
+        if (rc) return rc;
+    }
+    hipLaunchKernelGGL(k_gram_mirror, dim3((F + 255) / 256, F), dim3(256), 0, st, d_gram, F);
     HIPCHK(c, hipGetLastError());
     return UF3_OK;
 }

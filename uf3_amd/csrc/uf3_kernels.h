@@ -2669,9 +2669,16 @@ __device__ __forceinline__ void gram_slab_steps(const double *sa, const double *
     }
 }
 
+// SUB: the product over a SUBSET of the rows and of the columns (uf3_gram_force_rows_dev: the force rows of the atoms of one
+// species, on the columns of the blocks that species takes part in).  rowmap lists the rows (seg[0]: first entry, seg[1]: how
+// many -- both on the device, nobody waits for the count; the list is readable two slabs past its end), colmap the n_cols
+// columns in ascending order; patches, ranges and the triangle test are in subset columns, gram / ord are written at the mapped
+// ones.  n_rows is then only the bound the launch was sized for.
+template <bool SUB>
 __global__ void __launch_bounds__(256, 2)
 k_gram_tiled(const double *x, const double *y, int64_t n_rows, int n_feat, int64_t ld, int rows_per_chunk, int blocks_per_chunk,
-             const GramBlock *blocks, const int *frag_rowcol, double *gram, double *ord) {
+             const GramBlock *blocks, const int *frag_rowcol, double *gram, double *ord, const int *rowmap, const int *seg,
+             const int *colmap, int n_cols) {
     __shared__ double slab[4][GT_KS * GT_LDW];
     const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
     // all workgroups of one row chunk run on the same XCD, back to back (one L2 serves their re-reads)
@@ -2679,6 +2686,8 @@ k_gram_tiled(const double *x, const double *y, int64_t n_rows, int n_feat, int64
     const int chunk = xcd + 8 * (slot / blocks_per_chunk);
     const GramBlock gb = load_const(blocks + slot % blocks_per_chunk);
     const int64_t r0 = (int64_t)chunk * rows_per_chunk;
+    const int *rowbase = nullptr;
+    if (SUB) { n_rows = seg[1]; rowbase = rowmap + seg[0]; } else n_cols = n_feat;
     if (r0 >= n_rows) return;
     const int64_t r1 = min(n_rows, r0 + rows_per_chunk);
     const int kind = wave == 0 ? gb.kind[0] : (wave == 1 ? gb.kind[1] : (wave == 2 ? gb.kind[2] : gb.kind[3]));
@@ -2694,11 +2703,16 @@ k_gram_tiled(const double *x, const double *y, int64_t n_rows, int n_feat, int64
 #pragma unroll
     for (int q = 0; q < 4; q++) {
         const int col = gb.range[q] * 64 + sc;
-        pq[q] = x + (col < n_feat ? col : 0);
-        mq[q] = col < n_feat ? 1.0 : 0.0;
+        pq[q] = x + (col < n_cols ? (SUB ? colmap[col] : col) : 0);
+        mq[q] = col < n_cols ? 1.0 : 0.0;
     }
     const bool want_ord = gb.ord_mask != 0 && ord && y;
     double gq[4][GT_KS / 4], yq[GT_KS / 4], ysc = 0.0, oq[4] = {0.0, 0.0, 0.0, 0.0};
+    int ridx[GT_KS / 4];                                 // SUB: rows of the NEXT fetch (their indices arrive a slab ahead of the data)
+    if (SUB) {
+#pragma unroll
+        for (int j = 0; j < GT_KS / 4; j++) ridx[j] = rowbase[r0 + sr + 4 * j];
+    }
     // (X^T y is accumulated here, when the prefetched values are consumed anyway -- at fetch time it would wait for the
     // loads before the slab's MFMAs instead of after them)
     auto store = [&](bool with_ord) {
@@ -2726,10 +2740,14 @@ k_gram_tiled(const double *x, const double *y, int64_t n_rows, int n_feat, int64
             ysc = yscale;
 #pragma unroll
             for (int j = 0; j < GT_KS / 4; j++) {
-                const int64_t row = rs + sr + 4 * j;
+                const int64_t row = SUB ? (int64_t)ridx[j] : rs + sr + 4 * j;
                 if (ORD) yq[j] = y[row];
 #pragma unroll
                 for (int q = 0; q < 4; q++) gq[q][j] = pq[q][row * ld];
+            }
+            if (SUB) {
+#pragma unroll
+                for (int j = 0; j < GT_KS / 4; j++) ridx[j] = rowbase[rs + GT_KS + sr + 4 * j];
             }
         };
         if (n_full > 0) {
@@ -2748,10 +2766,11 @@ k_gram_tiled(const double *x, const double *y, int64_t n_rows, int n_feat, int64
         if (r_tail < r1) {                          // ragged end of the last chunk: rows past it are zeros
 #pragma unroll
             for (int j = 0; j < GT_KS / 4; j++) {
-                const int64_t row = r_tail + sr + 4 * j;
+                const int64_t lrow = r_tail + sr + 4 * j;
 #pragma unroll
                 for (int q = 0; q < 4; q++) gq[q][j] = 0.0;
-                if (row < r1) {
+                if (lrow < r1) {
+                    const int64_t row = SUB ? (int64_t)rowbase[lrow] : lrow;
 #pragma unroll
                     for (int q = 0; q < 4; q++) {
                         gq[q][j] = pq[q][row * ld];
@@ -2778,7 +2797,7 @@ k_gram_tiled(const double *x, const double *y, int64_t n_rows, int n_feat, int64
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             const int col = gb.range[q] * 64 + sc;
-            if (((gb.ord_mask >> q) & 1) && col < n_feat && oq[q] != 0.0) unsafeAtomicAdd(ord + col, oq[q]);
+            if (((gb.ord_mask >> q) & 1) && col < n_cols && oq[q] != 0.0) unsafeAtomicAdd(ord + (SUB ? colmap[col] : col), oq[q]);
         }
     }
     if (kind == 0) return;
@@ -2794,9 +2813,47 @@ k_gram_tiled(const double *x, const double *y, int64_t n_rows, int n_feat, int64
                 const int gi = a0 + 16 * i + frag_rowcol[(lane * 4 + v) * 2];
                 const int gj = b0 + 16 * j + frag_rowcol[(lane * 4 + v) * 2 + 1];
                 const double val = acc[i][j][v];
-                if (gi < n_feat && gj < n_feat && gj >= gi && val != 0.0) unsafeAtomicAdd(gram + (size_t)gi * n_feat + gj, val);
+                if (gi < n_cols && gj < n_cols && gj >= gi && val != 0.0) {
+                    const int mi = SUB ? colmap[gi] : gi, mj = SUB ? colmap[gj] : gj;
+                    unsafeAtomicAdd(gram + (size_t)mi * n_feat + mj, val);
+                }
             }
         }
+}
+
+// Force rows by species (uf3_gram_force_rows_dev).  seg[2 s] / seg[2 s + 1]: first entry and number of entries of species s
+// in rows[]; cursor[s]: entries handed out so far.  Two launches: counts (what = 0), then the lists (what = 1; the blocks
+// work the segment starts out of the counts themselves).  The three rows of an atom stay adjacent; the order of the atoms within
+// a segment is whatever the atomics make it (a sum over the rows does not care).
+__global__ void __launch_bounds__(256)
+k_species_rows(const BasisDev *B, const int32_t *z, int64_t n_atoms, int what, int *seg, int *cursor, int *rows) {
+    __shared__ int cnt[UF3_MAX_SPECIES], base[UF3_MAX_SPECIES];
+    const int tid = threadIdx.x;
+    if (tid < UF3_MAX_SPECIES) cnt[tid] = 0;
+    __syncthreads();
+    const int64_t m = (int64_t)blockIdx.x * 256 + tid;
+    int s = -1, rank = 0;
+    if (m < n_atoms) {
+        const int zz = z[m];
+        s = (zz >= 0 && zz < 120) ? B->z2s[zz] : -1;
+        if (s >= 0) rank = atomicAdd(&cnt[s], 1);
+    }
+    __syncthreads();
+    if (what == 0) {
+        if (tid < UF3_MAX_SPECIES && cnt[tid]) atomicAdd(&seg[2 * tid + 1], 3 * cnt[tid]);
+        return;
+    }
+    if (tid < UF3_MAX_SPECIES) {
+        int start = 0;
+        for (int q = 0; q < tid; q++) start += seg[2 * q + 1];
+        if (blockIdx.x == 0) seg[2 * tid] = start;
+        base[tid] = start + (cnt[tid] ? atomicAdd(&cursor[tid], 3 * cnt[tid]) : 0);
+    }
+    __syncthreads();
+    if (s >= 0) {
+        int *o = rows + base[s] + 3 * rank;
+        o[0] = (int)(3 * m); o[1] = (int)(3 * m + 1); o[2] = (int)(3 * m + 2);
+    }
 }
 
 // X^T X for narrow matrices (F <= 80: one-element bases, config 4's F = 73), slabs through LDS.  The direct kernel gives every

@@ -120,7 +120,10 @@ class DeviceFitAccumulator:
         self._counts[1] += float(n_yf)
         self._gram(x_e, d_ye, self.gram_e, self.ord_e)
         if self.with_forces:
-            self._gram(x_f.view(-1, self.n_feat), d_yf, self.gram_f, self.ord_f)
+            # (rows listed by species, each list multiplied on the columns of its species' blocks only)
+            self.ctx.check(self.ctx.lib.uf3_gram_force_rows_dev(
+                self.db.handle, x_f.data_ptr(), d_yf.data_ptr(), d_z.data_ptr(), n_atoms, self.n_feat, 1,
+                self.gram_f.data_ptr(), self.ord_f.data_ptr()))
 
     def packed(self):
         """Device tensor [G_e | G_f | o_e | o_f | m_e | m_f] on the UNFROZEN columns (F' of them): the additive
