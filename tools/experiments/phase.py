@@ -7,7 +7,7 @@ import torch
 from uf3_amd import _lib, synthetic
 from uf3_amd.representation import process
 dev = torch.device("cuda", 0)
-basis = synthetic.notebook_basis(['Mo', 'W'])
+basis = synthetic.notebook_basis(['Mo', 'W'], lead3=0 if 'lead0' in sys.argv else 3)
 frames = [synthetic.lattice_frame("bcc", (10, 20, 25), 3.165, [42, 74], 3000 + k) for k in range(8)]
 batch = _lib.FrameBatch(frames)
 fz = process.BasisFeaturizer(basis, device=0)

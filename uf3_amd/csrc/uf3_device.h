@@ -61,6 +61,7 @@ struct TrioDev {
     int band_tile[3];  // separate them, band_tile[b] = first column tile of band b); TrioHead::grouped = 1
     int layout;        // grouped windows: number of this trio's window layout (legs' knot sequences, window box, thresholds)
     int gsrc_off;      // ... and where its fold table starts in FeatArgs::gsrc
+    int wrow[3];       // ... and, per leg, the number of its first window row (one row per knot interval from 3 on, see uf3_basis_create)
 };
 
 struct BasisDev {

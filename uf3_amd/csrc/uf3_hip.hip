@@ -117,6 +117,8 @@ struct uf3_basis {
     size_t c2_len = 0, c3_len = 0, n_recs = 0;
     size_t n_pair_recs = 0;
     size_t trio_rec_lo = 0;          // first knot record a trio leg refers to
+    size_t wrow_lo = 0;              // where the window rows of the grouped layouts start (they follow the knot records)
+    int n_wrows = 0;                 // ... and how many there are
     int dense_stride[16] = {0};      // per featurizer mode: largest staged-record stride (doubles) among its trios
     int dense_stride_f[16] = {0};    // ... when force rows are wanted (grouped 3 x 3 x 9 windows stage 32-double records)
     bool dense_grouped[16] = {false}; // a trio of the mode stages grouped n windows (even-aligned groups: up to two padding records per pass)
@@ -295,6 +297,30 @@ static void fill_leg(LegDev &leg, const double *t, int nk, std::vector<KnotRec> 
     recs.insert(recs.end(), mine.begin(), mine.end());
 }
 
+// Coefficients, in powers of u = x - t[i], of the cubic B-spline basis function j on the knot interval (t[i], t[i+1]]:
+// Cox - de Boor with polynomials instead of numbers (long double; 0 / 0 := 0 at repeated knots).  Zero when the interval is
+// outside the function's support.
+static void bspline_piece(const double *t, int j, int i, double c[4]) {
+    long double cur[4][4];
+    for (int k = 0; k < 4; k++) for (int e = 0; e < 4; e++) cur[k][e] = (e == 0 && j + k == i) ? 1.0L : 0.0L;
+    for (int d = 1; d <= 3; d++)
+        for (int k = 0; k + d <= 3; k++) {
+            const int q = j + k;
+            const long double den1 = (long double)t[q + d] - t[q], den2 = (long double)t[q + d + 1] - t[q + 1];
+            long double out[4] = {0, 0, 0, 0};
+            if (den1 != 0) {
+                const long double a0 = ((long double)t[i] - t[q]) / den1, a1 = 1.0L / den1;
+                for (int e = 0; e < 4; e++) { out[e] += a0 * cur[k][e]; if (e < 3) out[e + 1] += a1 * cur[k][e]; }
+            }
+            if (den2 != 0) {
+                const long double b0 = ((long double)t[q + d + 1] - t[i]) / den2, b1 = -1.0L / den2;
+                for (int e = 0; e < 4; e++) { out[e] += b0 * cur[k + 1][e]; if (e < 3) out[e + 1] += b1 * cur[k + 1][e]; }
+            }
+            for (int e = 0; e < 4; e++) cur[k][e] = out[e];
+        }
+    for (int e = 0; e < 4; e++) c[e] = (double)cur[0][e];
+}
+
 extern "C" int uf3_basis_create(uf3_ctx *c, const uf3_basis_spec *s, uf3_basis **out) {
     if (!c || !s || !out) return fail(c, UF3_EINVAL, "uf3_basis_create: null argument");
     if (s->n_species < 1 || s->n_species > UF3_MAX_SPECIES)
@@ -343,6 +369,7 @@ extern "C" int uf3_basis_create(uf3_ctx *c, const uf3_basis_spec *s, uf3_basis *
     b->n_pair_recs = recs.size();
     std::vector<TrioDev> trios(h.T);
     std::vector<const double *> legn_knots(h.T, nullptr);        // knots of leg n of every trio
+    std::vector<const double *> leg_knots(3 * (size_t)h.T, nullptr);   // ... and of every leg
     const double *tp = s->trio_knots;
     double lo3 = 1e300, hi3 = -1e300;
     size_t lut_len = 0;
@@ -358,6 +385,7 @@ extern "C" int uf3_basis_create(uf3_ctx *c, const uf3_basis_spec *s, uf3_basis *
             if (nk < 8) { delete b; return fail(c, UF3_EINVAL, "trio knot vector too short"); }
             fill_leg(td.leg[d], tp, nk, recs);
             if (d == 2) legn_knots[t] = tp;
+            leg_knots[3 * (size_t)t + d] = tp;
             for (int q = 0; q < nk; q++) {
                 lo3 = std::min(lo3, tp[q]);
                 if (d < 2) hi3 = std::max(hi3, tp[q]);     // angles.py:322-325: centre legs only
@@ -464,7 +492,7 @@ extern "C" int uf3_basis_create(uf3_ctx *c, const uf3_basis_spec *s, uf3_basis *
                 b->dense_grouped[9] = true;
             }
         }
-        if (td.dense) b->dense_stride_f[td.dense] = std::max(b->dense_stride_f[td.dense], td.grouped ? 32 : dl.stride);
+        if (td.dense) b->dense_stride_f[td.dense] = std::max(b->dense_stride_f[td.dense], td.grouped ? 34 : dl.stride);
         if (td.grouped && (td.leg[0].nk > 255 || td.leg[1].nk > 255 || td.leg[2].nk > 255 || recs.size() > 65535)) td.grouped = 0;   // (GroupedLayout packs them)
         if (td.dense && td.grouped) b->dense_grouped[td.dense] = true;
         td.thr0 = -1e300; td.thr2 = 1e300;
@@ -537,6 +565,54 @@ extern "C" int uf3_basis_create(uf3_ctx *c, const uf3_basis_spec *s, uf3_basis *
                 while (gsrc.size() & 1) gsrc.push_back(15);      // (blocks start on a 4-byte boundary)
             }
         }
+        // Window rows of the grouped layouts, appended to the knot records (so they travel to LDS with them): for every leg and
+        // knot interval i one row of 18 doubles [t_i, t_i+1 | 4 functions x (c0 c1 c2 c3)] -- the polynomial pieces, in powers of
+        // x - t_i, of four consecutive basis functions of the leg's window (leg n: the window of the GROUP interval i belongs
+        // to), starting at window slot sb: 0 for the legs l and m (three slots: the fourth function is not stored), and
+        // clamp(i - 3 - window start, 0, 1) for leg n (five slots: every function alive on the interval is among the four, the
+        // fifth slot is zero).  Zeros where a function is past the window or vanishes on the interval.  The staging pass
+        // evaluates a record's window slots straight from the row, every slot of every record is written in every pass, and
+        // nothing has to be cleared (trio_block_grouped).  TrioDev::wrow: the number of a leg's first row.
+        b->wrow_lo = recs.size();
+        std::vector<double> wrows;
+        int n_rows = 0;
+        for (size_t q = 0; q < layout_rep.size(); q++) {
+            const int t = layout_rep[q];
+            TrioDev &rep = trios[t];
+            for (int a = 0; a < 3; a++) {
+                const double *tk = leg_knots[3 * (size_t)t + a];
+                const int nk = rep.leg[a].nk;
+                rep.wrow[a] = n_rows;
+                for (int i = 3; i <= nk - 5; i++, n_rows++) {
+                    double row[18] = {0};
+                    row[0] = tk[i]; row[1] = tk[i + 1];
+                    int w_lo = rep.lo[a], w_ext = a == 0 ? rep.ext[0] : 3, sb = 0;
+                    if (a == 2) {
+                        const int f = i - 3 - rep.lo[2], grp = f <= 1 ? 0 : (f >= 4 ? 2 : 1);
+                        w_lo = rep.lo[2] + 2 * grp; w_ext = std::min(5, rep.ext[2] - 2 * grp);
+                        sb = std::max(0, std::min(1, f - 2 * grp));
+                    }
+                    for (int fq = 0; fq < 4 && sb + fq < w_ext; fq++) {
+                        const int j = w_lo + sb + fq;
+                        if (j >= i - 3 && j <= i && j >= 0 && j <= nk - 5) bspline_piece(tk, j, i, row + 2 + 4 * fq);
+                    }
+                    wrows.insert(wrows.end(), row, row + 18);
+                }
+            }
+        }
+        // (rows of nine 16-byte pairs, one behind the other: lanes that read pair k of different rows hit different banks -- 9 is
+        // odd, rows 16 apart share one)
+        b->n_wrows = n_rows;
+        while (wrows.size() % 12) wrows.push_back(0.0);
+        for (size_t q = 0; q < wrows.size(); q += 12) {
+            KnotRec kr;
+            std::memcpy(&kr, &wrows[q], sizeof kr);
+            recs.push_back(kr);
+        }
+        for (auto &td : trios)
+            if (td.grouped && td.layout >= 0) for (int a = 0; a < 3; a++) td.wrow[a] = trios[layout_rep[td.layout]].wrow[a];
+        if (n_rows > 65535)                                                 // (GroupedLayout packs the row numbers in 16 bits)
+            for (auto &td : trios) if (td.grouped) { delete b; return fail(c, UF3_EINVAL, "too many knot intervals for the grouped windows"); }
     }
     std::sort(bounds.begin(), bounds.end());
     bounds.erase(std::unique(bounds.begin(), bounds.end()), bounds.end());
@@ -1073,6 +1149,7 @@ extern "C" int uf3_featurize_dev(uf3_basis *b, const uf3_frames *fr, const doubl
         A.n_recs = (int)b->n_recs;
         A.n_pair_recs = (int)b->n_pair_recs;
         A.trio_rec_lo = (int)b->trio_rec_lo;
+        A.wrow_base = (int)(b->wrow_lo * 6); A.n_wrows = b->n_wrows;
         A.n_pair_cols = 0;
         for (int p = 0; p < b->host.P; p++) A.n_pair_cols += b->host.pairs[p].nb;
         if (old_n3) cap = A.n3.cap;
@@ -1104,7 +1181,12 @@ extern "C" int uf3_featurize_dev(uf3_basis *b, const uf3_frames *fr, const doubl
                 if (!(b->modes & (1 << mode))) continue;
                 const bool dense_mode = mode >= 6;
                 // knot records go to LDS when the block then still reaches the occupancy its registers allow
-                size_t n_rec_mode = mode == 0 ? b->n_pair_recs : b->n_recs - b->trio_rec_lo;
+                // (10: mode 7 with grouped windows only -- the force launches of a basis whose mode-7 blocks are all grouped)
+                const int launch_mode = (mode == 7 && want_f && b->all_grouped7 && !img_launch && !getenv("UF3_NO_GROUPED_ONLY")) ? 10
+                                        : ((mode == 9 && want_f && b->all_banded9 && !img_launch && !getenv("UF3_NO_GROUPED_ONLY")) ? 11 : mode);
+                // (a grouped-only launch reads the window rows, not the knot records of the legs)
+                A.trio_rec_lo = (int)(launch_mode == 10 ? b->wrow_lo : b->trio_rec_lo);
+                size_t n_rec_mode = mode == 0 ? b->n_pair_recs : b->n_recs - (size_t)A.trio_rec_lo;
                 const int S = b->host.S;
                 const size_t cu_lds = 160 * 1024 - 1024;
                 if (dense_mode) A.dsrc_lds = dsrc_ok && !(mode == 7 && want_f && b->all_grouped7);
@@ -1128,14 +1210,15 @@ extern "C" int uf3_featurize_dev(uf3_basis *b, const uf3_frames *fr, const doubl
                     if (mode <= 7 && !getenv("UF3_NO_OCC3")) {
                         // records per staging pass: as many as the stage allows; fewer (smaller stage) if that lets a third
                         // workgroup onto the CU -- the kernel is latency-bound.  Three workgroups per CU need <= 52 KB each
-                        // (LDS is granted in coarse granules: 53 KB did not fit).  Candidates in order of preference: more
-                        // records per pass first, tables in LDS before tables in HBM
+                        // (LDS is granted in coarse granules: 53 KB did not fit).  Candidates in order of preference: the
+                        // knot records / window rows in LDS first, then more records per pass
                         const int tries[3] = {nrec_max, std::min(nrec_max, 20), std::min(nrec_max, 15)};
                         const size_t budget = (WPB == 4 ? 52 : 13 * WPB) * 1024;      // (12 waves per CU: 3 x 4 or 2 x 6)
                         const bool dsrc_allowed = A.dsrc_lds, recs_allowed = !getenv("UF3_NO_LDS_RECS") && !(img_launch && mode != 0);
                         for (int q = 0; q < 12 && !found; q++) {
-                            const int nr = tries[q / 4];
-                            const bool with_recs = (q & 2) == 0, with_dsrc = (q & 1) == 0;
+                            // (the records / window rows in LDS first: a staging lane reads eleven 16-byte pieces of them per pass)
+                            const int nr = tries[(q % 6) / 2];
+                            const bool with_recs = q < 6, with_dsrc = (q & 1) == 0;
                             if ((with_recs && !recs_allowed) || (with_dsrc && !dsrc_allowed)) continue;
                             size_t need = feat_lds_bytes(F, S, cap, A.cand_cap, want_e && !A.e_direct, with_recs ? n_rec_mode : 0, mode,
                                                          stage_for(nr), nr, A.n_pair_cols) + (with_dsrc ? sizeof(int) * b->n_dsrc : 0) + gsrc_bytes;
@@ -1153,9 +1236,6 @@ extern "C" int uf3_featurize_dev(uf3_basis *b, const uf3_frames *fr, const doubl
                     recs_lds = lds_recs <= lds_target && !getenv("UF3_NO_LDS_RECS") && !(img_launch && mode != 0);
                     lds = recs_lds ? lds_recs : lds_plain;
                 }
-                // (10: mode 7 with grouped windows only -- the force launches of a basis whose mode-7 blocks are all grouped)
-                const int launch_mode = (mode == 7 && want_f && b->all_grouped7 && !img_launch && !getenv("UF3_NO_GROUPED_ONLY")) ? 10
-                                        : ((mode == 9 && want_f && b->all_banded9 && !img_launch && !getenv("UF3_NO_GROUPED_ONLY")) ? 11 : mode);
                 if (lds > 160 * 1024 - 512) return fail(c, UF3_EOVERFLOW, "featurizer LDS footprint exceeds 160 KB (F or neighbour count too large)");
                 // blocks of WPB waves, each walking a contiguous run of atoms (keeps the shared energy row on
                 // one frame); many more blocks than resident slots (measured: 2 per slot 3400 frames/s, 16-48 per slot

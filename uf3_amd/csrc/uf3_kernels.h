@@ -462,6 +462,7 @@ struct FeatArgs {
     int cand_cap;       // 2-body candidates staged per atom
     int n_recs;         // KnotRec count (for the LDS copy)
     int n_pair_recs;    // ... of which belong to the pair blocks (they come first)
+    int wrow_base, n_wrows;   // window rows of the grouped layouts: where they start (16-byte units from the first knot record), how many
     int trio_rec_lo;    // first record a trio leg refers to (>= n_pair_recs unless a trio leg shares a pair's knot sequence)
     int n_pair_cols;    // columns of all pair blocks together (they follow the S one-body columns)
     int dense_stage;    // doubles of per-wave stage the MFMA specialisation needs (max over dense trios)
@@ -1452,15 +1453,15 @@ __device__ __forceinline__ void trio_block_banded(const FeatArgs &A, const Basis
     "ds_read_b64 %[da], %[vd]\n"                                                                \
     "ds_read_b64 %[mb], %[vm]\n"                                                                \
     "ds_read_b64 %[nb], %[vn]\n"                                                                \
-    "ds_read_b64 %[la2], %[va] offset:512\n"                                                    \
-    "ds_read_b64 %[da2], %[vd] offset:512\n"                                                    \
-    "ds_read_b64 %[mb2], %[vm] offset:512\n"                                                    \
-    "ds_read_b64 %[nb2], %[vn] offset:512\n"                                                    \
+    "ds_read_b64 %[la2], %[va] offset:544\n"                                                    \
+    "ds_read_b64 %[da2], %[vd] offset:544\n"                                                    \
+    "ds_read_b64 %[mb2], %[vm] offset:544\n"                                                    \
+    "ds_read_b64 %[nb2], %[vn] offset:544\n"                                                    \
     "s_sub_u32 %[n" G "], %[n" G "], 2\n"                                                       \
-    "v_add_u32 %[va], 0x400, %[va]\n"                                                           \
-    "v_add_u32 %[vd], 0x400, %[vd]\n"                                                           \
-    "v_add_u32 %[vm], 0x400, %[vm]\n"                                                           \
-    "v_add_u32 %[vn], 0x400, %[vn]\n"                                                           \
+    "v_add_u32 %[va], 0x440, %[va]\n"                                                           \
+    "v_add_u32 %[vd], 0x440, %[vd]\n"                                                           \
+    "v_add_u32 %[vm], 0x440, %[vm]\n"                                                           \
+    "v_add_u32 %[vn], 0x440, %[vn]\n"                                                           \
     "s_waitcnt lgkmcnt(4)\n"                                                                    \
     "v_mul_f64 %[la], %[la], %[da]\n"                                                           \
     "v_mul_f64 %[mb], %[mb], %[nb]\n"                                                           \
@@ -1478,10 +1479,10 @@ __device__ __forceinline__ void trio_block_banded(const FeatArgs &A, const Basis
     "ds_read_b64 %[da], %[vd]\n"                                                                \
     "ds_read_b64 %[mb], %[vm]\n"                                                                \
     "ds_read_b64 %[nb], %[vn]\n"                                                                \
-    "v_add_u32 %[va], 0x200, %[va]\n"                                                           \
-    "v_add_u32 %[vd], 0x200, %[vd]\n"                                                           \
-    "v_add_u32 %[vm], 0x200, %[vm]\n"                                                           \
-    "v_add_u32 %[vn], 0x200, %[vn]\n"                                                           \
+    "v_add_u32 %[va], 0x220, %[va]\n"                                                           \
+    "v_add_u32 %[vd], 0x220, %[vd]\n"                                                           \
+    "v_add_u32 %[vm], 0x220, %[vm]\n"                                                           \
+    "v_add_u32 %[vn], 0x220, %[vn]\n"                                                           \
     "s_waitcnt lgkmcnt(2)\n"                                                                    \
     "v_mul_f64 %[la], %[la], %[da]\n"                                                           \
     "s_waitcnt lgkmcnt(0)\n"                                                                    \
@@ -1515,7 +1516,7 @@ struct GroupedLayout {
     double lo_r[3], hi_r[3], gthr0, gthr2;
     // per lane, packed (they stay in registers across blocks and atoms):
     unsigned ops;                         // byte offsets of the four MFMA operands inside a staged record: va | vd << 8 | vm << 16 | vn << 24
-    unsigned legpack;                     // staging role (li, leg): first knot record of the leg | knots << 16 | first pair of its window inside a record << 24
+    unsigned legpack;                     // staging role (li, leg): number of the leg's first window row (TrioDev::wrow) | knots << 16 | first pair of its window inside a record << 24
     double leg_t0, leg_inv_h;             // ... and its support start / interval guess
     unsigned tiles01, tiles23;            // accumulator element v -> double index inside a dumped group tile (16 bits each, 0xffff: none)
 };
@@ -1544,7 +1545,7 @@ __device__ __forceinline__ void grouped_layout_setup(const FeatArgs &A, int t, c
         L.ops = va | (vd << 8) | (vm << 16) | (vn << 24);                   // (a record is 256 bytes)
     }
     const int li = (lane * 21846) >> 16, leg = lane - 3 * li;
-    const int rec_off = leg == 0 ? td->leg[0].rec_off : (leg == 1 ? td->leg[1].rec_off : td->leg[2].rec_off);
+    const int rec_off = leg == 0 ? td->wrow[0] : (leg == 1 ? td->wrow[1] : td->wrow[2]);     // (the leg's window rows)
     const int nk = leg == 0 ? td->leg[0].nk : (leg == 1 ? td->leg[1].nk : td->leg[2].nk);
     L.leg_t0 = leg == 0 ? td->leg[0].t0 : (leg == 1 ? td->leg[1].t0 : td->leg[2].t0);
     L.leg_inv_h = leg == 0 ? td->leg[0].inv_h : (leg == 1 ? td->leg[1].inv_h : td->leg[2].inv_h);
@@ -1564,11 +1565,11 @@ __device__ __forceinline__ void grouped_layout_setup(const FeatArgs &A, int t, c
 }
 
 // th: the block's dispatch header; gsrc: its fold table (see FeatArgs::gsrc), gsrc_off = th.grouped >> 8
-template <bool WANT_E, bool IMG>
+template <bool WANT_E, bool IMG, bool ROWS_LDS>        // ROWS_LDS: recs (the window rows behind them) is an LDS copy
 __device__ __forceinline__ void trio_block_grouped(const FeatArgs &A, const BasisDev *B, const KnotRec *recs, const FrameGeom &g,
                                                    const WaveLds &w, int m, int sm, const TrioHead &th, const ESink &es,
                                                    const GroupedLayout &L, const unsigned short *gsrc) {
-    constexpr int STRIDE = 32, GW = 5, NG = 3;
+    constexpr int STRIDE = 34, GW = 5, NG = 3;   // (34, not 32: the same slot of consecutive records falls into different banks)
     constexpr bool WANT_F = true;
     PhaseClock pc;
     const int lane = lane_id();
@@ -1591,6 +1592,9 @@ __device__ __forceinline__ void trio_block_grouped(const FeatArgs &A, const Basi
     lg.rec_off = (int)(L.legpack & 0xffffu); lg.nk = (int)((L.legpack >> 16) & 0xffu); lg.t0 = L.leg_t0; lg.inv_h = L.leg_inv_h;
     lg.tlast = 0.0;
     const int w_off = (int)(L.legpack >> 24);
+    // the pair at oZ of every record slot -- what the masked operands read -- must be zero: the fold of the block before dumped its
+    // tiles over the stage (the only place these pairs are ever written)
+    if (lane < A.dense_stage / STRIDE) *(double2 *)(w.stage + lane * STRIDE + (oD + 8)) = double2{0.0, 0.0};
     pc.lap(1);
     for (int p0 = 0; p0 < k.n_items; p0 += batch) {
         int n_valid, n_g0, n_g01;
@@ -1624,20 +1628,18 @@ __device__ __forceinline__ void trio_block_grouped(const FeatArgs &A, const Basi
             const int st0 = (b0 + 1) >> 1, st1 = (b1 - b0 + 1) >> 1, st2 = (n_part - b1 + 1) >> 1;
             const int n_staged = 2 * (st0 + st1 + st2);
             const bool mine = li < n_part && !(A.skip & 16);
-            if (!(A.skip & 16)) {
-                // the pass's records (and its padding records) start from zero.  The usual stage (24 records of 32 doubles) is
-                // cleared whole by six unconditional stores -- cheaper than a loop over the records in use
-                if (A.dense_stage == 768) {
-#pragma unroll
-                    for (int u = 0; u < 6; u++) *(double2 *)(w.stage + 2 * lane + u * 2 * WAVE) = double2{0.0, 0.0};
-                } else
-                    for (int q = 2 * lane; q < n_staged * STRIDE; q += 2 * WAVE) *(double2 *)(w.stage + q) = double2{0.0, 0.0};
+            // Nothing is cleared: every slot of every record of the pass is written below (window slots from the leg's window row,
+            // zeros included), the pair at oZ is never written, and of a padding record -- the slot after an odd group -- only the
+            // l window matters (its A operand must be zero; the rest is multiplied by it, and stale stage contents are finite).
+            if (!(A.skip & 16) && lane < 9) {
+                const int pr = (lane * 21846) >> 16, ch = lane - 3 * pr;            // padding record pr, pair ch of its l window
+                const int odd0 = b0 & 1, odd1 = (b1 - b0) & 1, odd2 = (n_part - b1) & 1;
+                const int slot = pr == 0 ? b0 : (pr == 1 ? b1 + odd0 : n_part + odd0 + odd1);
+                if ((pr == 0 ? odd0 : (pr == 1 ? odd1 : odd2)) && ch < ext_l)
+                    *(double2 *)(w.stage + (size_t)slot * STRIDE + 2 * ch) = double2{0.0, 0.0};
             }
             if (mine) {
                 const int gi = base + li;
-                // the LDS round trips of a pass in two waves instead of seven: everything that hangs on gi alone first, then
-                // the knot record together with the direction components (left alone the compiler reads them one by one, each
-                // behind its own wait)
                 const double x = w.geo[leg * GEO_N + gi];
                 const int2 pk = ((const int2 *)(w.geo + 6 * GEO_N))[gi];
                 const double a3 = w.geo[(3 + leg) * GEO_N + gi];
@@ -1645,26 +1647,64 @@ __device__ __forceinline__ void trio_block_grouped(const FeatArgs &A, const Basi
                 const int i1 = pk.x & 0xffff, i2 = pk.x >> 16;
                 const double *oc = w.ox + (size_t)leg * A.n3.cap;
                 const double oc1 = oc[i1], oi1 = w.oir[i1], oc2 = oc[i2], oi2 = w.oir[i2];
-                KnotRec kr;
-                double v[4], d[4];
-                const int first = load_interval(recs, lg, x, kr) - 3;
-                bspline4<WANT_F>(kr, x, v, d);
-                double *rec = w.stage + (size_t)(li + (li >= b0 ? (b0 & 1) : 0) + (li >= b1 ? ((b1 - b0) & 1) : 0)) * STRIDE;
+                // the window row of x's knot interval: the whole row at the guessed interval at once, again only when the guess
+                // was off (non-uniform knots, x on a boundary)
+                const int hi = lg.nk - 5;
+                int iv = 3 + (int)((x - lg.t0) * lg.inv_h);
+                iv = iv < 3 ? 3 : (iv > hi ? hi : iv);
+                const double2 *rows = (const double2 *)recs + A.wrow_base + 9 * (lg.rec_off - 3);   // (rows of nine pairs, see uf3_basis_create)
+                double2 kn, cf[8];
+                // (through the LDS or the global address space explicitly: a generic pointer makes flat loads)
+                typedef double __attribute__((ext_vector_type(2))) Pair;
+                typedef const __attribute__((address_space(3))) Pair *LdsPairs;
+                typedef const __attribute__((address_space(1))) Pair *GlobalPairs;
+                typedef typename std::conditional<ROWS_LDS, LdsPairs, GlobalPairs>::type Pairs;
+                auto load_row = [&](int i) {
+                    Pairs q = (Pairs)(const Pair *)(rows + 9 * i);
+                    Pair t0 = q[0], t[8];
+#pragma unroll
+                    for (int e = 0; e < 8; e++) t[e] = q[1 + e];
+                    kn = double2{t0.x, t0.y};
+#pragma unroll
+                    for (int e = 0; e < 8; e++) cf[e] = double2{t[e].x, t[e].y};
+                    __builtin_amdgcn_sched_group_barrier(0x120, 9, 0);                   // DS or VMEM reads
+                };
+                load_row(iv);
+                if (__builtin_expect(x > kn.y && iv < hi, 0)) {
+                    do { ++iv; load_row(iv); } while (x > kn.y && iv < hi);
+                } else if (__builtin_expect(x <= kn.x && iv > 3, 0)) {
+                    do { --iv; load_row(iv); } while (x <= kn.x && iv > 3);
+                }
+                const double u = x - kn.x;
                 const int cls = pk.y & 3, grp = pk.y >> 2;
-                // leg n: window = the record's group; legs l, m: the block's window
-                const int w_lo = leg == 0 ? L.lo_l : (leg == 1 ? L.lo_m : L.lo_n + 2 * grp);
-                const int w_ext = leg == 0 ? ext_l : (leg == 1 ? ext_m : min(GW, ext_n - 2 * grp));
+                // first window slot of the row's four functions (see uf3_basis_create)
+                const int sb = leg == 2 ? max(0, min(1, iv - 3 - L.lo_n - 2 * grp)) : 0;
+                double *rec = w.stage + (size_t)(li + (li >= b0 ? (b0 & 1) : 0) + (li >= b1 ? ((b1 - b0) & 1) : 0)) * STRIDE;
+                double *win = rec + w_off + 2 * sb;
+                // which of (value, derivative) goes to K slot 0 / 1 (table in the header of this section)
                 const bool d0 = leg == 0 ? cls != 2 : (leg == 1 ? cls == 2 : false);
                 const bool d1 = leg == 0 ? false : (leg == 1 ? cls == 0 : cls != 0);
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const unsigned ws = (unsigned)(first + q - w_lo);
-                    if (ws < (unsigned)w_ext)
-                        *(double2 *)(rec + w_off + 2 * ws) = double2{d0 ? d[q] : v[q], d1 ? d[q] : v[q]};
-                }
                 const double u1 = oc1 * oi1, u2 = oc2 * oi2;
-                *(double2 *)(rec + oD + 2 * leg) = double2{u1, cls == 0 ? u2 : a3};
-                if (leg == 0 && cls == 0) rec[oD + 6] = 1.0;
+                const double2 dir = double2{u1, cls == 0 ? u2 : a3};
+                // five stores per lane.  Leg n: its four functions and the zero of the fifth slot; legs l and m (three slots): three
+                // functions, then leg l the energy flag and both their direction pair; leg n's direction pair is the sixth
+#pragma unroll
+                for (int fq = 0; fq < 4; fq++) {
+                    const double c0 = cf[2 * fq].x, c1 = cf[2 * fq].y, c2 = cf[2 * fq + 1].x, c3 = cf[2 * fq + 1].y;
+                    double pv = fma(c3, u, c2), pd = fma(c3, u, pv);            // Horner, value and derivative together
+                    pv = fma(pv, u, c1); pd = fma(pd, u, pv);
+                    pv = fma(pv, u, c0);
+                    double2 val = double2{d0 ? pd : pv, d1 ? pd : pv};
+                    double *dst = win + 2 * fq;
+                    bool on = fq < ext_l || leg != 0;                            // (a narrower l window ends where m's begins)
+                    if (fq == 3) {
+                        if (leg == 0) { val = double2{cls == 0 ? 1.0 : 0.0, 0.0}; dst = rec + oD + 6; on = true; }
+                        else if (leg == 1) { val = dir; dst = rec + oD + 2; }
+                    }
+                    if (on) *(double2 *)dst = val;
+                }
+                if (leg != 1) *(double2 *)(leg == 0 ? rec + oD : rec + w_off + (sb ? 0 : 8)) = leg == 0 ? dir : double2{0.0, 0.0};
+                if (leg == 2) *(double2 *)(rec + oD + 4) = dir;
             }
             wave_sync();
             pc.lap(4);
@@ -2078,7 +2118,7 @@ k_featurize(FeatArgs A) {
                 else if (MODE == 5) trio_block<WANT_E, WANT_F, 6, 1, IMG>(A, B, recs, g, w, m, sm, t, es);
                 else if (MODE == 7 && WANT_F && th.grouped) {
                     if (__builtin_expect((th.grouped & 0xff) - 1 != GL.id, 0)) grouped_layout_setup<WANT_E>(A, t, fragp, GL);
-                    trio_block_grouped<WANT_E, IMG>(A, B, recs, g, w, m, sm, th, es, GL, gsrc);
+                    trio_block_grouped<WANT_E, IMG, RECS_LDS>(A, B, recs, g, w, m, sm, th, es, GL, gsrc);
                 }
                 else if (MODE == 9 && WANT_F && th.grouped)
                     trio_block_banded<WANT_E, IMG>(A, B, recs, g, w, m, sm, t, es, fragp, dsrc);
