@@ -1009,7 +1009,7 @@ __device__ __forceinline__ void dense_fold(const FeatArgs &A, const WaveLds &w, 
     }
 }
 
-template <bool WANT_E, bool WANT_F, int MODE, bool IMG>
+template <bool WANT_E, bool WANT_F, int MODE, bool IMG, bool RL>
 __device__ __forceinline__ void trio_block_mfma(const FeatArgs &A, const BasisDev *B, const KnotRec *recs, const FrameGeom &g,
                                                 const WaveLds &w, int m, int sm, int t, const ESink &es,
                                                 const int (&fragp)[4], const int *dsrc) {
@@ -1134,7 +1134,7 @@ __device__ __forceinline__ void trio_block_mfma(const FeatArgs &A, const BasisDe
                              oi2 = WANT_F ? w.oir[i2] : 0.0;
                 KnotRec kr;
                 double v[4], d[4];
-                const int first = load_interval(recs, lg, x, kr) - 3;
+                const int first = load_interval<RL>(recs, lg, x, kr) - 3;
                 bspline4<WANT_F>(kr, x, v, d);
                 if (WANT_F) {
                     double *rec = w.stage + (size_t)li * dl.stride;
@@ -1279,7 +1279,7 @@ __device__ __forceinline__ void banded_steps(unsigned va0, unsigned vd0, unsigne
 #undef UF3_BAND_STEP
 #undef UF3_BAND_ADVANCE
 
-template <bool WANT_E, bool IMG>
+template <bool WANT_E, bool IMG, bool RL>
 __device__ __forceinline__ void trio_block_banded(const FeatArgs &A, const BasisDev *B, const KnotRec *recs, const FrameGeom &g,
                                                   const WaveLds &w, int m, int sm, int t, const ESink &es,
                                                   const int (&fragp)[4], const int *dsrc) {
@@ -1384,7 +1384,7 @@ __device__ __forceinline__ void trio_block_banded(const FeatArgs &A, const Basis
                 const double oc1 = oc[i1], oi1 = w.oir[i1], oc2 = oc[i2], oi2 = w.oir[i2];
                 KnotRec kr;
                 double v[4], d[4];
-                const int first = load_interval(recs, lg, x, kr) - 3;
+                const int first = load_interval<RL>(recs, lg, x, kr) - 3;
                 bspline4<WANT_F>(kr, x, v, d);
                 double *rec = w.stage + (size_t)(li + (li >= b0 ? (b0 & 1) : 0) + (li >= b1 ? ((b1 - b0) & 1) : 0)) * STRIDE;
                 const int cls = pk.y;
@@ -1555,7 +1555,9 @@ __device__ __forceinline__ void grouped_layout_setup(const FeatArgs &A, int t, c
     unsigned ts[4];
 #pragma unroll
     for (int v = 0; v < 4; v++) {
-        const int row = fragp[v] >> 4, col = fragp[v] & 15;
+        // (from the probed table itself, not from fragp: layouts change rarely -- never within a basis with one set of 3-body
+        // settings --, and in a grouped-only launch nothing else would keep those four registers alive)
+        const int row = load_const(A.frag + (lane * 4 + v) * 2), col = load_const(A.frag + (lane * 4 + v) * 2 + 1);
         const int c = (row * inv_l) >> 16, pl = row - c * ext_l;
         // (accumulator rows past the window -- 4 ext_l .. 15 -- are parked in row 3 of the tile when ext_l < 4, a row the fold
         // never reads, so that the dump needs no lane mask; with ext_l == 4 every row is in use)
@@ -1797,7 +1799,7 @@ __device__ __forceinline__ void trio_block_grouped(const FeatArgs &A, const Basi
 // bond once and adds its four basis values / derivatives into a per-wave row buffer in LDS (native ds_add_f64;
 // bonds of one shell hit the same four columns, the LDS serialises those); the buffer then leaves as coalesced
 // rows.  Columns of pair blocks the atom does not belong to stay zero in the buffer.
-template <bool WANT_E, bool WANT_F>
+template <bool WANT_E, bool WANT_F, bool RL>           // RL: recs is the workgroup's LDS copy
 __device__ __forceinline__ void pair_rows(const FeatArgs &A, const BasisDev *B, const KnotRec *recs, const WaveLds &w, int m,
                                           int sm, int n_cand, const ESink &es) {
     const int lane = lane_id(), F = B->F, S = B->S;
@@ -1828,7 +1830,7 @@ __device__ __forceinline__ void pair_rows(const FeatArgs &A, const BasisDev *B, 
             if (!(d > p_rmin && d < p_rmax)) continue;                // a 3-body-only neighbour
             KnotRec kr;
             double v[4], dv[4];
-            const int first = load_interval(recs, leg, d, kr) - 3;
+            const int first = load_interval<RL>(recs, leg, d, kr) - 3;
             bspline4<WANT_F>(kr, d, v, dv);
             const double s = 2.0 / d;                   // both directed images of the bond (distances.py:116-141)
             const double dir[3] = {s * c[0], s * c[1], s * c[2]};
@@ -2076,7 +2078,7 @@ k_featurize(FeatArgs A) {
             });
             if (n_cand > A.cand_cap) { if (lane == 0) atomicMax(A.cand_need, n_cand); n_cand = A.cand_cap; }
             wave_sync();
-            pair_rows<WANT_E, WANT_F>(A, B, recs, w, m, sm, n_cand, es);
+            pair_rows<WANT_E, WANT_F, RECS_LDS>(A, B, recs, w, m, sm, n_cand, es);
             if (A.build_n3) build_n3_list(A, B, g, w, m, n_cand);
         }
         // ---- 3-body ---------------------------------------------------------------------------
@@ -2121,9 +2123,9 @@ k_featurize(FeatArgs A) {
                     trio_block_grouped<WANT_E, IMG, RECS_LDS>(A, B, recs, g, w, m, sm, th, es, GL, gsrc);
                 }
                 else if (MODE == 9 && WANT_F && th.grouped)
-                    trio_block_banded<WANT_E, IMG>(A, B, recs, g, w, m, sm, t, es, fragp, dsrc);
+                    trio_block_banded<WANT_E, IMG, RECS_LDS>(A, B, recs, g, w, m, sm, t, es, fragp, dsrc);
                 else if (!GROUPED_ONLY)
-                    trio_block_mfma<WANT_E, WANT_F, (MODE >= 6 ? MODE : 6), IMG>(A, B, recs, g, w, m, sm, t, es, fragp, dsrc);
+                    trio_block_mfma<WANT_E, WANT_F, (MODE >= 6 ? MODE : 6), IMG, RECS_LDS>(A, B, recs, g, w, m, sm, t, es, fragp, dsrc);
             }
         }
     }
