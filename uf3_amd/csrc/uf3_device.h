@@ -175,31 +175,35 @@ __device__ __forceinline__ int find_interval(const KnotRec *recs, const LegDev &
 // Same search, returning the interval's record as well: the whole record at the initial guess is fetched at once
 // and only re-fetched when the guess was off (non-uniform knots, or x on an interval boundary), so the common
 // case costs one memory round trip instead of two.
-// LDS: the records are the workgroup's LDS copy -- said explicitly, because through a generic pointer these become flat loads
-// (slower than DS reads, and their results can only be waited for together with every global load and store in flight)
-template <bool LDS = false>
+// AS: where the records are -- 3: the workgroup's LDS copy, 1: global memory, 0: not said (a generic pointer).  Said explicitly
+// wherever the caller knows: through a generic pointer (a member of the kernel's argument struct) these become flat loads,
+// slower than DS reads, and their results can only be waited for together with everything else in flight on both counters.
+typedef double __attribute__((ext_vector_type(2))) KnotPair;
+template <int AS> struct KnotPairs { typedef const KnotPair *type; };
+template <> struct KnotPairs<1> { typedef const __attribute__((address_space(1))) KnotPair *type; };
+template <> struct KnotPairs<3> { typedef const __attribute__((address_space(3))) KnotPair *type; };
+
+template <int AS = 0>
 __device__ __forceinline__ void load_knot_rec(const KnotRec *p, KnotRec &k) {
     // six 16-byte reads issued back to back (the compiler otherwise fetches t[3], tests it, and only then the rest)
-    typedef double __attribute__((ext_vector_type(2))) Pair;
-    typedef typename std::conditional<LDS, const __attribute__((address_space(3))) Pair *, const Pair *>::type Pairs;
-    Pairs q = (Pairs)(const Pair *)p;
-    const Pair v0 = q[0], v1 = q[1], v2 = q[2], v3 = q[3], v4 = q[4], v5 = q[5];
+    typename KnotPairs<AS>::type q = (typename KnotPairs<AS>::type)(const KnotPair *)p;
+    const KnotPair v0 = q[0], v1 = q[1], v2 = q[2], v3 = q[3], v4 = q[4], v5 = q[5];
     __builtin_amdgcn_sched_group_barrier(0x120, 6, 0);             // DS or VMEM reads
     k.t[0] = v0.x; k.t[1] = v0.y; k.t[2] = v1.x; k.t[3] = v1.y; k.t[4] = v2.x; k.t[5] = v2.y;
     k.r[0] = v3.x; k.r[1] = v3.y; k.r[2] = v4.x; k.r[3] = v4.y; k.r[4] = v5.x; k.r[5] = v5.y;
 }
 
-template <bool LDS = false>
+template <int AS = 0>
 __device__ __forceinline__ int load_interval(const KnotRec *recs, const LegDev &leg, double x, KnotRec &k) {
     const int hi = leg.nk - 5;
     int i = 3 + (int)((x - leg.t0) * leg.inv_h);
     i = i < 3 ? 3 : (i > hi ? hi : i);
     const KnotRec *base = recs + leg.rec_off;
-    load_knot_rec<LDS>(base + i, k);
+    load_knot_rec<AS>(base + i, k);
     if (__builtin_expect(x > k.t[3] && i < hi, 0)) {
-        do { ++i; load_knot_rec<LDS>(base + i, k); } while (x > k.t[3] && i < hi);
+        do { ++i; load_knot_rec<AS>(base + i, k); } while (x > k.t[3] && i < hi);
     } else if (__builtin_expect(x <= k.t[2] && i > 3, 0)) {
-        do { --i; load_knot_rec<LDS>(base + i, k); } while (x <= k.t[2] && i > 3);
+        do { --i; load_knot_rec<AS>(base + i, k); } while (x <= k.t[2] && i > 3);
     }
     return i;
 }
@@ -207,20 +211,22 @@ __device__ __forceinline__ int load_interval(const KnotRec *recs, const LegDev &
 // The two halves of load_interval, for callers that look up several legs at once: every leg's record at its guessed
 // interval goes out first (load_interval_guess), the rare corrections follow (load_interval_fix) -- three dependent
 // memory round trips become one.
+template <int AS = 0>
 __device__ __forceinline__ int load_interval_guess(const KnotRec *recs, const LegDev &leg, double x, KnotRec &k) {
     const int hi = leg.nk - 5;
     int i = 3 + (int)((x - leg.t0) * leg.inv_h);
     i = i < 3 ? 3 : (i > hi ? hi : i);
-    load_knot_rec(recs + leg.rec_off + i, k);
+    load_knot_rec<AS>(recs + leg.rec_off + i, k);
     return i;
 }
+template <int AS = 0>
 __device__ __forceinline__ int load_interval_fix(const KnotRec *recs, const LegDev &leg, double x, int i, KnotRec &k) {
     const int hi = leg.nk - 5;
     const KnotRec *base = recs + leg.rec_off;
     if (__builtin_expect(x > k.t[3] && i < hi, 0)) {
-        do { ++i; load_knot_rec(base + i, k); } while (x > k.t[3] && i < hi);
+        do { ++i; load_knot_rec<AS>(base + i, k); } while (x > k.t[3] && i < hi);
     } else if (__builtin_expect(x <= k.t[2] && i > 3, 0)) {
-        do { --i; load_knot_rec(base + i, k); } while (x <= k.t[2] && i > 3);
+        do { --i; load_knot_rec<AS>(base + i, k); } while (x <= k.t[2] && i > 3);
     }
     return i;
 }

@@ -946,11 +946,24 @@ __device__ __forceinline__ void dense_fold(const FeatArgs &A, const WaveLds &w, 
     const bool in_regs = nsrc <= 2 && ncol <= MAXIT * WAVE;      // wave-uniform
     int o0[MAXIT], o1[MAXIT];
     if (in_regs) {
+        // (the table through the LDS or the global address space explicitly: a generic pointer makes flat loads)
+        auto fetch = [&](auto as_tag) {
+            typedef decltype(as_tag) Ints;
+            Ints tab = (Ints)(dsrc + td->src_off);
+#pragma unroll
+            for (int it = 0; it < MAXIT; it++) {
+                const int col = min(lane + it * WAVE, ncol - 1);
+                o0[it] = tab[col * nsrc];
+                o1[it] = tab[col * nsrc + (nsrc > 1 ? 1 : 0)];
+            }
+        };
+        if (A.dsrc_lds) fetch((const __attribute__((address_space(3))) int *)nullptr);
+        else fetch((const __attribute__((address_space(1))) int *)nullptr);
 #pragma unroll
         for (int it = 0; it < MAXIT; it++) {
             const int col = lane + it * WAVE;
-            o0[it] = col < ncol ? dsrc[td->src_off + col * nsrc] : -1;
-            o1[it] = (col < ncol && nsrc > 1) ? dsrc[td->src_off + col * nsrc + 1] : -1;
+            if (col >= ncol) o0[it] = -1;
+            if (col >= ncol || nsrc < 2) o1[it] = -1;
         }
     }
     for (int c0 = c_first; c0 <= c_last; c0 += cpp) {
@@ -1134,7 +1147,7 @@ __device__ __forceinline__ void trio_block_mfma(const FeatArgs &A, const BasisDe
                              oi2 = WANT_F ? w.oir[i2] : 0.0;
                 KnotRec kr;
                 double v[4], d[4];
-                const int first = load_interval<RL>(recs, lg, x, kr) - 3;
+                const int first = load_interval<RL ? 3 : 1>(recs, lg, x, kr) - 3;
                 bspline4<WANT_F>(kr, x, v, d);
                 if (WANT_F) {
                     double *rec = w.stage + (size_t)li * dl.stride;
@@ -1384,7 +1397,7 @@ __device__ __forceinline__ void trio_block_banded(const FeatArgs &A, const Basis
                 const double oc1 = oc[i1], oi1 = w.oir[i1], oc2 = oc[i2], oi2 = w.oir[i2];
                 KnotRec kr;
                 double v[4], d[4];
-                const int first = load_interval<RL>(recs, lg, x, kr) - 3;
+                const int first = load_interval<RL ? 3 : 1>(recs, lg, x, kr) - 3;
                 bspline4<WANT_F>(kr, x, v, d);
                 double *rec = w.stage + (size_t)(li + (li >= b0 ? (b0 & 1) : 0) + (li >= b1 ? ((b1 - b0) & 1) : 0)) * STRIDE;
                 const int cls = pk.y;
@@ -1830,7 +1843,7 @@ __device__ __forceinline__ void pair_rows(const FeatArgs &A, const BasisDev *B, 
             if (!(d > p_rmin && d < p_rmax)) continue;                // a 3-body-only neighbour
             KnotRec kr;
             double v[4], dv[4];
-            const int first = load_interval<RL>(recs, leg, d, kr) - 3;
+            const int first = load_interval<RL ? 3 : 1>(recs, leg, d, kr) - 3;
             bspline4<WANT_F>(kr, d, v, dv);
             const double s = 2.0 / d;                   // both directed images of the bond (distances.py:116-141)
             const double dir[3] = {s * c[0], s * c[1], s * c[2]};
@@ -2173,7 +2186,10 @@ struct EvalArgs {
 __device__ __forceinline__ bool trio_value(const BasisDev *B, const double *c3, int trio, double rl, double rm, double rn,
                                            bool want_grad, double &val, double *grad) {
     if (trio < 0) return false;
-    const TrioDev *td = load_const(&B->trios) + trio;
+    // (the per-lane descriptor through the global address space explicitly: B->trios is a pointer read from memory, through it
+    // the loads would be flat loads)
+    typedef const __attribute__((address_space(1))) TrioDev *GlobalTrio;
+    GlobalTrio td = (GlobalTrio)(load_const(&B->trios) + trio);
     const KnotRec *recs = load_const(&B->recs);
     // all descriptor fields in flight together (per-lane trio: vector loads), then a branch-free range test.  When every trio
     // has the same legs and grid (one set of 3-body settings: the usual case) those come from trio 0 through scalar loads and
@@ -2186,7 +2202,12 @@ __device__ __forceinline__ bool trio_value(const BasisDev *B, const double *c3, 
         l0 = load_const(&t0->leg[0]); l1 = load_const(&t0->leg[1]); l2 = load_const(&t0->leg[2]);
         dim_m = load_const(&t0->dim_m); dim_n = load_const(&t0->dim_n);
     } else {
-        l0 = td->leg[0]; l1 = td->leg[1]; l2 = td->leg[2];
+        auto leg_of = [&](int q) {
+            LegDev l;
+            l.rec_off = td->leg[q].rec_off; l.nk = td->leg[q].nk; l.t0 = td->leg[q].t0; l.tlast = td->leg[q].tlast; l.inv_h = td->leg[q].inv_h;
+            return l;
+        };
+        l0 = leg_of(0); l1 = leg_of(1); l2 = leg_of(2);
         dim_m = td->dim_m; dim_n = td->dim_n;
     }
     if (!((rl > l0.t0) & (rl < l0.tlast) & (rm > l1.t0) & (rm < l1.tlast) & (rn > l2.t0) & (rn < l2.tlast))) return false;
@@ -2194,8 +2215,8 @@ __device__ __forceinline__ bool trio_value(const BasisDev *B, const double *c3, 
     // the three legs' knot records go out together, then -- the coefficient block only needs the interval indices -- the
     // coefficient rows, EVAL_CGROUP at a time, ahead of the arithmetic that consumes them.
     KnotRec kl, km, kn;
-    int il = load_interval_guess(recs, l0, rl, kl), im = load_interval_guess(recs, l1, rm, km), in = load_interval_guess(recs, l2, rn, kn);
-    il = load_interval_fix(recs, l0, rl, il, kl); im = load_interval_fix(recs, l1, rm, im, km); in = load_interval_fix(recs, l2, rn, in, kn);
+    int il = load_interval_guess<1>(recs, l0, rl, kl), im = load_interval_guess<1>(recs, l1, rm, km), in = load_interval_guess<1>(recs, l2, rn, kn);
+    il = load_interval_fix<1>(recs, l0, rl, il, kl); im = load_interval_fix<1>(recs, l1, rm, im, km); in = load_interval_fix<1>(recs, l2, rn, in, kn);
     int mn = dim_m * dim_n;
     const double *c = c3 + lut_off + (il - 3) * mn + (im - 3) * dim_n + (in - 3);
     typedef double coeff4 __attribute__((ext_vector_type(4), aligned(8)));
@@ -2286,7 +2307,7 @@ k_eval(EvalArgs A) {
             KnotRec kr;
             const LegDev leg = ev_pairs_uniform ? load_const(&B->pairs[0].leg) : B->pairs[B->pair_of[pair_idx]].leg;
             const int col = B->pair_col[pair_idx];
-            int i = load_interval(recs_g, leg, d, kr);
+            int i = load_interval<1>(recs_g, leg, d, kr);
             double v[4], dv[4];
             bspline4<true>(kr, d, v, dv);
             const double *cf = A.c2 + (col - S) + (i - 3);
