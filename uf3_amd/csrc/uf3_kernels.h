@@ -793,7 +793,7 @@ __device__ __forceinline__ void trio_block(const FeatArgs &A, const BasisDev *B,
     const TrioDev *td = &td_copy;
     TrioWalk k;
     trio_walk_setup<WANT_F, IMG>(A, w, td->sc, td->sa, td->sb, sm, k);
-    const int ncol = td->ncol, F = B->F;
+    const int ncol = td->ncol, F = load_const(&B->F);     // (a scalar load: as B->F it is a vector load and a wait on everything in flight)
     for (int c0 = 0; c0 < ncol; c0 += NCH * WAVE) {
         ColSrc src[NCH][NSRC];
         double acc[NCH][4];
@@ -1035,7 +1035,7 @@ __device__ __forceinline__ void trio_block_mfma(const FeatArgs &A, const BasisDe
     PhaseClock pc;
     TrioWalk k;
     trio_walk_setup<WANT_F, IMG>(A, w, td->sc, td->sa, td->sb, sm, k);
-    const int ncol = td->ncol, F = B->F;
+    const int ncol = td->ncol, F = load_const(&B->F);     // (a scalar load: as B->F it is a vector load and a wait on everything in flight)
     const int lo_l = td->lo[0], lo_m = td->lo[1], lo_n = td->lo[2];
     const int ext_l = td->ext[0], ext_m = td->ext[1], ext_n = td->ext[2];
     const DenseLayout dl = dense_layout(ext_l, ext_m, ext_n);
@@ -1304,7 +1304,7 @@ __device__ __forceinline__ void trio_block_banded(const FeatArgs &A, const Basis
     PhaseClock pc;
     TrioWalk k;
     trio_walk_setup<WANT_F, IMG>(A, w, td->sc, td->sa, td->sb, sm, k);
-    const int F = B->F;
+    const int F = load_const(&B->F);
     const int lo_l = td->lo[0], lo_m = td->lo[1], lo_n = td->lo[2];
     const int ext_l = td->ext[0], ext_m = td->ext[1], ext_n = td->ext[2];
     const DenseLayout dl = dense_layout(ext_l, ext_m, ext_n);          // (dl.stride == STRIDE: the host sends no other window here)
@@ -1590,7 +1590,8 @@ __device__ __forceinline__ void trio_block_grouped(const FeatArgs &A, const Basi
     const int lane = lane_id();
     TrioWalk k;
     trio_walk_setup<WANT_F, IMG>(A, w, th.sc, th.sa, th.sb, sm, k);
-    const int ncol = th.ncol, F = B->F;
+    const int ncol = th.ncol, F = load_const(&B->F);      // (a scalar load: as B->F it was a vector load, once per block, and a wait on
+                                                          // everything in flight -- the row stores of the block before included)
     const unsigned short *gsrc_blk = gsrc + (th.grouped >> 8);      // the block's fold table (LDS when it fits)
     const int ext_l = L.ext_l, ext_m = 3, ext_n = L.ext_n;
     const int oM = 2 * ext_l, oN = oM + 2 * ext_m, oD = oN + 2 * GW;
@@ -1815,7 +1816,7 @@ __device__ __forceinline__ void trio_block_grouped(const FeatArgs &A, const Basi
 template <bool WANT_E, bool WANT_F, bool RL>           // RL: recs is the workgroup's LDS copy
 __device__ __forceinline__ void pair_rows(const FeatArgs &A, const BasisDev *B, const KnotRec *recs, const WaveLds &w, int m,
                                           int sm, int n_cand, const ESink &es) {
-    const int lane = lane_id(), F = B->F, S = B->S;
+    const int lane = lane_id(), F = load_const(&B->F), S = load_const(&B->S);
     const int n2 = A.n_pair_cols;                       // pair columns are [S, S + n2)
     double *row = w.pstage;                             // [4][n2]: energy, fx, fy, fz
     const int pairs_uniform = load_const(&B->pairs_uniform), lead2 = load_const(&B->lead2), trail2 = load_const(&B->trail2);
@@ -2369,7 +2370,7 @@ k_eval(EvalArgs A) {
         }
     });
     drain(queued);
-    if (B->T > 0) {
+    if (load_const(&B->T) > 0) {
         size_t base = (size_t)m * cap;
         int n;
         if (fuse) {
