@@ -1879,7 +1879,7 @@ __device__ __forceinline__ void build_n3_list(const FeatArgs &A, const BasisDev 
     const int lane = lane_id(), cap = A.n3.cap;
     unsigned long long *key = (unsigned long long *)w.pstage;      // the row buffer is free again
     int *src = (int *)(key + cap);
-    const double rmin3 = B->rmin3, rmax3 = B->rmax3;
+    const double rmin3 = load_const(&B->rmin3), rmax3 = load_const(&B->rmax3);
     int count = 0;
     for (int e0 = 0; e0 < n_cand; e0 += WAVE) {
         const int e = e0 + lane;
@@ -2297,7 +2297,7 @@ k_eval(EvalArgs A) {
     // 2-body: bonds inside their pair's range are queued in LDS and evaluated 64 at a time (about one candidate in
     // five survives the range test: evaluating in place would leave most lanes idle in the spline code)
     int queued = 0;
-    const double rmin3 = B->rmin3, rmax3 = B->rmax3;
+    const double rmin3 = load_const(&B->rmin3), rmax3 = load_const(&B->rmax3);
     const int ev_pairs_uniform = load_const(&B->pairs_uniform);
     const double ev_rmin0 = load_const(&B->pairs[0].rmin), ev_rmax0 = load_const(&B->pairs[0].rmax);
     auto drain = [&](int count) {
