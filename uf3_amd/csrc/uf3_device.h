@@ -31,6 +31,9 @@ struct PairDev {
     int nb;            // basis functions (nk-4)
     int sa, sb;        // species indices, sa <= sb
     double rmin, rmax; // strict range: max(r_min,0) < d < r_max
+    double s_lo, s_hi; // the same test on the SQUARED distance s as the kernels form it: rmin < sqrt(s) < rmax  <=>  s_lo < s < s_hi
+                       // (sqrt correctly rounded, hence monotonic: s_lo = the largest double whose root is <= rmin, s_hi the
+                       // smallest whose root is >= rmax; found by uf3_basis_create)
 };
 
 // what the per-(atom, trio) dispatch of k_featurize looks at, in one 32-byte block at the head of TrioDev: ONE scalar load per
@@ -69,6 +72,7 @@ struct BasisDev {
     int S, P, T, F;
     int lead2, trail2;
     double rmin3, rmax3;   // 3-body neighbour range: rmin3 < d <= rmax3
+    double s3_lo, s3_hi;   // ... on the squared distance: s3_lo < s <= s3_hi (largest doubles whose roots are <= rmin3 / rmax3)
     double rmax2;          // largest pair r_max
     double rsearch;        // cell-list radius = max(rmax2, rmax3) (= BSplineBasis.r_cut)
     int trio_legs_uniform; // every trio has the legs (knot sequences) and grid dimensions of trio 0: the evaluator reads them once,
@@ -261,6 +265,9 @@ __device__ __forceinline__ void bspline4(const KnotRec &k, double x, double *v, 
 
 // unfused |d|: ((dx*dx + dy*dy) + dz*dz), the order scipy's cdist uses, so that range
 // comparisons at the cut-offs agree with the reference to the last bit
+__device__ __forceinline__ double norm3_sq_rn(double dx, double dy, double dz) {        // the radicand of norm3_rn
+    return __dadd_rn(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)), __dmul_rn(dz, dz));
+}
 __device__ __forceinline__ double norm3_rn(double dx, double dy, double dz) {
     double s = __dadd_rn(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)), __dmul_rn(dz, dz));
     return sqrt(s);

@@ -321,6 +321,22 @@ static void bspline_piece(const double *t, int j, int i, double c[4]) {
     for (int e = 0; e < 4; e++) c[e] = (double)cur[0][e];
 }
 
+// Range tests on the squared distance.  The kernels form s = (dx dx + dy dy) + dz dz without fused operations and take the
+// correctly rounded root, so that "d < r" agrees with the reference's cdist to the last bit; the root is monotonic in s, so
+// the same decisions can be taken on s itself against thresholds found here, and the root is left to the few candidates kept.
+static double sq_root_le(double r) {          // the largest double s with sqrt(s) <= r   (r >= 0)
+    double s = r * r;
+    while (std::sqrt(s) <= r) s = std::nextafter(s, HUGE_VAL);
+    while (s > 0 && std::sqrt(s) > r) s = std::nextafter(s, -HUGE_VAL);
+    return s;
+}
+static double sq_root_ge(double r) {          // the smallest double s with sqrt(s) >= r
+    double s = r * r;
+    while (s > 0 && std::sqrt(s) >= r) s = std::nextafter(s, -HUGE_VAL);
+    while (std::sqrt(s) < r) s = std::nextafter(s, HUGE_VAL);
+    return s;
+}
+
 extern "C" int uf3_basis_create(uf3_ctx *c, const uf3_basis_spec *s, uf3_basis **out) {
     if (!c || !s || !out) return fail(c, UF3_EINVAL, "uf3_basis_create: null argument");
     if (s->n_species < 1 || s->n_species > UF3_MAX_SPECIES)
@@ -361,6 +377,7 @@ extern "C" int uf3_basis_create(uf3_ctx *c, const uf3_basis_spec *s, uf3_basis *
         pd.sa = std::min(a, bb); pd.sb = std::max(a, bb);
         pd.rmin = s->pair_rmin[p] > 0 ? s->pair_rmin[p] : 0.0;   // max(r_min, 0), distances.py:60
         pd.rmax = s->pair_rmax[p];
+        pd.s_lo = sq_root_le(pd.rmin); pd.s_hi = sq_root_ge(pd.rmax);
         h.rmax2 = std::max(h.rmax2, pd.rmax);
         bounds.push_back(pd.col + pd.nb);
         b->c2_len += (size_t)pd.nb;
@@ -403,6 +420,7 @@ extern "C" int uf3_basis_create(uf3_ctx *c, const uf3_basis_spec *s, uf3_basis *
     b->c3_len = lut_len;
     h.rmin3 = h.T ? std::max(lo3, 0.0) : 0.0;
     h.rmax3 = h.T ? hi3 : 0.0;
+    h.s3_lo = sq_root_le(h.rmin3); h.s3_hi = sq_root_le(h.rmax3);
     h.rsearch = std::max(h.rmax2, h.rmax3);
     std::vector<int> lut(lut_len ? lut_len : 1, -1);
     for (int t = 0; t < h.T; t++) {

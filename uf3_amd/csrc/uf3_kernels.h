@@ -2064,18 +2064,20 @@ k_featurize(FeatArgs A) {
         if (MODE == 0) {
             int n_cand = 0;
             const bool build3 = A.build_n3 != 0;
-            const double rmin3 = load_const(&B->rmin3), rmax3 = load_const(&B->rmax3);
+            // (the range tests on the SQUARED distance, against thresholds that make them the same decisions as on its correctly
+            // rounded root -- PairDev::s_lo: the root itself, 20 instructions, is taken once for the candidates kept, below)
+            const double s3_lo = load_const(&B->s3_lo), s3_hi = load_const(&B->s3_hi);
             const int pairs_uniform0 = load_const(&B->pairs_uniform);
-            const double2 rr0 = double2{load_const(&B->pairs[0].rmin), load_const(&B->pairs[0].rmax)};
+            const double2 rr0 = double2{load_const(&B->pairs[0].s_lo), load_const(&B->pairs[0].s_hi)};
             if (!(A.skip & 1)) for_each_candidate(g, A.cl, m, [&](bool ok, const SlotRec &sr, int sj, int s0, int s1, int s2) {
                 double dx = 0, dy = 0, dz = 0, d = 0;
                 if (ok) {
                     image_delta(g, sr, s0, s1, s2, pm, dx, dy, dz);
-                    d = norm3_rn(dx, dy, dz);
+                    d = norm3_sq_rn(dx, dy, dz);
                     // kept if inside its pair's range (distances.py:66, strict both sides) or a 3-body neighbour;
-                    // (r_min, r_max) in one load, no short-circuit: every clause evaluated would be a memory round trip
-                    const double2 rr = pairs_uniform0 ? rr0 : *(const double2 *)&B->pairs[B->pair_of[sm * UF3_MAX_SPECIES + sj]].rmin;
-                    ok = ((d > rr.x) & (d < rr.y)) | (build3 & (d > rmin3) & (d <= rmax3));
+                    // (s_lo, s_hi) in one load, no short-circuit: every clause evaluated would be a memory round trip
+                    const double2 rr = pairs_uniform0 ? rr0 : *(const double2 *)&B->pairs[B->pair_of[sm * UF3_MAX_SPECIES + sj]].s_lo;
+                    ok = ((d > rr.x) & (d < rr.y)) | (build3 & (d > s3_lo) & (d <= s3_hi));
                 }
                 unsigned long long mask = __ballot(ok);
                 if (ok) {
@@ -2091,6 +2093,11 @@ k_featurize(FeatArgs A) {
                 n_cand += __popcll(mask);
             });
             if (n_cand > A.cand_cap) { if (lane == 0) atomicMax(A.cand_need, n_cand); n_cand = A.cand_cap; }
+            wave_sync();
+            for (int e = lane; e < n_cand; e += WAVE) {                       // squared distance -> distance
+                double *c = w.cand + (size_t)e * CAND_STRIDE + 3;
+                *c = sqrt(*c);
+            }
             wave_sync();
             pair_rows<WANT_E, WANT_F, RECS_LDS>(A, B, recs, w, m, sm, n_cand, es);
             if (A.build_n3) build_n3_list(A, B, g, w, m, n_cand);
