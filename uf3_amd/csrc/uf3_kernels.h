@@ -2304,13 +2304,13 @@ k_eval(EvalArgs A) {
     // 2-body: bonds inside their pair's range are queued in LDS and evaluated 64 at a time (about one candidate in
     // five survives the range test: evaluating in place would leave most lanes idle in the spline code)
     int queued = 0;
-    const double rmin3 = load_const(&B->rmin3), rmax3 = load_const(&B->rmax3);
     const int ev_pairs_uniform = load_const(&B->pairs_uniform);
-    const double ev_rmin0 = load_const(&B->pairs[0].rmin), ev_rmax0 = load_const(&B->pairs[0].rmax);
+    const double ev_rmin0 = load_const(&B->pairs[0].s_lo), ev_rmax0 = load_const(&B->pairs[0].s_hi);   // (thresholds on the squared distance)
+    const double s3_lo = load_const(&B->s3_lo), s3_hi = load_const(&B->s3_hi);
     auto drain = [&](int count) {
         const double *c = queue + (size_t)lane * EVAL_Q;
         if (lane < count) {
-            const double dx = c[0], dy = c[1], dz = c[2], d = c[3];
+            const double dx = c[0], dy = c[1], dz = c[2], d = sqrt(c[3]);        // (queued with the squared distance, see below)
             const int pair_idx = sm * UF3_MAX_SPECIES + (int)c[4];
             KnotRec kr;
             const LegDev leg = ev_pairs_uniform ? load_const(&B->pairs[0].leg) : B->pairs[B->pair_of[pair_idx]].leg;
@@ -2335,11 +2335,13 @@ k_eval(EvalArgs A) {
         double dx = 0, dy = 0, dz = 0, d = 0;
         bool ok3 = false;
         if (ok) {
+            // (d: the SQUARED distance here; the ranges as thresholds on it that give the decisions of the correctly rounded root,
+            // PairDev::s_lo -- the root is taken where a kept candidate is used)
             double rmin = ev_rmin0, rmax = ev_rmax0;
-            if (!ev_pairs_uniform) { const PairDev &pd = B->pairs[B->pair_of[sm * UF3_MAX_SPECIES + sj]]; rmin = pd.rmin; rmax = pd.rmax; }
+            if (!ev_pairs_uniform) { const PairDev &pd = B->pairs[B->pair_of[sm * UF3_MAX_SPECIES + sj]]; rmin = pd.s_lo; rmax = pd.s_hi; }
             image_delta(g, sr, s0, s1, s2, pm, dx, dy, dz);
-            d = norm3_rn(dx, dy, dz);
-            ok3 = fuse & (d > rmin3) & (d <= rmax3);                 // angles.py:340: lower strict, upper inclusive
+            d = norm3_sq_rn(dx, dy, dz);
+            ok3 = fuse & (d > s3_lo) & (d <= s3_hi);                 // angles.py:340: lower strict, upper inclusive
             ok = (d > rmin) & (d < rmax);
         }
         if (fuse) {
@@ -2392,7 +2394,7 @@ k_eval(EvalArgs A) {
                 int rank = 0;
                 for (int f = 0; f < n; f++) rank += ukey[f] < k;
                 N3Entry en;
-                en.dx = ux[q]; en.dy = uy[q]; en.dz = uz[q]; en.r = ur[q];
+                en.dx = ux[q]; en.dy = uy[q]; en.dz = uz[q]; en.r = sqrt(ur[q]);
                 en.parent = uparent[q]; en.shiftc = ushift[q]; en.sidx = (int)(unsigned)k; en.spec = (int)(k >> 32);
                 A.n3.ent[base + rank] = en;
                 ox[rank] = en.dx; oy[rank] = en.dy; oz[rank] = en.dz; orr[rank] = en.r;
