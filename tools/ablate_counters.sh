@@ -2,9 +2,12 @@
 # Per-phase instruction budget of the matrix-core featurizer launch: PMC passes with UF3_DEBUG_SKIP ablations
 # (1 two-body, 2 centre role, 4 neighbour role, 8 MFMA steps, 16 leg evaluation + staging, 32 row stores).
 #     gpurun --timeout 900 -- 'bash tools/ablate_counters.sh gpurun_out/abl "0 8 16 24 6"'
+# The switches are compiled in with -DUF3_ABLATE only (build that library first, here, where hipcc is:
+#     (cd uf3_amd/csrc && hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=fast -DUF3_ABLATE -shared -o ../../exp/libuf3hip_ablate.so uf3_hip.hip)
 set -u
 RUN=${1:?output directory}; SKIPS=${2:-"0 8 16 24 6"}
-mkdir -p "$RUN"; export TMPDIR=/tmp UF3_BENCH_NOCHECK=1
+mkdir -p "$RUN"; export TMPDIR=/tmp UF3_BENCH_NOCHECK=1 UF3_LIB_PATH=$PWD/exp/libuf3hip_ablate.so
+[ -f "$UF3_LIB_PATH" ] || { echo "build exp/libuf3hip_ablate.so first (see the header of this script)"; exit 1; }
 for s in $SKIPS; do
   UF3_DEBUG_SKIP=$s timeout 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_MFMA SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAVE_CYCLES SQ_WAIT_INST_ANY \
     -d $RUN/s$s -o p --output-format csv -- python bench.py --no-cpu-baseline --no-extra --no-traffic --steps 2 --warmup 1 --frames-per-step 32 > $RUN/s$s.json 2>/dev/null

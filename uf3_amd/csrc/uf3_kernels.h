@@ -400,6 +400,15 @@ __device__ __forceinline__ bool neighbour_is_first(const FrameGeom &g, int sm, i
 //   24-26 A1, 27-29 A2, 30-32 A3, 34-35 int4 {first l, first m, first n, centre flag}, 36-37 zero pair
 // pair record (doubles): 0-7 (B,B')[4], 8-10 2*(R_j-R_m)/r, 11 {first basis index, -}
 
+// Ablation switches (experiments only: the library built with -DUF3_ABLATE reads UF3_DEBUG_SKIP; tools/ablate_counters.sh):
+// 1 two-body, 2 centre role, 4 neighbour role, 8 MFMA steps, 16 leg evaluation + staging, 32 row stores, 128 the grouped
+// fold, 256 its energy adds.  Compiled out otherwise -- eighteen tests of a scalar, six of them per staging pass.
+#ifdef UF3_ABLATE
+#define UF3_SKIP(bit) (A.skip & (bit))
+#else
+#define UF3_SKIP(bit) 0
+#endif
+
 // optional in-kernel phase timers (experiments only: -DUF3_PHASE_TIMING); lane 0 of every wave adds the
 // cycles it spent in a phase to a global table
 #ifdef UF3_PHASE_TIMING
@@ -651,7 +660,7 @@ __device__ __forceinline__ void trio_walk_setup(const FeatArgs &A, const WaveLds
     k.img_check = (IMG && WANT_F && A.outside) ? __builtin_amdgcn_readfirstlane(A.outside[0]) : 0;   // 0 off, 1 range rule, 2 + extension lists
     if (k.img_check && A.n3.xcap > 0) k.img_check = 2;
     k.cnt_c = 0; k.ra_lo = 0; k.rb_lo = 0; k.nb_ = 1;
-    if (sm == sc && !(A.skip & 2)) {          // m is the centre: own neighbours of species sa x sb
+    if (sm == sc && !UF3_SKIP(2)) {          // m is the centre: own neighbours of species sa x sb
         k.ra_lo = w.so[sa]; k.rb_lo = w.so[sb];
         int na = w.so[sa + 1] - k.ra_lo;
         k.nb_ = w.so[sb + 1] - k.rb_lo;
@@ -659,7 +668,7 @@ __device__ __forceinline__ void trio_walk_setup(const FeatArgs &A, const WaveLds
         if (k.nb_ < 1) k.nb_ = 1;
     }
     k.total_n = 0; k.rc_lo = 0; k.ncen = 0; k.sx = -1;
-    if (WANT_F && !(A.skip & 4)) {            // m is a neighbour of a centre of species sc
+    if (WANT_F && !UF3_SKIP(4)) {            // m is a neighbour of a centre of species sc
         if (sm == sa) k.sx = sb; else if (sm == sb) k.sx = sa;
         if (k.sx >= 0) {
             k.rc_lo = w.so[sc];
@@ -1002,7 +1011,7 @@ __device__ __forceinline__ void dense_fold(const FeatArgs &A, const WaveLds &w, 
                     if (q >= nc) break;
                     const double val = w0 * t0[q] + w1 * t1[q];
                     const int comp = c0 + q;
-                    if (comp < 3) { if (!(A.skip & 32)) __builtin_nontemporal_store(val, A.x_f + (size_t)m * 3 * F + (size_t)comp * F + td->col + col); }
+                    if (comp < 3) { if (!UF3_SKIP(32)) __builtin_nontemporal_store(val, A.x_f + (size_t)m * 3 * F + (size_t)comp * F + td->col + col); }
                     else es.add(td->col + col, val);
                 }
             }
@@ -1015,7 +1024,7 @@ __device__ __forceinline__ void dense_fold(const FeatArgs &A, const WaveLds &w, 
                         if (off >= 0) val += dump[q * rows_c + off];
                     }
                     const int comp = c0 + q;
-                    if (comp < 3) { if (!(A.skip & 32)) __builtin_nontemporal_store(val, A.x_f + (size_t)m * 3 * F + (size_t)comp * F + td->col + col); }
+                    if (comp < 3) { if (!UF3_SKIP(32)) __builtin_nontemporal_store(val, A.x_f + (size_t)m * 3 * F + (size_t)comp * F + td->col + col); }
                     else es.add(td->col + col, val);
                 }
         }
@@ -1129,10 +1138,10 @@ __device__ __forceinline__ void trio_block_mfma(const FeatArgs &A, const BasisDe
             const int n_part = min(nrec, n_valid - base);
             // staged records, padded with an all-zero record to an even count (a step is two records)
             const int n_real = WANT_F ? n_part : (n_part + 1) >> 1, n_staged = n_real + (n_real & 1);
-            const bool mine = li < n_part && !(A.skip & 16);
+            const bool mine = li < n_part && !UF3_SKIP(16);
             // the records of this pass (and the padding record) start from zero: one contiguous fill by the whole wave.
             // LDS writes of a wave stay in program order, so the fill lands before any lane's scatter below
-            if (!(A.skip & 16))
+            if (!UF3_SKIP(16))
                 for (int q = 2 * lane; q < n_staged * dl.stride; q += 2 * WAVE) *(double2 *)(w.stage + q) = double2{0.0, 0.0};
             if (mine) {
                 const int gi = base + li;
@@ -1181,7 +1190,7 @@ __device__ __forceinline__ void trio_block_mfma(const FeatArgs &A, const BasisDe
             const int s_c = SPLIT ? (max(0, min(n_part, n_cls01 - base)) + 1) & ~1 : n_staged;
             wave_sync();
             pc.lap(4);
-            if (!(A.skip & 8)) {
+            if (!UF3_SKIP(8)) {
                 constexpr int S0 = MODE == 6 ? 32 : (MODE == 7 ? 40 : (MODE == 8 ? 48 : 56));    // the usual stride of the mode
                 constexpr int ALL = (1 << CT) - 1;
                 if (dl.stride == S0) {       // wave-uniform
@@ -1378,8 +1387,8 @@ __device__ __forceinline__ void trio_block_banded(const FeatArgs &A, const Basis
             const int b0 = max(0, min(n_part, n_g0 - base)), b1 = max(0, min(n_part, n_g01 - base));
             const int st0 = (b0 + 1) >> 1, st1 = (b1 - b0 + 1) >> 1, st2 = (n_part - b1 + 1) >> 1;
             const int n_staged = 2 * (st0 + st1 + st2);
-            const bool mine = li < n_part && !(A.skip & 16);
-            if (!(A.skip & 16)) {
+            const bool mine = li < n_part && !UF3_SKIP(16);
+            if (!UF3_SKIP(16)) {
                 if (A.dense_stage == 1280) {                   // (the usual stage, 20 records of 64 doubles: cleared whole, no loop)
 #pragma unroll
                     for (int u = 0; u < 10; u++) *(double2 *)(w.stage + 2 * lane + u * 2 * WAVE) = double2{0.0, 0.0};
@@ -1415,7 +1424,7 @@ __device__ __forceinline__ void trio_block_banded(const FeatArgs &A, const Basis
             }
             wave_sync();
             pc.lap(4);
-            if (!(A.skip & 8)) {
+            if (!UF3_SKIP(8)) {
                 // band b's steps go to the column tiles band_tile[b] .. + 2 (wave-uniform switches: the tiles are registers)
                 const unsigned off1 = (unsigned)(2 * st0) * (STRIDE * 8), off2 = off1 + (unsigned)(2 * st1) * (STRIDE * 8);
 #define UF3_BAND(BT, OFF, NST)                                                                                                    \
@@ -1643,11 +1652,11 @@ __device__ __forceinline__ void trio_block_grouped(const FeatArgs &A, const Basi
             const int b0 = max(0, min(n_part, n_g0 - base)), b1 = max(0, min(n_part, n_g01 - base));
             const int st0 = (b0 + 1) >> 1, st1 = (b1 - b0 + 1) >> 1, st2 = (n_part - b1 + 1) >> 1;
             const int n_staged = 2 * (st0 + st1 + st2);
-            const bool mine = li < n_part && !(A.skip & 16);
+            const bool mine = li < n_part && !UF3_SKIP(16);
             // Nothing is cleared: every slot of every record of the pass is written below (window slots from the leg's window row,
             // zeros included), the pair at oZ is never written, and of a padding record -- the slot after an odd group -- only the
             // l window matters (its A operand must be zero; the rest is multiplied by it, and stale stage contents are finite).
-            if (!(A.skip & 16) && lane < 9) {
+            if (!UF3_SKIP(16) && lane < 9) {
                 const int pr = (lane * 21846) >> 16, ch = lane - 3 * pr;            // padding record pr, pair ch of its l window
                 const int odd0 = b0 & 1, odd1 = (b1 - b0) & 1, odd2 = (n_part - b1) & 1;
                 const int slot = pr == 0 ? b0 : (pr == 1 ? b1 + odd0 : n_part + odd0 + odd1);
@@ -1724,7 +1733,7 @@ __device__ __forceinline__ void trio_block_grouped(const FeatArgs &A, const Basi
             }
             wave_sync();
             pc.lap(4);
-            if (!(A.skip & 8)) grouped_pass_steps(a_va, a_vd, a_vm, a_vn, st0, st1, st2, acc[0][0][0], acc[1][0][0], acc[2][0][0]);
+            if (!UF3_SKIP(8)) grouped_pass_steps(a_va, a_vd, a_vm, a_vn, st0, st1, st2, acc[0][0][0], acc[1][0][0], acc[2][0][0]);
             pc.lap(5);
             wave_sync();
         }
@@ -1735,7 +1744,7 @@ __device__ __forceinline__ void trio_block_grouped(const FeatArgs &A, const Basi
     // addresses per column; a combination that does not apply points at column 15 of tile 0, which no record ever touches and
     // is therefore zero): 24 reads at fixed component distances and their sum, no address arithmetic, no weights.
     double *tiles = w.stage;                                     // 3 x 16 x 16 doubles = the host's minimum stage
-    if (A.skip & 128) return;                                    // (ablation: no fold, no rows)
+    if (UF3_SKIP(128)) return;                                    // (ablation: no fold, no rows)
     // the fold table's entries of this lane's (at most two) columns: six tile addresses each
     // (through the LDS or the global address space explicitly: as a generic pointer it is a flat load, whose results the
     // compiler can only wait for with vmcnt(0) -- i.e. together with the row stores of the round before)
@@ -1795,7 +1804,7 @@ __device__ __forceinline__ void trio_block_grouped(const FeatArgs &A, const Basi
             for (int c = 0; c < 4; c++) sum[c] = ((tv[0][c] + tv[1][c]) + (tv[2][c] + tv[3][c])) + (tv[4][c] + tv[5][c]);
         }
         pc.lap(8);
-        if (!(A.skip & 32)) {
+        if (!UF3_SKIP(32)) {
             // (streaming stores: the rows are not read again by this launch -- they should not push the neighbour lists, which
             // are, out of the L2)
             double *dst = A.x_f + (size_t)m * 3 * F + th.col + col;
@@ -1803,7 +1812,7 @@ __device__ __forceinline__ void trio_block_grouped(const FeatArgs &A, const Basi
             __builtin_nontemporal_store(sum[2], dst + 2 * (size_t)F);
         }
         pc.lap(9);
-        if (WANT_E && !(A.skip & 256)) es.add(th.col + col, sum[3]);
+        if (WANT_E && !UF3_SKIP(256)) es.add(th.col + col, sum[3]);
     }
     wave_sync();
     pc.lap(6);
@@ -2069,7 +2078,7 @@ k_featurize(FeatArgs A) {
             const double s3_lo = load_const(&B->s3_lo), s3_hi = load_const(&B->s3_hi);
             const int pairs_uniform0 = load_const(&B->pairs_uniform);
             const double2 rr0 = double2{load_const(&B->pairs[0].s_lo), load_const(&B->pairs[0].s_hi)};
-            if (!(A.skip & 1)) for_each_candidate(g, A.cl, m, [&](bool ok, const SlotRec &sr, int sj, int s0, int s1, int s2) {
+            if (!UF3_SKIP(1)) for_each_candidate(g, A.cl, m, [&](bool ok, const SlotRec &sr, int sj, int s0, int s1, int s2) {
                 double dx = 0, dy = 0, dz = 0, d = 0;
                 if (ok) {
                     image_delta(g, sr, s0, s1, s2, pm, dx, dy, dz);
@@ -2133,7 +2142,7 @@ k_featurize(FeatArgs A) {
                 if (t_mode != MODE) continue;
                 const int t_sc = th.sc, t_sa = th.sa, t_sb = th.sb;
                 const bool touches = (t_sc == sm) || (WANT_F && (t_sa == sm || t_sb == sm));
-                if (!touches) { if (WANT_F && !(A.skip & 32)) zero_rows(A.x_f, m, F, th.col, t_ncol); continue; }
+                if (!touches) { if (WANT_F && !UF3_SKIP(32)) zero_rows(A.x_f, m, F, th.col, t_ncol); continue; }
                 if (MODE == 1) trio_block<WANT_E, WANT_F, 1, 1, IMG>(A, B, recs, g, w, m, sm, t, es);
                 else if (MODE == 2) trio_block<WANT_E, WANT_F, 1, 2, IMG>(A, B, recs, g, w, m, sm, t, es);
                 else if (MODE == 3) trio_block<WANT_E, WANT_F, 2, 1, IMG>(A, B, recs, g, w, m, sm, t, es);
