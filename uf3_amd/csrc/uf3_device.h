@@ -287,6 +287,16 @@ __device__ __forceinline__ double norm3_leg(double dx, double dy, double dz) {
     return s > 0.0 ? g : 0.0;
 }
 
+// 1 / x for a distance: the hardware estimate + two Newton steps (about one ulp; 9 instructions where the IEEE quotient, with its
+// scaling for extreme arguments, is ~30).  Used where a derivative is turned into a force along a bond: nothing there is
+// compared or indexed, the tolerance on rows / forces is relative 1e-9.
+__device__ __forceinline__ double fast_rcp(double x) {
+    double y = __builtin_amdgcn_rcp(x);
+    y = fma(fma(-x, y, 1.0), y, y);
+    y = fma(fma(-x, y, 1.0), y, y);
+    return y;
+}
+
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 // inclusive prefix sum over the 64 lanes on the DPP network (row shifts, then row broadcasts): no LDS round trips
 __device__ __forceinline__ int wave_scan_incl(int v) {

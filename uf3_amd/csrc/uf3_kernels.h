@@ -2331,10 +2331,9 @@ k_eval(EvalArgs A) {
             double phi = 0, dphi = 0;
             for (int q = 0; q < 4; q++) { phi += cf[q] * v[q]; dphi += cf[q] * dv[q]; }
             e += phi;
-            double s = 2.0 * dphi / d;
+            const double t = dphi * fast_rcp(d), s = 2.0 * t;
             fx += s * dx; fy += s * dy; fz += s * dz;
             if (want_v) {   // d/d(strain) of the directed pair sum: phi'(r) r (x) r / r
-                double t = dphi / d;
                 vir[0] += t * dx * dx; vir[1] += t * dy * dy; vir[2] += t * dz * dz;
                 vir[3] += t * dy * dz; vir[4] += t * dx * dz; vir[5] += t * dx * dy;
             }
@@ -2434,17 +2433,17 @@ k_eval(EvalArgs A) {
             if (!trio_value(B, A.c3, trio, rl, rm, rn, want_f || want_v, val, gr)) continue;
             e += val;
             if (want_f) {   // F_m = -dV/dR_m = gl * u_ij + gm * u_ik
-                double a = gr[0] / rl, b = gr[1] / rm;
+                const double a = gr[0] * fast_rcp(rl), b = gr[1] * fast_rcp(rm);
                 fx += a * ox[aa] + b * ox[bb]; fy += a * oy[aa] + b * oy[bb]; fz += a * oz[aa] + b * oz[bb];
                 if (!GATHER) {   // F_j = -gl u_ij + gn (R_k - R_j) / rn,  F_k = -gm u_ik - gn (R_k - R_j) / rn
-                    const double cc = gr[2] / rn;
+                    const double cc = gr[2] * fast_rcp(rn);
                     const double cx = cc * (ox[bb] - ox[aa]), cy = cc * (oy[bb] - oy[aa]), cz = cc * (oz[bb] - oz[aa]);
                     lds_add(gx + aa, cx - a * ox[aa]); lds_add(gy + aa, cy - a * oy[aa]); lds_add(gz + aa, cz - a * oz[aa]);
                     lds_add(gx + bb, -cx - b * ox[bb]); lds_add(gy + bb, -cy - b * oy[bb]); lds_add(gz + bb, -cz - b * oz[bb]);
                 }
             }
             if (want_v) {   // each triplet once (at its centre): sum over legs of dV/dr * r (x) r / r
-                double ta = gr[0] / rl, tb = gr[1] / rm, tc = gr[2] / rn;
+                double ta = gr[0] * fast_rcp(rl), tb = gr[1] * fast_rcp(rm), tc = gr[2] * fast_rcp(rn);
                 double cx = ox[bb] - ox[aa], cy = oy[bb] - oy[aa], cz = oz[bb] - oz[aa];
                 vir[0] += ta * ox[aa] * ox[aa] + tb * ox[bb] * ox[bb] + tc * cx * cx;
                 vir[1] += ta * oy[aa] * oy[aa] + tb * oy[bb] * oy[bb] + tc * cy * cy;
@@ -2495,7 +2494,7 @@ k_eval(EvalArgs A) {
                 if (m_first) { rl = orr[q]; rm = rk; trio = B->trio_of[(sc * UF3_MAX_SPECIES + sm) * UF3_MAX_SPECIES + ksp]; }
                 else { rl = rk; rm = orr[q]; trio = B->trio_of[(sc * UF3_MAX_SPECIES + ksp) * UF3_MAX_SPECIES + sm]; }
                 if (!trio_value(B, A.c3, trio, rl, rm, rn, true, val, gr)) continue;
-                double ge = (m_first ? gr[0] : gr[1]) / orr[q], gn = gr[2] / rn;
+                double ge = (m_first ? gr[0] : gr[1]) * fast_rcp(orr[q]), gn = gr[2] * fast_rcp(rn);
                 fx += ge * ox[q] + gn * ex; fy += ge * oy[q] + gn * ey; fz += ge * oz[q] + gn * ez;
             }
         }
