@@ -38,7 +38,8 @@ struct PairDev {
 
 // what the per-(atom, trio) dispatch of k_featurize looks at, in one 32-byte block at the head of TrioDev: ONE scalar load per
 // trio and atom (read field by field, each behind its own branch, it was eight dependent scalar round trips)
-// grouped: 0, or (layout + 1) | offset of the block's fold table in FeatArgs::gsrc << 8
+// grouped: 0, or (layout + 1) | offset of the block's fold table in FeatArgs::gsrc << 8 (grouped windows), or
+// 1 | first column tiles of the three bands << 8, 4 bits each (banded windows)
 struct TrioHead { int dense, nsrc, ncol, sc, sa, sb, col, grouped; };
 
 struct TrioDev {
@@ -62,7 +63,7 @@ struct TrioDev {
     double gthr0, gthr2;
     int grouped;
     int banded;        // MODE 9 force launches: the leg-n intervals fall into <= 3 bands of <= 3 column tiles each (gthr0 / gthr2
-    int band_tile[3];  // separate them, band_tile[b] = first column tile of band b); TrioHead::grouped = 1
+    int band_tile[3];  // separate them, band_tile[b] = first column tile of band b); TrioHead::grouped = 1 | tiles << 8
     int layout;        // grouped windows: number of this trio's window layout (legs' knot sequences, window box, thresholds)
     int gsrc_off;      // ... and where its fold table starts in FeatArgs::gsrc
     int wrow[3];       // ... and, per leg, the number of its first window row (one row per knot interval from 3 on, see uf3_basis_create)

@@ -109,7 +109,7 @@ struct uf3_basis {
     unsigned short *d_gsrc = nullptr; // grouped windows: fold tables (FeatArgs::gsrc)
     size_t n_gsrc = 0;
     bool all_grouped7 = false;       // every mode-7 trio stages grouped windows (its force launches do not touch dsrc)
-    bool all_banded9 = false;        // every mode-9 trio runs banded (trio_block_banded)
+    bool all_banded9 = false;        // every mode-9 trio runs banded (trio_block_banded) with its bands on the column tiles 0, 1, 2
     size_t n_dsrc = 0;
     int *d_sp_cols = nullptr;        // [S][F]: the columns of the blocks species s takes part in, ascending (uf3_gram_force_rows_dev)
     int sp_ncols[UF3_MAX_SPECIES] = {0};
@@ -653,12 +653,14 @@ extern "C" int uf3_basis_create(uf3_ctx *c, const uf3_basis_spec *s, uf3_basis *
     b->all_grouped7 = true;
     for (auto &td : trios) if (td.dense == 7 && !td.grouped) b->all_grouped7 = false;
     b->all_banded9 = true;
-    for (auto &td : trios) if (td.dense == 9 && !td.banded) b->all_banded9 = false;
+    for (auto &td : trios)      // (the banded-only launch names its accumulator tiles at compile time: bands on the tiles 0, 1, 2)
+        if (td.dense == 9 && !(td.banded && td.band_tile[0] == 0 && td.band_tile[1] == 1 && td.band_tile[2] == 2)) b->all_banded9 = false;
     HIPCHK(c, hipMalloc(&b->d_gsrc, sizeof(unsigned short) * std::max<size_t>(8, gsrc.size() + 8)));
     if (!gsrc.empty()) HIPCHK(c, hipMemcpy(b->d_gsrc, gsrc.data(), sizeof(unsigned short) * gsrc.size(), hipMemcpyHostToDevice));
     for (auto &td : trios)
         td.head = TrioHead{td.dense, td.nsrc, td.ncol, td.sc, td.sa, td.sb, td.col,
-                           td.grouped ? ((td.layout + 1) | (td.gsrc_off << 8)) : (td.banded ? 1 : 0)};
+                           td.grouped ? ((td.layout + 1) | (td.gsrc_off << 8))
+                                      : (td.banded ? (1 | (td.band_tile[0] << 8) | (td.band_tile[1] << 12) | (td.band_tile[2] << 16)) : 0)};
     HIPCHK(c, hipMalloc(&b->d_trios, sizeof(TrioDev) * std::max<size_t>(1, trios.size())));
     if (!trios.empty())
         HIPCHK(c, hipMemcpy(b->d_trios, trios.data(), sizeof(TrioDev) * trios.size(), hipMemcpyHostToDevice));

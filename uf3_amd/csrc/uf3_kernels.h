@@ -1301,7 +1301,11 @@ __device__ __forceinline__ void banded_steps(unsigned va0, unsigned vd0, unsigne
 #undef UF3_BAND_STEP
 #undef UF3_BAND_ADVANCE
 
-template <bool WANT_E, bool IMG, bool RL>
+// STATIC012: the bands' first column tiles are 0, 1, 2 (what the 6 x 6 x 12 window of an untrimmed block gives): the three asm
+// statements of a pass then name their accumulator tiles at compile time and follow each other without a branch between them.
+// Chosen per tile at run time (four-way switches around the statements), the compiler copies accumulator tiles at every join --
+// ~45 64-bit moves per band and pass, a quarter of the launch's vector instructions.
+template <bool WANT_E, bool IMG, bool RL, bool STATIC012>
 __device__ __forceinline__ void trio_block_banded(const FeatArgs &A, const BasisDev *B, const KnotRec *recs, const FrameGeom &g,
                                                   const WaveLds &w, int m, int sm, int t, const ESink &es,
                                                   const int (&fragp)[4], const int *dsrc) {
@@ -1437,9 +1441,18 @@ __device__ __forceinline__ void trio_block_banded(const FeatArgs &A, const Basis
     else banded_steps(aL[0] + (OFF), aD[0] + (OFF), aL[1] + (OFF), aD[1] + (OFF), bM[3] + (OFF), bN[3] + (OFF), bM[4] + (OFF), bN[4] + (OFF),       \
                       bM[5] + (OFF), bN[5] + (OFF), NST, acc[0][3], acc[0][4], acc[0][5], acc[1][3], acc[1][4], acc[1][5]);
                 // (the records of a walk step are sorted by band: a pass mostly holds one or two of them)
-                if (st0 > 0) { UF3_BAND(bt0, 0u, st0) }
-                if (st1 > 0) { UF3_BAND(bt1, off1, st1) }
-                if (st2 > 0) { UF3_BAND(bt2, off2, st2) }
+                if (STATIC012) {                       // (a band without steps falls through its statement)
+                    banded_steps(aL[0], aD[0], aL[1], aD[1], bM[0], bN[0], bM[1], bN[1], bM[2], bN[2], st0,
+                                 acc[0][0], acc[0][1], acc[0][2], acc[1][0], acc[1][1], acc[1][2]);
+                    banded_steps(aL[0] + off1, aD[0] + off1, aL[1] + off1, aD[1] + off1, bM[1] + off1, bN[1] + off1, bM[2] + off1, bN[2] + off1,
+                                 bM[3] + off1, bN[3] + off1, st1, acc[0][1], acc[0][2], acc[0][3], acc[1][1], acc[1][2], acc[1][3]);
+                    banded_steps(aL[0] + off2, aD[0] + off2, aL[1] + off2, aD[1] + off2, bM[2] + off2, bN[2] + off2, bM[3] + off2, bN[3] + off2,
+                                 bM[4] + off2, bN[4] + off2, st2, acc[0][2], acc[0][3], acc[0][4], acc[1][2], acc[1][3], acc[1][4]);
+                } else {
+                    if (st0 > 0) { UF3_BAND(bt0, 0u, st0) }
+                    if (st1 > 0) { UF3_BAND(bt1, off1, st1) }
+                    if (st2 > 0) { UF3_BAND(bt2, off2, st2) }
+                }
 #undef UF3_BAND
             }
             pc.lap(5);
@@ -1964,7 +1977,7 @@ template <bool WANT_E, bool WANT_F, bool RECS_LDS, int MODE_, bool IMG>
 __global__ void __launch_bounds__(WPB * WAVE, MODE_ == 0 ? 4 : ((MODE_ == 6 || MODE_ == 7 || MODE_ == 10) ? 3 : 2))
 k_featurize(FeatArgs A) {
     constexpr int MODE = MODE_ == 10 ? 7 : (MODE_ == 11 ? 9 : MODE_);
-    constexpr bool GROUPED_ONLY = MODE_ == 10 || MODE_ == 11;      // (11: mode 9, banded windows only)
+    constexpr bool GROUPED_ONLY = MODE_ == 10 || MODE_ == 11;      // (11: mode 9, banded windows with the band tiles 0, 1, 2 only)
     extern __shared__ __align__(16) unsigned char smem[];
     const BasisDev *B = A.B;
     const int F = load_const(&B->F), S = load_const(&B->S), n_trios = load_const(&B->T), cap = A.n3.cap;
@@ -2153,7 +2166,9 @@ k_featurize(FeatArgs A) {
                     trio_block_grouped<WANT_E, IMG, RECS_LDS>(A, B, recs, g, w, m, sm, th, es, GL, gsrc);
                 }
                 else if (MODE == 9 && WANT_F && th.grouped)
-                    trio_block_banded<WANT_E, IMG, RECS_LDS>(A, B, recs, g, w, m, sm, t, es, fragp, dsrc);
+                    // (TrioHead::grouped of a banded trio: 1 | its bands' first tiles << 8, 4 bits each)
+                    // MODE_ 11: the host has checked that every banded trio of the basis has the tiles 0, 1, 2
+                    trio_block_banded<WANT_E, IMG, RECS_LDS, MODE_ == 11>(A, B, recs, g, w, m, sm, t, es, fragp, dsrc);
                 else if (!GROUPED_ONLY)
                     trio_block_mfma<WANT_E, WANT_F, (MODE >= 6 ? MODE : 6), IMG, RECS_LDS>(A, B, recs, g, w, m, sm, t, es, fragp, dsrc);
             }
