@@ -1859,7 +1859,7 @@ extern "C" int uf3_gram_force_rows_dev(uf3_basis *b, const double *d_x_f, const 
     Timed tm(c, T_GRAM);
     HIPCHK(c, hipMemsetAsync(seg, 0, sizeof(int) * 3 * UF3_MAX_SPECIES, st));
     HIPCHK(c, hipMemsetAsync(rows + 3 * n_atoms, 0, sizeof(int) * (n_list - 3 * (size_t)n_atoms), st));
-    const unsigned nblk = (unsigned)((n_atoms + 255) / 256);
+    const unsigned nblk = (unsigned)((n_atoms + SR_ATOMS - 1) / SR_ATOMS);
     hipLaunchKernelGGL(k_species_rows, dim3(nblk), dim3(256), 0, st, (const BasisDev *)b->dev, d_z, n_atoms, 0, seg, cursor, rows);
     hipLaunchKernelGGL(k_species_rows, dim3(nblk), dim3(256), 0, st, (const BasisDev *)b->dev, d_z, n_atoms, 1, seg, cursor, rows);
     for (int sp = 0; sp < S; sp++) {

@@ -2921,18 +2921,22 @@ k_gram_tiled(const double *x, const double *y, int64_t n_rows, int n_feat, int64
 // in rows[]; cursor[s]: entries handed out so far.  Two launches: counts (what = 0), then the lists (what = 1; the blocks
 // work the segment starts out of the counts themselves).  The three rows of an atom stay adjacent; the order of the atoms within
 // a segment is whatever the atomics make it (a sum over the rows does not care).
+#define SR_ATOMS 4096      // atoms per workgroup (one global atomic per workgroup, species and pass: ~300 workgroups per million atoms)
 __global__ void __launch_bounds__(256)
 k_species_rows(const BasisDev *B, const int32_t *z, int64_t n_atoms, int what, int *seg, int *cursor, int *rows) {
     __shared__ int cnt[UF3_MAX_SPECIES], base[UF3_MAX_SPECIES];
     const int tid = threadIdx.x;
+    const int64_t a0 = (int64_t)blockIdx.x * SR_ATOMS;
     if (tid < UF3_MAX_SPECIES) cnt[tid] = 0;
     __syncthreads();
-    const int64_t m = (int64_t)blockIdx.x * 256 + tid;
-    int s = -1, rank = 0;
-    if (m < n_atoms) {
+    auto species_of = [&](int64_t m) {
+        if (m >= n_atoms) return -1;
         const int zz = z[m];
-        s = (zz >= 0 && zz < 120) ? B->z2s[zz] : -1;
-        if (s >= 0) rank = atomicAdd(&cnt[s], 1);
+        return (zz >= 0 && zz < 120) ? (int)B->z2s[zz] : -1;
+    };
+    for (int it = 0; it < SR_ATOMS / 256; it++) {
+        const int s = species_of(a0 + it * 256 + tid);
+        if (s >= 0) atomicAdd(&cnt[s], 1);
     }
     __syncthreads();
     if (what == 0) {
@@ -2944,11 +2948,16 @@ k_species_rows(const BasisDev *B, const int32_t *z, int64_t n_atoms, int what, i
         for (int q = 0; q < tid; q++) start += seg[2 * q + 1];
         if (blockIdx.x == 0) seg[2 * tid] = start;
         base[tid] = start + (cnt[tid] ? atomicAdd(&cursor[tid], 3 * cnt[tid]) : 0);
+        cnt[tid] = 0;
     }
     __syncthreads();
-    if (s >= 0) {
-        int *o = rows + base[s] + 3 * rank;
-        o[0] = (int)(3 * m); o[1] = (int)(3 * m + 1); o[2] = (int)(3 * m + 2);
+    for (int it = 0; it < SR_ATOMS / 256; it++) {
+        const int64_t m = a0 + it * 256 + tid;
+        const int s = species_of(m);
+        if (s >= 0) {
+            int *o = rows + base[s] + 3 * atomicAdd(&cnt[s], 1);
+            o[0] = (int)(3 * m); o[1] = (int)(3 * m + 1); o[2] = (int)(3 * m + 2);
+        }
     }
 }
 
