@@ -2056,6 +2056,8 @@ k_featurize(FeatArgs A) {
     int erow_frame = -1;
     GroupedLayout GL;
     GL.id = -1;
+    FrameGeom g;                                                 // geometry of the frame the wave's current atom belongs to
+    int g_frame = -1;
     for (int m0 = block_first; m0 < block_end; m0 += WPB) {      // the block's waves take consecutive atoms
         const int m = m0 + wave;
         const bool active = m < block_end;
@@ -2074,7 +2076,7 @@ k_featurize(FeatArgs A) {
         }
         if (!active) continue;
         const int fr = load_const(A.frame_of + m);
-        const FrameGeom g = A.geoms[fr];
+        if (fr != g_frame) { g = A.geoms[fr]; g_frame = fr; }         // (wave-uniform; consecutive atoms mostly share their frame)
         const int sm = ((const __attribute__((address_space(4))) signed char *)(unsigned long long)A.spec)[m];
         const double pm[3] = {A.pos[3 * (size_t)m], A.pos[3 * (size_t)m + 1], A.pos[3 * (size_t)m + 2]};
         ESink es;
