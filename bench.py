@@ -49,9 +49,44 @@ if ROOT not in sys.path:
 import numpy as np  # noqa: E402
 
 
-def main():
+def rank_command(n_gpus, argv, port, python=None):
+    """The command line that starts ``n_gpus`` ranks of this script on one node -- the same one the driver uses for N > 1
+    (one process per GPU, rendezvous on 127.0.0.1)."""
+    return [python or sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={int(n_gpus)}",
+            "--master-addr", "127.0.0.1", "--master-port", str(int(port)), os.path.abspath(__file__)] + list(argv)
+
+
+def spawn_ranks(n_gpus, argv, device_count=None, runner=None, port=None):
+    """``python bench.py --gpus N`` without a launcher around it: start the N ranks here, or refuse LOUDLY when this node
+    does not have N GPUs -- never a silent one-rank run that reports n_gpus = 1.  Returns the exit code of the launcher.
+    ``device_count`` / ``runner`` / ``port`` are injection points of the CPU-side test."""
+    if device_count is None:
+        import torch
+        device_count = torch.cuda.device_count()
+    if device_count < n_gpus:
+        sys.stderr.write(f"bench.py: --gpus {n_gpus} asked for, {device_count} visible on this node: refusing to run "
+                         f"(no silent fallback to fewer ranks)\n")
+        return 2
+    if port is None:
+        import socket
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: what RCCL needs on this driver
+    env.setdefault("OMP_NUM_THREADS", "4")
+    if runner is None:
+        import subprocess
+        runner = subprocess.call
+    return int(runner(rank_command(n_gpus, argv, port), env=env))
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None,
+                    help="ranks = GPUs of this node (default: WORLD_SIZE under torch.distributed.run, else 1); without a "
+                         "launcher around it, --gpus N > 1 starts the N ranks itself")
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--cpu-workers", type=int, default=0, help="processes of the cpu_baseline pool (0: all cores, <= 32)")
@@ -59,8 +94,10 @@ def main():
                     help="frames per step and rank (128 x 10k atoms: 13.4 GB of rows in HBM, sized for 288 GB); smaller "
                          "batches leave a few per cent on the table to launch tails (32: -2.5 %%)")
     ap.add_argument("--atoms", type=int, default=10000, help="10000 = north-star; smaller = debug only")
-    ap.add_argument("--mode", choices=["featurize", "fit"], default="featurize",
-                    help="featurize = BASELINE metric (rows into HBM); fit = config 4 (rows -> X^T X / X^T y on the device)")
+    ap.add_argument("--mode", choices=["featurize", "fit", "eval"], default="featurize",
+                    help="featurize = BASELINE metric (rows into HBM); fit = config 4 (rows -> X^T X / X^T y on the device); "
+                         "eval = config 5 (one 50k-atom ternary frame per step, decomposed over the ranks: a block of centres "
+                         "per rank + one all_reduce of [forces | energy | strain derivative])")
     ap.add_argument("--workload", choices=["c4", "w", "lead0"], default=None,
                     help="c4 = W/Mo notebook basis F=434 (featurize default); w = W only, F=73 (fit default); "
                          "lead0 = W/Mo without leading trim, F=1798 (bandwidth-heavier)")
@@ -69,25 +106,48 @@ def main():
     ap.add_argument("--no-traffic", action="store_true",
                     help="do not measure roofline.traffic in this run (two short child runs under rocprofv3 --pmc); the figure "
                          "of the committed PMC passes under profiles/ is quoted instead")
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
+
+    distributed = "RANK" in os.environ and "MASTER_PORT" in os.environ      # launched by torch.distributed.run
+    world = int(os.environ.get("WORLD_SIZE", "1")) if distributed else 1
+    if args.gpus is None:
+        args.gpus = world
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    if not distributed and args.gpus > 1:
+        # (the driver's N = 1 command shape with a larger N: be the launcher)
+        sys.exit(spawn_ranks(args.gpus, argv))
+    if distributed and args.gpus != world:
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks: refusing to run\n")
+        sys.exit(2)
 
     import torch
     import torch.distributed as dist
     from uf3_amd import _lib, synthetic
     from uf3_amd.representation import process
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    distributed = "RANK" in os.environ and "MASTER_PORT" in os.environ      # launched by torch.distributed.run
+    rank = int(os.environ.get("RANK", "0")) if distributed else 0
+    local_rank = int(os.environ.get("LOCAL_RANK", "0")) if distributed else 0
+    if torch.cuda.device_count() <= local_rank:
+        sys.stderr.write(f"bench.py: rank {rank} needs GPU {local_rank}, {torch.cuda.device_count()} visible: no GPU, no number "
+                         f"(there is no CPU path)\n")
+        sys.exit(2)
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        assert dist.get_world_size() == world == args.gpus
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", local_rank if distributed else 0)
     os.environ["UF3_DEVICE"] = str(dev.index)
+
+    if args.mode == "eval":
+        out = eval_mode(args, torch, dist, dev, distributed, world, rank)
+        if distributed:
+            dist.barrier()
+            dist.destroy_process_group()
+        return out
 
     # ---- workload ---------------------------------------------------------------------
     if args.atoms == 10000:
@@ -196,7 +256,8 @@ def main():
             except (OSError, KeyError, ValueError):
                 pass
         feat_kernel = ("k_featurize<E,F,R,MODE> launch group of one step: MODE 0 (one-body + pairs + 3-body list build) + "
-                       "the matrix-core launch of the 3-body windows (MODE 7 at the default trims)")
+                       "the matrix-core launch of the 3-body windows (" + ("MODE 11, banded 6 x 6 x 12 windows" if wl == "lead0" else
+                                                                         "MODE 10, grouped n windows of the default trims") + ")")
         hbm = dict(achieved=round(hbm_gbs, 2), peak=8000.0, unit="GB/s", frac=round(hbm_gbs / 8000.0, 5),
                    algorithmic_bytes_per_launch=bytes_per_launch)
         if not fit:
@@ -267,6 +328,7 @@ def main():
             cpu = dict(value=round(value_cpu, 5), unit="frames/s", cores=cores, kind="port",
                        sample=f"frames of the same workload ({n_atoms} atoms, F={F}), {what}, "
                               f"oracle/uf3_oracle.c, {how}; GPU rows matched frame 0 to {err:.1e}")
+            cpu["reference_estimate"] = reference_estimate(1.0 / (dt + dt_fit), value_cpu, cores)
         metric = ("featurized frames/sec (10k-atom, 2-elem, 2+3-body)" if not fit else
                   "fitted frames/sec (featurize + X^T X / X^T y accumulate, 10k-atom frames)")
         out = dict(metric=metric, value=round(value, 3),
@@ -279,13 +341,99 @@ def main():
                                sharding=(f"frames x{world}, no data-path collective" if not fit else
                                          f"frames x{world}, one all_reduce(SUM) of 2F'^2+2F'+6 doubles at the end")),
                    roofline=roofline, cpu_baseline=cpu)
+        out["config"]["rccl_world_size"] = dist.get_world_size() if distributed else 1
         if world == 1 and not fit and wl == "c4" and args.atoms == 10000 and not args.no_extra:
             out["extra"] = extra_lines(dev, ctx, fz, frames, batch, d_pos, d_z, d_xe, d_xf,
                                        cpu=not args.no_cpu_baseline)
+            # the other BASELINE configurations again, compact, inside an object the driver's parser keeps
+            out["roofline"]["configs"] = compact_configs(out["extra"])
         print(json.dumps(out), flush=True)
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# --mode eval: BASELINE config 5, one large frame decomposed over the ranks (strong scaling)
+# ---------------------------------------------------------------------------------------------------------------
+def eval_mode(args, torch, dist, dev, distributed, world, rank):
+    """A step = energy + forces (+ strain derivative) of ONE 50 000-atom ternary frame.  N = 1: the whole-frame evaluator
+    (uf3_eval_virial_dev).  N > 1: every rank holds the frame's positions, evaluates the triplets centred in its contiguous block
+    of atoms (uf3_eval_centres_dev) into one flat device buffer [forces (3N) | energy | dE/d(strain) (6)] and the ranks sum
+    that buffer with ONE all_reduce over RCCL (parallel.sharded_evaluate's arithmetic, device-resident).  The reference's
+    calculator is a single process (uf3/forcefield/calculator.py:124-153)."""
+    from uf3_amd import _lib, parallel, synthetic
+    basis = synthetic.notebook_basis(['V', 'Mo', 'W'])
+    reps = (25, 25, 40) if args.atoms == 10000 else (max(2, round((args.atoms / 2) ** (1 / 3))),) * 3
+    atoms = synthetic.lattice_frame("bcc", reps, 3.165, [23, 42, 74], 4000)
+    model, calc = _random_model(basis, 11)
+    ctx = _lib.get_context(dev.index)
+    db = _lib.device_basis(basis, ctx)
+    batch = _lib.FrameBatch([atoms])
+    n = batch.n_atoms
+    lo, hi = parallel.shard_range(n, rank, world)
+    d_pos = torch.from_numpy(batch.pos).to(dev)
+    d_z = torch.from_numpy(batch.z).to(dev)
+    flat = torch.zeros(3 * n + 7, dtype=torch.float64, device=dev)
+    p_f, p_e, p_v = flat.data_ptr(), flat.data_ptr() + 8 * 3 * n, flat.data_ptr() + 8 * (3 * n + 1)
+    ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+    common = (db.handle, C.byref(batch.struct), C.c_void_p(d_pos.data_ptr()), C.c_void_p(d_z.data_ptr()),
+              _lib._p(calc._c1), _lib._p(calc._c2), _lib._p(calc._c3))
+
+    def step():
+        if world == 1:
+            ctx.check(ctx.lib.uf3_eval_virial_dev(*common, C.c_void_p(p_e), C.c_void_p(p_f), C.c_void_p(p_v)))
+        else:
+            flat.zero_()            # (the _dev entry leaves rows outside block + halo untouched)
+            ctx.check(ctx.lib.uf3_eval_centres_dev(*common, lo, hi, C.c_void_p(p_e), C.c_void_p(p_f), C.c_void_p(p_v)))
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+
+    def fence():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if distributed:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank != 0:
+        return None
+    host = flat.cpu().numpy()
+    f, e = host[:3 * n].reshape(n, 3), float(host[3 * n])
+    assert np.isfinite(host).all() and np.abs(f.sum(0)).max() < 1e-8 * max(1.0, np.abs(f).max()) * n ** 0.5
+    dt = elapsed / args.steps
+    cpu = None
+    if not args.no_cpu_baseline and n <= 60000:
+        from oracle import oracle as O
+        t1 = time.perf_counter()
+        ref = O.evaluate(O.OracleBasis(basis), atoms, model.coefficients)
+        dt_cpu = time.perf_counter() - t1
+        err = max(abs(e - ref[0]) / abs(ref[0]), np.abs(f - ref[1]).max() / np.abs(ref[1]).max())
+        assert err < 1e-9, err
+        cpu = dict(value=round(n / dt_cpu), unit="atom-steps/s", cores=1, kind="port",
+                   sample=f"the same frame once through oracle/uf3_oracle.c's evaluator, single thread, {dt_cpu:.1f} s; "
+                          f"the reduced GPU energy / forces matched to {err:.1e}")
+    out = dict(metric="evaluated atom-steps/sec (50k-atom ternary frame, energy + forces + strain derivative)", value=round(n / dt),
+               unit="atom-steps/s", n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(dt * 1e3, 4),
+               higher_is_better=True, scaling="strong", vs_baseline=None, dtype="f64", data="synthetic",
+               config=dict(workload=f"C5: {n}-atom ternary bcc frame, 2+3-body notebook basis, F={int(basis.n_feats)}", mode="eval",
+                           atoms_per_frame=n, sharding=(f"blocks of centres x{world}, one all_reduce(SUM) of 3N+7 doubles per step"
+                                                        if world > 1 else "whole frame on one GPU"),
+                           rccl_world_size=dist.get_world_size() if distributed else 1),
+               roofline=_roof(n * (100.0 * PAIRS_PER_ATOM + 700.0 * TRIPLETS_PER_ATOM), 52.0 * n + 75 + 8.0 * len(calc._c3), dt,
+                              "mfma", note="flops = N (100 p + 700 T): every triplet once at its centre"),
+               cpu_baseline=cpu)
+    print(json.dumps(out), flush=True)
     return out
 
 
@@ -556,6 +704,39 @@ def extra_lines(dev, ctx, fz, frames, batch, d_pos, d_z, d_xe, d_xf, cpu=True):
     guarded("eval_50k", lambda: extra_eval_50k(torch, dev, cpu=cpu))
     guarded("eval_128", extra_eval_128)
     return out
+
+
+def compact_configs(extra):
+    """{config: [value, unit, ms_per_step, fp64_frac, hbm_frac]} of the sub-lines (same numbers as `extra`, which holds the
+    details); fit_*: the fp64 fraction is ALGORITHMIC featurizer flops + EXECUTED upper-triangle Gram flops over the step"""
+    table = dict(columns=["value", "unit", "ms_per_step", "fp64_frac", "hbm_frac"],
+                 note="fp64_frac / hbm_frac = algorithmic flops / bytes of SURVEY 8d over 78.6 TF / 8 TB/s; fit_*: algorithmic "
+                      "featurizer flops + executed upper-triangle Gram flops; eval_128 is a latency (us per call, lower is better)")
+    for name, line in extra.items():
+        if "error" in line:
+            table[name] = ["error", line["error"][:80], None, None, None]
+            continue
+        r = line.get("roofline", {})
+        table[name] = [line.get("value"), line.get("unit"), line.get("ms_per_step"),
+                       r.get("fp64", {}).get("frac"), r.get("hbm", {}).get("frac")]
+        if "cpu_baseline" in line:
+            table[name + "_cpu_port"] = [line["cpu_baseline"]["value"], line["cpu_baseline"]["unit"], None, None, None]
+    return table
+
+
+def reference_estimate(port_one_core, port_all, cores):
+    """What the NumPy reference itself would do, as an ESTIMATE: the port's rate on this box divided by the reference : port
+    ratio calibrated in the build container (profiles/reference_calibration.json, tools/experiments/reference_timing.py --
+    the reference cannot run 10k-atom frames).  None when the calibration file is absent."""
+    try:
+        cal = json.load(open(os.path.join(ROOT, "profiles", "reference_calibration.json")))
+        ratio = float(cal["reference_to_port_ratio"])
+    except (OSError, KeyError, ValueError):
+        return None
+    return dict(label="estimate", reference_to_port_ratio=ratio, calibrated_at_atoms=cal.get("ratio_taken_at_atoms"),
+                frames_per_s_one_process=port_one_core / ratio, frames_per_s_all_cores=port_all / ratio, cores=cores,
+                source="profiles/reference_calibration.json: reference (numba absent: jitted loops interpreted, pessimistic) "
+                       "vs oracle/uf3_oracle.c on identical small frames, one process each")
 
 
 def _cpu_worker(job):

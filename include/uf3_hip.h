@@ -153,10 +153,12 @@ int uf3_gram_force_rows_dev(uf3_basis *basis, const double *d_x_f, const double 
  *   uf3_fit_rows_dev   energy rows of a batch divided by their frames' atom counts (per-atom normalisation, :697-700; in
  *                      place), and the target moments: moments[1..2] += (sum, sum of squares) of the FROZEN energies
  *                      y_e - x_e[:, frozen] . c_frozen, moments[4..5] += those of the force targets (y_f may be NULL).
- *                      moments[0] / [3] (the counts) are the caller's.
+ *                      moments[0] / [3] (the counts) are the caller's.  The energy rows are PACKED: row f starts at
+ *                      d_x_e + f * n_feat (no leading dimension, unlike uf3_gram_dev: pass unpadded rows).
  *   uf3_fit_pack_dev   flat [G_e (F x F) | G_f (F x F) | o_e (F) | o_f (F) | m_e (3) | m_f (3)] over all F columns ->
  *                      the same layout over the n_keep unfrozen columns, frozen columns folded out on the Gram level
  *                      (o_keep -= G[keep, frozen] . c_frozen): the additive pieces one rank hands to the all-reduce.
+ *                      n_keep == 0 (every column frozen) is allowed: the six moments are then the whole packed buffer.
  * keep / frozen are int64 column indices in HBM, c_frozen the frozen coefficients in HBM.
  */
 int uf3_fit_rows_dev(uf3_ctx *ctx, int32_t n_frames, int32_t n_feat, double *d_x_e, const double *d_atom_counts,

@@ -169,3 +169,36 @@ def test_shard_range_and_packing():
              m_e=rng.random(3), m_f=rng.random(3))
     q = parallel.unpack_pieces(parallel.pack_pieces(p, 4), 4)
     assert all(np.array_equal(p[k], q[k]) for k in p)
+
+
+def test_bench_launcher_starts_n_ranks_or_refuses(capsys):
+    """`python bench.py --gpus N` without torch.distributed.run around it is its own launcher (the shape of the driver's N = 1
+    command): N ranks through torch.distributed.run on 127.0.0.1, or a loud refusal -- never a one-rank run labelled N."""
+    import subprocess
+    import sys
+    import bench
+    seen = {}
+
+    def runner(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 0
+
+    argv = ["--gpus", "4", "--steps", "3", "--warmup", "1", "--mode", "fit"]
+    assert bench.spawn_ranks(4, argv, device_count=8, runner=runner, port=29517) == 0
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29517"
+    assert cmd[-len(argv):] == argv and cmd[-len(argv) - 1].endswith("bench.py")
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    assert bench.spawn_ranks(4, argv, device_count=2, runner=runner) == 2          # too few GPUs: refused, nothing started
+    assert "refusing" in capsys.readouterr().err
+    # end to end on this box (no GPU): a non-zero exit and the message, not a JSON line with n_gpus = 1
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "MASTER_PORT", "LOCAL_RANK")}
+    import torch
+    if torch.cuda.device_count() < 2:
+        r = subprocess.run([sys.executable, bench.__file__, "--gpus", "2"], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode != 0 and "refusing" in r.stderr and "n_gpus" not in r.stdout
+    # a launcher whose world differs from --gpus is refused as well
+    env2 = dict(env, RANK="0", WORLD_SIZE="2", LOCAL_RANK="0", MASTER_PORT="29518", MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, bench.__file__, "--gpus", "4"], env=env2, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr

@@ -26,6 +26,8 @@ kw = dict(r_min_map=mine.r_min_map, r_max_map=mine.r_max_map, resolution_map=min
 ref_basis = rb.BSplineBasis(rc.ChemicalSystem(['W'], 3), **kw)
 fz = rp.BasisFeaturizer(ref_basis)
 ob = O.OracleBasis(mine)
+import json
+cases = []
 for reps, forces in (((2, 2, 2), True), ((3, 3, 3), True), ((4, 4, 4), False)):
     a = synthetic.lattice_frame("bcc", reps, 3.165, [74], seed=5)
     g = ref_geom(a)
@@ -35,5 +37,22 @@ for reps, forces in (((2, 2, 2), True), ((3, 3, 3), True), ((4, 4, 4), False)):
     t_or, ref = timed(O.featurize, ob, a)
     xe = np.array(rows[("x", "energy")][1:])
     err = np.abs(xe - ref["xe"]).max() / np.abs(ref["xe"]).max()
+    cases.append(dict(atoms=n, rows="energy + force rows" if forces else "energy row only (the restatement computes both)",
+                      reference_s=round(t_ref, 3), restatement_s=round(t_or, 6), ratio=round(t_ref / t_or, 1),
+                      energy_rows_agree_to=float(err)))
     print(f"{n:4d} atoms, {'energy + force rows' if forces else 'energy row only  '}: reference {t_ref:8.2f} s, "
           f"restatement {t_or * 1e3:7.2f} ms (computes both), ratio {t_ref / t_or:8.0f}, energy rows agree to {err:.1e}")
+
+full = [c for c in cases if c["rows"].startswith("energy + force")]
+out = dict(what="wall time of the reference's BasisFeaturizer.evaluate_configuration (uf3 v0.4.0, imported from /root/reference behind the "
+                "stand-ins of tests/golden/_standins) next to oracle/uf3_oracle.c on identical rattled bcc-W cells, notebook 2+3-body basis "
+                "(F = 73), one process each, build container",
+           caveat="numba absent: the reference's three jitted loops ran interpreted, so its 3-body times are pessimistic; the reference "
+                  "cannot run 10k-atom frames at all (583 GB M x M distance matrix, BASELINE.md section 3): the ratio is an ESTIMATE "
+                  "taken at the largest size with force rows it finishes here",
+           host=dict(cpu_count=os.cpu_count(), python=sys.version.split()[0], numpy=np.__version__),
+           cases=cases,
+           reference_to_port_ratio=full[-1]["ratio"], ratio_taken_at_atoms=full[-1]["atoms"])
+path = os.path.join(ROOT, "profiles", "reference_calibration.json")
+json.dump(out, open(path, "w"), indent=1)
+print("wrote", path)

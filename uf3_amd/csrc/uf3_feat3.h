@@ -1,0 +1,416 @@
+// uf3_feat3.h -- 3-body force (and energy) rows by BOND FACTORISATION: k_featurize3 (round 4).  gfx950 only.
+//
+// Reference: uf3/representation/angles.py:142-286 (featurize_force_3b / arrange_deriv_3b), :17-139 (energy), :424-632
+// (triplets, leg values and derivatives).  Same gather formulation as k_featurize's trio blocks (an atom m collects the
+// triplets it centres and those in which it is a neighbour of a centre e), but the sum over the triplets is taken in two
+// stages instead of one rank-2 update of the (component, l) x (m, n) window per triplet:
+//
+//   every term of m's rows has the form   T_f[c][i] * ( sum over the triplets that share the bond f )  P_g[j] Q[n]
+//   where f is a bond of m that stays fixed -- (m, a) when m is the centre and a sits on one centre leg, (m, e) when m is a
+//   neighbour of the centre e -- and g is the bond on the OTHER centre leg ((m, b), or (e, k)), Q the values of leg n:
+//
+//   stage 1 (per triplet, 4 multiply-adds per lane):   W_s[j][n] += P_s[j] Q_s[n]          s = x, y, z, plain
+//       centre role     P = (u_g,x B'(r_g), u_g,y B'(r_g), u_g,z B'(r_g), B(r_g))[j]     Q = B_n(r_ab)[n]
+//       neighbour role  P = B(r_ek)[j]     Q = (a3_x B_n'(r_mk), a3_y B_n', a3_z B_n', B_n(r_mk))[n]      a3 = unit(m -> k)
+//   stage 2 (per BOND f, 7 multiply-adds per window row and lane):
+//       X_c[i][j][n] += T_f[i][c] W_plain[j][n] + T_f[i][plain] W_c[j][n],     X_e[i][j][n] += T_f[i][plain] W_plain[j][n]
+//       T_f[i] = (u_f,x B'(r_f)[i], u_f,y B'(r_f)[i], u_f,z B'(r_f)[i], B(r_f)[i]),  u_f = unit(m -> other end of f)
+//
+// An atom of the benchmark has 273 triplet records but only ~50 (bond, block) pairs: the expansion over the three force
+// components and the window of the fixed leg -- what the matrix cores did per record -- happens once per bond.  Lanes are the
+// (j, n) positions of the W window (27 for the default trims) twice over: the two halves of the wave take alternate records
+// of a bond and keep partial sums, which meet in the fold.  No matrix cores, no per-record staging of three evaluated legs: a
+// record is the four n-leg values (centre role) or those, their derivatives times a3 and the four values of bond (e, k).
+//
+// Orientation: the fixed bond sits on leg l ("normal": rows i = l, window j = m) or on leg m ("transposed": i = m, j = l); a
+// block has one orientation per atom species -- transposed exactly when sa != sb and the atom is of species sb (then it is
+// always the SECOND neighbour, and its centre-role triplets are summed with the bond on leg m fixed instead).  Blocks with
+// sa == sb must fold symmetrically in (l, m) -- column(l, m, n) = raw(l, m, n) + raw(m, l, n) -- so that which of two equal
+// neighbours is "first" (angles.py:456-470, incl. the ghost-centre numbering quirk) does not matter; uf3_basis_create checks
+// that and everything else this kernel assumes (Feat3 eligibility) and the other launches remain for the rest.
+#pragma once
+
+struct Feat3Leg {
+    double t0, tlast, inv_h;
+    int nk, row0;              // knots; number of the leg's first window row (one per knot interval from 3 on)
+};
+
+struct Feat3Args {
+    const BasisDev *B;
+    const TrioDev *trios;
+    const double *rows;        // window rows [n_rows][18]: t_i, t_i+1 | 4 functions x (c0 c1 c2 c3), see uf3_basis_create
+    int n_rows;
+    const unsigned short *fsrc; // fold tables: per trio [orientation 0 | 1][column][source 0 | 1] -> f * 32 + j * ext_n + n, 31 = none
+    const int *trio_fsrc;      // [T] first entry of a trio's table
+    int n_fsrc;
+    Feat3Leg leg_p, leg_n;     // the centre legs (l and m share knots and window), leg n
+    int lo_p, ext_p, lo_n, ext_n;
+    const FrameGeom *geoms;
+    const int *frame_of;
+    N3Lists n3;
+    const double *pos;
+    const signed char *spec;
+    double *x_e, *x_f;
+    int natoms, atoms_per_block, e_direct;
+};
+
+#define F3_NREC 32            // records per engine pass (one per lane of a half-wave)
+#define F3_RS_C 6             // doubles per centre-role record: B_n x 4, a zero, pad
+#define F3_RS_N 24            // ... per neighbour-role record: B(r_ek) x 4 | (a3 B_n', B_n) x 4 | a zero quad
+#define F3_STAGE 768          // doubles of per-wave stage: 32 records of 24; the fold's dump [half][c][f][32] (EF = 3: 768)
+
+typedef double __attribute__((ext_vector_type(2))) F3Pair;
+typedef const __attribute__((address_space(3))) F3Pair *F3LdsPairs;
+typedef const __attribute__((address_space(3))) double *F3LdsDoubles;
+
+// four consecutive window functions of a leg at x (t0 < x < tlast): values v, derivatives d; returns the knot interval.
+// The row of the guessed interval is fetched whole and again only when the guess was off (non-uniform knots, x on a knot).
+template <bool DERIV>
+__device__ __forceinline__ int f3_eval(const double *rows, const Feat3Leg &lg, double x, double (&v)[4], double (&d)[4]) {
+    const int hi = lg.nk - 5;
+    int iv = 3 + (int)((x - lg.t0) * lg.inv_h);
+    iv = iv < 3 ? 3 : (iv > hi ? hi : iv);
+    F3Pair kn, cf[8];
+    auto load_row = [&](int i) {
+        F3LdsPairs q = (F3LdsPairs)(const F3Pair *)(rows + (size_t)(lg.row0 + i - 3) * 18);
+        F3Pair t0 = q[0], t[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) t[e] = q[1 + e];
+        kn = t0;
+#pragma unroll
+        for (int e = 0; e < 8; e++) cf[e] = t[e];
+        __builtin_amdgcn_sched_group_barrier(0x100, 9, 0);
+    };
+    load_row(iv);
+    if (__builtin_expect(x > kn.y && iv < hi, 0)) {
+        do { ++iv; load_row(iv); } while (x > kn.y && iv < hi);
+    } else if (__builtin_expect(x <= kn.x && iv > 3, 0)) {
+        do { --iv; load_row(iv); } while (x <= kn.x && iv > 3);
+    }
+    const double u = x - kn.x;
+#pragma unroll
+    for (int fq = 0; fq < 4; fq++) {
+        const double c0 = cf[2 * fq].x, c1 = cf[2 * fq].y, c2 = cf[2 * fq + 1].x, c3 = cf[2 * fq + 1].y;
+        double pv = fma(c3, u, c2), pd = fma(c3, u, pv);
+        pv = fma(pv, u, c1); pd = fma(pd, u, pv);
+        pv = fma(pv, u, c0);
+        v[fq] = pv;
+        if (DERIV) d[fq] = pd;
+    }
+    return iv;
+}
+
+template <bool WANT_E, int EF>
+__global__ void __launch_bounds__(WPB * WAVE, 3)
+k_featurize3(Feat3Args A) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const BasisDev *B = A.B;
+    const int F = load_const(&B->F), S = load_const(&B->S), n_trios = load_const(&B->T), cap = A.n3.cap;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // ---- LDS carve (feat3_lds_bytes on the host) ----------------------------------------------------------------------
+    double *erow = (double *)smem;
+    const bool e_lds = WANT_E && !A.e_direct;
+    const size_t e_d = e_lds ? (size_t)F + (F & 1) : 0;
+    double *rows = erow + e_d;                                        // window rows, shared
+    const size_t rows_d = (size_t)A.n_rows * 18;
+    const size_t list_d = 5 * (size_t)cap + ((5 * cap) & 1), tq_d = (size_t)cap * EF * 4;
+    constexpr size_t stage_d = F3_STAGE > 2 * 4 * EF * 32 ? F3_STAGE : 2 * 4 * EF * 32;
+    const size_t per_wave_d = list_d + tq_d + stage_d;
+    const size_t per_wave_i = 2 * (size_t)cap + 2 * ((size_t)cap + 1) + (UF3_MAX_SPECIES + 2) + (size_t)cap * (S + 1) + 32;
+    double *wd = rows + rows_d + (size_t)wave * per_wave_d;
+    int *wi = (int *)(rows + rows_d + (size_t)WPB * per_wave_d) + (size_t)wave * per_wave_i;
+    double *ox = wd, *oy = ox + cap, *oz = oy + cap, *orr = oz + cap, *oir = orr + cap;
+    double *tq = wd + list_d;                                         // [cap][EF][4]: T_f of every own bond
+    double *stage = tq + tq_d;
+    int *oparent = wi, *oshift = wi + cap, *noff = wi + 2 * cap, *nbase = noff + cap + 1, *so = nbase + cap + 1;
+    int *ospoff = so + (UF3_MAX_SPECIES + 2);
+    int *hdrs = ospoff + (size_t)cap * (S + 1);                       // [32] record headers of a pass, by rank
+    const int sp_stride = S + 1;
+    unsigned short *fsrc_l = (unsigned short *)((int *)(rows + rows_d + (size_t)WPB * per_wave_d) + (((size_t)WPB * per_wave_i + 3) & ~(size_t)3));
+
+    for (int q = tid; q < (int)rows_d; q += WPB * WAVE) rows[q] = A.rows[q];
+    for (int q = tid; q < A.n_fsrc / 2; q += WPB * WAVE) ((int *)fsrc_l)[q] = ((const int *)A.fsrc)[q];
+    if (e_lds) { for (int q = tid; q < F; q += WPB * WAVE) erow[q] = 0.0; }
+    __syncthreads();
+
+    // ---- per-lane constants of the W window ---------------------------------------------------------------------------
+    const int ext_p = A.ext_p, ext_n = A.ext_n, lo_n = A.lo_n, npos = ext_p * ext_n;
+    const int half = lane >> 5, pos = lane & 31;
+    const int p_lane = pos < npos ? pos / ext_n : 0;
+    const int n_lane = pos < npos ? pos - p_lane * ext_n : -(1 << 20);     // (idle lanes always read the zero slot)
+    const int sbn_max = ext_n > 4 ? ext_n - 4 : 0;
+    const Feat3Leg leg_p = A.leg_p, leg_n = A.leg_n;
+
+    const int bid = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    const int block_first = bid * A.atoms_per_block;
+    const int block_end = min(block_first + A.atoms_per_block, A.natoms);
+    int erow_frame = -1;
+    FrameGeom g;
+    int g_frame = -1;
+    for (int m0 = block_first; m0 < block_end; m0 += WPB) {
+        const int m = m0 + wave;
+        const bool active = m < block_end;
+        if (e_lds) {
+            int f_first = load_const(A.frame_of + m0);
+            if (f_first != erow_frame) {
+                __syncthreads();
+                if (erow_frame >= 0)
+                    for (int q = tid; q < F; q += WPB * WAVE) {
+                        double v = erow[q];
+                        if (v != 0.0) { unsafeAtomicAdd(A.x_e + (size_t)erow_frame * F + q, v); erow[q] = 0.0; }
+                    }
+                __syncthreads();
+                erow_frame = f_first;
+            }
+        }
+        if (!active) continue;
+        const int fr = load_const(A.frame_of + m);
+        if (fr != g_frame) { g = A.geoms[fr]; g_frame = fr; }
+        const int sm = ((const __attribute__((address_space(4))) signed char *)(unsigned long long)A.spec)[m];
+        ESink es;
+        es.lds = erow; es.glob = WANT_E ? A.x_e + (size_t)fr * F : nullptr; es.direct = !e_lds || (fr != erow_frame);
+
+        // ---- own 3-body list -> LDS; species offsets of the neighbours' lists ----------------------------------------
+        const int n_own = load_const(A.n3.cnt + m);
+        wave_sync();
+        for (int e = lane; e < n_own; e += WAVE) {
+            const N3Entry en = A.n3.ent[(size_t)m * cap + e];
+            ox[e] = en.dx; oy[e] = en.dy; oz[e] = en.dz; orr[e] = en.r; oir[e] = 1.0 / en.r;
+            oparent[e] = en.parent; oshift[e] = en.shiftc;
+        }
+        if (lane <= S) so[lane] = A.n3.spoff[(size_t)m * (UF3_MAX_SPECIES + 1) + lane];
+        wave_sync();
+        for (int q = lane; q < n_own * (S + 1); q += WAVE) {
+            const int e = q / (S + 1), sp = q - e * (S + 1);
+            ospoff[e * (S + 1) + sp] = A.n3.spoff[(size_t)oparent[e] * (UF3_MAX_SPECIES + 1) + sp];
+        }
+        // ---- T_f of every own bond (zero when the bond is outside the centre legs' range) ------------------------------
+        for (int e = lane; e < n_own; e += WAVE) {
+            const double r = orr[e];
+            double v[4] = {0, 0, 0, 0}, d[4] = {0, 0, 0, 0};
+            if (r > leg_p.t0 && r < leg_p.tlast) f3_eval<true>(rows, leg_p, r, v, d);
+            const double ir = oir[e], ux = ox[e] * ir, uy = oy[e] * ir, uz = oz[e] * ir;
+#pragma unroll
+            for (int q = 0; q < EF; q++) {
+                double *dst = tq + ((size_t)e * EF + q) * 4;
+                *(double2 *)dst = double2{ux * d[q], uy * d[q]};
+                *(double2 *)(dst + 2) = double2{uz * d[q], v[q]};
+            }
+        }
+        wave_sync();
+
+        for (int t = 0; t < n_trios; t++) {
+            const TrioDev *td = A.trios + t;
+            typedef int int8_v __attribute__((ext_vector_type(8)));
+            const int8_v hv = *(const __attribute__((address_space(4))) int8_v *)(unsigned long long)&td->head;
+            const int t_nsrc = hv[1], t_ncol = hv[2], t_sc = hv[3], t_sa = hv[4], t_sb = hv[5], t_col = hv[6];
+            (void)t_nsrc;
+            const bool centre = t_sc == sm, nbr = t_sa == sm || t_sb == sm;
+            if (!centre && !nbr) { zero_rows(A.x_f, m, F, t_col, t_ncol); continue; }
+            const bool tr = t_sa != t_sb && sm == t_sb;              // transposed: the fixed bond sits on leg m
+
+            double xacc[EF][4], ws[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int q = 0; q < EF; q++) { xacc[q][0] = xacc[q][1] = xacc[q][2] = xacc[q][3] = 0.0; }
+            int cur = -1;                                           // the bond whose W is being summed (own-list index)
+
+            // stage 2: the open bond's W into the rows of the window
+            auto flush = [&](bool is_c) {
+                if (cur < 0) return;
+                F3LdsPairs tp = (F3LdsPairs)(const F3Pair *)(tq + (size_t)cur * EF * 4);
+                F3Pair tv[EF][2];
+#pragma unroll
+                for (int q = 0; q < EF; q++) { tv[q][0] = tp[2 * q]; tv[q][1] = tp[2 * q + 1]; }
+#pragma unroll
+                for (int q = 0; q < EF; q++) {
+                    const double bv = tv[q][1].y;
+                    xacc[q][0] = fma(tv[q][0].x, ws[3], fma(bv, ws[0], xacc[q][0]));
+                    xacc[q][1] = fma(tv[q][0].y, ws[3], fma(bv, ws[1], xacc[q][1]));
+                    xacc[q][2] = fma(tv[q][1].x, ws[3], fma(bv, ws[2], xacc[q][2]));
+                    if (WANT_E && is_c) xacc[q][3] = fma(bv, ws[3], xacc[q][3]);
+                }
+                ws[0] = ws[1] = ws[2] = ws[3] = 0.0;
+            };
+
+            // stage 1 over the records of one walk step.  valid / hdr per lane (key | sbn << 8 | g << 16); the lambdas write
+            // a lane's record to a stage slot.  Records come in key-major order; the two halves take alternate records of a key.
+            auto engine = [&](bool valid, int hdr, bool is_c, auto write_record) {
+                const unsigned long long mask = __ballot(valid);
+                const int nv = __popcll(mask), rank = mbcnt(mask);
+                for (int sp0 = 0; sp0 < nv; sp0 += F3_NREC) {
+                    const int slot = rank - sp0;
+                    if (valid && slot >= 0 && slot < F3_NREC) { write_record(slot); hdrs[slot] = hdr; }
+                    wave_sync();
+                    const int v_hdr = hdrs[pos];
+                    const int r_end = min(F3_NREC, nv - sp0);
+                    for (int r = 0; r < r_end;) {
+                        const int h0 = __builtin_amdgcn_readlane(v_hdr, r);
+                        const int key = h0 & 0xff;
+                        if (key != cur) { flush(is_c); cur = key; }
+                        const int h1 = __builtin_amdgcn_readlane(v_hdr, min(r + 1, F3_NREC - 1));
+                        const bool have2 = r + 1 < r_end && (h1 & 0xff) == key;
+                        // (the second half without a record of its own re-reads the first half's -- finite numbers -- against
+                        // the zero slot: a stale header could point anywhere)
+                        const bool second = half && have2;
+                        const int hm = second ? h1 : h0;
+                        int idx = n_lane - ((hm >> 8) & 0xff);
+                        idx = (half == 0 || have2) ? idx : 4;
+                        idx = min((unsigned)idx, 4u);
+                        const int rec = r + (second ? 1 : 0);
+                        if (is_c) {
+                            const double q = ((F3LdsDoubles)(const double *)(stage + (size_t)rec * F3_RS_C))[idx];
+                            F3LdsPairs tp = (F3LdsPairs)(const F3Pair *)(tq + ((size_t)((hm >> 16) & 0xff) * EF + p_lane) * 4);
+                            const F3Pair t0 = tp[0], t1 = tp[1];
+                            ws[0] = fma(t0.x, q, ws[0]); ws[1] = fma(t0.y, q, ws[1]);
+                            ws[2] = fma(t1.x, q, ws[2]); ws[3] = fma(t1.y, q, ws[3]);
+                        } else {
+                            const double *rp = stage + (size_t)rec * F3_RS_N;
+                            const double p = ((F3LdsDoubles)rp)[p_lane];
+                            F3LdsPairs qp = (F3LdsPairs)(const F3Pair *)(rp + 4 + 4 * idx);
+                            const F3Pair q0 = qp[0], q1 = qp[1];
+                            ws[0] = fma(p, q0.x, ws[0]); ws[1] = fma(p, q0.y, ws[1]);
+                            ws[2] = fma(p, q1.x, ws[2]); ws[3] = fma(p, q1.y, ws[3]);
+                        }
+                        r += have2 ? 2 : 1;
+                    }
+                    wave_sync();
+                }
+            };
+
+            // ---- centre role: m centres (f, g), f on the fixed leg --------------------------------------------------------
+            if (centre) {
+                const int fs = tr ? t_sb : t_sa, gs = tr ? t_sa : t_sb;
+                const int f_lo = so[fs], nF = so[fs + 1] - f_lo, g_lo = so[gs], nG = so[gs + 1] - g_lo;
+                const bool same = t_sa == t_sb;
+                const int total = __builtin_amdgcn_readfirstlane(nF * nG);
+                const float rcp_ng = __builtin_amdgcn_rcpf((float)max(nG, 1));
+                for (int p0 = 0; p0 < total; p0 += WAVE) {
+                    const int p = p0 + lane;
+                    bool valid = p < total;
+                    int fi = (int)(((float)p + 0.5f) * rcp_ng);
+                    fi -= (fi * nG > p) ? 1 : 0;
+                    fi += ((fi + 1) * nG <= p) ? 1 : 0;
+                    const int gi = p - fi * nG;
+                    valid = valid && (!same || gi > fi);
+                    const int f = f_lo + fi, gg = g_lo + gi;
+                    double bn[4] = {0, 0, 0, 0}, dum[4];
+                    int sbn = 0;
+                    if (valid) {
+                        const double rf = orr[f], rg = orr[gg];
+                        const double ex = ox[gg] - ox[f], ey = oy[gg] - oy[f], ez = oz[gg] - oz[f];
+                        const double rn = norm3_leg(ex, ey, ez);
+                        valid = (rf > leg_p.t0) & (rf < leg_p.tlast) & (rg > leg_p.t0) & (rg < leg_p.tlast) &
+                                (rn > leg_n.t0) & (rn < leg_n.tlast);
+                        if (valid) {
+                            const int iv = f3_eval<false>(rows, leg_n, rn, bn, dum);
+                            sbn = max(0, min(sbn_max, iv - 3 - lo_n));
+                        }
+                    }
+                    engine(valid, f | (sbn << 8) | (gg << 16), true, [&](int slot) {
+                        double *rp = stage + (size_t)slot * F3_RS_C;
+                        *(double2 *)rp = double2{bn[0], bn[1]};
+                        *(double2 *)(rp + 2) = double2{bn[2], bn[3]};
+                        *(double2 *)(rp + 4) = double2{0.0, 0.0};
+                    });
+                }
+                flush(true);
+                cur = -1;
+            }
+            // ---- neighbour role: m is a neighbour of the centre e (fixed bond (m, e)); k runs over e's list -----------------
+            if (nbr) {
+                const int sx = sm == t_sa ? t_sb : t_sa;
+                const int rc_lo = so[t_sc], ncen = so[t_sc + 1] - rc_lo;
+                int total_n = 0;
+                for (int e0 = 0; e0 < ncen; e0 += WAVE) {
+                    const int e = e0 + lane;
+                    int cnt = 0, base = 0;
+                    if (e < ncen) {
+                        const int *sp = ospoff + (size_t)(rc_lo + e) * sp_stride;
+                        base = sp[sx]; cnt = sp[sx + 1] - base;
+                    }
+                    const int incl = wave_scan_incl(cnt);
+                    if (e < ncen) { noff[e] = total_n + incl - cnt; nbase[e] = base; }
+                    total_n += __builtin_amdgcn_readlane(incl, WAVE - 1);
+                }
+                total_n = __builtin_amdgcn_readfirstlane(total_n);
+                if (lane == 0) noff[ncen] = total_n;
+                wave_sync();
+                for (int p0 = 0; p0 < total_n; p0 += WAVE) {
+                    const int q = p0 + lane;
+                    bool valid = q < total_n;
+                    double pv[4] = {0, 0, 0, 0}, bn[4] = {0, 0, 0, 0}, bd[4] = {0, 0, 0, 0}, a3[3] = {0, 0, 0}, dum[4];
+                    int sbn = 0, e = 0;
+                    if (valid) {
+                        int lo = 0, hi = ncen - 1;
+                        while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (noff[mid] <= q) lo = mid; else hi = mid - 1; }
+                        e = rc_lo + lo;
+                        const int kk = nbase[lo] + (q - noff[lo]);
+                        const int pc = oparent[e];
+                        const double oex = ox[e], oey = oy[e], oez = oz[e], oer = orr[e];
+                        const N3Entry ke = A.n3.ent[(size_t)pc * cap + kk];
+                        int s0, s1, s2;
+                        unpack3(oshift[e], s0, s1, s2);
+                        valid = !(ke.parent == m && ke.shiftc == pack3(-s0, -s1, -s2));       // k is m itself
+                        const double ex = oex + ke.dx, ey = oey + ke.dy, ez = oez + ke.dz;   // m -> k
+                        const double rn = norm3_leg(ex, ey, ez), rk = ke.r;
+                        valid = valid & (oer > leg_p.t0) & (oer < leg_p.tlast) & (rk > leg_p.t0) & (rk < leg_p.tlast) &
+                                (rn > leg_n.t0) & (rn < leg_n.tlast);
+                        if (valid) {
+                            const double in = fast_rcp(rn);
+                            a3[0] = ex * in; a3[1] = ey * in; a3[2] = ez * in;
+                            f3_eval<false>(rows, leg_p, rk, pv, dum);
+                            const int iv = f3_eval<true>(rows, leg_n, rn, bn, bd);
+                            sbn = max(0, min(sbn_max, iv - 3 - lo_n));
+                        }
+                    }
+                    engine(valid, e | (sbn << 8), false, [&](int slot) {
+                        double *rp = stage + (size_t)slot * F3_RS_N;
+                        *(double2 *)rp = double2{pv[0], pv[1]};
+                        *(double2 *)(rp + 2) = double2{pv[2], pv[3]};
+#pragma unroll
+                        for (int u = 0; u < 4; u++) {
+                            *(double2 *)(rp + 4 + 4 * u) = double2{a3[0] * bd[u], a3[1] * bd[u]};
+                            *(double2 *)(rp + 6 + 4 * u) = double2{a3[2] * bd[u], bn[u]};
+                        }
+                        *(double2 *)(rp + 20) = double2{0.0, 0.0};
+                        *(double2 *)(rp + 22) = double2{0.0, 0.0};
+                    });
+                }
+                flush(false);
+                cur = -1;
+            }
+            // ---- fold: both halves' partial rows -> LDS [half][c][f][32], the block's columns sum their source bins --------
+            wave_sync();
+            constexpr int NC = WANT_E ? 4 : 3;
+#pragma unroll
+            for (int c = 0; c < NC; c++)
+#pragma unroll
+                for (int q = 0; q < EF; q++) stage[((half * 4 + c) * EF + q) * 32 + pos] = xacc[q][c];
+            wave_sync();
+            const unsigned short *ft = fsrc_l + load_const(A.trio_fsrc + t) + (size_t)(tr ? 2 * t_ncol : 0);
+            for (int col = lane; col < t_ncol; col += WAVE) {
+                const int s0 = ft[2 * col], s1 = ft[2 * col + 1];
+                double sum[4] = {0, 0, 0, 0};
+#pragma unroll
+                for (int c = 0; c < NC; c++) {
+                    const double *d0 = stage + (size_t)c * EF * 32, *d1 = stage + (size_t)(4 + c) * EF * 32;
+                    sum[c] = (d0[s0] + d1[s0]) + (d0[s1] + d1[s1]);
+                }
+                double *dst = A.x_f + (size_t)m * 3 * F + t_col + col;
+                __builtin_nontemporal_store(sum[0], dst); __builtin_nontemporal_store(sum[1], dst + F);
+                __builtin_nontemporal_store(sum[2], dst + 2 * (size_t)F);
+                if (WANT_E) es.add(t_col + col, sum[3]);
+            }
+            wave_sync();
+        }
+    }
+    if (e_lds) {
+        __syncthreads();
+        if (erow_frame >= 0)
+            for (int q = tid; q < F; q += WPB * WAVE) {
+                double v = erow[q];
+                if (v != 0.0) unsafeAtomicAdd(A.x_e + (size_t)erow_frame * F + q, v);
+            }
+    }
+}

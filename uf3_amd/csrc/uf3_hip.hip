@@ -12,6 +12,7 @@
 
 #include "../../include/uf3_hip.h"
 #include "uf3_kernels.h"
+#include "uf3_feat3.h"
 
 // ------------------------------------------------------------------------------ plumbing
 struct Buf {
@@ -57,7 +58,7 @@ struct uf3_ctx {
     Buf geoms, offsets, frame_of, atom_bin, atom_wrap, spec, key_in, key_out, val_in, val_out, sort_tmp,
         bin_start, slots, flags,
         n3_cnt, n3_int, n3_dbl, e_atom, nbr_f, coeff, stage_pos, stage_z, stage_out, stage_out2,
-        gram_tiles[4], gram_tij, frag, dbg,
+        gram_tiles[UF3_MAX_SPECIES + 1], gram_tij, frag, dbg,
         sp_rows, sp_seg,                // force rows by species (uf3_gram_force_rows_dev): row lists | segment starts, counts, cursors
         halo,                           // marks + index list of the halo atoms of a decomposed frame
         n3x_ent, n3x_off,               // extension lists (batches with atoms outside their cell; see N3Lists)
@@ -65,7 +66,7 @@ struct uf3_ctx {
     int n3_cap = 0, cand_cap = 0;
     int n3x_cap = 0;                 // capacity of the extension lists (0 until a batch needed them)
     bool img_mode = false;           // a batch with atoms far outside their cell has been seen: 3-body launches with the image-range rule
-    int gram_plan_np[4] = {0, 0, 0, 0}, gram_plan_blocks[4] = {0, 0, 0, 0}, gram_plan_next = 0;   // workgroup plans of k_gram_tiled held in
+    int gram_plan_np[UF3_MAX_SPECIES + 1] = {0}, gram_plan_blocks[UF3_MAX_SPECIES + 1] = {0}, gram_plan_next = 0;   // workgroup plans of k_gram_tiled held in
                                                      // gram_tiles[] (each for this many 64-column ranges; 0: none)
     int gram_direct_feat = 0;                        // tile-pair table of k_gram_mfma held in gram_tij (for this n_feat; 0: none)
     bool n3_tuned = false;           // capacity re-sized once to the lists actually seen
@@ -125,6 +126,15 @@ struct uf3_basis {
     int dense_dump[16] = {0};        // ... smallest stage (doubles) the fold of its widest window needs
     int modes = 1;                   // bit m set: some trio block is handled by featurizer specialisation m
     double r_cut = 0;
+    // k_featurize3 (3-body force rows by bond factorisation, uf3_feat3.h): eligibility and tables
+    bool feat3_ok = false;
+    double *d_f3rows = nullptr;      // window rows of the centre legs and of leg n
+    int n_f3rows = 0;
+    unsigned short *d_f3src = nullptr;   // fold tables
+    int n_f3src = 0;
+    int *d_f3off = nullptr;          // [T] a trio's table
+    Feat3Leg f3_leg_p, f3_leg_n;
+    int f3_lo_p = 0, f3_ext_p = 0, f3_lo_n = 0, f3_ext_n = 0;
 };
 
 static thread_local std::string g_err;
@@ -175,10 +185,10 @@ extern "C" void uf3_ctx_destroy(uf3_ctx *c) {
     hipStreamSynchronize(c->stream);
     Buf *all[] = {&c->geoms, &c->offsets, &c->frame_of, &c->atom_bin, &c->atom_wrap, &c->spec, &c->key_in,
                   &c->key_out, &c->val_in, &c->val_out, &c->sort_tmp, &c->bin_start, &c->slots, &c->flags, &c->n3_cnt, &c->n3_int, &c->n3_dbl, &c->e_atom, &c->nbr_f, &c->coeff,
-                  &c->stage_pos, &c->stage_z, &c->stage_out, &c->stage_out2, &c->gram_tiles[0], &c->gram_tiles[1], &c->gram_tiles[2],
-                  &c->gram_tiles[3], &c->sp_rows, &c->sp_seg, &c->gram_tij, &c->frag, &c->dbg, &c->halo, &c->n3x_ent, &c->n3x_off,
+                  &c->stage_pos, &c->stage_z, &c->stage_out, &c->stage_out2, &c->sp_rows, &c->sp_seg, &c->gram_tij, &c->frag, &c->dbg, &c->halo, &c->n3x_ent, &c->n3x_off,
                   &c->bin_cnt};
     for (Buf *b : all) b->release();
+    for (Buf &b : c->gram_tiles) b.release();
     c->pin_in.release(); c->pin_geo.release(); c->pin_out.release(); c->pin_flags.release();
     for (auto &pd : c->pending_chk) if (pd.ev) hipEventDestroy(pd.ev);
     if (c->pin_in_done) hipEventDestroy(c->pin_in_done);
@@ -680,6 +690,94 @@ extern "C" int uf3_basis_create(uf3_ctx *c, const uf3_basis_spec *s, uf3_basis *
         }
         if (trios[t].dim_l != trios[0].dim_l || trios[t].dim_m != trios[0].dim_m || trios[t].dim_n != trios[0].dim_n) h.trio_legs_uniform = 0;
     }
+    // ---- k_featurize3 (uf3_feat3.h): one window layout for all trios, centre legs alike, a W window of at most 31 positions;
+    // trios with two equal neighbour species must fold symmetrically in (l, m)
+    {
+        bool ok = h.T > 0 && h.trio_legs_uniform && !getenv("UF3_NO_FEAT3");
+        auto same_leg = [](const LegDev &a, const LegDev &q) {
+            return a.rec_off == q.rec_off && a.nk == q.nk && a.t0 == q.t0 && a.tlast == q.tlast && a.inv_h == q.inv_h;
+        };
+        if (ok) {
+            const TrioDev &t0 = trios[0];
+            ok = t0.lo[0] == t0.lo[1] && t0.ext[0] == t0.ext[1] && same_leg(t0.leg[0], t0.leg[1]) && t0.ext[0] <= 3 &&
+                 t0.ext[0] * t0.ext[2] <= 31 && t0.leg[0].nk >= 8 && t0.leg[2].nk >= 8;
+            for (int t = 0; t < h.T && ok; t++) {
+                const TrioDev &td = trios[t];
+                for (int a = 0; a < 3; a++) ok = ok && td.lo[a] == t0.lo[a] && td.ext[a] == t0.ext[a];
+                ok = ok && td.nsrc <= 2 && td.ncol >= 1;
+                if (ok && td.sa == td.sb)               // (l, m, n) and (m, l, n) feed the same column
+                    for (int col = 0; col < td.ncol && ok; col++)
+                        for (int q = 0; q < td.nsrc && ok; q++) {
+                            const int sp = colsrc[td.src_off + col * td.nsrc + q];
+                            if (sp < 0) continue;
+                            const int swapped = ((sp >> 8) & 255) | ((sp & 255) << 8) | (sp & 0xff0000);
+                            bool found = false;
+                            for (int q2 = 0; q2 < td.nsrc; q2++) found = found || colsrc[td.src_off + col * td.nsrc + q2] == swapped;
+                            ok = found;
+                        }
+            }
+        }
+        if (ok) {
+            const TrioDev &t0 = trios[0];
+            b->f3_lo_p = t0.lo[0]; b->f3_ext_p = t0.ext[0]; b->f3_lo_n = t0.lo[2]; b->f3_ext_n = t0.ext[2];
+            std::vector<double> rows;
+            int n_rows = 0;
+            for (int kind = 0; kind < 2; kind++) {
+                const int a = kind == 0 ? 0 : 2;
+                const double *tk = leg_knots[a];
+                const int nk = t0.leg[a].nk, w_lo = t0.lo[a], w_ext = t0.ext[a];
+                Feat3Leg &lg = kind == 0 ? b->f3_leg_p : b->f3_leg_n;
+                lg.t0 = t0.leg[a].t0; lg.tlast = t0.leg[a].tlast; lg.inv_h = t0.leg[a].inv_h; lg.nk = nk; lg.row0 = n_rows;
+                for (int i = 3; i <= nk - 5; i++, n_rows++) {
+                    // four consecutive functions of the window, the first at slot clamp(i - 3 - window start, 0, ext - 4); zeros
+                    // where a function lies past the window or vanishes on the interval
+                    double row[18] = {0};
+                    row[0] = tk[i]; row[1] = tk[i + 1];
+                    const int sb = std::max(0, std::min(std::max(0, w_ext - 4), i - 3 - w_lo));
+                    for (int fq = 0; fq < 4 && sb + fq < w_ext; fq++) {
+                        const int j = w_lo + sb + fq;
+                        if (j >= i - 3 && j <= i && j >= 0 && j <= nk - 5) bspline_piece(tk, j, i, row + 2 + 4 * fq);
+                    }
+                    rows.insert(rows.end(), row, row + 18);
+                }
+            }
+            b->n_f3rows = n_rows;
+            std::vector<unsigned short> fsrc;
+            std::vector<int> foff(h.T, 0);
+            for (int t = 0; t < h.T; t++) {
+                const TrioDev &td = trios[t];
+                std::vector<unsigned short> mine;
+                for (int o = 0; o < 2; o++)
+                    for (int col = 0; col < td.ncol; col++)
+                        for (int q = 0; q < 2; q++) {
+                            const int sp = q < td.nsrc ? colsrc[td.src_off + col * td.nsrc + q] : -1;
+                            unsigned short e = 31;
+                            if (sp >= 0) {
+                                const int l = (sp & 255) - td.lo[0], m = ((sp >> 8) & 255) - td.lo[1], n = ((sp >> 16) & 255) - td.lo[2];
+                                e = (unsigned short)((o == 0 ? l : m) * 32 + (o == 0 ? m : l) * td.ext[2] + n);
+                            }
+                            mine.push_back(e);
+                        }
+                int at = -1;
+                for (size_t off = 0; off + mine.size() <= fsrc.size() && at < 0; off += 2)
+                    if (std::equal(mine.begin(), mine.end(), fsrc.begin() + off)) at = (int)off;
+                if (at < 0) { at = (int)fsrc.size(); fsrc.insert(fsrc.end(), mine.begin(), mine.end()); }
+                foff[t] = at;
+            }
+            while (fsrc.size() & 1) fsrc.push_back(31);
+            ok = fsrc.size() * 2 <= 16384;
+            if (ok) {
+                b->n_f3src = (int)fsrc.size();
+                HIPCHK(c, hipMalloc(&b->d_f3rows, sizeof(double) * rows.size()));
+                HIPCHK(c, hipMemcpy(b->d_f3rows, rows.data(), sizeof(double) * rows.size(), hipMemcpyHostToDevice));
+                HIPCHK(c, hipMalloc(&b->d_f3src, sizeof(unsigned short) * fsrc.size()));
+                HIPCHK(c, hipMemcpy(b->d_f3src, fsrc.data(), sizeof(unsigned short) * fsrc.size(), hipMemcpyHostToDevice));
+                HIPCHK(c, hipMalloc(&b->d_f3off, sizeof(int) * foff.size()));
+                HIPCHK(c, hipMemcpy(b->d_f3off, foff.data(), sizeof(int) * foff.size(), hipMemcpyHostToDevice));
+            }
+        }
+        b->feat3_ok = ok;
+    }
     // the force rows of an atom of species s are zero outside the blocks s takes part in (and in the one-body columns)
     {
         std::vector<int> sp_cols((size_t)h.S * h.F, 0);
@@ -713,6 +811,7 @@ extern "C" void uf3_basis_destroy(uf3_basis *b) {
     hipSetDevice(b->ctx->device);
     hipStreamSynchronize(b->ctx->stream);
     hipFree(b->dev); hipFree(b->d_trios); hipFree(b->d_recs); hipFree(b->d_lut); hipFree(b->d_colsrc); hipFree(b->d_dsrc); hipFree(b->d_gsrc); hipFree(b->d_sp_cols);
+    hipFree(b->d_f3rows); hipFree(b->d_f3src); hipFree(b->d_f3off);
     delete b;
 }
 
@@ -1124,7 +1223,9 @@ extern "C" int uf3_featurize_dev(uf3_basis *b, const uf3_frames *fr, const doubl
     uf3_ctx *c = b->ctx;
     if (!d_pos || !d_z) return fail(c, UF3_EINVAL, "null positions / species");
     if (!d_xe && !d_xf) return UF3_OK;
-    { int rc0 = poll_pending(c, false); if (rc0) return rc0; }     // verdicts on earlier asynchronous calls that have arrived
+    // verdicts on earlier asynchronous calls that have arrived: returned to the asynchronous caller (their owner) HERE, so not
+    // kept for uf3_ctx_synchronize as well -- a caller that redoes the work would meet the same verdict again after a clean redo
+    { int rc0 = poll_pending(c, false, false); if (rc0) return rc0; }
     Prepared P;
     const bool old_n3 = getenv("UF3_SEPARATE_N3") != nullptr;     // debugging: lists from k_build_n3 instead
     int rc = prepare(b, fr, d_pos, d_z, old_n3, P);       // cell list only: MODE 0 builds the 3-body lists itself
@@ -1195,10 +1296,14 @@ extern "C" int uf3_featurize_dev(uf3_basis *b, const uf3_frames *fr, const doubl
             hipLaunchKernelGGL(k_build_n3_ext, dim3(std::min(P.natoms, 2048)), dim3(64), (size_t)xcap * (8 + 32 + 12) + 16, st,
                                b->dev, P.geoms, P.frame_of, P.cl, A.n3, d_pos, P.natoms, c->flags.as<int>());
         }
+        // 3-body force rows by bond factorisation (k_featurize3) where the basis allows it: one launch for all trio blocks,
+        // behind the pair launch that builds the lists
+        const bool feat3 = b->feat3_ok && want_f && (has3 || old_n3) && !img_launch && cap <= 255 && !getenv("UF3_NO_FEAT3");
         {
             Timed tm(c, T_FEAT);
             for (int mode = 0; mode <= 9; mode++) {
                 if (!(b->modes & (1 << mode))) continue;
+                if (feat3 && mode >= 1) continue;
                 const bool dense_mode = mode >= 6;
                 // knot records go to LDS when the block then still reaches the occupancy its registers allow
                 // (10: mode 7 with grouped windows only -- the force launches of a basis whose mode-7 blocks are all grouped)
@@ -1304,6 +1409,38 @@ extern "C" int uf3_featurize_dev(uf3_basis *b, const uf3_frames *fr, const doubl
                 }
 #undef UF3_LAUNCH
 #undef UF3_LAUNCH1
+            }
+            if (feat3) {
+                Feat3Args G;
+                G.B = b->dev; G.trios = b->d_trios; G.rows = b->d_f3rows; G.n_rows = b->n_f3rows;
+                G.fsrc = b->d_f3src; G.trio_fsrc = b->d_f3off; G.n_fsrc = b->n_f3src;
+                G.leg_p = b->f3_leg_p; G.leg_n = b->f3_leg_n;
+                G.lo_p = b->f3_lo_p; G.ext_p = b->f3_ext_p; G.lo_n = b->f3_lo_n; G.ext_n = b->f3_ext_n;
+                G.geoms = P.geoms; G.frame_of = P.frame_of; G.n3 = A.n3; G.pos = d_pos; G.spec = P.spec;
+                G.x_e = d_xe; G.x_f = d_xf; G.natoms = P.natoms; G.e_direct = A.e_direct;
+                const int S = b->host.S;
+                const bool e_lds = want_e && !A.e_direct;
+                const size_t e_d = e_lds ? (size_t)F + (F & 1) : 0, rows_d = (size_t)b->n_f3rows * 18;
+                const size_t list_d = 5 * (size_t)cap + ((5 * cap) & 1), tq_d = (size_t)cap * 3 * 4, stage_d = F3_STAGE;
+                const size_t per_wave_i = 2 * (size_t)cap + 2 * ((size_t)cap + 1) + (UF3_MAX_SPECIES + 2) + (size_t)cap * (S + 1) + 32;
+                const size_t ints = ((size_t)WPB * per_wave_i + 3) & ~(size_t)3;
+                const size_t lds = (e_d + rows_d + WPB * (list_d + tq_d + stage_d)) * 8 + ints * 4 + (size_t)b->n_f3src * 2 + 32;
+                if (lds > 160 * 1024 - 512) return fail(c, UF3_EOVERFLOW, "featurizer LDS footprint exceeds 160 KB (F or neighbour count too large)");
+                int per_cu = std::max(1, std::min(8, (int)((size_t)(160 * 1024) / lds)));
+                int n_blocks = std::min((P.natoms + WPB - 1) / WPB, c->n_cu * per_cu * 24);
+                int apb = ((P.natoms + n_blocks - 1) / n_blocks + WPB - 1) / WPB * WPB;
+                n_blocks = (P.natoms + apb - 1) / apb;
+                G.atoms_per_block = apb;
+                if (getenv("UF3_DEBUG_LDS"))
+                    fprintf(stderr, "uf3 featurize3: lds %zu B, cap %d, blocks %d x %d atoms, window %d x %d\n", lds, cap, n_blocks, apb, G.ext_p, G.ext_n);
+                const unsigned grid = (unsigned)((n_blocks + 7) / 8 * 8);
+                if (want_e) {
+                    HIPCHK(c, hipFuncSetAttribute((const void *)k_featurize3<true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                    hipLaunchKernelGGL((k_featurize3<true, 3>), dim3(grid), dim3(WPB * WAVE), lds, st, G);
+                } else {
+                    HIPCHK(c, hipFuncSetAttribute((const void *)k_featurize3<false, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                    hipLaunchKernelGGL((k_featurize3<false, 3>), dim3(grid), dim3(WPB * WAVE), lds, st, G);
+                }
             }
         }
         HIPCHK(c, hipGetLastError());
@@ -1663,10 +1800,12 @@ static int launch_gram_tiled(uf3_ctx *c, const double *dx, const double *dy, int
     const int np = (n_cols + 63) / 64;
     // LDS-tiled kernel: patches of 64 x 64 packed into workgroups (at most four patches on at most four column ranges)
     int ps = -1;
-    for (int q = 0; q < 4; q++) if (c->gram_plan_np[q] == np) ps = q;
+    // (one slot per species' column subset + the full matrix: a basis of UF3_MAX_SPECIES species never evicts)
+    const int n_slots = UF3_MAX_SPECIES + 1;
+    for (int q = 0; q < n_slots; q++) if (c->gram_plan_np[q] == np) ps = q;
     if (ps < 0) {
         ps = c->gram_plan_next;
-        c->gram_plan_next = (ps + 1) & 3;
+        c->gram_plan_next = (ps + 1) % n_slots;
         std::vector<GramBlock> plan;
         auto fresh = [&]() { GramBlock g; memset(&g, 0, sizeof g); for (int q = 0; q < 4; q++) g.range[q] = -1; return g; };
         auto slot_of = [&](GramBlock &g, int r, bool add) {
@@ -1731,7 +1870,7 @@ static int launch_gram_tiled(uf3_ctx *c, const double *dx, const double *dy, int
         for (auto &g : plan)
             for (int q = 0; q < 4; q++) if (g.range[q] < 0) g.range[q] = g.range[0];
         c->gram_plan_np[ps] = 0;
-        HIPCHK(c, hipStreamSynchronize(st));                           // (a launch may still be reading the plan this one replaces)
+        HIPCHK(c, hipDeviceSynchronize());                             // (a launch -- on this or an earlier stream of the context -- may still be reading the plan this one replaces)
         HIPCHK(c, c->gram_tiles[ps].ensure(sizeof(GramBlock) * plan.size()));
         HIPCHK(c, hipMemcpyAsync(c->gram_tiles[ps].p, plan.data(), sizeof(GramBlock) * plan.size(), hipMemcpyHostToDevice, st));
         HIPCHK(c, hipStreamSynchronize(st));
@@ -1858,7 +1997,9 @@ extern "C" int uf3_gram_force_rows_dev(uf3_basis *b, const double *d_x_f, const 
     int *seg = c->sp_seg.as<int>(), *cursor = seg + 2 * UF3_MAX_SPECIES, *rows = c->sp_rows.as<int>();
     Timed tm(c, T_GRAM);
     HIPCHK(c, hipMemsetAsync(seg, 0, sizeof(int) * 3 * UF3_MAX_SPECIES, st));
-    HIPCHK(c, hipMemsetAsync(rows + 3 * n_atoms, 0, sizeof(int) * (n_list - 3 * (size_t)n_atoms), st));
+    // (the whole list: k_species_rows skips atoms whose species is outside the basis, so entries between the end of the segments
+    // and 3 n_atoms would otherwise be uninitialised row indices for the kernel's one-slab-ahead prefetch; 12 bytes per atom)
+    HIPCHK(c, hipMemsetAsync(rows, 0, sizeof(int) * n_list, st));
     const unsigned nblk = (unsigned)((n_atoms + SR_ATOMS - 1) / SR_ATOMS);
     hipLaunchKernelGGL(k_species_rows, dim3(nblk), dim3(256), 0, st, (const BasisDev *)b->dev, d_z, n_atoms, 0, seg, cursor, rows);
     hipLaunchKernelGGL(k_species_rows, dim3(nblk), dim3(256), 0, st, (const BasisDev *)b->dev, d_z, n_atoms, 1, seg, cursor, rows);
@@ -1918,11 +2059,12 @@ extern "C" int uf3_fit_pack_dev(uf3_ctx *c, int32_t n_feat, const double *d_flat
                                 const int64_t *d_frozen, const double *d_c_frozen, int32_t n_frozen, double n_energy_rows,
                                 double n_force_rows, double *d_packed) {
     if (!c) return fail(nullptr, UF3_EINVAL, "null ctx");
-    if (n_feat < 1 || n_keep < 1 || n_keep > n_feat || !d_flat || !d_keep || !d_packed || n_frozen < 0 ||
+    if (n_feat < 1 || n_keep < 0 || n_keep > n_feat || !d_flat || (n_keep && !d_keep) || !d_packed || n_frozen < 0 ||
         (n_frozen && (!d_frozen || !d_c_frozen)))
         return fail(c, UF3_EINVAL, "uf3_fit_pack_dev: bad argument");
     HIPCHK(c, hipSetDevice(c->device));
-    hipLaunchKernelGGL(k_fit_pack, dim3((unsigned)n_keep, 2), dim3(256), 0, c->stream, n_feat, d_flat, d_keep, n_keep, d_frozen,
+    // (n_keep == 0, every column frozen: the six moments are the whole packed buffer)
+    hipLaunchKernelGGL(k_fit_pack, dim3((unsigned)std::max(n_keep, 1), 2), dim3(256), 0, c->stream, n_feat, d_flat, d_keep, n_keep, d_frozen,
                        d_c_frozen, n_frozen, n_energy_rows, n_force_rows, d_packed);
     HIPCHK(c, hipGetLastError());
     return UF3_OK;

@@ -3128,14 +3128,16 @@ k_fit_pack(int n_feat, const double *flat, const int64_t *keep, int n_keep, cons
     const size_t F = (size_t)n_feat, K = (size_t)n_keep;
     const double *gram = flat + which * F * F, *ordn = flat + 2 * F * F + which * F;
     double *g_out = packed + which * K * K, *o_out = packed + 2 * K * K + which * K;
-    const double *row = gram + (size_t)keep[i] * F;
-    for (int j = tid; j < n_keep; j += 256) g_out[(size_t)i * K + j] = row[keep[j]];
-    double dot = 0.0;
-    for (int q = tid; q < n_frozen; q += 256) dot += row[frozen[q]] * c_frozen[q];
-    part[tid] = dot;
-    __syncthreads();
-    for (int w = 128; w > 0; w >>= 1) { if (tid < w) part[tid] += part[tid + w]; __syncthreads(); }
-    if (tid == 0) o_out[i] = ordn[keep[i]] - part[0];
+    if (i < n_keep) {                                 // (n_keep == 0 -- every column frozen -- launches one block for the moments)
+        const double *row = gram + (size_t)keep[i] * F;
+        for (int j = tid; j < n_keep; j += 256) g_out[(size_t)i * K + j] = row[keep[j]];
+        double dot = 0.0;
+        for (int q = tid; q < n_frozen; q += 256) dot += row[frozen[q]] * c_frozen[q];
+        part[tid] = dot;
+        __syncthreads();
+        for (int w = 128; w > 0; w >>= 1) { if (tid < w) part[tid] += part[tid + w]; __syncthreads(); }
+        if (tid == 0) o_out[i] = ordn[keep[i]] - part[0];
+    }
     if (i == 0 && tid < 3) {
         const double *m_in = flat + 2 * F * F + 2 * F + 3 * which;
         double *m_out = packed + 2 * K * K + 2 * K + 3 * which;
