@@ -889,7 +889,7 @@ def test_evaluator_on_the_ragged_binary_fcc_frame():
     assert rel_err(f, f_ref) < TOL and worst_elementwise(f, f_ref) <= 1.0
     assert np.abs(f.sum(axis=0)).max() < 1e-9 * np.abs(f).max() * len(atoms) ** 0.5
     x_e, x_f, _ = process.BasisFeaturizer(basis).featurize_frames([atoms])
-    assert abs(x_e[0] @ coeff - e[0]) <= 1e-10 * abs(e[0]) and rel_err(-(x_f @ coeff), f) < TOL     # E = x_e c, F = -X_f c
+    assert abs(x_e[0] @ coeff - e[0]) <= 1e-10 * abs(e[0]) and rel_err(x_f @ coeff, f) < TOL     # E = x_e c, F = X_f c (the force rows carry the sign)
 
 
 def test_gram_of_a_single_column():
