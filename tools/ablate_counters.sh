@@ -5,7 +5,7 @@
 # The switches are compiled in with -DUF3_ABLATE only (build that library first, here, where hipcc is:
 #     (cd uf3_amd/csrc && hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=fast -DUF3_ABLATE -shared -o ../../exp/libuf3hip_ablate.so uf3_hip.hip)
 set -u
-RUN=${1:?output directory}; SKIPS=${2:-"0 8 16 24 6"}
+RUN=${1:?output directory}; SKIPS=${2:-"0 1 2 3 4 8 16 32 64"}
 mkdir -p "$RUN"; export TMPDIR=/tmp UF3_BENCH_NOCHECK=1 UF3_LIB_PATH=$PWD/exp/libuf3hip_ablate.so
 [ -f "$UF3_LIB_PATH" ] || { echo "build exp/libuf3hip_ablate.so first (see the header of this script)"; exit 1; }
 for s in $SKIPS; do

@@ -52,10 +52,11 @@ struct Feat3Args {
     const signed char *spec;
     double *x_e, *x_f;
     int natoms, atoms_per_block, e_direct;
+    int skip;                  // ablations (-DUF3_ABLATE builds only): 1 stage 1, 2 stage 2, 4 centre walk, 8 neighbour walk, 16 fold + stores, 32 bond tables, 64 leg evaluations of the walks
 };
 
 #define F3_NREC 32            // records per engine pass (one per lane of a half-wave)
-#define F3_RS_C 6             // doubles per centre-role record: B_n x 4, a zero, pad
+#define F3_RS_C 12            // doubles per centre-role record: B_n over the whole n window (ext_n <= 11), zero-padded
 #define F3_RS_N 24            // ... per neighbour-role record: B(r_ek) x 4 | (a3 B_n', B_n) x 4 | a zero quad
 #define F3_STAGE 768          // doubles of per-wave stage: 32 records of 24; the fold's dump [half][c][f][32] (EF = 3: 768)
 
@@ -114,24 +115,26 @@ k_featurize3(Feat3Args A) {
     const size_t e_d = e_lds ? (size_t)F + (F & 1) : 0;
     double *rows = erow + e_d;                                        // window rows, shared
     const size_t rows_d = (size_t)A.n_rows * 18;
-    const size_t list_d = 5 * (size_t)cap + ((5 * cap) & 1), tq_d = (size_t)cap * EF * 4;
-    constexpr size_t stage_d = F3_STAGE > 2 * 4 * EF * 32 ? F3_STAGE : 2 * 4 * EF * 32;
+    const size_t list_d = 5 * (size_t)cap + ((5 * cap) & 1), tq_d = (size_t)cap * EF * 8;
+    constexpr size_t stage_d = F3_STAGE > 4 * EF * 32 ? F3_STAGE : 4 * EF * 32;
     const size_t per_wave_d = list_d + tq_d + stage_d;
-    const size_t per_wave_i = 2 * (size_t)cap + 2 * ((size_t)cap + 1) + (UF3_MAX_SPECIES + 2) + (size_t)cap * (S + 1) + 32;
+    const size_t per_wave_i = 2 * (size_t)cap + 2 * ((size_t)cap + 1) + (UF3_MAX_SPECIES + 2) + (size_t)cap * (S + 1) + 64;
     double *wd = rows + rows_d + (size_t)wave * per_wave_d;
     int *wi = (int *)(rows + rows_d + (size_t)WPB * per_wave_d) + (size_t)wave * per_wave_i;
     double *ox = wd, *oy = ox + cap, *oz = oy + cap, *orr = oz + cap, *oir = orr + cap;
-    double *tq = wd + list_d;                                         // [cap][EF][4]: T_f of every own bond
+    double *tq = wd + list_d;                                         // [cap][EF][8]: T_f of every own bond, laid out per half (flush)
     double *stage = tq + tq_d;
     int *oparent = wi, *oshift = wi + cap, *noff = wi + 2 * cap, *nbase = noff + cap + 1, *so = nbase + cap + 1;
     int *ospoff = so + (UF3_MAX_SPECIES + 2);
-    int *hdrs = ospoff + (size_t)cap * (S + 1);                       // [32] record headers of a pass, by rank
+    int *hdrs = ospoff + (size_t)cap * (S + 1);                       // [32 + 32] key | aux of the records of a pass, by rank
     const int sp_stride = S + 1;
     unsigned short *fsrc_l = (unsigned short *)((int *)(rows + rows_d + (size_t)WPB * per_wave_d) + (((size_t)WPB * per_wave_i + 3) & ~(size_t)3));
 
     for (int q = tid; q < (int)rows_d; q += WPB * WAVE) rows[q] = A.rows[q];
     for (int q = tid; q < A.n_fsrc / 2; q += WPB * WAVE) ((int *)fsrc_l)[q] = ((const int *)A.fsrc)[q];
     if (e_lds) { for (int q = tid; q < F; q += WPB * WAVE) erow[q] = 0.0; }
+    for (int q = lane; q < (int)stage_d; q += WAVE) stage[q] = 0.0;      // (slots past a pass's records are read against zeros: finite)
+    for (int q = lane; q < (int)tq_d; q += WAVE) tq[q] = 0.0;
     __syncthreads();
 
     // ---- per-lane constants of the W window ---------------------------------------------------------------------------
@@ -140,6 +143,7 @@ k_featurize3(Feat3Args A) {
     const int p_lane = pos < npos ? pos / ext_n : 0;
     const int n_lane = pos < npos ? pos - p_lane * ext_n : -(1 << 20);     // (idle lanes always read the zero slot)
     const int sbn_max = ext_n > 4 ? ext_n - 4 : 0;
+    const int qn_lane = pos < npos ? n_lane : F3_RS_C - 1;            // (idle lanes read a record's zero padding)
     const Feat3Leg leg_p = A.leg_p, leg_n = A.leg_n;
 
     const int bid = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
@@ -189,13 +193,15 @@ k_featurize3(Feat3Args A) {
         for (int e = lane; e < n_own; e += WAVE) {
             const double r = orr[e];
             double v[4] = {0, 0, 0, 0}, d[4] = {0, 0, 0, 0};
-            if (r > leg_p.t0 && r < leg_p.tlast) f3_eval<true>(rows, leg_p, r, v, d);
+            if (r > leg_p.t0 && r < leg_p.tlast && !UF3_SKIP(32)) f3_eval<true>(rows, leg_p, r, v, d);
             const double ir = oir[e], ux = ox[e] * ir, uy = oy[e] * ir, uz = oz[e] * ir;
 #pragma unroll
             for (int q = 0; q < EF; q++) {
-                double *dst = tq + ((size_t)e * EF + q) * 4;
+                double *dst = tq + ((size_t)e * EF + q) * 8;
                 *(double2 *)dst = double2{ux * d[q], uy * d[q]};
-                *(double2 *)(dst + 2) = double2{uz * d[q], v[q]};
+                *(double2 *)(dst + 2) = double2{v[q], v[q]};
+                *(double2 *)(dst + 4) = double2{uz * d[q], v[q]};
+                *(double2 *)(dst + 6) = double2{v[q], 0.0};
             }
         }
         wave_sync();
@@ -210,76 +216,87 @@ k_featurize3(Feat3Args A) {
             if (!centre && !nbr) { zero_rows(A.x_f, m, F, t_col, t_ncol); continue; }
             const bool tr = t_sa != t_sb && sm == t_sb;              // transposed: the fixed bond sits on leg m
 
-            double xacc[EF][4], ws[4] = {0, 0, 0, 0};
+            // The halves of the wave split the four sums of a position: lanes 0-31 hold (x, y), lanes 32-63 (z, plain), of W and of
+            // the rows (x, y | z, energy) alike.
+            const double *tq_lane = tq + (size_t)p_lane * 8 + 4 * half;   // a lane's pair of bond 0's T rows
+            double xacc[EF][2], ws[2] = {0, 0};
 #pragma unroll
-            for (int q = 0; q < EF; q++) { xacc[q][0] = xacc[q][1] = xacc[q][2] = xacc[q][3] = 0.0; }
+            for (int q = 0; q < EF; q++) { xacc[q][0] = xacc[q][1] = 0.0; }
             int cur = -1;                                           // the bond whose W is being summed (own-list index)
 
-            // stage 2: the open bond's W into the rows of the window
+            // stage 2: the open bond's W into the rows of the window.  tq row of (bond, i): [Tx Ty T3 T3 | Tz T3 T3 0] -- a half
+            // reads its four (U0 U1 V0 V1): row_k += U_k W_plain + V_k W_k (the energy row takes W_plain of the centre role only)
             auto flush = [&](bool is_c) {
-                if (cur < 0) return;
-                F3LdsPairs tp = (F3LdsPairs)(const F3Pair *)(tq + (size_t)cur * EF * 4);
+                if (cur < 0 || UF3_SKIP(2)) return;
+                F3LdsPairs tp = (F3LdsPairs)(const F3Pair *)(tq + (size_t)cur * EF * 8 + 4 * half);
                 F3Pair tv[EF][2];
 #pragma unroll
-                for (int q = 0; q < EF; q++) { tv[q][0] = tp[2 * q]; tv[q][1] = tp[2 * q + 1]; }
+                for (int q = 0; q < EF; q++) { tv[q][0] = tp[4 * q]; tv[q][1] = tp[4 * q + 1]; }
+                // W_plain lives in the upper half: to every lane
+                const int lo = __double2loint(ws[1]), hi = __double2hiint(ws[1]);
+                const auto r0 = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+                const auto r1 = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+                const double wpl = __hiloint2double(r1[1], r0[1]);
+                const double wpl1 = (half && !is_c) ? 0.0 : wpl;
 #pragma unroll
                 for (int q = 0; q < EF; q++) {
-                    const double bv = tv[q][1].y;
-                    xacc[q][0] = fma(tv[q][0].x, ws[3], fma(bv, ws[0], xacc[q][0]));
-                    xacc[q][1] = fma(tv[q][0].y, ws[3], fma(bv, ws[1], xacc[q][1]));
-                    xacc[q][2] = fma(tv[q][1].x, ws[3], fma(bv, ws[2], xacc[q][2]));
-                    if (WANT_E && is_c) xacc[q][3] = fma(bv, ws[3], xacc[q][3]);
+                    xacc[q][0] = fma(tv[q][0].x, wpl, fma(tv[q][1].x, ws[0], xacc[q][0]));
+                    xacc[q][1] = fma(tv[q][0].y, wpl1, fma(tv[q][1].y, ws[1], xacc[q][1]));
                 }
-                ws[0] = ws[1] = ws[2] = ws[3] = 0.0;
+                ws[0] = ws[1] = 0.0;
             };
 
-            // stage 1 over the records of one walk step.  valid / hdr per lane (key | sbn << 8 | g << 16); the lambdas write
-            // a lane's record to a stage slot.  Records come in key-major order; the two halves take alternate records of a key.
-            auto engine = [&](bool valid, int hdr, bool is_c, auto write_record) {
+            // stage 1 over the records of one walk step: valid / key / aux per lane -- key = the fixed bond, aux = the byte offset of
+            // bond g's T rows (centre role) or the first n slot (neighbour role); write_record puts a lane's record into a stage
+            // slot.  Records arrive in key-major order; a pass holds <= 32 of them.  Runs of one key are found with one ballot, a
+            // run is summed four records at a time (operands first, then the multiply-adds), what a lane needs of a record it
+            // reads itself (broadcast reads: no per-record work on the scalar unit).
+            auto engine = [&](bool valid, int key_l, int aux, bool is_c, auto write_record) {
                 const unsigned long long mask = __ballot(valid);
                 const int nv = __popcll(mask), rank = mbcnt(mask);
                 for (int sp0 = 0; sp0 < nv; sp0 += F3_NREC) {
                     const int slot = rank - sp0;
-                    if (valid && slot >= 0 && slot < F3_NREC) { write_record(slot); hdrs[slot] = hdr; }
+                    if (valid && slot >= 0 && slot < F3_NREC) { write_record(slot); hdrs[slot] = key_l; hdrs[32 + slot] = aux; }
                     wave_sync();
-                    const int v_hdr = hdrs[pos];
                     const int r_end = min(F3_NREC, nv - sp0);
-                    for (int r = 0; r < r_end;) {
-                        const int h0 = __builtin_amdgcn_readlane(v_hdr, r);
-                        const int key = h0 & 0xff;
+                    const int v_key = hdrs[pos], v_prev = hdrs[max(pos - 1, 0)];
+                    unsigned gm = (unsigned)__ballot(lane < r_end && (lane == 0 || v_key != v_prev));
+                    while (gm && !UF3_SKIP(1)) {
+                        const int g0 = __builtin_ctz(gm);
+                        gm &= gm - 1;
+                        const int g1 = gm ? __builtin_ctz(gm) : r_end;
+                        const int key = __builtin_amdgcn_readlane(v_key, g0);
                         if (key != cur) { flush(is_c); cur = key; }
-                        const int h1 = __builtin_amdgcn_readlane(v_hdr, min(r + 1, F3_NREC - 1));
-                        const bool have2 = r + 1 < r_end && (h1 & 0xff) == key;
-                        // (the second half without a record of its own re-reads the first half's -- finite numbers -- against
-                        // the zero slot: a stale header could point anywhere)
-                        const bool second = half && have2;
-                        const int hm = second ? h1 : h0;
-                        int idx = n_lane - ((hm >> 8) & 0xff);
-                        idx = (half == 0 || have2) ? idx : 4;
-                        idx = min((unsigned)idx, 4u);
-                        const int rec = r + (second ? 1 : 0);
-                        if (is_c) {
-                            const double q = ((F3LdsDoubles)(const double *)(stage + (size_t)rec * F3_RS_C))[idx];
-                            F3LdsPairs tp = (F3LdsPairs)(const F3Pair *)(tq + ((size_t)((hm >> 16) & 0xff) * EF + p_lane) * 4);
-                            const F3Pair t0 = tp[0], t1 = tp[1];
-                            ws[0] = fma(t0.x, q, ws[0]); ws[1] = fma(t0.y, q, ws[1]);
-                            ws[2] = fma(t1.x, q, ws[2]); ws[3] = fma(t1.y, q, ws[3]);
-                        } else {
-                            const double *rp = stage + (size_t)rec * F3_RS_N;
-                            const double p = ((F3LdsDoubles)rp)[p_lane];
-                            F3LdsPairs qp = (F3LdsPairs)(const F3Pair *)(rp + 4 + 4 * idx);
-                            const F3Pair q0 = qp[0], q1 = qp[1];
-                            ws[0] = fma(p, q0.x, ws[0]); ws[1] = fma(p, q0.y, ws[1]);
-                            ws[2] = fma(p, q1.x, ws[2]); ws[3] = fma(p, q1.y, ws[3]);
+                        for (int r0 = g0; r0 < g1; r0 += 4) {
+                            double a0[4], a1[4], bq[4];
+                            const int *auxp = hdrs + 32 + r0;
+#pragma unroll
+                            for (int i = 0; i < 4; i++) {
+                                a0[i] = a1[i] = bq[i] = 0.0;
+                                if (r0 + i >= g1) continue;                          // (wave-uniform)
+                                const int ax = ((const __attribute__((address_space(3))) int *)auxp)[i];
+                                if (is_c) {
+                                    bq[i] = ((F3LdsDoubles)(const double *)(stage + (size_t)(r0 + i) * F3_RS_C))[qn_lane];
+                                    const F3Pair t = *(F3LdsPairs)(const F3Pair *)((const char *)tq_lane + ax);
+                                    a0[i] = t.x; a1[i] = t.y;
+                                } else {
+                                    const int idx = min((unsigned)(n_lane - ax), 4u);
+                                    const double *rp = stage + (size_t)(r0 + i) * F3_RS_N;
+                                    bq[i] = ((F3LdsDoubles)rp)[p_lane];
+                                    const F3Pair t = *(F3LdsPairs)(const F3Pair *)(rp + 4 + 4 * idx + 2 * half);
+                                    a0[i] = t.x; a1[i] = t.y;
+                                }
+                            }
+#pragma unroll
+                            for (int i = 0; i < 4; i++) { ws[0] = fma(a0[i], bq[i], ws[0]); ws[1] = fma(a1[i], bq[i], ws[1]); }
                         }
-                        r += have2 ? 2 : 1;
                     }
                     wave_sync();
                 }
             };
 
             // ---- centre role: m centres (f, g), f on the fixed leg --------------------------------------------------------
-            if (centre) {
+            if (centre && !UF3_SKIP(4)) {
                 const int fs = tr ? t_sb : t_sa, gs = tr ? t_sa : t_sb;
                 const int f_lo = so[fs], nF = so[fs + 1] - f_lo, g_lo = so[gs], nG = so[gs + 1] - g_lo;
                 const bool same = t_sa == t_sb;
@@ -302,23 +319,24 @@ k_featurize3(Feat3Args A) {
                         const double rn = norm3_leg(ex, ey, ez);
                         valid = (rf > leg_p.t0) & (rf < leg_p.tlast) & (rg > leg_p.t0) & (rg < leg_p.tlast) &
                                 (rn > leg_n.t0) & (rn < leg_n.tlast);
-                        if (valid) {
+                        if (valid && !UF3_SKIP(64)) {
                             const int iv = f3_eval<false>(rows, leg_n, rn, bn, dum);
                             sbn = max(0, min(sbn_max, iv - 3 - lo_n));
                         }
                     }
-                    engine(valid, f | (sbn << 8) | (gg << 16), true, [&](int slot) {
+                    engine(valid, f, gg * (EF * 64), true, [&](int slot) {
                         double *rp = stage + (size_t)slot * F3_RS_C;
-                        *(double2 *)rp = double2{bn[0], bn[1]};
-                        *(double2 *)(rp + 2) = double2{bn[2], bn[3]};
-                        *(double2 *)(rp + 4) = double2{0.0, 0.0};
+#pragma unroll
+                        for (int u = 0; u < F3_RS_C; u += 2) *(double2 *)(rp + u) = double2{0.0, 0.0};
+#pragma unroll
+                        for (int u = 0; u < 4; u++) rp[sbn + u] = bn[u];
                     });
                 }
                 flush(true);
                 cur = -1;
             }
             // ---- neighbour role: m is a neighbour of the centre e (fixed bond (m, e)); k runs over e's list -----------------
-            if (nbr) {
+            if (nbr && !UF3_SKIP(8)) {
                 const int sx = sm == t_sa ? t_sb : t_sa;
                 const int rc_lo = so[t_sc], ncen = so[t_sc + 1] - rc_lo;
                 int total_n = 0;
@@ -356,7 +374,7 @@ k_featurize3(Feat3Args A) {
                         const double rn = norm3_leg(ex, ey, ez), rk = ke.r;
                         valid = valid & (oer > leg_p.t0) & (oer < leg_p.tlast) & (rk > leg_p.t0) & (rk < leg_p.tlast) &
                                 (rn > leg_n.t0) & (rn < leg_n.tlast);
-                        if (valid) {
+                        if (valid && !UF3_SKIP(64)) {
                             const double in = fast_rcp(rn);
                             a3[0] = ex * in; a3[1] = ey * in; a3[2] = ez * in;
                             f3_eval<false>(rows, leg_p, rk, pv, dum);
@@ -364,7 +382,7 @@ k_featurize3(Feat3Args A) {
                             sbn = max(0, min(sbn_max, iv - 3 - lo_n));
                         }
                     }
-                    engine(valid, e | (sbn << 8), false, [&](int slot) {
+                    engine(valid, e, sbn, false, [&](int slot) {
                         double *rp = stage + (size_t)slot * F3_RS_N;
                         *(double2 *)rp = double2{pv[0], pv[1]};
                         *(double2 *)(rp + 2) = double2{pv[2], pv[3]};
@@ -380,13 +398,14 @@ k_featurize3(Feat3Args A) {
                 flush(false);
                 cur = -1;
             }
+            if (UF3_SKIP(16)) continue;
             // ---- fold: both halves' partial rows -> LDS [half][c][f][32], the block's columns sum their source bins --------
             wave_sync();
             constexpr int NC = WANT_E ? 4 : 3;
 #pragma unroll
-            for (int c = 0; c < NC; c++)
+            for (int k = 0; k < 2; k++)
 #pragma unroll
-                for (int q = 0; q < EF; q++) stage[((half * 4 + c) * EF + q) * 32 + pos] = xacc[q][c];
+                for (int q = 0; q < EF; q++) stage[((2 * half + k) * EF + q) * 32 + pos] = xacc[q][k];
             wave_sync();
             const unsigned short *ft = fsrc_l + load_const(A.trio_fsrc + t) + (size_t)(tr ? 2 * t_ncol : 0);
             for (int col = lane; col < t_ncol; col += WAVE) {
@@ -394,8 +413,8 @@ k_featurize3(Feat3Args A) {
                 double sum[4] = {0, 0, 0, 0};
 #pragma unroll
                 for (int c = 0; c < NC; c++) {
-                    const double *d0 = stage + (size_t)c * EF * 32, *d1 = stage + (size_t)(4 + c) * EF * 32;
-                    sum[c] = (d0[s0] + d1[s0]) + (d0[s1] + d1[s1]);
+                    const double *d0 = stage + (size_t)c * EF * 32;
+                    sum[c] = d0[s0] + d0[s1];
                 }
                 double *dst = A.x_f + (size_t)m * 3 * F + t_col + col;
                 __builtin_nontemporal_store(sum[0], dst); __builtin_nontemporal_store(sum[1], dst + F);

@@ -700,7 +700,7 @@ extern "C" int uf3_basis_create(uf3_ctx *c, const uf3_basis_spec *s, uf3_basis *
         if (ok) {
             const TrioDev &t0 = trios[0];
             ok = t0.lo[0] == t0.lo[1] && t0.ext[0] == t0.ext[1] && same_leg(t0.leg[0], t0.leg[1]) && t0.ext[0] <= 3 &&
-                 t0.ext[0] * t0.ext[2] <= 31 && t0.leg[0].nk >= 8 && t0.leg[2].nk >= 8;
+                 t0.ext[0] * t0.ext[2] <= 31 && t0.ext[2] <= 11 && t0.leg[0].nk >= 8 && t0.leg[2].nk >= 8;
             for (int t = 0; t < h.T && ok; t++) {
                 const TrioDev &td = trios[t];
                 for (int a = 0; a < 3; a++) ok = ok && td.lo[a] == t0.lo[a] && td.ext[a] == t0.ext[a];
@@ -1417,12 +1417,12 @@ extern "C" int uf3_featurize_dev(uf3_basis *b, const uf3_frames *fr, const doubl
                 G.leg_p = b->f3_leg_p; G.leg_n = b->f3_leg_n;
                 G.lo_p = b->f3_lo_p; G.ext_p = b->f3_ext_p; G.lo_n = b->f3_lo_n; G.ext_n = b->f3_ext_n;
                 G.geoms = P.geoms; G.frame_of = P.frame_of; G.n3 = A.n3; G.pos = d_pos; G.spec = P.spec;
-                G.x_e = d_xe; G.x_f = d_xf; G.natoms = P.natoms; G.e_direct = A.e_direct;
+                G.x_e = d_xe; G.x_f = d_xf; G.natoms = P.natoms; G.e_direct = A.e_direct; G.skip = A.skip;
                 const int S = b->host.S;
                 const bool e_lds = want_e && !A.e_direct;
                 const size_t e_d = e_lds ? (size_t)F + (F & 1) : 0, rows_d = (size_t)b->n_f3rows * 18;
-                const size_t list_d = 5 * (size_t)cap + ((5 * cap) & 1), tq_d = (size_t)cap * 3 * 4, stage_d = F3_STAGE;
-                const size_t per_wave_i = 2 * (size_t)cap + 2 * ((size_t)cap + 1) + (UF3_MAX_SPECIES + 2) + (size_t)cap * (S + 1) + 32;
+                const size_t list_d = 5 * (size_t)cap + ((5 * cap) & 1), tq_d = (size_t)cap * 3 * 8, stage_d = F3_STAGE;
+                const size_t per_wave_i = 2 * (size_t)cap + 2 * ((size_t)cap + 1) + (UF3_MAX_SPECIES + 2) + (size_t)cap * (S + 1) + 64;
                 const size_t ints = ((size_t)WPB * per_wave_i + 3) & ~(size_t)3;
                 const size_t lds = (e_d + rows_d + WPB * (list_d + tq_d + stage_d)) * 8 + ints * 4 + (size_t)b->n_f3src * 2 + 32;
                 if (lds > 160 * 1024 - 512) return fail(c, UF3_EOVERFLOW, "featurizer LDS footprint exceeds 160 KB (F or neighbour count too large)");
