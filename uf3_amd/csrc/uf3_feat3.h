@@ -55,10 +55,10 @@ struct Feat3Args {
     int skip;                  // ablations (-DUF3_ABLATE builds only): 1 stage 1, 2 stage 2, 4 centre walk, 8 neighbour walk, 16 fold + stores, 32 bond tables, 64 leg evaluations of the walks
 };
 
-#define F3_NREC 32            // records per engine pass (one per lane of a half-wave)
-#define F3_RS_C 12            // doubles per centre-role record: B_n over the whole n window (ext_n <= 11), zero-padded
-#define F3_RS_N 24            // ... per neighbour-role record: B(r_ek) x 4 | (a3 B_n', B_n) x 4 | a zero quad
-#define F3_STAGE 768          // doubles of per-wave stage: 32 records of 24; the fold's dump [half][c][f][32] (EF = 3: 768)
+#define F3_NREC 48            // neighbour-role records per engine pass
+#define F3_RS_C 12            // doubles per centre-role record: B_n over the whole n window (ext_n <= 11), zero-padded; one per lane
+#define F3_RS_N 20            // ... per neighbour-role record: B(r_ek) x 4 | (a3 B_n', B_n) x 4
+#define F3_STAGE 964          // doubles of per-wave stage: 48 records of 20 (64 of 12; the fold's dump [c][f][32]) + a zero quad
 
 typedef double __attribute__((ext_vector_type(2))) F3Pair;
 typedef const __attribute__((address_space(3))) F3Pair *F3LdsPairs;
@@ -109,49 +109,50 @@ k_featurize3(Feat3Args A) {
     const int F = load_const(&B->F), S = load_const(&B->S), n_trios = load_const(&B->T), cap = A.n3.cap;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // ---- LDS carve (feat3_lds_bytes on the host) ----------------------------------------------------------------------
+    // ---- LDS carve (the same sums in uf3_featurize_dev) -----------------------------------------------------------------
     double *erow = (double *)smem;
     const bool e_lds = WANT_E && !A.e_direct;
     const size_t e_d = e_lds ? (size_t)F + (F & 1) : 0;
     double *rows = erow + e_d;                                        // window rows, shared
     const size_t rows_d = (size_t)A.n_rows * 18;
-    const size_t list_d = 5 * (size_t)cap + ((5 * cap) & 1), tq_d = (size_t)cap * EF * 8;
-    constexpr size_t stage_d = F3_STAGE > 4 * EF * 32 ? F3_STAGE : 4 * EF * 32;
+    const size_t list_d = 5 * (size_t)cap + ((5 * cap) & 1), tq_d = (size_t)cap * EF * 4;
+    constexpr size_t stage_d = F3_STAGE;
+    static_assert(4 * EF * 32 <= F3_STAGE - 4 && 64 * F3_RS_C <= F3_STAGE - 4 && F3_NREC * F3_RS_N <= F3_STAGE - 4, "stage too small");
     const size_t per_wave_d = list_d + tq_d + stage_d;
-    const size_t per_wave_i = 2 * (size_t)cap + 2 * ((size_t)cap + 1) + (UF3_MAX_SPECIES + 2) + (size_t)cap * (S + 1) + 64;
+    const size_t per_wave_i = 2 * (size_t)cap + 2 * ((size_t)cap + 1) + (UF3_MAX_SPECIES + 2) + (size_t)cap * (S + 1) + 2 * F3_NREC;
     double *wd = rows + rows_d + (size_t)wave * per_wave_d;
     int *wi = (int *)(rows + rows_d + (size_t)WPB * per_wave_d) + (size_t)wave * per_wave_i;
     double *ox = wd, *oy = ox + cap, *oz = oy + cap, *orr = oz + cap, *oir = orr + cap;
-    double *tq = wd + list_d;                                         // [cap][EF][8]: T_f of every own bond, laid out per half (flush)
+    double *tq = wd + list_d;                                         // [cap][EF][4]: T_f = (Tx Ty Tz T3) of every own bond
     double *stage = tq + tq_d;
+    double *zq = stage + (F3_STAGE - 4);                              // a quad of zeros
     int *oparent = wi, *oshift = wi + cap, *noff = wi + 2 * cap, *nbase = noff + cap + 1, *so = nbase + cap + 1;
     int *ospoff = so + (UF3_MAX_SPECIES + 2);
-    int *hdrs = ospoff + (size_t)cap * (S + 1);                       // [32 + 32] key | aux of the records of a pass, by rank
+    int *hdrs = ospoff + (size_t)cap * (S + 1);                       // [NREC + NREC] key | first n slot of the records of a pass
     const int sp_stride = S + 1;
     unsigned short *fsrc_l = (unsigned short *)((int *)(rows + rows_d + (size_t)WPB * per_wave_d) + (((size_t)WPB * per_wave_i + 3) & ~(size_t)3));
 
     for (int q = tid; q < (int)rows_d; q += WPB * WAVE) rows[q] = A.rows[q];
     for (int q = tid; q < A.n_fsrc / 2; q += WPB * WAVE) ((int *)fsrc_l)[q] = ((const int *)A.fsrc)[q];
     if (e_lds) { for (int q = tid; q < F; q += WPB * WAVE) erow[q] = 0.0; }
-    for (int q = lane; q < (int)stage_d; q += WAVE) stage[q] = 0.0;      // (slots past a pass's records are read against zeros: finite)
+    for (int q = lane; q < (int)stage_d; q += WAVE) stage[q] = 0.0;
     for (int q = lane; q < (int)tq_d; q += WAVE) tq[q] = 0.0;
     __syncthreads();
 
-    // ---- per-lane constants of the W window ---------------------------------------------------------------------------
+    // ---- per-lane constants of the W window: lanes 0-31 hold the sums (x, y) of a position, lanes 32-63 (z, plain) ----------
     const int ext_p = A.ext_p, ext_n = A.ext_n, lo_n = A.lo_n, npos = ext_p * ext_n;
     const int half = lane >> 5, pos = lane & 31;
     const int p_lane = pos < npos ? pos / ext_n : 0;
-    const int n_lane = pos < npos ? pos - p_lane * ext_n : -(1 << 20);     // (idle lanes always read the zero slot)
+    const int n_lane = pos < npos ? pos - p_lane * ext_n : -(1 << 20);     // (idle lanes always read zeros)
     const int sbn_max = ext_n > 4 ? ext_n - 4 : 0;
-    const int qn_lane = pos < npos ? n_lane : F3_RS_C - 1;            // (idle lanes read a record's zero padding)
+    const int qn_lane = pos < npos ? n_lane : F3_RS_C - 1;            // (... a centre-role record's zero padding)
     const Feat3Leg leg_p = A.leg_p, leg_n = A.leg_n;
+    const double *tq_lane = tq + (size_t)p_lane * 4 + 2 * half;       // a lane's pair of bond 0's T rows
 
     const int bid = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
     const int block_first = bid * A.atoms_per_block;
     const int block_end = min(block_first + A.atoms_per_block, A.natoms);
     int erow_frame = -1;
-    FrameGeom g;
-    int g_frame = -1;
     for (int m0 = block_first; m0 < block_end; m0 += WPB) {
         const int m = m0 + wave;
         const bool active = m < block_end;
@@ -170,7 +171,6 @@ k_featurize3(Feat3Args A) {
         }
         if (!active) continue;
         const int fr = load_const(A.frame_of + m);
-        if (fr != g_frame) { g = A.geoms[fr]; g_frame = fr; }
         const int sm = ((const __attribute__((address_space(4))) signed char *)(unsigned long long)A.spec)[m];
         ESink es;
         es.lds = erow; es.glob = WANT_E ? A.x_e + (size_t)fr * F : nullptr; es.direct = !e_lds || (fr != erow_frame);
@@ -197,11 +197,9 @@ k_featurize3(Feat3Args A) {
             const double ir = oir[e], ux = ox[e] * ir, uy = oy[e] * ir, uz = oz[e] * ir;
 #pragma unroll
             for (int q = 0; q < EF; q++) {
-                double *dst = tq + ((size_t)e * EF + q) * 8;
+                double *dst = tq + ((size_t)e * EF + q) * 4;
                 *(double2 *)dst = double2{ux * d[q], uy * d[q]};
-                *(double2 *)(dst + 2) = double2{v[q], v[q]};
-                *(double2 *)(dst + 4) = double2{uz * d[q], v[q]};
-                *(double2 *)(dst + 6) = double2{v[q], 0.0};
+                *(double2 *)(dst + 2) = double2{uz * d[q], v[q]};
             }
         }
         wave_sync();
@@ -210,97 +208,48 @@ k_featurize3(Feat3Args A) {
             const TrioDev *td = A.trios + t;
             typedef int int8_v __attribute__((ext_vector_type(8)));
             const int8_v hv = *(const __attribute__((address_space(4))) int8_v *)(unsigned long long)&td->head;
-            const int t_nsrc = hv[1], t_ncol = hv[2], t_sc = hv[3], t_sa = hv[4], t_sb = hv[5], t_col = hv[6];
-            (void)t_nsrc;
+            const int t_ncol = hv[2], t_sc = hv[3], t_sa = hv[4], t_sb = hv[5], t_col = hv[6];
             const bool centre = t_sc == sm, nbr = t_sa == sm || t_sb == sm;
             if (!centre && !nbr) { zero_rows(A.x_f, m, F, t_col, t_ncol); continue; }
             const bool tr = t_sa != t_sb && sm == t_sb;              // transposed: the fixed bond sits on leg m
 
-            // The halves of the wave split the four sums of a position: lanes 0-31 hold (x, y), lanes 32-63 (z, plain), of W and of
-            // the rows (x, y | z, energy) alike.
-            const double *tq_lane = tq + (size_t)p_lane * 8 + 4 * half;   // a lane's pair of bond 0's T rows
             double xacc[EF][2], ws[2] = {0, 0};
 #pragma unroll
             for (int q = 0; q < EF; q++) { xacc[q][0] = xacc[q][1] = 0.0; }
             int cur = -1;                                           // the bond whose W is being summed (own-list index)
 
-            // stage 2: the open bond's W into the rows of the window.  tq row of (bond, i): [Tx Ty T3 T3 | Tz T3 T3 0] -- a half
-            // reads its four (U0 U1 V0 V1): row_k += U_k W_plain + V_k W_k (the energy row takes W_plain of the centre role only)
+            // stage 2: the open bond's W into the rows of the window.  Lower half: rows (x, y) += (Tx, Ty) W_plain + T3 (W_x, W_y);
+            // upper half: rows (z, energy) += (Tz, T3) W_plain + T3 (W_z, 0) -- the energy row from the centre role only.
             auto flush = [&](bool is_c) {
                 if (cur < 0 || UF3_SKIP(2)) return;
-                F3LdsPairs tp = (F3LdsPairs)(const F3Pair *)(tq + (size_t)cur * EF * 8 + 4 * half);
-                F3Pair tv[EF][2];
+                const double *tc = tq + (size_t)cur * EF * 4;
+                F3Pair tv[EF];
+                double t3[EF];
 #pragma unroll
-                for (int q = 0; q < EF; q++) { tv[q][0] = tp[4 * q]; tv[q][1] = tp[4 * q + 1]; }
-                // W_plain lives in the upper half: to every lane
+                for (int q = 0; q < EF; q++) { tv[q] = *(F3LdsPairs)(const F3Pair *)(tc + 4 * q + 2 * half); t3[q] = ((F3LdsDoubles)tc)[4 * q + 3]; }
                 const int lo = __double2loint(ws[1]), hi = __double2hiint(ws[1]);
                 const auto r0 = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
                 const auto r1 = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
-                const double wpl = __hiloint2double(r1[1], r0[1]);
-                const double wpl1 = (half && !is_c) ? 0.0 : wpl;
+                const double wpl = __hiloint2double(r1[1], r0[1]);            // W_plain (the upper half's second sum) in every lane
+                const double wpl1 = (half && !is_c) ? 0.0 : wpl, ws1 = half ? 0.0 : ws[1];
 #pragma unroll
                 for (int q = 0; q < EF; q++) {
-                    xacc[q][0] = fma(tv[q][0].x, wpl, fma(tv[q][1].x, ws[0], xacc[q][0]));
-                    xacc[q][1] = fma(tv[q][0].y, wpl1, fma(tv[q][1].y, ws[1], xacc[q][1]));
+                    xacc[q][0] = fma(tv[q].x, wpl, fma(t3[q], ws[0], xacc[q][0]));
+                    xacc[q][1] = fma(tv[q].y, wpl1, fma(t3[q], ws1, xacc[q][1]));
                 }
                 ws[0] = ws[1] = 0.0;
             };
 
-            // stage 1 over the records of one walk step: valid / key / aux per lane -- key = the fixed bond, aux = the byte offset of
-            // bond g's T rows (centre role) or the first n slot (neighbour role); write_record puts a lane's record into a stage
-            // slot.  Records arrive in key-major order; a pass holds <= 32 of them.  Runs of one key are found with one ballot, a
-            // run is summed four records at a time (operands first, then the multiply-adds), what a lane needs of a record it
-            // reads itself (broadcast reads: no per-record work on the scalar unit).
-            auto engine = [&](bool valid, int key_l, int aux, bool is_c, auto write_record) {
-                const unsigned long long mask = __ballot(valid);
-                const int nv = __popcll(mask), rank = mbcnt(mask);
-                for (int sp0 = 0; sp0 < nv; sp0 += F3_NREC) {
-                    const int slot = rank - sp0;
-                    if (valid && slot >= 0 && slot < F3_NREC) { write_record(slot); hdrs[slot] = key_l; hdrs[32 + slot] = aux; }
-                    wave_sync();
-                    const int r_end = min(F3_NREC, nv - sp0);
-                    const int v_key = hdrs[pos], v_prev = hdrs[max(pos - 1, 0)];
-                    unsigned gm = (unsigned)__ballot(lane < r_end && (lane == 0 || v_key != v_prev));
-                    while (gm && !UF3_SKIP(1)) {
-                        const int g0 = __builtin_ctz(gm);
-                        gm &= gm - 1;
-                        const int g1 = gm ? __builtin_ctz(gm) : r_end;
-                        const int key = __builtin_amdgcn_readlane(v_key, g0);
-                        if (key != cur) { flush(is_c); cur = key; }
-                        for (int r0 = g0; r0 < g1; r0 += 4) {
-                            double a0[4], a1[4], bq[4];
-                            const int *auxp = hdrs + 32 + r0;
-#pragma unroll
-                            for (int i = 0; i < 4; i++) {
-                                a0[i] = a1[i] = bq[i] = 0.0;
-                                if (r0 + i >= g1) continue;                          // (wave-uniform)
-                                const int ax = ((const __attribute__((address_space(3))) int *)auxp)[i];
-                                if (is_c) {
-                                    bq[i] = ((F3LdsDoubles)(const double *)(stage + (size_t)(r0 + i) * F3_RS_C))[qn_lane];
-                                    const F3Pair t = *(F3LdsPairs)(const F3Pair *)((const char *)tq_lane + ax);
-                                    a0[i] = t.x; a1[i] = t.y;
-                                } else {
-                                    const int idx = min((unsigned)(n_lane - ax), 4u);
-                                    const double *rp = stage + (size_t)(r0 + i) * F3_RS_N;
-                                    bq[i] = ((F3LdsDoubles)rp)[p_lane];
-                                    const F3Pair t = *(F3LdsPairs)(const F3Pair *)(rp + 4 + 4 * idx + 2 * half);
-                                    a0[i] = t.x; a1[i] = t.y;
-                                }
-                            }
-#pragma unroll
-                            for (int i = 0; i < 4; i++) { ws[0] = fma(a0[i], bq[i], ws[0]); ws[1] = fma(a1[i], bq[i], ws[1]); }
-                        }
-                    }
-                    wave_sync();
-                }
-            };
-
-            // ---- centre role: m centres (f, g), f on the fixed leg --------------------------------------------------------
+            // ---- centre role: m centres (f, g), f on the fixed leg.  Items p = fi * nG + gi, one per lane and stage slot (not
+            // compacted: a void item is a record of zeros); the records of a fixed bond are a run of slots and the T rows of
+            // their partners g a run of the table: stage 1 reads both at constant offsets from the run's first record.
             if (centre && !UF3_SKIP(4)) {
                 const int fs = tr ? t_sb : t_sa, gs = tr ? t_sa : t_sb;
                 const int f_lo = so[fs], nF = so[fs + 1] - f_lo, g_lo = so[gs], nG = so[gs + 1] - g_lo;
                 const bool same = t_sa == t_sb;
                 const int total = __builtin_amdgcn_readfirstlane(nF * nG);
+                const int nGs = __builtin_amdgcn_readfirstlane(nG), f_los = __builtin_amdgcn_readfirstlane(f_lo),
+                          g_los = __builtin_amdgcn_readfirstlane(g_lo);
                 const float rcp_ng = __builtin_amdgcn_rcpf((float)max(nG, 1));
                 for (int p0 = 0; p0 < total; p0 += WAVE) {
                     const int p = p0 + lane;
@@ -324,18 +273,54 @@ k_featurize3(Feat3Args A) {
                             sbn = max(0, min(sbn_max, iv - 3 - lo_n));
                         }
                     }
-                    engine(valid, f, gg * (EF * 64), true, [&](int slot) {
-                        double *rp = stage + (size_t)slot * F3_RS_C;
+                    {
+                        double *rp = stage + (size_t)lane * F3_RS_C;
 #pragma unroll
                         for (int u = 0; u < F3_RS_C; u += 2) *(double2 *)(rp + u) = double2{0.0, 0.0};
+                        if (valid) {
 #pragma unroll
-                        for (int u = 0; u < 4; u++) rp[sbn + u] = bn[u];
-                    });
+                            for (int u = 0; u < 4; u++) rp[sbn + u] = bn[u];
+                        }
+                    }
+                    wave_sync();
+                    // rows fi of the item rectangle that this step touches
+                    const int p1 = min(total, p0 + WAVE);
+                    int fi_s = p0 / nGs;
+                    for (int pr = fi_s * nGs; pr < p1 && !UF3_SKIP(1); pr += nGs, fi_s++) {
+                        int s0 = max(pr, p0), s1 = min(pr + nGs, p1);               // items of this row inside the step
+                        if (same) s0 = max(s0, pr + fi_s + 1);
+                        if (s0 >= s1) continue;
+                        const int key = f_los + fi_s;
+                        if (key != cur) { flush(true); cur = key; }
+                        const double *qp = stage + (size_t)(s0 - p0) * F3_RS_C + qn_lane;
+                        const double *tp = tq_lane + (size_t)(g_los + (s0 - pr)) * EF * 4;
+                        int cnt = s1 - s0;
+                        auto body = [&](auto tag) {
+                            constexpr int CNT = decltype(tag)::value;
+                            double bq[CNT];
+                            F3Pair tt[CNT];
+#pragma unroll
+                            for (int i = 0; i < CNT; i++) {
+                                bq[i] = ((F3LdsDoubles)qp)[i * F3_RS_C];
+                                tt[i] = *(F3LdsPairs)(const F3Pair *)(tp + (size_t)i * EF * 4);
+                            }
+#pragma unroll
+                            for (int i = 0; i < CNT; i++) { ws[0] = fma(tt[i].x, bq[i], ws[0]); ws[1] = fma(tt[i].y, bq[i], ws[1]); }
+                            qp += CNT * F3_RS_C; tp += (size_t)CNT * EF * 4; cnt -= CNT;
+                        };
+                        while (cnt >= 4) body(std::integral_constant<int, 4>{});
+                        if (cnt == 3) body(std::integral_constant<int, 3>{});
+                        else if (cnt == 2) body(std::integral_constant<int, 2>{});
+                        else if (cnt == 1) body(std::integral_constant<int, 1>{});
+                    }
+                    wave_sync();
                 }
                 flush(true);
                 cur = -1;
             }
-            // ---- neighbour role: m is a neighbour of the centre e (fixed bond (m, e)); k runs over e's list -----------------
+            // ---- neighbour role: m is a neighbour of the centre e (fixed bond (m, e)); k runs over e's list.  The valid items of
+            // a step are compacted into the stage in order (runs of a fixed bond are found with one ballot); what a lane needs of
+            // a record besides its operands -- the first n slot -- it reads itself (no per-record work on the scalar unit).
             if (nbr && !UF3_SKIP(8)) {
                 const int sx = sm == t_sa ? t_sb : t_sa;
                 const int rc_lo = so[t_sc], ncen = so[t_sc + 1] - rc_lo;
@@ -382,24 +367,66 @@ k_featurize3(Feat3Args A) {
                             sbn = max(0, min(sbn_max, iv - 3 - lo_n));
                         }
                     }
-                    engine(valid, e, sbn, false, [&](int slot) {
-                        double *rp = stage + (size_t)slot * F3_RS_N;
-                        *(double2 *)rp = double2{pv[0], pv[1]};
-                        *(double2 *)(rp + 2) = double2{pv[2], pv[3]};
+                    const unsigned long long mask = __ballot(valid);
+                    const int nv = __popcll(mask), rank = mbcnt(mask);
+                    for (int sp0 = 0; sp0 < nv; sp0 += F3_NREC) {
+                        const int slot = rank - sp0;
+                        if (valid && slot >= 0 && slot < F3_NREC) {
+                            double *rp = stage + (size_t)slot * F3_RS_N;
+                            *(double2 *)rp = double2{pv[0], pv[1]};
+                            *(double2 *)(rp + 2) = double2{pv[2], pv[3]};
 #pragma unroll
-                        for (int u = 0; u < 4; u++) {
-                            *(double2 *)(rp + 4 + 4 * u) = double2{a3[0] * bd[u], a3[1] * bd[u]};
-                            *(double2 *)(rp + 6 + 4 * u) = double2{a3[2] * bd[u], bn[u]};
+                            for (int u = 0; u < 4; u++) {
+                                *(double2 *)(rp + 4 + 4 * u) = double2{a3[0] * bd[u], a3[1] * bd[u]};
+                                *(double2 *)(rp + 6 + 4 * u) = double2{a3[2] * bd[u], bn[u]};
+                            }
+                            hdrs[slot] = e; hdrs[F3_NREC + slot] = sbn;
                         }
-                        *(double2 *)(rp + 20) = double2{0.0, 0.0};
-                        *(double2 *)(rp + 22) = double2{0.0, 0.0};
-                    });
+                        wave_sync();
+                        const int r_end = min(F3_NREC, nv - sp0);
+                        const int v_key = hdrs[min(lane, F3_NREC - 1)], v_prev = hdrs[min(max(lane - 1, 0), F3_NREC - 1)];
+                        unsigned long long gm = __ballot(lane < r_end && (lane == 0 || v_key != v_prev));
+                        while (gm && !UF3_SKIP(1)) {
+                            const int g0 = __builtin_ctzll(gm);
+                            gm &= gm - 1;
+                            const int g1 = gm ? __builtin_ctzll(gm) : r_end;
+                            const int key = __builtin_amdgcn_readlane(v_key, g0);
+                            if (key != cur) { flush(false); cur = key; }
+                            const double *rp = stage + (size_t)g0 * F3_RS_N;
+                            const int *sp = hdrs + F3_NREC + g0;
+                            int cnt = g1 - g0;
+                            auto body = [&](auto tag) {
+                                constexpr int CNT = decltype(tag)::value;
+                                double bq[CNT];
+                                F3Pair tt[CNT];
+                                int sb[CNT];
+#pragma unroll
+                                for (int i = 0; i < CNT; i++) sb[i] = ((const __attribute__((address_space(3))) int *)sp)[i];
+#pragma unroll
+                                for (int i = 0; i < CNT; i++) {
+                                    const unsigned idx = (unsigned)(n_lane - sb[i]);
+                                    F3LdsPairs qa = (F3LdsPairs)(const F3Pair *)(rp + i * F3_RS_N + 4 + 2 * half) + 2 * idx;
+                                    qa = idx < 4u ? qa : (F3LdsPairs)(const F3Pair *)zq;
+                                    bq[i] = ((F3LdsDoubles)rp)[i * F3_RS_N + p_lane];
+                                    tt[i] = *qa;
+                                }
+#pragma unroll
+                                for (int i = 0; i < CNT; i++) { ws[0] = fma(bq[i], tt[i].x, ws[0]); ws[1] = fma(bq[i], tt[i].y, ws[1]); }
+                                rp += CNT * F3_RS_N; sp += CNT; cnt -= CNT;
+                            };
+                            while (cnt >= 4) body(std::integral_constant<int, 4>{});
+                            if (cnt == 3) body(std::integral_constant<int, 3>{});
+                            else if (cnt == 2) body(std::integral_constant<int, 2>{});
+                            else if (cnt == 1) body(std::integral_constant<int, 1>{});
+                        }
+                        wave_sync();
+                    }
                 }
                 flush(false);
                 cur = -1;
             }
             if (UF3_SKIP(16)) continue;
-            // ---- fold: both halves' partial rows -> LDS [half][c][f][32], the block's columns sum their source bins --------
+            // ---- fold: the rows of the window -> LDS [c][f][32]; the block's columns sum their (one or two) source bins --------
             wave_sync();
             constexpr int NC = WANT_E ? 4 : 3;
 #pragma unroll
