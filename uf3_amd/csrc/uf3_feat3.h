@@ -55,10 +55,10 @@ struct Feat3Args {
     int skip;                  // ablations (-DUF3_ABLATE builds only): 1 stage 1, 2 stage 2, 4 centre walk, 8 neighbour walk, 16 fold + stores, 32 bond tables, 64 leg evaluations of the walks
 };
 
-#define F3_NREC 48            // neighbour-role records per engine pass
-#define F3_RS_C 12            // doubles per centre-role record: B_n over the whole n window (ext_n <= 11), zero-padded; one per lane
+#define F3_NREC 32            // neighbour-role records per engine pass (32 x 20 doubles: with the stage at 5 KB per wave four workgroups fit a CU at list capacity 16)
+#define F3_RS_C 10            // doubles per centre-role record: B_n over the whole n window (ext_n <= 11), zero-padded (ext_n <= 9); one per lane
 #define F3_RS_N 20            // ... per neighbour-role record: B(r_ek) x 4 | (a3 B_n', B_n) x 4
-#define F3_STAGE 964          // doubles of per-wave stage: 48 records of 20 (64 of 12; the fold's dump [c][f][32]) + a zero quad
+#define F3_STAGE 644          // doubles of per-wave stage: 48 records of 20 (64 of 12; the fold's dump [c][f][32]) + a zero quad
 
 typedef double __attribute__((ext_vector_type(2))) F3Pair;
 typedef const __attribute__((address_space(3))) F3Pair *F3LdsPairs;
@@ -102,7 +102,7 @@ __device__ __forceinline__ int f3_eval(const double *rows, const Feat3Leg &lg, d
 }
 
 template <bool WANT_E, int EF>
-__global__ void __launch_bounds__(WPB * WAVE, 3)
+__global__ void __launch_bounds__(WPB * WAVE, 4)
 k_featurize3(Feat3Args A) {
     extern __shared__ __align__(16) unsigned char smem[];
     const BasisDev *B = A.B;
@@ -428,25 +428,19 @@ k_featurize3(Feat3Args A) {
             if (UF3_SKIP(16)) continue;
             // ---- fold: the rows of the window -> LDS [c][f][32]; the block's columns sum their (one or two) source bins --------
             wave_sync();
-            constexpr int NC = WANT_E ? 4 : 3;
+            // (pairs: a lane's two rows side by side -- [half][f][32 positions] x (x, y | z, energy))
 #pragma unroll
-            for (int k = 0; k < 2; k++)
-#pragma unroll
-                for (int q = 0; q < EF; q++) stage[((2 * half + k) * EF + q) * 32 + pos] = xacc[q][k];
+            for (int q = 0; q < EF; q++) *(double2 *)(stage + (size_t)(((half * EF + q) * 32 + pos) * 2)) = double2{xacc[q][0], xacc[q][1]};
             wave_sync();
             const unsigned short *ft = fsrc_l + load_const(A.trio_fsrc + t) + (size_t)(tr ? 2 * t_ncol : 0);
             for (int col = lane; col < t_ncol; col += WAVE) {
                 const int s0 = ft[2 * col], s1 = ft[2 * col + 1];
-                double sum[4] = {0, 0, 0, 0};
-#pragma unroll
-                for (int c = 0; c < NC; c++) {
-                    const double *d0 = stage + (size_t)c * EF * 32;
-                    sum[c] = d0[s0] + d0[s1];
-                }
+                F3LdsPairs d0 = (F3LdsPairs)(const F3Pair *)stage, d1 = d0 + EF * 32;
+                const F3Pair a0 = d0[s0], a1 = d0[s1], b0 = d1[s0], b1 = d1[s1];
                 double *dst = A.x_f + (size_t)m * 3 * F + t_col + col;
-                __builtin_nontemporal_store(sum[0], dst); __builtin_nontemporal_store(sum[1], dst + F);
-                __builtin_nontemporal_store(sum[2], dst + 2 * (size_t)F);
-                if (WANT_E) es.add(t_col + col, sum[3]);
+                __builtin_nontemporal_store(a0.x + a1.x, dst); __builtin_nontemporal_store(a0.y + a1.y, dst + F);
+                __builtin_nontemporal_store(b0.x + b1.x, dst + 2 * (size_t)F);
+                if (WANT_E) es.add(t_col + col, b0.y + b1.y);
             }
             wave_sync();
         }

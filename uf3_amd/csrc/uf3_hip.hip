@@ -700,7 +700,7 @@ extern "C" int uf3_basis_create(uf3_ctx *c, const uf3_basis_spec *s, uf3_basis *
         if (ok) {
             const TrioDev &t0 = trios[0];
             ok = t0.lo[0] == t0.lo[1] && t0.ext[0] == t0.ext[1] && same_leg(t0.leg[0], t0.leg[1]) && t0.ext[0] <= 3 &&
-                 t0.ext[0] * t0.ext[2] <= 31 && t0.ext[2] <= 11 && t0.leg[0].nk >= 8 && t0.leg[2].nk >= 8;
+                 t0.ext[0] * t0.ext[2] <= 31 && t0.ext[2] <= 9 && t0.leg[0].nk >= 8 && t0.leg[2].nk >= 8;
             for (int t = 0; t < h.T && ok; t++) {
                 const TrioDev &td = trios[t];
                 for (int a = 0; a < 3; a++) ok = ok && td.lo[a] == t0.lo[a] && td.ext[a] == t0.ext[a];
