@@ -181,13 +181,15 @@ k_featurize3(Feat3Args A) {
         for (int e = lane; e < n_own; e += WAVE) {
             const N3Entry en = A.n3.ent[(size_t)m * cap + e];
             ox[e] = en.dx; oy[e] = en.dy; oz[e] = en.dz; orr[e] = en.r; oir[e] = 1.0 / en.r;
-            oparent[e] = en.parent; oshift[e] = en.shiftc;
+            int s0, s1, s2;
+            unpack3(en.shiftc, s0, s1, s2);
+            oparent[e] = en.parent; oshift[e] = pack3(-s0, -s1, -s2);      // (m's image as the neighbour's list names it)
         }
         if (lane <= S) so[lane] = A.n3.spoff[(size_t)m * (UF3_MAX_SPECIES + 1) + lane];
         wave_sync();
-        for (int q = lane; q < n_own * (S + 1); q += WAVE) {
-            const int e = q / (S + 1), sp = q - e * (S + 1);
-            ospoff[e * (S + 1) + sp] = A.n3.spoff[(size_t)oparent[e] * (UF3_MAX_SPECIES + 1) + sp];
+        for (int e = lane; e < n_own; e += WAVE) {
+            const int *src = A.n3.spoff + (size_t)oparent[e] * (UF3_MAX_SPECIES + 1);
+            for (int sp = 0; sp <= S; sp++) ospoff[e * (S + 1) + sp] = src[sp];
         }
         // ---- T_f of every own bond (zero when the bond is outside the centre legs' range) ------------------------------
         for (int e = lane; e < n_own; e += WAVE) {
@@ -352,9 +354,7 @@ k_featurize3(Feat3Args A) {
                         const int pc = oparent[e];
                         const double oex = ox[e], oey = oy[e], oez = oz[e], oer = orr[e];
                         const N3Entry ke = A.n3.ent[(size_t)pc * cap + kk];
-                        int s0, s1, s2;
-                        unpack3(oshift[e], s0, s1, s2);
-                        valid = !(ke.parent == m && ke.shiftc == pack3(-s0, -s1, -s2));       // k is m itself
+                        valid = !(ke.parent == m && ke.shiftc == oshift[e]);                  // k is m itself
                         const double ex = oex + ke.dx, ey = oey + ke.dy, ez = oez + ke.dz;   // m -> k
                         const double rn = norm3_leg(ex, ey, ez), rk = ke.r;
                         valid = valid & (oer > leg_p.t0) & (oer < leg_p.tlast) & (rk > leg_p.t0) & (rk < leg_p.tlast) &
