@@ -55,10 +55,20 @@ struct Feat3Args {
     int skip;                  // ablations (-DUF3_ABLATE builds only): 1 stage 1, 2 stage 2, 4 centre walk, 8 neighbour walk, 16 fold + stores, 32 bond tables, 64 leg evaluations of the walks
 };
 
-#define F3_NREC 32            // neighbour-role records per engine pass (32 x 20 doubles: with the stage at 5 KB per wave four workgroups fit a CU at list capacity 16)
-#define F3_RS_C 10            // doubles per centre-role record: B_n over the whole n window (ext_n <= 11), zero-padded (ext_n <= 9); one per lane
-#define F3_RS_N 20            // ... per neighbour-role record: B(r_ek) x 4 | (a3 B_n', B_n) x 4
-#define F3_STAGE 644          // doubles of per-wave stage: 48 records of 20 (64 of 12; the fold's dump [c][f][32]) + a zero quad
+// Compile-time shape of a launch: EF = rows of the window on the fixed leg (= ext of the centre legs), NR = rounds of 32 W
+// positions per half-wave (ext_p * ext_n <= 32 NR - 1: one position stays free as the fold's zero), the strides that follow.
+template <int EF, int NR>
+struct F3Cfg {
+    static constexpr int PS = 32 * NR;                           // positions per fixed-leg row in the fold's dump
+    static constexpr int EFP = (EF + 1) & ~1;                    // dense bond values of a neighbour-role record, padded
+    static constexpr int RS_N = EFP + 16;                        // doubles per neighbour-role record: B(r_ek)[ext_p] | (a3 B_n', B_n) x 4
+    static constexpr int RS_C = NR == 1 ? 10 : (NR == 2 ? 12 : 14);   // ... per centre-role record: B_n over the n window (ext_n < RS_C), zero-padded
+    static constexpr int NREC = 32;                              // neighbour-role records per engine pass
+    static constexpr int DUMP = NR == 1 ? 4 * EF * 32 : EF * PS + 2;   // the fold's dump: pairs of all four rows | one component at a time
+    static constexpr int STAGE0 = 64 * RS_C > NREC * RS_N ? 64 * RS_C : NREC * RS_N;
+    static constexpr int STAGE = (STAGE0 > DUMP ? STAGE0 : DUMP) + 4;  // + a quad of zeros
+    static constexpr int MIN_WAVES = NR == 1 ? 4 : 2;            // waves per SIMD the registers are bounded for
+};
 
 typedef double __attribute__((ext_vector_type(2))) F3Pair;
 typedef const __attribute__((address_space(3))) F3Pair *F3LdsPairs;
@@ -101,31 +111,32 @@ __device__ __forceinline__ int f3_eval(const double *rows, const Feat3Leg &lg, d
     return iv;
 }
 
-template <bool WANT_E, int EF>
-__global__ void __launch_bounds__(WPB * WAVE, 4)
+template <bool WANT_E, int EF, int NR>
+__global__ void __launch_bounds__(WPB * WAVE, (NR == 1 ? 4 : 2))
 k_featurize3(Feat3Args A) {
+    typedef F3Cfg<EF, NR> Cfg;
+    constexpr int RS_C = Cfg::RS_C, RS_N = Cfg::RS_N, NREC = Cfg::NREC, PS = Cfg::PS, EFP = Cfg::EFP;
     extern __shared__ __align__(16) unsigned char smem[];
     const BasisDev *B = A.B;
     const int F = load_const(&B->F), S = load_const(&B->S), n_trios = load_const(&B->T), cap = A.n3.cap;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // ---- LDS carve (the same sums in uf3_featurize_dev) -----------------------------------------------------------------
+    // ---- LDS carve (feat3_lds_bytes on the host) ----------------------------------------------------------------------
     double *erow = (double *)smem;
     const bool e_lds = WANT_E && !A.e_direct;
     const size_t e_d = e_lds ? (size_t)F + (F & 1) : 0;
     double *rows = erow + e_d;                                        // window rows, shared
     const size_t rows_d = (size_t)A.n_rows * 18;
     const size_t list_d = 5 * (size_t)cap + ((5 * cap) & 1), tq_d = (size_t)cap * EF * 4;
-    constexpr size_t stage_d = F3_STAGE;
-    static_assert(4 * EF * 32 <= F3_STAGE - 4 && 64 * F3_RS_C <= F3_STAGE - 4 && F3_NREC * F3_RS_N <= F3_STAGE - 4, "stage too small");
+    constexpr size_t stage_d = Cfg::STAGE;
     const size_t per_wave_d = list_d + tq_d + stage_d;
-    const size_t per_wave_i = 2 * (size_t)cap + 2 * ((size_t)cap + 1) + (UF3_MAX_SPECIES + 2) + (size_t)cap * (S + 1) + 2 * F3_NREC;
+    const size_t per_wave_i = 2 * (size_t)cap + 2 * ((size_t)cap + 1) + (UF3_MAX_SPECIES + 2) + (size_t)cap * (S + 1) + 2 * NREC;
     double *wd = rows + rows_d + (size_t)wave * per_wave_d;
     int *wi = (int *)(rows + rows_d + (size_t)WPB * per_wave_d) + (size_t)wave * per_wave_i;
     double *ox = wd, *oy = ox + cap, *oz = oy + cap, *orr = oz + cap, *oir = orr + cap;
     double *tq = wd + list_d;                                         // [cap][EF][4]: T_f = (Tx Ty Tz T3) of every own bond
     double *stage = tq + tq_d;
-    double *zq = stage + (F3_STAGE - 4);                              // a quad of zeros
+    double *zq = stage + (Cfg::STAGE - 4);                            // a quad of zeros
     int *oparent = wi, *oshift = wi + cap, *noff = wi + 2 * cap, *nbase = noff + cap + 1, *so = nbase + cap + 1;
     int *ospoff = so + (UF3_MAX_SPECIES + 2);
     int *hdrs = ospoff + (size_t)cap * (S + 1);                       // [NREC + NREC] key | first n slot of the records of a pass
@@ -139,15 +150,20 @@ k_featurize3(Feat3Args A) {
     for (int q = lane; q < (int)tq_d; q += WAVE) tq[q] = 0.0;
     __syncthreads();
 
-    // ---- per-lane constants of the W window: lanes 0-31 hold the sums (x, y) of a position, lanes 32-63 (z, plain) ----------
-    const int ext_p = A.ext_p, ext_n = A.ext_n, lo_n = A.lo_n, npos = ext_p * ext_n;
-    const int half = lane >> 5, pos = lane & 31;
-    const int p_lane = pos < npos ? pos / ext_n : 0;
-    const int n_lane = pos < npos ? pos - p_lane * ext_n : -(1 << 20);     // (idle lanes always read zeros)
-    const int sbn_max = ext_n > 4 ? ext_n - 4 : 0;
-    const int qn_lane = pos < npos ? n_lane : F3_RS_C - 1;            // (... a centre-role record's zero padding)
+    // ---- per-lane constants of the W window: lanes 0-31 hold the sums (x, y) of a position, lanes 32-63 (z, plain); a lane
+    // serves NR positions, 32 apart --------------------------------------------------------------------------------------
+    const int ext_p = A.ext_p, ext_n = A.ext_n, lo_n = A.lo_n, lo_p = A.lo_p, npos = ext_p * ext_n;
+    const int half = lane >> 5;
+    int p_lane[NR], n_lane[NR], qn_lane[NR];
+#pragma unroll
+    for (int r = 0; r < NR; r++) {
+        const int pos = r * 32 + (lane & 31);
+        p_lane[r] = pos < npos ? pos / ext_n : 0;
+        n_lane[r] = pos < npos ? pos - p_lane[r] * ext_n : -(1 << 20);      // (idle positions always read zeros)
+        qn_lane[r] = pos < npos ? n_lane[r] : RS_C - 1;                    // (... a centre-role record's zero padding)
+    }
+    const int sbn_max = ext_n > 4 ? ext_n - 4 : 0, sbp_max = ext_p > 4 ? ext_p - 4 : 0;
     const Feat3Leg leg_p = A.leg_p, leg_n = A.leg_n;
-    const double *tq_lane = tq + (size_t)p_lane * 4 + 2 * half;       // a lane's pair of bond 0's T rows
 
     const int bid = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
     const int block_first = bid * A.atoms_per_block;
@@ -191,17 +207,27 @@ k_featurize3(Feat3Args A) {
             const int *src = A.n3.spoff + (size_t)oparent[e] * (UF3_MAX_SPECIES + 1);
             for (int sp = 0; sp <= S; sp++) ospoff[e * (S + 1) + sp] = src[sp];
         }
-        // ---- T_f of every own bond (zero when the bond is outside the centre legs' range) ------------------------------
+        // ---- T_f of every own bond: rows over the whole window of the centre legs, zero where the bond's four functions are
+        // not (and all zero when the bond is outside the legs' range) -------------------------------------------------------
         for (int e = lane; e < n_own; e += WAVE) {
             const double r = orr[e];
             double v[4] = {0, 0, 0, 0}, d[4] = {0, 0, 0, 0};
-            if (r > leg_p.t0 && r < leg_p.tlast && !UF3_SKIP(32)) f3_eval<true>(rows, leg_p, r, v, d);
+            int sbp = 0;
+            if (r > leg_p.t0 && r < leg_p.tlast && !UF3_SKIP(32)) {
+                const int iv = f3_eval<true>(rows, leg_p, r, v, d);
+                sbp = max(0, min(sbp_max, iv - 3 - lo_p));
+            }
             const double ir = oir[e], ux = ox[e] * ir, uy = oy[e] * ir, uz = oz[e] * ir;
+            double *dst = tq + (size_t)e * EF * 4;
+            if (EF > 4) {
 #pragma unroll
-            for (int q = 0; q < EF; q++) {
-                double *dst = tq + ((size_t)e * EF + q) * 4;
-                *(double2 *)dst = double2{ux * d[q], uy * d[q]};
-                *(double2 *)(dst + 2) = double2{uz * d[q], v[q]};
+                for (int q = 0; q < EF; q++) { *(double2 *)(dst + 4 * q) = double2{0.0, 0.0}; *(double2 *)(dst + 4 * q + 2) = double2{0.0, 0.0}; }
+                dst += 4 * sbp;
+            }
+#pragma unroll
+            for (int q = 0; q < (EF < 4 ? EF : 4); q++) {
+                *(double2 *)(dst + 4 * q) = double2{ux * d[q], uy * d[q]};
+                *(double2 *)(dst + 4 * q + 2) = double2{uz * d[q], v[q]};
             }
         }
         wave_sync();
@@ -215,9 +241,13 @@ k_featurize3(Feat3Args A) {
             if (!centre && !nbr) { zero_rows(A.x_f, m, F, t_col, t_ncol); continue; }
             const bool tr = t_sa != t_sb && sm == t_sb;              // transposed: the fixed bond sits on leg m
 
-            double xacc[EF][2], ws[2] = {0, 0};
+            double xacc[NR][EF][2], ws[NR][2];
 #pragma unroll
-            for (int q = 0; q < EF; q++) { xacc[q][0] = xacc[q][1] = 0.0; }
+            for (int r = 0; r < NR; r++) {
+                ws[r][0] = ws[r][1] = 0.0;
+#pragma unroll
+                for (int q = 0; q < EF; q++) { xacc[r][q][0] = xacc[r][q][1] = 0.0; }
+            }
             int cur = -1;                                           // the bond whose W is being summed (own-list index)
 
             // stage 2: the open bond's W into the rows of the window.  Lower half: rows (x, y) += (Tx, Ty) W_plain + T3 (W_x, W_y);
@@ -229,17 +259,20 @@ k_featurize3(Feat3Args A) {
                 double t3[EF];
 #pragma unroll
                 for (int q = 0; q < EF; q++) { tv[q] = *(F3LdsPairs)(const F3Pair *)(tc + 4 * q + 2 * half); t3[q] = ((F3LdsDoubles)tc)[4 * q + 3]; }
-                const int lo = __double2loint(ws[1]), hi = __double2hiint(ws[1]);
-                const auto r0 = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
-                const auto r1 = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
-                const double wpl = __hiloint2double(r1[1], r0[1]);            // W_plain (the upper half's second sum) in every lane
-                const double wpl1 = (half && !is_c) ? 0.0 : wpl, ws1 = half ? 0.0 : ws[1];
 #pragma unroll
-                for (int q = 0; q < EF; q++) {
-                    xacc[q][0] = fma(tv[q].x, wpl, fma(t3[q], ws[0], xacc[q][0]));
-                    xacc[q][1] = fma(tv[q].y, wpl1, fma(t3[q], ws1, xacc[q][1]));
+                for (int r = 0; r < NR; r++) {
+                    const int lo = __double2loint(ws[r][1]), hi = __double2hiint(ws[r][1]);
+                    const auto r0 = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+                    const auto r1 = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+                    const double wpl = __hiloint2double(r1[1], r0[1]);        // W_plain (the upper half's second sum) in every lane
+                    const double wpl1 = (half && !is_c) ? 0.0 : wpl, ws1 = half ? 0.0 : ws[r][1];
+#pragma unroll
+                    for (int q = 0; q < EF; q++) {
+                        xacc[r][q][0] = fma(tv[q].x, wpl, fma(t3[q], ws[r][0], xacc[r][q][0]));
+                        xacc[r][q][1] = fma(tv[q].y, wpl1, fma(t3[q], ws1, xacc[r][q][1]));
+                    }
+                    ws[r][0] = ws[r][1] = 0.0;
                 }
-                ws[0] = ws[1] = 0.0;
             };
 
             // ---- centre role: m centres (f, g), f on the fixed leg.  Items p = fi * nG + gi, one per lane and stage slot (not
@@ -276,9 +309,9 @@ k_featurize3(Feat3Args A) {
                         }
                     }
                     {
-                        double *rp = stage + (size_t)lane * F3_RS_C;
+                        double *rp = stage + (size_t)lane * RS_C;
 #pragma unroll
-                        for (int u = 0; u < F3_RS_C; u += 2) *(double2 *)(rp + u) = double2{0.0, 0.0};
+                        for (int u = 0; u < RS_C; u += 2) *(double2 *)(rp + u) = double2{0.0, 0.0};
                         if (valid) {
 #pragma unroll
                             for (int u = 0; u < 4; u++) rp[sbn + u] = bn[u];
@@ -294,21 +327,24 @@ k_featurize3(Feat3Args A) {
                         if (s0 >= s1) continue;
                         const int key = f_los + fi_s;
                         if (key != cur) { flush(true); cur = key; }
-                        const double *qp = stage + (size_t)(s0 - p0) * F3_RS_C + qn_lane;
-                        const double *tp = tq_lane + (size_t)(g_los + (s0 - pr)) * EF * 4;
+                        const double *qp = stage + (size_t)(s0 - p0) * RS_C;
+                        const double *tp = tq + (size_t)(g_los + (s0 - pr)) * EF * 4 + 2 * half;
                         int cnt = s1 - s0;
                         auto body = [&](auto tag) {
                             constexpr int CNT = decltype(tag)::value;
-                            double bq[CNT];
-                            F3Pair tt[CNT];
 #pragma unroll
-                            for (int i = 0; i < CNT; i++) {
-                                bq[i] = ((F3LdsDoubles)qp)[i * F3_RS_C];
-                                tt[i] = *(F3LdsPairs)(const F3Pair *)(tp + (size_t)i * EF * 4);
+                            for (int r = 0; r < NR; r++) {
+                                double bq[CNT];
+                                F3Pair tt[CNT];
+#pragma unroll
+                                for (int i = 0; i < CNT; i++) {
+                                    bq[i] = ((F3LdsDoubles)qp)[i * RS_C + qn_lane[r]];
+                                    tt[i] = *(F3LdsPairs)(const F3Pair *)(tp + (size_t)i * EF * 4 + 4 * p_lane[r]);
+                                }
+#pragma unroll
+                                for (int i = 0; i < CNT; i++) { ws[r][0] = fma(tt[i].x, bq[i], ws[r][0]); ws[r][1] = fma(tt[i].y, bq[i], ws[r][1]); }
                             }
-#pragma unroll
-                            for (int i = 0; i < CNT; i++) { ws[0] = fma(tt[i].x, bq[i], ws[0]); ws[1] = fma(tt[i].y, bq[i], ws[1]); }
-                            qp += CNT * F3_RS_C; tp += (size_t)CNT * EF * 4; cnt -= CNT;
+                            qp += CNT * RS_C; tp += (size_t)CNT * EF * 4; cnt -= CNT;
                         };
                         while (cnt >= 4) body(std::integral_constant<int, 4>{});
                         if (cnt == 3) body(std::integral_constant<int, 3>{});
@@ -345,7 +381,7 @@ k_featurize3(Feat3Args A) {
                     const int q = p0 + lane;
                     bool valid = q < total_n;
                     double pv[4] = {0, 0, 0, 0}, bn[4] = {0, 0, 0, 0}, bd[4] = {0, 0, 0, 0}, a3[3] = {0, 0, 0}, dum[4];
-                    int sbn = 0, e = 0;
+                    int sbn = 0, sbp = 0, e = 0;
                     if (valid) {
                         int lo = 0, hi = ncen - 1;
                         while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (noff[mid] <= q) lo = mid; else hi = mid - 1; }
@@ -362,29 +398,37 @@ k_featurize3(Feat3Args A) {
                         if (valid && !UF3_SKIP(64)) {
                             const double in = fast_rcp(rn);
                             a3[0] = ex * in; a3[1] = ey * in; a3[2] = ez * in;
-                            f3_eval<false>(rows, leg_p, rk, pv, dum);
+                            const int ivp = f3_eval<false>(rows, leg_p, rk, pv, dum);
+                            sbp = max(0, min(sbp_max, ivp - 3 - lo_p));
                             const int iv = f3_eval<true>(rows, leg_n, rn, bn, bd);
                             sbn = max(0, min(sbn_max, iv - 3 - lo_n));
                         }
                     }
                     const unsigned long long mask = __ballot(valid);
                     const int nv = __popcll(mask), rank = mbcnt(mask);
-                    for (int sp0 = 0; sp0 < nv; sp0 += F3_NREC) {
+                    for (int sp0 = 0; sp0 < nv; sp0 += NREC) {
                         const int slot = rank - sp0;
-                        if (valid && slot >= 0 && slot < F3_NREC) {
-                            double *rp = stage + (size_t)slot * F3_RS_N;
-                            *(double2 *)rp = double2{pv[0], pv[1]};
-                            *(double2 *)(rp + 2) = double2{pv[2], pv[3]};
+                        if (valid && slot >= 0 && slot < NREC) {
+                            double *rp = stage + (size_t)slot * RS_N;
+                            if (EF > 4) {
+#pragma unroll
+                                for (int u = 0; u < EFP; u += 2) *(double2 *)(rp + u) = double2{0.0, 0.0};
+#pragma unroll
+                                for (int u = 0; u < 4; u++) rp[sbp + u] = pv[u];
+                            } else {
+                                *(double2 *)rp = double2{pv[0], pv[1]};
+                                *(double2 *)(rp + 2) = double2{pv[2], pv[3]};
+                            }
 #pragma unroll
                             for (int u = 0; u < 4; u++) {
-                                *(double2 *)(rp + 4 + 4 * u) = double2{a3[0] * bd[u], a3[1] * bd[u]};
-                                *(double2 *)(rp + 6 + 4 * u) = double2{a3[2] * bd[u], bn[u]};
+                                *(double2 *)(rp + EFP + 4 * u) = double2{a3[0] * bd[u], a3[1] * bd[u]};
+                                *(double2 *)(rp + EFP + 2 + 4 * u) = double2{a3[2] * bd[u], bn[u]};
                             }
-                            hdrs[slot] = e; hdrs[F3_NREC + slot] = sbn;
+                            hdrs[slot] = e; hdrs[NREC + slot] = sbn;
                         }
                         wave_sync();
-                        const int r_end = min(F3_NREC, nv - sp0);
-                        const int v_key = hdrs[min(lane, F3_NREC - 1)], v_prev = hdrs[min(max(lane - 1, 0), F3_NREC - 1)];
+                        const int r_end = min(NREC, nv - sp0);
+                        const int v_key = hdrs[min(lane, NREC - 1)], v_prev = hdrs[min(max(lane - 1, 0), NREC - 1)];
                         unsigned long long gm = __ballot(lane < r_end && (lane == 0 || v_key != v_prev));
                         while (gm && !UF3_SKIP(1)) {
                             const int g0 = __builtin_ctzll(gm);
@@ -392,27 +436,30 @@ k_featurize3(Feat3Args A) {
                             const int g1 = gm ? __builtin_ctzll(gm) : r_end;
                             const int key = __builtin_amdgcn_readlane(v_key, g0);
                             if (key != cur) { flush(false); cur = key; }
-                            const double *rp = stage + (size_t)g0 * F3_RS_N;
-                            const int *sp = hdrs + F3_NREC + g0;
+                            const double *rp = stage + (size_t)g0 * RS_N;
+                            const int *sp = hdrs + NREC + g0;
                             int cnt = g1 - g0;
                             auto body = [&](auto tag) {
                                 constexpr int CNT = decltype(tag)::value;
-                                double bq[CNT];
-                                F3Pair tt[CNT];
                                 int sb[CNT];
 #pragma unroll
                                 for (int i = 0; i < CNT; i++) sb[i] = ((const __attribute__((address_space(3))) int *)sp)[i];
 #pragma unroll
-                                for (int i = 0; i < CNT; i++) {
-                                    const unsigned idx = (unsigned)(n_lane - sb[i]);
-                                    F3LdsPairs qa = (F3LdsPairs)(const F3Pair *)(rp + i * F3_RS_N + 4 + 2 * half) + 2 * idx;
-                                    qa = idx < 4u ? qa : (F3LdsPairs)(const F3Pair *)zq;
-                                    bq[i] = ((F3LdsDoubles)rp)[i * F3_RS_N + p_lane];
-                                    tt[i] = *qa;
-                                }
+                                for (int r = 0; r < NR; r++) {
+                                    double bq[CNT];
+                                    F3Pair tt[CNT];
 #pragma unroll
-                                for (int i = 0; i < CNT; i++) { ws[0] = fma(bq[i], tt[i].x, ws[0]); ws[1] = fma(bq[i], tt[i].y, ws[1]); }
-                                rp += CNT * F3_RS_N; sp += CNT; cnt -= CNT;
+                                    for (int i = 0; i < CNT; i++) {
+                                        const unsigned idx = (unsigned)(n_lane[r] - sb[i]);
+                                        F3LdsPairs qa = (F3LdsPairs)(const F3Pair *)(rp + i * RS_N + EFP + 2 * half) + 2 * idx;
+                                        qa = idx < 4u ? qa : (F3LdsPairs)(const F3Pair *)zq;
+                                        bq[i] = ((F3LdsDoubles)rp)[i * RS_N + p_lane[r]];
+                                        tt[i] = *qa;
+                                    }
+#pragma unroll
+                                    for (int i = 0; i < CNT; i++) { ws[r][0] = fma(bq[i], tt[i].x, ws[r][0]); ws[r][1] = fma(bq[i], tt[i].y, ws[r][1]); }
+                                }
+                                rp += CNT * RS_N; sp += CNT; cnt -= CNT;
                             };
                             while (cnt >= 4) body(std::integral_constant<int, 4>{});
                             if (cnt == 3) body(std::integral_constant<int, 3>{});
@@ -426,23 +473,48 @@ k_featurize3(Feat3Args A) {
                 cur = -1;
             }
             if (UF3_SKIP(16)) continue;
-            // ---- fold: the rows of the window -> LDS [c][f][32]; the block's columns sum their (one or two) source bins --------
-            wave_sync();
-            // (pairs: a lane's two rows side by side -- [half][f][32 positions] x (x, y | z, energy))
-#pragma unroll
-            for (int q = 0; q < EF; q++) *(double2 *)(stage + (size_t)(((half * EF + q) * 32 + pos) * 2)) = double2{xacc[q][0], xacc[q][1]};
+            // ---- fold: the rows of the window -> LDS, the block's columns sum their (one or two) source bins -----------------
             wave_sync();
             const unsigned short *ft = fsrc_l + load_const(A.trio_fsrc + t) + (size_t)(tr ? 2 * t_ncol : 0);
-            for (int col = lane; col < t_ncol; col += WAVE) {
-                const int s0 = ft[2 * col], s1 = ft[2 * col + 1];
-                F3LdsPairs d0 = (F3LdsPairs)(const F3Pair *)stage, d1 = d0 + EF * 32;
-                const F3Pair a0 = d0[s0], a1 = d0[s1], b0 = d1[s0], b1 = d1[s1];
-                double *dst = A.x_f + (size_t)m * 3 * F + t_col + col;
-                __builtin_nontemporal_store(a0.x + a1.x, dst); __builtin_nontemporal_store(a0.y + a1.y, dst + F);
-                __builtin_nontemporal_store(b0.x + b1.x, dst + 2 * (size_t)F);
-                if (WANT_E) es.add(t_col + col, b0.y + b1.y);
+            if (NR == 1) {
+                // (pairs: a lane's two rows side by side -- [half][f][32 positions] x (x, y | z, energy))
+#pragma unroll
+                for (int q = 0; q < EF; q++)
+                    *(double2 *)(stage + (size_t)(((half * EF + q) * 32 + (lane & 31)) * 2)) = double2{xacc[0][q][0], xacc[0][q][1]};
+                wave_sync();
+                for (int col = lane; col < t_ncol; col += WAVE) {
+                    const int s0 = ft[2 * col], s1 = ft[2 * col + 1];
+                    F3LdsPairs d0 = (F3LdsPairs)(const F3Pair *)stage, d1 = d0 + EF * 32;
+                    const F3Pair a0 = d0[s0], a1 = d0[s1], b0 = d1[s0], b1 = d1[s1];
+                    double *dst = A.x_f + (size_t)m * 3 * F + t_col + col;
+                    __builtin_nontemporal_store(a0.x + a1.x, dst); __builtin_nontemporal_store(a0.y + a1.y, dst + F);
+                    __builtin_nontemporal_store(b0.x + b1.x, dst + 2 * (size_t)F);
+                    if (WANT_E) es.add(t_col + col, b0.y + b1.y);
+                }
+                wave_sync();
+            } else {
+                // one component at a time: [f][32 NR positions] of doubles (+ a zero behind them for the second source a column
+                // may not have)
+                constexpr int NC = WANT_E ? 4 : 3;
+#pragma unroll
+                for (int c = 0; c < NC; c++) {
+                    if (half == (c >> 1)) {
+#pragma unroll
+                        for (int r = 0; r < NR; r++)
+#pragma unroll
+                            for (int q = 0; q < EF; q++) stage[q * PS + r * 32 + (lane & 31)] = xacc[r][q][c & 1];
+                    }
+                    if (lane == 0) stage[EF * PS] = 0.0;
+                    wave_sync();
+                    for (int col = lane; col < t_ncol; col += WAVE) {
+                        const int s0 = ft[2 * col], s1 = ft[2 * col + 1];
+                        const double v = ((F3LdsDoubles)stage)[s0] + ((F3LdsDoubles)stage)[s1];
+                        if (c < 3) __builtin_nontemporal_store(v, A.x_f + ((size_t)m * 3 + c) * F + t_col + col);
+                        else es.add(t_col + col, v);
+                    }
+                    wave_sync();
+                }
             }
-            wave_sync();
         }
     }
     if (e_lds) {

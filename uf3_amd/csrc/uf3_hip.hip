@@ -135,6 +135,7 @@ struct uf3_basis {
     int *d_f3off = nullptr;          // [T] a trio's table
     Feat3Leg f3_leg_p, f3_leg_n;
     int f3_lo_p = 0, f3_ext_p = 0, f3_lo_n = 0, f3_ext_n = 0;
+    int f3_nr = 0;                   // rounds of 32 window positions of the launch that serves the window (1: default trims; 2, 3: wider)
 };
 
 static thread_local std::string g_err;
@@ -699,8 +700,13 @@ extern "C" int uf3_basis_create(uf3_ctx *c, const uf3_basis_spec *s, uf3_basis *
         };
         if (ok) {
             const TrioDev &t0 = trios[0];
-            ok = t0.lo[0] == t0.lo[1] && t0.ext[0] == t0.ext[1] && same_leg(t0.leg[0], t0.leg[1]) && t0.ext[0] <= 3 &&
-                 t0.ext[0] * t0.ext[2] <= 31 && t0.ext[2] <= 9 && t0.leg[0].nk >= 8 && t0.leg[2].nk >= 8;
+            // the instantiated shapes (rows of the centre-leg window, rounds of 32 positions): (3, 1) (4, 2) (5, 3) (6, 3)
+            const int ep = t0.ext[0], en = t0.ext[2], np = ep * en;
+            b->f3_nr = ep == 3 ? 1 : (ep == 4 ? 2 : 3);
+            const bool shape = (ep == 3 && np <= 31 && en <= 9) || (ep == 4 && np <= 64 && en <= 11) ||
+                               ((ep == 5 || ep == 6) && np <= 96 && en <= 13);
+            ok = t0.lo[0] == t0.lo[1] && t0.ext[0] == t0.ext[1] && same_leg(t0.leg[0], t0.leg[1]) && shape &&
+                 t0.leg[0].nk >= 8 && t0.leg[2].nk >= 8 && !(ep > 3 && getenv("UF3_NO_FEAT3_WIDE"));
             for (int t = 0; t < h.T && ok; t++) {
                 const TrioDev &td = trios[t];
                 for (int a = 0; a < 3; a++) ok = ok && td.lo[a] == t0.lo[a] && td.ext[a] == t0.ext[a];
@@ -751,10 +757,13 @@ extern "C" int uf3_basis_create(uf3_ctx *c, const uf3_basis_spec *s, uf3_basis *
                     for (int col = 0; col < td.ncol; col++)
                         for (int q = 0; q < 2; q++) {
                             const int sp = q < td.nsrc ? colsrc[td.src_off + col * td.nsrc + q] : -1;
-                            unsigned short e = 31;
+                            // (a column's missing second source: position 31 of row 0 -- never a window position in the
+                            // one-round launch --, or the zero behind the dumped rows)
+                            const int ps = 32 * b->f3_nr;
+                            unsigned short e = (unsigned short)(b->f3_nr == 1 ? 31 : td.ext[0] * ps);
                             if (sp >= 0) {
                                 const int l = (sp & 255) - td.lo[0], m = ((sp >> 8) & 255) - td.lo[1], n = ((sp >> 16) & 255) - td.lo[2];
-                                e = (unsigned short)((o == 0 ? l : m) * 32 + (o == 0 ? m : l) * td.ext[2] + n);
+                                e = (unsigned short)((o == 0 ? l : m) * ps + (o == 0 ? m : l) * td.ext[2] + n);
                             }
                             mine.push_back(e);
                         }
@@ -1420,9 +1429,17 @@ extern "C" int uf3_featurize_dev(uf3_basis *b, const uf3_frames *fr, const doubl
                 G.x_e = d_xe; G.x_f = d_xf; G.natoms = P.natoms; G.e_direct = A.e_direct; G.skip = A.skip;
                 const int S = b->host.S;
                 const bool e_lds = want_e && !A.e_direct;
+                const int ep = b->f3_ext_p, nr = b->f3_nr;
+                int stage = 0, nrec = 0;
+                switch (ep) {
+                    case 3: stage = F3Cfg<3, 1>::STAGE; nrec = F3Cfg<3, 1>::NREC; break;
+                    case 4: stage = F3Cfg<4, 2>::STAGE; nrec = F3Cfg<4, 2>::NREC; break;
+                    case 5: stage = F3Cfg<5, 3>::STAGE; nrec = F3Cfg<5, 3>::NREC; break;
+                    default: stage = F3Cfg<6, 3>::STAGE; nrec = F3Cfg<6, 3>::NREC; break;
+                }
                 const size_t e_d = e_lds ? (size_t)F + (F & 1) : 0, rows_d = (size_t)b->n_f3rows * 18;
-                const size_t list_d = 5 * (size_t)cap + ((5 * cap) & 1), tq_d = (size_t)cap * 3 * 4, stage_d = F3_STAGE;
-                const size_t per_wave_i = 2 * (size_t)cap + 2 * ((size_t)cap + 1) + (UF3_MAX_SPECIES + 2) + (size_t)cap * (S + 1) + 2 * F3_NREC;
+                const size_t list_d = 5 * (size_t)cap + ((5 * cap) & 1), tq_d = (size_t)cap * ep * 4, stage_d = (size_t)stage;
+                const size_t per_wave_i = 2 * (size_t)cap + 2 * ((size_t)cap + 1) + (UF3_MAX_SPECIES + 2) + (size_t)cap * (S + 1) + 2 * (size_t)nrec;
                 const size_t ints = ((size_t)WPB * per_wave_i + 3) & ~(size_t)3;
                 const size_t lds = (e_d + rows_d + WPB * (list_d + tq_d + stage_d)) * 8 + ints * 4 + (size_t)b->n_f3src * 2 + 32;
                 if (lds > 160 * 1024 - 512) return fail(c, UF3_EOVERFLOW, "featurizer LDS footprint exceeds 160 KB (F or neighbour count too large)");
@@ -1432,15 +1449,21 @@ extern "C" int uf3_featurize_dev(uf3_basis *b, const uf3_frames *fr, const doubl
                 n_blocks = (P.natoms + apb - 1) / apb;
                 G.atoms_per_block = apb;
                 if (getenv("UF3_DEBUG_LDS"))
-                    fprintf(stderr, "uf3 featurize3: lds %zu B, cap %d, blocks %d x %d atoms, window %d x %d\n", lds, cap, n_blocks, apb, G.ext_p, G.ext_n);
+                    fprintf(stderr, "uf3 featurize3: lds %zu B, cap %d, blocks %d x %d atoms, window %d x %d, %d round(s)\n", lds, cap, n_blocks, apb,
+                            G.ext_p, G.ext_n, nr);
                 const unsigned grid = (unsigned)((n_blocks + 7) / 8 * 8);
-                if (want_e) {
-                    HIPCHK(c, hipFuncSetAttribute((const void *)k_featurize3<true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                    hipLaunchKernelGGL((k_featurize3<true, 3>), dim3(grid), dim3(WPB * WAVE), lds, st, G);
-                } else {
-                    HIPCHK(c, hipFuncSetAttribute((const void *)k_featurize3<false, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                    hipLaunchKernelGGL((k_featurize3<false, 3>), dim3(grid), dim3(WPB * WAVE), lds, st, G);
+#define UF3_F3_LAUNCH(E, EFv, NRv)                                                                                          \
+    do {                                                                                                                   \
+        HIPCHK(c, hipFuncSetAttribute((const void *)k_featurize3<E, EFv, NRv>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL((k_featurize3<E, EFv, NRv>), dim3(grid), dim3(WPB * WAVE), lds, st, G);                          \
+    } while (0)
+                switch (ep) {
+                    case 3: if (want_e) UF3_F3_LAUNCH(true, 3, 1); else UF3_F3_LAUNCH(false, 3, 1); break;
+                    case 4: if (want_e) UF3_F3_LAUNCH(true, 4, 2); else UF3_F3_LAUNCH(false, 4, 2); break;
+                    case 5: if (want_e) UF3_F3_LAUNCH(true, 5, 3); else UF3_F3_LAUNCH(false, 5, 3); break;
+                    default: if (want_e) UF3_F3_LAUNCH(true, 6, 3); else UF3_F3_LAUNCH(false, 6, 3); break;
                 }
+#undef UF3_F3_LAUNCH
             }
         }
         HIPCHK(c, hipGetLastError());
