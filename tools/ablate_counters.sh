@@ -10,7 +10,7 @@ mkdir -p "$RUN"; export TMPDIR=/tmp UF3_BENCH_NOCHECK=1 UF3_LIB_PATH=$PWD/exp/li
 [ -f "$UF3_LIB_PATH" ] || { echo "build exp/libuf3hip_ablate.so first (see the header of this script)"; exit 1; }
 for s in $SKIPS; do
   UF3_DEBUG_SKIP=$s timeout 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_MFMA SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAVE_CYCLES SQ_WAIT_INST_ANY \
-    -d $RUN/s$s -o p --output-format csv -- python bench.py --no-cpu-baseline --no-extra --no-traffic --steps 2 --warmup 1 --frames-per-step 32 > $RUN/s$s.json 2>/dev/null
+    -d $RUN/s$s -o p --output-format csv -- python bench.py --no-cpu-baseline --no-extra --no-traffic --steps 2 --warmup 1 --frames-per-step ${UF3_ABL_FRAMES:-32} ${UF3_ABL_ARGS:-} > $RUN/s$s.json 2>/dev/null
 done
 python - "$RUN" $SKIPS <<'PY'
 import csv, glob, sys, collections
@@ -24,6 +24,6 @@ for s in skips:
             acc[r["Counter_Name"]] += float(r["Counter_Value"]); n[r["Counter_Name"]] += 1
     if not acc: print(s, "no data"); continue
     launches = max(n.values())
-    per_atom = {k: v / launches / 320000 for k, v in acc.items()}
+    per_atom = {k: v / launches / float(__import__("os").environ.get("UF3_ABL_ATOMS", "320000")) for k, v in acc.items()}
     print(f"skip {s:>3}: " + "  ".join(f"{k[3:]} {per_atom[k]:.0f}" for k in sorted(per_atom)))
 PY

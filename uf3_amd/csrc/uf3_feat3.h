@@ -45,6 +45,7 @@ struct Feat3Args {
     int n_fsrc;
     Feat3Leg leg_p, leg_n;     // the centre legs (l and m share knots and window), leg n
     int lo_p, ext_p, lo_n, ext_n;
+    int pr_rows;               // window rows (of the summed leg) per round of 32 positions: 32 / ext_n, at most ext_p
     const FrameGeom *geoms;
     const int *frame_of;
     N3Lists n3;
@@ -64,7 +65,7 @@ struct F3Cfg {
     static constexpr int RS_N = EFP + 16;                        // doubles per neighbour-role record: B(r_ek)[ext_p] | (a3 B_n', B_n) x 4
     static constexpr int RS_C = NR == 1 ? 10 : (NR == 2 ? 12 : 14);   // ... per centre-role record: B_n over the n window (ext_n < RS_C), zero-padded
     static constexpr int NREC = 32;                              // neighbour-role records per engine pass
-    static constexpr int DUMP = NR == 1 ? 4 * EF * 32 : EF * PS + 2;   // the fold's dump: pairs of all four rows | one component at a time
+    static constexpr int DUMP = NR == 1 ? 4 * EF * 32 : 2 * (EF * PS + 2);   // the fold's dump: pairs of all four rows | one component per half at a time
     static constexpr int STAGE0 = 64 * RS_C > NREC * RS_N ? 64 * RS_C : NREC * RS_N;
     static constexpr int STAGE = (STAGE0 > DUMP ? STAGE0 : DUMP) + 4;  // + a quad of zeros
     static constexpr int MIN_WAVES = NR == 1 ? 4 : 2;            // waves per SIMD the registers are bounded for
@@ -130,7 +131,7 @@ k_featurize3(Feat3Args A) {
     const size_t list_d = 5 * (size_t)cap + ((5 * cap) & 1), tq_d = (size_t)cap * EF * 4;
     constexpr size_t stage_d = Cfg::STAGE;
     const size_t per_wave_d = list_d + tq_d + stage_d;
-    const size_t per_wave_i = 2 * (size_t)cap + 2 * ((size_t)cap + 1) + (UF3_MAX_SPECIES + 2) + (size_t)cap * (S + 1) + 2 * NREC;
+    const size_t per_wave_i = 2 * (size_t)cap + 2 * ((size_t)cap + 1) + (UF3_MAX_SPECIES + 2) + (size_t)cap * (S + 1) + 2 * NREC + cap;
     double *wd = rows + rows_d + (size_t)wave * per_wave_d;
     int *wi = (int *)(rows + rows_d + (size_t)WPB * per_wave_d) + (size_t)wave * per_wave_i;
     double *ox = wd, *oy = ox + cap, *oz = oy + cap, *orr = oz + cap, *oir = orr + cap;
@@ -139,7 +140,8 @@ k_featurize3(Feat3Args A) {
     double *zq = stage + (Cfg::STAGE - 4);                            // a quad of zeros
     int *oparent = wi, *oshift = wi + cap, *noff = wi + 2 * cap, *nbase = noff + cap + 1, *so = nbase + cap + 1;
     int *ospoff = so + (UF3_MAX_SPECIES + 2);
-    int *hdrs = ospoff + (size_t)cap * (S + 1);                       // [NREC + NREC] key | first n slot of the records of a pass
+    int *osbp = ospoff + (size_t)cap * (S + 1);                       // first window row of every own bond
+    int *hdrs = osbp + cap;                       // [NREC + NREC] key | first n slot of the records of a pass
     const int sp_stride = S + 1;
     unsigned short *fsrc_l = (unsigned short *)((int *)(rows + rows_d + (size_t)WPB * per_wave_d) + (((size_t)WPB * per_wave_i + 3) & ~(size_t)3));
 
@@ -155,15 +157,25 @@ k_featurize3(Feat3Args A) {
     const int ext_p = A.ext_p, ext_n = A.ext_n, lo_n = A.lo_n, lo_p = A.lo_p, npos = ext_p * ext_n;
     const int half = lane >> 5;
     int p_lane[NR], n_lane[NR], qn_lane[NR];
+    const int pr_rows = A.pr_rows;
 #pragma unroll
     for (int r = 0; r < NR; r++) {
-        const int pos = r * 32 + (lane & 31);
-        p_lane[r] = pos < npos ? pos / ext_n : 0;
-        n_lane[r] = pos < npos ? pos - p_lane[r] * ext_n : -(1 << 20);      // (idle positions always read zeros)
-        qn_lane[r] = pos < npos ? n_lane[r] : RS_C - 1;                    // (... a centre-role record's zero padding)
+        // round r holds the rows r * pr_rows ... of the summed leg: local position (row, n) = lane & 31
+        const int pl = (lane & 31) / ext_n, p = r * pr_rows + pl;
+        const bool on = pl < pr_rows && p < ext_p;
+        p_lane[r] = on ? p : 0;
+        n_lane[r] = on ? (lane & 31) - pl * ext_n : -(1 << 20);            // (idle positions always read zeros)
+        qn_lane[r] = on ? n_lane[r] : RS_C - 1;                            // (... a centre-role record's zero padding)
     }
+    (void)npos;
     const int sbn_max = ext_n > 4 ? ext_n - 4 : 0, sbp_max = ext_p > 4 ? ext_p - 4 : 0;
     const Feat3Leg leg_p = A.leg_p, leg_n = A.leg_n;
+    // rounds that hold rows of a bond whose four functions start at window row sb (all of them when the window has <= 4 rows)
+    auto rounds_of = [&](int sb) {
+        if (EF <= 4) return (1 << NR) - 1;
+        const int r0 = sb / pr_rows, r1 = min(sb + 3, ext_p - 1) / pr_rows;
+        return ((2 << r1) - 1) & ~((1 << r0) - 1);
+    };
 
     const int bid = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
     const int block_first = bid * A.atoms_per_block;
@@ -217,6 +229,7 @@ k_featurize3(Feat3Args A) {
                 const int iv = f3_eval<true>(rows, leg_p, r, v, d);
                 sbp = max(0, min(sbp_max, iv - 3 - lo_p));
             }
+            if (EF > 4) osbp[e] = sbp;
             const double ir = oir[e], ux = ox[e] * ir, uy = oy[e] * ir, uz = oz[e] * ir;
             double *dst = tq + (size_t)e * EF * 4;
             if (EF > 4) {
@@ -252,15 +265,20 @@ k_featurize3(Feat3Args A) {
 
             // stage 2: the open bond's W into the rows of the window.  Lower half: rows (x, y) += (Tx, Ty) W_plain + T3 (W_x, W_y);
             // upper half: rows (z, energy) += (Tz, T3) W_plain + T3 (W_z, 0) -- the energy row from the centre role only.
+            int wmask = 0;                                          // rounds that took records since the last flush
             auto flush = [&](bool is_c) {
                 if (cur < 0 || UF3_SKIP(2)) return;
                 const double *tc = tq + (size_t)cur * EF * 4;
+                // (wide windows: only the rounds that were summed into)
                 F3Pair tv[EF];
                 double t3[EF];
 #pragma unroll
-                for (int q = 0; q < EF; q++) { tv[q] = *(F3LdsPairs)(const F3Pair *)(tc + 4 * q + 2 * half); t3[q] = ((F3LdsDoubles)tc)[4 * q + 3]; }
+                for (int q = 0; q < EF; q++) {
+                    tv[q] = *(F3LdsPairs)(const F3Pair *)(tc + 4 * q + 2 * half); t3[q] = ((F3LdsDoubles)tc)[4 * q + 3];
+                }
 #pragma unroll
                 for (int r = 0; r < NR; r++) {
+                    if (EF > 4 && !((wmask >> r) & 1)) continue;
                     const int lo = __double2loint(ws[r][1]), hi = __double2hiint(ws[r][1]);
                     const auto r0 = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
                     const auto r1 = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
@@ -273,6 +291,7 @@ k_featurize3(Feat3Args A) {
                     }
                     ws[r][0] = ws[r][1] = 0.0;
                 }
+                wmask = 0;
             };
 
             // ---- centre role: m centres (f, g), f on the fixed leg.  Items p = fi * nG + gi, one per lane and stage slot (not
@@ -308,6 +327,13 @@ k_featurize3(Feat3Args A) {
                             sbn = max(0, min(sbn_max, iv - 3 - lo_n));
                         }
                     }
+                    int smask = (1 << NR) - 1;                      // rounds the partners g of this step have rows in
+                    if (EF > 4) {
+                        const int rm = valid ? rounds_of(osbp[gg]) : 0;
+                        smask = 0;
+#pragma unroll
+                        for (int r = 0; r < NR; r++) smask |= __ballot((rm >> r) & 1) ? (1 << r) : 0;
+                    }
                     {
                         double *rp = stage + (size_t)lane * RS_C;
 #pragma unroll
@@ -327,6 +353,7 @@ k_featurize3(Feat3Args A) {
                         if (s0 >= s1) continue;
                         const int key = f_los + fi_s;
                         if (key != cur) { flush(true); cur = key; }
+                        wmask |= smask;
                         const double *qp = stage + (size_t)(s0 - p0) * RS_C;
                         const double *tp = tq + (size_t)(g_los + (s0 - pr)) * EF * 4 + 2 * half;
                         int cnt = s1 - s0;
@@ -334,6 +361,7 @@ k_featurize3(Feat3Args A) {
                             constexpr int CNT = decltype(tag)::value;
 #pragma unroll
                             for (int r = 0; r < NR; r++) {
+                                if (EF > 4 && !((smask >> r) & 1)) continue;
                                 double bq[CNT];
                                 F3Pair tt[CNT];
 #pragma unroll
@@ -406,6 +434,13 @@ k_featurize3(Feat3Args A) {
                     }
                     const unsigned long long mask = __ballot(valid);
                     const int nv = __popcll(mask), rank = mbcnt(mask);
+                    int smask = (1 << NR) - 1;                      // rounds the bonds (e, k) of this step have rows in
+                    if (EF > 4) {
+                        const int rm = valid ? rounds_of(sbp) : 0;
+                        smask = 0;
+#pragma unroll
+                        for (int r = 0; r < NR; r++) smask |= __ballot((rm >> r) & 1) ? (1 << r) : 0;
+                    }
                     for (int sp0 = 0; sp0 < nv; sp0 += NREC) {
                         const int slot = rank - sp0;
                         if (valid && slot >= 0 && slot < NREC) {
@@ -436,6 +471,7 @@ k_featurize3(Feat3Args A) {
                             const int g1 = gm ? __builtin_ctzll(gm) : r_end;
                             const int key = __builtin_amdgcn_readlane(v_key, g0);
                             if (key != cur) { flush(false); cur = key; }
+                            wmask |= smask;
                             const double *rp = stage + (size_t)g0 * RS_N;
                             const int *sp = hdrs + NREC + g0;
                             int cnt = g1 - g0;
@@ -446,6 +482,7 @@ k_featurize3(Feat3Args A) {
                                 for (int i = 0; i < CNT; i++) sb[i] = ((const __attribute__((address_space(3))) int *)sp)[i];
 #pragma unroll
                                 for (int r = 0; r < NR; r++) {
+                                    if (EF > 4 && !((smask >> r) & 1)) continue;
                                     double bq[CNT];
                                     F3Pair tt[CNT];
 #pragma unroll
@@ -493,24 +530,27 @@ k_featurize3(Feat3Args A) {
                 }
                 wave_sync();
             } else {
-                // one component at a time: [f][32 NR positions] of doubles (+ a zero behind them for the second source a column
-                // may not have)
-                constexpr int NC = WANT_E ? 4 : 3;
+                // one component of each half at a time -- (x | z), then (y | energy): two buffers [f][32 NR positions] of doubles, a
+                // zero behind each for the second source a column may not have
+                constexpr int BUF = EF * PS + 2;
 #pragma unroll
-                for (int c = 0; c < NC; c++) {
-                    if (half == (c >> 1)) {
+                for (int k = 0; k < 2; k++) {
 #pragma unroll
-                        for (int r = 0; r < NR; r++)
+                    for (int r = 0; r < NR; r++)
 #pragma unroll
-                            for (int q = 0; q < EF; q++) stage[q * PS + r * 32 + (lane & 31)] = xacc[r][q][c & 1];
-                    }
-                    if (lane == 0) stage[EF * PS] = 0.0;
+                        for (int q = 0; q < EF; q++) stage[half * BUF + q * PS + r * 32 + (lane & 31)] = xacc[r][q][k];
+                    if (lane == 0 || lane == 32) stage[half * BUF + EF * PS] = 0.0;
                     wave_sync();
                     for (int col = lane; col < t_ncol; col += WAVE) {
                         const int s0 = ft[2 * col], s1 = ft[2 * col + 1];
-                        const double v = ((F3LdsDoubles)stage)[s0] + ((F3LdsDoubles)stage)[s1];
-                        if (c < 3) __builtin_nontemporal_store(v, A.x_f + ((size_t)m * 3 + c) * F + t_col + col);
-                        else es.add(t_col + col, v);
+                        F3LdsDoubles da = (F3LdsDoubles)stage, db = da + BUF;
+                        const double va = da[s0] + da[s1];
+                        __builtin_nontemporal_store(va, A.x_f + ((size_t)m * 3 + k) * F + t_col + col);
+                        if (k == 0 || WANT_E) {
+                            const double vb = db[s0] + db[s1];
+                            if (k == 0) __builtin_nontemporal_store(vb, A.x_f + ((size_t)m * 3 + 2) * F + t_col + col);
+                            else es.add(t_col + col, vb);
+                        }
                     }
                     wave_sync();
                 }

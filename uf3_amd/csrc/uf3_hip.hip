@@ -702,9 +702,12 @@ extern "C" int uf3_basis_create(uf3_ctx *c, const uf3_basis_spec *s, uf3_basis *
             const TrioDev &t0 = trios[0];
             // the instantiated shapes (rows of the centre-leg window, rounds of 32 positions): (3, 1) (4, 2) (5, 3) (6, 3)
             const int ep = t0.ext[0], en = t0.ext[2], np = ep * en;
+            // (a round of 32 positions holds whole rows of the summed leg: 32 / ext_n of them)
             b->f3_nr = ep == 3 ? 1 : (ep == 4 ? 2 : 3);
-            const bool shape = (ep == 3 && np <= 31 && en <= 9) || (ep == 4 && np <= 64 && en <= 11) ||
-                               ((ep == 5 || ep == 6) && np <= 96 && en <= 13);
+            const int prr = en > 0 && en <= 32 ? std::min(ep, 32 / en) : 0;
+            (void)np;
+            const bool shape = prr > 0 && prr * b->f3_nr >= ep &&
+                               ((ep == 3 && prr * en <= 31 && en <= 9) || (ep == 4 && en <= 11) || ((ep == 5 || ep == 6) && en <= 13));
             ok = t0.lo[0] == t0.lo[1] && t0.ext[0] == t0.ext[1] && same_leg(t0.leg[0], t0.leg[1]) && shape &&
                  t0.leg[0].nk >= 8 && t0.leg[2].nk >= 8 && !(ep > 3 && getenv("UF3_NO_FEAT3_WIDE"));
             for (int t = 0; t < h.T && ok; t++) {
@@ -763,7 +766,8 @@ extern "C" int uf3_basis_create(uf3_ctx *c, const uf3_basis_spec *s, uf3_basis *
                             unsigned short e = (unsigned short)(b->f3_nr == 1 ? 31 : td.ext[0] * ps);
                             if (sp >= 0) {
                                 const int l = (sp & 255) - td.lo[0], m = ((sp >> 8) & 255) - td.lo[1], n = ((sp >> 16) & 255) - td.lo[2];
-                                e = (unsigned short)((o == 0 ? l : m) * ps + (o == 0 ? m : l) * td.ext[2] + n);
+                                const int prr = std::min(td.ext[0], 32 / td.ext[2]), j = o == 0 ? m : l;
+                                e = (unsigned short)((o == 0 ? l : m) * ps + (j / prr) * 32 + (j % prr) * td.ext[2] + n);
                             }
                             mine.push_back(e);
                         }
@@ -1425,6 +1429,7 @@ extern "C" int uf3_featurize_dev(uf3_basis *b, const uf3_frames *fr, const doubl
                 G.fsrc = b->d_f3src; G.trio_fsrc = b->d_f3off; G.n_fsrc = b->n_f3src;
                 G.leg_p = b->f3_leg_p; G.leg_n = b->f3_leg_n;
                 G.lo_p = b->f3_lo_p; G.ext_p = b->f3_ext_p; G.lo_n = b->f3_lo_n; G.ext_n = b->f3_ext_n;
+                G.pr_rows = std::min(b->f3_ext_p, 32 / b->f3_ext_n);
                 G.geoms = P.geoms; G.frame_of = P.frame_of; G.n3 = A.n3; G.pos = d_pos; G.spec = P.spec;
                 G.x_e = d_xe; G.x_f = d_xf; G.natoms = P.natoms; G.e_direct = A.e_direct; G.skip = A.skip;
                 const int S = b->host.S;
@@ -1439,7 +1444,7 @@ extern "C" int uf3_featurize_dev(uf3_basis *b, const uf3_frames *fr, const doubl
                 }
                 const size_t e_d = e_lds ? (size_t)F + (F & 1) : 0, rows_d = (size_t)b->n_f3rows * 18;
                 const size_t list_d = 5 * (size_t)cap + ((5 * cap) & 1), tq_d = (size_t)cap * ep * 4, stage_d = (size_t)stage;
-                const size_t per_wave_i = 2 * (size_t)cap + 2 * ((size_t)cap + 1) + (UF3_MAX_SPECIES + 2) + (size_t)cap * (S + 1) + 2 * (size_t)nrec;
+                const size_t per_wave_i = 2 * (size_t)cap + 2 * ((size_t)cap + 1) + (UF3_MAX_SPECIES + 2) + (size_t)cap * (S + 1) + 2 * (size_t)nrec + (size_t)cap;
                 const size_t ints = ((size_t)WPB * per_wave_i + 3) & ~(size_t)3;
                 const size_t lds = (e_d + rows_d + WPB * (list_d + tq_d + stage_d)) * 8 + ints * 4 + (size_t)b->n_f3src * 2 + 32;
                 if (lds > 160 * 1024 - 512) return fail(c, UF3_EOVERFLOW, "featurizer LDS footprint exceeds 160 KB (F or neighbour count too large)");
