@@ -247,7 +247,7 @@ def main(argv=None):
         traffic, traffic_source = None, None
         if world == 1 and not fit and not args.no_traffic:
             traffic, traffic_source = measure_traffic(B, args.workload, args.atoms)
-        for name in (() if traffic is not None else ("round3_hbm_counters.json", "round2_hbm_counters.json", "round1_hbm_counters.json")):
+        for name in (() if traffic is not None else ("round4_hbm_counters.json", "round3_hbm_counters.json", "round2_hbm_counters.json", "round1_hbm_counters.json")):
             try:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
                 if pmc["workload"] == dict(atoms_per_frame=n_atoms, n_feat=F, frames_per_step=B):
@@ -255,17 +255,18 @@ def main(argv=None):
                     break
             except (OSError, KeyError, ValueError):
                 pass
-        feat_kernel = ("k_featurize<E,F,R,MODE> launch group of one step: MODE 0 (one-body + pairs + 3-body list build) + "
-                       "the matrix-core launch of the 3-body windows (" + ("MODE 11, banded 6 x 6 x 12 windows" if wl == "lead0" else
-                                                                         "MODE 10, grouped n windows of the default trims") + ")")
+        feat_kernel = ("k_featurize launch group of one step: k_featurize<..., MODE 0> (one-body + pair columns + 3-body list build) + "
+                       "k_featurize3 (3-body energy / force rows by bond factorisation, fp64 vector units, no matrix cores; "
+                       + ("6 x 12 windows in three rounds" if wl == "lead0" else "3 x 9 windows of the default trims, four waves per SIMD") + ")")
         hbm = dict(achieved=round(hbm_gbs, 2), peak=8000.0, unit="GB/s", frac=round(hbm_gbs / 8000.0, 5),
                    algorithmic_bytes_per_launch=bytes_per_launch)
         if not fit:
             roofline = dict(bound="mfma", achieved=round(feat_tf, 3), peak=78.6, unit="TFLOP/s", frac=round(feat_tf / 78.6, 5),
                             traffic=traffic, traffic_source=traffic_source, hbm=hbm,
-                            bound_note="fp64 issue: an fp64 MFMA holds the SIMD's vector issue for its 64 cycles on MI355X "
-                                       "(tools/experiments/dp_pipe_bench.hip), so the 141 MFMA + ~6000 vector instructions "
-                                       "per atom add up; achieved = ALGORITHMIC flops (SURVEY 8d), the HBM view is in `hbm`",
+                            bound_note="compute roofline = the fp64 peak, 78.6 TF (vector and matrix fp64 are one pipe on MI355X, "
+                                       "tools/experiments/dp_pipe_bench.hip); since round 4 the 3-body rows come from the vector units "
+                                       "alone (k_featurize3: ~5400 vector instructions and ~6100 LDS cycles per atom, LDS ~80 % busy); "
+                                       "achieved = ALGORITHMIC flops (SURVEY 8d), the HBM view is in `hbm`",
                             kernel=feat_kernel, launch_ms=round(launch_ms, 4), launches=launches,
                             algorithmic_flops_per_launch=flops_frame * B,
                             neighbor_ms_per_step=round(timing["neighbor_ms"] / args.steps, 4))

@@ -77,6 +77,10 @@ typedef const __attribute__((address_space(3))) double *F3LdsDoubles;
 
 // four consecutive window functions of a leg at x (t0 < x < tlast): values v, derivatives d; returns the knot interval.
 // The row of the guessed interval is fetched whole and again only when the guess was off (non-uniform knots, x on a knot).
+#ifndef F3_ROWS_GLOBAL
+#define F3_ROWS_GLOBAL 0
+#endif
+typedef const __attribute__((address_space(1))) F3Pair *F3GlobalPairs;
 template <bool DERIV>
 __device__ __forceinline__ int f3_eval(const double *rows, const Feat3Leg &lg, double x, double (&v)[4], double (&d)[4]) {
     const int hi = lg.nk - 5;
@@ -84,14 +88,18 @@ __device__ __forceinline__ int f3_eval(const double *rows, const Feat3Leg &lg, d
     iv = iv < 3 ? 3 : (iv > hi ? hi : iv);
     F3Pair kn, cf[8];
     auto load_row = [&](int i) {
+#if F3_ROWS_GLOBAL
+        F3GlobalPairs q = (F3GlobalPairs)(const F3Pair *)(rows + (size_t)(lg.row0 + i - 3) * 18);
+#else
         F3LdsPairs q = (F3LdsPairs)(const F3Pair *)(rows + (size_t)(lg.row0 + i - 3) * 18);
+#endif
         F3Pair t0 = q[0], t[8];
 #pragma unroll
         for (int e = 0; e < 8; e++) t[e] = q[1 + e];
         kn = t0;
 #pragma unroll
         for (int e = 0; e < 8; e++) cf[e] = t[e];
-        __builtin_amdgcn_sched_group_barrier(0x100, 9, 0);
+        __builtin_amdgcn_sched_group_barrier(F3_ROWS_GLOBAL ? 0x020 : 0x100, 9, 0);
     };
     load_row(iv);
     if (__builtin_expect(x > kn.y && iv < hi, 0)) {
@@ -126,14 +134,15 @@ k_featurize3(Feat3Args A) {
     double *erow = (double *)smem;
     const bool e_lds = WANT_E && !A.e_direct;
     const size_t e_d = e_lds ? (size_t)F + (F & 1) : 0;
-    double *rows = erow + e_d;                                        // window rows, shared
+    double *rows_lds = erow + e_d;                                    // window rows, shared
+    const double *rows = F3_ROWS_GLOBAL ? A.rows : rows_lds;
     const size_t rows_d = (size_t)A.n_rows * 18;
     const size_t list_d = 5 * (size_t)cap + ((5 * cap) & 1), tq_d = (size_t)cap * EF * 4;
     constexpr size_t stage_d = Cfg::STAGE;
     const size_t per_wave_d = list_d + tq_d + stage_d;
     const size_t per_wave_i = 2 * (size_t)cap + 2 * ((size_t)cap + 1) + (UF3_MAX_SPECIES + 2) + (size_t)cap * (S + 1) + 2 * NREC + cap;
-    double *wd = rows + rows_d + (size_t)wave * per_wave_d;
-    int *wi = (int *)(rows + rows_d + (size_t)WPB * per_wave_d) + (size_t)wave * per_wave_i;
+    double *wd = rows_lds + rows_d + (size_t)wave * per_wave_d;
+    int *wi = (int *)(rows_lds + rows_d + (size_t)WPB * per_wave_d) + (size_t)wave * per_wave_i;
     double *ox = wd, *oy = ox + cap, *oz = oy + cap, *orr = oz + cap, *oir = orr + cap;
     double *tq = wd + list_d;                                         // [cap][EF][4]: T_f = (Tx Ty Tz T3) of every own bond
     double *stage = tq + tq_d;
@@ -143,9 +152,9 @@ k_featurize3(Feat3Args A) {
     int *osbp = ospoff + (size_t)cap * (S + 1);                       // first window row of every own bond
     int *hdrs = osbp + cap;                       // [NREC + NREC] key | first n slot of the records of a pass
     const int sp_stride = S + 1;
-    unsigned short *fsrc_l = (unsigned short *)((int *)(rows + rows_d + (size_t)WPB * per_wave_d) + (((size_t)WPB * per_wave_i + 3) & ~(size_t)3));
+    unsigned short *fsrc_l = (unsigned short *)((int *)(rows_lds + rows_d + (size_t)WPB * per_wave_d) + (((size_t)WPB * per_wave_i + 3) & ~(size_t)3));
 
-    for (int q = tid; q < (int)rows_d; q += WPB * WAVE) rows[q] = A.rows[q];
+    for (int q = tid; q < (int)rows_d; q += WPB * WAVE) rows_lds[q] = A.rows[q];
     for (int q = tid; q < A.n_fsrc / 2; q += WPB * WAVE) ((int *)fsrc_l)[q] = ((const int *)A.fsrc)[q];
     if (e_lds) { for (int q = tid; q < F; q += WPB * WAVE) erow[q] = 0.0; }
     for (int q = lane; q < (int)stage_d; q += WAVE) stage[q] = 0.0;
