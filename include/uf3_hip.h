@@ -113,9 +113,13 @@ void uf3_basis_destroy(uf3_basis *basis);
  * 64-column chunks) = (1,1) (1,2) (2,1) (2,2) (6,1)); bits 6..9: 3-body blocks whose window of non-trimmed bins runs on the
  * fp64 matrix cores, rows (component, l) x columns (n, m) in 16 x 16 tiles: (row tiles, column tiles) = (1,1) (1,2) (1,<=4)
  * (<=2,<=6).  Within bit 7 the 3 x 3 x <=9 windows of the reference's default trims stage grouped n windows, within bit 9
- * the wide windows run banded; both are chosen per block by uf3_basis_create.  Setting
- * UF3_NO_MFMA_FEAT in the environment before uf3_basis_create keeps every block on the generic kernels (used by the tests
- * to compare the two paths). */
+ * the wide windows run banded; both are chosen per block by uf3_basis_create.  Bit 12 (round 4): the
+ * basis qualifies for k_featurize3 -- one window layout on all trios, centre legs alike, 3 x <= 9 up to 6 x <= 13 kept bins,
+ * symmetric folds for equal neighbour species --, which then writes the 3-body FORCE (and with them energy) rows of every block
+ * by bond factorisation on the fp64 vector units (uf3_amd/csrc/uf3_feat3.h); the launches of bits 1..9 remain for energy-only
+ * calls, for batches with atoms far outside their cell and for every other basis.  Setting UF3_NO_FEAT3 in the environment
+ * before uf3_basis_create switches k_featurize3 off, UF3_NO_MFMA_FEAT keeps every block on the generic kernels (used by the
+ * tests to compare the three paths). */
 int uf3_basis_featurizer_modes(const uf3_basis *basis, int32_t *mask);
 
 /*

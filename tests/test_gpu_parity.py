@@ -1227,11 +1227,16 @@ def test_matrix_core_and_generic_trio_kernels_agree(which, bit):
             meta["basis_kwargs"]["leading_trim"] = {"2": 0, "3": 3}
             meta["basis_kwargs"]["trailing_trim"] = {"2": 3, "3": 3}
         frames, basis = [atoms], basis_from_meta(meta)
-    xe_m, xf_m, modes_m = _fresh_rows(basis, frames)
-    xe_g, xf_g, modes_g = _fresh_rows(basis, frames, UF3_NO_MFMA_FEAT="1")
+    xe_m, xf_m, modes_m = _fresh_rows(basis, frames, UF3_NO_FEAT3="1")
+    xe_g, xf_g, modes_g = _fresh_rows(basis, frames, UF3_NO_FEAT3="1", UF3_NO_MFMA_FEAT="1")
     assert modes_m & (0x3c0 if bit is None else 1 << bit), f"expected featurizer mode bit {bit} for this basis, got {modes_m:#x}"
-    assert not (modes_g & 0x3c0) and (modes_g & 0x3e)
+    assert not (modes_g & 0x3c0) and (modes_g & 0x3e) and not (modes_m & 0x1000) and not (modes_g & 0x1000)
     assert rel_err(xe_m, xe_g) < 1e-12 and rel_err(xf_m, xf_g) < 1e-12
+    # round 4: the bond-factorised launch (k_featurize3, mode bit 12) where the basis qualifies -- a third, independent traversal
+    xe_b, xf_b, modes_b = _fresh_rows(basis, frames)
+    assert bool(modes_b & 0x1000) == (which in ("notebook_binary", "four_by_four", "six_by_six", "five_by_five_unary")), hex(modes_b)
+    assert rel_err(xe_b, xe_m) < 1e-12 and rel_err(xf_b, xf_m) < 1e-12
+    assert worst_elementwise(xf_b, xf_m, rtol=1e-9, floor=1e-12) <= 1.0
     ob = O.OracleBasis(basis)
     off = 0
     for k, fr in enumerate(frames):

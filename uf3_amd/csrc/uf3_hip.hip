@@ -790,6 +790,7 @@ extern "C" int uf3_basis_create(uf3_ctx *c, const uf3_basis_spec *s, uf3_basis *
             }
         }
         b->feat3_ok = ok;
+        if (ok) b->modes |= 1 << 12;
     }
     // the force rows of an atom of species s are zero outside the blocks s takes part in (and in the one-body columns)
     {
