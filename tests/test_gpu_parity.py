@@ -1321,6 +1321,32 @@ def test_grouped_windows_with_non_uniform_knot_sequences():
     assert np.abs(x_f[:, :, basis.n_feats - 40:]).max() > 0
 
 
+def test_bond_factorised_launch_with_non_uniform_knot_sequences():
+    """k_featurize3 (mode bit 12) on one unevenly spaced set of knot sequences shared by all trios -- the interval guess of its
+    window rows is wrong for most distances -- at the default trims and without the leading trim (6 x 6 x 12 windows, three
+    rounds), against the oracle entry by entry and against the matrix-core launches."""
+    from uf3_amd.data import composition
+    from uf3_amd.representation import bspline
+
+    def clamped(lo, hi, n_int, power):
+        inner = lo + (hi - lo) * np.linspace(0.0, 1.0, n_int + 1) ** power
+        return np.concatenate([[lo] * 3, inner, [hi] * 3])
+
+    cs = composition.ChemicalSystem(['Mo', 'W'], 3)
+    pairs, trios = cs.interactions_map[2], cs.interactions_map[3]
+    knots = {p: clamped(0.001, 5.5, 15, 1.3) for p in pairs}
+    for t in trios:
+        knots[t] = [clamped(1.5, 3.5, 6, 1.5), clamped(1.5, 7.0, 12, 0.75)]
+    frames = [synthetic.lattice_frame("bcc", (3, 3, 4), 3.165, [42, 74], 87, rattle=0.15),
+              synthetic.lattice_frame("fcc", (2, 3, 2), 4.0, [42, 74], 88, rattle=0.2)]
+    for lead in (3, 0):
+        basis = bspline.BSplineBasis(cs, knots_map=knots, leading_trim={2: 0, 3: lead}, trailing_trim={2: 3, 3: 3})
+        assert process.BasisFeaturizer(basis)._dev()[1].featurizer_modes & (1 << 12)
+        x_e, x_f = _check_against_oracle(basis, frames)
+        xe_m, xf_m, modes_m = _fresh_rows(basis, frames, UF3_NO_FEAT3="1")
+        assert not (modes_m & (1 << 12)) and worst_elementwise(x_f, xf_m) <= 1.0 and rel_err(x_e, xe_m) < 1e-12
+
+
 def _lj_like_model():
     """2-body W model whose coefficients are a least-squares B-spline fit of a Lennard-Jones curve."""
     from uf3_amd.data import composition
