@@ -165,7 +165,7 @@ k_featurize3(Feat3Args A) {
     // serves NR positions, 32 apart --------------------------------------------------------------------------------------
     const int ext_p = A.ext_p, ext_n = A.ext_n, lo_n = A.lo_n, lo_p = A.lo_p, npos = ext_p * ext_n;
     const int half = lane >> 5;
-    int p_lane[NR], n_lane[NR], qn_lane[NR];
+    int p_lane[NR], n_lane[NR], qn_lane[NR], n32_lane[NR];
     const int pr_rows = A.pr_rows;
 #pragma unroll
     for (int r = 0; r < NR; r++) {
@@ -175,6 +175,7 @@ k_featurize3(Feat3Args A) {
         p_lane[r] = on ? p : 0;
         n_lane[r] = on ? (lane & 31) - pl * ext_n : -(1 << 20);            // (idle positions always read zeros)
         qn_lane[r] = on ? n_lane[r] : RS_C - 1;                            // (... a centre-role record's zero padding)
+        n32_lane[r] = n_lane[r] * 32;
     }
     (void)npos;
     const int sbn_max = ext_n > 4 ? ext_n - 4 : 0, sbp_max = ext_p > 4 ? ext_p - 4 : 0;
@@ -468,7 +469,7 @@ k_featurize3(Feat3Args A) {
                                 *(double2 *)(rp + EFP + 4 * u) = double2{a3[0] * bd[u], a3[1] * bd[u]};
                                 *(double2 *)(rp + EFP + 2 + 4 * u) = double2{a3[2] * bd[u], bn[u]};
                             }
-                            hdrs[slot] = e; hdrs[NREC + slot] = sbn;
+                            hdrs[slot] = e; hdrs[NREC + slot] = sbn * 32;      // (byte offset of the first n slot's quad)
                         }
                         wave_sync();
                         const int r_end = min(NREC, nv - sp0);
@@ -496,11 +497,11 @@ k_featurize3(Feat3Args A) {
                                     F3Pair tt[CNT];
 #pragma unroll
                                     for (int i = 0; i < CNT; i++) {
-                                        const unsigned idx = (unsigned)(n_lane[r] - sb[i]);
-                                        F3LdsPairs qa = (F3LdsPairs)(const F3Pair *)(rp + i * RS_N + EFP + 2 * half) + 2 * idx;
-                                        qa = idx < 4u ? qa : (F3LdsPairs)(const F3Pair *)zq;
+                                        const unsigned off = (unsigned)(n32_lane[r] - sb[i]);          // 32 (n - first slot)
+                                        const char *qa = (const char *)(rp + i * RS_N + EFP + 2 * half) + off;
+                                        qa = off < 128u ? qa : (const char *)zq;
                                         bq[i] = ((F3LdsDoubles)rp)[i * RS_N + p_lane[r]];
-                                        tt[i] = *qa;
+                                        tt[i] = *(F3LdsPairs)(const F3Pair *)qa;
                                     }
 #pragma unroll
                                     for (int i = 0; i < CNT; i++) { ws[r][0] = fma(bq[i], tt[i].x, ws[r][0]); ws[r][1] = fma(bq[i], tt[i].y, ws[r][1]); }

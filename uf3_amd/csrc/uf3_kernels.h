@@ -1974,7 +1974,7 @@ __device__ __forceinline__ int trio_mode(const TrioDev *td) {
 // MODE_ 10 = MODE 7 for a basis whose mode-7 blocks all stage grouped windows (the launch then carries no code and no
 // registers of the ordinary two-tile path); MODE_ 11 = MODE 9 with banded windows only, likewise.
 template <bool WANT_E, bool WANT_F, bool RECS_LDS, int MODE_, bool IMG>
-__global__ void __launch_bounds__(WPB * WAVE, MODE_ == 0 ? 4 : ((MODE_ == 6 || MODE_ == 7 || MODE_ == 10) ? 3 : 2))
+__global__ void __launch_bounds__(WPB * WAVE, MODE_ == 0 ? 5 : ((MODE_ == 6 || MODE_ == 7 || MODE_ == 10) ? 3 : 2))
 k_featurize(FeatArgs A) {
     constexpr int MODE = MODE_ == 10 ? 7 : (MODE_ == 11 ? 9 : MODE_);
     constexpr bool GROUPED_ONLY = MODE_ == 10 || MODE_ == 11;      // (11: mode 9, banded windows with the band tiles 0, 1, 2 only)
