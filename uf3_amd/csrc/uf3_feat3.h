@@ -18,9 +18,9 @@
 //
 // An atom of the benchmark has 273 triplet records but only ~50 (bond, block) pairs: the expansion over the three force
 // components and the window of the fixed leg -- what the matrix cores did per record -- happens once per bond.  Lanes are the
-// (j, n) positions of the W window (27 for the default trims) twice over: the two halves of the wave take alternate records
-// of a bond and keep partial sums, which meet in the fold.  No matrix cores, no per-record staging of three evaluated legs: a
-// record is the four n-leg values (centre role) or those, their derivatives times a3 and the four values of bond (e, k).
+// (j, n) positions of the W window (27 for the default trims) twice over: lanes 0-31 keep the sums (x, y) of a position, lanes
+// 32-63 (z, plain).  No matrix cores, no per-record staging of three evaluated legs: a record is the n-leg values (centre
+// role) or those, their derivatives times a3 and the values of bond (e, k).  DESIGN.md section 3.6.
 //
 // Orientation: the fixed bond sits on leg l ("normal": rows i = l, window j = m) or on leg m ("transposed": i = m, j = l); a
 // block has one orientation per atom species -- transposed exactly when sa != sb and the atom is of species sb (then it is
@@ -40,7 +40,8 @@ struct Feat3Args {
     const TrioDev *trios;
     const double *rows;        // window rows [n_rows][18]: t_i, t_i+1 | 4 functions x (c0 c1 c2 c3), see uf3_basis_create
     int n_rows;
-    const unsigned short *fsrc; // fold tables: per trio [orientation 0 | 1][column][source 0 | 1] -> f * 32 + j * ext_n + n, 31 = none
+    const unsigned short *fsrc; // fold tables: per trio [orientation 0 | 1][column][source 0 | 1] -> index of the source bin in the fold's
+                               // dump (row f of the fixed leg, position of (j, n): uf3_basis_create), or of a zero
     const int *trio_fsrc;      // [T] first entry of a trio's table
     int n_fsrc;
     Feat3Leg leg_p, leg_n;     // the centre legs (l and m share knots and window), leg n

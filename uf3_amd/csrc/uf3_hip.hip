@@ -84,6 +84,7 @@ struct uf3_ctx {
     std::string async_msg;
     bool frag_ready = false;
     int32_t *d_stage_z = nullptr;       // species of the staged batch (tail of stage_pos)
+    bool pin_in_busy = false;           // a kernel that reads pin_in directly has been launched and not yet waited for
     size_t pin_in_pending = 0;          // small batch: bytes of positions | species waiting in pin_in; the cell-list
                                         // stage appends the frame geometry and sends everything in ONE copy
     PinBuf pin_in, pin_geo, pin_out;    // positions + species | frame geometry + offsets | results
@@ -1133,6 +1134,7 @@ static int prepare(uf3_basis *b, const uf3_frames *fr, const double *d_pos, cons
                            natoms, nbins, d_pos, d_z, c->frame_of.as<int>(), c->atom_bin.as<int>(), c->atom_wrap.as<int>(),
                            c->spec.as<signed char>(), c->bin_start.as<int>(), c->slots.as<SlotRec>(), flags, 2,
                            host_block, (int4 *)c->stage_pos.p, (int)(host_block_bytes / 16));
+        if (host_block) c->pin_in_busy = true;     // (until the caller's wait for the stream: upload_frames checks)
         // (host_block: no event behind the kernel -- a record between two launches costs the next kernel ~5 us of dispatch
         // latency, and the only caller on this path, the synchronous evaluator entry, waits for the stream before it returns)
         P.flags_zeroed = true;
@@ -1530,6 +1532,8 @@ static int upload_frames(uf3_ctx *c, const uf3_frames *fr, const double *pos, co
     c->d_stage_z = (int32_t *)((char *)c->stage_pos.p + bp);
     c->pin_in_pending = 0;
     if (bp + bz <= UF3_PIN_LIMIT) {
+        // (an entry that returned an error behind a launch reading the staging block directly never waited for it)
+        if (c->pin_in_busy) { HIPCHK(c, hipStreamSynchronize(c->stream)); c->pin_in_busy = false; }
         HIPCHK(c, hipEventSynchronize(c->pin_in_done));
         HIPCHK(c, c->pin_in.ensure(bp + bz + geo_room));
         std::memcpy(c->pin_in.p, pos, bp);
@@ -1731,6 +1735,7 @@ static int eval_host(uf3_basis *b, const uf3_frames *fr, const double *pos, cons
             if (rc) return rc;
             if (!zero_copy) HIPCHK(c, hipMemcpyAsync(c->pin_out.p, d_e, total + 16, hipMemcpyDeviceToHost, c->stream));
             HIPCHK(c, hipStreamSynchronize(c->stream));
+            c->pin_in_busy = false;
             poll_pending(c, true);           // (remembered, see above)
             {
                 const int *fl = (const int *)((const char *)c->pin_out.p + total);

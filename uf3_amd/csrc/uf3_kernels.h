@@ -1044,7 +1044,7 @@ __device__ __forceinline__ void trio_block_mfma(const FeatArgs &A, const BasisDe
     PhaseClock pc;
     TrioWalk k;
     trio_walk_setup<WANT_F, IMG>(A, w, td->sc, td->sa, td->sb, sm, k);
-    const int ncol = td->ncol, F = load_const(&B->F);     // (a scalar load: as B->F it is a vector load and a wait on everything in flight)
+    const int F = load_const(&B->F);     // (a scalar load: as B->F it is a vector load and a wait on everything in flight)
     const int lo_l = td->lo[0], lo_m = td->lo[1], lo_n = td->lo[2];
     const int ext_l = td->ext[0], ext_m = td->ext[1], ext_n = td->ext[2];
     const DenseLayout dl = dense_layout(ext_l, ext_m, ext_n);
@@ -1615,7 +1615,7 @@ __device__ __forceinline__ void trio_block_grouped(const FeatArgs &A, const Basi
     const int ncol = th.ncol, F = load_const(&B->F);      // (a scalar load: as B->F it was a vector load, once per block, and a wait on
                                                           // everything in flight -- the row stores of the block before included)
     const unsigned short *gsrc_blk = gsrc + (th.grouped >> 8);      // the block's fold table (LDS when it fits)
-    const int ext_l = L.ext_l, ext_m = 3, ext_n = L.ext_n;
+    const int ext_l = L.ext_l, ext_m = 3;
     const int oM = 2 * ext_l, oN = oM + 2 * ext_m, oD = oN + 2 * GW;
     const int li = (lane * 21846) >> 16, leg = lane - 3 * li;
     double4_t acc[NG][1][1];
@@ -1664,7 +1664,6 @@ __device__ __forceinline__ void trio_block_grouped(const FeatArgs &A, const Basi
             // every group starts on an even slot (its steps never share a record pair with another group's)
             const int b0 = max(0, min(n_part, n_g0 - base)), b1 = max(0, min(n_part, n_g01 - base));
             const int st0 = (b0 + 1) >> 1, st1 = (b1 - b0 + 1) >> 1, st2 = (n_part - b1 + 1) >> 1;
-            const int n_staged = 2 * (st0 + st1 + st2);
             const bool mine = li < n_part && !UF3_SKIP(16);
             // Nothing is cleared: every slot of every record of the pass is written below (window slots from the leg's window row,
             // zeros included), the pair at oZ is never written, and of a padding record -- the slot after an odd group -- only the

@@ -126,9 +126,9 @@ class UFCalculator(_Base):
         e = np.empty(1)
         f = np.empty((batch.n_atoms, 3)) if forces else None
         v = np.empty((1, 6)) if virial else None
-        ctx.check(ctx.lib.uf3_eval_atoms(db.handle, C.byref(batch.struct), _lib._p(batch.pos), _lib._p(batch.z),
-                                         _lib._p(self._c1), _lib._p(self._c2), _lib._p(self._c3), int(atom_begin),
-                                         int(atom_end), _lib._p(e), _lib._p(f), _lib._p(v)))
+        addr = _lib._addr
+        ctx.check(ctx.lib.uf3_eval_atoms(db.handle, C.byref(batch.struct), addr(batch.pos), addr(batch.z), self._pc[0], self._pc[1],
+                                         self._pc[2], int(atom_begin), int(atom_end), addr(e), addr(f), addr(v)))
         return float(e[0]), f, (v[0] if virial else None)
 
     def evaluate_centre_range(self, atoms, atom_begin, atom_end, forces=True, virial=False):
@@ -145,9 +145,9 @@ class UFCalculator(_Base):
         e = np.empty(1)
         f = np.empty((batch.n_atoms, 3)) if forces else None
         v = np.empty((1, 6)) if virial else None
-        ctx.check(ctx.lib.uf3_eval_centres(db.handle, C.byref(batch.struct), _lib._p(batch.pos), _lib._p(batch.z),
-                                           _lib._p(self._c1), _lib._p(self._c2), _lib._p(self._c3), int(atom_begin),
-                                           int(atom_end), _lib._p(e), _lib._p(f), _lib._p(v)))
+        addr = _lib._addr
+        ctx.check(ctx.lib.uf3_eval_centres(db.handle, C.byref(batch.struct), addr(batch.pos), addr(batch.z), self._pc[0], self._pc[1],
+                                           self._pc[2], int(atom_begin), int(atom_end), addr(e), addr(f), addr(v)))
         return float(e[0]), f, (v[0] if virial else None)
 
     def calculate(self, atoms=None, properties=None, system_changes=tuple(all_changes)):
