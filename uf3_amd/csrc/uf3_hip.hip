@@ -1219,6 +1219,7 @@ static int ensure_frag(uf3_ctx *c);
 static size_t feat_lds_bytes(int F, int S, int cap, int cand_cap, bool want_e, size_t n_recs, int mode, int dense_stage,
                              int dense_nrec, int n_pair_cols) {
     const bool dense = mode >= 6;
+    if (mode == 0) F = S + n_pair_cols;            // (the pair launch's energy row: one-body + pair columns)
     size_t e_d = want_e ? (size_t)F + (F & 1) : 0;
     size_t cand_d = (size_t)cand_cap * CAND_STRIDE;
     size_t pair_buf_d = std::max(4 * (size_t)n_pair_cols, (3 * (size_t)cap + 1) / 2 + 2);

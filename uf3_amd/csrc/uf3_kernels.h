@@ -1987,7 +1987,9 @@ k_featurize(FeatArgs A) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);           // wave-uniform: LDS pointers and atom indices in SGPRs
     double *erow = (double *)smem;                                         // [F] shared by the block (WANT_E)
     const bool e_lds = WANT_E && !A.e_direct;
-    const size_t e_d = e_lds ? (size_t)F + (F & 1) : 0;
+    // (the pair launch adds to the one-body and pair columns only: its LDS row ends there)
+    const int FE = MODE == 0 ? S + A.n_pair_cols : F;
+    const size_t e_d = e_lds ? (size_t)FE + (FE & 1) : 0;
     // LDS carve (must match feat_lds_bytes on the host).  MODE 0 (pairs): candidate list + pair records, pair
     // knot records only; trio modes: own neighbour list + triplet records, all knot records.
     const size_t cand_d = (size_t)A.cand_cap * CAND_STRIDE;
@@ -2043,7 +2045,7 @@ k_featurize(FeatArgs A) {
             gsrc = (const unsigned short *)dl;
         }
     }
-    if (e_lds) { for (int q = tid; q < F; q += WPB * WAVE) erow[q] = 0.0; }
+    if (e_lds) { for (int q = tid; q < FE; q += WPB * WAVE) erow[q] = 0.0; }
     if (DENSE) for (int q = lane; q < (int)stage_d; q += WAVE) w.stage[q] = 0.0;   // masked operands read stale slots
     __syncthreads();
     // workgroups go to the 8 XCDs round-robin by their linear id, each XCD has its own L2: give every XCD one contiguous
@@ -2065,7 +2067,7 @@ k_featurize(FeatArgs A) {
             if (f_first != erow_frame) {                          // block-uniform
                 __syncthreads();
                 if (erow_frame >= 0)
-                    for (int q = tid; q < F; q += WPB * WAVE) {
+                    for (int q = tid; q < FE; q += WPB * WAVE) {
                         double v = erow[q];
                         if (v != 0.0) { unsafeAtomicAdd(A.x_e + (size_t)erow_frame * F + q, v); erow[q] = 0.0; }
                     }
@@ -2178,7 +2180,7 @@ k_featurize(FeatArgs A) {
     if (e_lds) {
         __syncthreads();
         if (erow_frame >= 0)
-            for (int q = tid; q < F; q += WPB * WAVE) {
+            for (int q = tid; q < FE; q += WPB * WAVE) {
                 double v = erow[q];
                 if (v != 0.0) unsafeAtomicAdd(A.x_e + (size_t)erow_frame * F + q, v);
             }
