@@ -1453,7 +1453,8 @@ extern "C" int uf3_featurize_dev(uf3_basis *b, const uf3_frames *fr, const doubl
                 const size_t lds = (e_d + rows_d + WPB * (list_d + tq_d + stage_d)) * 8 + ints * 4 + (size_t)b->n_f3src * 2 + 32;
                 if (lds > 160 * 1024 - 512) return fail(c, UF3_EOVERFLOW, "featurizer LDS footprint exceeds 160 KB (F or neighbour count too large)");
                 int per_cu = std::max(1, std::min(8, (int)((size_t)(160 * 1024) / lds)));
-                int n_blocks = std::min((P.natoms + WPB - 1) / WPB, c->n_cu * per_cu * 24);
+                const int bps = getenv("UF3_F3_BPS") ? std::max(1, atoi(getenv("UF3_F3_BPS"))) : 24;
+                int n_blocks = std::min((P.natoms + WPB - 1) / WPB, c->n_cu * per_cu * bps);
                 int apb = ((P.natoms + n_blocks - 1) / n_blocks + WPB - 1) / WPB * WPB;
                 n_blocks = (P.natoms + apb - 1) / apb;
                 G.atoms_per_block = apb;

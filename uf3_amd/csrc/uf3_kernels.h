@@ -2253,7 +2253,11 @@ __device__ __forceinline__ bool trio_value(const BasisDev *B, const double *c3, 
     int il = load_interval_guess<1>(recs, l0, rl, kl), im = load_interval_guess<1>(recs, l1, rm, km), in = load_interval_guess<1>(recs, l2, rn, kn);
     il = load_interval_fix<1>(recs, l0, rl, il, kl); im = load_interval_fix<1>(recs, l1, rm, im, km); in = load_interval_fix<1>(recs, l2, rn, in, kn);
     int mn = dim_m * dim_n;
+#ifdef UF3_ABLATE_EVAL_COEF
+    const double *c = c3 + lut_off + ((il - 3) * mn + (im - 3) * dim_n + (in - 3)) * 0;      // (experiment: every lane the same rows)
+#else
     const double *c = c3 + lut_off + (il - 3) * mn + (im - 3) * dim_n + (in - 3);
+#endif
     typedef double coeff4 __attribute__((ext_vector_type(4), aligned(8)));
     coeff4 cc[EVAL_CGROUP];
 #pragma unroll
@@ -2448,6 +2452,9 @@ k_eval(EvalArgs A) {
             double rn = norm3_leg(ox[bb] - ox[aa], oy[bb] - oy[aa], oz[bb] - oz[aa]);
             int trio = B->trio_of[(sm * UF3_MAX_SPECIES + ospec[aa]) * UF3_MAX_SPECIES + ospec[bb]];
             double val, gr[3];
+#if defined(UF3_ABLATE_EVAL) && UF3_ABLATE_EVAL == 1
+            if (rl > 0) continue;           // (experiment: no triplet values)
+#endif
             if (!trio_value(B, A.c3, trio, rl, rm, rn, want_f || want_v, val, gr)) continue;
             e += val;
             if (want_f) {   // F_m = -dV/dR_m = gl * u_ij + gm * u_ik
