@@ -63,9 +63,10 @@ template <int EF, int NR>
 struct F3Cfg {
     static constexpr int PS = 32 * NR;                           // positions per fixed-leg row in the fold's dump
     static constexpr int EFP = (EF + 1) & ~1;                    // dense bond values of a neighbour-role record, padded
-    static constexpr int RS_N = EFP + 16;                        // doubles per neighbour-role record: B(r_ek)[ext_p] | (a3 B_n', B_n) x 4
+    static constexpr int RS_N = EFP + 16 + (NR == 1 ? 2 : 0);    // doubles per neighbour-role record: B(r_ek)[ext_p] | (a3 B_n', B_n) x 4 (| pad: 44 dwords apart, the
+                                                                 // eight lanes of a 16-byte store group hit different banks)
     static constexpr int RS_C = NR == 1 ? 10 : (NR == 2 ? 12 : 14);   // ... per centre-role record: B_n over the n window (ext_n < RS_C), zero-padded
-    static constexpr int NREC = 32;                              // neighbour-role records per engine pass
+    static constexpr int NREC = NR == 1 ? 29 : 32;               // neighbour-role records per engine pass
     static constexpr int DUMP = NR == 1 ? 4 * EF * 32 : 2 * (EF * PS + 2);   // the fold's dump: pairs of all four rows | one component per half at a time
     static constexpr int STAGE0 = 64 * RS_C > NREC * RS_N ? 64 * RS_C : NREC * RS_N;
     static constexpr int STAGE = (STAGE0 > DUMP ? STAGE0 : DUMP) + 4;  // + a quad of zeros
