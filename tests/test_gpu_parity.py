@@ -1234,7 +1234,7 @@ def test_matrix_core_and_generic_trio_kernels_agree(which, bit):
     assert rel_err(xe_m, xe_g) < 1e-12 and rel_err(xf_m, xf_g) < 1e-12
     # round 4: the bond-factorised launch (k_featurize3, mode bit 12) where the basis qualifies -- a third, independent traversal
     xe_b, xf_b, modes_b = _fresh_rows(basis, frames)
-    assert bool(modes_b & 0x1000) == (which in ("notebook_binary", "four_by_four", "six_by_six", "five_by_five_unary")), hex(modes_b)
+    assert bool(modes_b & 0x1000) == (which in ("notebook_binary", "default_resolution", "h2o_golden", "four_by_four", "six_by_six", "five_by_five_unary")), hex(modes_b)
     assert rel_err(xe_b, xe_m) < 1e-12 and rel_err(xf_b, xf_m) < 1e-12
     assert worst_elementwise(xf_b, xf_m, rtol=1e-9, floor=1e-12) <= 1.0
     ob = O.OracleBasis(basis)

@@ -704,11 +704,12 @@ extern "C" int uf3_basis_create(uf3_ctx *c, const uf3_basis_spec *s, uf3_basis *
             // the instantiated shapes (rows of the centre-leg window, rounds of 32 positions): (3, 1) (4, 2) (5, 3) (6, 3)
             const int ep = t0.ext[0], en = t0.ext[2], np = ep * en;
             // (a round of 32 positions holds whole rows of the summed leg: 32 / ext_n of them)
-            b->f3_nr = ep == 3 ? 1 : (ep == 4 ? 2 : 3);
+            b->f3_nr = ep <= 3 ? 1 : (ep == 4 ? 2 : 3);          // (windows of one or two rows -- the reference's default resolution
+                                                                  // keeps 2 x 2 x 7 bins -- run in the three-row launch)
             const int prr = en > 0 && en <= 32 ? std::min(ep, 32 / en) : 0;
             (void)np;
             const bool shape = prr > 0 && prr * b->f3_nr >= ep &&
-                               ((ep == 3 && prr * en <= 31 && en <= 9) || (ep == 4 && en <= 11) || ((ep == 5 || ep == 6) && en <= 13));
+                               ((ep >= 1 && ep <= 3 && prr * en <= 31 && en <= 9) || (ep == 4 && en <= 11) || ((ep == 5 || ep == 6) && en <= 13));
             ok = t0.lo[0] == t0.lo[1] && t0.ext[0] == t0.ext[1] && same_leg(t0.leg[0], t0.leg[1]) && shape &&
                  t0.leg[0].nk >= 8 && t0.leg[2].nk >= 8 && !(ep > 3 && getenv("UF3_NO_FEAT3_WIDE"));
             for (int t = 0; t < h.T && ok; t++) {
@@ -1438,7 +1439,7 @@ extern "C" int uf3_featurize_dev(uf3_basis *b, const uf3_frames *fr, const doubl
                 G.x_e = d_xe; G.x_f = d_xf; G.natoms = P.natoms; G.e_direct = A.e_direct; G.skip = A.skip;
                 const int S = b->host.S;
                 const bool e_lds = want_e && !A.e_direct;
-                const int ep = b->f3_ext_p, nr = b->f3_nr;
+                const int ep = std::max(3, b->f3_ext_p), nr = b->f3_nr;          // (rows of the launch's shape)
                 int stage = 0, nrec = 0;
                 switch (ep) {
                     case 3: stage = F3Cfg<3, 1>::STAGE; nrec = F3Cfg<3, 1>::NREC; break;
