@@ -133,3 +133,20 @@ def test_supercell_argument_accepts_lattice_tilings_only():
     assert check(out, geometry.get_supercell(out, r_cut=fz.r_cut)) is None
     with pytest.raises(ValueError):
         check(out, geometry.get_supercell(out, r_cut=3 * fz.r_cut))
+
+
+def test_bench_line_keeps_the_other_configurations_where_the_driver_looks():
+    """bench.py: the sub-lines of the other BASELINE configurations are repeated, compact, inside `roofline` (the driver's
+    parser drops `extra`), and the CPU baseline carries the calibrated estimate for the NumPy reference."""
+    import bench
+    extra = {"fit_w": dict(value=6900.0, unit="frames/s", ms_per_step=18.5,
+                           roofline=dict(fp64=dict(frac=0.27), hbm=dict(frac=0.0004))),
+             "eval_50k": dict(value=1.1e8, unit="atom-steps/s", ms_per_step=0.45, roofline=dict(fp64=dict(frac=0.1), hbm=dict(frac=0.001)),
+                              cpu_baseline=dict(value=5700, unit="atom-steps/s")),
+             "lead0": dict(error="RuntimeError: boom")}
+    table = bench.compact_configs(extra)
+    assert table["fit_w"] == [6900.0, "frames/s", 18.5, 0.27, 0.0004]
+    assert table["eval_50k_cpu_port"][:2] == [5700, "atom-steps/s"] and table["lead0"][0] == "error"
+    assert table["columns"] == ["value", "unit", "ms_per_step", "fp64_frac", "hbm_frac"]
+    est = bench.reference_estimate(0.4, 4.8, 32)
+    assert est is None or (est["label"] == "estimate" and est["frames_per_s_all_cores"] == pytest.approx(4.8 / est["reference_to_port_ratio"]))
