@@ -2331,6 +2331,7 @@ k_eval(EvalArgs A) {
     double vir[6] = {0, 0, 0, 0, 0, 0};
     double pm[3] = {A.pos[3 * (size_t)m], A.pos[3 * (size_t)m + 1], A.pos[3 * (size_t)m + 2]};
     double e = 0.0, fx = 0.0, fy = 0.0, fz = 0.0;
+    PhaseClock pce;                   // (-DUF3_PHASE_TIMING builds only: tools/experiments/eval_phase.py)
     if (lane == 0) e = A.c1[sm];
     // 2-body: bonds inside their pair's range are queued in LDS and evaluated 64 at a time (about one candidate in
     // five survives the range test: evaluating in place would leave most lanes idle in the spline code)
@@ -2409,6 +2410,7 @@ k_eval(EvalArgs A) {
         }
     });
     drain(queued);
+    pce.lap(10);
     if (load_const(&B->T) > 0) {
         size_t base = (size_t)m * cap;
         int n;
@@ -2441,6 +2443,7 @@ k_eval(EvalArgs A) {
             }
         }
         __syncthreads();
+        pce.lap(11);
         int n_pairs = n * (n - 1) / 2;
         for (int p = lane; p < n_pairs; p += WAVE) {
             // (pair index -> (aa < bb) as in trio_walk_geom: hardware root + one guard each way, no loops)
@@ -2478,6 +2481,7 @@ k_eval(EvalArgs A) {
                 vir[5] += ta * ox[aa] * oy[aa] + tb * ox[bb] * oy[bb] + tc * cx * cy;
             }
         }
+        pce.lap(12);
         if (want_f && !GATHER) {
             __syncthreads();
             for (int q = lane; q < n; q += WAVE) {
@@ -2524,6 +2528,7 @@ k_eval(EvalArgs A) {
             }
         }
     }
+    pce.lap(13);
     e = wave_sum(e);
     if (lane == 0) A.e_atom[m] = e;
     if (want_v) {
