@@ -171,6 +171,18 @@ k_prepare_small(const BasisDev *B, const FrameGeom *geoms, const int64_t *atom_o
     }
     __syncthreads();
     if (outside) flags[4] = 1;                                    // (after the barrier: thread 0 has zeroed it)
+    if (natoms <= 256) {
+        // an MD-step cell: rank sort -- every thread counts the keys below its own (distinct keys: the rank is the slot) with
+        // broadcast reads, one barrier instead of the bitonic network's log^2 n
+        __shared__ unsigned long long sorted[256];
+        const unsigned long long mine = tid < natoms ? keys[tid] : ~0ull;
+        int rank = 0;
+        for (int b = 0; b < natoms; b++) rank += keys[b] < mine;
+        if (tid < natoms) sorted[rank] = mine;
+        __syncthreads();
+        if (tid < natoms) keys[tid] = sorted[tid];
+        __syncthreads();
+    } else
     for (int size = 2; size <= n_pow2; size <<= 1)
         for (int stride = size >> 1; stride > 0; stride >>= 1) {
             for (int t = tid; t < n_pow2 / 2; t += nt) {
