@@ -13,6 +13,7 @@
 #include "../../include/uf3_hip.h"
 #include "uf3_kernels.h"
 #include "uf3_feat3.h"
+#include <chrono>
 
 // ------------------------------------------------------------------------------ plumbing
 struct Buf {
@@ -40,7 +41,7 @@ struct PinBuf {
         if (p) hipHostFree(p);
         p = nullptr; cap = 0;
         size_t want = std::max(bytes, (size_t)4096);
-        hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+        hipError_t e = hipHostMalloc(&p, want, hipHostMallocCoherent);   // (fine-grained: kernels read and write these blocks in flight)
         if (e == hipSuccess) cap = want;
         return e;
     }
@@ -84,6 +85,8 @@ struct uf3_ctx {
     std::string async_msg;
     bool frag_ready = false;
     int32_t *d_stage_z = nullptr;       // species of the staged batch (tail of stage_pos)
+    unsigned eval_seq = 0;              // sequence number of the last small evaluator call whose tail kernel signals through the pinned block
+    bool tail_signalled = false;        // ... and whether the last eval_impl's k_frame_sum signals
     bool pin_in_busy = false;           // a kernel that reads pin_in directly has been launched and not yet waited for
     size_t pin_in_pending = 0;          // small batch: bytes of positions | species waiting in pin_in; the cell-list
                                         // stage appends the frame geometry and sends everything in ONE copy
@@ -1638,6 +1641,7 @@ static int eval_impl(uf3_basis *b, const uf3_frames *fr, const double *d_pos, co
     {
         Timed tm(c, T_EVAL);
         for (int attempt = 0; ; attempt++) {
+            c->tail_signalled = false;
             if (fuse) {
                 rc = n3_alloc(c, P.natoms, c->n3_cap, A.n3);
                 if (rc) return rc;
@@ -1670,9 +1674,16 @@ static int eval_impl(uf3_basis *b, const uf3_frames *fr, const double *d_pos, co
             }
             // (one workgroup per frame and component: wide for big frames, the loop is a latency chain)
             const int sum_threads = P.natoms / P.n_frames >= 2048 ? 1024 : 256;
+            // (into the caller's pinned block: the launch's last workgroup signals the host itself; flags[12] counts workgroups)
+            unsigned seq = 0;
+            if (mirror && !getenv("UF3_NO_TAIL_SPIN")) {
+                if (++c->eval_seq == 0) c->eval_seq = 1;
+                seq = c->eval_seq;
+                c->tail_signalled = true;
+            }
             hipLaunchKernelGGL(k_frame_sum, dim3(P.n_frames, d_virials ? 7 : 1), dim3(sum_threads), 0, st, A.e_atom,
                                A.virial, P.d_offsets, d_energies, d_virials, (const int *)c->flags.as<int>(), flags_tail,
-                               mirror, (const double *)d_forces, d_forces ? 3 * P.natoms : 0, (int)atom_begin, (int)atom_end);
+                               mirror, (const double *)d_forces, d_forces ? 3 * P.natoms : 0, (int)atom_begin, (int)atom_end, seq, c->flags.as<int>() + 12);
             if (fuse && !deferred_cap) {
                 // the lists were part of this launch: did they fit?  (Asked after everything is queued -- all kernels
                 // are safe on clipped lists -- so that the GPU does not idle while the host looks.)
@@ -1725,19 +1736,32 @@ static int eval_host(uf3_basis *b, const uf3_frames *fr, const double *pos, cons
         // small batch (an MD step): results and the neighbour stage's status words come back in ONE download and ONE
         // wait -- the lists are built at the remembered capacity and the evaluation runs on them right away; if they
         // overflowed (or a species / wrap error was flagged) the results are discarded and the call repeated / failed
-        HIPCHK(c, c->pin_out.ensure(total + 16));
+        HIPCHK(c, c->pin_out.ensure(total + 32));
         int *d_flags_tail = (int *)((char *)c->stage_out.p + total);
         for (int attempt = 0; attempt < 6; attempt++) {
             int cap_used = 0;
             // (up to the one-workgroup cell-list limit the last kernel writes the results into the pinned block itself; the
             // mirror's layout has the forces right behind the 7 nf sums, as d_e does)
             const bool zero_copy = natoms <= UF3_SMALL_ATOMS && !getenv("UF3_NO_ZERO_COPY");
+            *(volatile unsigned *)((char *)c->pin_out.p + total + 16) = 0;
             rc = eval_impl(b, fr, c->stage_pos.as<double>(), c->d_stage_z, c1, c2, c3, d_e, forces ? d_f : nullptr,
                            virials ? d_v : nullptr, atom_begin, atom_end, &cap_used, d_flags_tail,
                            zero_copy ? (double *)c->pin_out.p : nullptr, centre_share);
             if (rc) return rc;
             if (!zero_copy) HIPCHK(c, hipMemcpyAsync(c->pin_out.p, d_e, total + 16, hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(c, hipStreamSynchronize(c->stream));
+            bool arrived = false;
+            if (zero_copy && c->tail_signalled) {
+                // the tail kernel's last store, behind a system-scope fence, is this call's sequence number: poll the pinned
+                // block for it (a few us sooner than the stream's completion signal reaches the host); bounded, then the
+                // ordinary wait
+                const unsigned *word = (const unsigned *)((const char *)c->pin_out.p + total + 16);
+                const auto t_end = std::chrono::steady_clock::now() + std::chrono::milliseconds(2);
+                for (int spin = 0; !arrived; spin++) {
+                    arrived = __atomic_load_n(word, __ATOMIC_ACQUIRE) == c->eval_seq;
+                    if (!arrived && (spin & 255) == 255 && std::chrono::steady_clock::now() > t_end) break;
+                }
+            }
+            if (!arrived) HIPCHK(c, hipStreamSynchronize(c->stream));
             c->pin_in_busy = false;
             poll_pending(c, true);           // (remembered, see above)
             {

@@ -2555,40 +2555,46 @@ k_eval(EvalArgs A) {
 // second pass of the two-pass evaluator: 16 lanes per atom m; for every entry (centre c, image shift s) of m's list the
 // lanes look m up in c's list (entry with parent m and shift -s: the lists are symmetric) and take what c's triplets put
 // on it; fixed lane order + a fixed shuffle tree: deterministic
+// (the 16 lanes of atom m; every lane returns the sum)
+__device__ __forceinline__ void eval_collect_atom(const EvalArgs &A, int m, int sub, double &sx, double &sy, double &sz) {
+    const int cap = A.n3.cap, n = A.n3.cnt[m];
+    const int c_lo = A.halo_mark ? A.atom_lo : 0, c_hi = A.halo_mark ? A.atom_hi : A.natoms;
+    const N3Entry *mine = A.n3.ent + (size_t)m * cap;
+    sx = 0.0; sy = 0.0; sz = 0.0;
+    // lanes <-> own entries; each lane scans its centre's list (independent loads: three dependent round trips per
+    // entry instead of three per list position)
+    for (int q = sub; q < n; q += 16) {
+        const int2 me = *(const int2 *)&mine[q].parent;
+        const int c = me.x;
+        if (c < c_lo || c >= c_hi) continue;               // (a centre outside the block: another rank's)
+        int s0, s1, s2;
+        unpack3(me.y, s0, s1, s2);
+        const int back = pack3(-s0, -s1, -s2), nc = A.n3.cnt[c];
+        const N3Entry *theirs = A.n3.ent + (size_t)c * cap;
+        int hit = -1;
+        for (int r0 = 0; r0 < nc; r0 += 8) {                // eight entries' keys in flight together (a plain loop waits for each)
+            int2 key[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) key[u] = *(const int2 *)&theirs[min(r0 + u, nc - 1)].parent;
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                if (r0 + u < nc && key[u].x == m && key[u].y == back) hit = r0 + u;
+        }
+        if (hit >= 0) {
+            const double *f = A.nbr_f + 3 * ((size_t)c * cap + hit);
+            sx += f[0]; sy += f[1]; sz += f[2];
+        }
+    }
+    for (int sh = 8; sh > 0; sh >>= 1) { sx += __shfl_xor(sx, sh, 16); sy += __shfl_xor(sy, sh, 16); sz += __shfl_xor(sz, sh, 16); }
+}
+
 __global__ void __launch_bounds__(256)
 k_eval_collect(EvalArgs A) {
     const int m = (int)((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3)) * 16 + (threadIdx.x >> 4), sub = threadIdx.x & 15;
     if (m < A.natoms && (!A.halo_mark || (m >= A.atom_lo && m < A.atom_hi) || A.halo_mark[m])) {
-        const int cap = A.n3.cap, n = A.n3.cnt[m];
-        const int c_lo = A.halo_mark ? A.atom_lo : 0, c_hi = A.halo_mark ? A.atom_hi : A.natoms;
-        const N3Entry *mine = A.n3.ent + (size_t)m * cap;
-        double sx = 0.0, sy = 0.0, sz = 0.0;
-        // lanes <-> own entries; each lane scans its centre's list (independent loads: three dependent round trips per
-        // entry instead of three per list position)
-        for (int q = sub; q < n; q += 16) {
-            const int2 me = *(const int2 *)&mine[q].parent;
-            const int c = me.x;
-            if (c < c_lo || c >= c_hi) continue;               // (a centre outside the block: another rank's)
-            int s0, s1, s2;
-            unpack3(me.y, s0, s1, s2);
-            const int back = pack3(-s0, -s1, -s2), nc = A.n3.cnt[c];
-            const N3Entry *theirs = A.n3.ent + (size_t)c * cap;
-            int hit = -1;
-            for (int r0 = 0; r0 < nc; r0 += 8) {                // eight entries' keys in flight together (a plain loop waits for each)
-                int2 key[8];
-#pragma unroll
-                for (int u = 0; u < 8; u++) key[u] = *(const int2 *)&theirs[min(r0 + u, nc - 1)].parent;
-                asm volatile("" ::: "memory");
-#pragma unroll
-                for (int u = 0; u < 8; u++)
-                    if (r0 + u < nc && key[u].x == m && key[u].y == back) hit = r0 + u;
-            }
-            if (hit >= 0) {
-                const double *f = A.nbr_f + 3 * ((size_t)c * cap + hit);
-                sx += f[0]; sy += f[1]; sz += f[2];
-            }
-        }
-        for (int sh = 8; sh > 0; sh >>= 1) { sx += __shfl_xor(sx, sh, 16); sy += __shfl_xor(sy, sh, 16); sz += __shfl_xor(sz, sh, 16); }
+        double sx, sy, sz;
+        eval_collect_atom(A, m, sub, sx, sy, sz);
         if (sub == 0) { double *f = A.forces + 3 * (size_t)m; f[0] += sx; f[1] += sy; f[2] += sz; }
     }
 }
@@ -2599,9 +2605,38 @@ k_eval_collect(EvalArgs A) {
 // one download)
 // (mirror: the caller's pinned result block, energies [nf] | virials [nf][6] | forces [n_force] | status words -- device-visible
 // host memory, written here directly so that a small batch needs no copy-engine transfer behind its last kernel)
+// (one per-frame sum by the first `width_t` threads of the workgroup -- every thread of the workgroup calls; the order of
+// the additions depends on width_t only)
+__device__ __forceinline__ double frame_sum_tree(const double *src, int width, int64_t a0, int64_t a1, int width_t, double *part) {
+    double s = 0.0;
+    if ((int)threadIdx.x < width_t) {
+        // (eight loads in flight per trip, added in the order a plain loop adds them: the loop was a chain of dependent round
+        // trips, 16 us for a 50 k-atom frame)
+        int64_t a = a0 + threadIdx.x;
+        const int64_t bd = width_t;
+        for (; a + 7 * bd < a1; a += 8 * bd) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) v[u] = src[(a + u * bd) * width];
+#pragma unroll
+            for (int u = 0; u < 8; u++) s += v[u];
+        }
+        for (; a < a1; a += bd) s += src[a * width];
+        part[threadIdx.x] = s;
+    }
+    __syncthreads();
+    for (int w = width_t / 2; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) part[threadIdx.x] += part[threadIdx.x + w];
+        __syncthreads();
+    }
+    const double r = part[0];
+    __syncthreads();
+    return r;
+}
+
 __global__ void k_frame_sum(const double *e_atom, const double *v_atom, const int64_t *atom_offsets, double *e_out,
                             double *v_out, const int *flags_src, int *flags_dst, double *mirror, const double *forces,
-                            int n_force, int a_lo, int a_hi) {
+                            int n_force, int a_lo, int a_hi, unsigned seq, int *tail_count) {
     __shared__ double part[1024];
     const int f = blockIdx.x, comp = (int)blockIdx.y - 1;
     if (flags_dst && f == 0 && comp < 0 && threadIdx.x < 4) flags_dst[threadIdx.x] = flags_src[threadIdx.x];
@@ -2612,30 +2647,27 @@ __global__ void k_frame_sum(const double *e_atom, const double *v_atom, const in
     }
     const double *src = comp < 0 ? e_atom : v_atom + comp;
     const int width = comp < 0 ? 1 : 6;
-    double s = 0.0;
     // (a share of a block of atoms: only [a_lo, a_hi) carries values)
     const int64_t a0 = max(atom_offsets[f], (int64_t)a_lo), a1 = min(atom_offsets[f + 1], (int64_t)a_hi);
-    // (eight loads in flight per trip, added in the order a plain loop adds them: the loop was a chain of dependent round trips,
-    // 16 us for a 50 k-atom frame)
-    int64_t a = a0 + threadIdx.x;
-    const int64_t bd = blockDim.x;
-    for (; a + 7 * bd < a1; a += 8 * bd) {
-        double v[8];
-#pragma unroll
-        for (int u = 0; u < 8; u++) v[u] = src[(a + u * bd) * width];
-#pragma unroll
-        for (int u = 0; u < 8; u++) s += v[u];
-    }
-    for (; a < a1; a += bd) s += src[a * width];
-    part[threadIdx.x] = s;
-    __syncthreads();
-    for (int w = blockDim.x / 2; w > 0; w >>= 1) {
-        if ((int)threadIdx.x < w) part[threadIdx.x] += part[threadIdx.x + w];
-        __syncthreads();
-    }
+    const double total = frame_sum_tree(src, width, a0, a1, (int)blockDim.x, part);
     if (threadIdx.x == 0) {
-        if (comp < 0) e_out[f] = part[0]; else v_out[(size_t)f * 6 + comp] = part[0];
-        if (mirror) { if (comp < 0) mirror[f] = part[0]; else mirror[gridDim.x + (size_t)f * 6 + comp] = part[0]; }
+        if (comp < 0) e_out[f] = total; else v_out[(size_t)f * 6 + comp] = total;
+        if (mirror) { if (comp < 0) mirror[f] = total; else mirror[gridDim.x + (size_t)f * 6 + comp] = total; }
+    }
+    // (seq != 0: a launch into the caller's pinned block -- the last store of its last workgroup, behind system-scope fences, is
+    // the call's sequence number, which the host entry polls for instead of waiting for the stream's completion signal)
+    if (seq) {
+        __shared__ int last;
+        __threadfence_system();
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int n_blocks = (int)(gridDim.x * gridDim.y);
+            last = n_blocks == 1 || atomicAdd(tail_count, 1) == n_blocks - 1;
+            if (last) {
+                if (n_blocks > 1) { *tail_count = 0; __threadfence_system(); }
+                __hip_atomic_store((unsigned *)(mirror + 7 * (size_t)gridDim.x + n_force) + 4, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
     }
 }
 
