@@ -135,7 +135,18 @@ def main(argv=None):
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # (RCCL prints its version banner on stdout when the first communicator comes up: file descriptor 1 points at stderr
+        # until then, so that this program's stdout stays the ONE JSON line)
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.barrier()
+            torch.cuda.synchronize()
+        finally:
+            os.dup2(saved_stdout, 1)
+            os.close(saved_stdout)
         assert dist.get_world_size() == world == args.gpus
     else:
         torch.cuda.set_device(0)
