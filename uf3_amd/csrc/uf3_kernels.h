@@ -121,6 +121,82 @@ k_prepare_small(const BasisDev *B, const FrameGeom *geoms, const int64_t *atom_o
     // block (device-visible host memory): this workgroup fetches them itself -- a few KB over the link -- instead of waiting for
     // a copy engine's transfer in front of it (one dependent step of an MD call less).  pos, z, geoms, atom_offsets point into
     // dev_block, where the later kernels read them.
+    if (n_frames == 1 && natoms <= 256 && nt >= natoms) {
+        // One cell of an MD step, one atom per thread, every fetch of the kernel in flight at once: the staging block's copy
+        // for the later kernels, the thread's own atom and the frame geometry straight from the staging block, the species
+        // table from the basis; then one barrier, the bins, a rank sort (every thread counts the keys below its own -- distinct
+        // keys: the rank is the slot) and the slot record written from the registers the atom arrived in.  Three dependent
+        // memory round trips less than the general path below.
+        __shared__ int geom_words[(sizeof(FrameGeom) + 3) / 4];
+        __shared__ int z2s_words[30];
+        const long long to_host = host_block ? (const char *)host_block - (const char *)dev_block : 0;
+        const double *hpos = (const double *)((const char *)pos + to_host);
+        const int32_t *hz = (const int32_t *)((const char *)z + to_host);
+        const int *hgeom = (const int *)((const char *)geoms + to_host);
+        double x = 0, y = 0, w = 0;
+        int zz = 0;
+        if (tid < natoms) { x = hpos[3 * tid]; y = hpos[3 * tid + 1]; w = hpos[3 * tid + 2]; zz = hz[tid]; }
+        if (tid < (int)(sizeof(FrameGeom) / 4)) geom_words[tid] = hgeom[tid];
+        if (tid < 30) z2s_words[tid] = ((const int *)B->z2s)[tid];
+        if (host_block) for (int q = tid; q < block_int4s; q += nt) dev_block[q] = host_block[q];
+        if (tid < n_zero_flags) flags[1 + tid] = 0;
+        if (tid == 0) { flags[3] = 0; flags[4] = 0; }
+        __syncthreads();
+        const FrameGeom &g = *(const FrameGeom *)geom_words;
+        unsigned long long key = ~0ull;
+        bool outside = false;
+        int ws = 0;
+        if (tid < natoms) {
+            frame_of[tid] = 0;
+            int sp = (zz >= 0 && zz < 120) ? ((const signed char *)z2s_words)[zz] : -1;
+            if (sp < 0) { atomicExch(flags, 2); sp = 0; }
+            spec[tid] = (signed char)sp;
+            int bin[3], wrap[3];
+            for (int k = 0; k < 3; k++) {
+                double f = x * g.inv[k] + y * g.inv[3 + k] + w * g.inv[6 + k];
+                outside |= f < g.win_lo[k] || f > g.win_hi[k];
+                if (g.per[k]) {
+                    double fl = floor(f);
+                    int b = (int)((f - fl) * g.nb[k]);
+                    bin[k] = b >= g.nb[k] ? g.nb[k] - 1 : (b < 0 ? 0 : b);
+                    wrap[k] = (int)fl;
+                    if (wrap[k] < -250 || wrap[k] > 250) { atomicExch(flags, 1); wrap[k] = 0; }
+                } else {
+                    long long q = (long long)floor(f / g.binw[k]);
+                    int b = (int)(q % g.nb[k]);
+                    bin[k] = b < 0 ? b + g.nb[k] : b;
+                    wrap[k] = 0;
+                }
+            }
+            const int lb = (bin[0] * g.nb[1] + bin[1]) * g.nb[2] + bin[2];
+            atom_bin[tid] = lb;
+            atom_wrap[tid] = pack3(wrap[0], wrap[1], wrap[2]);
+            ws = pack_ws(wrap[0], wrap[1], wrap[2], sp);
+            key = ((unsigned long long)(unsigned)(g.bin_base + lb) << 32) | (unsigned)tid;
+        }
+        keys[tid] = key;
+        __syncthreads();
+        if (outside) flags[4] = 1;                                // (after a barrier: thread 0 has zeroed it)
+        int rank = 0;
+        for (int b = 0; b < natoms; b++) rank += keys[b] < key;
+        __shared__ unsigned long long sorted[256];
+        if (tid < natoms) {
+            sorted[rank] = key;
+            SlotRec r;
+            r.x = x; r.y = y; r.z = w; r.atom = tid; r.ws = ws;
+            slots[rank] = r;
+        }
+        __syncthreads();
+        for (int b = tid; b <= nbins; b += nt) {                  // first slot with bin >= b
+            int lo = 0, hi = natoms;
+            while (lo < hi) {
+                int mid = (lo + hi) >> 1;
+                if ((int)(sorted[mid] >> 32) < b) lo = mid + 1; else hi = mid;
+            }
+            bin_start[b] = lo;
+        }
+        return;
+    }
     if (host_block) {
         for (int q = tid; q < block_int4s; q += nt) dev_block[q] = host_block[q];
         __syncthreads();
