@@ -2212,8 +2212,8 @@ k_featurize(FeatArgs A) {
                 *c = sqrt(*c);
             }
             wave_sync();
-            pair_rows<WANT_E, WANT_F, RECS_LDS>(A, B, recs, w, m, sm, n_cand, es);
-            if (A.build_n3) build_n3_list(A, B, g, w, m, n_cand);
+            if (!UF3_SKIP(512)) pair_rows<WANT_E, WANT_F, RECS_LDS>(A, B, recs, w, m, sm, n_cand, es);
+            if (A.build_n3 && !UF3_SKIP(1024)) build_n3_list(A, B, g, w, m, n_cand);
         }
         // ---- 3-body ---------------------------------------------------------------------------
         if (MODE != 0 && n_trios > 0) {
