@@ -309,6 +309,16 @@ __device__ __forceinline__ int wave_scan_incl(int v) {
     v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);    // row_bcast:31 -> rows 2, 3
     return v;
 }
+// inclusive prefix maximum of non-negative values over the 64 lanes, same network
+__device__ __forceinline__ int wave_scan_max(int v) {
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true));
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true));
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true));
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true));
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false));
+    return v;
+}
 __device__ __forceinline__ int mbcnt(unsigned long long mask) {
     return __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
 }
@@ -361,20 +371,25 @@ __device__ __forceinline__ void for_each_candidate(const FrameGeom &g, const Cel
         const int incl = wave_scan_incl(len);
         const int total = __builtin_amdgcn_readlane(incl, WAVE - 1);
         const int rel = slot0 - (incl - len);                 // slot = rel + flat index, inside this run
-        const int last = min(WAVE, n_runs - r0) - 1;
-        // slot record and packed image shift of flat candidate idx.  The run of idx = the first run whose inclusive end lies
-        // beyond idx: binary search over the lanes' prefix sums (six shuffles; a linear count over up to 49 runs cost 75-150
-        // vector instructions per step).  Indices past the end read slot 0 (never used).
-        auto fetch = [&](int idx, SlotRec &sr, int &shpk) {
-            int run = 0, run_hi = last;
-#pragma unroll
-            for (int it = 0; it < 6; it++) {
-                const int mid = (run + run_hi) >> 1;
-                const bool right = __shfl(incl, mid) <= idx;
-                run = right ? mid + 1 : run;
-                run_hi = right ? run_hi : mid;
-            }
-            run = min(run, last);
+        // (number of the first non-empty run behind each run; WAVE: none)
+        const unsigned long long nonempty = __ballot(len > 0);
+        const unsigned long long behind = lane < WAVE - 1 ? nonempty >> (lane + 1) : 0ull;
+        const int next_ne = behind ? lane + 1 + __builtin_ctzll(behind) : WAVE;
+        // slot record and packed image shift of the flat candidates wbase + lane (a window of 64).  The run of a candidate = the
+        // first non-empty run after the last run that ends at or before it: every non-empty run that ends inside the window
+        // pushes the number of its successor to the lane of its end (`ds_permute`: one crossbar trip, the ends of non-empty runs
+        // are distinct), an inclusive maximum over the lanes (DPP) spreads it, and the lanes before the first end take the run
+        // that contains wbase (one ballot).  (Before: a binary search over the lanes' prefix sums, six dependent shuffles.)
+        // Indices past the end read slot 0 (never used).
+        auto fetch = [&](int wbase, SlotRec &sr, int &shpk) {
+            const int idx = wbase + lane;
+            const int p = incl - wbase;
+            const bool sender = (len > 0) & (p > 0) & (p < WAVE);
+            const int got = __builtin_amdgcn_ds_permute((sender ? p : 0) << 2, sender ? next_ne + 1 : 0);
+            const unsigned long long holds = __ballot((len > 0) & (p > 0));        // non-empty runs that end behind wbase
+            const int first = holds ? __builtin_ctzll(holds) : 0;
+            const int reached = wave_scan_max(lane == 0 ? 0 : got);
+            const int run = min(reached ? reached - 1 : first, WAVE - 1);
             const int slot = __shfl(rel, run) + idx;
             shpk = __shfl(shp, run);
             sr = cl.slots[idx < total ? slot : 0];
@@ -382,12 +397,12 @@ __device__ __forceinline__ void for_each_candidate(const FrameGeom &g, const Cel
         // the records of step i + 1 are requested before step i is handed to f (its global round trip hides behind f's work)
         SlotRec sr_next;
         int shp_next;
-        if (total > 0) fetch(lane, sr_next, shp_next);
+        if (total > 0) fetch(0, sr_next, shp_next);
         for (int base = 0; base < total; base += WAVE) {
             const int idx = base + lane;
             SlotRec sr = sr_next;
             const int shpk = shp_next;
-            if (base + WAVE < total) fetch(idx + WAVE, sr_next, shp_next);
+            if (base + WAVE < total) fetch(base + WAVE, sr_next, shp_next);
             int sh0, sh1, sh2;
             unpack3(shpk, sh0, sh1, sh2);
             bool ok = idx < total;
