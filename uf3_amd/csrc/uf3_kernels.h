@@ -11,6 +11,9 @@
 //                     MODE 6 / 7  3-body windows of <= 32 rows on the fp64 matrix cores (7: three waves / SIMD)
 //                     MODE 8 / 9  ... of <= 64 / <= 128 rows
 //                     MODE 1-5    generic output-stationary 3-body kernels (wider windows)
+//   k_featurize3<E, EF, NR>   (uf3_feat3.h) the 3-body force rows of a basis that qualifies (mode bit 12), by bond
+//                     factorisation on the vector units: the launch the headline runs; the matrix-core modes above
+//                     then serve energy-only calls, batches with atoms far outside their cell and the other bases
 //   k_eval<GATHER, VIR>   energy + forces (+ virial) of a fitted model        one wave / atom: every triplet once at its
 //                     centre + k_eval_collect (whole batch), or gathered at its three atoms (a block of atoms)
 //   k_frame_sum       per-frame sums of the per-atom energies / virial shares
