@@ -1036,13 +1036,14 @@ static int n3_tune(uf3_ctx *c, const N3Lists &n3, int natoms) {
 
 // 3-body lists of the HALO of the block of atoms [lo, hi), whose own lists exist: the atoms outside the block that those
 // lists mention are marked and collected on the device (c->halo: marks [natoms] | indices [natoms] | count), then built
-static int build_halo_lists(uf3_basis *b, const Prepared &P, const N3Lists &n3, const double *d_pos, int lo, int hi) {
+static int build_halo_lists(uf3_basis *b, const Prepared &P, const N3Lists &n3, const double *d_pos, int lo, int hi,
+                            bool marks_zeroed = false) {
     uf3_ctx *c = b->ctx;
     hipStream_t st = c->stream;
     const int natoms = P.natoms, nb_ = hi - lo;
     HIPCHK(c, c->halo.ensure(sizeof(int) * ((size_t)natoms + 4)));
     int *mark = c->halo.as<int>(), *range = mark + natoms;
-    HIPCHK(c, hipMemsetAsync(mark, 0, sizeof(int) * (size_t)natoms, st));
+    if (!marks_zeroed) HIPCHK(c, hipMemsetAsync(mark, 0, sizeof(int) * (size_t)natoms, st));
     if (nb_ <= 0 || natoms - nb_ <= 0) return UF3_OK;
     const size_t lds = (size_t)n3.cap * (8 + 32 + 16);
     hipLaunchKernelGGL(k_mark_halo, dim3((nb_ + 3) / 4), dim3(256), 0, st, n3, lo, hi, mark, range);
@@ -1636,7 +1637,10 @@ static int eval_impl(uf3_basis *b, const uf3_frames *fr, const double *d_pos, co
     A.virial = d_virials ? A.e_atom + P.natoms : nullptr;
     A.nbr_f = nullptr; A.n3_need = nullptr; A.fuse_n3 = 0;
     A.halo_mark = nullptr;
-    if (centre_share && !whole && d_forces)      // (rows of atoms that no centre of the block touches: zero)
+    // (rows of atoms that no centre of the block touches: zero.  A block of centres with the fused list build zeroes rows, list
+    // counts and halo marks in ONE launch inside the loop below)
+    const bool zero3 = centres && fuse && !getenv("UF3_NO_HALO");
+    if (centre_share && !whole && d_forces && !zero3)
         HIPCHK(c, hipMemsetAsync(d_forces, 0, 24 * (size_t)P.natoms, st));
     {
         Timed tm(c, T_EVAL);
@@ -1657,14 +1661,21 @@ static int eval_impl(uf3_basis *b, const uf3_frames *fr, const double *d_pos, co
                 HIPCHK(c, c->nbr_f.ensure(24 * (size_t)P.natoms * cap));
                 A.nbr_f = c->nbr_f.as<double>();
                 const int64_t n_centres = atom_end - atom_begin;
-                if (centres && fuse) HIPCHK(c, hipMemsetAsync(A.n3.cnt, 0, sizeof(int) * (size_t)P.natoms, st));   // (lists not built: empty)
+                if (zero3) {
+                    HIPCHK(c, c->halo.ensure(sizeof(int) * ((size_t)P.natoms + 4)));
+                    const size_t words = 8 * (size_t)P.natoms;
+                    hipLaunchKernelGGL(k_zero3, dim3((unsigned)std::min<size_t>((words + 255) / 256, 4096)), dim3(256), 0, st,
+                                       (unsigned *)d_forces, 6 * (size_t)P.natoms, (unsigned *)A.n3.cnt, (size_t)P.natoms,
+                                       (unsigned *)c->halo.p, (size_t)P.natoms);
+                }
+                else if (centres && fuse) HIPCHK(c, hipMemsetAsync(A.n3.cnt, 0, sizeof(int) * (size_t)P.natoms, st));   // (lists not built: empty)
                 if (A.virial) hipLaunchKernelGGL((k_eval<false, true>), dim3((unsigned)((n_centres + 7) / 8 * 8)), dim3(64), lds, st, A);
                 else hipLaunchKernelGGL((k_eval<false, false>), dim3((unsigned)((n_centres + 7) / 8 * 8)), dim3(64), lds, st, A);
                 if (fuse && deferred_cap) *deferred_cap = (int)cap;
                 if (centres) {
                     // the block's lists exist now (this launch built them, or prepare did): the halo's, then the collection
                     // pass over block + halo
-                    if (fuse || getenv("UF3_NO_HALO")) { int rh = build_halo_lists(b, P, A.n3, d_pos, (int)atom_begin, (int)atom_end); if (rh) return rh; }
+                    if (fuse || getenv("UF3_NO_HALO")) { int rh = build_halo_lists(b, P, A.n3, d_pos, (int)atom_begin, (int)atom_end, zero3); if (rh) return rh; }
                     A.halo_mark = c->halo.as<int>();
                 }
                 hipLaunchKernelGGL(k_eval_collect, dim3((unsigned)(((P.natoms + 15) / 16 + 7) / 8 * 8)), dim3(256), 0, st, A);

@@ -452,6 +452,18 @@ k_mark_halo(N3Lists n3, int lo, int hi, int *mark, int *range) {
 }
 
 // largest list length of a batch (capacity tuning after the first build of a context)
+// three buffers zeroed by one launch (the decomposed evaluator's force rows, list counts and halo marks: three fills and
+// their launch gaps were a tenth of a rank's share at world 8)
+__global__ void __launch_bounds__(256)
+k_zero3(unsigned *p0, size_t n0, unsigned *p1, size_t n1, unsigned *p2, size_t n2) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n0 + n1 + n2; i += stride) {
+        if (i < n0) p0[i] = 0u;
+        else if (i < n0 + n1) p1[i - n0] = 0u;
+        else p2[i - n0 - n1] = 0u;
+    }
+}
+
 __global__ void k_max_count(const int *cnt, int n, int *out) {
     int v = 0;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) v = max(v, cnt[i]);
@@ -2679,7 +2691,10 @@ __device__ __forceinline__ void eval_collect_atom(const EvalArgs &A, int m, int 
 
 __global__ void __launch_bounds__(256)
 k_eval_collect(EvalArgs A) {
-    const int m = (int)((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3)) * 16 + (threadIdx.x >> 4), sub = threadIdx.x & 15;
+    // (whole batch: one contiguous eighth of the atoms per XCD, as in k_eval.  A block of centres: the atoms with work are the
+    // block and its halo -- one contiguous stretch, which that mapping would hand to one or two XCDs: plain round-robin instead)
+    const int wg = A.halo_mark ? (int)blockIdx.x : (int)((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3));
+    const int m = wg * 16 + (threadIdx.x >> 4), sub = threadIdx.x & 15;
     if (m < A.natoms && (!A.halo_mark || (m >= A.atom_lo && m < A.atom_hi) || A.halo_mark[m])) {
         double sx, sy, sz;
         eval_collect_atom(A, m, sub, sx, sy, sz);
