@@ -451,7 +451,6 @@ k_mark_halo(N3Lists n3, int lo, int hi, int *mark, int *range) {
     }
 }
 
-// largest list length of a batch (capacity tuning after the first build of a context)
 // three buffers zeroed by one launch (the decomposed evaluator's force rows, list counts and halo marks: three fills and
 // their launch gaps were a tenth of a rank's share at world 8)
 __global__ void __launch_bounds__(256)
@@ -464,6 +463,7 @@ k_zero3(unsigned *p0, size_t n0, unsigned *p1, size_t n1, unsigned *p2, size_t n
     }
 }
 
+// largest list length of a batch (capacity tuning after the first build of a context)
 __global__ void k_max_count(const int *cnt, int n, int *out) {
     int v = 0;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) v = max(v, cnt[i]);
