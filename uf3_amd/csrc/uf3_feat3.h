@@ -122,14 +122,17 @@ __device__ __forceinline__ int f3_eval(const double *rows, const Feat3Leg &lg, d
     return iv;
 }
 
-template <bool WANT_E, int EF, int NR>
+// (CAP: the list capacity as a compile-time constant -- 16, what a tuned context settles on for bcc / fcc cells -- or 0 for
+// the launch's run-time value: with it every per-wave LDS array sits at a constant offset from two bases, offsets that go into
+// the LDS instructions' immediate fields instead of scalar registers the kernel has too few of)
+template <bool WANT_E, int EF, int NR, int CAP = 0>
 __global__ void __launch_bounds__(WPB * WAVE, (NR == 1 ? 4 : 2))
 k_featurize3(Feat3Args A) {
     typedef F3Cfg<EF, NR> Cfg;
     constexpr int RS_C = Cfg::RS_C, RS_N = Cfg::RS_N, NREC = Cfg::NREC, PS = Cfg::PS, EFP = Cfg::EFP;
     extern __shared__ __align__(16) unsigned char smem[];
     const BasisDev *B = A.B;
-    const int F = load_const(&B->F), S = load_const(&B->S), n_trios = load_const(&B->T), cap = A.n3.cap;
+    const int F = load_const(&B->F), S = load_const(&B->S), n_trios = load_const(&B->T), cap = CAP > 0 ? CAP : A.n3.cap;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // ---- LDS carve (feat3_lds_bytes on the host) ----------------------------------------------------------------------
@@ -150,9 +153,9 @@ k_featurize3(Feat3Args A) {
     double *stage = tq + tq_d;
     double *zq = stage + (Cfg::STAGE - 4);                            // a quad of zeros
     int *oparent = wi, *oshift = wi + cap, *noff = wi + 2 * cap, *nbase = noff + cap + 1, *so = nbase + cap + 1;
-    int *ospoff = so + (UF3_MAX_SPECIES + 2);
-    int *osbp = ospoff + (size_t)cap * (S + 1);                       // first window row of every own bond
+    int *osbp = so + (UF3_MAX_SPECIES + 2);                           // first window row of every own bond
     int *hdrs = osbp + cap;                       // [NREC + NREC] key | first n slot of the records of a pass
+    int *ospoff = hdrs + 2 * NREC;                // [cap][S + 1] (last: the only array whose place depends on S)
     const int sp_stride = S + 1;
     unsigned short *fsrc_l = (unsigned short *)((int *)(rows_lds + rows_d + (size_t)WPB * per_wave_d) + (((size_t)WPB * per_wave_i + 3) & ~(size_t)3));
 

@@ -1467,11 +1467,13 @@ extern "C" int uf3_featurize_dev(uf3_basis *b, const uf3_frames *fr, const doubl
                     fprintf(stderr, "uf3 featurize3: lds %zu B, cap %d, blocks %d x %d atoms, window %d x %d, %d round(s)\n", lds, cap, n_blocks, apb,
                             G.ext_p, G.ext_n, nr);
                 const unsigned grid = (unsigned)((n_blocks + 7) / 8 * 8);
-#define UF3_F3_LAUNCH(E, EFv, NRv)                                                                                          \
+#define UF3_F3_LAUNCH1(E, EFv, NRv, CAPv)                                                                                   \
     do {                                                                                                                   \
-        HIPCHK(c, hipFuncSetAttribute((const void *)k_featurize3<E, EFv, NRv>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        hipLaunchKernelGGL((k_featurize3<E, EFv, NRv>), dim3(grid), dim3(WPB * WAVE), lds, st, G);                          \
+        HIPCHK(c, hipFuncSetAttribute((const void *)k_featurize3<E, EFv, NRv, CAPv>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL((k_featurize3<E, EFv, NRv, CAPv>), dim3(grid), dim3(WPB * WAVE), lds, st, G);                    \
     } while (0)
+#define UF3_F3_LAUNCH(E, EFv, NRv)                                                                                          \
+    do { if (cap == 16 && !getenv("UF3_F3_NO_CAP16")) UF3_F3_LAUNCH1(E, EFv, NRv, 16); else UF3_F3_LAUNCH1(E, EFv, NRv, 0); } while (0)
                 switch (ep) {
                     case 3: if (want_e) UF3_F3_LAUNCH(true, 3, 1); else UF3_F3_LAUNCH(false, 3, 1); break;
                     case 4: if (want_e) UF3_F3_LAUNCH(true, 4, 2); else UF3_F3_LAUNCH(false, 4, 2); break;
@@ -1479,6 +1481,7 @@ extern "C" int uf3_featurize_dev(uf3_basis *b, const uf3_frames *fr, const doubl
                     default: if (want_e) UF3_F3_LAUNCH(true, 6, 3); else UF3_F3_LAUNCH(false, 6, 3); break;
                 }
 #undef UF3_F3_LAUNCH
+#undef UF3_F3_LAUNCH1
             }
         }
         HIPCHK(c, hipGetLastError());
@@ -1669,8 +1672,13 @@ static int eval_impl(uf3_basis *b, const uf3_frames *fr, const double *d_pos, co
                                        (unsigned *)c->halo.p, (size_t)P.natoms);
                 }
                 else if (centres && fuse) HIPCHK(c, hipMemsetAsync(A.n3.cnt, 0, sizeof(int) * (size_t)P.natoms, st));   // (lists not built: empty)
-                if (A.virial) hipLaunchKernelGGL((k_eval<false, true>), dim3((unsigned)((n_centres + 7) / 8 * 8)), dim3(64), lds, st, A);
-                else hipLaunchKernelGGL((k_eval<false, false>), dim3((unsigned)((n_centres + 7) / 8 * 8)), dim3(64), lds, st, A);
+                const dim3 eg((unsigned)((n_centres + 7) / 8 * 8));
+                if (cap == 16 && !getenv("UF3_EVAL_NO_CAP16")) {
+                    if (A.virial) hipLaunchKernelGGL((k_eval<false, true, 16>), eg, dim3(64), lds, st, A);
+                    else hipLaunchKernelGGL((k_eval<false, false, 16>), eg, dim3(64), lds, st, A);
+                }
+                else if (A.virial) hipLaunchKernelGGL((k_eval<false, true>), eg, dim3(64), lds, st, A);
+                else hipLaunchKernelGGL((k_eval<false, false>), eg, dim3(64), lds, st, A);
                 if (fuse && deferred_cap) *deferred_cap = (int)cap;
                 if (centres) {
                     // the block's lists exist now (this launch built them, or prepare did): the halo's, then the collection

@@ -2414,12 +2414,15 @@ __device__ __forceinline__ double wave_sum(double v) {
 #ifndef EVAL_MINW
 #define EVAL_MINW 3
 #endif
-template <bool GATHER, bool VIR>
+// (CAP: the list capacity as a compile-time constant -- 16, what a tuned context settles on for bcc / fcc cells -- or 0 for
+// the launch's run-time value: with it every LDS array of the one-wave workgroup sits at a constant address, in the LDS
+// instructions' immediate fields instead of scalar registers, of which the kernel spills 73)
+template <bool GATHER, bool VIR, int CAP = 0>
 __global__ void __launch_bounds__(64, EVAL_MINW)
 k_eval(EvalArgs A) {
     extern __shared__ __align__(16) unsigned char smem[];
     const BasisDev *B = A.B;
-    const int cap = A.n3.cap;
+    const int cap = CAP > 0 ? CAP : A.n3.cap;
     const KnotRec *recs_g = load_const(&B->recs);
     const int S = load_const(&B->S);
     double *ox = (double *)smem, *oy = ox + cap, *oz = oy + cap, *orr = oz + cap;
