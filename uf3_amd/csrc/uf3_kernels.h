@@ -143,7 +143,7 @@ k_prepare_small(const BasisDev *B, const FrameGeom *geoms, const int64_t *atom_o
         if (tid < 30) z2s_words[tid] = ((const int *)B->z2s)[tid];
         if (host_block) for (int q = tid; q < block_int4s; q += nt) dev_block[q] = host_block[q];
         if (tid < n_zero_flags) flags[1 + tid] = 0;
-        if (tid == 0) { flags[3] = 0; flags[4] = 0; }
+        if (tid == 0) { flags[3] = 0; flags[4] = 0; flags[12] = 0; }      // ([12]: k_frame_sum's count of finished workgroups -- left over by an aborted call otherwise)
         __syncthreads();
         const FrameGeom &g = *(const FrameGeom *)geom_words;
         unsigned long long key = ~0ull;
@@ -205,7 +205,7 @@ k_prepare_small(const BasisDev *B, const FrameGeom *geoms, const int64_t *atom_o
         __syncthreads();
     }
     if (tid < n_zero_flags) flags[1 + tid] = 0;                   // (n3_need, cand_need of the launches that follow)
-    if (tid == 0) { flags[3] = 0; flags[4] = 0; }                 // (extension-list need, "some atom outside its cell")
+    if (tid == 0) { flags[3] = 0; flags[4] = 0; flags[12] = 0; }  // (extension-list need, "some atom outside its cell", k_frame_sum's workgroup count)
     bool outside = false;
     int n_pow2 = 64;
     while (n_pow2 < natoms) n_pow2 <<= 1;
