@@ -354,6 +354,7 @@ def main(argv=None):
                                          f"frames x{world}, one all_reduce(SUM) of 2F'^2+2F'+6 doubles at the end")),
                    roofline=roofline, cpu_baseline=cpu)
         out["config"]["rccl_world_size"] = dist.get_world_size() if distributed else 1
+        out["config"]["forced_collective"] = bool(distributed and os.environ.get("UF3_FORCE_COLLECTIVE"))
         if world == 1 and not fit and wl == "c4" and args.atoms == 10000 and not args.no_extra:
             out["extra"] = extra_lines(dev, ctx, fz, frames, batch, d_pos, d_z, d_xe, d_xf,
                                        cpu=not args.no_cpu_baseline)
@@ -393,11 +394,15 @@ def eval_mode(args, torch, dist, dev, distributed, world, rank):
     common = (db.handle, C.byref(batch.struct), C.c_void_p(d_pos.data_ptr()), C.c_void_p(d_z.data_ptr()),
               _lib._p(calc._c1), _lib._p(calc._c2), _lib._p(calc._c3))
 
+    # UF3_FORCE_COLLECTIVE under the launcher with ONE rank: the decomposed route (a block of centres = the whole frame) and its
+    # all_reduce on the device buffer, so that a one-GPU box exercises what the ranks of an 8-GPU node run
+    forced = bool(distributed and os.environ.get("UF3_FORCE_COLLECTIVE"))
+
     def step():
-        if world == 1:
+        if world == 1 and not forced:
             ctx.check(ctx.lib.uf3_eval_virial_dev(*common, C.c_void_p(p_e), C.c_void_p(p_f), C.c_void_p(p_v)))
         else:
-            flat.zero_()            # (the _dev entry leaves rows outside block + halo untouched)
+            # (uf3_eval_centres_dev zeroes every force row itself and overwrites energy / strain derivative: nothing to clear)
             ctx.check(ctx.lib.uf3_eval_centres_dev(*common, lo, hi, C.c_void_p(p_e), C.c_void_p(p_f), C.c_void_p(p_v)))
             dist.all_reduce(flat, op=dist.ReduceOp.SUM)
 
@@ -440,8 +445,8 @@ def eval_mode(args, torch, dist, dev, distributed, world, rank):
                higher_is_better=True, scaling="strong", vs_baseline=None, dtype="f64", data="synthetic",
                config=dict(workload=f"C5: {n}-atom ternary bcc frame, 2+3-body notebook basis, F={int(basis.n_feats)}", mode="eval",
                            atoms_per_frame=n, sharding=(f"blocks of centres x{world}, one all_reduce(SUM) of 3N+7 doubles per step"
-                                                        if world > 1 else "whole frame on one GPU"),
-                           rccl_world_size=dist.get_world_size() if distributed else 1),
+                                                        if world > 1 or forced else "whole frame on one GPU"),
+                           rccl_world_size=dist.get_world_size() if distributed else 1, forced_collective=forced),
                roofline=_roof(n * (100.0 * PAIRS_PER_ATOM + 700.0 * TRIPLETS_PER_ATOM), 52.0 * n + 75 + 8.0 * len(calc._c3), dt,
                               "mfma", note="flops = N (100 p + 700 T): every triplet once at its centre"),
                cpu_baseline=cpu)

@@ -13,6 +13,8 @@
  *   uf3_gram[_dev]        <- uf3/regression/least_squares.py:716-760 (X^T X, X^T y)
  *   uf3_eval[_dev]        <- uf3/forcefield/calculator.py:156-343  (energy, forces)
  *   uf3_neighbors_debug   <- distances.py:48-69 / angles.py:289-346 index semantics
+ *   uf3_pair_geometry, uf3_distance_matrix, uf3_direction_cosines
+ *                         <- the free functions of distances.py:19-143, 212-235, 331-364 and angles.py:289-346
  *
  * Conventions
  *   - every function returns 0 on success, a non-zero UF3_E* code otherwise;
@@ -218,6 +220,8 @@ int uf3_eval_atoms_dev(uf3_basis *basis, const uf3_frames *frames, const double 
  * others zero.  Shares over disjoint ranges add up to uf3_eval_virial's results like those of uf3_eval_atoms, at a third
  * of the triplet work: what a rank of a decomposed frame computes before the one sum-reduce of
  * [energy | strain derivative | forces] (uf3_amd/parallel.py: sharded_evaluate).  forces / virials may be NULL.
+ * Both variants write EVERY row of `forces` (the _dev variant zeroes the whole array on the stream before it adds the
+ * shares): the caller does not clear the buffer between calls.
  */
 int uf3_eval_centres(uf3_basis *basis, const uf3_frames *frames, const double *pos, const int32_t *z,
                      const double *c1, const double *c2, const double *c3, int64_t atom_begin, int64_t atom_end,
@@ -236,6 +240,25 @@ int uf3_eval_centres_dev(uf3_basis *basis, const uf3_frames *frames, const doubl
 int uf3_neighbors_debug(uf3_basis *basis, const uf3_frames *frame, const double *pos, const int32_t *z,
                         int64_t *pair_count, int64_t *pair_ij, int64_t pair_cap,
                         int64_t *n3_count, int64_t *n3_ij, int64_t n3_cap);
+
+/*
+ * The same 2-body pairs with their geometry: pair_geo [P][pair_cap][4] = distance, then (R_j - R_i) / distance -- what
+ * distances_by_interaction / derivatives_by_interaction (distances.py:19-143) select out of the dense distance matrix
+ * and what compute_direction_cosines (:331-364) divides, as lists, in the order of pair_ij.  Caps of 0: counts only.
+ */
+int uf3_pair_geometry(uf3_basis *basis, const uf3_frames *frame, const double *pos, const int32_t *z,
+                      int64_t *pair_count, int64_t *pair_ij, double *pair_geo, int64_t pair_cap);
+
+/*
+ * Dense helpers behind the module-level functions of uf3.representation.distances / angles, for frames small enough
+ * for an n x m matrix (the reference's own limit).  Host buffers.
+ *   uf3_distance_matrix     out [na][nb] = |a_i - b_j| in scipy cdist's order of operations (get_distance_matrix,
+ *                           distances.py:212-235; identify_ij's matrix, angles.py:289-346)
+ *   uf3_direction_cosines   out [n_atoms][3][n_d] = ((m == j) - (m == i)) (R_j - R_i) / r_ij (distances.py:331-364)
+ */
+int uf3_distance_matrix(uf3_ctx *ctx, const double *a, int64_t na, const double *b, int64_t nb, double *out);
+int uf3_direction_cosines(uf3_ctx *ctx, const double *sup_pos, int64_t n_sup, const int64_t *i_where,
+                          const int64_t *j_where, const double *rij, int64_t n_d, int64_t n_atoms, double *out);
 
 #ifdef __cplusplus
 }

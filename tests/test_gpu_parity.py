@@ -648,6 +648,29 @@ def test_dense_neighbourhoods_and_capacity_regrowth():
     assert len(n3) / len(atoms) > 50
 
 
+def test_lists_too_long_for_the_bond_factorised_launch_fall_back():
+    """k_featurize3's LDS layout grows ~170-260 B per list entry and wave; lists of > ~100 (6 x 12 windows)
+    or > ~200 entries (default trims) do not fit 160 KB.  Such calls must run on the matrix-core / generic launches that
+    served them before, not fail with UF3_EOVERFLOW."""
+    # 6 x 12 windows, ~115 three-body neighbours per atom (cell edge 7.1 A >= 2 r_max3): against the oracle
+    basis = synthetic.notebook_basis(['Mo', 'W'], lead3=0)
+    atoms = synthetic.lattice_frame("bcc", (5, 5, 5), 1.42, [42, 74], 5, rattle=0.05, strain=0.0)
+    fz = process.BasisFeaturizer(basis)
+    assert fz._dev()[1].featurizer_modes & 0x1000                      # the basis qualifies; the lists do not
+    _, n3 = fz.neighbor_indices(atoms)
+    assert np.bincount(n3[:, 0]).max() > 100
+    _check_against_oracle(basis, [atoms])
+    # default trims, > 200 neighbours per atom: the default route against the generic kernels
+    basis3 = synthetic.notebook_basis(['W'])
+    dense = synthetic.lattice_frame("bcc", (7, 7, 7), 1.15, [74], 6, rattle=0.03, strain=0.0)
+    _, n3 = process.BasisFeaturizer(basis3).neighbor_indices(dense)
+    assert np.bincount(n3[:, 0]).max() > 200
+    xe_d, xf_d, modes_d = _fresh_rows(basis3, [dense])
+    xe_g, xf_g, modes_g = _fresh_rows(basis3, [dense], UF3_NO_FEAT3="1", UF3_NO_MFMA_FEAT="1")
+    assert (modes_d & 0x1000) and not (modes_g & 0x13c0)
+    assert rel_err(xe_d, xe_g) < 1e-11 and rel_err(xf_d, xf_g) < 1e-11
+
+
 def test_three_species_wide_blocks():
     """ternary, lead 0: 18 trio blocks of 139/233 columns (several 64-column chunks, nsrc 1 and 2)."""
     d, meta, atoms = load_case("case_ternary24_slab")
@@ -1584,3 +1607,31 @@ def test_two_gpu_decomposed_evaluation_over_rccl_matches_the_oracle(tmp_path):
         assert abs(float(d["e"]) - e_ref) <= TOL * max(1.0, abs(e_ref))
         assert worst_elementwise(d["f"], f_ref) <= 1.0
         assert np.allclose(d["v"], v1[0], rtol=1e-10, atol=1e-10) and rel_err(d["f"], f1) < 1e-12
+
+
+@pytest.mark.parametrize("mode", ["featurize", "fit", "eval"])
+def test_bench_under_the_launcher_runs_rccl_on_device_buffers(mode):
+    """every GPU test run initialises RCCL.  bench.py exactly as the driver starts it for N > 1
+    (torch.distributed.run, one rank per GPU, rendezvous on 127.0.0.1) with ONE rank and UF3_FORCE_COLLECTIVE=1: the
+    communicator comes up, the barrier / MAX-reduce run, and the data-path all_reduce (packed fit pieces; the decomposed
+    evaluator's [forces | energy | strain derivative]) is issued on the device buffer itself."""
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    argv = ["--gpus", "1", "--steps", "2", "--warmup", "1", "--mode", mode, "--no-cpu-baseline", "--no-extra", "--no-traffic"]
+    argv += ["--atoms", "2000"] + (["--frames-per-step", "4"] if mode != "eval" else [])
+    env = dict(os.environ, UF3_FORCE_COLLECTIVE="1", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4")
+    res = subprocess.run(bench.rank_command(1, argv, port), env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 1 and out["config"]["rccl_world_size"] == 1
+    assert out["config"].get("forced_collective") is True
+    assert np.isfinite(out["value"]) and out["value"] > 0

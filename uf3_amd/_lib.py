@@ -22,7 +22,8 @@ EXPORTS = ["uf3_ctx_create", "uf3_ctx_destroy", "uf3_ctx_set_stream", "uf3_ctx_s
            "uf3_featurize", "uf3_featurize_dev", "uf3_gram", "uf3_gram_dev",
            "uf3_eval", "uf3_eval_dev", "uf3_eval_virial", "uf3_eval_virial_dev", "uf3_eval_atoms", "uf3_eval_atoms_dev",
            "uf3_eval_centres", "uf3_eval_centres_dev",
-           "uf3_neighbors_debug", "uf3_fit_rows_dev", "uf3_fit_pack_dev", "uf3_gram_force_rows_dev"]
+           "uf3_neighbors_debug", "uf3_fit_rows_dev", "uf3_fit_pack_dev", "uf3_gram_force_rows_dev",
+           "uf3_pair_geometry", "uf3_distance_matrix", "uf3_direction_cosines"]
 
 
 class HipUnavailable(RuntimeError):
@@ -129,6 +130,9 @@ def load():
             getattr(lib, name).argtypes = [vp, C.POINTER(Frames), vp, vp, vp, vp, vp, i64, i64, vp, vp, vp]
         lib.uf3_neighbors_debug.argtypes = [vp, C.POINTER(Frames), vp, vp, vp, vp, i64, vp, vp, i64]
         lib.uf3_gram_force_rows_dev.argtypes = [vp, vp, vp, vp, i64, i64, i32, vp, vp]
+        lib.uf3_pair_geometry.argtypes = [vp, C.POINTER(Frames), vp, vp, vp, vp, vp, i64]
+        lib.uf3_distance_matrix.argtypes = [vp, vp, i64, vp, i64, vp]
+        lib.uf3_direction_cosines.argtypes = [vp, vp, i64, vp, vp, vp, i64, i64, vp]
         lib.uf3_fit_rows_dev.argtypes = [vp, i32, i32, vp, vp, vp, vp, i64, vp, vp, i32, vp]
         lib.uf3_fit_pack_dev.argtypes = [vp, i32, vp, vp, i32, vp, vp, i32, dbl, dbl, vp]
         _lib = lib
@@ -281,6 +285,83 @@ class DeviceBasis:
         mask = C.c_int32(0)
         self.ctx.check(self.ctx.lib.uf3_basis_featurizer_modes(self.handle, C.byref(mask)))
         return mask.value
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None) and os.getpid() == self._pid and self.ctx.handle:
+                self.ctx.lib.uf3_basis_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
+class RawDeviceBasis:
+    """Device tables from a hand-made description instead of a ``BSplineBasis``: what the module-level functions of
+    ``uf3_amd.representation.distances`` / ``angles`` need -- pair ranges without a spline space, or 3-body knot sets
+    whose raw L x M x N bins are the output columns (no symmetry fold, no template).
+
+    species_z   ascending atomic numbers
+    pairs       {(za, zb): (r_min, r_max)} for any subset of the S(S+1)/2 pairs (the others get an empty range)
+    trios       list of ((zc, za, zb), [l_knots, m_knots, n_knots], lut) -- lut: int32 [L*M*N] raw bin -> column of the
+                block or -1 -- in column order behind the one-body and pair columns
+    r_cut       image range of the reference supercell to reproduce
+    """
+
+    def __init__(self, species_z, pairs=None, trios=(), r_cut=None, ctx=None):
+        self.ctx = ctx or get_context()
+        zs = [int(z) for z in species_z]
+        assert zs == sorted(set(zs)) and zs, "species_z: ascending atomic numbers"
+        pairs = {tuple(sorted((int(a), int(b)))): v for (a, b), v in (pairs or {}).items()}
+        keep = {}
+        keep["species_z"] = np.array(zs, dtype=np.int32)
+        all_pairs = [(zs[i], zs[j]) for i in range(len(zs)) for j in range(i, len(zs))]
+        self.pairs = all_pairs
+        ranges = [pairs.get(p, (0.0, 0.0)) for p in all_pairs]
+        keep["pair_z"] = np.array(all_pairs, dtype=np.int32).reshape(-1, 2)
+        keep["pair_nk"] = np.full(len(all_pairs), 8, dtype=np.int32)
+        # (a spline space is not needed for neighbour queries: the shortest legal knot vector over the range)
+        keep["pair_knots"] = np.ascontiguousarray(np.concatenate(
+            [np.repeat([max(float(lo), 0.0), max(float(hi), max(float(lo), 0.0) + 1.0)], 4) for lo, hi in ranges]))
+        keep["pair_rmin"] = np.array([float(lo) for lo, _ in ranges])
+        keep["pair_rmax"] = np.array([float(hi) for _, hi in ranges])
+        col = len(zs)
+        keep["pair_col"] = np.arange(col, col + 4 * len(all_pairs), 4, dtype=np.int32)
+        col += 4 * len(all_pairs)
+        trio_col, trio_ncol, luts, knots, nk = [], [], [], [], []
+        for zt, ks, lut in trios:
+            ks = [np.asarray(k, dtype=np.float64) for k in ks]
+            lut = np.ascontiguousarray(lut, dtype=np.int32).ravel()
+            assert lut.size == int(np.prod([len(k) - 4 for k in ks]))
+            ncol = int(lut.max()) + 1 if lut.size and lut.max() >= 0 else 1
+            trio_col.append(col)
+            trio_ncol.append(ncol)
+            col += ncol
+            luts.append(lut)
+            knots.extend(ks)
+            nk.append([len(k) for k in ks])
+        self.trio_col, self.trio_ncol = trio_col, trio_ncol
+        keep["trio_z"] = np.array([list(zt) for zt, _, _ in trios], dtype=np.int32).reshape(-1, 3)
+        keep["trio_nk"] = np.array(nk, dtype=np.int32).reshape(-1, 3)
+        keep["trio_knots"] = np.ascontiguousarray(np.concatenate(knots)) if knots else np.zeros(1)
+        keep["trio_col"] = np.array(trio_col, dtype=np.int32)
+        keep["trio_ncol"] = np.array(trio_ncol, dtype=np.int32)
+        keep["trio_lut"] = np.ascontiguousarray(np.concatenate(luts)) if luts else np.zeros(1, np.int32)
+        s = BasisSpec()
+        s.n_species, s.n_pairs, s.n_trios = len(zs), len(all_pairs), len(trios)
+        for name in ("species_z", "pair_z", "pair_nk", "pair_knots", "pair_rmin", "pair_rmax", "pair_col",
+                     "trio_z", "trio_nk", "trio_knots", "trio_col", "trio_ncol", "trio_lut"):
+            setattr(s, name, _p(keep[name]))
+        s.lead2, s.trail2 = 0, 0
+        s.n_feat = col
+        if r_cut is None:
+            r_cut = max([float(hi) for _, hi in ranges] + [float(k[-1]) for k in knots] + [1e-6])
+        s.r_cut = float(r_cut)
+        self.spec, self._keep = s, keep
+        self.n_feat, self.n_species = col, len(zs)
+        h = C.c_void_p()
+        self.ctx.check(self.ctx.lib.uf3_basis_create(self.ctx.handle, C.byref(s), C.byref(h)))
+        self.handle = h
+        self._pid = os.getpid()
 
     def __del__(self):
         try:

@@ -4,6 +4,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -85,6 +86,9 @@ struct uf3_ctx {
     std::string async_msg;
     bool frag_ready = false;
     int32_t *d_stage_z = nullptr;       // species of the staged batch (tail of stage_pos)
+    // environment switches of the featurizer's asynchronous path, read once (uf3_ctx_create)
+    bool env_no_feat3 = false, env_f3_no_cap16 = false, env_debug_lds = false;
+    int env_f3_bps = 24;
     unsigned eval_seq = 0;              // sequence number of the last small evaluator call whose tail kernel signals through the pinned block
     bool tail_signalled = false;        // ... and whether the last eval_impl's k_frame_sum signals
     bool pin_in_busy = false;           // a kernel that reads pin_in directly has been launched and not yet waited for
@@ -175,6 +179,10 @@ extern "C" int uf3_ctx_create(int device, uf3_ctx **out) {
     HIPCHK(c, hipGetDeviceProperties(&prop, device));
     c->lds_max = (int)prop.sharedMemPerBlock;
     c->n_cu = prop.multiProcessorCount;
+    c->env_no_feat3 = getenv("UF3_NO_FEAT3") != nullptr;
+    c->env_f3_no_cap16 = getenv("UF3_F3_NO_CAP16") != nullptr;
+    c->env_debug_lds = getenv("UF3_DEBUG_LDS") != nullptr;
+    if (getenv("UF3_F3_BPS")) c->env_f3_bps = std::max(1, atoi(getenv("UF3_F3_BPS")));
     if (std::string(prop.gcnArchName).find("gfx950") == std::string::npos) {
         std::string m = std::string("uf3_hip is built for gfx950 only, device is ") + prop.gcnArchName;
         delete c;
@@ -1239,6 +1247,29 @@ static size_t feat_lds_bytes(int F, int S, int cap, int cand_cap, bool want_e, s
     return (e_d + WPB * per_wave_d) * 8 + ints * 4 + n_recs * sizeof(KnotRec) + 32;
 }
 
+// LDS footprint of k_featurize3 at list capacity cap (uf3_feat3.h): grows by ~168 B (3-row windows) to ~264 B (6-row windows)
+// per list entry and wave -- faster than the launches it replaces, so uf3_featurize_dev asks BEFORE it chooses the launch
+static void feat3_shape(const uf3_basis *b, int &ep, int &stage, int &nrec) {
+    ep = std::max(3, b->f3_ext_p);
+    switch (ep) {
+        case 3: stage = F3Cfg<3, 1>::STAGE; nrec = F3Cfg<3, 1>::NREC; break;
+        case 4: stage = F3Cfg<4, 2>::STAGE; nrec = F3Cfg<4, 2>::NREC; break;
+        case 5: stage = F3Cfg<5, 3>::STAGE; nrec = F3Cfg<5, 3>::NREC; break;
+        default: stage = F3Cfg<6, 3>::STAGE; nrec = F3Cfg<6, 3>::NREC; break;
+    }
+}
+static size_t feat3_lds_bytes(const uf3_basis *b, int cap, bool e_lds) {
+    int ep, stage, nrec;
+    feat3_shape(b, ep, stage, nrec);
+    const int F = b->host.F, S = b->host.S;
+    const size_t e_d = e_lds ? (size_t)F + (F & 1) : 0, rows_d = (size_t)b->n_f3rows * 18;
+    const size_t list_d = 5 * (size_t)cap + ((5 * cap) & 1), tq_d = (size_t)cap * ep * 4, stage_d = (size_t)stage;
+    const size_t per_wave_i = 2 * (size_t)cap + 2 * ((size_t)cap + 1) + (UF3_MAX_SPECIES + 2) + (size_t)cap * (S + 1) + 2 * (size_t)nrec + (size_t)cap;
+    const size_t ints = ((size_t)WPB * per_wave_i + 3) & ~(size_t)3;
+    return (e_d + rows_d + WPB * (list_d + tq_d + stage_d)) * 8 + ints * 4 + (size_t)b->n_f3src * 2 + 32;
+}
+#define UF3_LDS_LIMIT ((size_t)160 * 1024 - 512)
+
 extern "C" int uf3_featurize_dev(uf3_basis *b, const uf3_frames *fr, const double *d_pos, const int32_t *d_z,
                                  double *d_xe, double *d_xf) {
     if (!b) return fail(nullptr, UF3_EINVAL, "null basis");
@@ -1320,7 +1351,10 @@ extern "C" int uf3_featurize_dev(uf3_basis *b, const uf3_frames *fr, const doubl
         }
         // 3-body force rows by bond factorisation (k_featurize3) where the basis allows it: one launch for all trio blocks,
         // behind the pair launch that builds the lists
-        const bool feat3 = b->feat3_ok && want_f && (has3 || old_n3) && !img_launch && cap <= 255 && !getenv("UF3_NO_FEAT3");
+        // (dense or long-range lists, past ~200 entries at the default trims and ~100 on the 6 x 12 windows, do not fit its
+        // LDS layout: those calls keep the matrix-core / generic launches, which handled them before k_featurize3 existed)
+        const bool feat3 = b->feat3_ok && want_f && (has3 || old_n3) && !img_launch && cap <= 255 && !c->env_no_feat3 &&
+                           feat3_lds_bytes(b, cap, want_e && !A.e_direct) <= UF3_LDS_LIMIT;
         {
             Timed tm(c, T_FEAT);
             for (int mode = 0; mode <= 9; mode++) {
@@ -1441,39 +1475,34 @@ extern "C" int uf3_featurize_dev(uf3_basis *b, const uf3_frames *fr, const doubl
                 G.pr_rows = std::min(b->f3_ext_p, 32 / b->f3_ext_n);
                 G.geoms = P.geoms; G.frame_of = P.frame_of; G.n3 = A.n3; G.pos = d_pos; G.spec = P.spec;
                 G.x_e = d_xe; G.x_f = d_xf; G.natoms = P.natoms; G.e_direct = A.e_direct; G.skip = A.skip;
-                const int S = b->host.S;
-                const bool e_lds = want_e && !A.e_direct;
-                const int ep = std::max(3, b->f3_ext_p), nr = b->f3_nr;          // (rows of the launch's shape)
-                int stage = 0, nrec = 0;
-                switch (ep) {
-                    case 3: stage = F3Cfg<3, 1>::STAGE; nrec = F3Cfg<3, 1>::NREC; break;
-                    case 4: stage = F3Cfg<4, 2>::STAGE; nrec = F3Cfg<4, 2>::NREC; break;
-                    case 5: stage = F3Cfg<5, 3>::STAGE; nrec = F3Cfg<5, 3>::NREC; break;
-                    default: stage = F3Cfg<6, 3>::STAGE; nrec = F3Cfg<6, 3>::NREC; break;
-                }
-                const size_t e_d = e_lds ? (size_t)F + (F & 1) : 0, rows_d = (size_t)b->n_f3rows * 18;
-                const size_t list_d = 5 * (size_t)cap + ((5 * cap) & 1), tq_d = (size_t)cap * ep * 4, stage_d = (size_t)stage;
-                const size_t per_wave_i = 2 * (size_t)cap + 2 * ((size_t)cap + 1) + (UF3_MAX_SPECIES + 2) + (size_t)cap * (S + 1) + 2 * (size_t)nrec + (size_t)cap;
-                const size_t ints = ((size_t)WPB * per_wave_i + 3) & ~(size_t)3;
-                const size_t lds = (e_d + rows_d + WPB * (list_d + tq_d + stage_d)) * 8 + ints * 4 + (size_t)b->n_f3src * 2 + 32;
-                if (lds > 160 * 1024 - 512) return fail(c, UF3_EOVERFLOW, "featurizer LDS footprint exceeds 160 KB (F or neighbour count too large)");
+                int ep, stage, nrec;
+                feat3_shape(b, ep, stage, nrec);
+                (void)stage; (void)nrec;
+                const int nr = b->f3_nr;
+                const size_t lds = feat3_lds_bytes(b, cap, want_e && !A.e_direct);      // (<= UF3_LDS_LIMIT: checked where feat3 was decided)
                 int per_cu = std::max(1, std::min(8, (int)((size_t)(160 * 1024) / lds)));
-                const int bps = getenv("UF3_F3_BPS") ? std::max(1, atoi(getenv("UF3_F3_BPS"))) : 24;
+                const int bps = c->env_f3_bps;
                 int n_blocks = std::min((P.natoms + WPB - 1) / WPB, c->n_cu * per_cu * bps);
                 int apb = ((P.natoms + n_blocks - 1) / n_blocks + WPB - 1) / WPB * WPB;
                 n_blocks = (P.natoms + apb - 1) / apb;
                 G.atoms_per_block = apb;
-                if (getenv("UF3_DEBUG_LDS"))
+                if (c->env_debug_lds)
                     fprintf(stderr, "uf3 featurize3: lds %zu B, cap %d, blocks %d x %d atoms, window %d x %d, %d round(s)\n", lds, cap, n_blocks, apb,
                             G.ext_p, G.ext_n, nr);
                 const unsigned grid = (unsigned)((n_blocks + 7) / 8 * 8);
+        /* (the attribute is set once per instance and context, and again only when a call needs more) */                     \
 #define UF3_F3_LAUNCH1(E, EFv, NRv, CAPv)                                                                                   \
     do {                                                                                                                   \
-        HIPCHK(c, hipFuncSetAttribute((const void *)k_featurize3<E, EFv, NRv, CAPv>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        static thread_local std::map<const uf3_ctx *, size_t> lds_set;                                                     \
+        size_t &have = lds_set[c];                                                                                         \
+        if (lds > have) {                                                                                                  \
+            HIPCHK(c, hipFuncSetAttribute((const void *)k_featurize3<E, EFv, NRv, CAPv>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+            have = lds;                                                                                                    \
+        }                                                                                                                  \
         hipLaunchKernelGGL((k_featurize3<E, EFv, NRv, CAPv>), dim3(grid), dim3(WPB * WAVE), lds, st, G);                    \
     } while (0)
 #define UF3_F3_LAUNCH(E, EFv, NRv)                                                                                          \
-    do { if (cap == 16 && !getenv("UF3_F3_NO_CAP16")) UF3_F3_LAUNCH1(E, EFv, NRv, 16); else UF3_F3_LAUNCH1(E, EFv, NRv, 0); } while (0)
+    do { if (cap == 16 && !c->env_f3_no_cap16) UF3_F3_LAUNCH1(E, EFv, NRv, 16); else UF3_F3_LAUNCH1(E, EFv, NRv, 0); } while (0)
                 switch (ep) {
                     case 3: if (want_e) UF3_F3_LAUNCH(true, 3, 1); else UF3_F3_LAUNCH(false, 3, 1); break;
                     case 4: if (want_e) UF3_F3_LAUNCH(true, 4, 2); else UF3_F3_LAUNCH(false, 4, 2); break;
@@ -2151,12 +2180,12 @@ extern "C" int uf3_fit_pack_dev(uf3_ctx *c, int32_t n_feat, const double *d_flat
 }
 
 // ------------------------------------------------------------------------------ neighbour debug
-extern "C" int uf3_neighbors_debug(uf3_basis *b, const uf3_frames *fr, const double *pos, const int32_t *z,
-                                   int64_t *pair_count, int64_t *pair_ij, int64_t pair_cap, int64_t *n3_count,
-                                   int64_t *n3_ij, int64_t n3_cap) {
+static int neighbors_impl(uf3_basis *b, const uf3_frames *fr, const double *pos, const int32_t *z,
+                          int64_t *pair_count, int64_t *pair_ij, double *pair_geo, int64_t pair_cap, int64_t *n3_count,
+                          int64_t *n3_ij, int64_t n3_cap) {
     if (!b) return fail(nullptr, UF3_EINVAL, "null basis");
     uf3_ctx *c = b->ctx;
-    if (!fr || fr->n_frames != 1) return fail(c, UF3_EINVAL, "uf3_neighbors_debug takes exactly one frame");
+    if (!fr || fr->n_frames != 1) return fail(c, UF3_EINVAL, "the neighbour queries take exactly one frame");
     int natoms = 0;
     int rc = upload_frames(c, fr, pos, z, natoms);
     if (rc) return rc;
@@ -2166,36 +2195,106 @@ extern "C" int uf3_neighbors_debug(uf3_basis *b, const uf3_frames *fr, const dou
     int np = b->host.P;
     std::vector<long long> counts(np + 2, 0);
     std::vector<long long> tuples;
+    std::vector<double> geo;
     long long cap = 0;
     for (int pass = 0; pass < 2; pass++) {
-        HIPCHK(c, c->dbg.ensure(8 * (size_t)(np + 2) + 24 * (size_t)std::max<long long>(1, cap)));
+        const size_t head = 8 * (size_t)(np + 2), ncap = (size_t)std::max<long long>(1, cap);
+        HIPCHK(c, c->dbg.ensure(head + 24 * ncap + (pair_geo ? 32 * ncap : 0)));
         long long *d_counts = c->dbg.as<long long>(), *d_tuples = d_counts + np + 2;
-        HIPCHK(c, hipMemsetAsync(d_counts, 0, 8 * (size_t)(np + 2), c->stream));
+        double *d_geo = pair_geo ? (double *)(d_tuples + 3 * ncap) : nullptr;
+        HIPCHK(c, hipMemsetAsync(d_counts, 0, head, c->stream));
         hipLaunchKernelGGL(k_debug_pairs, dim3(natoms), dim3(64), 0, c->stream, b->dev, P.geoms, P.frame_of, P.cl,
-                           (const double *)c->stage_pos.as<double>(), P.spec, natoms, d_counts, d_tuples, cap);
-        HIPCHK(c, hipMemcpyAsync(counts.data(), d_counts, 8 * (size_t)(np + 2), hipMemcpyDeviceToHost, c->stream));
+                           (const double *)c->stage_pos.as<double>(), P.spec, natoms, d_counts, d_tuples, cap, d_geo);
+        HIPCHK(c, hipMemcpyAsync(counts.data(), d_counts, head, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         if (pass == 0) { cap = counts[np + 1]; if (cap == 0) break; continue; }
         tuples.resize(3 * (size_t)cap);
         HIPCHK(c, hipMemcpy(tuples.data(), d_tuples, 24 * (size_t)cap, hipMemcpyDeviceToHost));
+        if (pair_geo) {
+            geo.resize(4 * (size_t)cap);
+            HIPCHK(c, hipMemcpy(geo.data(), d_geo, 32 * (size_t)cap, hipMemcpyDeviceToHost));
+        }
     }
     rc = check_flags(c);
     if (rc) return rc;
     if (pair_count) for (int p = 0; p < np; p++) pair_count[p] = counts[p];
     if (n3_count) *n3_count = counts[np];
-    struct T3 { long long p, i, j; };
+    struct T3 { long long p, i, j, at; };
     std::vector<T3> v((size_t)cap);
-    for (long long q = 0; q < cap; q++) v[q] = {tuples[3 * q], tuples[3 * q + 1], tuples[3 * q + 2]};
+    for (long long q = 0; q < cap; q++) v[q] = {tuples[3 * q], tuples[3 * q + 1], tuples[3 * q + 2], q};
     std::sort(v.begin(), v.end(), [](const T3 &a, const T3 &bb) {
         return a.p != bb.p ? a.p < bb.p : (a.i != bb.i ? a.i < bb.i : a.j < bb.j);
     });
     std::vector<long long> cur(np + 1, 0);
     for (const T3 &t : v) {
         if (t.p < np) {
-            if (pair_ij && cur[t.p] < pair_cap) { pair_ij[2 * (t.p * pair_cap + cur[t.p])] = t.i; pair_ij[2 * (t.p * pair_cap + cur[t.p]) + 1] = t.j; }
+            if (cur[t.p] < pair_cap) {
+                const long long o = t.p * pair_cap + cur[t.p];
+                if (pair_ij) { pair_ij[2 * o] = t.i; pair_ij[2 * o + 1] = t.j; }
+                if (pair_geo) for (int k = 0; k < 4; k++) pair_geo[4 * o + k] = geo[4 * (size_t)t.at + k];
+            }
         } else if (n3_ij && cur[np] < n3_cap) { n3_ij[2 * cur[np]] = t.i; n3_ij[2 * cur[np] + 1] = t.j; }
         cur[t.p]++;
     }
+    return UF3_OK;
+}
+
+extern "C" int uf3_neighbors_debug(uf3_basis *b, const uf3_frames *fr, const double *pos, const int32_t *z,
+                                   int64_t *pair_count, int64_t *pair_ij, int64_t pair_cap, int64_t *n3_count,
+                                   int64_t *n3_ij, int64_t n3_cap) {
+    return neighbors_impl(b, fr, pos, z, pair_count, pair_ij, nullptr, pair_cap, n3_count, n3_ij, n3_cap);
+}
+
+extern "C" int uf3_pair_geometry(uf3_basis *b, const uf3_frames *fr, const double *pos, const int32_t *z,
+                                 int64_t *pair_count, int64_t *pair_ij, double *pair_geo, int64_t pair_cap) {
+    if (pair_cap > 0 && !pair_geo) return fail(b ? b->ctx : nullptr, UF3_EINVAL, "uf3_pair_geometry: null pair_geo");
+    return neighbors_impl(b, fr, pos, z, pair_count, pair_ij, pair_cap > 0 ? pair_geo : nullptr, pair_cap, nullptr, nullptr, 0);
+}
+
+// ------------------------------------------------------------------------------ dense helpers (small frames)
+extern "C" int uf3_distance_matrix(uf3_ctx *c, const double *a, int64_t na, const double *bb, int64_t nb, double *out) {
+    if (!c) return fail(nullptr, UF3_EINVAL, "null ctx");
+    if (na < 0 || nb < 0 || (na && !a) || (nb && !bb)) return fail(c, UF3_EINVAL, "uf3_distance_matrix: bad argument");
+    const size_t n = (size_t)na * (size_t)nb;
+    if (!n) return UF3_OK;
+    if (!out) return fail(c, UF3_EINVAL, "uf3_distance_matrix: null out");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, c->dbg.ensure(24 * (size_t)(na + nb) + 8 * n));
+    double *d_a = c->dbg.as<double>(), *d_b = d_a + 3 * na, *d_out = d_b + 3 * nb;
+    HIPCHK(c, hipMemcpyAsync(d_a, a, 24 * (size_t)na, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(d_b, bb, 24 * (size_t)nb, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_distance_matrix, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, d_a, (long long)na, d_b,
+                       (long long)nb, d_out);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(out, d_out, 8 * n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return UF3_OK;
+}
+
+extern "C" int uf3_direction_cosines(uf3_ctx *c, const double *sup_pos, int64_t n_sup, const int64_t *i_where,
+                                     const int64_t *j_where, const double *rij, int64_t n_d, int64_t n_atoms, double *out) {
+    if (!c) return fail(nullptr, UF3_EINVAL, "null ctx");
+    if (n_sup < 0 || n_d < 0 || n_atoms < 0) return fail(c, UF3_EINVAL, "uf3_direction_cosines: bad argument");
+    const size_t n = (size_t)n_atoms * 3 * (size_t)n_d;
+    if (!n) return UF3_OK;
+    if (!sup_pos || !i_where || !j_where || !rij || !out) return fail(c, UF3_EINVAL, "uf3_direction_cosines: null argument");
+    for (int64_t q = 0; q < n_d; q++)
+        if (i_where[q] < 0 || i_where[q] >= n_sup || j_where[q] < 0 || j_where[q] >= n_sup)
+            return fail(c, UF3_EINVAL, "uf3_direction_cosines: index outside the supercell");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, c->dbg.ensure(24 * (size_t)n_sup + 24 * (size_t)n_d + 8 * n));
+    double *d_pos = c->dbg.as<double>();
+    long long *d_i = (long long *)(d_pos + 3 * n_sup), *d_j = d_i + n_d;
+    double *d_r = (double *)(d_j + n_d), *d_out = d_r + n_d;
+    HIPCHK(c, hipMemcpyAsync(d_pos, sup_pos, 24 * (size_t)n_sup, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(d_i, i_where, 8 * (size_t)n_d, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(d_j, j_where, 8 * (size_t)n_d, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(d_r, rij, 8 * (size_t)n_d, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_direction_cosines, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, d_pos, d_i, d_j, d_r,
+                       (long long)n_d, (long long)n_atoms, d_out);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(out, d_out, 8 * n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     return UF3_OK;
 }
 

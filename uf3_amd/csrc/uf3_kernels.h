@@ -130,8 +130,8 @@ k_prepare_small(const BasisDev *B, const FrameGeom *geoms, const int64_t *atom_o
         // table from the basis; then one barrier, the bins, a rank sort (every thread counts the keys below its own -- distinct
         // keys: the rank is the slot) and the slot record written from the registers the atom arrived in.  Three dependent
         // memory round trips less than the general path below.
-        __shared__ int geom_words[(sizeof(FrameGeom) + 3) / 4];
-        __shared__ int z2s_words[30];
+        __shared__ __align__(8) int geom_words[(sizeof(FrameGeom) + 3) / 4];      // (read back as a FrameGeom: doubles inside)
+        __shared__ __align__(8) int z2s_words[30];
         const long long to_host = host_block ? (const char *)host_block - (const char *)dev_block : 0;
         const double *hpos = (const double *)((const char *)pos + to_host);
         const int32_t *hz = (const int32_t *)((const char *)z + to_host);
@@ -3314,7 +3314,7 @@ k_fit_pack(int n_feat, const double *flat, const int64_t *keep, int n_keep, cons
 __global__ void __launch_bounds__(64)
 k_debug_pairs(const BasisDev *B, const FrameGeom *geoms, const int *frame_of, CellList cl, const double *pos,
               const signed char *spec, int natoms, long long *counts /*[P+1]*/, long long *tuples /*[cap][3]*/,
-              long long cap) {
+              long long cap, double *geo /*[cap][4]: d, (R_j - R_i) / d; may be null*/) {
     int m = blockIdx.x;
     if (m >= natoms) return;
     const FrameGeom g = geoms[frame_of[m]];
@@ -3332,7 +3332,11 @@ k_debug_pairs(const BasisDev *B, const FrameGeom *geoms, const int *frame_of, Ce
         if (d > pd.rmin && d < pd.rmax) {
             atomicAdd((unsigned long long *)&counts[p], 1ULL);
             long long o = (long long)atomicAdd((unsigned long long *)&counts[B->P + 1], 1ULL);
-            if (o < cap) { tuples[3 * o] = p; tuples[3 * o + 1] = m - g.atom_lo; tuples[3 * o + 2] = sidx; }
+            if (o < cap) {
+                tuples[3 * o] = p; tuples[3 * o + 1] = m - g.atom_lo; tuples[3 * o + 2] = sidx;
+                // distances.py:331-364: delta_r / rij, IEEE quotients (nothing else in the library divides this way)
+                if (geo) { geo[4 * o] = d; geo[4 * o + 1] = dx / d; geo[4 * o + 2] = dy / d; geo[4 * o + 3] = dz / d; }
+            }
         }
         if (B->T > 0 && d > B->rmin3 && d <= B->rmax3) {
             atomicAdd((unsigned long long *)&counts[B->P], 1ULL);
@@ -3340,4 +3344,29 @@ k_debug_pairs(const BasisDev *B, const FrameGeom *geoms, const int *frame_of, Ce
             if (o < cap) { tuples[3 * o] = B->P; tuples[3 * o + 1] = m - g.atom_lo; tuples[3 * o + 2] = sidx; }
         }
     });
+}
+
+
+// ---------------------------------------------------------------------------------
+// dense helpers behind the module-level surfaces of uf3.representation.distances (small frames: O(n m) memory like the
+// reference's cdist): the distance matrix in scipy's order of operations, and compute_direction_cosines
+// ---------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_distance_matrix(const double *a, long long na, const double *b, long long nb, double *out) {
+    const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= na * nb) return;
+    const long long i = q / nb, j = q - i * nb;
+    out[q] = norm3_rn(a[3 * i] - b[3 * j], a[3 * i + 1] - b[3 * j + 1], a[3 * i + 2] - b[3 * j + 2]);
+}
+
+// out [n_atoms][3][n_d] = ((m == j) - (m == i)) * (R_j - R_i)[c] / r_ij   (distances.py:331-364)
+__global__ void __launch_bounds__(256)
+k_direction_cosines(const double *sup_pos, const long long *i_where, const long long *j_where, const double *rij,
+                    long long n_d, long long n_atoms, double *out) {
+    const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n_atoms * 3 * n_d) return;
+    const long long idx = q % n_d, c = (q / n_d) % 3, m = q / (3 * n_d);
+    const long long i = i_where[idx], j = j_where[idx];
+    const double kron = (double)((m == j) - (m == i));
+    out[q] = __dmul_rn(kron, sup_pos[3 * j + c] - sup_pos[3 * i + c]) / rij[idx];
 }
