@@ -660,9 +660,14 @@ def test_lists_too_long_for_the_bond_factorised_launch_fall_back():
     _, n3 = fz.neighbor_indices(atoms)
     assert np.bincount(n3[:, 0]).max() > 100
     _check_against_oracle(basis, [atoms])
-    # default trims, > 200 neighbours per atom: the default route against the generic kernels
-    basis3 = synthetic.notebook_basis(['W'])
-    dense = synthetic.lattice_frame("bcc", (7, 7, 7), 1.15, [74], 6, rattle=0.03, strain=0.0)
+    # default trims, > 200 three-body neighbours per atom (a short pair range keeps the pair launch's candidate stage small):
+    # the default route against the generic kernels
+    cs = synthetic.composition.ChemicalSystem(['W'], 3)
+    basis3 = synthetic.bspline.BSplineBasis(
+        cs, r_min_map={('W', 'W'): 0.3, ('W', 'W', 'W'): [1.0, 1.0, 1.0]},
+        r_max_map={('W', 'W'): 2.5, ('W', 'W', 'W'): [4.0, 4.0, 8.0]},
+        resolution_map={('W', 'W'): 10, ('W', 'W', 'W'): [6, 6, 12]}, leading_trim={2: 0, 3: 3}, trailing_trim={2: 3, 3: 3})
+    dense = synthetic.lattice_frame("bcc", (6, 6, 6), 1.357, [74], 6, rattle=0.03, strain=0.0)
     _, n3 = process.BasisFeaturizer(basis3).neighbor_indices(dense)
     assert np.bincount(n3[:, 0]).max() > 200
     xe_d, xf_d, modes_d = _fresh_rows(basis3, [dense])

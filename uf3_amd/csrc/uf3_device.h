@@ -265,13 +265,19 @@ __device__ __forceinline__ void bspline4(const KnotRec &k, double x, double *v, 
 }
 
 // unfused |d|: ((dx*dx + dy*dy) + dz*dz), the order scipy's cdist uses, so that range
-// comparisons at the cut-offs agree with the reference to the last bit
+// comparisons at the cut-offs agree with the reference to the last bit.  (`__dmul_rn` / `__dadd_rn` are plain `*` / `+` in
+// this toolchain's headers and the library is built with -ffp-contract=fast: until round 5 the compiler fused these into
+// fma(dz, dz, fma(dx, dx, dy * dy)) -- one ulp off scipy's sum in about one distance in ten, found when the distance VALUES
+// were first compared bit for bit (tests/test_module_surfaces.py).  `#pragma clang fp contract(off)` does not help under
+// -ffp-contract=fast, where the backend fuses whatever it meets; the empty asm makes the three squares opaque to it.)
 __device__ __forceinline__ double norm3_sq_rn(double dx, double dy, double dz) {        // the radicand of norm3_rn
-    return __dadd_rn(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)), __dmul_rn(dz, dz));
+    double xx = dx * dx, yy = dy * dy, zz = dz * dz;
+    asm("" : "+v"(xx), "+v"(yy), "+v"(zz));
+    const double xy = xx + yy;
+    return xy + zz;
 }
 __device__ __forceinline__ double norm3_rn(double dx, double dy, double dz) {
-    double s = __dadd_rn(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)), __dmul_rn(dz, dz));
-    return sqrt(s);
+    return sqrt(norm3_sq_rn(dx, dy, dz));
 }
 
 // |d| for the THIRD leg of a triplet (r_jk): not part of any neighbour-index decision -- it selects knot intervals, where a

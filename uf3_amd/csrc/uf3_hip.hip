@@ -1417,7 +1417,17 @@ extern "C" int uf3_featurize_dev(uf3_basis *b, const uf3_frames *fr, const doubl
                     recs_lds = lds_recs <= lds_target && !getenv("UF3_NO_LDS_RECS") && !(img_launch && mode != 0);
                     lds = recs_lds ? lds_recs : lds_plain;
                 }
-                if (lds > 160 * 1024 - 512) return fail(c, UF3_EOVERFLOW, "featurizer LDS footprint exceeds 160 KB (F or neighbour count too large)");
+                if (lds > UF3_LDS_LIMIT && mode == 0 && !c->cand_tuned && c->cand_cap > 64) {
+                    // the candidate capacity is still the density ESTIMATE (60 % headroom): a dense frame must not fail on the
+                    // guess -- take what fits, the overflow flag reports the true need and the call is repeated with it
+                    while (c->cand_cap > 64 && feat_lds_bytes(F, S, cap, c->cand_cap, want_e && !A.e_direct, recs_lds ? n_rec_mode : 0, 0,
+                                                              A.dense_stage, A.dense_nrec, A.n_pair_cols) + lds_extra > UF3_LDS_LIMIT)
+                        c->cand_cap = (c->cand_cap * 7 / 8 + 7) / 8 * 8;
+                    A.cand_cap = c->cand_cap;
+                    lds = feat_lds_bytes(F, S, cap, A.cand_cap, want_e && !A.e_direct, recs_lds ? n_rec_mode : 0, 0, A.dense_stage,
+                                         A.dense_nrec, A.n_pair_cols) + lds_extra;
+                }
+                if (lds > UF3_LDS_LIMIT) return fail(c, UF3_EOVERFLOW, "featurizer LDS footprint exceeds 160 KB (F or neighbour count too large)");
                 // blocks of WPB waves, each walking a contiguous run of atoms (keeps the shared energy row on
                 // one frame); many more blocks than resident slots (measured: 2 per slot 3400 frames/s, 16-48 per slot
                 // 3640, finer again slower): the tail of the launch is short and concurrent blocks work on nearby atoms

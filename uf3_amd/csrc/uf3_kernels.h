@@ -463,6 +463,66 @@ k_zero3(unsigned *p0, size_t n0, unsigned *p1, size_t n1, unsigned *p2, size_t n
     }
 }
 
+// ---------------------------------------------------------------------------------
+// MD route: persistent superset lists (a Verlet list with a skin).  One entry per neighbour image within r_search + skin of
+// the atom at build time: who it is (atom, image shift relative to the ORIGINAL positions, reference supercell index,
+// species) -- no geometry, which every step recomputes from the current positions exactly as the cell-list walk would.
+// Entries are sorted by (species, supercell index): a step filters them by the true distances and compacts the survivors
+// IN THAT ORDER, so the pairs an atom sums and its 3-body list are the same sequence whatever superset they were drawn from --
+// results do not depend on when the lists were last rebuilt (calculator.py:124-153 rebuilds everything every call).
+// ---------------------------------------------------------------------------------
+struct __attribute__((aligned(16))) SupEntry { int parent, shiftc, sidx, spec; };
+
+__global__ void __launch_bounds__(64)
+k_build_sup(const BasisDev *B, const FrameGeom *geoms, const int *frame_of, CellList cl, const double *pos, int natoms,
+            double r_sup2, SupEntry *ent, int *cnt, int cap, int *overflow_need) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    unsigned long long *key = (unsigned long long *)smem;
+    int *eparent = (int *)(key + cap), *eshift = eparent + cap;
+    const int m = (int)((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3));
+    if (m >= natoms) return;
+    const int lane = lane_id();
+    const FrameGeom g = geoms[frame_of[m]];
+    const double pm[3] = {pos[3 * (size_t)m], pos[3 * (size_t)m + 1], pos[3 * (size_t)m + 2]};
+    int count = 0;
+    for_each_candidate(g, cl, m, [&](bool ok, const SlotRec &sr, int sj, int s0, int s1, int s2) {
+        if (ok) {
+            double dx, dy, dz;
+            image_delta(g, sr, s0, s1, s2, pm, dx, dy, dz);
+            ok = norm3_sq_rn(dx, dy, dz) <= r_sup2;
+        }
+        const unsigned long long mask = __ballot(ok);
+        if (ok) {
+            const int e = count + mbcnt(mask);
+            if (e < cap) {
+                key[e] = ((unsigned long long)sj << 32) | (unsigned)supercell_index(g, s0, s1, s2, sr.atom - g.atom_lo);
+                eparent[e] = sr.atom; eshift[e] = pack3(s0, s1, s2);
+            }
+        }
+        count += __popcll(mask);
+    });
+    __syncthreads();
+    if (count > cap) { if (lane == 0) atomicMax(overflow_need, count); count = cap; }
+    if (lane == 0) cnt[m] = count;
+    for (int e = lane; e < count; e += WAVE) {       // rank sort by (species, supercell index): distinct keys
+        const unsigned long long k = key[e];
+        int rank = 0;
+        for (int f = 0; f < count; f++) rank += key[f] < k;
+        SupEntry out;
+        out.parent = eparent[e]; out.shiftc = eshift[e]; out.sidx = (int)(unsigned)k; out.spec = (int)(k >> 32);
+        ent[(size_t)m * cap + rank] = out;
+    }
+}
+
+// a small batch's staged block (positions | species, in the caller's pinned memory) into device memory, and the status words
+// of the launches behind it zeroed: what k_prepare_small does on the way for calls that build a cell list
+__global__ void __launch_bounds__(256)
+k_md_fetch(const int4 *host_block, int4 *dev_block, int block_int4s, int *flags) {
+    for (int q = threadIdx.x; q < block_int4s; q += blockDim.x) dev_block[q] = host_block[q];
+    if (threadIdx.x < 6) flags[1 + threadIdx.x] = 0;
+    if (threadIdx.x == 0) flags[12] = 0;
+}
+
 // largest list length of a batch (capacity tuning after the first build of a context)
 __global__ void k_max_count(const int *cnt, int n, int *out) {
     int v = 0;
@@ -2314,6 +2374,14 @@ struct EvalArgs {
     // collection pass of a block of CENTRES (uf3_eval_centres): only the centres [atom_lo, atom_hi) have run, and only the
     // atoms inside the block or marked as its halo have lists
     const int *halo_mark;         // [natoms] != 0: a halo atom of the block; null: every atom collects from every centre
+    // MD route (k_eval<..., MD = true>): the candidates come from the context's persistent superset lists instead of a cell-list walk
+    const SupEntry *sup_ent;      // [natoms][sup_cap] neighbours within r_search + skin at build time, sorted by (species, supercell index)
+    const int *sup_cnt;           // [natoms]
+    int sup_cap;
+    const double *pos_ref;        // [natoms][3] positions the lists were built from
+    const int32_t *z_now;         // [natoms] atomic numbers of THIS call (compared with the species the lists were built for)
+    double md_hard2, md_soft2;    // squared displacement limits: (skin / 2)^2 -- beyond it the lists may miss a neighbour -- and the early warning
+    int *md_flags;                // [0] = 1: some atom moved past the hard limit (results invalid, rebuild and repeat); [1] = 1: past the soft one
 };
 
 #ifndef EVAL_CGROUP
@@ -2417,8 +2485,13 @@ __device__ __forceinline__ double wave_sum(double v) {
 // (CAP: the list capacity as a compile-time constant -- 16, what a tuned context settles on for bcc / fcc cells -- or 0 for
 // the launch's run-time value: with it every LDS array of the one-wave workgroup sits at a constant address, in the LDS
 // instructions' immediate fields instead of scalar registers, of which the kernel spills 73)
-template <bool GATHER, bool VIR, int CAP = 0>
-__global__ void __launch_bounds__(64, EVAL_MINW)
+// (MD: the candidates of the pair walk come from the persistent superset lists, see k_build_sup -- no cell list, no sort; only
+// with !GATHER.  The survivors are taken in list order, which is the order the fused build below sorts into.)
+#ifndef EVAL_MD_MINW
+#define EVAL_MD_MINW 4
+#endif
+template <bool GATHER, bool VIR, int CAP = 0, bool MD = false>
+__global__ void __launch_bounds__(64, MD ? EVAL_MD_MINW : EVAL_MINW)
 k_eval(EvalArgs A) {
     extern __shared__ __align__(16) unsigned char smem[];
     const BasisDev *B = A.B;
@@ -2434,7 +2507,7 @@ k_eval(EvalArgs A) {
     double *ux = gz + cap, *uy = ux + cap, *uz = uy + cap, *ur = uz + cap;
     unsigned long long *ukey = (unsigned long long *)(ur + cap);
     int *uparent = (int *)(ukey + cap), *ushift = uparent + cap;
-    const bool fuse = !GATHER && A.fuse_n3;
+    const bool fuse = !GATHER && !MD && A.fuse_n3;
     int count3 = 0;
     // (one contiguous eighth of the atoms per XCD, as in k_featurize; the grid is a multiple of 8)
     int m = A.atom_lo + (int)((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3));
@@ -2477,6 +2550,74 @@ k_eval(EvalArgs A) {
             }
         }
     };
+    if (MD) {
+        // the lists are valid while no atom has moved more than skin / 2 since they were built, and for the species they were built for
+        {
+            const double ux0 = pm[0] - A.pos_ref[3 * (size_t)m], uy0 = pm[1] - A.pos_ref[3 * (size_t)m + 1], uz0 = pm[2] - A.pos_ref[3 * (size_t)m + 2];
+            const double moved = ux0 * ux0 + uy0 * uy0 + uz0 * uz0;
+            const int zz = A.z_now[m];
+            const bool other_species = zz < 0 || zz >= 120 || B->z2s[zz] != sm;
+            if (lane == 0) {
+                if (!(moved <= A.md_hard2) || other_species) A.md_flags[0] = 1;
+                if (!(moved <= A.md_soft2)) A.md_flags[1] = 1;
+            }
+        }
+        const int n_sup = min(A.sup_cnt[m], A.sup_cap);
+        const SupEntry *sup = A.sup_ent + (size_t)m * A.sup_cap;
+        const size_t base3 = (size_t)m * cap;
+        for (int q0 = 0; q0 < n_sup; q0 += WAVE) {
+            const int q = q0 + lane;
+            bool ok = q < n_sup;
+            const SupEntry en = sup[ok ? q : 0];
+            SlotRec sr;
+            sr.x = A.pos[3 * (size_t)en.parent]; sr.y = A.pos[3 * (size_t)en.parent + 1]; sr.z = A.pos[3 * (size_t)en.parent + 2];
+            int s0, s1, s2;
+            unpack3(en.shiftc, s0, s1, s2);
+            const int sj = en.spec;
+            double dx, dy, dz;
+            image_delta(g, sr, s0, s1, s2, pm, dx, dy, dz);
+            const double d = norm3_sq_rn(dx, dy, dz);
+            double rmin = ev_rmin0, rmax = ev_rmax0;
+            if (!ev_pairs_uniform) { const PairDev &pd = B->pairs[B->pair_of[sm * UF3_MAX_SPECIES + sj]]; rmin = pd.s_lo; rmax = pd.s_hi; }
+            const bool ok3 = ok & (d > s3_lo) & (d <= s3_hi);
+            ok = ok & (d > rmin) & (d < rmax);
+            // 3-body list: the survivors in list order ARE the (species, supercell index) order
+            const unsigned long long mask3 = __ballot(ok3);
+            if (ok3) {
+                const int slot = count3 + mbcnt(mask3);
+                if (slot < cap) {
+                    N3Entry ne;
+                    ne.dx = dx; ne.dy = dy; ne.dz = dz; ne.r = sqrt(d);
+                    ne.parent = en.parent; ne.shiftc = en.shiftc; ne.sidx = en.sidx; ne.spec = sj;
+                    A.n3.ent[base3 + slot] = ne;
+                    ox[slot] = dx; oy[slot] = dy; oz[slot] = dz; orr[slot] = ne.r;
+                    oparent[slot] = en.parent; oshift[slot] = en.shiftc; osidx[slot] = en.sidx; ospec[slot] = sj;
+                    gx[slot] = 0.0; gy[slot] = 0.0; gz[slot] = 0.0;
+                }
+            }
+            count3 += __popcll(mask3);
+            const unsigned long long mask = __ballot(ok);
+            if (ok) {
+                double *c = queue + (size_t)(queued + mbcnt(mask)) * EVAL_Q;
+                c[0] = dx; c[1] = dy; c[2] = dz; c[3] = d; c[4] = (double)sj;
+            }
+            queued += __popcll(mask);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (queued >= WAVE) {
+                drain(WAVE);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                queued -= WAVE;                                             // move the tail to the front
+                double tail[EVAL_Q];
+                if (lane < queued) for (int u = 0; u < EVAL_Q; u++) tail[u] = queue[(size_t)(WAVE + lane) * EVAL_Q + u];
+                __builtin_amdgcn_wave_barrier();
+                if (lane < queued) for (int u = 0; u < EVAL_Q; u++) queue[(size_t)lane * EVAL_Q + u] = tail[u];
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+    } else
     for_each_candidate(g, A.cl, m, [&](bool ok, const SlotRec &sr, int sj, int s0, int s1, int s2) {
         double dx = 0, dy = 0, dz = 0, d = 0;
         bool ok3 = false;
@@ -2548,6 +2689,12 @@ k_eval(EvalArgs A) {
                 oparent[rank] = en.parent; oshift[rank] = en.shiftc; osidx[rank] = en.sidx; ospec[rank] = en.spec;
                 gx[rank] = 0.0; gy[rank] = 0.0; gz[rank] = 0.0;
             }
+        } else if (MD) {
+            // (written in place by the filter above, already in order)
+            __syncthreads();
+            if (count3 > cap) { if (lane == 0) atomicMax(A.n3_need, count3); count3 = cap; }
+            n = count3;
+            if (lane == 0) A.n3.cnt[m] = n;
         } else {
             n = A.n3.cnt[m];
             for (int q = lane; q < n; q += WAVE) {
