@@ -632,8 +632,16 @@ def _random_model(basis, seed):
     return model, calculator.UFCalculator(model)
 
 
-def extra_eval_50k(torch, dev, cpu=True, steps=20, warmup=3):
-    """BASELINE config 5 on one GPU: energy + forces of a 50 000-atom ternary frame per step (uf3_eval_dev, inputs and outputs in HBM)"""
+MD_SKIN = 0.5          # Angstrom: skin of the evaluator's persistent neighbour lists in the MD-step lines
+MD_WALK = 0.01         # Angstrom: every step moves every coordinate by a seeded uniform(-MD_WALK, MD_WALK) draw
+
+
+def extra_eval_50k(torch, dev, cpu=True, steps=200, warmup=20):
+    """BASELINE config 5 on one GPU: an MD step = move every atom (a seeded +-0.01 A random walk, applied on the device) + energy
+    and forces of the 50 000-atom ternary frame (uf3_eval_dev, inputs and outputs in HBM).  The evaluator runs its MD route:
+    neighbour lists kept out to r_cut + 0.5 A, rebuilt (cell list + list build, inside the timed region) whenever an atom has
+    moved 0.7 x 0.25 A from where they were built.  The reference's calculator rebuilds everything on every call
+    (uf3/forcefield/calculator.py:124-153)."""
     from uf3_amd import _lib, synthetic
     basis = synthetic.notebook_basis(['V', 'Mo', 'W'])
     atoms = synthetic.lattice_frame("bcc", (25, 25, 40), 3.165, [23, 42, 74], 4000)
@@ -646,52 +654,133 @@ def extra_eval_50k(torch, dev, cpu=True, steps=20, warmup=3):
     d_z = torch.from_numpy(batch.z).to(dev)
     d_e = torch.empty((1,), dtype=torch.float64, device=dev)
     d_f = torch.empty((n, 3), dtype=torch.float64, device=dev)
+    # the walk: a pool of seeded displacement fields, one drawn (with a sign) per step -- one small device kernel per step
+    g = torch.Generator(device=dev).manual_seed(17)
+    pool = (torch.rand((64, n, 3), dtype=torch.float64, device=dev, generator=g) * 2.0 - 1.0) * MD_WALK
+    order = np.random.default_rng(17).integers(0, 64, 1 << 16)
+    signs = np.random.default_rng(18).choice([-1.0, 1.0], 1 << 16)
+    counter = [0]
+    prev = ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)      # (the walk runs on torch's stream: one order of events)
+    ctx.md_skin(MD_SKIN)
 
     def step():
+        k = counter[0]
+        counter[0] += 1
+        d_pos.add_(pool[order[k & 0xffff]], alpha=float(signs[k & 0xffff]))
         ctx.check(ctx.lib.uf3_eval_dev(db.handle, C.byref(batch.struct), C.c_void_p(d_pos.data_ptr()),
                                        C.c_void_p(d_z.data_ptr()), _lib._p(calc._c1), _lib._p(calc._c2), _lib._p(calc._c3),
                                        C.c_void_p(d_e.data_ptr()), C.c_void_p(d_f.data_ptr())))
 
-    dt, t = _timed(torch, dev, ctx, step, steps, warmup)
-    f = d_f.cpu().numpy()
-    out = dict(metric="evaluated atom-steps/sec (50k-atom ternary frame, energy + forces)", value=round(n / dt), unit="atom-steps/s",
-               ms_per_step=round(dt * 1e3, 4), steps=steps, atoms_per_frame=n, n_feat=int(basis.n_feats),
+    try:
+        for _ in range(warmup):
+            step()
+        torch.cuda.synchronize(dev)
+        s0 = ctx.md_stats()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize(dev)
+        dt = (time.perf_counter() - t0) / steps
+        s1 = ctx.md_stats()
+        ctx.timing_reset(True)
+        n2 = max(2, steps // 4)
+        for _ in range(n2):
+            step()
+        torch.cuda.synchronize(dev)
+        t = {k: v / n2 for k, v in ctx.timing_read().items()}
+        ctx.timing_reset(False)
+        f = d_f.cpu().numpy()
+        e_gpu = float(d_e.item())
+        final = d_pos.cpu().numpy()
+        # the rebuild-everything route on the final positions (what every call did until round 4), timed on frozen atoms
+        ctx.md_skin(0.0)
+        d_f2 = torch.empty_like(d_f)
+
+        def plain():
+            ctx.check(ctx.lib.uf3_eval_dev(db.handle, C.byref(batch.struct), C.c_void_p(d_pos.data_ptr()),
+                                           C.c_void_p(d_z.data_ptr()), _lib._p(calc._c1), _lib._p(calc._c2), _lib._p(calc._c3),
+                                           C.c_void_p(d_e.data_ptr()), C.c_void_p(d_f2.data_ptr())))
+        for _ in range(3):
+            plain()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(20):
+            plain()
+        torch.cuda.synchronize(dev)
+        dt_plain = (time.perf_counter() - t0) / 20
+        f_plain = d_f2.cpu().numpy()
+        assert np.abs(f - f_plain).max() <= 1e-12 * np.abs(f_plain).max() and abs(e_gpu - float(d_e.item())) <= 1e-12 * abs(e_gpu)
+    finally:
+        ctx.md_skin(0.0)
+        ctx.restore_stream(prev)
+    out = dict(metric="evaluated atom-steps/sec (50k-atom ternary frame, energy + forces, atoms moving every step)", value=round(n / dt),
+               unit="atom-steps/s", ms_per_step=round(dt * 1e3, 4), steps=steps, atoms_per_frame=n, n_feat=int(basis.n_feats),
+               md=dict(skin_A=MD_SKIN, walk_A=MD_WALK, list_builds_in_timed_steps=s1["builds"] - s0["builds"],
+                       steps_repeated=s1["redone"] - s0["redone"],
+                       rebuild_everything_route=dict(value=round(n / dt_plain), ms_per_step=round(dt_plain * 1e3, 4),
+                                                     note="md skin 0 (cell list + candidate walk + list sort on every call), frozen positions")),
                roofline=_roof(n * (100.0 * PAIRS_PER_ATOM + 700.0 * TRIPLETS_PER_ATOM), 52.0 * n + 75 + 8.0 * len(calc._c3), dt, "mfma",
                               eval_kernels_ms_per_step=round(t["eval_ms"], 4), neighbor_ms_per_step=round(t["neighbor_ms"], 4),
                               note="flops = N (100 p + 700 T): every triplet once at its centre (3 legs x ~60 + 64-term "
                                    "contraction with value and 3 partials ~450 + forces); bytes = 52 N + the coefficient grids"))
     if cpu:
         from oracle import oracle as O
+        from uf3_amd.data.atoms import Atoms
+        moved = Atoms(numbers=atoms.get_atomic_numbers(), positions=final, cell=atoms.get_cell(), pbc=True)
         ob = O.OracleBasis(basis)
         t0 = time.perf_counter()
-        ref = O.evaluate(ob, atoms, model.coefficients)
+        ref = O.evaluate(ob, moved, model.coefficients)
         dt_cpu = time.perf_counter() - t0
         e_ref, f_ref = ref[0], ref[1]
-        err = max(abs(float(d_e.item()) - e_ref) / abs(e_ref), np.abs(f - f_ref).max() / np.abs(f_ref).max())
+        err = max(abs(e_gpu - e_ref) / abs(e_ref), np.abs(f - f_ref).max() / np.abs(f_ref).max())
         assert err < 1e-9, err
         out["cpu_baseline"] = dict(value=round(n / dt_cpu), unit="atom-steps/s", cores=1, kind="port",
-                                   sample=f"the same frame once through oracle/uf3_oracle.c's evaluator, single thread, "
-                                          f"{dt_cpu:.1f} s; GPU energy / forces matched to {err:.1e}")
+                                   sample=f"the frame of the last step once through oracle/uf3_oracle.c's evaluator, single thread, "
+                                          f"{dt_cpu:.1f} s; GPU energy / forces (MD route, lists several steps old) matched to {err:.1e}")
     return out
 
 
-def extra_eval_128(calls=300):
-    """latency of one MD-step call on a small cell: UFCalculator.evaluate_frames (host arrays in and out), 128-atom W frame"""
-    from uf3_amd import synthetic
+def extra_eval_128(calls=2000):
+    """latency of one MD step on a small cell: move the atoms (seeded +-0.01 A walk, host arrays) + UFCalculator.evaluate_frames
+    (host arrays in and out), 128-atom W frame, neighbour lists kept with a 0.5 A skin and rebuilt inside the timed loop"""
+    from uf3_amd import _lib, synthetic
     basis = synthetic.notebook_basis(['W'])
     atoms = synthetic.lattice_frame("bcc", (4, 4, 4), 3.165, [74], seed=3)
-    _, calc = _random_model(basis, 1)
-    for _ in range(10):
+    model, _ = _random_model(basis, 1)
+    from uf3_amd.forcefield import calculator
+    calc = calculator.UFCalculator(model, md_skin=MD_SKIN)
+    ctx = _lib.get_context(None)
+    n = len(atoms)
+    rng = np.random.default_rng(19)
+    noise = rng.uniform(-MD_WALK, MD_WALK, (256, n, 3))
+    pick = rng.integers(0, 256, calls + 64)
+    sign = rng.choice([-1.0, 1.0], calls + 64)
+    for k in range(32):
+        atoms.positions += sign[k] * noise[pick[k]]
         calc.evaluate_frames([atoms])
+    s0 = ctx.md_stats()
     t0 = time.perf_counter()
-    for _ in range(calls):
+    for k in range(32, 32 + calls):
+        atoms.positions += sign[k] * noise[pick[k]]
         calc.evaluate_frames([atoms])
     dt = (time.perf_counter() - t0) / calls
-    n = len(atoms)
-    return dict(metric="latency of one energy + force call (128-atom W frame, host arrays in and out)", value=round(dt * 1e6, 2),
+    s1 = ctx.md_stats()
+    e, f, _ = calc.evaluate_frames([atoms])
+    plain = calculator.UFCalculator(model, md_skin=0.0)
+    for _ in range(10):
+        e0, f0, _ = plain.evaluate_frames([atoms])
+    t0 = time.perf_counter()
+    for _ in range(300):
+        plain.evaluate_frames([atoms])
+    dt_plain = (time.perf_counter() - t0) / 300
+    assert np.abs(f - f0).max() <= 1e-12 * np.abs(f0).max() and abs(e[0] - e0[0]) <= 1e-12 * abs(e0[0])
+    return dict(metric="latency of one MD step: move + energy + force call (128-atom W frame, host arrays in and out)", value=round(dt * 1e6, 2),
                 unit="us/call", higher_is_better=False, ms_per_step=round(dt * 1e3, 5), steps=calls, atoms_per_frame=n,
+                md=dict(skin_A=MD_SKIN, walk_A=MD_WALK, list_builds_in_timed_steps=s1["builds"] - s0["builds"],
+                        steps_repeated=s1["redone"] - s0["redone"],
+                        rebuild_everything_route=dict(value=round(dt_plain * 1e6, 2), unit="us/call", note="md skin 0, frozen positions")),
                 roofline=_roof(n * (100.0 * PAIRS_PER_ATOM + 700.0 * TRIPLETS_PER_ATOM), 52.0 * n + 75, dt, "mfma",
-                               note="launch / latency bound: one dependent chain upload -> cell list -> evaluation -> download"))
+                               note="launch / latency bound: one dependent chain upload -> evaluation on the lists -> download"))
 
 
 def extra_lines(dev, ctx, fz, frames, batch, d_pos, d_z, d_xe, d_xf, cpu=True):

@@ -108,6 +108,18 @@ int uf3_ctx_timing_reset(uf3_ctx *ctx, int enable);
 int uf3_ctx_timing_read(uf3_ctx *ctx, double *featurize_ms, int64_t *featurize_launches,
                         double *neighbor_ms, double *gram_ms, double *eval_ms);
 
+/* MD route of the evaluator (round 5).  The reference's calculator rebuilds supercell, distances and neighbour pairs on every
+ * call (uf3/forcefield/calculator.py:124-153, 183-343).  With skin > 0 (Angstrom; 0 = off, the default) the whole-batch
+ * energy + force entries (uf3_eval[_virial][_dev] on a basis with 3-body terms) keep, per atom, every neighbour image within
+ * r_cut + skin in device memory -- sorted by (species, reference supercell index), no geometry -- and each call filters that
+ * list by the true distances of ITS positions: the surviving pairs and 3-body lists are the reference's, in a fixed order, so
+ * results do not depend on when the lists were built.  They are rebuilt when the batch layout (offsets, cells, pbc), the basis
+ * or a species changes, and when an atom has moved more than skin / 2 from where they were built (checked on the device in
+ * every call; past 0.7 of that the next call rebuilds first, past all of it the call repeats itself on new lists).
+ * uf3_ctx_md_stats: list builds | calls served from lists | calls repeated because an atom outran the skin. */
+int uf3_ctx_md_skin(uf3_ctx *ctx, double skin);
+int uf3_ctx_md_stats(uf3_ctx *ctx, int64_t *builds, int64_t *steps, int64_t *redone);
+
 int uf3_basis_create(uf3_ctx *ctx, const uf3_basis_spec *spec, uf3_basis **out);
 void uf3_basis_destroy(uf3_basis *basis);
 /* Diagnostics: which featurizer specialisations the basis uses.  Bit 0: one-body + pair blocks (the launch that also

@@ -836,6 +836,122 @@ def test_md_step_call_routes_agree_bit_for_bit(monkeypatch):
     assert abs(e[0] - e_o) <= 1e-11 * max(1.0, abs(e_o)) and worst_elementwise(f, f_o, 1e-9) <= 1.0
 
 
+def _random_model(basis, seed):
+    model = ls.WeightedLinearModel(basis)
+    coeff = np.random.default_rng(seed).normal(0, 0.05, basis.n_feats)
+    coeff[basis.col_idx] = 0.0
+    model.coefficients = coeff
+    return model, coeff
+
+
+@pytest.mark.parametrize("reps,steps", [((4, 4, 4), 50), ((6, 6, 6), 50), ((12, 12, 12), 24), ((25, 25, 20), 12)])
+def test_md_route_on_a_displaced_trajectory_does_not_depend_on_rebuilds(reps, steps):
+    """the evaluator's MD route (persistent superset lists with a skin, uf3_ctx_md_skin) on a seeded
+    random walk that crosses several rebuilds -- every step bit-equal to the same route with the lists built from scratch at
+    that step's positions (a step filters the lists by the true distances and takes the survivors in (species, supercell
+    index) order, so when the lists were built cannot matter), equal to the plain rebuild-everything route to rounding, and
+    to the oracle to 1e-9.  Sizes: the one-cell fast path (128 atoms), the one-workgroup cell list (432), the pinned staging
+    block (3456), plain copies (25 000).  Reference: uf3/forcefield/calculator.py:124-153, 183-343 (every call from scratch)."""
+    elements, numbers = (['Mo', 'W'], [42, 74]) if reps[0] <= 12 else (['V', 'Mo', 'W'], [23, 42, 74])
+    basis = synthetic.notebook_basis(elements)
+    model, coeff = _random_model(basis, 21)
+    calc_md = calculator.UFCalculator(model, md_skin=0.4)
+    calc_plain = calculator.UFCalculator(model, md_skin=0.0)
+    start = synthetic.lattice_frame("bcc", reps, 3.165, numbers, seed=31)
+    n = len(start)
+    ctx = _lib.get_context(None)
+    for _ in range(2):
+        calc_plain.evaluate_frames([start])                      # (list capacity tuned: the MD route starts from a tuned context)
+    walk = 0.03 if n < 10000 else 0.02
+    rng = np.random.default_rng(5)
+    path, pos = [], start.get_positions()
+    for step in range(steps):
+        pos = pos + rng.uniform(-walk, walk, (n, 3))
+        if step in (steps // 2, steps // 2 + 1):
+            pos[7] += [0.31, -0.2, 0.12]                          # one atom outruns skin / 2 in a single step: the call repeats itself
+        path.append(pos.copy())                                   # (twice: were the first absorbed by a rebuild that was due anyway)
+
+    def frame(step):
+        return Atoms(numbers=start.get_atomic_numbers(), positions=path[step], cell=start.get_cell(), pbc=True)
+
+    # the walk on lists that live across steps
+    ctx.md_skin(0.0)
+    before = ctx.md_stats()
+    trace = [calc_md.evaluate_frames([frame(step)], virial=step % 5 == 4) for step in range(steps)]
+    after = ctx.md_stats()
+    builds, served, redone = (after[k] - before[k] for k in ("builds", "steps", "redone"))
+    assert 3 <= builds < steps and redone >= 1 and served >= steps, (builds, served, redone)
+    # every step against lists built from scratch at that step's positions, the plain route, the oracle
+    ob = O.OracleBasis(basis)
+    for step in range(steps):
+        atoms, virial, got = frame(step), step % 5 == 4, trace[step]
+        hot = step in (steps // 2, steps // 2 + 1)
+        if step % 2 == 0 or hot:
+            ctx.md_skin(0.0)                                      # (changing the skin drops the lists: the next call builds them)
+            fresh = calc_md.evaluate_frames([atoms], virial=virial)
+            assert np.array_equal(got[0], fresh[0]) and np.array_equal(got[1], fresh[1]), step
+            if virial:
+                assert np.array_equal(got[3], fresh[3]), step
+        if step % 6 == 0 or hot:
+            plain = calc_plain.evaluate_frames([atoms], virial=virial)
+            assert abs(got[0][0] - plain[0][0]) <= 1e-12 * max(1.0, abs(plain[0][0])) and rel_err(got[1], plain[1]) < 1e-12
+            if virial:
+                assert rel_err(got[3], plain[3]) < 1e-11
+        if (step % 12 == 0 or hot) and n <= 4000:
+            e_o, f_o = O.evaluate(ob, atoms, coeff)
+            assert abs(got[0][0] - e_o) <= 1e-11 * max(1.0, abs(e_o)) and worst_elementwise(got[1], f_o, 1e-9) <= 1.0
+    ctx.md_skin(0.0)
+
+
+def test_md_route_rebuilds_on_layout_species_and_cell_changes():
+    """The lists are tied to (basis, offsets, cells, pbc, species): any change rebuilds them instead of serving stale neighbours;
+    a batch of several frames runs on lists as well.  Each result against the plain route."""
+    basis = synthetic.notebook_basis(['Mo', 'W'])
+    model, coeff = _random_model(basis, 22)
+    calc_md = calculator.UFCalculator(model, md_skin=0.5)
+    calc_plain = calculator.UFCalculator(model, md_skin=0.0)
+    frames = [synthetic.lattice_frame("bcc", r, 3.165, [42, 74], seed=40 + k) for k, r in enumerate(((4, 4, 4), (3, 3, 2), (5, 4, 3)))]
+    ctx = _lib.get_context(None)
+    for _ in range(2):
+        calc_plain.evaluate_frames(frames)
+
+    cases = []                                                      # (the plain route afterwards: its calls would drop the lists)
+
+    def md(batch, virial=False):
+        cases.append((batch, virial, calc_md.evaluate_frames(batch, virial=virial)))
+
+    ctx.md_skin(0.0)
+    s0 = ctx.md_stats()
+    md(frames); md(frames, True); md(frames)
+    s1 = ctx.md_stats()
+    assert s1["builds"] - s0["builds"] == 1 and s1["steps"] - s0["steps"] >= 3
+    md([frames[0]])                                                 # another layout
+    assert ctx.md_stats()["builds"] == s1["builds"] + 1
+    z = frames[0].get_atomic_numbers()
+    z[5] = 42 if z[5] == 74 else 74
+    swapped = Atoms(numbers=z, positions=frames[0].get_positions(), cell=frames[0].get_cell(), pbc=True)
+    md([swapped])                                                   # a species changed: found on the device, the call repeats on new lists
+    s2 = ctx.md_stats()
+    assert s2["builds"] == s1["builds"] + 2 and s2["redone"] >= s1["redone"] + 1
+    strained = Atoms(numbers=z, positions=swapped.get_positions() * 1.01, cell=np.asarray(swapped.get_cell()) * 1.01, pbc=True)
+    md([strained], True)                                            # the cell changed
+    assert ctx.md_stats()["builds"] == s2["builds"] + 1
+    wrapped = strained.get_positions()
+    wrapped[3] += np.asarray(strained.get_cell())[0]                # an atom re-wrapped by a whole lattice vector: far beyond the skin
+    md([Atoms(numbers=z, positions=wrapped, cell=strained.get_cell(), pbc=True)])
+    assert ctx.md_stats()["redone"] >= s2["redone"] + 1
+    with pytest.raises(_lib.SpeciesError):
+        z2 = z.copy(); z2[0] = 29
+        calc_md.evaluate_frames([Atoms(numbers=z2, positions=wrapped, cell=strained.get_cell(), pbc=True)])
+    md([strained])
+    for batch, virial, a in cases:
+        b = calc_plain.evaluate_frames(batch, virial=virial)
+        assert np.allclose(a[0], b[0], rtol=1e-12, atol=1e-12) and rel_err(a[1], b[1]) < 1e-12
+        if virial:
+            assert rel_err(a[3], b[3]) < 1e-11
+    ctx.md_skin(0.0)
+
+
 def _table_fit_case():
     import pandas as pd
     t = np.load(os.path.join(GOLDEN, "table_fit.npz"), allow_pickle=False)
@@ -1011,7 +1127,10 @@ def test_atom_range_shares_add_up_to_the_frame():
         e_g, f_g, _, v_g = calc.evaluate_frames([atoms], virial=True)
     finally:
         del os.environ["UF3_EVAL_GATHER"]
-    assert e_g[0] == e[0] and np.array_equal(v_g, v) and rel_err(f_g, f) < 1e-12
+    if float(os.environ.get("UF3_MD_SKIN", 0)) > 0:          # (the whole suite on the MD route: its pair sums run in list order)
+        assert abs(e_g[0] - e[0]) <= 1e-12 * abs(e[0]) and rel_err(v_g, v) < 1e-12 and rel_err(f_g, f) < 1e-12
+    else:
+        assert e_g[0] == e[0] and np.array_equal(v_g, v) and rel_err(f_g, f) < 1e-12
     os.environ["UF3_SEPARATE_N3"] = "1"                                       # lists from k_build_n3 instead of the
     try:                                                                      # centre pass's own walk: same lists
         e_s, f_s, _, v_s = calc.evaluate_frames([atoms], virial=True)

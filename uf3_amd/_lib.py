@@ -23,7 +23,8 @@ EXPORTS = ["uf3_ctx_create", "uf3_ctx_destroy", "uf3_ctx_set_stream", "uf3_ctx_s
            "uf3_eval", "uf3_eval_dev", "uf3_eval_virial", "uf3_eval_virial_dev", "uf3_eval_atoms", "uf3_eval_atoms_dev",
            "uf3_eval_centres", "uf3_eval_centres_dev",
            "uf3_neighbors_debug", "uf3_fit_rows_dev", "uf3_fit_pack_dev", "uf3_gram_force_rows_dev",
-           "uf3_pair_geometry", "uf3_distance_matrix", "uf3_direction_cosines"]
+           "uf3_pair_geometry", "uf3_distance_matrix", "uf3_direction_cosines",
+           "uf3_ctx_md_skin", "uf3_ctx_md_stats"]
 
 
 class HipUnavailable(RuntimeError):
@@ -114,6 +115,8 @@ def load():
         lib.uf3_ctx_timing_reset.argtypes = [vp, C.c_int]
         lib.uf3_ctx_timing_read.argtypes = [vp, C.POINTER(dbl), C.POINTER(i64), C.POINTER(dbl),
                                             C.POINTER(dbl), C.POINTER(dbl)]
+        lib.uf3_ctx_md_skin.argtypes = [vp, dbl]
+        lib.uf3_ctx_md_stats.argtypes = [vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)]
         lib.uf3_basis_create.argtypes = [vp, C.POINTER(BasisSpec), C.POINTER(vp)]
         lib.uf3_basis_destroy.argtypes = [vp]
         lib.uf3_basis_destroy.restype = None
@@ -198,6 +201,20 @@ class Context:
                                                 C.byref(g), C.byref(e)))
         return dict(featurize_ms=f.value, featurize_launches=n.value, neighbor_ms=nb.value,
                     gram_ms=g.value, eval_ms=e.value)
+
+    def md_skin(self, skin):
+        """MD route of the evaluator: keep per-atom superset neighbour lists out to ``r_cut + skin`` (Angstrom) on the device
+        and reuse them while no atom has moved more than ``skin / 2``; 0 switches it off (every call rebuilds, as the
+        reference's calculator does).  Results do not depend on when the lists were built."""
+        skin = float(skin)
+        if getattr(self, "_md_skin", 0.0) != skin:
+            self.check(self.lib.uf3_ctx_md_skin(self.handle, skin))
+            self._md_skin = skin
+
+    def md_stats(self):
+        b, s, r = C.c_int64(), C.c_int64(), C.c_int64()
+        self.check(self.lib.uf3_ctx_md_stats(self.handle, C.byref(b), C.byref(s), C.byref(r)))
+        return dict(builds=b.value, steps=s.value, redone=r.value)
 
     def __del__(self):
         try:

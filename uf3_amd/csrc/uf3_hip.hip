@@ -98,6 +98,22 @@ struct uf3_ctx {
     hipEvent_t pin_in_done = nullptr, pin_geo_done = nullptr;   // the copies out of pin_in / pin_geo have executed
     std::vector<double> coeff_shadow;   // host copy of the model last uploaded by uf3_eval (c1 | c2 | c3)
     const void *coeff_dev = nullptr;    // ... and where it lives
+    // MD route of the evaluator (uf3_ctx_md_skin): persistent superset lists with a skin, see k_build_sup.  Everything a step
+    // needs besides the current positions lives in its own buffers -- the workspace above belongs to whichever call ran last
+    struct MdState {
+        double skin = 0.0;              // 0: off
+        bool valid = false;             // the lists describe (basis, offsets, cells, pbc) below
+        bool stale = false;             // some atom has passed the early-warning displacement: rebuild before the next step
+        const uf3_basis *basis = nullptr;
+        int natoms = 0, n_frames = 0, cap = 0;
+        std::vector<int64_t> offsets;
+        std::vector<double> cells;
+        std::vector<uint8_t> pbc;
+        Buf ent, cnt, pos_ref, geo, frame_of, spec;       // geo: FrameGeom [n_frames] | atom offsets [n_frames + 1]
+        size_t geo_bytes = 0;
+        long long builds = 0, steps = 0, redone = 0;
+    } md;
+    bool md_step = false;               // the last eval_impl ran on the persistent lists (its status words 2 / 3 are the displacement flags)
     // timing
     bool timing = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -202,6 +218,7 @@ extern "C" void uf3_ctx_destroy(uf3_ctx *c) {
                   &c->bin_cnt};
     for (Buf *b : all) b->release();
     for (Buf &b : c->gram_tiles) b.release();
+    { Buf *mdb[] = {&c->md.ent, &c->md.cnt, &c->md.pos_ref, &c->md.geo, &c->md.frame_of, &c->md.spec}; for (Buf *b : mdb) b->release(); }
     c->pin_in.release(); c->pin_geo.release(); c->pin_out.release(); c->pin_flags.release();
     for (auto &pd : c->pending_chk) if (pd.ev) hipEventDestroy(pd.ev);
     if (c->pin_in_done) hipEventDestroy(c->pin_in_done);
@@ -873,7 +890,9 @@ static bool invert3(const double *m, double *inv) {
     return true;
 }
 
-static int make_geom(uf3_ctx *c, const uf3_basis *b, const uf3_frames *fr, int f, FrameGeom &g, int &bin_cursor) {
+// (extra: added to the search radius of the cell list -- the skin of the MD route's superset lists; the reference's image range
+// `fac` and the window stay those of r_cut)
+static int make_geom(uf3_ctx *c, const uf3_basis *b, const uf3_frames *fr, int f, FrameGeom &g, int &bin_cursor, double extra = 0.0) {
     const double *cell = fr->cells + 9 * (size_t)f;
     const uint8_t *pbc = fr->pbc + 3 * (size_t)f;
     int64_t lo = fr->atom_offsets[f], hi = fr->atom_offsets[f + 1];
@@ -915,7 +934,7 @@ static int make_geom(uf3_ctx *c, const uf3_basis *b, const uf3_frames *fr, int f
         }
     }
     if (!invert3(eff, g.inv)) return fail(c, UF3_EINVAL, "cell is singular along a periodic direction");
-    double rs = b->host.rsearch;
+    double rs = b->host.rsearch + extra;
     // bins of half the search radius (scan radius 2): 125 bins cover 15.6 r^3 instead of 27 r^3 for 27 full-size bins
     const double bin_frac = getenv("UF3_BIN_FRAC") ? atof(getenv("UF3_BIN_FRAC")) : 0.5;
     if (n_per) {
@@ -969,6 +988,7 @@ struct Prepared {
     const int *frame_of = nullptr;
     const signed char *spec = nullptr;
     const int64_t *d_offsets = nullptr;
+    size_t geo_bytes = 0;       // FrameGeom [n_frames] | atom offsets [n_frames + 1] behind `geoms`, one block
     bool deferred = false;      // the list-capacity / error flags of this build have not been read yet
     bool flags_zeroed = false;  // the cell-list stage has already zeroed the n3 / candidate status words
 };
@@ -1068,7 +1088,7 @@ static int build_halo_lists(uf3_basis *b, const Prepared &P, const N3Lists &n3, 
 // n3_lo / n3_hi: build the 3-body lists only for the atoms [n3_lo, n3_hi) and for their halo (the atoms in their
 // lists): what a rank of a decomposed frame needs (n3_hi < 0: every atom)
 static int prepare(uf3_basis *b, const uf3_frames *fr, const double *d_pos, const int32_t *d_z, bool need_n3,
-                   Prepared &P, bool defer_check = false, int64_t n3_lo = 0, int64_t n3_hi = -1) {
+                   Prepared &P, bool defer_check = false, int64_t n3_lo = 0, int64_t n3_hi = -1, double extra_radius = 0.0) {
     uf3_ctx *c = b->ctx;
     if (!fr || fr->n_frames < 1 || !fr->atom_offsets || !fr->cells || !fr->pbc)
         return fail(c, UF3_EINVAL, "bad uf3_frames");
@@ -1083,7 +1103,7 @@ static int prepare(uf3_basis *b, const uf3_frames *fr, const double *d_pos, cons
     int bin_cursor = 0;
     double dens = 0;
     for (int f = 0; f < nf; f++) {
-        int rc = make_geom(c, b, fr, f, geoms[f], bin_cursor);
+        int rc = make_geom(c, b, fr, f, geoms[f], bin_cursor, extra_radius);
         if (rc) return rc;
         int n = geoms[f].atom_hi - geoms[f].atom_lo;
         double vol = 0;
@@ -1176,6 +1196,7 @@ static int prepare(uf3_basis *b, const uf3_frames *fr, const double *d_pos, cons
     HIPCHK(c, hipGetLastError());
 
     P.natoms = natoms; P.n_frames = nf; P.nbins = nbins; P.max_density = dens;
+    P.geo_bytes = geo_bytes + off_bytes;
     P.geoms = d_geoms;
     P.frame_of = c->frame_of.as<int>();
     P.spec = c->spec.as<signed char>();
@@ -1289,11 +1310,13 @@ extern "C" int uf3_featurize_dev(uf3_basis *b, const uf3_frames *fr, const doubl
     const bool has3 = b->host.T > 0 && !old_n3;
     if (has3 && c->n3_cap == 0) c->n3_cap = n3_cap_estimate(b, P.max_density);
     int cap = 1;
-    if (c->cand_cap == 0) {
+    auto cand_estimate = [&]() {
         double r = b->host.rsearch;
         double est = P.max_density > 0 ? 4.18879 * r * r * r * P.max_density : 64.0;
-        c->cand_cap = std::max(32, ((int)(est * 1.6) + 16 + 7) / 8 * 8);
-    }
+        return std::max(32, ((int)(est * 1.6) + 16 + 7) / 8 * 8);
+    };
+    if (c->cand_cap == 0) c->cand_cap = cand_estimate();
+    bool caps_reset = false;
     FeatArgs A;
     A.B = b->dev; A.trios = b->d_trios; A.recs = b->d_recs; A.colsrc = b->d_colsrc;
     A.frag = nullptr;
@@ -1355,6 +1378,7 @@ extern "C" int uf3_featurize_dev(uf3_basis *b, const uf3_frames *fr, const doubl
         // LDS layout: those calls keep the matrix-core / generic launches, which handled them before k_featurize3 existed)
         const bool feat3 = b->feat3_ok && want_f && (has3 || old_n3) && !img_launch && cap <= 255 && !c->env_no_feat3 &&
                            feat3_lds_bytes(b, cap, want_e && !A.e_direct) <= UF3_LDS_LIMIT;
+        bool restart = false;
         {
             Timed tm(c, T_FEAT);
             for (int mode = 0; mode <= 9; mode++) {
@@ -1427,6 +1451,17 @@ extern "C" int uf3_featurize_dev(uf3_basis *b, const uf3_frames *fr, const doubl
                     lds = feat_lds_bytes(F, S, cap, A.cand_cap, want_e && !A.e_direct, recs_lds ? n_rec_mode : 0, 0, A.dense_stage,
                                          A.dense_nrec, A.n_pair_cols) + lds_extra;
                 }
+                if (lds > UF3_LDS_LIMIT && !caps_reset) {
+                    // the capacities are grow-only memories of the densest batch this context has seen: a sparser batch on a wider
+                    // basis must not fail on them -- back to this batch's own estimates, once, and the call starts over
+                    const int est3 = has3 ? n3_cap_estimate(b, P.max_density) : 0, estc = cand_estimate();
+                    if ((has3 && c->n3_cap > est3) || c->cand_cap > estc) {
+                        if (has3 && c->n3_cap > est3) { c->n3_cap = est3; c->n3_tuned = false; }
+                        if (c->cand_cap > estc) { c->cand_cap = estc; c->cand_tuned = false; }
+                        caps_reset = restart = true;
+                        break;
+                    }
+                }
                 if (lds > UF3_LDS_LIMIT) return fail(c, UF3_EOVERFLOW, "featurizer LDS footprint exceeds 160 KB (F or neighbour count too large)");
                 // blocks of WPB waves, each walking a contiguous run of atoms (keeps the shared energy row on
                 // one frame); many more blocks than resident slots (measured: 2 per slot 3400 frames/s, 16-48 per slot
@@ -1476,7 +1511,7 @@ extern "C" int uf3_featurize_dev(uf3_basis *b, const uf3_frames *fr, const doubl
 #undef UF3_LAUNCH
 #undef UF3_LAUNCH1
             }
-            if (feat3) {
+            if (feat3 && !restart) {
                 Feat3Args G;
                 G.B = b->dev; G.trios = b->d_trios; G.rows = b->d_f3rows; G.n_rows = b->n_f3rows;
                 G.fsrc = b->d_f3src; G.trio_fsrc = b->d_f3off; G.n_fsrc = b->n_f3src;
@@ -1524,6 +1559,7 @@ extern "C" int uf3_featurize_dev(uf3_basis *b, const uf3_frames *fr, const doubl
             }
         }
         HIPCHK(c, hipGetLastError());
+        if (restart) continue;
         if ((!has3 || c->n3_tuned) && c->cand_tuned && !old_n3 && !getenv("UF3_SYNC_FEATURIZE")) {
             // capacities known from earlier calls: do not wait.  The status words follow the launches into a pinned
             // slot; the next call on this context / uf3_ctx_synchronize looks at them (UF3_ERETRY if they overflowed)
@@ -1622,6 +1658,105 @@ extern "C" int uf3_featurize(uf3_basis *b, const uf3_frames *fr, const double *p
 }
 
 // ------------------------------------------------------------------------------ eval
+// ---- MD route: persistent superset lists with a skin (uf3_ctx_md_skin) ----------------------
+// The reference's calculator rebuilds supercell, distances and neighbour pairs on every call (calculator.py:124-153,
+// 183-343).  An MD loop repeats that work on almost the same positions: with a skin s the context keeps, per atom, every
+// neighbour image within r_cut + s of it (k_build_sup: who, which image, reference supercell index, species -- sorted by
+// (species, supercell index), no geometry) and a step filters that list by the TRUE distances of the current positions.  The
+// survivors come out in the order the rebuild-every-step route sorts its lists into, so a step's result does not depend on
+// when the lists were built.  Valid while no atom has moved more than s / 2 from where the lists were built, the cells, the
+// offsets and the species are the same: the kernel checks displacement and species, the host the rest.
+static bool md_key_matches(const uf3_ctx::MdState &md, const uf3_basis *b, const uf3_frames *fr) {
+    if (!md.valid || md.basis != b || !fr || !fr->atom_offsets || !fr->cells || !fr->pbc || fr->n_frames != md.n_frames) return false;
+    const size_t nf = (size_t)fr->n_frames;
+    return fr->atom_offsets[nf] == md.natoms && !memcmp(fr->atom_offsets, md.offsets.data(), 8 * (nf + 1)) &&
+           !memcmp(fr->cells, md.cells.data(), 72 * nf) && !memcmp(fr->pbc, md.pbc.data(), 3 * nf);
+}
+
+static int md_build(uf3_basis *b, const uf3_frames *fr, const double *d_pos, const int32_t *d_z, Prepared &P) {
+    uf3_ctx *c = b->ctx;
+    uf3_ctx::MdState &md = c->md;
+    md.valid = false; md.stale = false;
+    int rc = prepare(b, fr, d_pos, d_z, false, P, false, 0, -1, md.skin);      // cell list at r_cut + skin
+    if (rc) return rc;
+    hipStream_t st = c->stream;
+    const int natoms = P.natoms, nf = P.n_frames;
+    const double r_sup = b->host.rsearch + md.skin;
+    if (md.cap == 0 || md.basis != b) {
+        const double est = P.max_density > 0 ? 4.18879 * r_sup * r_sup * r_sup * P.max_density : 64.0;
+        md.cap = std::max(32, ((int)(est * 1.3) + 16 + 7) / 8 * 8);
+    }
+    int *flags = c->flags.as<int>();
+    const double r_sup2 = r_sup * r_sup * (1.0 + 1e-12);
+    for (int attempt = 0; ; attempt++) {
+        const int cap = md.cap;
+        HIPCHK(c, md.ent.ensure(sizeof(SupEntry) * (size_t)natoms * cap));
+        HIPCHK(c, md.cnt.ensure(sizeof(int) * (size_t)natoms));
+        HIPCHK(c, hipMemsetAsync(flags + 5, 0, sizeof(int), st));
+        const size_t lds = (size_t)cap * 16;
+        if ((int)lds > c->lds_max) return fail(c, UF3_EOVERFLOW, "MD neighbour list does not fit in LDS");
+        hipLaunchKernelGGL(k_build_sup, dim3((unsigned)((natoms + 7) / 8 * 8)), dim3(64), lds, st, b->dev, P.geoms, P.frame_of, P.cl,
+                           d_pos, natoms, r_sup2, md.ent.as<SupEntry>(), md.cnt.as<int>(), cap, flags + 5);
+        HIPCHK(c, hipGetLastError());
+        int fl[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        HIPCHK(c, hipMemcpyAsync(fl, flags, sizeof(fl), hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipStreamSynchronize(st));
+        c->pin_in_busy = false;
+        if (fl[0]) return check_flags(c);
+        if (fl[5] <= cap) break;
+        if (attempt >= 5) return fail(c, UF3_EOVERFLOW, "MD neighbour capacity did not converge");
+        md.cap = (fl[5] + 8 + 7) / 8 * 8;
+    }
+    // what a step reads besides the lists: frame geometry | offsets, frame and species of every atom, the positions of the build
+    const size_t geo_bytes = (sizeof(FrameGeom) * (size_t)nf + 15) / 16 * 16;
+    HIPCHK(c, md.geo.ensure(P.geo_bytes));
+    HIPCHK(c, md.frame_of.ensure(4 * (size_t)natoms));
+    HIPCHK(c, md.spec.ensure((size_t)natoms));
+    HIPCHK(c, md.pos_ref.ensure(24 * (size_t)natoms));
+    HIPCHK(c, hipMemcpyAsync(md.geo.p, P.geoms, P.geo_bytes, hipMemcpyDeviceToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(md.frame_of.p, P.frame_of, 4 * (size_t)natoms, hipMemcpyDeviceToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(md.spec.p, P.spec, (size_t)natoms, hipMemcpyDeviceToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(md.pos_ref.p, d_pos, 24 * (size_t)natoms, hipMemcpyDeviceToDevice, st));
+    md.geo_bytes = geo_bytes;
+    md.basis = b; md.natoms = natoms; md.n_frames = nf;
+    md.offsets.assign(fr->atom_offsets, fr->atom_offsets + nf + 1);
+    md.cells.assign(fr->cells, fr->cells + 9 * (size_t)nf);
+    md.pbc.assign(fr->pbc, fr->pbc + 3 * (size_t)nf);
+    md.valid = true;
+    md.builds++;
+    return UF3_OK;
+}
+
+// a step on the lists: `P` as the kernels behind it expect it, from the context's persistent copies
+static void md_prepared(const uf3_ctx *c, Prepared &P) {
+    const uf3_ctx::MdState &md = c->md;
+    P = Prepared();
+    P.natoms = md.natoms; P.n_frames = md.n_frames;
+    P.geoms = md.geo.as<FrameGeom>();
+    P.d_offsets = (const int64_t *)((const char *)md.geo.p + md.geo_bytes);
+    P.frame_of = md.frame_of.as<int>();
+    P.spec = md.spec.as<signed char>();
+    P.flags_zeroed = true;
+    std::memset(&P.n3, 0, sizeof(P.n3));
+    std::memset(&P.cl, 0, sizeof(P.cl));
+}
+
+extern "C" int uf3_ctx_md_skin(uf3_ctx *c, double skin) {
+    if (!c) return fail(nullptr, UF3_EINVAL, "null ctx");
+    if (!(skin >= 0.0) || skin > 4.0) return fail(c, UF3_EINVAL, "uf3_ctx_md_skin: skin must lie in [0, 4] Angstrom");
+    if (skin != c->md.skin) { c->md.valid = false; c->md.cap = 0; }
+    c->md.skin = skin;
+    return UF3_OK;
+}
+
+extern "C" int uf3_ctx_md_stats(uf3_ctx *c, int64_t *builds, int64_t *steps, int64_t *redone) {
+    if (!c) return fail(nullptr, UF3_EINVAL, "null ctx");
+    if (builds) *builds = c->md.builds;
+    if (steps) *steps = c->md.steps;
+    if (redone) *redone = c->md.redone;
+    return UF3_OK;
+}
+
 static int eval_impl(uf3_basis *b, const uf3_frames *fr, const double *d_pos, const int32_t *d_z, const double *c1,
                      const double *c2, const double *c3, double *d_energies, double *d_forces, double *d_virials,
                      int64_t atom_begin = 0, int64_t atom_end = -1, int *deferred_cap = nullptr, int *flags_tail = nullptr,
@@ -1644,10 +1779,37 @@ static int eval_impl(uf3_basis *b, const uf3_frames *fr, const double *d_pos, co
     const bool two_pass = (whole || centres) && d_forces && b->host.T > 0 && !getenv("UF3_EVAL_GATHER");
     const bool fuse = two_pass && c->n3_tuned && c->n3_cap > 0 && !getenv("UF3_SEPARATE_N3");
     Prepared P;
-    int rc = prepare(b, fr, d_pos, d_z, !fuse, P, deferred_cap != nullptr, atom_begin, whole ? -1 : atom_end);
-    if (rc) return rc;
-    if (deferred_cap) *deferred_cap = P.deferred ? P.n3.cap : 0;
+    int rc;
     hipStream_t st = c->stream;
+    // MD route: the candidates of every atom from the context's persistent lists instead of a cell-list walk (see md_build)
+    const bool md_step = c->md.skin > 0.0 && fuse && whole && !getenv("UF3_NO_MD");
+    c->md_step = md_step;
+    if (md_step) {
+        HIPCHK(c, hipSetDevice(c->device));
+        if (c->md.stale || !md_key_matches(c->md, b, fr)) {
+            rc = md_build(b, fr, d_pos, d_z, P);
+            if (rc) return rc;
+        } else if (c->pin_in_pending && d_pos == c->stage_pos.as<double>()) {
+            // a small batch staged by upload_frames: positions | species are still in the caller's pinned block
+            const size_t at = c->pin_in_pending;
+            c->pin_in_pending = 0;
+            if (c->md.natoms <= UF3_SMALL_ATOMS && !getenv("UF3_NO_ZERO_COPY")) {
+                hipLaunchKernelGGL(k_md_fetch, dim3(1), dim3(256), 0, st, (const int4 *)c->pin_in.p, (int4 *)c->stage_pos.p, (int)(at / 16),
+                                   c->flags.as<int>());
+                c->pin_in_busy = true;
+            } else {
+                HIPCHK(c, hipMemcpyAsync(c->stage_pos.p, c->pin_in.p, at, hipMemcpyHostToDevice, st));
+                HIPCHK(c, hipEventRecord(c->pin_in_done, st));
+                HIPCHK(c, hipMemsetAsync(c->flags.as<int>() + 1, 0, 4 * sizeof(int), st));
+            }
+        } else
+            HIPCHK(c, hipMemsetAsync(c->flags.as<int>() + 1, 0, 4 * sizeof(int), st));
+        md_prepared(c, P);
+    } else {
+        rc = prepare(b, fr, d_pos, d_z, !fuse, P, deferred_cap != nullptr, atom_begin, whole ? -1 : atom_end);
+        if (rc) return rc;
+    }
+    if (deferred_cap) *deferred_cap = P.deferred ? P.n3.cap : 0;
     size_t n1 = (size_t)b->host.S, n2 = b->c2_len, n3 = b->c3_len;
     HIPCHK(c, c->coeff.ensure(8 * (n1 + n2 + n3 + 1)));
     double *dc = c->coeff.as<double>();
@@ -1693,7 +1855,18 @@ static int eval_impl(uf3_basis *b, const uf3_frames *fr, const double *d_pos, co
                 if (rc) return rc;
                 A.fuse_n3 = 1;
                 A.n3_need = c->flags.as<int>() + 1;
-                if (!P.flags_zeroed || attempt) HIPCHK(c, hipMemsetAsync(A.n3_need, 0, sizeof(int), st));
+                if (!P.flags_zeroed || attempt) HIPCHK(c, hipMemsetAsync(A.n3_need, 0, (md_step ? 3 : 1) * sizeof(int), st));
+            }
+            if (md_step) {
+                const uf3_ctx::MdState &md = c->md;
+                A.fuse_n3 = 0;
+                A.geoms = P.geoms; A.frame_of = P.frame_of; A.spec = P.spec;
+                A.sup_ent = md.ent.as<SupEntry>(); A.sup_cnt = md.cnt.as<int>(); A.sup_cap = md.cap;
+                A.pos_ref = md.pos_ref.as<double>(); A.z_now = d_z;
+                const double hard = 0.5 * md.skin * (1.0 - 1e-9), soft = 0.7 * hard;
+                A.md_hard2 = hard * hard; A.md_soft2 = soft * soft;
+                A.md_flags = c->flags.as<int>() + 2;
+                c->md.steps++;
             }
             const size_t cap = (size_t)A.n3.cap;
             // own list (32 + 20 B per entry), queue of bonds, force on the entries (24), walk-order entries + keys (48)
@@ -1712,12 +1885,20 @@ static int eval_impl(uf3_basis *b, const uf3_frames *fr, const double *d_pos, co
                 }
                 else if (centres && fuse) HIPCHK(c, hipMemsetAsync(A.n3.cnt, 0, sizeof(int) * (size_t)P.natoms, st));   // (lists not built: empty)
                 const dim3 eg((unsigned)((n_centres + 7) / 8 * 8));
-                if (cap == 16 && !getenv("UF3_EVAL_NO_CAP16")) {
-                    if (A.virial) hipLaunchKernelGGL((k_eval<false, true, 16>), eg, dim3(64), lds, st, A);
-                    else hipLaunchKernelGGL((k_eval<false, false, 16>), eg, dim3(64), lds, st, A);
+                {
+                    // instance: strain derivative | list capacity 16 as a constant | candidates from the persistent lists | centre
+                    // legs from per-bond tables (one set of 3-body legs, T <= 64, short lists: the usual case)
+                    const bool cap16 = cap == 16 && !getenv("UF3_EVAL_NO_CAP16");
+                    const bool tab = b->host.trio_legs_uniform && b->host.T <= WAVE && cap <= EVAL_TAB_CAP && !getenv("UF3_EVAL_NO_TAB");
+                    const int inst = (A.virial ? 1 : 0) | (cap16 ? 2 : 0) | (md_step ? 4 : 0) | (tab ? 8 : 0);
+#define UF3_EVAL_CASE(I) case I: hipLaunchKernelGGL((k_eval<false, ((I) & 1) != 0, ((I) & 2) ? 16 : 0, ((I) & 4) != 0, ((I) & 8) != 0>), eg, dim3(64), lds, st, A); break;
+                    switch (inst) {
+                        UF3_EVAL_CASE(0) UF3_EVAL_CASE(1) UF3_EVAL_CASE(2) UF3_EVAL_CASE(3) UF3_EVAL_CASE(4) UF3_EVAL_CASE(5)
+                        UF3_EVAL_CASE(6) UF3_EVAL_CASE(7) UF3_EVAL_CASE(8) UF3_EVAL_CASE(9) UF3_EVAL_CASE(10) UF3_EVAL_CASE(11)
+                        UF3_EVAL_CASE(12) UF3_EVAL_CASE(13) UF3_EVAL_CASE(14) UF3_EVAL_CASE(15)
+                    }
+#undef UF3_EVAL_CASE
                 }
-                else if (A.virial) hipLaunchKernelGGL((k_eval<false, true>), eg, dim3(64), lds, st, A);
-                else hipLaunchKernelGGL((k_eval<false, false>), eg, dim3(64), lds, st, A);
                 if (fuse && deferred_cap) *deferred_cap = (int)cap;
                 if (centres) {
                     // the block's lists exist now (this launch built them, or prepare did): the halo's, then the collection
@@ -1749,6 +1930,17 @@ static int eval_impl(uf3_basis *b, const uf3_frames *fr, const double *d_pos, co
                 HIPCHK(c, hipMemcpyAsync(fl, c->flags.p, sizeof(fl), hipMemcpyDeviceToHost, st));
                 HIPCHK(c, hipStreamSynchronize(st));
                 if (fl[0]) return check_flags(c);
+                if (md_step && fl[2]) {
+                    // an atom beyond skin / 2 of where the lists were built (or of another species): the results are void --
+                    // new lists from these positions, and again
+                    if (attempt >= 5) return fail(c, UF3_EOVERFLOW, "MD neighbour lists did not settle");
+                    c->md.redone++;
+                    rc = md_build(b, fr, d_pos, d_z, P);
+                    if (rc) return rc;
+                    md_prepared(c, P);
+                    continue;
+                }
+                if (md_step && fl[3]) c->md.stale = true;        // (early warning: rebuild in front of the next step)
                 if (fl[1] > (int)cap) {
                     if (attempt >= 5) return fail(c, UF3_EOVERFLOW, "3-body neighbour capacity did not converge");
                     c->n3_cap = (fl[1] + 8 + 7) / 8 * 8;
@@ -1825,6 +2017,8 @@ static int eval_host(uf3_basis *b, const uf3_frames *fr, const double *pos, cons
             {
                 const int *fl = (const int *)((const char *)c->pin_out.p + total);
                 if (fl[0]) return check_flags(c);
+                if (c->md_step && fl[2]) { c->md.valid = false; c->md.redone++; continue; }      // (lists outrun: rebuilt by the repeat)
+                if (c->md_step && fl[3]) c->md.stale = true;
                 if (cap_used && fl[1] > cap_used) { c->n3_cap = (fl[1] + 8 + 7) / 8 * 8; continue; }
             }
             const double *h = (const double *)c->pin_out.p;

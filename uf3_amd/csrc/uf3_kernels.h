@@ -2468,12 +2468,76 @@ __device__ __forceinline__ bool trio_value(const BasisDev *B, const double *c3, 
     return true;
 }
 
+// The same value and partials for the centre pass of k_eval when every trio has the legs of trio 0 (the usual case): the two
+// CENTRE legs are bonds of the atom's list, evaluated once per bond into an LDS table (interval | four values | four
+// derivatives) instead of once per triplet -- 14 evaluations instead of 182 per atom, and ONE knot record live per lane instead
+// of three (72 of the kernel's registers) --, leg n at the guessed interval together with the first coefficient rows, the rows
+// after them two groups ahead of the arithmetic: two dependent memory round trips per triplet instead of five.  Same knot
+// records, same de Boor triangle, same order of the contraction as trio_value: the same bits.
+// tl / tm: [8] values | derivatives of legs l / m; il / im their intervals; lut_off from the wave's table
+__device__ __forceinline__ bool trio_value_tab(const KnotRec *recs, const double *c3, int lut_off, const LegDev &l2, int dim_m, int dim_n,
+                                               int il, int im, const double *tl, const double *tm, double rn, bool want_grad,
+                                               double &val, double *grad) {
+    typedef double coeff4 __attribute__((ext_vector_type(4), aligned(8)));
+    KnotRec kn;
+    const int in_g = load_interval_guess<1>(recs, l2, rn, kn);
+    const int mn = dim_m * dim_n;
+    // (rows through ONE per-lane 32-bit byte offset on top of the uniform grid pointer: as 64-bit per-lane pointers the row
+    // addresses, hoisted by the compiler, cost two registers each)
+    const unsigned off0 = 8u * (unsigned)(lut_off + (il - 3) * mn + (im - 3) * dim_n - 3);
+    unsigned off = off0 + 8u * (unsigned)in_g;
+    auto row = [&](int a, int q) { return *(const coeff4 *)((const char *)c3 + (off + 8u * (unsigned)(a * mn + q * dim_n))); };
+    coeff4 cc[EVAL_CGROUP];
+#pragma unroll
+    for (int q = 0; q < EVAL_CGROUP; q++) cc[q] = row(q >> 2, q & 3);
+    asm volatile("" ::: "memory");
+    const int in = load_interval_fix<1>(recs, l2, rn, in_g, kn);
+    if (__builtin_expect(in != in_g, 0)) {             // (non-uniform knots, or rn on an interval boundary)
+        off = off0 + 8u * (unsigned)in;
+#pragma unroll
+        for (int q = 0; q < EVAL_CGROUP; q++) cc[q] = row(q >> 2, q & 3);
+        asm volatile("" ::: "memory");
+    }
+    double vn[4], dn[4];
+    bspline4<true>(kn, rn, vn, dn);
+    double v = 0, g0 = 0, g1 = 0, g2 = 0;
+    double sa = 0, sda = 0, sma = 0;
+#pragma unroll
+    for (int q0 = 0; q0 < 16; q0 += EVAL_CGROUP) {
+        if (q0 > 0) {
+#pragma unroll
+            for (int q = 0; q < EVAL_CGROUP; q++) cc[q] = row((q0 + q) >> 2, (q0 + q) & 3);
+            asm volatile("" ::: "memory");
+        }
+#pragma unroll
+        for (int q = 0; q < EVAL_CGROUP; q++) {
+            const int a = (q0 + q) >> 2, b = (q0 + q) & 3;
+            const double s = cc[q][0] * vn[0] + cc[q][1] * vn[1] + cc[q][2] * vn[2] + cc[q][3] * vn[3];
+            const double vmb = tm[b];
+            if (b == 0) { sa = vmb * s; } else sa += vmb * s;
+            if (want_grad) {
+                const double sd = cc[q][0] * dn[0] + cc[q][1] * dn[1] + cc[q][2] * dn[2] + cc[q][3] * dn[3];
+                const double dmb = tm[4 + b];
+                if (b == 0) { sda = vmb * sd; sma = dmb * s; } else { sda += vmb * sd; sma += dmb * s; }
+            }
+            if (b == 3) {
+                const double vla = tl[a];
+                v += vla * sa;
+                if (want_grad) { g0 += tl[4 + a] * sa; g1 += vla * sma; g2 += vla * sda; }
+            }
+        }
+    }
+    val = v; grad[0] = g0; grad[1] = g1; grad[2] = g2;
+    return true;
+}
+
 __device__ __forceinline__ double wave_sum(double v) {
     for (int sh = 32; sh > 0; sh >>= 1) v += __shfl_xor(v, sh);
     return v;
 }
 
 #define EVAL_Q 5          // doubles per queued bond of the evaluator
+#define EVAL_TAB_CAP 36   // longest list whose per-bond leg tables (2 x 64 B + 2 x 4 B per entry) fit over the queue of the pair walk
 // GATHER: every atom also walks the triplets it belongs to as a neighbour (each triplet evaluated at its three atoms;
 // what a block of atoms of a decomposed frame needs).  !GATHER: each triplet once, at its centre, which also sums the
 // force it puts on each of its list entries (nbr_f, in LDS first); k_eval_collect then adds to every atom what its
@@ -2487,11 +2551,14 @@ __device__ __forceinline__ double wave_sum(double v) {
 // instructions' immediate fields instead of scalar registers, of which the kernel spills 73)
 // (MD: the candidates of the pair walk come from the persistent superset lists, see k_build_sup -- no cell list, no sort; only
 // with !GATHER.  The survivors are taken in list order, which is the order the fused build below sorts into.)
-#ifndef EVAL_MD_MINW
-#define EVAL_MD_MINW 4
+// (TAB: the centre legs of the triplets from per-bond tables, trio_value_tab -- chosen by the host when every trio has the legs of
+// trio 0, T <= 64 and the list capacity is <= EVAL_TAB_CAP; one knot record live per lane instead of three: 109 registers,
+// four waves per SIMD.  A template parameter because the two triplet paths in ONE kernel cost the registers of the larger.)
+#ifndef EVAL_TAB_MINW
+#define EVAL_TAB_MINW 4
 #endif
-template <bool GATHER, bool VIR, int CAP = 0, bool MD = false>
-__global__ void __launch_bounds__(64, MD ? EVAL_MD_MINW : EVAL_MINW)
+template <bool GATHER, bool VIR, int CAP = 0, bool MD = false, bool TAB = false>
+__global__ void __launch_bounds__(64, TAB ? EVAL_TAB_MINW : EVAL_MINW)
 k_eval(EvalArgs A) {
     extern __shared__ __align__(16) unsigned char smem[];
     const BasisDev *B = A.B;
@@ -2707,7 +2774,46 @@ k_eval(EvalArgs A) {
         __syncthreads();
         pce.lap(11);
         int n_pairs = n * (n - 1) / 2;
-        for (int p = lane; p < n_pairs; p += WAVE) {
+        // Centre pass, one set of 3-body legs (trio_value_tab): the centre legs of every bond once, into LDS (over the queue of
+        // the pair walk, which is done with); the species -> trio and trio -> grid offset tables in one register each, looked up
+        // with lane shuffles instead of two dependent loads
+        const bool tab_path = TAB && !GATHER && n_pairs > 0;
+        double *tlv = queue, *tmv = tlv;
+        int *tli = (int *)(queue + 16 * EVAL_TAB_CAP), *tmi = tli;
+        LegDev leg_n;
+        int tab_dim_m = 0, tab_dim_n = 0, trio_tab = -1, lut_tab = 0;
+        if (tab_path) {
+            const TrioDev *t0 = load_const(&B->trios);
+            const LegDev l0 = load_const(&t0->leg[0]), l1 = load_const(&t0->leg[1]);
+            leg_n = load_const(&t0->leg[2]);
+            tab_dim_m = load_const(&t0->dim_m); tab_dim_n = load_const(&t0->dim_n);
+            const bool same01 = l0.rec_off == l1.rec_off && l0.nk == l1.nk;
+            if (!same01) { tmv = tlv + 8 * EVAL_TAB_CAP; tmi = tli + EVAL_TAB_CAP; }
+            trio_tab = B->trio_of[sm * UF3_MAX_SPECIES * UF3_MAX_SPECIES + lane];
+            typedef const __attribute__((address_space(1))) TrioDev *GlobalTrio;
+            if (lane < load_const(&B->T)) lut_tab = ((GlobalTrio)t0)[lane].lut_off;
+            for (int q = lane; q < n; q += WAVE) {
+                const double r = orr[q];
+                for (int which = 0; which < (same01 ? 1 : 2); which++) {
+                    const LegDev &lg = which ? l1 : l0;
+                    int i = -1;
+                    double v[4] = {0, 0, 0, 0}, d[4] = {0, 0, 0, 0};
+                    if ((r > lg.t0) & (r < lg.tlast)) {
+                        KnotRec k;
+                        i = load_interval<1>(recs_g, lg, r, k);
+                        bspline4<true>(k, r, v, d);
+                    }
+                    double *dst = (which ? tmv : tlv) + 8 * q;
+                    for (int u = 0; u < 4; u++) { dst[u] = v[u]; dst[4 + u] = d[u]; }
+                    (which ? tmi : tli)[q] = i;
+                }
+            }
+            __syncthreads();
+        }
+#pragma unroll 1
+        for (int p0 = 0; p0 < n_pairs; p0 += WAVE) {      // (not unrolled: two triplets' loads in flight per lane do not fit the registers)
+            const bool act = p0 + lane < n_pairs;
+            const int p = act ? p0 + lane : 0;
             // (pair index -> (aa < bb) as in trio_walk_geom: hardware root + one guard each way, no loops)
             int bb = (int)((1.0f + __builtin_amdgcn_sqrtf(fmaf(8.0f, (float)p, 1.0f))) * 0.5f);
             bb -= (bb * (bb - 1) / 2 > p) ? 1 : 0;
@@ -2715,12 +2821,22 @@ k_eval(EvalArgs A) {
             int aa = p - bb * (bb - 1) / 2;
             double rl = orr[aa], rm = orr[bb];
             double rn = norm3_leg(ox[bb] - ox[aa], oy[bb] - oy[aa], oz[bb] - oz[aa]);
-            int trio = B->trio_of[(sm * UF3_MAX_SPECIES + ospec[aa]) * UF3_MAX_SPECIES + ospec[bb]];
             double val, gr[3];
 #if defined(UF3_ABLATE_EVAL) && UF3_ABLATE_EVAL == 1
             if (rl > 0) continue;           // (experiment: no triplet values)
 #endif
-            if (!trio_value(B, A.c3, trio, rl, rm, rn, want_f || want_v, val, gr)) continue;
+            if (TAB) {
+                // (the shuffles in uniform control flow: every lane of the tables takes part)
+                const int trio = __shfl(trio_tab, ospec[aa] * UF3_MAX_SPECIES + ospec[bb]);
+                const int lut_off = __shfl(lut_tab, max(trio, 0));
+                const int il = tli[aa], im = tmi[bb];
+                if (!(act & (trio >= 0) & (il >= 0) & (im >= 0) & (rn > leg_n.t0) & (rn < leg_n.tlast))) continue;
+                trio_value_tab(recs_g, A.c3, lut_off, leg_n, tab_dim_m, tab_dim_n, il, im, tlv + 8 * aa, tmv + 8 * bb, rn,
+                               want_f || want_v, val, gr);
+            } else if (!TAB) {
+                int trio = B->trio_of[(sm * UF3_MAX_SPECIES + ospec[aa]) * UF3_MAX_SPECIES + ospec[bb]];
+                if (!act || !trio_value(B, A.c3, trio, rl, rm, rn, want_f || want_v, val, gr)) continue;
+            }
             e += val;
             if (want_f) {   // F_m = -dV/dR_m = gl * u_ij + gm * u_ik
                 const double a = gr[0] * fast_rcp(rl), b = gr[1] * fast_rcp(rm);

@@ -15,6 +15,8 @@ ASE is importable and is otherwise a duck-typed stand-alone.
 """
 import ctypes as C
 
+import os
+
 import numpy as np
 
 from uf3_amd import _lib
@@ -59,11 +61,16 @@ def coefficients_by_interaction(element_list, interactions_map, partition_sizes,
 class UFCalculator(_Base):
     implemented_properties = ['energy', 'forces', 'stress']
 
-    def __init__(self, model, device=None, **kwargs):
+    def __init__(self, model, device=None, md_skin=None, **kwargs):
+        """``md_skin`` (Angstrom): keep the device's neighbour lists between calls out to ``r_cut + md_skin`` and rebuild them
+        only when an atom has moved more than ``md_skin / 2`` (``_lib.Context.md_skin``) -- what an MD or relaxation loop
+        wants; 0 rebuilds everything on every call like the reference (``calculator.py:124-153``).  Default: the
+        environment's ``UF3_MD_SKIN``, else 0."""
         super().__init__(**kwargs)
         self.bspline_config = model.bspline_config
         self.model = model
         self.device = device
+        self.md_skin = float(os.environ.get("UF3_MD_SKIN", 0.0)) if md_skin is None else float(md_skin)
         basis = self.bspline_config
         self.solutions = coefficients_by_interaction(basis.element_list, basis.interactions_map,
                                                      basis.partition_sizes, model.coefficients)
@@ -96,6 +103,8 @@ class UFCalculator(_Base):
     def evaluate_frames(self, atoms_list, forces=True, virial=False):
         """Energies [n_frames], forces [sum N, 3] (and dE/d(strain) [n_frames, 6]) of a batch of frames."""
         ctx = _lib.get_context(self.device)
+        if getattr(ctx, "_md_skin", 0.0) != self.md_skin:
+            ctx.md_skin(self.md_skin)
         db = _lib.device_basis(self.bspline_config, ctx)
         batch = _lib.FrameBatch(atoms_list)
         e = np.empty(batch.n_frames)
