@@ -1127,10 +1127,9 @@ def test_atom_range_shares_add_up_to_the_frame():
         e_g, f_g, _, v_g = calc.evaluate_frames([atoms], virial=True)
     finally:
         del os.environ["UF3_EVAL_GATHER"]
-    if float(os.environ.get("UF3_MD_SKIN", 0)) > 0:          # (the whole suite on the MD route: its pair sums run in list order)
-        assert abs(e_g[0] - e[0]) <= 1e-12 * abs(e[0]) and rel_err(v_g, v) < 1e-12 and rel_err(f_g, f) < 1e-12
-    else:
-        assert e_g[0] == e[0] and np.array_equal(v_g, v) and rel_err(f_g, f) < 1e-12
+    # (to rounding, not to the bit: the two routes are different kernels since round 5 -- the centre pass takes its centre legs
+    # from per-bond tables and leg n's knot records from LDS, and the compiler contracts the two spline evaluations differently)
+    assert abs(e_g[0] - e[0]) <= 1e-13 * abs(e[0]) and rel_err(v_g, v) < 1e-13 and rel_err(f_g, f) < 1e-12
     os.environ["UF3_SEPARATE_N3"] = "1"                                       # lists from k_build_n3 instead of the
     try:                                                                      # centre pass's own walk: same lists
         e_s, f_s, _, v_s = calc.evaluate_frames([atoms], virial=True)

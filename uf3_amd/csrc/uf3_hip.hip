@@ -110,6 +110,8 @@ struct uf3_ctx {
         std::vector<double> cells;
         std::vector<uint8_t> pbc;
         Buf ent, cnt, pos_ref, geo, frame_of, spec;       // geo: FrameGeom [n_frames] | atom offsets [n_frames + 1]
+        Buf inbox, surv;                                  // see EvalArgs::md_inbox / md_surv
+        size_t inbox_zeroed = 0;                          // bytes of inbox known to hold no stamp of a future launch
         size_t geo_bytes = 0;
         long long builds = 0, steps = 0, redone = 0;
     } md;
@@ -152,6 +154,7 @@ struct uf3_basis {
     double r_cut = 0;
     // k_featurize3 (3-body force rows by bond factorisation, uf3_feat3.h): eligibility and tables
     bool feat3_ok = false;
+    bool eval_tab_ok = false;        // the evaluator's centre pass may run its TAB instances (see k_eval)
     double *d_f3rows = nullptr;      // window rows of the centre legs and of leg n
     int n_f3rows = 0;
     unsigned short *d_f3src = nullptr;   // fold tables
@@ -218,7 +221,7 @@ extern "C" void uf3_ctx_destroy(uf3_ctx *c) {
                   &c->bin_cnt};
     for (Buf *b : all) b->release();
     for (Buf &b : c->gram_tiles) b.release();
-    { Buf *mdb[] = {&c->md.ent, &c->md.cnt, &c->md.pos_ref, &c->md.geo, &c->md.frame_of, &c->md.spec}; for (Buf *b : mdb) b->release(); }
+    { Buf *mdb[] = {&c->md.ent, &c->md.cnt, &c->md.pos_ref, &c->md.geo, &c->md.frame_of, &c->md.spec, &c->md.inbox, &c->md.surv}; for (Buf *b : mdb) b->release(); }
     c->pin_in.release(); c->pin_geo.release(); c->pin_out.release(); c->pin_flags.release();
     for (auto &pd : c->pending_chk) if (pd.ev) hipEventDestroy(pd.ev);
     if (c->pin_in_done) hipEventDestroy(c->pin_in_done);
@@ -720,6 +723,8 @@ extern "C" int uf3_basis_create(uf3_ctx *c, const uf3_basis_spec *s, uf3_basis *
         }
         if (trios[t].dim_l != trios[0].dim_l || trios[t].dim_m != trios[0].dim_m || trios[t].dim_n != trios[0].dim_n) h.trio_legs_uniform = 0;
     }
+    // k_eval<TAB>: one set of 3-body legs, the trio tables in one register each, leg n's knot records in the workgroup's LDS
+    b->eval_tab_ok = h.trio_legs_uniform && h.T <= WAVE && trios[0].leg[2].nk - 7 <= EVAL_TAB_KN;
     // ---- k_featurize3 (uf3_feat3.h): one window layout for all trios, centre legs alike, a W window of at most 31 positions;
     // trios with two equal neighbour species must fold symmetrically in (l, m)
     {
@@ -1707,6 +1712,19 @@ static int md_build(uf3_basis *b, const uf3_frames *fr, const double *d_pos, con
         if (attempt >= 5) return fail(c, UF3_EOVERFLOW, "MD neighbour capacity did not converge");
         md.cap = (fl[5] + 8 + 7) / 8 * 8;
     }
+    hipLaunchKernelGGL(k_sup_reverse, dim3((unsigned)(((natoms + 15) / 16 + 7) / 8 * 8)), dim3(256), 0, st, md.ent.as<SupEntry>(),
+                       (const int *)md.cnt.as<int>(), md.cap, natoms);
+    HIPCHK(c, hipGetLastError());
+    // inbox of every (atom, list position): zeroed when (re)allocated -- stamps start at 1
+    {
+        const size_t need = 32 * (size_t)natoms * md.cap;
+        const void *before = md.inbox.p;
+        HIPCHK(c, md.inbox.ensure(need));
+        if (md.inbox.p != before || md.inbox_zeroed < need) {
+            HIPCHK(c, hipMemsetAsync(md.inbox.p, 0, md.inbox.cap, st));
+            md.inbox_zeroed = md.inbox.cap;
+        }
+    }
     // what a step reads besides the lists: frame geometry | offsets, frame and species of every atom, the positions of the build
     const size_t geo_bytes = (sizeof(FrameGeom) * (size_t)nf + 15) / 16 * 16;
     HIPCHK(c, md.geo.ensure(P.geo_bytes));
@@ -1867,10 +1885,14 @@ static int eval_impl(uf3_basis *b, const uf3_frames *fr, const double *d_pos, co
                 A.md_hard2 = hard * hard; A.md_soft2 = soft * soft;
                 A.md_flags = c->flags.as<int>() + 2;
                 c->md.steps++;
+                HIPCHK(c, c->md.surv.ensure(sizeof(int) * (size_t)P.natoms * A.n3.cap));
+                A.md_inbox = c->md.inbox.as<double>(); A.md_surv = c->md.surv.as<int>();
+                A.md_stamp = (double)c->md.steps;
             }
             const size_t cap = (size_t)A.n3.cap;
             // own list (32 + 20 B per entry), queue of bonds, force on the entries (24), walk-order entries + keys (48)
-            const size_t lds = cap * 32 + (5 * cap + 2) * 4 + 16 + 2 * WAVE * EVAL_Q * sizeof(double) + cap * 24 + cap * 48;
+            // (+ leg n's knot records for the TAB instances)
+            const size_t lds = cap * 32 + (5 * cap + 2) * 4 + 16 + 2 * WAVE * EVAL_Q * sizeof(double) + cap * 24 + cap * 48 + 16 + EVAL_TAB_KN * sizeof(KnotRec);
             if ((int)lds > c->lds_max) return fail(c, UF3_EOVERFLOW, "3-body neighbour list does not fit in LDS");
             if (two_pass) {
                 HIPCHK(c, c->nbr_f.ensure(24 * (size_t)P.natoms * cap));
@@ -1889,7 +1911,7 @@ static int eval_impl(uf3_basis *b, const uf3_frames *fr, const double *d_pos, co
                     // instance: strain derivative | list capacity 16 as a constant | candidates from the persistent lists | centre
                     // legs from per-bond tables (one set of 3-body legs, T <= 64, short lists: the usual case)
                     const bool cap16 = cap == 16 && !getenv("UF3_EVAL_NO_CAP16");
-                    const bool tab = b->host.trio_legs_uniform && b->host.T <= WAVE && cap <= EVAL_TAB_CAP && !getenv("UF3_EVAL_NO_TAB");
+                    const bool tab = b->eval_tab_ok && cap <= EVAL_TAB_CAP && !getenv("UF3_EVAL_NO_TAB");
                     const int inst = (A.virial ? 1 : 0) | (cap16 ? 2 : 0) | (md_step ? 4 : 0) | (tab ? 8 : 0);
 #define UF3_EVAL_CASE(I) case I: hipLaunchKernelGGL((k_eval<false, ((I) & 1) != 0, ((I) & 2) ? 16 : 0, ((I) & 4) != 0, ((I) & 8) != 0>), eg, dim3(64), lds, st, A); break;
                     switch (inst) {
@@ -1906,7 +1928,8 @@ static int eval_impl(uf3_basis *b, const uf3_frames *fr, const double *d_pos, co
                     if (fuse || getenv("UF3_NO_HALO")) { int rh = build_halo_lists(b, P, A.n3, d_pos, (int)atom_begin, (int)atom_end, zero3); if (rh) return rh; }
                     A.halo_mark = c->halo.as<int>();
                 }
-                hipLaunchKernelGGL(k_eval_collect, dim3((unsigned)(((P.natoms + 15) / 16 + 7) / 8 * 8)), dim3(256), 0, st, A);
+                if (md_step) hipLaunchKernelGGL(k_eval_collect_md, dim3((unsigned)(((P.natoms + 15) / 16 + 7) / 8 * 8)), dim3(256), 0, st, A);
+                else hipLaunchKernelGGL(k_eval_collect, dim3((unsigned)(((P.natoms + 15) / 16 + 7) / 8 * 8)), dim3(256), 0, st, A);
             } else if (atom_end > atom_begin) {
                 if (A.virial) hipLaunchKernelGGL((k_eval<true, true>), dim3((unsigned)((atom_end - atom_begin + 7) / 8 * 8)), dim3(64), lds, st, A);
                 else hipLaunchKernelGGL((k_eval<true, false>), dim3((unsigned)((atom_end - atom_begin + 7) / 8 * 8)), dim3(64), lds, st, A);

@@ -514,6 +514,32 @@ k_build_sup(const BasisDev *B, const FrameGeom *geoms, const int *frame_of, Cell
     }
 }
 
+// where an atom sits in each of its neighbours' lists: entry q of atom m (neighbour j at image shift s) gets, packed above its
+// species, 1 + the index of (m at shift -s) in j's list (0: not there -- the two ends of a pair at the very edge of the build
+// radius may round differently).  What a step's centre pass needs to hand a neighbour its share of the triplet forces directly
+// (k_eval<MD>: md_inbox) instead of leaving it to be looked for (k_eval_collect).  16 lanes per atom.
+__global__ void __launch_bounds__(256)
+k_sup_reverse(SupEntry *ent, const int *cnt, int cap, int natoms) {
+    const int wg = (int)((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3));
+    const int m = wg * 16 + (threadIdx.x >> 4), sub = threadIdx.x & 15;
+    if (m >= natoms) return;
+    const int n = min(cnt[m], cap);
+    for (int q = sub; q < n; q += 16) {
+        SupEntry *mine = ent + (size_t)m * cap + q;
+        const int j = mine->parent;
+        int s0, s1, s2;
+        unpack3(mine->shiftc, s0, s1, s2);
+        const int back = pack3(-s0, -s1, -s2), nj = min(cnt[j], cap);
+        const SupEntry *theirs = ent + (size_t)j * cap;
+        int hit = -1;
+        for (int r = 0; r < nj; r++) {
+            const int2 key = *(const int2 *)&theirs[r].parent;
+            if (key.x == m && key.y == back) hit = r;
+        }
+        mine->spec = (mine->spec & 0xff) | ((hit + 1) << 8);      // (the species byte is all the scan of other lanes' entries reads... it reads parent | shiftc only)
+    }
+}
+
 // a small batch's staged block (positions | species, in the caller's pinned memory) into device memory, and the status words
 // of the launches behind it zeroed: what k_prepare_small does on the way for calls that build a cell list
 __global__ void __launch_bounds__(256)
@@ -2381,6 +2407,10 @@ struct EvalArgs {
     const double *pos_ref;        // [natoms][3] positions the lists were built from
     const int32_t *z_now;         // [natoms] atomic numbers of THIS call (compared with the species the lists were built for)
     double md_hard2, md_soft2;    // squared displacement limits: (skin / 2)^2 -- beyond it the lists may miss a neighbour -- and the early warning
+    double *md_inbox;             // [natoms][sup_cap][4]: force the triplets centred on a neighbour put on this atom | the step's stamp, at the
+                                  // atom's own list position of that neighbour (written by the neighbour's centre pass)
+    int *md_surv;                 // [natoms][n3.cap] list position (in the superset list) of each entry of the step's 3-body list
+    double md_stamp;              // this launch's stamp: inbox entries with another one are left over from earlier steps
     int *md_flags;                // [0] = 1: some atom moved past the hard limit (results invalid, rebuild and repeat); [1] = 1: past the soft one
 };
 
@@ -2475,12 +2505,19 @@ __device__ __forceinline__ bool trio_value(const BasisDev *B, const double *c3, 
 // after them two groups ahead of the arithmetic: two dependent memory round trips per triplet instead of five.  Same knot
 // records, same de Boor triangle, same order of the contraction as trio_value: the same bits.
 // tl / tm: [8] values | derivatives of legs l / m; il / im their intervals; lut_off from the wave's table
+template <int AS>
 __device__ __forceinline__ bool trio_value_tab(const KnotRec *recs, const double *c3, int lut_off, const LegDev &l2, int dim_m, int dim_n,
                                                int il, int im, const double *tl, const double *tm, double rn, bool want_grad,
                                                double &val, double *grad) {
     typedef double coeff4 __attribute__((ext_vector_type(4), aligned(8)));
     KnotRec kn;
-    const int in_g = load_interval_guess<1>(recs, l2, rn, kn);
+#ifdef UF3_ABL_KN
+    int in_g = 3 + (int)((rn - l2.t0) * l2.inv_h);
+    in_g = in_g < 3 ? 3 : (in_g > l2.nk - 5 ? l2.nk - 5 : in_g);
+    for (int u = 0; u < 6; u++) { kn.t[u] = l2.t0 + (in_g - 5 + u) * 0.4; kn.r[u] = 2.5 / (1 + (u > 0) + (u > 2)); }
+#else
+    const int in_g = load_interval_guess<AS>(recs, l2, rn, kn);
+#endif
     const int mn = dim_m * dim_n;
     // (rows through ONE per-lane 32-bit byte offset on top of the uniform grid pointer: as 64-bit per-lane pointers the row
     // addresses, hoisted by the compiler, cost two registers each)
@@ -2491,7 +2528,11 @@ __device__ __forceinline__ bool trio_value_tab(const KnotRec *recs, const double
 #pragma unroll
     for (int q = 0; q < EVAL_CGROUP; q++) cc[q] = row(q >> 2, q & 3);
     asm volatile("" ::: "memory");
-    const int in = load_interval_fix<1>(recs, l2, rn, in_g, kn);
+#ifdef UF3_ABL_KN
+    const int in = in_g;
+#else
+    const int in = load_interval_fix<AS>(recs, l2, rn, in_g, kn);
+#endif
     if (__builtin_expect(in != in_g, 0)) {             // (non-uniform knots, or rn on an interval boundary)
         off = off0 + 8u * (unsigned)in;
 #pragma unroll
@@ -2504,7 +2545,11 @@ __device__ __forceinline__ bool trio_value_tab(const KnotRec *recs, const double
     double sa = 0, sda = 0, sma = 0;
 #pragma unroll
     for (int q0 = 0; q0 < 16; q0 += EVAL_CGROUP) {
+#ifdef UF3_ABL_HALF
+        if (q0 == 4) {
+#else
         if (q0 > 0) {
+#endif
 #pragma unroll
             for (int q = 0; q < EVAL_CGROUP; q++) cc[q] = row((q0 + q) >> 2, (q0 + q) & 3);
             asm volatile("" ::: "memory");
@@ -2537,6 +2582,7 @@ __device__ __forceinline__ double wave_sum(double v) {
 }
 
 #define EVAL_Q 5          // doubles per queued bond of the evaluator
+#define EVAL_TAB_KN 24    // most knot intervals of leg n whose records the TAB instances copy into LDS
 #define EVAL_TAB_CAP 36   // longest list whose per-bond leg tables (2 x 64 B + 2 x 4 B per entry) fit over the queue of the pair walk
 // GATHER: every atom also walks the triplets it belongs to as a neighbour (each triplet evaluated at its three atoms;
 // what a block of atoms of a decomposed frame needs).  !GATHER: each triplet once, at its centre, which also sums the
@@ -2640,7 +2686,7 @@ k_eval(EvalArgs A) {
             sr.x = A.pos[3 * (size_t)en.parent]; sr.y = A.pos[3 * (size_t)en.parent + 1]; sr.z = A.pos[3 * (size_t)en.parent + 2];
             int s0, s1, s2;
             unpack3(en.shiftc, s0, s1, s2);
-            const int sj = en.spec;
+            const int sj = en.spec & 0xff, rev1 = en.spec >> 8;       // (1 + this atom's position in the neighbour's list, k_sup_reverse)
             double dx, dy, dz;
             image_delta(g, sr, s0, s1, s2, pm, dx, dy, dz);
             const double d = norm3_sq_rn(dx, dy, dz);
@@ -2653,12 +2699,11 @@ k_eval(EvalArgs A) {
             if (ok3) {
                 const int slot = count3 + mbcnt(mask3);
                 if (slot < cap) {
-                    N3Entry ne;
-                    ne.dx = dx; ne.dy = dy; ne.dz = dz; ne.r = sqrt(d);
-                    ne.parent = en.parent; ne.shiftc = en.shiftc; ne.sidx = en.sidx; ne.spec = sj;
-                    A.n3.ent[base3 + slot] = ne;
-                    ox[slot] = dx; oy[slot] = dy; oz[slot] = dz; orr[slot] = ne.r;
+                    // (no list in memory: the collection pass of this route reads the inbox, not the neighbours' lists)
+                    ox[slot] = dx; oy[slot] = dy; oz[slot] = dz; orr[slot] = sqrt(d);
                     oparent[slot] = en.parent; oshift[slot] = en.shiftc; osidx[slot] = en.sidx; ospec[slot] = sj;
+                    ooff[slot] = rev1;
+                    A.md_surv[base3 + slot] = q;
                     gx[slot] = 0.0; gy[slot] = 0.0; gz[slot] = 0.0;
                 }
             }
@@ -2778,9 +2823,10 @@ k_eval(EvalArgs A) {
         // the pair walk, which is done with); the species -> trio and trio -> grid offset tables in one register each, looked up
         // with lane shuffles instead of two dependent loads
         const bool tab_path = TAB && !GATHER && n_pairs > 0;
+        KnotRec *kn_lds = (KnotRec *)(smem + ((((unsigned char *)(ushift + cap) - smem) + 15) & ~(size_t)15));
         double *tlv = queue, *tmv = tlv;
         int *tli = (int *)(queue + 16 * EVAL_TAB_CAP), *tmi = tli;
-        LegDev leg_n;
+        LegDev leg_n, leg_n_lds;
         int tab_dim_m = 0, tab_dim_n = 0, trio_tab = -1, lut_tab = 0;
         if (tab_path) {
             const TrioDev *t0 = load_const(&B->trios);
@@ -2792,6 +2838,15 @@ k_eval(EvalArgs A) {
             trio_tab = B->trio_of[sm * UF3_MAX_SPECIES * UF3_MAX_SPECIES + lane];
             typedef const __attribute__((address_space(1))) TrioDev *GlobalTrio;
             if (lane < load_const(&B->T)) lut_tab = ((GlobalTrio)t0)[lane].lut_off;
+            // leg n's knot records (intervals 3 .. nk - 5) into LDS: 96 bytes per triplet less through the vector memory path,
+            // which bounds this kernel (the coefficient rows stay there: 512 bytes per triplet)
+            {
+                const int4 *src = (const int4 *)(recs_g + leg_n.rec_off + 3);
+                int4 *dst = (int4 *)kn_lds;
+                for (int q = lane; q < (leg_n.nk - 7) * 6; q += WAVE) dst[q] = src[q];
+            }
+            leg_n_lds = leg_n;
+            leg_n_lds.rec_off = -3;                      // (interval i of the copy: kn_lds[i - 3])
             for (int q = lane; q < n; q += WAVE) {
                 const double r = orr[q];
                 for (int which = 0; which < (same01 ? 1 : 2); which++) {
@@ -2831,7 +2886,7 @@ k_eval(EvalArgs A) {
                 const int lut_off = __shfl(lut_tab, max(trio, 0));
                 const int il = tli[aa], im = tmi[bb];
                 if (!(act & (trio >= 0) & (il >= 0) & (im >= 0) & (rn > leg_n.t0) & (rn < leg_n.tlast))) continue;
-                trio_value_tab(recs_g, A.c3, lut_off, leg_n, tab_dim_m, tab_dim_n, il, im, tlv + 8 * aa, tmv + 8 * bb, rn,
+                trio_value_tab<3>(kn_lds, A.c3, lut_off, leg_n_lds, tab_dim_m, tab_dim_n, il, im, tlv + 8 * aa, tmv + 8 * bb, rn,
                                want_f || want_v, val, gr);
             } else if (!TAB) {
                 int trio = B->trio_of[(sm * UF3_MAX_SPECIES + ospec[aa]) * UF3_MAX_SPECIES + ospec[bb]];
@@ -2860,7 +2915,19 @@ k_eval(EvalArgs A) {
             }
         }
         pce.lap(12);
-        if (want_f && !GATHER) {
+        if (want_f && !GATHER && MD) {
+            // what this centre's triplets put on each neighbour, straight into the neighbour's inbox at ITS list position of this atom
+            __syncthreads();
+            for (int q = lane; q < n; q += WAVE) {
+                const int rev1 = ooff[q];
+                if (rev1 > 0) {
+                    typedef double inbox4 __attribute__((ext_vector_type(4)));
+                    const inbox4 v = {gx[q], gy[q], gz[q], A.md_stamp};
+                    *(inbox4 *)(A.md_inbox + 4 * ((size_t)oparent[q] * A.sup_cap + (rev1 - 1))) = v;
+                }
+            }
+        }
+        if (want_f && !GATHER && !MD) {
             __syncthreads();
             for (int q = lane; q < n; q += WAVE) {
                 double *dst = A.nbr_f + 3 * (base + q);
@@ -2966,6 +3033,26 @@ k_eval_collect(EvalArgs A) {
         eval_collect_atom(A, m, sub, sx, sy, sz);
         if (sub == 0) { double *f = A.forces + 3 * (size_t)m; f[0] += sx; f[1] += sy; f[2] += sz; }
     }
+}
+
+// collection pass of the MD route: atom m adds what its neighbours' centre passes left in its inbox, over the entries of ITS
+// 3-body list in list order (16 lanes, entries strided, one shuffle tree: the order of the additions depends on the step's lists
+// only, not on when the superset lists were built).  An entry whose stamp is not this launch's has no counterpart this step.
+__global__ void __launch_bounds__(256)
+k_eval_collect_md(EvalArgs A) {
+    const int wg = (int)((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3));
+    const int m = wg * 16 + (threadIdx.x >> 4), sub = threadIdx.x & 15;
+    if (m >= A.natoms) return;
+    const int cap = A.n3.cap, n = min(A.n3.cnt[m], cap);
+    double sx = 0.0, sy = 0.0, sz = 0.0;
+    for (int t = sub; t < n; t += 16) {
+        typedef double inbox4 __attribute__((ext_vector_type(4)));
+        const int q = A.md_surv[(size_t)m * cap + t];
+        const inbox4 v = *(const inbox4 *)(A.md_inbox + 4 * ((size_t)m * A.sup_cap + q));
+        if (v[3] == A.md_stamp) { sx += v[0]; sy += v[1]; sz += v[2]; }
+    }
+    for (int sh = 8; sh > 0; sh >>= 1) { sx += __shfl_xor(sx, sh, 16); sy += __shfl_xor(sy, sh, 16); sz += __shfl_xor(sz, sh, 16); }
+    if (sub == 0) { double *f = A.forces + 3 * (size_t)m; f[0] += sx; f[1] += sy; f[2] += sz; }
 }
 
 // per-frame sums of per-atom quantities: blockIdx.y = 0 energy (width 1), 1..6 virial components (width 6, if
