@@ -1,6 +1,6 @@
 export TMPDIR=/tmp PYTHONPATH=$PWD
 mkdir -p gpurun_out/evtr
-timeout 200 rocprofv3 --kernel-trace -d gpurun_out/evtr -o t --output-format csv -- python tools/experiments/eval_trace.py 4 2>&1 | tail -1
+UF3_MD_SKIN=${UF3_MD_SKIN:-0} timeout 200 rocprofv3 --kernel-trace -d gpurun_out/evtr -o t --output-format csv -- python tools/experiments/eval_trace.py 4 2>&1 | tail -1
 python - <<'PY'
 import csv, glob
 rows = []

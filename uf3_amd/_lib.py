@@ -447,6 +447,19 @@ class FrameBatch:
         self.n_atoms = int(self.offsets[-1])
         self.struct = make_frames(self.offsets, self.cells, self.pbc)
 
+    def refresh(self, atoms):
+        """The same single frame again (an MD step): positions, species, cell and boundary flags copied into the existing
+        arrays -- no allocations, the C struct stays.  False when the atom count differs (build a new batch)."""
+        if self.n_frames != 1 or len(atoms) != self.n_atoms:
+            return False
+        pos = getattr(atoms, "positions", None)
+        np.copyto(self.pos, pos if pos is not None else atoms.get_positions())
+        num = getattr(atoms, "numbers", None)
+        np.copyto(self.z, num if num is not None else atoms.get_atomic_numbers(), casting="unsafe")
+        np.copyto(self.cells[0], atoms.get_cell())
+        self.pbc[0, :] = atoms.get_pbc() if hasattr(atoms, "get_pbc") else atoms.pbc
+        return True
+
 
 def make_frames(offsets, cells, pbc):
     f = Frames()

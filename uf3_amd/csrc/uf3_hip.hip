@@ -1891,8 +1891,12 @@ static int eval_impl(uf3_basis *b, const uf3_frames *fr, const double *d_pos, co
             }
             const size_t cap = (size_t)A.n3.cap;
             // own list (32 + 20 B per entry), queue of bonds, force on the entries (24), walk-order entries + keys (48)
-            // (+ leg n's knot records for the TAB instances)
-            const size_t lds = cap * 32 + (5 * cap + 2) * 4 + 16 + 2 * WAVE * EVAL_Q * sizeof(double) + cap * 24 + cap * 48 + 16 + EVAL_TAB_KN * sizeof(KnotRec);
+            const size_t lds_plain = cap * 32 + (5 * cap + 2) * 4 + 16 + 2 * WAVE * EVAL_Q * sizeof(double) + cap * 24 + cap * 48;
+            // TAB instances (centre legs from per-bond tables, k_eval): + leg n's knot records, + the tables when they do not fit
+            // over the queue.  Chosen by the basis alone -- not by the capacity -- unless the longer layout does not fit at all
+            const size_t lds_tab = lds_plain + 16 + EVAL_TAB_KN * sizeof(KnotRec) + (cap > EVAL_TAB_CAP ? 136 * cap + 16 : 0);
+            const bool tab = two_pass && b->eval_tab_ok && (int)lds_tab <= c->lds_max && !getenv("UF3_EVAL_NO_TAB");
+            const size_t lds = tab ? lds_tab : lds_plain;
             if ((int)lds > c->lds_max) return fail(c, UF3_EOVERFLOW, "3-body neighbour list does not fit in LDS");
             if (two_pass) {
                 HIPCHK(c, c->nbr_f.ensure(24 * (size_t)P.natoms * cap));
@@ -1911,7 +1915,6 @@ static int eval_impl(uf3_basis *b, const uf3_frames *fr, const double *d_pos, co
                     // instance: strain derivative | list capacity 16 as a constant | candidates from the persistent lists | centre
                     // legs from per-bond tables (one set of 3-body legs, T <= 64, short lists: the usual case)
                     const bool cap16 = cap == 16 && !getenv("UF3_EVAL_NO_CAP16");
-                    const bool tab = b->eval_tab_ok && cap <= EVAL_TAB_CAP && !getenv("UF3_EVAL_NO_TAB");
                     const int inst = (A.virial ? 1 : 0) | (cap16 ? 2 : 0) | (md_step ? 4 : 0) | (tab ? 8 : 0);
 #define UF3_EVAL_CASE(I) case I: hipLaunchKernelGGL((k_eval<false, ((I) & 1) != 0, ((I) & 2) ? 16 : 0, ((I) & 4) != 0, ((I) & 8) != 0>), eg, dim3(64), lds, st, A); break;
                     switch (inst) {

@@ -2824,8 +2824,12 @@ k_eval(EvalArgs A) {
         // with lane shuffles instead of two dependent loads
         const bool tab_path = TAB && !GATHER && n_pairs > 0;
         KnotRec *kn_lds = (KnotRec *)(smem + ((((unsigned char *)(ushift + cap) - smem) + 15) & ~(size_t)15));
-        double *tlv = queue, *tmv = tlv;
-        int *tli = (int *)(queue + 16 * EVAL_TAB_CAP), *tmi = tli;
+        // (the per-bond tables over the queue of the pair walk, which is done with; lists longer than EVAL_TAB_CAP: behind the knot
+        // records -- the choice of the instance must not depend on the capacity, or a context's first call, at the estimated
+        // capacity, would differ from the later ones in the last bit)
+        const int ts = cap <= EVAL_TAB_CAP ? EVAL_TAB_CAP : cap;
+        double *tlv = cap <= EVAL_TAB_CAP ? queue : (double *)(kn_lds + EVAL_TAB_KN), *tmv = tlv;
+        int *tli = (int *)(tlv + 16 * ts), *tmi = tli;
         LegDev leg_n, leg_n_lds;
         int tab_dim_m = 0, tab_dim_n = 0, trio_tab = -1, lut_tab = 0;
         if (tab_path) {
@@ -2834,7 +2838,7 @@ k_eval(EvalArgs A) {
             leg_n = load_const(&t0->leg[2]);
             tab_dim_m = load_const(&t0->dim_m); tab_dim_n = load_const(&t0->dim_n);
             const bool same01 = l0.rec_off == l1.rec_off && l0.nk == l1.nk;
-            if (!same01) { tmv = tlv + 8 * EVAL_TAB_CAP; tmi = tli + EVAL_TAB_CAP; }
+            if (!same01) { tmv = tlv + 8 * ts; tmi = tli + ts; }
             trio_tab = B->trio_of[sm * UF3_MAX_SPECIES * UF3_MAX_SPECIES + lane];
             typedef const __attribute__((address_space(1))) TrioDev *GlobalTrio;
             if (lane < load_const(&B->T)) lut_tab = ((GlobalTrio)t0)[lane].lut_off;

@@ -71,6 +71,7 @@ class UFCalculator(_Base):
         self.model = model
         self.device = device
         self.md_skin = float(os.environ.get("UF3_MD_SKIN", 0.0)) if md_skin is None else float(md_skin)
+        self._last_batch = None
         basis = self.bspline_config
         self.solutions = coefficients_by_interaction(basis.element_list, basis.interactions_map,
                                                      basis.partition_sizes, model.coefficients)
@@ -106,7 +107,11 @@ class UFCalculator(_Base):
         if getattr(ctx, "_md_skin", 0.0) != self.md_skin:
             ctx.md_skin(self.md_skin)
         db = _lib.device_basis(self.bspline_config, ctx)
-        batch = _lib.FrameBatch(atoms_list)
+        # (an MD loop hands over the same single frame again and again: its batch is kept and refreshed in place)
+        batch = self._last_batch
+        if len(atoms_list) != 1 or batch is None or not batch.refresh(atoms_list[0]):
+            batch = _lib.FrameBatch(atoms_list)
+            self._last_batch = batch if len(atoms_list) == 1 else None
         e = np.empty(batch.n_frames)
         f = np.empty((batch.n_atoms, 3)) if forces else None
         addr = _lib._addr                     # (plain ints: the host side of an MD-step call is as long as its kernels)
