@@ -213,6 +213,9 @@ def main(argv=None):
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    if fit and distributed and os.environ.get("UF3_NATIVE_RCCL"):
+        from uf3_amd import parallel
+        parallel.native_comm(ctx, rank, world)           # (the communicator comes up outside the timed region, like torch's)
     for _ in range(args.warmup):
         step()
     fence()
@@ -226,7 +229,8 @@ def main(argv=None):
     if fit:
         # the pieces of this rank, frozen columns folded out on the device, and the ONE collective of the fit
         from uf3_amd import parallel
-        flat = parallel.allreduce_packed(acc.packed())
+        # (UF3_NATIVE_RCCL: the collective through the library's own communicator, uf3_allreduce_sum_f64, instead of torch.distributed's)
+        flat = parallel.allreduce_packed(acc.packed(), ctx=ctx if os.environ.get("UF3_NATIVE_RCCL") else None)
     fence()
     elapsed = time.perf_counter() - t0
     timing = ctx.timing_read()
@@ -355,6 +359,8 @@ def main(argv=None):
                    roofline=roofline, cpu_baseline=cpu)
         out["config"]["rccl_world_size"] = dist.get_world_size() if distributed else 1
         out["config"]["forced_collective"] = bool(distributed and os.environ.get("UF3_FORCE_COLLECTIVE"))
+        out["config"]["collective"] = ("uf3_allreduce_sum_f64 (librccl behind the C ABI)" if distributed and os.environ.get("UF3_NATIVE_RCCL")
+                                       else "torch.distributed all_reduce (RCCL)")
         if world == 1 and not fit and wl == "c4" and args.atoms == 10000 and not args.no_extra:
             out["extra"] = extra_lines(dev, ctx, fz, frames, batch, d_pos, d_z, d_xe, d_xf,
                                        cpu=not args.no_cpu_baseline)
@@ -397,6 +403,9 @@ def eval_mode(args, torch, dist, dev, distributed, world, rank):
     # UF3_FORCE_COLLECTIVE under the launcher with ONE rank: the decomposed route (a block of centres = the whole frame) and its
     # all_reduce on the device buffer, so that a one-GPU box exercises what the ranks of an 8-GPU node run
     forced = bool(distributed and os.environ.get("UF3_FORCE_COLLECTIVE"))
+    native = bool(distributed and os.environ.get("UF3_NATIVE_RCCL"))       # the sum through uf3_allreduce_sum_f64 (librccl behind the C ABI)
+    if native:
+        parallel.native_comm(ctx, rank, world)
 
     def step():
         if world == 1 and not forced:
@@ -404,7 +413,10 @@ def eval_mode(args, torch, dist, dev, distributed, world, rank):
         else:
             # (uf3_eval_centres_dev zeroes every force row itself and overwrites energy / strain derivative: nothing to clear)
             ctx.check(ctx.lib.uf3_eval_centres_dev(*common, lo, hi, C.c_void_p(p_e), C.c_void_p(p_f), C.c_void_p(p_v)))
-            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+            if native:
+                ctx.allreduce_sum(flat.data_ptr(), flat.numel())
+            else:
+                dist.all_reduce(flat, op=dist.ReduceOp.SUM)
 
     def fence():
         if distributed:
@@ -446,7 +458,8 @@ def eval_mode(args, torch, dist, dev, distributed, world, rank):
                config=dict(workload=f"C5: {n}-atom ternary bcc frame, 2+3-body notebook basis, F={int(basis.n_feats)}", mode="eval",
                            atoms_per_frame=n, sharding=(f"blocks of centres x{world}, one all_reduce(SUM) of 3N+7 doubles per step"
                                                         if world > 1 or forced else "whole frame on one GPU"),
-                           rccl_world_size=dist.get_world_size() if distributed else 1, forced_collective=forced),
+                           rccl_world_size=dist.get_world_size() if distributed else 1, forced_collective=forced,
+                           collective=("uf3_allreduce_sum_f64 (librccl behind the C ABI)" if native else "torch.distributed all_reduce (RCCL)")),
                roofline=_roof(n * (100.0 * PAIRS_PER_ATOM + 700.0 * TRIPLETS_PER_ATOM), 52.0 * n + 75 + 8.0 * len(calc._c3), dt,
                               "mfma", note="flops = N (100 p + 700 T): every triplet once at its centre"),
                cpu_baseline=cpu)

@@ -120,6 +120,22 @@ int uf3_ctx_timing_read(uf3_ctx *ctx, double *featurize_ms, int64_t *featurize_l
 int uf3_ctx_md_skin(uf3_ctx *ctx, double skin);
 int uf3_ctx_md_stats(uf3_ctx *ctx, int64_t *builds, int64_t *steps, int64_t *redone);
 
+/* RCCL behind the C ABI (round 5; SURVEY 8b's `uf3_gram_allreduce`).  One process per GPU.  The one exchange of the path is
+ * the SUM over the ranks of the packed normal-equation pieces [G_e | G_f | o_e | o_f | m_e | m_f] (and, for a decomposed
+ * frame, of [forces | energy | strain derivative]); the reference returns per-chunk results to the parent process and adds them
+ * there (uf3/representation/process.py:196-254, uf3/regression/least_squares.py:391-412).  Rank 0 draws an id
+ * (uf3_comm_unique_id, UF3_COMM_ID_BYTES bytes), the host gets it to the other ranks by any channel it has (MPI, a file,
+ * torch.distributed's store), every rank joins with uf3_comm_init -- a collective call --; uf3_allreduce_sum_f64 then sums a
+ * device buffer in place over xGMI, on the context's stream, asynchronously.  librccl is opened at run time (the copy already in
+ * the process, else UF3_RCCL_PATH, else the system's): the library itself links against nothing but HIP. */
+#define UF3_COMM_ID_BYTES 128
+int uf3_comm_unique_id(uf3_ctx *ctx, void *id);
+int uf3_comm_init(uf3_ctx *ctx, int n_ranks, int rank, const void *id);
+int uf3_comm_destroy(uf3_ctx *ctx);
+int uf3_comm_info(const uf3_ctx *ctx, int32_t *n_ranks, int32_t *rank);     /* 0 / -1 without a communicator */
+int uf3_allreduce_sum_f64(uf3_ctx *ctx, double *d_buf, int64_t n);
+int uf3_gram_allreduce(uf3_ctx *ctx, double *d_packed, int64_t n);           /* the same call under SURVEY 8b's name */
+
 int uf3_basis_create(uf3_ctx *ctx, const uf3_basis_spec *spec, uf3_basis **out);
 void uf3_basis_destroy(uf3_basis *basis);
 /* Diagnostics: which featurizer specialisations the basis uses.  Bit 0: one-body + pair blocks (the launch that also

@@ -1734,6 +1734,54 @@ def test_two_gpu_decomposed_evaluation_over_rccl_matches_the_oracle(tmp_path):
         assert np.allclose(d["v"], v1[0], rtol=1e-10, atol=1e-10) and rel_err(d["f"], f1) < 1e-12
 
 
+def test_rccl_behind_the_c_abi_single_rank():
+    """uf3_comm_unique_id / uf3_comm_init / uf3_allreduce_sum_f64 (librccl opened by the library itself): a communicator of one
+    rank comes up on this GPU and the in-place sum of a device buffer runs on the context's stream; the fit pipeline takes that
+    route when the context has a communicator."""
+    import torch
+    from uf3_amd import parallel, pipeline
+    ctx = _lib.get_context(None)
+    assert ctx.comm_info() == (0, -1)
+    with pytest.raises(_lib.UF3Error):
+        ctx.allreduce_sum(0, 0)                                   # no communicator yet
+    parallel.native_comm(ctx, rank=0, world_size=1)
+    try:
+        assert ctx.comm_info() == (1, 0)
+        dev = torch.device("cuda", ctx.device)
+        buf = torch.arange(100003, dtype=torch.float64, device=dev) * 0.25
+        ref = buf.clone()
+        prev = ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+        try:
+            ctx.allreduce_sum(buf.data_ptr(), buf.numel())
+        finally:
+            ctx.restore_stream(prev)
+        torch.cuda.synchronize(dev)
+        assert torch.equal(buf, ref)
+        out = parallel.allreduce_packed(buf, force=True, ctx=ctx)
+        torch.cuda.synchronize(dev)
+        assert out is buf and torch.equal(buf, ref)
+        # the fit pipeline end to end with the context's communicator in the data path
+        basis = synthetic.notebook_basis(['W'])
+        frames = [synthetic.lattice_frame("bcc", (3, 3, 3), 3.165, [74], seed=60 + k) for k in range(6)]
+        rng = np.random.default_rng(2)
+        e = rng.normal(-480, 1.0, len(frames))
+        f = [rng.normal(0, 0.3, (len(a), 3)) for a in frames]
+        reg = basis.get_regularization_matrix(ridge_1b=1e-8, ridge_2b=0.0, ridge_3b=1e-8, curvature_2b=1e-8, curvature_3b=0.0)
+        m1, m2 = ls.WeightedLinearModel(basis, regularizer=reg), ls.WeightedLinearModel(basis, regularizer=reg)
+        fz = process.BasisFeaturizer(basis)
+        os.environ["UF3_FORCE_COLLECTIVE"] = "1"
+        try:
+            pipeline.fit_frames(m1, fz, frames, e, f, weight=0.4)
+        finally:
+            del os.environ["UF3_FORCE_COLLECTIVE"]
+        ctx.comm_destroy()
+        pipeline.fit_frames(m2, fz, frames, e, f, weight=0.4)
+        assert np.allclose(m1.coefficients, m2.coefficients, rtol=1e-5, atol=1e-6)      # (the Gram kernels add with atomics: not to the bit)
+    finally:
+        ctx.comm_destroy()
+    assert ctx.comm_info() == (0, -1)
+
+
 @pytest.mark.parametrize("mode", ["featurize", "fit", "eval"])
 def test_bench_under_the_launcher_runs_rccl_on_device_buffers(mode):
     """every GPU test run initialises RCCL.  bench.py exactly as the driver starts it for N > 1
@@ -1752,11 +1800,17 @@ def test_bench_under_the_launcher_runs_rccl_on_device_buffers(mode):
     argv = ["--gpus", "1", "--steps", "2", "--warmup", "1", "--mode", mode, "--no-cpu-baseline", "--no-extra", "--no-traffic"]
     argv += ["--atoms", "2000"] + (["--frames-per-step", "4"] if mode != "eval" else [])
     env = dict(os.environ, UF3_FORCE_COLLECTIVE="1", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4")
-    res = subprocess.run(bench.rank_command(1, argv, port), env=env, capture_output=True, text=True, timeout=600)
-    assert res.returncode == 0, res.stderr[-2000:]
-    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, res.stdout[-2000:]
-    out = json.loads(lines[0])
-    assert out["n_gpus"] == 1 and out["config"]["rccl_world_size"] == 1
-    assert out["config"].get("forced_collective") is True
-    assert np.isfinite(out["value"]) and out["value"] > 0
+    values = {}
+    for native in ((False, True) if mode != "featurize" else (False,)):       # (the data-path sum through the library's own communicator)
+        if native:
+            env["UF3_NATIVE_RCCL"] = "1"
+        res = subprocess.run(bench.rank_command(1, argv, port + (1 if native else 0)), env=env, capture_output=True, text=True, timeout=600)
+        assert res.returncode == 0, res.stderr[-2000:]
+        lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, res.stdout[-2000:]
+        out = json.loads(lines[0])
+        assert out["n_gpus"] == 1 and out["config"]["rccl_world_size"] == 1
+        assert out["config"].get("forced_collective") is True
+        assert out["config"]["collective"].startswith("uf3_allreduce_sum_f64" if native else "torch.distributed")
+        assert np.isfinite(out["value"]) and out["value"] > 0
+        values[native] = out["value"]

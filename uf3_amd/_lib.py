@@ -24,7 +24,8 @@ EXPORTS = ["uf3_ctx_create", "uf3_ctx_destroy", "uf3_ctx_set_stream", "uf3_ctx_s
            "uf3_eval_centres", "uf3_eval_centres_dev",
            "uf3_neighbors_debug", "uf3_fit_rows_dev", "uf3_fit_pack_dev", "uf3_gram_force_rows_dev",
            "uf3_pair_geometry", "uf3_distance_matrix", "uf3_direction_cosines",
-           "uf3_ctx_md_skin", "uf3_ctx_md_stats"]
+           "uf3_ctx_md_skin", "uf3_ctx_md_stats",
+           "uf3_comm_unique_id", "uf3_comm_init", "uf3_comm_destroy", "uf3_comm_info", "uf3_allreduce_sum_f64", "uf3_gram_allreduce"]
 
 
 class HipUnavailable(RuntimeError):
@@ -116,6 +117,12 @@ def load():
         lib.uf3_ctx_timing_read.argtypes = [vp, C.POINTER(dbl), C.POINTER(i64), C.POINTER(dbl),
                                             C.POINTER(dbl), C.POINTER(dbl)]
         lib.uf3_ctx_md_skin.argtypes = [vp, dbl]
+        lib.uf3_comm_unique_id.argtypes = [vp, vp]
+        lib.uf3_comm_init.argtypes = [vp, C.c_int, C.c_int, vp]
+        lib.uf3_comm_destroy.argtypes = [vp]
+        lib.uf3_comm_info.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]
+        lib.uf3_allreduce_sum_f64.argtypes = [vp, vp, i64]
+        lib.uf3_gram_allreduce.argtypes = [vp, vp, i64]
         lib.uf3_ctx_md_stats.argtypes = [vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)]
         lib.uf3_basis_create.argtypes = [vp, C.POINTER(BasisSpec), C.POINTER(vp)]
         lib.uf3_basis_destroy.argtypes = [vp]
@@ -210,6 +217,29 @@ class Context:
         if getattr(self, "_md_skin", 0.0) != skin:
             self.check(self.lib.uf3_ctx_md_skin(self.handle, skin))
             self._md_skin = skin
+
+    # ---- RCCL through the library itself (uf3_comm_*): no torch.distributed in the data path ----------------------------
+    def comm_unique_id(self):
+        buf = C.create_string_buffer(128)
+        self.check(self.lib.uf3_comm_unique_id(self.handle, buf))
+        return buf.raw
+
+    def comm_init(self, n_ranks, rank, unique_id):
+        """Collective: every rank calls it with the id rank 0 drew (``comm_unique_id``) -- carried over by whatever the host
+        has (``parallel.native_comm`` uses torch.distributed's store, a file works as well)."""
+        self.check(self.lib.uf3_comm_init(self.handle, int(n_ranks), int(rank), C.c_char_p(bytes(unique_id))))
+
+    def comm_destroy(self):
+        self.check(self.lib.uf3_comm_destroy(self.handle))
+
+    def comm_info(self):
+        n, r = C.c_int32(), C.c_int32()
+        self.check(self.lib.uf3_comm_info(self.handle, C.byref(n), C.byref(r)))
+        return n.value, r.value
+
+    def allreduce_sum(self, device_ptr, n):
+        """Sum ``n`` doubles at ``device_ptr`` over the ranks, in place, on the context's stream (asynchronous)."""
+        self.check(self.lib.uf3_allreduce_sum_f64(self.handle, C.c_void_p(device_ptr), int(n)))
 
     def md_stats(self):
         b, s, r = C.c_int64(), C.c_int64(), C.c_int64()

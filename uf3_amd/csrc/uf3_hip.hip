@@ -15,6 +15,7 @@
 #include "uf3_kernels.h"
 #include "uf3_feat3.h"
 #include <chrono>
+#include <dlfcn.h>
 
 // ------------------------------------------------------------------------------ plumbing
 struct Buf {
@@ -115,6 +116,9 @@ struct uf3_ctx {
         size_t geo_bytes = 0;
         long long builds = 0, steps = 0, redone = 0;
     } md;
+    // RCCL communicator of this rank (uf3_comm_init): the library is opened at run time (no link dependency), see rccl_api()
+    void *comm = nullptr;
+    int comm_ranks = 0, comm_rank = -1;
     bool md_step = false;               // the last eval_impl ran on the persistent lists (its status words 2 / 3 are the displacement flags)
     // timing
     bool timing = false;
@@ -211,6 +215,7 @@ extern "C" int uf3_ctx_create(int device, uf3_ctx **out) {
     return UF3_OK;
 }
 
+extern "C" int uf3_comm_destroy(uf3_ctx *c);
 extern "C" void uf3_ctx_destroy(uf3_ctx *c) {
     if (!c) return;
     hipSetDevice(c->device);
@@ -221,6 +226,7 @@ extern "C" void uf3_ctx_destroy(uf3_ctx *c) {
                   &c->bin_cnt};
     for (Buf *b : all) b->release();
     for (Buf &b : c->gram_tiles) b.release();
+    if (c->comm) uf3_comm_destroy(c);
     { Buf *mdb[] = {&c->md.ent, &c->md.cnt, &c->md.pos_ref, &c->md.geo, &c->md.frame_of, &c->md.spec, &c->md.inbox, &c->md.surv}; for (Buf *b : mdb) b->release(); }
     c->pin_in.release(); c->pin_geo.release(); c->pin_out.release(); c->pin_flags.release();
     for (auto &pd : c->pending_chk) if (pd.ev) hipEventDestroy(pd.ev);
@@ -2109,6 +2115,102 @@ extern "C" int uf3_eval_centres(uf3_basis *b, const uf3_frames *fr, const double
     if (atom_end < 0) return fail(b->ctx, UF3_EINVAL, "uf3_eval_centres: atom range outside the batch");
     return eval_host(b, fr, pos, z, c1, c2, c3, energies, forces, virials, atom_begin, atom_end, true);
 }
+
+// ------------------------------------------------------------------------------ RCCL behind the C ABI
+// One process per GPU; the ONE exchange of the path is the sum of the packed normal-equation pieces (and, for a decomposed
+// frame, of [forces | energy | strain derivative]) over the ranks -- what the reference does by returning per-chunk results
+// to the parent process and adding them there (uf3/representation/process.py:196-254, uf3/regression/least_squares.py:
+// 391-412); SURVEY 8b's `uf3_gram_allreduce`.  librccl is opened at run time: the copy already in the process (a PyTorch-ROCm
+// wheel brings its own, next to its own HIP runtime, and two HIP runtimes in one process do not mix), else UF3_RCCL_PATH,
+// else the system's.
+struct RcclId { char b[128]; };            // ncclUniqueId, passed by value
+struct RcclApi {
+    void *lib = nullptr;
+    int (*GetUniqueId)(void *) = nullptr;
+    int (*CommInitRank)(void **, int, RcclId, int) = nullptr;
+    int (*CommDestroy)(void *) = nullptr;
+    int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+    std::string why;
+};
+static RcclApi &rccl_api() {
+    static RcclApi api;
+    static bool tried = false;
+    if (tried) return api;
+    tried = true;
+    const char *names[] = {getenv("UF3_RCCL_PATH"), "librccl.so.1", "librccl.so"};
+    for (int pass = 0; pass < 2 && !api.lib; pass++)                 // first: whatever is loaded already
+        for (const char *nm : names) {
+            if (!nm || api.lib) continue;
+            api.lib = dlopen(nm, RTLD_NOW | RTLD_LOCAL | (pass == 0 ? RTLD_NOLOAD : 0));
+        }
+    if (!api.lib) { api.why = std::string("librccl not found: ") + (dlerror() ? dlerror() : "?"); return api; }
+    api.GetUniqueId = (decltype(api.GetUniqueId))dlsym(api.lib, "ncclGetUniqueId");
+    api.CommInitRank = (decltype(api.CommInitRank))dlsym(api.lib, "ncclCommInitRank");
+    api.CommDestroy = (decltype(api.CommDestroy))dlsym(api.lib, "ncclCommDestroy");
+    api.AllReduce = (decltype(api.AllReduce))dlsym(api.lib, "ncclAllReduce");
+    api.GetErrorString = (decltype(api.GetErrorString))dlsym(api.lib, "ncclGetErrorString");
+    if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllReduce) { api.why = "librccl lacks the nccl* entry points"; api.lib = nullptr; }
+    return api;
+}
+static int rccl_fail(uf3_ctx *c, const char *what, int rc) {
+    RcclApi &r = rccl_api();
+    return fail(c, UF3_EHIP, std::string(what) + ": " + (r.GetErrorString ? r.GetErrorString(rc) : "RCCL error") + " (" + std::to_string(rc) + ")");
+}
+
+extern "C" int uf3_comm_unique_id(uf3_ctx *c, void *id128) {
+    if (!c || !id128) return fail(c, UF3_EINVAL, "uf3_comm_unique_id: null argument");
+    RcclApi &r = rccl_api();
+    if (!r.lib) return fail(c, UF3_EHIP, r.why);
+    HIPCHK(c, hipSetDevice(c->device));
+    const int rc = r.GetUniqueId(id128);
+    return rc ? rccl_fail(c, "ncclGetUniqueId", rc) : UF3_OK;
+}
+
+extern "C" int uf3_comm_init(uf3_ctx *c, int n_ranks, int rank, const void *id128) {
+    if (!c || !id128 || n_ranks < 1 || rank < 0 || rank >= n_ranks) return fail(c, UF3_EINVAL, "uf3_comm_init: bad argument");
+    RcclApi &r = rccl_api();
+    if (!r.lib) return fail(c, UF3_EHIP, r.why);
+    if (c->comm) { int rc0 = uf3_comm_destroy(c); if (rc0) return rc0; }
+    HIPCHK(c, hipSetDevice(c->device));
+    RcclId id;
+    std::memcpy(id.b, id128, sizeof(id.b));
+    const int rc = r.CommInitRank(&c->comm, n_ranks, id, rank);
+    if (rc) { c->comm = nullptr; return rccl_fail(c, "ncclCommInitRank", rc); }
+    c->comm_ranks = n_ranks; c->comm_rank = rank;
+    return UF3_OK;
+}
+
+extern "C" int uf3_comm_destroy(uf3_ctx *c) {
+    if (!c) return fail(nullptr, UF3_EINVAL, "null ctx");
+    if (!c->comm) return UF3_OK;
+    RcclApi &r = rccl_api();
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    const int rc = r.CommDestroy ? r.CommDestroy(c->comm) : 0;
+    c->comm = nullptr; c->comm_ranks = 0; c->comm_rank = -1;
+    return rc ? rccl_fail(c, "ncclCommDestroy", rc) : UF3_OK;
+}
+
+extern "C" int uf3_comm_info(const uf3_ctx *c, int32_t *n_ranks, int32_t *rank) {
+    if (!c) return fail(nullptr, UF3_EINVAL, "null ctx");
+    if (n_ranks) *n_ranks = c->comm ? c->comm_ranks : 0;
+    if (rank) *rank = c->comm ? c->comm_rank : -1;
+    return UF3_OK;
+}
+
+// in place, on the context's stream, asynchronous like every *_dev entry
+extern "C" int uf3_allreduce_sum_f64(uf3_ctx *c, double *d_buf, int64_t n) {
+    if (!c || (n > 0 && !d_buf) || n < 0) return fail(c, UF3_EINVAL, "uf3_allreduce_sum_f64: bad argument");
+    if (!c->comm) return fail(c, UF3_EINVAL, "uf3_allreduce_sum_f64: no communicator (uf3_comm_init)");
+    if (n == 0) return UF3_OK;
+    RcclApi &r = rccl_api();
+    HIPCHK(c, hipSetDevice(c->device));
+    const int rc = r.AllReduce(d_buf, d_buf, (size_t)n, /* ncclFloat64 */ 8, /* ncclSum */ 0, c->comm, c->stream);
+    return rc ? rccl_fail(c, "ncclAllReduce", rc) : UF3_OK;
+}
+
+extern "C" int uf3_gram_allreduce(uf3_ctx *c, double *d_packed, int64_t n) { return uf3_allreduce_sum_f64(c, d_packed, n); }
 
 // ------------------------------------------------------------------------------ gram
 static int ensure_frag(uf3_ctx *c) {

@@ -87,18 +87,78 @@ def unpack_pieces(buf, n_cols, with_forces=True):
     return out
 
 
-def allreduce_packed(flat, force=None):
+def native_comm(ctx, rank=None, world_size=None, id_path=None):
+    """
+    Bring up the library's own RCCL communicator on ``ctx`` (``uf3_comm_init`` -- librccl bound behind the C ABI, no
+    torch.distributed in the data path).  The 128-byte id rank 0 draws reaches the other ranks through torch.distributed's
+    default process group when one is up (any backend: it is a host-side broadcast), else through the file ``id_path``
+    (rank 0 writes it, the others wait for it) -- the launcher's RANK / WORLD_SIZE tell who is who.  Returns ``ctx``.
+    """
+    import os
+    import time
+    rank = int(os.environ.get("RANK", 0)) if rank is None else int(rank)
+    world_size = int(os.environ.get("WORLD_SIZE", 1)) if world_size is None else int(world_size)
+    uid = None
+    dist = None
+    try:
+        import torch.distributed as dist_mod
+        if dist_mod.is_available() and dist_mod.is_initialized():
+            dist = dist_mod
+    except ImportError:
+        pass
+    if world_size == 1:
+        uid = ctx.comm_unique_id()
+    elif dist is not None and id_path is None:
+        box = [ctx.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        uid = box[0]
+    else:
+        if id_path is None:
+            raise ValueError("native_comm: more than one rank needs a process group or an id_path to pass the id")
+        if rank == 0:
+            uid = ctx.comm_unique_id()
+            with open(id_path + ".tmp", "wb") as f:
+                f.write(uid)
+            os.replace(id_path + ".tmp", id_path)
+        else:
+            t_end = time.time() + 120
+            while not os.path.exists(id_path):
+                if time.time() > t_end:
+                    raise TimeoutError(f"native_comm: {id_path} did not appear")
+                time.sleep(0.01)
+            with open(id_path, "rb") as f:
+                uid = f.read()
+    ctx.comm_init(world_size, rank, uid)
+    return ctx
+
+
+def allreduce_packed(flat, force=None, ctx=None):
     """
     Sum a packed piece buffer (torch tensor, device or host) over all ranks of the default process group, in place
     where the backend allows: with "nccl" (= RCCL over xGMI) the DEVICE buffer goes straight into the collective;
     with "gloo" (CPU tests) a host copy is reduced.  No-op without a process group, and -- unless ``force`` (default:
     the environment variable UF3_FORCE_COLLECTIVE) -- in a group of one rank: forcing it runs the collective itself on
-    a one-GPU box (a sum over one rank: the buffer is unchanged).
+    a one-GPU box (a sum over one rank: the buffer is unchanged).  ``ctx`` with a communicator of its own
+    (``native_comm``): the collective is the library's (``uf3_allreduce_sum_f64``), not torch.distributed's.
     """
     import os
     import torch.distributed as dist
     if force is None:
         force = bool(os.environ.get("UF3_FORCE_COLLECTIVE"))
+    if ctx is not None and ctx.comm_info()[0] > 0:
+        # the library's own communicator (native_comm): the device buffer through uf3_allreduce_sum_f64, ordered on the
+        # caller's stream like the kernels that filled it
+        import torch
+        if not flat.is_cuda:
+            raise ValueError("the library's communicator reduces device buffers")
+        if ctx.comm_info()[0] == 1 and not force:
+            return flat
+        prev = ctx.set_stream(torch.cuda.current_stream(flat.device).cuda_stream)
+        try:
+            ctx.allreduce_sum(flat.data_ptr(), flat.numel())
+        finally:
+            ctx.restore_stream(prev)
+        return flat
     if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not force):
         return flat
     if dist.get_backend() == "nccl":

@@ -246,7 +246,7 @@ def fit_frames(model, featurizer, frames, energies, forces=None, weight=0.5, red
                 raise
     n_cols = int(acc._keep.numel())
     if reduce:
-        flat = parallel.allreduce_packed(flat)
+        flat = parallel.allreduce_packed(flat, ctx=acc.ctx)          # (the library's own communicator when the context has one)
     pieces = parallel.unpack_pieces(flat.cpu().numpy(), n_cols, with_forces=with_forces)
     model.fit_from_pieces(pieces, weight=weight)
     return pieces
