@@ -1734,6 +1734,50 @@ def test_two_gpu_decomposed_evaluation_over_rccl_matches_the_oracle(tmp_path):
         assert np.allclose(d["v"], v1[0], rtol=1e-10, atol=1e-10) and rel_err(d["f"], f1) < 1e-12
 
 
+def _native_fit_worker(rank, world, out_dir):
+    """no torch.distributed: the communicator's id travels through a file, the sum through uf3_allreduce_sum_f64"""
+    import torch
+    from uf3_amd import parallel, pipeline
+    os.environ["UF3_DEVICE"] = str(rank)
+    torch.cuda.set_device(rank)
+    basis = synthetic.notebook_basis(['W'])
+    frames = [synthetic.lattice_frame("bcc", (3, 3, 3 + (k % 3)), 3.165, [74], seed=150 + k) for k in range(9)]
+    rng = np.random.default_rng(11)
+    energies = rng.normal(size=len(frames))
+    forces = [rng.normal(size=(len(f), 3)) for f in frames]
+    reg = basis.get_regularization_matrix(ridge_1b=1e-8, ridge_2b=0.0, ridge_3b=1e-8, curvature_2b=1e-8, curvature_3b=0.0)
+    model = ls.WeightedLinearModel(basis, regularizer=reg)
+    fz = process.BasisFeaturizer(basis, device=rank)
+    ctx, _ = fz._dev()
+    parallel.native_comm(ctx, rank, world, id_path=os.path.join(out_dir, "comm_id"))
+    lo, hi = parallel.shard_range(len(frames), rank, world)
+    pipeline.fit_frames(model, fz, frames[lo:hi], energies[lo:hi], forces[lo:hi], weight=0.4, with_forces=True)
+    np.save(os.path.join(out_dir, f"native_{rank}.npy"), model.coefficients)
+    ctx.comm_destroy()
+
+
+def test_two_gpu_fit_through_the_librarys_own_communicator(tmp_path):
+    """The same two-GPU fit with RCCL bound behind the C ABI (uf3_comm_init / uf3_allreduce_sum_f64) and NO torch.distributed:
+    the id goes through a file.  Skips where the box has a single GPU."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    import torch.multiprocessing as mp
+    from uf3_amd import pipeline
+    mp.spawn(_native_fit_worker, args=(2, str(tmp_path)), nprocs=2, join=True)
+    basis = synthetic.notebook_basis(['W'])
+    frames = [synthetic.lattice_frame("bcc", (3, 3, 3 + (k % 3)), 3.165, [74], seed=150 + k) for k in range(9)]
+    rng = np.random.default_rng(11)
+    energies = rng.normal(size=len(frames))
+    forces = [rng.normal(size=(len(f), 3)) for f in frames]
+    reg = basis.get_regularization_matrix(ridge_1b=1e-8, ridge_2b=0.0, ridge_3b=1e-8, curvature_2b=1e-8, curvature_3b=0.0)
+    model = ls.WeightedLinearModel(basis, regularizer=reg)
+    pipeline.fit_frames(model, process.BasisFeaturizer(basis), frames, energies, forces, weight=0.4, reduce=False)
+    c0, c1 = np.load(tmp_path / "native_0.npy"), np.load(tmp_path / "native_1.npy")
+    assert np.array_equal(c0, c1)
+    assert np.allclose(c0, model.coefficients, rtol=1e-8, atol=1e-10)
+
+
 def test_rccl_behind_the_c_abi_single_rank():
     """uf3_comm_unique_id / uf3_comm_init / uf3_allreduce_sum_f64 (librccl opened by the library itself): a communicator of one
     rank comes up on this GPU and the in-place sum of a device buffer runs on the context's stream; the fit pipeline takes that
