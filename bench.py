@@ -254,7 +254,8 @@ def main(argv=None):
         bytes_per_launch = synthetic.algorithmic_bytes(n_atoms, F) * B
         hbm_gbs = bytes_per_launch / (launch_ms * 1e-3) / 1e9
         # algorithmic fp64 work of the featurizer: ~100 flop per directed pair, ~3.1 kflop per triplet
-        pairs_per_atom, trip_per_atom = 58.0, 91.0
+        # (p, T as realised on frame 0 of this batch, from the device's own lists -- not the ideal lattice's 58 / 91)
+        pairs_per_atom, trip_per_atom = realised_counts(fz, frames[0])
         flops_frame = n_atoms * (100.0 * pairs_per_atom + 3100.0 * trip_per_atom)
         feat_tf = flops_frame * B / (launch_ms * 1e-3) / 1e12
         # HBM bytes per launch from the PMC passes of this same command (separate rocprofv3 --pmc FETCH_SIZE /
@@ -284,6 +285,10 @@ def main(argv=None):
                                        "achieved = ALGORITHMIC flops (SURVEY 8d), the HBM view is in `hbm`",
                             kernel=feat_kernel, launch_ms=round(launch_ms, 4), launches=launches,
                             algorithmic_flops_per_launch=flops_frame * B,
+                            realised_per_atom=dict(pairs=round(pairs_per_atom, 2), triplet_candidates=round(trip_per_atom, 2),
+                                                   note="frame 0 of the batch, from the device's lists (uf3_neighbors_debug); the ideal "
+                                                        "bcc lattice has 58 / 91"),
+                            executed_fp64=_executed_fp64(n_atoms, F, B, launch_ms),
                             neighbor_ms_per_step=round(timing["neighbor_ms"] / args.steps, 4))
         else:
             n_keep = int(acc._keep.numel())
@@ -407,8 +412,23 @@ def eval_mode(args, torch, dist, dev, distributed, world, rank):
     if native:
         parallel.native_comm(ctx, rank, world)
 
+    # N = 1: an MD step -- every atom moves (seeded +-0.01 A walk, one device kernel) and the evaluator runs its MD route
+    # (neighbour lists kept with a 0.5 A skin, rebuilt inside the timed region when an atom nears skin / 2); the decomposed
+    # route of N > 1 rebuilds its lists every step (uf3_eval_centres has no persistent lists yet)
+    moving = world == 1 and not forced
+    if moving:
+        g = torch.Generator(device=dev).manual_seed(17)
+        pool = (torch.rand((64, n, 3), dtype=torch.float64, device=dev, generator=g) * 2.0 - 1.0) * MD_WALK
+        order = np.random.default_rng(17).integers(0, 64, 1 << 16)
+        signs = np.random.default_rng(18).choice([-1.0, 1.0], 1 << 16)
+        ctx.md_skin(MD_SKIN)
+    counter = [0]
+
     def step():
-        if world == 1 and not forced:
+        if moving:
+            k = counter[0] & 0xffff
+            counter[0] += 1
+            d_pos.add_(pool[order[k]], alpha=float(signs[k]))
             ctx.check(ctx.lib.uf3_eval_virial_dev(*common, C.c_void_p(p_e), C.c_void_p(p_f), C.c_void_p(p_v)))
         else:
             # (uf3_eval_centres_dev zeroes every force row itself and overwrites energy / strain derivative: nothing to clear)
@@ -438,6 +458,11 @@ def eval_mode(args, torch, dist, dev, distributed, world, rank):
     if rank != 0:
         return None
     host = flat.cpu().numpy()
+    if moving:
+        from uf3_amd.data.atoms import Atoms
+        atoms = Atoms(numbers=atoms.get_atomic_numbers(), positions=d_pos.cpu().numpy(), cell=atoms.get_cell(), pbc=True)   # (what the last step saw)
+        md_stats = ctx.md_stats()
+        ctx.md_skin(0.0)
     f, e = host[:3 * n].reshape(n, 3), float(host[3 * n])
     assert os.environ.get("UF3_BENCH_NOCHECK") or (np.isfinite(host).all() and np.abs(f.sum(0)).max() < 1e-8 * max(1.0, np.abs(f).max()) * n ** 0.5)
     dt = elapsed / args.steps
@@ -458,6 +483,8 @@ def eval_mode(args, torch, dist, dev, distributed, world, rank):
                config=dict(workload=f"C5: {n}-atom ternary bcc frame, 2+3-body notebook basis, F={int(basis.n_feats)}", mode="eval",
                            atoms_per_frame=n, sharding=(f"blocks of centres x{world}, one all_reduce(SUM) of 3N+7 doubles per step"
                                                         if world > 1 or forced else "whole frame on one GPU"),
+                           md=(dict(skin_A=MD_SKIN, walk_A=MD_WALK, list_builds=md_stats["builds"], steps_repeated=md_stats["redone"])
+                               if moving else None),
                            rccl_world_size=dist.get_world_size() if distributed else 1, forced_collective=forced,
                            collective=("uf3_allreduce_sum_f64 (librccl behind the C ABI)" if native else "torch.distributed all_reduce (RCCL)")),
                roofline=_roof(n * (100.0 * PAIRS_PER_ATOM + 700.0 * TRIPLETS_PER_ATOM), 52.0 * n + 75 + 8.0 * len(calc._c3), dt,
@@ -519,6 +546,35 @@ def measure_traffic(frames_per_step, workload, atoms):
 # ---------------------------------------------------------------------------------------------------------------
 PAIRS_PER_ATOM, TRIPLETS_PER_ATOM = 58.0, 91.0        # realised on the rattled bcc cells
 PEAK_FP64_TF, PEAK_HBM_GBS = 78.6, 8000.0
+
+
+def _executed_fp64(n_atoms, n_feat, frames_per_step, launch_ms):
+    """The EXECUTED fp64 work of the headline launch group (the algorithmic figure prices every triplet at SURVEY 8d's
+    3.1 kflop; the bond-factorised kernel issues about half of that): wave-instruction counts of the committed PMC pass
+    (profiles/round*_fp64_counters.json, tools/profile_round.sh) over THIS run's launch time; null when no pass matches
+    the workload."""
+    for name in ("round5_fp64_counters.json",):
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
+            if pmc["workload"] == dict(atoms_per_frame=n_atoms, n_feat=n_feat, frames_per_step=frames_per_step):
+                tf = pmc["executed_fp64_flops_per_launch"] / (launch_ms * 1e-3) / 1e12
+                return dict(flops_per_launch=pmc["executed_fp64_flops_per_launch"], achieved=round(tf, 3), unit="TFLOP/s",
+                            frac=round(tf / PEAK_FP64_TF, 5),
+                            source="profiles/" + name + ": 64 x (2 FMA + MUL + ADD + TRANS) fp64 wave-instructions of one launch group "
+                                   "(rocprofv3 --pmc, not measured in this run), lanes switched off by the exec mask included")
+        except (OSError, KeyError, ValueError):
+            pass
+    return None
+
+
+def realised_counts(fz, atoms):
+    """(directed pairs inside their pair range, pairs j < k of 3-body neighbours) per atom of a frame, read back from the
+    lists the device builds (uf3_neighbors_debug): SURVEY 8d's p and T as realised -- the rattle moves the 8 neighbours at
+    5.48 A across the 5.5 A cut-off."""
+    pairs, n3 = fz.neighbor_indices(atoms)
+    n = len(atoms)
+    q = np.bincount(n3[:, 0], minlength=1).astype(np.float64) if len(n3) else np.zeros(1)
+    return sum(len(v) for v in pairs.values()) / n, float((q * (q - 1) / 2).sum()) / n
 
 
 def _featurizer_flops(n_atoms):

@@ -18,6 +18,11 @@ $T rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_
     -d $RUN/pmc2 -o p2 --output-format csv -- $B --steps 4 --warmup 2 > /dev/null 2>&1
 $T rocprofv3 --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT \
     -d $RUN/pmc3 -o p3 --output-format csv -- $B --steps 4 --warmup 2 > /dev/null 2>&1
+# executed fp64 work (round 5): wave-instructions by kind, the matrix cores' operations, lane-cycles of the vector unit
+$T rocprofv3 --pmc SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_THREAD_CYCLES_VALU SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 \
+    -d $RUN/pmc4 -o p4 --output-format csv -- $B --steps 4 --warmup 2 > /dev/null 2>&1
+# the evaluator's MD route against the rebuild-everything route: counters per atom and kernel times (tools/md_counters.sh)
+bash tools/md_counters.sh > $RUN/eval_counters.txt 2>&1
 # the same trace over the whole default run: the sub-lines of the other BASELINE configurations (fit, lead-0, evaluator) included
 $T rocprofv3 --kernel-trace --stats -d $RUN/trace_extra -o x --output-format csv -- python bench.py --no-cpu-baseline --no-traffic > $RUN/bench_traced_extra.json 2>/dev/null
 $T python tools/bench_kernels.py > $RUN/kernels.json 2> $RUN/kernels.err

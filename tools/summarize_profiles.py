@@ -5,6 +5,8 @@
 Reads   <run>/trace/*_kernel_stats.csv           (rocprofv3 --kernel-trace --stats --output-format csv)
         <run>/pmc_fetch, <run>/pmc_write         (--pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes)
         <run>/pmc1, <run>/pmc2, <run>/pmc3       (passes of SQ counters; pmc3 = MFMA / LDS activity)
+        <run>/pmc4                               (fp64 wave-instructions by kind: the EXECUTED work, <prefix>_fp64_counters.json)
+        <run>/eval_counters.txt                  (tools/md_counters.sh: the evaluator's routes)
         <run>/bench_default.json, <run>/kernels.json
 Writes  <prefix>_kernel_stats.csv, <prefix>_hbm_counters.json, <prefix>_sq_counters.txt,
         <prefix>_bench_n1.json, <prefix>_secondary_kernels.json
@@ -90,9 +92,11 @@ def main(run, prefix):
                 "streaming read; the reads here are mostly 48-B gathers of neighbour-list entries, so the "
                 "uncorrected sum is quoted as `traffic` and the x2-corrected sum as the upper bound. Every "
                 "specialisation reads the neighbour lists again; nothing is read-modify-written: rows are "
-                "written once per (atom, column range).  WRITE_SIZE (uncalibrated per the guide) checks out against "
-                "this kernel's known writes: rows (= the algorithmic bytes) + 3-body lists (48 B x capacity 16 per "
-                "atom) are written exactly once, and the counter reads within a few per cent of their sum.",
+                "written once per (atom, column range).  WRITE_SIZE (uncalibrated per the guide) against this kernel's "
+                "known writes -- rows (= the algorithmic bytes) + 3-body lists (48 B x capacity 16 per atom), each written "
+                "exactly once: see write_amplification below (rows are 3472 B = 54.25 cache lines, so the column segments "
+                "of a block start and end mid-line and the partial lines of neighbouring segments are written twice).",
+        "write_amplification": (write_kib * 1024) / (alg_bytes + 48 * 16 * bench["config"]["atoms_per_frame"] * bench["config"]["frames_per_step"]),
         "workload": {"atoms_per_frame": bench["config"]["atoms_per_frame"], "n_feat": bench["config"]["n_feat"],
                      "frames_per_step": bench["config"]["frames_per_step"]},
     }
@@ -103,7 +107,24 @@ def main(run, prefix):
              "# SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles summed over waves; "
              "SQ_INSTS_* count wave-instructions", ""]
     sq = {}
-    for d in ("pmc1", "pmc2", "pmc3"):
+    # executed fp64 work of one launch group: 64 lanes per wave-instruction (idle lanes included: an upper bound), 2 per FMA
+    fp = featurize_counters(os.path.join(run, "pmc4"))
+    if fp:
+        g = {k: group_mean(v) for k, v in fp.items()}
+        flops = 64.0 * (2 * g.get("SQ_INSTS_VALU_FMA_F64", 0) + g.get("SQ_INSTS_VALU_MUL_F64", 0) + g.get("SQ_INSTS_VALU_ADD_F64", 0)
+                        + g.get("SQ_INSTS_VALU_TRANS_F64", 0)) + 512.0 * g.get("SQ_INSTS_VALU_MFMA_MOPS_F64", 0)
+        sec = bench["roofline"]["launch_ms"] * 1e-3
+        json.dump({"tool": "rocprofv3 --pmc SQ_INSTS_VALU_{FMA,MUL,ADD,TRANS}_F64 SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_THREAD_CYCLES_VALU (one pass)",
+                   "wave_instructions_per_launch_group": g,
+                   "executed_fp64_flops_per_launch": flops,
+                   "executed_fp64_tflops": flops / sec / 1e12, "executed_fp64_frac_of_78.6TF": flops / sec / 1e12 / 78.6,
+                   "algorithmic_fp64_flops_per_launch": bench["roofline"].get("algorithmic_flops_per_launch"),
+                   "note": "flops = 64 lanes x (2 FMA + MUL + ADD + TRANS wave-instructions) + 512 per MFMA_MOPS unit: lanes switched off by the "
+                           "exec mask are counted, so this is an upper bound on the useful work and the pipe's true occupancy by fp64 issue",
+                   "workload": hbm["workload"]}, open(prefix + "_fp64_counters.json", "w"), indent=1)
+    if os.path.exists(os.path.join(run, "eval_counters.txt")):
+        shutil.copy(os.path.join(run, "eval_counters.txt"), prefix + "_eval_counters.txt")
+    for d in ("pmc1", "pmc2", "pmc3", "pmc4"):
         sq.update(featurize_counters(os.path.join(run, d)))
     kernels = sorted({k for per in sq.values() for k in per})
     for kern in kernels + ["ALL k_featurize launches of one step"]:

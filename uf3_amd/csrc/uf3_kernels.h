@@ -532,9 +532,14 @@ k_sup_reverse(SupEntry *ent, const int *cnt, int cap, int natoms) {
         const int back = pack3(-s0, -s1, -s2), nj = min(cnt[j], cap);
         const SupEntry *theirs = ent + (size_t)j * cap;
         int hit = -1;
-        for (int r = 0; r < nj; r++) {
-            const int2 key = *(const int2 *)&theirs[r].parent;
-            if (key.x == m && key.y == back) hit = r;
+        for (int r0 = 0; r0 < nj; r0 += 8) {               // eight entries' keys in flight together (a plain loop waits for each)
+            int2 key[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) key[u] = *(const int2 *)&theirs[min(r0 + u, nj - 1)].parent;
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                if (r0 + u < nj && key[u].x == m && key[u].y == back) hit = r0 + u;
         }
         mine->spec = (mine->spec & 0xff) | ((hit + 1) << 8);      // (the species byte is all the scan of other lanes' entries reads... it reads parent | shiftc only)
     }
