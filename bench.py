@@ -101,6 +101,9 @@ def main(argv=None):
     ap.add_argument("--workload", choices=["c4", "w", "lead0"], default=None,
                     help="c4 = W/Mo notebook basis F=434 (featurize default); w = W only, F=73 (fit default); "
                          "lead0 = W/Mo without leading trim, F=1798 (bandwidth-heavier)")
+    ap.add_argument("--row-ld", type=int, default=0,
+                    help="doubles between consecutive force rows in HBM (featurize mode): 0 = F (dense rows, the default), -1 = F "
+                         "rounded up to a multiple of 16 (every row on 128-byte lines of its own), else the stride itself")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the sub-lines of the other BASELINE configurations")
     ap.add_argument("--no-traffic", action="store_true",
@@ -185,9 +188,11 @@ def main(argv=None):
     d_pos = torch.from_numpy(batch.pos).to(dev)
     d_z = torch.from_numpy(batch.z).to(dev)
     d_xe = torch.empty((B, F), dtype=torch.float64, device=dev)
-    d_xf = torch.empty((batch.n_atoms, 3, F), dtype=torch.float64, device=dev)
-    ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
     fit = args.mode == "fit"
+    ld = F if (args.row_ld == 0 or fit) else (fz.aligned_ld(F) if args.row_ld < 0 else max(F, args.row_ld))
+    d_xf_full = torch.empty((batch.n_atoms, 3, ld), dtype=torch.float64, device=dev)
+    d_xf = d_xf_full[:, :, :F]                                    # (the columns that hold rows; contiguous when ld == F)
+    ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
     acc = flat = None
     if fit:
         # targets of the batch (synthetic: any numbers do for the arithmetic; the parity of the fit is a test), already
@@ -206,7 +211,7 @@ def main(argv=None):
         if fit:
             acc.add_device_batch(batch.struct, B, batch.n_atoms, d_pos, d_z, d_counts, d_ye, d_yf, x_e=d_xe, x_f=d_xf)
         else:
-            fz.featurize_device(batch.struct, d_pos.data_ptr(), d_z.data_ptr(), d_xe.data_ptr(), d_xf.data_ptr())
+            fz.featurize_device(batch.struct, d_pos.data_ptr(), d_z.data_ptr(), d_xe.data_ptr(), d_xf_full.data_ptr(), ld=ld)
 
     def fence():
         if distributed:
@@ -262,7 +267,7 @@ def main(argv=None):
         # WRITE_SIZE runs, summary committed under profiles/); null when the workload differs
         traffic, traffic_source = None, None
         if world == 1 and not fit and not args.no_traffic:
-            traffic, traffic_source = measure_traffic(B, args.workload, args.atoms)
+            traffic, traffic_source = measure_traffic(B, args.workload, args.atoms, args.row_ld)
         for name in (() if traffic is not None else ("round4_hbm_counters.json", "round3_hbm_counters.json", "round2_hbm_counters.json", "round1_hbm_counters.json")):
             try:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
@@ -357,7 +362,8 @@ def main(argv=None):
                    ms_per_step=round(1e3 * elapsed / args.steps, 4), higher_is_better=True, scaling="weak",
                    vs_baseline=None, dtype="f64", data="synthetic",
                    config=dict(workload=workload, mode=args.mode, atoms_per_frame=n_atoms, n_feat=F, frames_per_step=B,
-                               outputs=("energy row + 3N force rows per frame, resident in HBM" if not fit else
+                               outputs=(("energy row + 3N force rows per frame, resident in HBM" + (f", rows {ld} doubles apart" if ld != F else ""))
+                                        if not fit else
                                         "packed {G_e, G_f, o_e, o_f, moments} of the unfrozen columns"),
                                sharding=(f"frames x{world}, no data-path collective" if not fit else
                                          f"frames x{world}, one all_reduce(SUM) of 2F'^2+2F'+6 doubles at the end")),
@@ -367,7 +373,7 @@ def main(argv=None):
         out["config"]["collective"] = ("uf3_allreduce_sum_f64 (librccl behind the C ABI)" if distributed and os.environ.get("UF3_NATIVE_RCCL")
                                        else "torch.distributed all_reduce (RCCL)")
         if world == 1 and not fit and wl == "c4" and args.atoms == 10000 and not args.no_extra:
-            out["extra"] = extra_lines(dev, ctx, fz, frames, batch, d_pos, d_z, d_xe, d_xf,
+            out["extra"] = extra_lines(dev, ctx, fz, frames, batch, d_pos, d_z, d_xe, d_xf_full,
                                        cpu=not args.no_cpu_baseline)
             # the other BASELINE configurations again, compact, inside an object the driver's parser keeps
             out["roofline"]["configs"] = compact_configs(out["extra"])
@@ -497,7 +503,7 @@ def eval_mode(args, torch, dist, dev, distributed, world, rank):
 # ---------------------------------------------------------------------------------------------------------------
 # roofline.traffic, measured in the run: HBM bytes of one k_featurize launch group from the PMC counters
 # ---------------------------------------------------------------------------------------------------------------
-def measure_traffic(frames_per_step, workload, atoms):
+def measure_traffic(frames_per_step, workload, atoms, row_ld=0):
     """Two short child runs of this script under `rocprofv3 --pmc` -- FETCH_SIZE and WRITE_SIZE in SEPARATE passes, counters
     only (no trace domains) -- on the same workload and batch; the k_featurize dispatches of a step are summed and averaged
     over the steps.  Units as in tools/summarize_profiles.py (MI355X_MICROARCH.md: the counters report KiB; on gfx950
@@ -518,7 +524,7 @@ def measure_traffic(frames_per_step, workload, atoms):
             out = os.path.join(work, counter)
             cmd = [exe, "--pmc", counter, "-d", out, "-o", "p", "--output-format", "csv", "--", sys.executable,
                    os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--no-extra", "--no-cpu-baseline", "--no-traffic",
-                   "--frames-per-step", str(frames_per_step), "--atoms", str(atoms)] + (["--workload", workload] if workload else [])
+                   "--frames-per-step", str(frames_per_step), "--atoms", str(atoms), "--row-ld", str(row_ld)] + (["--workload", workload] if workload else [])
             env = dict(os.environ, TMPDIR="/tmp", UF3_BENCH_NOCHECK="1")
             subprocess.run(cmd, env=env, cwd=work, timeout=240, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
             per_kernel = {}

@@ -161,6 +161,12 @@ int uf3_featurize(uf3_basis *basis, const uf3_frames *frames, const double *pos 
                   const int32_t *z /*[sumN]*/, double *x_e, double *x_f);
 int uf3_featurize_dev(uf3_basis *basis, const uf3_frames *frames, const double *d_pos,
                       const int32_t *d_z, double *d_x_e, double *d_x_f);
+/* The same with the force rows `ld` doubles apart (ld >= F; columns F .. ld of a row are left alone), the layout uf3_gram_dev
+ * and uf3_gram_force_rows_dev read through their own `ld`: with ld a multiple of 16 every row starts on a 128-byte line --
+ * rows of F = 434 or 1798 doubles do not, and the partial lines at the ends of a row's column segments are written twice
+ * (WRITE_SIZE 1.15 x the rows at F = 434, profiles/round5_hbm_counters.json). */
+int uf3_featurize_ld_dev(uf3_basis *basis, const uf3_frames *frames, const double *d_positions, const int32_t *d_z,
+                         double *d_x_e, double *d_x_f, int64_t ld);
 
 /*
  * Normal-equation pieces of a row block: gram[F][F] (+)= X^T X, ord[F] (+)= X^T y, with

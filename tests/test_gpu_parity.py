@@ -1317,6 +1317,45 @@ def test_featurize_frames_into_caller_buffers():
         fz.featurize_frames([atoms], out=(buf_e, buf_f[:, :2]))
 
 
+@pytest.mark.parametrize("lead3,env", [(3, {}), (0, {}), (3, {"UF3_NO_FEAT3": "1"}), (3, {"UF3_NO_FEAT3": "1", "UF3_NO_MFMA_FEAT": "1"})])
+def test_force_rows_with_a_row_stride(lead3, env, monkeypatch):
+    """uf3_featurize_ld_dev: force rows `ld` doubles apart (every row on 128-byte lines of its own) hold the dense rows' values
+    in their first F columns and leave the padding alone -- through the bond-factorised launch, its wide-window instance and the
+    matrix-core / generic launches."""
+    import torch
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    basis = synthetic.notebook_basis(['Mo', 'W'], lead3=lead3)
+    frames = [synthetic.lattice_frame("bcc", (4, 4, 3), 3.165, [42, 74], seed=90 + k) for k in range(3)]
+    fz = process.BasisFeaturizer(basis)
+    ctx, db = fz._dev()
+    dev = torch.device("cuda", ctx.device)
+    batch = _lib.FrameBatch(frames)
+    F, n = db.n_feat, batch.n_atoms
+    ld = fz.aligned_ld(F)
+    assert ld % 16 == 0 and F <= ld < F + 16
+    d_pos, d_z = torch.from_numpy(batch.pos).to(dev), torch.from_numpy(batch.z).to(dev)
+    prev = ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+    try:
+        dense_e = torch.empty((len(frames), F), dtype=torch.float64, device=dev)
+        dense = torch.empty((n, 3, F), dtype=torch.float64, device=dev)
+        wide_e = torch.empty_like(dense_e)
+        wide = torch.full((n, 3, ld), -7.25, dtype=torch.float64, device=dev)
+        for _ in range(2):                                                    # (capacities settled: the launches of the steady state)
+            fz.featurize_device(batch.struct, d_pos.data_ptr(), d_z.data_ptr(), dense_e.data_ptr(), dense.data_ptr())
+            ctx.synchronize()
+            fz.featurize_device(batch.struct, d_pos.data_ptr(), d_z.data_ptr(), wide_e.data_ptr(), wide.data_ptr(), ld=ld)
+            ctx.synchronize()
+        with pytest.raises(_lib.UF3Error):
+            fz.featurize_device(batch.struct, d_pos.data_ptr(), d_z.data_ptr(), wide_e.data_ptr(), wide.data_ptr(), ld=F - 1)
+    finally:
+        ctx.restore_stream(prev)
+    assert torch.equal(wide[:, :, :F], dense) and bool((wide[:, :, F:] == -7.25).all())
+    assert rel_err(wide_e.cpu().numpy(), dense_e.cpu().numpy()) < 1e-13
+    x_e, x_f, _ = fz.featurize_frames(frames)
+    assert rel_err(dense.cpu().numpy(), x_f) < 1e-13
+
+
 def test_featurize_frames_chunking_is_transparent():
     basis = synthetic.notebook_basis(['W'])
     frames = [synthetic.lattice_frame("bcc", (2, 2, 2 + (k % 2)), 3.165, [74], seed=70 + k) for k in range(7)]

@@ -25,7 +25,7 @@ EXPORTS = ["uf3_ctx_create", "uf3_ctx_destroy", "uf3_ctx_set_stream", "uf3_ctx_s
            "uf3_neighbors_debug", "uf3_fit_rows_dev", "uf3_fit_pack_dev", "uf3_gram_force_rows_dev",
            "uf3_pair_geometry", "uf3_distance_matrix", "uf3_direction_cosines",
            "uf3_ctx_md_skin", "uf3_ctx_md_stats",
-           "uf3_comm_unique_id", "uf3_comm_init", "uf3_comm_destroy", "uf3_comm_info", "uf3_allreduce_sum_f64", "uf3_gram_allreduce"]
+           "uf3_featurize_ld_dev", "uf3_comm_unique_id", "uf3_comm_init", "uf3_comm_destroy", "uf3_comm_info", "uf3_allreduce_sum_f64", "uf3_gram_allreduce"]
 
 
 class HipUnavailable(RuntimeError):
@@ -130,6 +130,7 @@ def load():
         lib.uf3_basis_featurizer_modes.argtypes = [vp, vp]
         for name in ("uf3_featurize", "uf3_featurize_dev"):
             getattr(lib, name).argtypes = [vp, C.POINTER(Frames), vp, vp, vp, vp]
+        lib.uf3_featurize_ld_dev.argtypes = [vp, C.POINTER(Frames), vp, vp, vp, vp, i64]
         for name in ("uf3_gram", "uf3_gram_dev"):
             getattr(lib, name).argtypes = [vp, vp, vp, i64, i32, i64, C.c_int, vp, vp]
         for name in ("uf3_eval", "uf3_eval_dev"):

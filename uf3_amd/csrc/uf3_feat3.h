@@ -53,6 +53,7 @@ struct Feat3Args {
     const double *pos;
     const signed char *spec;
     double *x_e, *x_f;
+    int ld;                    // doubles between consecutive force rows (>= F)
     int natoms, atoms_per_block, e_direct;
     int skip;                  // ablations (-DUF3_ABLATE builds only): 1 stage 1, 2 stage 2, 4 centre walk, 8 neighbour walk, 16 fold + stores, 32 bond tables, 64 leg evaluations of the walks
 };
@@ -266,7 +267,7 @@ k_featurize3(Feat3Args A) {
             const int8_v hv = *(const __attribute__((address_space(4))) int8_v *)(unsigned long long)&td->head;
             const int t_ncol = hv[2], t_sc = hv[3], t_sa = hv[4], t_sb = hv[5], t_col = hv[6];
             const bool centre = t_sc == sm, nbr = t_sa == sm || t_sb == sm;
-            if (!centre && !nbr) { zero_rows(A.x_f, m, F, t_col, t_ncol); continue; }
+            if (!centre && !nbr) { zero_rows(A.x_f, m, A.ld, t_col, t_ncol); continue; }
             const bool tr = t_sa != t_sb && sm == t_sb;              // transposed: the fixed bond sits on leg m
 
             double xacc[NR][EF][2], ws[NR][2];
@@ -538,9 +539,9 @@ k_featurize3(Feat3Args A) {
                     const int s0 = ft[2 * col], s1 = ft[2 * col + 1];
                     F3LdsPairs d0 = (F3LdsPairs)(const F3Pair *)stage, d1 = d0 + EF * 32;
                     const F3Pair a0 = d0[s0], a1 = d0[s1], b0 = d1[s0], b1 = d1[s1];
-                    double *dst = A.x_f + (size_t)m * 3 * F + t_col + col;
-                    __builtin_nontemporal_store(a0.x + a1.x, dst); __builtin_nontemporal_store(a0.y + a1.y, dst + F);
-                    __builtin_nontemporal_store(b0.x + b1.x, dst + 2 * (size_t)F);
+                    double *dst = A.x_f + (size_t)m * 3 * A.ld + t_col + col;
+                    __builtin_nontemporal_store(a0.x + a1.x, dst); __builtin_nontemporal_store(a0.y + a1.y, dst + A.ld);
+                    __builtin_nontemporal_store(b0.x + b1.x, dst + 2 * (size_t)A.ld);
                     if (WANT_E) es.add(t_col + col, b0.y + b1.y);
                 }
                 wave_sync();
@@ -560,10 +561,10 @@ k_featurize3(Feat3Args A) {
                         const int s0 = ft[2 * col], s1 = ft[2 * col + 1];
                         F3LdsDoubles da = (F3LdsDoubles)stage, db = da + BUF;
                         const double va = da[s0] + da[s1];
-                        __builtin_nontemporal_store(va, A.x_f + ((size_t)m * 3 + k) * F + t_col + col);
+                        __builtin_nontemporal_store(va, A.x_f + ((size_t)m * 3 + k) * A.ld + t_col + col);
                         if (k == 0 || WANT_E) {
                             const double vb = db[s0] + db[s1];
-                            if (k == 0) __builtin_nontemporal_store(vb, A.x_f + ((size_t)m * 3 + 2) * F + t_col + col);
+                            if (k == 0) __builtin_nontemporal_store(vb, A.x_f + ((size_t)m * 3 + 2) * A.ld + t_col + col);
                             else es.add(t_col + col, vb);
                         }
                     }

@@ -1302,9 +1302,26 @@ static size_t feat3_lds_bytes(const uf3_basis *b, int cap, bool e_lds) {
 }
 #define UF3_LDS_LIMIT ((size_t)160 * 1024 - 512)
 
+static int featurize_dev_impl(uf3_basis *b, const uf3_frames *fr, const double *d_pos, const int32_t *d_z,
+                              double *d_xe, double *d_xf, int64_t ld);
+
 extern "C" int uf3_featurize_dev(uf3_basis *b, const uf3_frames *fr, const double *d_pos, const int32_t *d_z,
                                  double *d_xe, double *d_xf) {
     if (!b) return fail(nullptr, UF3_EINVAL, "null basis");
+    return featurize_dev_impl(b, fr, d_pos, d_z, d_xe, d_xf, b->host.F);
+}
+
+// force rows `ld` doubles apart (ld >= F; the columns F .. ld of a row are not touched): with ld a multiple of 16 every row
+// starts on a 128-byte line -- rows of F = 434 or 1798 doubles do not, and the partial lines at their ends are written twice
+extern "C" int uf3_featurize_ld_dev(uf3_basis *b, const uf3_frames *fr, const double *d_pos, const int32_t *d_z,
+                                    double *d_xe, double *d_xf, int64_t ld) {
+    if (!b) return fail(nullptr, UF3_EINVAL, "null basis");
+    if (ld < b->host.F || ld > (1 << 24)) return fail(b->ctx, UF3_EINVAL, "uf3_featurize_ld_dev: ld must be >= the number of features");
+    return featurize_dev_impl(b, fr, d_pos, d_z, d_xe, d_xf, ld);
+}
+
+static int featurize_dev_impl(uf3_basis *b, const uf3_frames *fr, const double *d_pos, const int32_t *d_z,
+                              double *d_xe, double *d_xf, int64_t ld) {
     uf3_ctx *c = b->ctx;
     if (!d_pos || !d_z) return fail(c, UF3_EINVAL, "null positions / species");
     if (!d_xe && !d_xf) return UF3_OK;
@@ -1346,7 +1363,7 @@ extern "C" int uf3_featurize_dev(uf3_basis *b, const uf3_frames *fr, const doubl
     // the block-shared energy row costs 8 F bytes of LDS: past 48 KB the contributions go straight to HBM instead
     A.e_direct = (want_e && (size_t)F * 8 > 48 * 1024) ? 1 : 0;
     A.n3_need = c->flags.as<int>() + 1;
-    A.pos = d_pos; A.spec = P.spec; A.x_e = d_xe; A.x_f = d_xf; A.natoms = P.natoms;
+    A.pos = d_pos; A.spec = P.spec; A.x_e = d_xe; A.x_f = d_xf; A.ld = (int)ld; A.natoms = P.natoms;
     A.cand_need = c->flags.as<int>() + 2;
     // (UF3_KEEP_GHOST_TERMS: keep the force terms of ghost-centred triplets whose third atom the reference's image range
     // does not reach -- rows of unwrapped atoms are then the exact gradient of the energy row instead of the reference's)
@@ -1530,7 +1547,7 @@ extern "C" int uf3_featurize_dev(uf3_basis *b, const uf3_frames *fr, const doubl
                 G.lo_p = b->f3_lo_p; G.ext_p = b->f3_ext_p; G.lo_n = b->f3_lo_n; G.ext_n = b->f3_ext_n;
                 G.pr_rows = std::min(b->f3_ext_p, 32 / b->f3_ext_n);
                 G.geoms = P.geoms; G.frame_of = P.frame_of; G.n3 = A.n3; G.pos = d_pos; G.spec = P.spec;
-                G.x_e = d_xe; G.x_f = d_xf; G.natoms = P.natoms; G.e_direct = A.e_direct; G.skip = A.skip;
+                G.x_e = d_xe; G.x_f = d_xf; G.ld = (int)ld; G.natoms = P.natoms; G.e_direct = A.e_direct; G.skip = A.skip;
                 int ep, stage, nrec;
                 feat3_shape(b, ep, stage, nrec);
                 (void)stage; (void)nrec;

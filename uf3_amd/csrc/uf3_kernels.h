@@ -655,7 +655,8 @@ struct FeatArgs {
     const double *pos;
     const signed char *spec;
     double *x_e;        // [n_frames][F] or null
-    double *x_f;        // [natoms][3][F] or null
+    double *x_f;        // [natoms][3][ld] or null
+    int ld;             // doubles between consecutive force rows (>= F; F: dense rows)
     int *cand_need;     // overflow report of the 2-body candidate stage
     const int *outside; // != 0: some atom of the batch lies outside its cell (null: the image-range rule is switched off)
     int *n3_need;       // ... of the 3-body neighbour lists (MODE 0 builds them when build_n3 != 0)
@@ -996,7 +997,7 @@ __device__ __forceinline__ void trio_block(const FeatArgs &A, const BasisDev *B,
     const TrioDev *td = &td_copy;
     TrioWalk k;
     trio_walk_setup<WANT_F, IMG>(A, w, td->sc, td->sa, td->sb, sm, k);
-    const int ncol = td->ncol, F = load_const(&B->F);     // (a scalar load: as B->F it is a vector load and a wait on everything in flight)
+    const int ncol = td->ncol;
     for (int c0 = 0; c0 < ncol; c0 += NCH * WAVE) {
         ColSrc src[NCH][NSRC];
         double acc[NCH][4];
@@ -1025,9 +1026,9 @@ __device__ __forceinline__ void trio_block(const FeatArgs &A, const BasisDev *B,
             int col = c0 + ch * WAVE + lane;
             if (col < ncol) {
                 if (WANT_F) {
-                    double *dst = A.x_f + (size_t)m * 3 * F + td->col + col;
-                    __builtin_nontemporal_store(acc[ch][0], dst); __builtin_nontemporal_store(acc[ch][1], dst + F);
-                    __builtin_nontemporal_store(acc[ch][2], dst + 2 * (size_t)F);
+                    double *dst = A.x_f + (size_t)m * 3 * A.ld + td->col + col;
+                    __builtin_nontemporal_store(acc[ch][0], dst); __builtin_nontemporal_store(acc[ch][1], dst + A.ld);
+                    __builtin_nontemporal_store(acc[ch][2], dst + 2 * (size_t)A.ld);
                 }
                 if (WANT_E) es.add(td->col + col, acc[ch][3]);
             }
@@ -1205,7 +1206,7 @@ __device__ __forceinline__ void dense_fold(const FeatArgs &A, const WaveLds &w, 
                     if (q >= nc) break;
                     const double val = w0 * t0[q] + w1 * t1[q];
                     const int comp = c0 + q;
-                    if (comp < 3) { if (!UF3_SKIP(32)) __builtin_nontemporal_store(val, A.x_f + (size_t)m * 3 * F + (size_t)comp * F + td->col + col); }
+                    if (comp < 3) { if (!UF3_SKIP(32)) __builtin_nontemporal_store(val, A.x_f + (size_t)m * 3 * A.ld + (size_t)comp * A.ld + td->col + col); }
                     else es.add(td->col + col, val);
                 }
             }
@@ -1218,7 +1219,7 @@ __device__ __forceinline__ void dense_fold(const FeatArgs &A, const WaveLds &w, 
                         if (off >= 0) val += dump[q * rows_c + off];
                     }
                     const int comp = c0 + q;
-                    if (comp < 3) { if (!UF3_SKIP(32)) __builtin_nontemporal_store(val, A.x_f + (size_t)m * 3 * F + (size_t)comp * F + td->col + col); }
+                    if (comp < 3) { if (!UF3_SKIP(32)) __builtin_nontemporal_store(val, A.x_f + (size_t)m * 3 * A.ld + (size_t)comp * A.ld + td->col + col); }
                     else es.add(td->col + col, val);
                 }
         }
@@ -1806,8 +1807,8 @@ __device__ __forceinline__ void trio_block_grouped(const FeatArgs &A, const Basi
     const int lane = lane_id();
     TrioWalk k;
     trio_walk_setup<WANT_F, IMG>(A, w, th.sc, th.sa, th.sb, sm, k);
-    const int ncol = th.ncol, F = load_const(&B->F);      // (a scalar load: as B->F it was a vector load, once per block, and a wait on
-                                                          // everything in flight -- the row stores of the block before included)
+    const int ncol = th.ncol;                             // (the row stride A.ld is a kernel argument, a scalar: read through B it was a
+                                                          // vector load once per block and a wait on the row stores of the block before)
     const unsigned short *gsrc_blk = gsrc + (th.grouped >> 8);      // the block's fold table (LDS when it fits)
     const int ext_l = L.ext_l, ext_m = 3;
     const int oM = 2 * ext_l, oN = oM + 2 * ext_m, oD = oN + 2 * GW;
@@ -2013,9 +2014,9 @@ __device__ __forceinline__ void trio_block_grouped(const FeatArgs &A, const Basi
         if (!UF3_SKIP(32)) {
             // (streaming stores: the rows are not read again by this launch -- they should not push the neighbour lists, which
             // are, out of the L2)
-            double *dst = A.x_f + (size_t)m * 3 * F + th.col + col;
-            __builtin_nontemporal_store(sum[0], dst); __builtin_nontemporal_store(sum[1], dst + F);
-            __builtin_nontemporal_store(sum[2], dst + 2 * (size_t)F);
+            double *dst = A.x_f + (size_t)m * 3 * A.ld + th.col + col;
+            __builtin_nontemporal_store(sum[0], dst); __builtin_nontemporal_store(sum[1], dst + A.ld);
+            __builtin_nontemporal_store(sum[2], dst + 2 * (size_t)A.ld);
         }
         pc.lap(9);
         if (WANT_E && !UF3_SKIP(256)) es.add(th.col + col, sum[3]);
@@ -2031,7 +2032,7 @@ __device__ __forceinline__ void trio_block_grouped(const FeatArgs &A, const Basi
 template <bool WANT_E, bool WANT_F, bool RL>           // RL: recs is the workgroup's LDS copy
 __device__ __forceinline__ void pair_rows(const FeatArgs &A, const BasisDev *B, const KnotRec *recs, const WaveLds &w, int m,
                                           int sm, int n_cand, const ESink &es) {
-    const int lane = lane_id(), F = load_const(&B->F), S = load_const(&B->S);
+    const int lane = lane_id(), S = load_const(&B->S);
     const int n2 = A.n_pair_cols;                       // pair columns are [S, S + n2)
     double *row = w.pstage;                             // [4][n2]: energy, fx, fy, fz
     const int pairs_uniform = load_const(&B->pairs_uniform), lead2 = load_const(&B->lead2), trail2 = load_const(&B->trail2);
@@ -2078,9 +2079,9 @@ __device__ __forceinline__ void pair_rows(const FeatArgs &A, const BasisDev *B, 
     wave_sync();
     for (int col = lane; col < n2; col += WAVE) {
         if (WANT_F) {
-            double *dst = A.x_f + (size_t)m * 3 * F + S + col;
-            __builtin_nontemporal_store(row[n2 + col], dst); __builtin_nontemporal_store(row[2 * n2 + col], dst + F);
-            __builtin_nontemporal_store(row[3 * n2 + col], dst + 2 * (size_t)F);
+            double *dst = A.x_f + (size_t)m * 3 * A.ld + S + col;
+            __builtin_nontemporal_store(row[n2 + col], dst); __builtin_nontemporal_store(row[2 * n2 + col], dst + A.ld);
+            __builtin_nontemporal_store(row[3 * n2 + col], dst + 2 * (size_t)A.ld);
         }
         if (WANT_E) es.add(S + col, row[col]);
     }
@@ -2145,10 +2146,10 @@ __device__ __forceinline__ void build_n3_list(const FeatArgs &A, const BasisDev 
     wave_sync();
 }
 
-__device__ __forceinline__ void zero_rows(double *x_f, int m, int F, int col, int n) {
+__device__ __forceinline__ void zero_rows(double *x_f, int m, int ld, int col, int n) {
     for (int c = lane_id(); c < n; c += WAVE) {
-        double *dst = x_f + (size_t)m * 3 * F + col + c;
-        __builtin_nontemporal_store(0.0, dst); __builtin_nontemporal_store(0.0, dst + F); __builtin_nontemporal_store(0.0, dst + 2 * (size_t)F);
+        double *dst = x_f + (size_t)m * 3 * ld + col + c;
+        __builtin_nontemporal_store(0.0, dst); __builtin_nontemporal_store(0.0, dst + ld); __builtin_nontemporal_store(0.0, dst + 2 * (size_t)ld);
     }
 }
 
@@ -2277,7 +2278,7 @@ k_featurize(FeatArgs A) {
         ESink es;
         es.lds = erow; es.glob = WANT_E ? A.x_e + (size_t)fr * F : nullptr; es.direct = !e_lds || (fr != erow_frame);
         // ---- 1-body columns ------------------------------------------------------------------
-        if (MODE == 0 && WANT_F) zero_rows(A.x_f, m, F, 0, S);
+        if (MODE == 0 && WANT_F) zero_rows(A.x_f, m, A.ld, 0, S);
         if (MODE == 0 && WANT_E && lane == 0) es.add(sm, 1.0);
         // ---- 2-body: neighbour images -> LDS once, then one pass per pair block ------------------
         if (MODE == 0) {
@@ -2352,7 +2353,7 @@ k_featurize(FeatArgs A) {
                 if (t_mode != MODE) continue;
                 const int t_sc = th.sc, t_sa = th.sa, t_sb = th.sb;
                 const bool touches = (t_sc == sm) || (WANT_F && (t_sa == sm || t_sb == sm));
-                if (!touches) { if (WANT_F && !UF3_SKIP(32)) zero_rows(A.x_f, m, F, th.col, t_ncol); continue; }
+                if (!touches) { if (WANT_F && !UF3_SKIP(32)) zero_rows(A.x_f, m, A.ld, th.col, t_ncol); continue; }
                 if (MODE == 1) trio_block<WANT_E, WANT_F, 1, 1, IMG>(A, B, recs, g, w, m, sm, t, es);
                 else if (MODE == 2) trio_block<WANT_E, WANT_F, 1, 2, IMG>(A, B, recs, g, w, m, sm, t, es);
                 else if (MODE == 3) trio_block<WANT_E, WANT_F, 2, 1, IMG>(A, B, recs, g, w, m, sm, t, es);

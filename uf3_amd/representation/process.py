@@ -106,12 +106,23 @@ class BasisFeaturizer:
             start = stop
         return x_e, x_f, offsets
 
-    def featurize_device(self, frames_struct, d_pos, d_z, d_x_e=None, d_x_f=None):
-        """Device-resident entry: raw HBM pointers (ints), asynchronous on the context stream."""
+    def featurize_device(self, frames_struct, d_pos, d_z, d_x_e=None, d_x_f=None, ld=None):
+        """Device-resident entry: raw HBM pointers (ints), asynchronous on the context stream.  ``ld``: doubles between
+        consecutive force rows (default: the number of features, dense rows; a multiple of 16 puts every row on a cache
+        line of its own, ``aligned_ld``)."""
         import ctypes as C
         ctx, db = self._dev()
-        ctx.check(ctx.lib.uf3_featurize_dev(db.handle, C.byref(frames_struct), C.c_void_p(d_pos), C.c_void_p(d_z),
-                                            C.c_void_p(d_x_e or 0), C.c_void_p(d_x_f or 0)))
+        if ld is None or int(ld) == db.n_feat:
+            ctx.check(ctx.lib.uf3_featurize_dev(db.handle, C.byref(frames_struct), C.c_void_p(d_pos), C.c_void_p(d_z),
+                                                C.c_void_p(d_x_e or 0), C.c_void_p(d_x_f or 0)))
+        else:
+            ctx.check(ctx.lib.uf3_featurize_ld_dev(db.handle, C.byref(frames_struct), C.c_void_p(d_pos), C.c_void_p(d_z),
+                                                   C.c_void_p(d_x_e or 0), C.c_void_p(d_x_f or 0), int(ld)))
+
+    @staticmethod
+    def aligned_ld(n_feat):
+        """the row stride (doubles) that starts every force row on a 128-byte line"""
+        return (int(n_feat) + 15) // 16 * 16
 
     def neighbor_indices(self, geom):
         """
