@@ -348,6 +348,30 @@ class WeightedLinearModel(BasicLinearModel):
         return y_e, p_e, y_f, p_f
 
     # -- model files ------------------------------------------------------------------
+    def fix_repulsion_2b(self, pair, r_target=None, min_curvature=2.0):
+        """
+        Coefficients of the pair block that no training distance reached (``data_coverage`` False between the leading trim
+        and the first covered function) replaced by a second-order Taylor continuation of the fitted pair potential around
+        ``r_target`` (default: the centre of the first covered function), its curvature there raised to ``min_curvature``:
+        a repulsive wall where the data said nothing (reference ``least_squares.py:623-647``).
+        """
+        sizes, offsets = self.bspline_config.get_interaction_partitions()
+        first, n_basis = offsets[pair], sizes[pair]
+        block = np.arange(first, first + n_basis)
+        covered = np.asarray(self.data_coverage)[block]
+        first_covered = int(np.argmax(covered == True))  # noqa: E712  (element-wise, like the reference)
+        if first_covered == 0:
+            print(f"Coverage is sufficient; no fix applied to {pair}.")
+        to_fix = np.arange(self.bspline_config.leading_trim[2], first_covered)
+        knots = self.bspline_config.knots_map[pair]
+        centres = knots[2: n_basis + 2]
+        if r_target is None:
+            r_target = centres[first_covered]
+        values = get_spline_taylor_expansion(r_target, centres[to_fix], self.coefficients[block], knots,
+                                             min_curvature=min_curvature)
+        print(f"{pair} Correction: adjusted {len(to_fix)} coefficients.")
+        self.coefficients[block[to_fix]] = values
+
     def load(self, solution=None, filename=None):
         """Flatten a per-interaction coefficient dict (3-body given as full grids) into ``coefficients``."""
         if filename is not None:
@@ -394,6 +418,60 @@ class WeightedLinearModel(BasicLinearModel):
             raise ValueError("Incorrect coefficients: {} provided, {} expected.".format(
                 len(flat), sum(basis.partition_sizes)))
         self.coefficients = np.array(flat)
+
+
+def get_spline_taylor_expansion(r_target, r, coefficients, knot_sequence, min_curvature=0.0):
+    """Second-order Taylor polynomial, around ``r_target``, of the cubic spline sum_b c_b B_b on ``knot_sequence``, evaluated
+    at ``r``; the curvature is raised to ``min_curvature`` when that is not None (reference ``least_squares.py:650-663``,
+    there through ``ndsplines``)."""
+    from uf3_amd.representation import bspline
+    knots = np.asarray(knot_sequence, dtype=float)
+    c = np.asarray(coefficients, dtype=float)
+    elements = bspline.generate_basis_functions([knots[i:i + 5] for i in range(len(knots) - 4)])
+    at = np.atleast_1d(np.asarray(r_target, dtype=float))
+    value, slope, curvature = (float(sum(c[b] * elements[b](at, nu=nu)[0] for b in range(len(c)))) for nu in (0, 1, 2))
+    if min_curvature is not None:
+        curvature = max(curvature, min_curvature)
+    step = np.asarray(r, dtype=float) - r_target
+    return value + slope * step + 0.5 * curvature * step ** 2
+
+
+def find_pair_potential_well(coefficients, rounding_factor):
+    """Index of the coefficient that looks like the pair potential's well: the minimum -- unless it lies left of the
+    maximum and the coefficients before the maximum are flat to ``rounding_factor`` decimals (no well there: the index
+    behind the maximum).  Reference ``least_squares.py:1123-1144``."""
+    c = np.asarray(coefficients)
+    peak, well = int(np.argmax(c)), int(np.argmin(c))
+    if well < peak:
+        before_peak = np.round(c[:peak], rounding_factor)
+        if np.ptp(before_peak) < 10 ** -(rounding_factor - 1):
+            well = peak + 1
+    return well
+
+
+def postprocess_coefficients_2b(coefficients, core_hardness=2.0, min_core=2.0, min_slope=0.1, rounding_factor=3,
+                                smooth_cutoff=False, in_place=False):
+    """
+    A repulsive core for a vector of pair coefficients (reference ``least_squares.py:1075-1120``): left of the well, when the
+    coefficients only rise towards a maximum (the lower bound lies far below the data and they are nearly zero), they are
+    rebuilt from the maximum downwards in r as ``max(core_hardness * |next|, min_slope)``; the first coefficient is at least
+    ``min_core``; ``smooth_cutoff`` zeroes the last two.  Works on a copy unless ``in_place``.
+    """
+    c = coefficients if in_place else np.array(coefficients)
+    well = find_pair_potential_well(c, rounding_factor)
+    if well > 1:
+        left = np.round(c[:well], rounding_factor)
+        left = left + np.arange(len(left)) * 10 ** (-2 * rounding_factor)      # (a plateau leans towards the well)
+        slope = np.gradient(left)
+        peak = int(np.argmax(left))
+        if np.all(slope[:peak] >= 0):
+            for i in range(peak - 1, -1, -1):
+                c[i] = max(np.abs(c[i + 1]) * core_hardness, min_slope)
+    if c[0] < min_core:
+        c[0] = min_core
+    if smooth_cutoff:
+        c[-2:] = 0
+    return c
 
 
 def dataframe_to_tuples(df_features, n_elements=None, energy_key='energy', sample_weights=None):

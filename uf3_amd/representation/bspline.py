@@ -168,9 +168,25 @@ class BasisFunction:
                 out += 3.0 / (t[3] - t[0]) * self._b(0, 2, x)
             if t[4] > t[1]:
                 out -= 3.0 / (t[4] - t[1]) * self._b(1, 2, x)
+        elif nu == 2:
+            out = self._d(0, 3, x, 2)
         else:
-            raise NotImplementedError("nu in (0, 1)")
+            raise NotImplementedError("nu in (0, 1, 2)")
         out[(x < t[0]) | (x > t[4])] = 0.0
+        return out
+
+    def _d(self, s, k, x, nu):
+        """nu-th derivative of the degree-k element starting at knot s: d/dx B_{s,k} = k (B_{s,k-1} / (t_{s+k} - t_s) -
+        B_{s+1,k-1} / (t_{s+k+1} - t_{s+1})), terms over a zero knot span dropped like the recursion's 0/0."""
+        if nu == 0:
+            return self._b(s, k, x)
+        t = self.t
+        out = np.zeros_like(x)
+        d1, d2 = t[s + k] - t[s], t[s + k + 1] - t[s + 1]
+        if d1 > 0:
+            out += k / d1 * self._d(s, k - 1, x, nu - 1)
+        if d2 > 0:
+            out -= k / d2 * self._d(s + 1, k - 1, x, nu - 1)
         return out
 
 

@@ -124,6 +124,13 @@ class BasisFeaturizer:
         """the row stride (doubles) that starts every force row on a 128-byte line"""
         return (int(n_feat) + 15) // 16 * 16
 
+    def get_training_tuples(self, df_features, kappa, data_coordinator):
+        """(x, y, row weights) of a feature table -- deprecated in the reference (``process.py:508-535``), kept for scripts that
+        still call it; see ``dataframe_to_training_tuples``."""
+        import warnings
+        warnings.warn("get_training_tuples() is deprecated.", DeprecationWarning)
+        return dataframe_to_training_tuples(df_features, kappa=kappa, energy_key=data_coordinator.energy_key)
+
     def neighbor_indices(self, geom):
         """
         Neighbour indices in the reference's supercell numbering:
@@ -379,3 +386,24 @@ def existing_feature_tables(filename):
 
 def flatten_by_interactions(vector_map, pair_tuples):
     return np.concatenate([vector_map[pair] for pair in pair_tuples], axis=-1)
+
+
+def dataframe_to_training_tuples(df_features, kappa=0.5, energy_key='energy'):
+    """
+    The weights-per-row form of the training data (reference ``process.py:574-616``, deprecated there in favour of the
+    Gram-level weights): x = all columns but the first, y = the first, and a weight per row -- energy rows
+    ``kappa / (std_e n_e)``, force rows ``(1 - kappa) / (std_f n_f)`` with the population standard deviations of the two
+    target groups.  Rows are energies where the last index level equals ``energy_key``.
+    """
+    if kappa < 0 or kappa > 1:
+        raise ValueError("Invalid domain for kappa weighting parameter.")
+    if len(df_features) <= 1:
+        raise ValueError(f"Not enough samples ({len(df_features)} provided)")
+    is_energy = np.asarray(df_features.index.get_level_values(-1) == energy_key)
+    table = df_features.to_numpy()
+    y, x = table[:, 0], table[:, 1:]
+    n_e, n_f = int(is_energy.sum()), int((~is_energy).sum())
+    w = np.zeros(n_e + n_f)
+    w[is_energy] = kappa / np.std(y[is_energy]) / n_e
+    w[~is_energy] = (1 - kappa) / np.std(y[~is_energy]) / n_f
+    return x, y, w
