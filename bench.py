@@ -418,10 +418,10 @@ def eval_mode(args, torch, dist, dev, distributed, world, rank):
     if native:
         parallel.native_comm(ctx, rank, world)
 
-    # N = 1: an MD step -- every atom moves (seeded +-0.01 A walk, one device kernel) and the evaluator runs its MD route
-    # (neighbour lists kept with a 0.5 A skin, rebuilt inside the timed region when an atom nears skin / 2); the decomposed
-    # route of N > 1 rebuilds its lists every step (uf3_eval_centres has no persistent lists yet)
-    moving = world == 1 and not forced
+    # An MD step -- every atom moves (seeded +-0.01 A walk, one device kernel) and the evaluator runs its MD route (neighbour
+    # lists kept with a 0.5 A skin, rebuilt inside the timed region when an atom nears skin / 2): the whole frame at N = 1, a
+    # block of centres on whole-frame lists per rank at N > 1
+    moving = True      # (every rank applies the same seeded walk: the ranks of a decomposed frame see the same positions)
     if moving:
         g = torch.Generator(device=dev).manual_seed(17)
         pool = (torch.rand((64, n, 3), dtype=torch.float64, device=dev, generator=g) * 2.0 - 1.0) * MD_WALK
@@ -431,10 +431,10 @@ def eval_mode(args, torch, dist, dev, distributed, world, rank):
     counter = [0]
 
     def step():
-        if moving:
-            k = counter[0] & 0xffff
-            counter[0] += 1
-            d_pos.add_(pool[order[k]], alpha=float(signs[k]))
+        k = counter[0] & 0xffff
+        counter[0] += 1
+        d_pos.add_(pool[order[k]], alpha=float(signs[k]))
+        if world == 1 and not forced:
             ctx.check(ctx.lib.uf3_eval_virial_dev(*common, C.c_void_p(p_e), C.c_void_p(p_f), C.c_void_p(p_v)))
         else:
             # (uf3_eval_centres_dev zeroes every force row itself and overwrites energy / strain derivative: nothing to clear)

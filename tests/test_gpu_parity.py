@@ -905,6 +905,47 @@ def test_md_route_on_a_displaced_trajectory_does_not_depend_on_rebuilds(reps, st
     ctx.md_skin(0.0)
 
 
+def test_blocks_of_centres_on_the_md_route_add_up_to_the_frame():
+    """uf3_eval_centres with a skin (round 5): every rank keeps whole-frame lists across steps; the shares of disjoint blocks of
+    centres add up to the whole-frame result and to the oracle on every step of a walk that outruns the lists more than once,
+    rows of atoms far from a block stay zero, and an atom OUTSIDE the block that moves too far is noticed by the block's rank."""
+    from uf3_amd import parallel
+    basis = synthetic.notebook_basis(['Mo', 'W'])
+    model, coeff = _random_model(basis, 23)
+    calc_md = calculator.UFCalculator(model, md_skin=0.4)
+    calc_plain = calculator.UFCalculator(model, md_skin=0.0)
+    start = synthetic.lattice_frame("bcc", (7, 6, 5), 3.165, [42, 74], seed=2)
+    n = len(start)
+    ctx = _lib.get_context(None)
+    for _ in range(2):
+        calc_plain.evaluate_frames([start], virial=True)
+    rng = np.random.default_rng(9)
+    pos = start.get_positions()
+    ob = O.OracleBasis(basis)
+    ctx.md_skin(0.0)
+    before = ctx.md_stats()
+    for step in range(10):
+        pos = pos + rng.uniform(-0.04, 0.04, (n, 3))
+        if step == 6:
+            pos[n - 1] += [0.3, 0.1, -0.2]                        # an atom of the LAST block: the first block's rank must notice
+        atoms = Atoms(numbers=start.get_atomic_numbers(), positions=pos, cell=start.get_cell(), pbc=True)
+        for w in ((3, 8) if step % 3 == 0 else (3,)):
+            cs = [calc_md.evaluate_centre_range(atoms, *parallel.shard_range(n, r, w), virial=True) for r in range(w)]
+            e_sum, f_sum, v_sum = sum(s[0] for s in cs), sum(s[1] for s in cs), sum(s[2] for s in cs)
+            if step % 3 == 0 or step == 6:
+                e_o, f_o = O.evaluate(ob, atoms, coeff)
+                assert abs(e_sum - e_o) <= 1e-10 * abs(e_o) and worst_elementwise(f_sum, f_o) <= 1.0
+            for r, (_, fs, _) in enumerate(cs):
+                lo, hi = parallel.shard_range(n, r, w)
+                touched = np.flatnonzero(np.abs(fs).sum(axis=1) > 0)
+                assert set(range(lo, hi)) <= set(touched.tolist()) and (len(touched) < n or w == 3)
+        whole = calc_md.evaluate_frames([atoms], virial=True)
+        assert abs(e_sum - whole[0][0]) <= 1e-12 * abs(whole[0][0]) and rel_err(f_sum, whole[1]) < 1e-12 and rel_err(v_sum, whole[3][0]) < 1e-11
+    after = ctx.md_stats()
+    assert 2 <= after["builds"] - before["builds"] < 10 and after["redone"] - before["redone"] >= 1
+    ctx.md_skin(0.0)
+
+
 def test_md_route_rebuilds_on_layout_species_and_cell_changes():
     """The lists are tied to (basis, offsets, cells, pbc, species): any change rebuilds them instead of serving stale neighbours;
     a batch of several frames runs on lists as well.  Each result against the plain route."""

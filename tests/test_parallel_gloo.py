@@ -202,3 +202,52 @@ def test_bench_launcher_starts_n_ranks_or_refuses(capsys):
     env2 = dict(env, RANK="0", WORLD_SIZE="2", LOCAL_RANK="0", MASTER_PORT="29518", MASTER_ADDR="127.0.0.1")
     r = subprocess.run([sys.executable, bench.__file__, "--gpus", "4"], env=env2, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr
+
+
+class _FakeCommCtx:
+    """what parallel.native_comm needs of a context: an id to draw and a place to join with it"""
+
+    def __init__(self):
+        self.joined = None
+
+    def comm_unique_id(self):
+        return bytes(range(128))
+
+    def comm_init(self, n_ranks, rank, uid):
+        self.joined = (n_ranks, rank, bytes(uid))
+
+
+def _native_comm_rank(rank, world, port, out_dir, use_group):
+    """one rank of the id exchange: through torch.distributed's group (gloo here) or through a file"""
+    import torch.distributed as dist
+    from uf3_amd import parallel
+    ctx = _FakeCommCtx()
+    if use_group:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        parallel.native_comm(ctx, rank, world)
+        dist.destroy_process_group()
+    else:
+        parallel.native_comm(ctx, rank, world, id_path=os.path.join(out_dir, "comm_id"))
+    np.save(os.path.join(out_dir, f"joined_{int(use_group)}_{rank}.npy"), np.frombuffer(ctx.joined[2], dtype=np.uint8))
+    assert ctx.joined[:2] == (world, rank)
+
+
+@pytest.mark.parametrize("use_group", [True, False])
+def test_native_comm_carries_rank_zeros_id_to_every_rank(tmp_path, use_group):
+    """parallel.native_comm (the host side of RCCL behind the C ABI, uf3_comm_init): the 128-byte id rank 0 draws reaches the
+    other rank through the process group when one is up, else through a file; every rank joins with (world, rank, id)."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_native_comm_rank, args=(2, port, str(tmp_path), use_group), nprocs=2, join=True)
+    ids = [np.load(tmp_path / f"joined_{int(use_group)}_{r}.npy") for r in range(2)]
+    assert np.array_equal(ids[0], np.arange(128, dtype=np.uint8)) and np.array_equal(ids[0], ids[1])
+    from uf3_amd import parallel
+    lone = _FakeCommCtx()
+    parallel.native_comm(lone, 0, 1)
+    assert lone.joined == (1, 0, bytes(range(128)))
+    with pytest.raises(ValueError):
+        parallel.native_comm(_FakeCommCtx(), 1, 2)              # two ranks, no group, no file: no way to pass the id

@@ -122,6 +122,45 @@ def main():
             dec[f"world_{world}"] = dict(block_atoms=hi - lo, neighbor_ms=round(t["neighbor_ms"] / n, 4),
                                          eval_kernel_ms=round(t["eval_ms"] / n, 4), wall_ms=round(wall, 4))
         out["decomposed_50k_ternary_one_rank"] = dec
+        # the same share on the MD route (round 5): whole-frame lists kept with a 0.5 A skin, the atoms moving +-0.01 A per step
+        # (one device add per step, inside the timed loop like the list rebuilds)
+        g = torch.Generator(device=dev).manual_seed(17)
+        pool = (torch.rand((32, batch.n_atoms, 3), dtype=torch.float64, device=dev, generator=g) * 2.0 - 1.0) * 0.01
+        pick = np.random.default_rng(17).integers(0, 32, 4096)
+        sign = np.random.default_rng(18).choice([-1.0, 1.0], 4096)
+        prev = ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+        ctx.md_skin(0.5)
+        dec_md = {}
+        step_no = [0]
+        try:
+            for world in (1, 2, 4, 8):
+                lo, hi = 0, (batch.n_atoms + world - 1) // world
+
+                def call():
+                    k = step_no[0] & 4095
+                    step_no[0] += 1
+                    d_pos.add_(pool[pick[k]], alpha=float(sign[k]))
+                    ctx.check(ctx.lib.uf3_eval_centres_dev(
+                        db.handle, C.byref(batch.struct), C.c_void_p(d_pos.data_ptr()), C.c_void_p(d_z.data_ptr()),
+                        _lib._p(calc._c1), _lib._p(calc._c2), _lib._p(calc._c3), lo, hi, C.c_void_p(d_e.data_ptr()),
+                        C.c_void_p(d_f.data_ptr()), C.c_void_p(d_v.data_ptr())))
+                for _ in range(5):
+                    call()
+                torch.cuda.synchronize()
+                s0 = ctx.md_stats()
+                m = 10 * n
+                t0 = time.perf_counter()
+                for _ in range(m):
+                    call()
+                torch.cuda.synchronize()
+                wall = (time.perf_counter() - t0) / m * 1e3
+                s1 = ctx.md_stats()
+                dec_md[f"world_{world}"] = dict(block_atoms=hi - lo, wall_ms=round(wall, 4), steps=m,
+                                                list_builds=s1["builds"] - s0["builds"], steps_repeated=s1["redone"] - s0["redone"])
+        finally:
+            ctx.md_skin(0.0)
+            ctx.restore_stream(prev)
+        out["decomposed_50k_ternary_one_rank_md_route"] = dec_md
 
     # ---- fit accumulation (BASELINE config 4, one GPU's share): frames -> rows -> X^T X / X^T y, rows stay in HBM ---
     if not args.quick:

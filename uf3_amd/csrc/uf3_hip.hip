@@ -111,7 +111,7 @@ struct uf3_ctx {
         std::vector<double> cells;
         std::vector<uint8_t> pbc;
         Buf ent, cnt, pos_ref, geo, frame_of, spec;       // geo: FrameGeom [n_frames] | atom offsets [n_frames + 1]
-        Buf inbox, surv;                                  // see EvalArgs::md_inbox / md_surv
+        Buf inbox, surv, mark;                            // see EvalArgs::md_inbox / md_surv / md_mark
         size_t inbox_zeroed = 0;                          // bytes of inbox known to hold no stamp of a future launch
         size_t geo_bytes = 0;
         long long builds = 0, steps = 0, redone = 0;
@@ -227,7 +227,7 @@ extern "C" void uf3_ctx_destroy(uf3_ctx *c) {
     for (Buf *b : all) b->release();
     for (Buf &b : c->gram_tiles) b.release();
     if (c->comm) uf3_comm_destroy(c);
-    { Buf *mdb[] = {&c->md.ent, &c->md.cnt, &c->md.pos_ref, &c->md.geo, &c->md.frame_of, &c->md.spec, &c->md.inbox, &c->md.surv}; for (Buf *b : mdb) b->release(); }
+    { Buf *mdb[] = {&c->md.ent, &c->md.cnt, &c->md.pos_ref, &c->md.geo, &c->md.frame_of, &c->md.spec, &c->md.inbox, &c->md.surv, &c->md.mark}; for (Buf *b : mdb) b->release(); }
     c->pin_in.release(); c->pin_geo.release(); c->pin_out.release(); c->pin_flags.release();
     for (auto &pd : c->pending_chk) if (pd.ev) hipEventDestroy(pd.ev);
     if (c->pin_in_done) hipEventDestroy(c->pin_in_done);
@@ -1504,9 +1504,15 @@ static int featurize_dev_impl(uf3_basis *b, const uf3_frames *fr, const double *
                             "blocks %d x %d atoms, n_recs %zu, dense nrec %d stage %d\n", launch_mode, lds, lds_plain, lds_recs,
                             (int)recs_lds, cap, A.cand_cap, n_blocks, apb, n_rec_mode, A.dense_nrec, A.dense_stage);
 #define UF3_GRID(n) (((n) + 7) / 8 * 8)      /* whole rounds over the XCDs (surplus workgroups find no atoms) */
+/* (the attribute is set once per instance and context, and again only when a call needs more: host time on an asynchronous path) */ \
 #define UF3_LAUNCH1(E, Fo, R, M, I)                                                                                   \
     do {                                                                                                            \
-        HIPCHK(c, hipFuncSetAttribute((const void *)k_featurize<E, Fo, R, M, I>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        static thread_local std::map<const uf3_ctx *, size_t> lds_set;                                               \
+        size_t &have = lds_set[c];                                                                                  \
+        if (lds > have) {                                                                                           \
+            HIPCHK(c, hipFuncSetAttribute((const void *)k_featurize<E, Fo, R, M, I>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+            have = lds;                                                                                             \
+        }                                                                                                           \
         hipLaunchKernelGGL((k_featurize<E, Fo, R, M, I>), dim3(UF3_GRID(n_blocks)), dim3(WPB * WAVE), lds, st, A);   \
     } while (0)
 #define UF3_LAUNCH(M)                                                                                               \
@@ -1823,7 +1829,7 @@ static int eval_impl(uf3_basis *b, const uf3_frames *fr, const double *d_pos, co
     int rc;
     hipStream_t st = c->stream;
     // MD route: the candidates of every atom from the context's persistent lists instead of a cell-list walk (see md_build)
-    const bool md_step = c->md.skin > 0.0 && fuse && whole && !getenv("UF3_NO_MD");
+    const bool md_step = c->md.skin > 0.0 && fuse && (whole || centres) && !getenv("UF3_NO_MD");     // (a block of centres too: round 5)
     c->md_step = md_step;
     if (md_step) {
         HIPCHK(c, hipSetDevice(c->device));
@@ -1884,8 +1890,8 @@ static int eval_impl(uf3_basis *b, const uf3_frames *fr, const double *d_pos, co
     A.halo_mark = nullptr;
     // (rows of atoms that no centre of the block touches: zero.  A block of centres with the fused list build zeroes rows, list
     // counts and halo marks in ONE launch inside the loop below)
-    const bool zero3 = centres && fuse && !getenv("UF3_NO_HALO");
-    if (centre_share && !whole && d_forces && !zero3)
+    const bool zero3 = centres && fuse && !md_step && !getenv("UF3_NO_HALO");
+    if (centre_share && !whole && d_forces && !zero3 && !md_step)
         HIPCHK(c, hipMemsetAsync(d_forces, 0, 24 * (size_t)P.natoms, st));
     {
         Timed tm(c, T_EVAL);
@@ -1911,6 +1917,15 @@ static int eval_impl(uf3_basis *b, const uf3_frames *fr, const double *d_pos, co
                 HIPCHK(c, c->md.surv.ensure(sizeof(int) * (size_t)P.natoms * A.n3.cap));
                 A.md_inbox = c->md.inbox.as<double>(); A.md_surv = c->md.surv.as<int>();
                 A.md_stamp = (double)c->md.steps;
+                A.md_mark = nullptr; A.md_mark_now = 0;
+                if (centres) {
+                    // marks of the atoms the block's centres write to: zeroed when (re)allocated, launch numbers only grow
+                    const void *before = c->md.mark.p;
+                    HIPCHK(c, c->md.mark.ensure(sizeof(int) * (size_t)P.natoms));
+                    if (c->md.mark.p != before) HIPCHK(c, hipMemsetAsync(c->md.mark.p, 0, c->md.mark.cap, st));
+                    A.md_mark = c->md.mark.as<int>();
+                    A.md_mark_now = (int)(c->md.steps & 0x7fffffff);
+                }
             }
             const size_t cap = (size_t)A.n3.cap;
             // own list (32 + 20 B per entry), queue of bonds, force on the entries (24), walk-order entries + keys (48)
@@ -1922,8 +1937,12 @@ static int eval_impl(uf3_basis *b, const uf3_frames *fr, const double *d_pos, co
             const size_t lds = tab ? lds_tab : lds_plain;
             if ((int)lds > c->lds_max) return fail(c, UF3_EOVERFLOW, "3-body neighbour list does not fit in LDS");
             if (two_pass) {
-                HIPCHK(c, c->nbr_f.ensure(24 * (size_t)P.natoms * cap));
-                A.nbr_f = c->nbr_f.as<double>();
+                if (!md_step) {
+                    HIPCHK(c, c->nbr_f.ensure(24 * (size_t)P.natoms * cap));
+                    A.nbr_f = c->nbr_f.as<double>();
+                }
+                // (a block of centres on the MD route: its halo's rows are sums into zeros -- again on every attempt)
+                if (md_step && centres) HIPCHK(c, hipMemsetAsync(d_forces, 0, 24 * (size_t)P.natoms, st));
                 const int64_t n_centres = atom_end - atom_begin;
                 if (zero3) {
                     HIPCHK(c, c->halo.ensure(sizeof(int) * ((size_t)P.natoms + 4)));
@@ -1932,7 +1951,7 @@ static int eval_impl(uf3_basis *b, const uf3_frames *fr, const double *d_pos, co
                                        (unsigned *)d_forces, 6 * (size_t)P.natoms, (unsigned *)A.n3.cnt, (size_t)P.natoms,
                                        (unsigned *)c->halo.p, (size_t)P.natoms);
                 }
-                else if (centres && fuse) HIPCHK(c, hipMemsetAsync(A.n3.cnt, 0, sizeof(int) * (size_t)P.natoms, st));   // (lists not built: empty)
+                else if (centres && fuse && !md_step) HIPCHK(c, hipMemsetAsync(A.n3.cnt, 0, sizeof(int) * (size_t)P.natoms, st));   // (lists not built: empty)
                 const dim3 eg((unsigned)((n_centres + 7) / 8 * 8));
                 {
                     // instance: strain derivative | list capacity 16 as a constant | candidates from the persistent lists | centre
@@ -1948,13 +1967,15 @@ static int eval_impl(uf3_basis *b, const uf3_frames *fr, const double *d_pos, co
 #undef UF3_EVAL_CASE
                 }
                 if (fuse && deferred_cap) *deferred_cap = (int)cap;
-                if (centres) {
+                if (centres && !md_step) {
                     // the block's lists exist now (this launch built them, or prepare did): the halo's, then the collection
                     // pass over block + halo
                     if (fuse || getenv("UF3_NO_HALO")) { int rh = build_halo_lists(b, P, A.n3, d_pos, (int)atom_begin, (int)atom_end, zero3); if (rh) return rh; }
                     A.halo_mark = c->halo.as<int>();
                 }
-                if (md_step) hipLaunchKernelGGL(k_eval_collect_md, dim3((unsigned)(((P.natoms + 15) / 16 + 7) / 8 * 8)), dim3(256), 0, st, A);
+                if (md_step && centres)      // every atom checks itself; the block and the atoms its centres wrote to collect
+                    hipLaunchKernelGGL(k_eval_collect_md_halo, dim3((unsigned)((P.natoms + 15) / 16)), dim3(256), 0, st, A);
+                else if (md_step) hipLaunchKernelGGL(k_eval_collect_md, dim3((unsigned)(((P.natoms + 15) / 16 + 7) / 8 * 8)), dim3(256), 0, st, A);
                 else hipLaunchKernelGGL(k_eval_collect, dim3((unsigned)(((P.natoms + 15) / 16 + 7) / 8 * 8)), dim3(256), 0, st, A);
             } else if (atom_end > atom_begin) {
                 if (A.virial) hipLaunchKernelGGL((k_eval<true, true>), dim3((unsigned)((atom_end - atom_begin + 7) / 8 * 8)), dim3(64), lds, st, A);
@@ -1963,8 +1984,13 @@ static int eval_impl(uf3_basis *b, const uf3_frames *fr, const double *d_pos, co
             // (one workgroup per frame and component: wide for big frames, the loop is a latency chain)
             const int sum_threads = P.natoms / P.n_frames >= 2048 ? 1024 : 256;
             // (into the caller's pinned block: the launch's last workgroup signals the host itself; flags[12] counts workgroups)
+            // INVARIANT of the polled completion (eval_host returns without hipStreamSynchronize once the sequence number shows):
+            // k_frame_sum is the LAST launch of the call's chain, and its sequence store, behind system-scope fences, the last
+            // access of that chain to pin_in / pin_out -- the next call's memcpy into those blocks relies on it.  Anything queued
+            // behind this launch (a timing event, a second mirror write) must clear `tail_signalled` so that the host waits
+            // for the stream instead.
             unsigned seq = 0;
-            if (mirror && !getenv("UF3_NO_TAIL_SPIN")) {
+            if (mirror && !c->timing && !getenv("UF3_NO_TAIL_SPIN")) {        // (event timing queues a record behind the chain)
                 if (++c->eval_seq == 0) c->eval_seq = 1;
                 seq = c->eval_seq;
                 c->tail_signalled = true;

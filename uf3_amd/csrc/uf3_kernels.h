@@ -2417,6 +2417,8 @@ struct EvalArgs {
                                   // atom's own list position of that neighbour (written by the neighbour's centre pass)
     int *md_surv;                 // [natoms][n3.cap] list position (in the superset list) of each entry of the step's 3-body list
     double md_stamp;              // this launch's stamp: inbox entries with another one are left over from earlier steps
+    int *md_mark;                 // a block of centres (uf3_eval_centres on the MD route): [natoms] number of the last launch whose centres
+    int md_mark_now;              // wrote into the atom's inbox; null: whole batch
     int *md_flags;                // [0] = 1: some atom moved past the hard limit (results invalid, rebuild and repeat); [1] = 1: past the soft one
 };
 
@@ -2934,6 +2936,7 @@ k_eval(EvalArgs A) {
                     typedef double inbox4 __attribute__((ext_vector_type(4)));
                     const inbox4 v = {gx[q], gy[q], gz[q], A.md_stamp};
                     *(inbox4 *)(A.md_inbox + 4 * ((size_t)oparent[q] * A.sup_cap + (rev1 - 1))) = v;
+                    if (A.md_mark) A.md_mark[oparent[q]] = A.md_mark_now;
                 }
             }
         }
@@ -3048,6 +3051,37 @@ k_eval_collect(EvalArgs A) {
 // collection pass of the MD route: atom m adds what its neighbours' centre passes left in its inbox, over the entries of ITS
 // 3-body list in list order (16 lanes, entries strided, one shuffle tree: the order of the additions depends on the step's lists
 // only, not on when the superset lists were built).  An entry whose stamp is not this launch's has no counterpart this step.
+// The same for a block of CENTRES [atom_lo, atom_hi) of a decomposed frame (uf3_eval_centres on the MD route): every atom of the
+// frame checks ITSELF against the lists' reference positions and species (a rank's lists are only good while no atom of the
+// frame -- inside its block or not -- has moved skin / 2), and the atoms a centre of the block has written to this step
+// (md_mark == the launch's number; the block's own atoms always) add what they find in their inbox under this launch's stamp,
+// in the order of their superset lists.  Rows of all other atoms stay zero.
+__global__ void __launch_bounds__(256)
+k_eval_collect_md_halo(EvalArgs A) {
+    const int m = (int)blockIdx.x * 16 + (threadIdx.x >> 4), sub = threadIdx.x & 15;
+    if (m >= A.natoms) return;
+    const bool own = m >= A.atom_lo && m < A.atom_hi;
+    if (sub == 0 && !own) {                        // (the block's atoms have checked themselves in the centre pass)
+        const double ux = A.pos[3 * (size_t)m] - A.pos_ref[3 * (size_t)m], uy = A.pos[3 * (size_t)m + 1] - A.pos_ref[3 * (size_t)m + 1],
+                     uz = A.pos[3 * (size_t)m + 2] - A.pos_ref[3 * (size_t)m + 2];
+        const double moved = ux * ux + uy * uy + uz * uz;
+        const int zz = A.z_now[m];
+        const bool other_species = zz < 0 || zz >= 120 || A.B->z2s[zz] != A.spec[m];
+        if (!(moved <= A.md_hard2) || other_species) A.md_flags[0] = 1;
+        if (!(moved <= A.md_soft2)) A.md_flags[1] = 1;
+    }
+    if (!own && A.md_mark[m] != A.md_mark_now) return;
+    const int n = min(A.sup_cnt[m], A.sup_cap);
+    double sx = 0.0, sy = 0.0, sz = 0.0;
+    for (int q = sub; q < n; q += 16) {
+        typedef double inbox4 __attribute__((ext_vector_type(4)));
+        const inbox4 v = *(const inbox4 *)(A.md_inbox + 4 * ((size_t)m * A.sup_cap + q));
+        if (v[3] == A.md_stamp) { sx += v[0]; sy += v[1]; sz += v[2]; }
+    }
+    for (int sh = 8; sh > 0; sh >>= 1) { sx += __shfl_xor(sx, sh, 16); sy += __shfl_xor(sy, sh, 16); sz += __shfl_xor(sz, sh, 16); }
+    if (sub == 0) { double *f = A.forces + 3 * (size_t)m; f[0] += sx; f[1] += sy; f[2] += sz; }
+}
+
 __global__ void __launch_bounds__(256)
 k_eval_collect_md(EvalArgs A) {
     const int wg = (int)((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3));

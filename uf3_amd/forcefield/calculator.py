@@ -154,6 +154,8 @@ class UFCalculator(_Base):
         what ``parallel.sharded_evaluate`` reduces).
         """
         ctx = _lib.get_context(self.device)
+        if getattr(ctx, "_md_skin", 0.0) != self.md_skin:
+            ctx.md_skin(self.md_skin)             # (with a skin the ranks' whole-frame lists live across steps, DESIGN section 6)
         db = _lib.device_basis(self.bspline_config, ctx)
         batch = _lib.FrameBatch([atoms])
         e = np.empty(1)
