@@ -676,6 +676,33 @@ def test_lists_too_long_for_the_bond_factorised_launch_fall_back():
     assert rel_err(xe_d, xe_g) < 1e-11 and rel_err(xf_d, xf_g) < 1e-11
 
 
+@pytest.mark.parametrize("lattice,a,r3,want", [("fcc", 3.9, 4.0, 18), ("bcc", 3.165, 4.6, 26)])
+def test_bond_factorised_launch_at_list_capacities_24_and_32(lattice, a, r3, want, monkeypatch):
+    """k_featurize3 has the list capacity as a compile-time constant at 16, 24 and 32 (16 alone was tuned to the
+    bench cells): an fcc cell with 18 and a bcc cell with 26 three-body neighbours per atom settle on 24 and 32 -- the tuned
+    calls against the oracle and against the first call, which ran the generic instance at the estimated capacity."""
+    cs = synthetic.composition.ChemicalSystem(['Mo', 'W'], 3)
+    pairs, trios = cs.interactions_map[2], cs.interactions_map[3]
+    basis = synthetic.bspline.BSplineBasis(
+        cs, r_min_map={**{p: 0.001 for p in pairs}, **{t: [1.5, 1.5, 1.5] for t in trios}},
+        r_max_map={**{p: 5.5 for p in pairs}, **{t: [r3, r3, 2 * r3] for t in trios}},
+        resolution_map={**{p: 15 for p in pairs}, **{t: [6, 6, 12] for t in trios}}, leading_trim={2: 0, 3: 3}, trailing_trim={2: 3, 3: 3})
+    frames = [synthetic.lattice_frame(lattice, (4, 4, 4), a, [42, 74], seed=70 + k, rattle=0.03, strain=0.0) for k in range(2)]
+    monkeypatch.setattr(_lib, "_contexts", {})                    # (a context of its own: capacities are a context's grow-only memory)
+    fz = process.BasisFeaturizer(basis)
+    assert fz._dev()[1].featurizer_modes & 0x1000
+    _, n3 = fz.neighbor_indices(frames[0])
+    assert np.bincount(n3[:, 0]).max() == want
+    ob = O.OracleBasis(basis)
+    first = fz.featurize_frames(frames)                           # (at the estimated capacity: the generic instance)
+    x_e, x_f, off = fz.featurize_frames(frames)                   # (at the tuned capacity: the instance with the constant)
+    for k, atoms in enumerate(frames):
+        ref = O.featurize(ob, atoms)
+        assert rel_err(x_e[k], ref["xe"]) < TOL and rel_err(x_f[off[k]:off[k + 1]], ref["xf"]) < TOL
+    assert rel_err(first[1], x_f) < 1e-13 and rel_err(first[0], x_e) < 1e-13
+    _lib.drop_device_basis(basis)
+
+
 def test_three_species_wide_blocks():
     """ternary, lead 0: 18 trio blocks of 139/233 columns (several 64-column chunks, nsrc 1 and 2)."""
     d, meta, atoms = load_case("case_ternary24_slab")

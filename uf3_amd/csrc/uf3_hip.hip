@@ -1583,7 +1583,13 @@ static int featurize_dev_impl(uf3_basis *b, const uf3_frames *fr, const double *
 #define UF3_F3_LAUNCH(E, EFv, NRv)                                                                                          \
     do { if (cap == 16 && !c->env_f3_no_cap16) UF3_F3_LAUNCH1(E, EFv, NRv, 16); else UF3_F3_LAUNCH1(E, EFv, NRv, 0); } while (0)
                 switch (ep) {
-                    case 3: if (want_e) UF3_F3_LAUNCH(true, 3, 1); else UF3_F3_LAUNCH(false, 3, 1); break;
+                    case 3:      // (the default trims: the list capacity as a constant also at 24 and 32 -- fcc and denser cells)
+                        if ((cap == 24 || cap == 32) && !c->env_f3_no_cap16) {
+                            if (cap == 24) { if (want_e) UF3_F3_LAUNCH1(true, 3, 1, 24); else UF3_F3_LAUNCH1(false, 3, 1, 24); }
+                            else { if (want_e) UF3_F3_LAUNCH1(true, 3, 1, 32); else UF3_F3_LAUNCH1(false, 3, 1, 32); }
+                        }
+                        else if (want_e) UF3_F3_LAUNCH(true, 3, 1); else UF3_F3_LAUNCH(false, 3, 1);
+                        break;
                     case 4: if (want_e) UF3_F3_LAUNCH(true, 4, 2); else UF3_F3_LAUNCH(false, 4, 2); break;
                     case 5: if (want_e) UF3_F3_LAUNCH(true, 5, 3); else UF3_F3_LAUNCH(false, 5, 3); break;
                     default: if (want_e) UF3_F3_LAUNCH(true, 6, 3); else UF3_F3_LAUNCH(false, 6, 3); break;
