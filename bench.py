@@ -735,13 +735,15 @@ def extra_eval_50k(torch, dev, cpu=True, steps=200, warmup=20):
     order = np.random.default_rng(17).integers(0, 64, 1 << 16)
     signs = np.random.default_rng(18).choice([-1.0, 1.0], 1 << 16)
     counter = [0]
+    fields = [pool[i] for i in range(64)]                                   # (views made once: the step's host time is the GPU's idle time)
+    alphas = [float(x) for x in signs]
     prev = ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)      # (the walk runs on torch's stream: one order of events)
     ctx.md_skin(MD_SKIN)
 
     def step():
-        k = counter[0]
+        k = counter[0] & 0xffff
         counter[0] += 1
-        d_pos.add_(pool[order[k & 0xffff]], alpha=float(signs[k & 0xffff]))
+        d_pos.add_(fields[order[k]], alpha=alphas[k])
         ctx.check(ctx.lib.uf3_eval_dev(db.handle, C.byref(batch.struct), C.c_void_p(d_pos.data_ptr()),
                                        C.c_void_p(d_z.data_ptr()), _lib._p(calc._c1), _lib._p(calc._c2), _lib._p(calc._c3),
                                        C.c_void_p(d_e.data_ptr()), C.c_void_p(d_f.data_ptr())))

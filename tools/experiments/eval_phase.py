@@ -20,7 +20,8 @@ buf = (ctypes.c_ulonglong * 16)()
 ctx.lib.uf3_debug_phase(buf)
 calc.evaluate_frames([atoms])
 ctx.lib.uf3_debug_phase(buf)
-names = {10: "candidate walk + pair splines", 11: "3-body list (sort, store, LDS copy)", 12: "triplets", 13: "forces on the list entries -> HBM"}
+names = {9: "candidate walk (MD route: list filter)", 10: "pair splines of the last batch", 11: "3-body list (sort, store, LDS copy)",
+         14: "per-bond leg tables, knot records to LDS (TAB)", 12: "triplets", 13: "forces on the list entries -> HBM / inbox", 15: "wave sums, stores"}
 tot = sum(buf[i] for i in names)
 for i, n in names.items():
     print(f"{n:44s} {buf[i]:>14d} {100.0 * buf[i] / tot:5.1f}%")

@@ -2634,12 +2634,39 @@ k_eval(EvalArgs A) {
     int m = A.atom_lo + (int)((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3));
     if (m >= A.atom_hi) return;
     int lane = lane_id();
-    const FrameGeom g = A.geoms[A.frame_of[m]];
-    const int sm = A.spec[m];
+    // (MD route: what belongs to the atom is the same for all lanes -- through scalar loads, the frame's cell included: vector
+    // loads of them were a chain of dependent round trips in front of the list filter, and the cell sat in 18 vector registers)
+    FrameGeom g;
+    if (MD) {
+        const int fidx = load_const(A.frame_of + m);
+        for (int k = 0; k < 9; k++) g.cell[k] = load_const(&A.geoms[fidx].cell[k]);
+    } else
+        g = A.geoms[A.frame_of[m]];
+    const int sm = ((const __attribute__((address_space(4))) signed char *)(unsigned long long)A.spec)[m];
     const bool want_f = A.forces != nullptr, want_v = VIR && A.virial != nullptr;   // (VIR: compiled out of the usual launches)
     double vir[6] = {0, 0, 0, 0, 0, 0};
-    double pm[3] = {A.pos[3 * (size_t)m], A.pos[3 * (size_t)m + 1], A.pos[3 * (size_t)m + 2]};
+    double pm[3];
+    if (MD) { pm[0] = load_const(A.pos + 3 * (size_t)m); pm[1] = load_const(A.pos + 3 * (size_t)m + 1); pm[2] = load_const(A.pos + 3 * (size_t)m + 2); }
+    else { pm[0] = A.pos[3 * (size_t)m]; pm[1] = A.pos[3 * (size_t)m + 1]; pm[2] = A.pos[3 * (size_t)m + 2]; }
     double e = 0.0, fx = 0.0, fy = 0.0, fz = 0.0;
+    // TAB instances: what the triplet loop needs of the basis -- the legs of trio 0, the species -> trio and trio -> grid offset
+    // tables (one register each), leg n's knot records into LDS -- is requested HERE, ahead of the pair phase that hides it
+    KnotRec *kn_lds = (KnotRec *)(smem + ((((unsigned char *)(ushift + cap) - smem) + 15) & ~(size_t)15));
+    int trio_tab = -1, lut_tab = 0;
+    if (TAB && !GATHER) {
+        // (the legs' descriptors themselves are scalar loads, read again where they are used: held from here they cost ~40 of
+        // the scalar registers the kernel is short of)
+        const TrioDev *t0 = load_const(&B->trios);
+        const int n_rec_off = load_const(&t0->leg[2].rec_off), n_nk = load_const(&t0->leg[2].nk);
+        trio_tab = B->trio_of[sm * UF3_MAX_SPECIES * UF3_MAX_SPECIES + lane];
+        typedef const __attribute__((address_space(1))) TrioDev *GlobalTrio;
+        if (lane < load_const(&B->T)) lut_tab = ((GlobalTrio)t0)[lane].lut_off;
+        // leg n's knot records (intervals 3 .. nk - 5) into LDS: 96 bytes per triplet less through the vector memory path,
+        // which bounds this kernel (the coefficient rows stay there: 512 bytes per triplet)
+        const int4 *src = (const int4 *)(recs_g + n_rec_off + 3);
+        int4 *dst = (int4 *)kn_lds;
+        for (int q = lane; q < (n_nk - 7) * 6; q += WAVE) dst[q] = src[q];
+    }
     PhaseClock pce;                   // (-DUF3_PHASE_TIMING builds only: tools/experiments/eval_phase.py)
     if (lane == 0) e = A.c1[sm];
     // 2-body: bonds inside their pair's range are queued in LDS and evaluated 64 at a time (about one candidate in
@@ -2674,16 +2701,17 @@ k_eval(EvalArgs A) {
     if (MD) {
         // the lists are valid while no atom has moved more than skin / 2 since they were built, and for the species they were built for
         {
-            const double ux0 = pm[0] - A.pos_ref[3 * (size_t)m], uy0 = pm[1] - A.pos_ref[3 * (size_t)m + 1], uz0 = pm[2] - A.pos_ref[3 * (size_t)m + 2];
+            const double ux0 = pm[0] - load_const(A.pos_ref + 3 * (size_t)m), uy0 = pm[1] - load_const(A.pos_ref + 3 * (size_t)m + 1),
+                         uz0 = pm[2] - load_const(A.pos_ref + 3 * (size_t)m + 2);
             const double moved = ux0 * ux0 + uy0 * uy0 + uz0 * uz0;
-            const int zz = A.z_now[m];
+            const int zz = load_const(A.z_now + m);
             const bool other_species = zz < 0 || zz >= 120 || B->z2s[zz] != sm;
             if (lane == 0) {
                 if (!(moved <= A.md_hard2) || other_species) A.md_flags[0] = 1;
                 if (!(moved <= A.md_soft2)) A.md_flags[1] = 1;
             }
         }
-        const int n_sup = min(A.sup_cnt[m], A.sup_cap);
+        const int n_sup = min(load_const(A.sup_cnt + m), A.sup_cap);
         const SupEntry *sup = A.sup_ent + (size_t)m * A.sup_cap;
         const size_t base3 = (size_t)m * cap;
         for (int q0 = 0; q0 < n_sup; q0 += WAVE) {
@@ -2785,6 +2813,7 @@ k_eval(EvalArgs A) {
             __builtin_amdgcn_wave_barrier();
         }
     });
+    pce.lap(9);                       // (MD route: the list filter; else the candidate walk with its full pair batches)
     drain(queued);
     pce.lap(10);
     if (load_const(&B->T) > 0) {
@@ -2831,7 +2860,6 @@ k_eval(EvalArgs A) {
         // the pair walk, which is done with); the species -> trio and trio -> grid offset tables in one register each, looked up
         // with lane shuffles instead of two dependent loads
         const bool tab_path = TAB && !GATHER && n_pairs > 0;
-        KnotRec *kn_lds = (KnotRec *)(smem + ((((unsigned char *)(ushift + cap) - smem) + 15) & ~(size_t)15));
         // (the per-bond tables over the queue of the pair walk, which is done with; lists longer than EVAL_TAB_CAP: behind the knot
         // records -- the choice of the instance must not depend on the capacity, or a context's first call, at the estimated
         // capacity, would differ from the later ones in the last bit)
@@ -2839,26 +2867,16 @@ k_eval(EvalArgs A) {
         double *tlv = cap <= EVAL_TAB_CAP ? queue : (double *)(kn_lds + EVAL_TAB_KN), *tmv = tlv;
         int *tli = (int *)(tlv + 16 * ts), *tmi = tli;
         LegDev leg_n, leg_n_lds;
-        int tab_dim_m = 0, tab_dim_n = 0, trio_tab = -1, lut_tab = 0;
+        int tab_dim_m = 0, tab_dim_n = 0;
         if (tab_path) {
             const TrioDev *t0 = load_const(&B->trios);
             const LegDev l0 = load_const(&t0->leg[0]), l1 = load_const(&t0->leg[1]);
             leg_n = load_const(&t0->leg[2]);
             tab_dim_m = load_const(&t0->dim_m); tab_dim_n = load_const(&t0->dim_n);
-            const bool same01 = l0.rec_off == l1.rec_off && l0.nk == l1.nk;
-            if (!same01) { tmv = tlv + 8 * ts; tmi = tli + ts; }
-            trio_tab = B->trio_of[sm * UF3_MAX_SPECIES * UF3_MAX_SPECIES + lane];
-            typedef const __attribute__((address_space(1))) TrioDev *GlobalTrio;
-            if (lane < load_const(&B->T)) lut_tab = ((GlobalTrio)t0)[lane].lut_off;
-            // leg n's knot records (intervals 3 .. nk - 5) into LDS: 96 bytes per triplet less through the vector memory path,
-            // which bounds this kernel (the coefficient rows stay there: 512 bytes per triplet)
-            {
-                const int4 *src = (const int4 *)(recs_g + leg_n.rec_off + 3);
-                int4 *dst = (int4 *)kn_lds;
-                for (int q = lane; q < (leg_n.nk - 7) * 6; q += WAVE) dst[q] = src[q];
-            }
             leg_n_lds = leg_n;
             leg_n_lds.rec_off = -3;                      // (interval i of the copy: kn_lds[i - 3])
+            const bool same01 = l0.rec_off == l1.rec_off && l0.nk == l1.nk;
+            if (!same01) { tmv = tlv + 8 * ts; tmi = tli + ts; }
             for (int q = lane; q < n; q += WAVE) {
                 const double r = orr[q];
                 for (int which = 0; which < (same01 ? 1 : 2); which++) {
@@ -2877,6 +2895,7 @@ k_eval(EvalArgs A) {
             }
             __syncthreads();
         }
+        pce.lap(14);
 #pragma unroll 1
         for (int p0 = 0; p0 < n_pairs; p0 += WAVE) {      // (not unrolled: two triplets' loads in flight per lane do not fit the registers)
             const bool act = p0 + lane < n_pairs;
@@ -2996,6 +3015,7 @@ k_eval(EvalArgs A) {
         fx = wave_sum(fx); fy = wave_sum(fy); fz = wave_sum(fz);
         if (lane == 0) { A.forces[3 * (size_t)m] = fx; A.forces[3 * (size_t)m + 1] = fy; A.forces[3 * (size_t)m + 2] = fz; }
     }
+    pce.lap(15);
 }
 
 // second pass of the two-pass evaluator: 16 lanes per atom m; for every entry (centre c, image shift s) of m's list the
