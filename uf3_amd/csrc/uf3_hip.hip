@@ -1748,7 +1748,7 @@ static int md_build(uf3_basis *b, const uf3_frames *fr, const double *d_pos, con
         md.cap = (fl[5] + 8 + 7) / 8 * 8;
     }
     hipLaunchKernelGGL(k_sup_reverse, dim3((unsigned)(((natoms + 15) / 16 + 7) / 8 * 8)), dim3(256), 0, st, md.ent.as<SupEntry>(),
-                       (const int *)md.cnt.as<int>(), md.cap, natoms);
+                       (const int *)md.cnt.as<int>(), md.cap, natoms, P.geoms, P.frame_of, P.spec);
     HIPCHK(c, hipGetLastError());
     // inbox of every (atom, list position): zeroed when (re)allocated -- stamps start at 1
     {

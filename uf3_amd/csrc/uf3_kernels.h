@@ -519,29 +519,36 @@ k_build_sup(const BasisDev *B, const FrameGeom *geoms, const int *frame_of, Cell
 // radius may round differently).  What a step's centre pass needs to hand a neighbour its share of the triplet forces directly
 // (k_eval<MD>: md_inbox) instead of leaving it to be looked for (k_eval_collect).  16 lanes per atom.
 __global__ void __launch_bounds__(256)
-k_sup_reverse(SupEntry *ent, const int *cnt, int cap, int natoms) {
+k_sup_reverse(SupEntry *ent, const int *cnt, int cap, int natoms, const FrameGeom *geoms, const int *frame_of, const signed char *spec) {
     const int wg = (int)((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3));
     const int m = wg * 16 + (threadIdx.x >> 4), sub = threadIdx.x & 15;
     if (m >= natoms) return;
     const int n = min(cnt[m], cap);
+    const FrameGeom &g = geoms[frame_of[m]];
+    const int sm = spec[m], m_local = m - g.atom_lo;
     for (int q = sub; q < n; q += 16) {
         SupEntry *mine = ent + (size_t)m * cap + q;
         const int j = mine->parent;
         int s0, s1, s2;
         unpack3(mine->shiftc, s0, s1, s2);
+        // the neighbour's list is sorted by (species, supercell index): m at the opposite shift has a known key there -- a
+        // binary search (six probes) instead of a scan of the list (58 entries: 1.3 GB of reads per build at 50 k atoms)
         const int back = pack3(-s0, -s1, -s2), nj = min(cnt[j], cap);
+        const long long want = ((long long)sm << 32) | (unsigned)supercell_index(g, -s0, -s1, -s2, m_local);
         const SupEntry *theirs = ent + (size_t)j * cap;
-        int hit = -1;
-        for (int r0 = 0; r0 < nj; r0 += 8) {               // eight entries' keys in flight together (a plain loop waits for each)
-            int2 key[8];
-#pragma unroll
-            for (int u = 0; u < 8; u++) key[u] = *(const int2 *)&theirs[min(r0 + u, nj - 1)].parent;
-            asm volatile("" ::: "memory");
-#pragma unroll
-            for (int u = 0; u < 8; u++)
-                if (r0 + u < nj && key[u].x == m && key[u].y == back) hit = r0 + u;
+        int lo = 0, hi = nj;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            const int2 k = *(const int2 *)&theirs[mid].sidx;                      // (sidx, spec | position bits written by other lanes: the species byte is stable)
+            const long long key = ((long long)(k.y & 0xff) << 32) | (unsigned)k.x;
+            if (key < want) lo = mid + 1; else hi = mid;
         }
-        mine->spec = (mine->spec & 0xff) | ((hit + 1) << 8);      // (the species byte is all the scan of other lanes' entries reads... it reads parent | shiftc only)
+        int hit = -1;
+        if (lo < nj) {
+            const int2 id = *(const int2 *)&theirs[lo].parent;
+            if (id.x == m && id.y == back) hit = lo;
+        }
+        mine->spec = (mine->spec & 0xff) | ((hit + 1) << 8);
     }
 }
 
