@@ -96,6 +96,7 @@ struct uf3_ctx {
     size_t pin_in_pending = 0;          // small batch: bytes of positions | species waiting in pin_in; the cell-list
                                         // stage appends the frame geometry and sends everything in ONE copy
     PinBuf pin_in, pin_geo, pin_out;    // positions + species | frame geometry + offsets | results
+    PinBuf pin_eval;                    // device-resident evaluator calls: status words [4] | sequence number, written by the last kernel
     hipEvent_t pin_in_done = nullptr, pin_geo_done = nullptr;   // the copies out of pin_in / pin_geo have executed
     std::vector<double> coeff_shadow;   // host copy of the model last uploaded by uf3_eval (c1 | c2 | c3)
     const void *coeff_dev = nullptr;    // ... and where it lives
@@ -228,7 +229,7 @@ extern "C" void uf3_ctx_destroy(uf3_ctx *c) {
     for (Buf &b : c->gram_tiles) b.release();
     if (c->comm) uf3_comm_destroy(c);
     { Buf *mdb[] = {&c->md.ent, &c->md.cnt, &c->md.pos_ref, &c->md.geo, &c->md.frame_of, &c->md.spec, &c->md.inbox, &c->md.surv, &c->md.mark}; for (Buf *b : mdb) b->release(); }
-    c->pin_in.release(); c->pin_geo.release(); c->pin_out.release(); c->pin_flags.release();
+    c->pin_in.release(); c->pin_geo.release(); c->pin_out.release(); c->pin_flags.release(); c->pin_eval.release();
     for (auto &pd : c->pending_chk) if (pd.ev) hipEventDestroy(pd.ev);
     if (c->pin_in_done) hipEventDestroy(c->pin_in_done);
     if (c->pin_geo_done) hipEventDestroy(c->pin_geo_done);
@@ -2001,15 +2002,38 @@ static int eval_impl(uf3_basis *b, const uf3_frames *fr, const double *d_pos, co
                 seq = c->eval_seq;
                 c->tail_signalled = true;
             }
+            // a device-resident call that looks at its status words before it returns (the fused list build, the MD route): the
+            // last kernel puts them, and the call's sequence number behind them, into a pinned block the host polls -- no copy
+            // of 16 bytes through the runtime's staging and no wait for the stream's completion signal (~10 us of an MD step)
+            int *flags_host = nullptr;
+            unsigned *seq_host = nullptr;
+            if (!mirror && !flags_tail && fuse && !deferred_cap && !c->timing && !getenv("UF3_NO_TAIL_SPIN")) {
+                HIPCHK(c, c->pin_eval.ensure(64));
+                flags_host = (int *)c->pin_eval.p; seq_host = (unsigned *)c->pin_eval.p + 4;
+                if (++c->eval_seq == 0) c->eval_seq = 1;
+                seq = c->eval_seq;
+            }
             hipLaunchKernelGGL(k_frame_sum, dim3(P.n_frames, d_virials ? 7 : 1), dim3(sum_threads), 0, st, A.e_atom,
-                               A.virial, P.d_offsets, d_energies, d_virials, (const int *)c->flags.as<int>(), flags_tail,
-                               mirror, (const double *)d_forces, d_forces ? 3 * P.natoms : 0, (int)atom_begin, (int)atom_end, seq, c->flags.as<int>() + 12);
+                               A.virial, P.d_offsets, d_energies, d_virials, (const int *)c->flags.as<int>(), flags_host ? flags_host : flags_tail,
+                               mirror, (const double *)d_forces, d_forces ? 3 * P.natoms : 0, (int)atom_begin, (int)atom_end, seq, c->flags.as<int>() + 12,
+                               seq_host);
             if (fuse && !deferred_cap) {
                 // the lists were part of this launch: did they fit?  (Asked after everything is queued -- all kernels
                 // are safe on clipped lists -- so that the GPU does not idle while the host looks.)
                 int fl[4] = {0, 0, 0, 0};
-                HIPCHK(c, hipMemcpyAsync(fl, c->flags.p, sizeof(fl), hipMemcpyDeviceToHost, st));
-                HIPCHK(c, hipStreamSynchronize(st));
+                bool arrived = false;
+                if (seq_host) {
+                    const auto t_end = std::chrono::steady_clock::now() + std::chrono::milliseconds(2);
+                    for (int spin = 0; !arrived; spin++) {
+                        arrived = __atomic_load_n(seq_host, __ATOMIC_ACQUIRE) == seq;
+                        if (!arrived && (spin & 255) == 255 && std::chrono::steady_clock::now() > t_end) break;
+                    }
+                    if (!arrived) HIPCHK(c, hipStreamSynchronize(st));
+                    std::memcpy(fl, flags_host, sizeof(fl));
+                } else {
+                    HIPCHK(c, hipMemcpyAsync(fl, c->flags.p, sizeof(fl), hipMemcpyDeviceToHost, st));
+                    HIPCHK(c, hipStreamSynchronize(st));
+                }
                 if (fl[0]) return check_flags(c);
                 if (md_step && fl[2]) {
                     // an atom beyond skin / 2 of where the lists were built (or of another species): the results are void --

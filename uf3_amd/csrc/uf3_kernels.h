@@ -3163,7 +3163,7 @@ __device__ __forceinline__ double frame_sum_tree(const double *src, int width, i
 
 __global__ void k_frame_sum(const double *e_atom, const double *v_atom, const int64_t *atom_offsets, double *e_out,
                             double *v_out, const int *flags_src, int *flags_dst, double *mirror, const double *forces,
-                            int n_force, int a_lo, int a_hi, unsigned seq, int *tail_count) {
+                            int n_force, int a_lo, int a_hi, unsigned seq, int *tail_count, unsigned *seq_dst) {
     __shared__ double part[1024];
     const int f = blockIdx.x, comp = (int)blockIdx.y - 1;
     if (flags_dst && f == 0 && comp < 0 && threadIdx.x < 4) flags_dst[threadIdx.x] = flags_src[threadIdx.x];
@@ -3192,7 +3192,8 @@ __global__ void k_frame_sum(const double *e_atom, const double *v_atom, const in
             last = n_blocks == 1 || atomicAdd(tail_count, 1) == n_blocks - 1;
             if (last) {
                 if (n_blocks > 1) { *tail_count = 0; __threadfence_system(); }
-                __hip_atomic_store((unsigned *)(mirror + 7 * (size_t)gridDim.x + n_force) + 4, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                // (seq_dst: a device-resident call -- only the status words and this number go to the host's pinned block)
+                __hip_atomic_store(seq_dst ? seq_dst : (unsigned *)(mirror + 7 * (size_t)gridDim.x + n_force) + 4, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
             }
         }
     }
