@@ -973,6 +973,58 @@ def test_blocks_of_centres_on_the_md_route_add_up_to_the_frame():
     ctx.md_skin(0.0)
 
 
+@pytest.mark.parametrize("case", ["tiny_cell", "slab", "cluster", "ragged_batch", "triclinic"])
+def test_md_route_on_small_cells_slabs_clusters_and_batches(case):
+    """The MD route where a list holds several images of one neighbour (a 16-atom cell, 6.3 A across, against r_cut + skin = 5.9 A),
+    with open boundaries (slab, cluster), on a skewed cell and on a batch of frames of different sizes: a short walk, every step
+    against the oracle and the plain route, lists reused across steps."""
+    rng = np.random.default_rng(12)
+    els, nums = ['Mo', 'W'], [42, 74]
+    basis = synthetic.notebook_basis(els)
+    model, coeff = _random_model(basis, 24)
+    calc_md = calculator.UFCalculator(model, md_skin=0.4)
+    calc_plain = calculator.UFCalculator(model, md_skin=0.0)
+    if case == "tiny_cell":
+        frames = [synthetic.lattice_frame("bcc", (2, 2, 2), 3.165, nums, seed=81)]
+    elif case == "slab":
+        a = synthetic.lattice_frame("bcc", (4, 4, 3), 3.165, nums, seed=82)
+        frames = [Atoms(numbers=a.get_atomic_numbers(), positions=a.get_positions(), cell=a.get_cell(), pbc=[True, True, False])]
+    elif case == "cluster":
+        a = synthetic.lattice_frame("bcc", (3, 3, 3), 3.165, nums, seed=83)
+        frames = [Atoms(numbers=a.get_atomic_numbers(), positions=a.get_positions(), cell=a.get_cell(), pbc=False)]
+    elif case == "triclinic":
+        a = synthetic.lattice_frame("bcc", (3, 3, 3), 3.165, nums, seed=84)
+        shear = np.eye(3) + np.array([[0, 0.18, 0.07], [0, 0, -0.12], [0, 0, 0]])
+        frames = [Atoms(numbers=a.get_atomic_numbers(), positions=a.get_positions() @ shear, cell=np.asarray(a.get_cell()) @ shear, pbc=True)]
+    else:
+        frames = [synthetic.lattice_frame("bcc", r, 3.165, nums, seed=85 + k) for k, r in enumerate(((3, 3, 3), (2, 2, 2), (4, 3, 3)))]
+    ctx = _lib.get_context(None)
+    for _ in range(2):
+        calc_plain.evaluate_frames(frames)
+    ob = O.OracleBasis(basis)
+    ctx.md_skin(0.0)
+    s0 = ctx.md_stats()
+    trace, path = [], []
+    for step in range(8):
+        frames = [Atoms(numbers=f.get_atomic_numbers(), positions=f.get_positions() + rng.uniform(-0.03, 0.03, (len(f), 3)),
+                        cell=f.get_cell(), pbc=f.get_pbc()) for f in frames]
+        path.append(frames)
+        trace.append(calc_md.evaluate_frames(frames, virial=step % 2 == 1))
+    s1 = ctx.md_stats()
+    assert s1["steps"] - s0["steps"] >= 8 and 1 <= s1["builds"] - s0["builds"] < 8
+    for step, frames in enumerate(path):
+        got = trace[step]
+        plain = calc_plain.evaluate_frames(frames, virial=step % 2 == 1)
+        assert np.allclose(got[0], plain[0], rtol=1e-12, atol=1e-12) and rel_err(got[1], plain[1]) < 1e-12
+        if step % 2 == 1:
+            assert rel_err(got[3], plain[3]) < 1e-11
+        off = got[2]
+        for k, f in enumerate(frames):
+            e_o, f_o = O.evaluate(ob, f, coeff)
+            assert abs(got[0][k] - e_o) <= 1e-11 * max(1.0, abs(e_o)) and worst_elementwise(got[1][off[k]:off[k + 1]], f_o, 1e-9) <= 1.0
+    ctx.md_skin(0.0)
+
+
 def test_md_route_rebuilds_on_layout_species_and_cell_changes():
     """The lists are tied to (basis, offsets, cells, pbc, species): any change rebuilds them instead of serving stale neighbours;
     a batch of several frames runs on lists as well.  Each result against the plain route."""
