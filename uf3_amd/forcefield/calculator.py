@@ -58,20 +58,29 @@ def coefficients_by_interaction(element_list, interactions_map, partition_sizes,
     return solutions
 
 
+AUTO_MD_SKIN = 0.5        # Angstrom: the skin of ``md_skin="auto"``
+
+
 class UFCalculator(_Base):
     implemented_properties = ['energy', 'forces', 'stress']
 
     def __init__(self, model, device=None, md_skin=None, **kwargs):
         """``md_skin`` (Angstrom): keep the device's neighbour lists between calls out to ``r_cut + md_skin`` and rebuild them
         only when an atom has moved more than ``md_skin / 2`` (``_lib.Context.md_skin``) -- what an MD or relaxation loop
-        wants; 0 rebuilds everything on every call like the reference (``calculator.py:124-153``).  Default: the
-        environment's ``UF3_MD_SKIN``, else 0."""
+        wants; 0 rebuilds everything on every call like the reference (``calculator.py:124-153``).  Default (``None``): the
+        environment's ``UF3_MD_SKIN`` if set, else ``"auto"`` -- a skin of 0.5 Angstrom from the second consecutive call on
+        the same single frame (atom count, cell, boundary conditions) on, nothing kept for one-off calls on changing structures.
+        Results do not depend on the setting beyond rounding (1e-13), nor on when the lists were built."""
         super().__init__(**kwargs)
         self.bspline_config = model.bspline_config
         self.model = model
         self.device = device
-        self.md_skin = float(os.environ.get("UF3_MD_SKIN", 0.0)) if md_skin is None else float(md_skin)
+        if md_skin is None:
+            md_skin = os.environ.get("UF3_MD_SKIN", "auto")
+        self.md_auto = isinstance(md_skin, str) and md_skin.strip().lower() == "auto"
+        self.md_skin = AUTO_MD_SKIN if self.md_auto else float(md_skin)
         self._last_batch = None
+        self._last_layout = None
         basis = self.bspline_config
         self.solutions = coefficients_by_interaction(basis.element_list, basis.interactions_map,
                                                      basis.partition_sizes, model.coefficients)
@@ -104,14 +113,20 @@ class UFCalculator(_Base):
     def evaluate_frames(self, atoms_list, forces=True, virial=False):
         """Energies [n_frames], forces [sum N, 3] (and dE/d(strain) [n_frames, 6]) of a batch of frames."""
         ctx = _lib.get_context(self.device)
-        if getattr(ctx, "_md_skin", 0.0) != self.md_skin:
-            ctx.md_skin(self.md_skin)
         db = _lib.device_basis(self.bspline_config, ctx)
         # (an MD loop hands over the same single frame again and again: its batch is kept and refreshed in place)
         batch = self._last_batch
         if len(atoms_list) != 1 or batch is None or not batch.refresh(atoms_list[0]):
             batch = _lib.FrameBatch(atoms_list)
             self._last_batch = batch if len(atoms_list) == 1 else None
+        skin = self.md_skin
+        if self.md_auto:        # lists are worth keeping once the same single frame comes back
+            layout = (batch.n_atoms, batch.cells.tobytes(), batch.pbc.tobytes()) if batch.n_frames == 1 else None
+            if layout is None or layout != self._last_layout:
+                skin = 0.0
+            self._last_layout = layout
+        if getattr(ctx, "_md_skin", 0.0) != skin:
+            ctx.md_skin(skin)
         e = np.empty(batch.n_frames)
         f = np.empty((batch.n_atoms, 3)) if forces else None
         addr = _lib._addr                     # (plain ints: the host side of an MD-step call is as long as its kernels)
@@ -154,8 +169,9 @@ class UFCalculator(_Base):
         what ``parallel.sharded_evaluate`` reduces).
         """
         ctx = _lib.get_context(self.device)
-        if getattr(ctx, "_md_skin", 0.0) != self.md_skin:
-            ctx.md_skin(self.md_skin)             # (with a skin the ranks' whole-frame lists live across steps, DESIGN section 6)
+        skin = 0.0 if self.md_auto else self.md_skin            # (blocks of centres keep lists only when asked to)
+        if getattr(ctx, "_md_skin", 0.0) != skin:
+            ctx.md_skin(skin)                     # (with a skin the ranks' whole-frame lists live across steps, DESIGN section 6)
         db = _lib.device_basis(self.bspline_config, ctx)
         batch = _lib.FrameBatch([atoms])
         e = np.empty(1)
