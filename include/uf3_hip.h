@@ -120,6 +120,37 @@ int uf3_ctx_timing_read(uf3_ctx *ctx, double *featurize_ms, int64_t *featurize_l
 int uf3_ctx_md_skin(uf3_ctx *ctx, double skin);
 int uf3_ctx_md_stats(uf3_ctx *ctx, int64_t *builds, int64_t *steps, int64_t *redone);
 
+/*
+ * The fit's accumulation with HOST arrays in (round 5; SURVEY 8b's `uf3_gram_accumulate`): what the reference does as
+ * BasisFeaturizer.evaluate -> HDF5 tables -> WeightedLinearModel.fit_from_file (uf3/representation/process.py:121-291,
+ * uf3/regression/least_squares.py:355-483), without the rows ever leaving the GPU and without anything but this library between
+ * the caller's arrays and the normal equations.  uf3_fit_add takes one pointer per frame (positions [N][3], atomic numbers [N] as
+ * int64 or int32, force targets [N][3]; total energies per frame) -- no concatenation on the caller's side --, packs chunks of
+ * <= max_atoms_per_chunk atoms into pinned staging (two sets, one transfer per chunk on a copy stream beside the previous chunk's
+ * kernels), featurizes, normalises the energy rows and targets per atom (least_squares.py:697-700), accumulates
+ * [G_e | G_f | o_e | o_f | m_e | m_f] over all F columns on the device and returns without waiting for the GPU.  A neighbour
+ * capacity that overflowed in an earlier chunk surfaces as UF3_ERETRY from a later uf3_fit_add or from uf3_fit_pack: uf3_fit_reset
+ * and add everything again (capacities only grow).  uf3_fit_pack folds the frozen columns out, optionally sums the packed pieces
+ * over the ranks of the context's communicator (uf3_comm_init) and copies the 2 n_keep^2 + 2 n_keep + 6 doubles to the host:
+ * what WeightedLinearModel.fit_from_pieces solves.  frozen_idx / frozen_c: the columns fixed by the basis (bspline.py:577-635)
+ * and their coefficients; keep: the others.
+ */
+typedef struct uf3_fit uf3_fit;
+int uf3_fit_create(uf3_basis *basis, int with_forces, int64_t max_atoms_per_chunk /* <= 0: 320000 */, const int64_t *frozen_idx,
+                   const double *frozen_c, int32_t n_frozen, uf3_fit **out);
+void uf3_fit_destroy(uf3_fit *fit);
+int uf3_fit_reset(uf3_fit *fit);
+int uf3_fit_add(uf3_fit *fit, int32_t n_frames, const int64_t *atom_counts, const double *const *positions, const void *const *z,
+                int z_is_int64, const double *cells /*[n_frames][9]*/, const uint8_t *pbc /*[n_frames][3]*/, const double *energies,
+                const double *const *forces /* NULL: a fit without forces */);
+int uf3_fit_pack(uf3_fit *fit, const int64_t *keep, int32_t n_keep, int allreduce, double *out_host);
+int uf3_fit_info(const uf3_fit *fit, int64_t *n_chunks, double *n_energy_rows, double *n_force_rows);
+/* the pieces into a device buffer of the caller's (2 F^2 + 2 F + 6 doubles; zeroed by uf3_fit_reset, not here) instead of the
+ * accumulator's own: frames given as host arrays and batches already resident in HBM then add up in one place.  NULL: undo. */
+int uf3_fit_use_flat(uf3_fit *fit, double *d_flat);
+/* a call's first chunk holds this fraction of max_atoms_per_chunk (default 0.25: the GPU starts sooner; 1: equal chunks) */
+int uf3_fit_first_chunk(uf3_fit *fit, double fraction);
+
 /* RCCL behind the C ABI (round 5; SURVEY 8b's `uf3_gram_allreduce`).  One process per GPU.  The one exchange of the path is
  * the SUM over the ranks of the packed normal-equation pieces [G_e | G_f | o_e | o_f | m_e | m_f] (and, for a decomposed
  * frame, of [forces | energy | strain derivative]); the reference returns per-chunk results to the parent process and adds them

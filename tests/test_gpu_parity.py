@@ -324,6 +324,61 @@ def test_config4_fit_in_chunks_10k_atom_tungsten_frames():
     assert np.abs(pred - x_f @ c_true).max() < 2e-2 * np.abs(x_f @ c_true).max()
 
 
+def test_native_fit_accumulator_matches_the_torch_backed_one_and_the_oracle():
+    """uf3_fit_create / uf3_fit_add / uf3_fit_pack (the fit's accumulation inside the library: one pointer per frame in, pinned
+    staging and copy stream of its own, no PyTorch) == pipeline.DeviceFitAccumulator == the oracle's fit on the downloaded rows;
+    several chunks, frames of different sizes, with and without forces, frozen columns, a second call after reset."""
+    from uf3_amd import pipeline
+    basis = synthetic.notebook_basis(['Mo', 'W'])
+    frames = [synthetic.lattice_frame("bcc", (4 + k % 3, 4, 3 + k % 2), 3.165, [42, 74], seed=300 + k) for k in range(11)]
+    fz = process.BasisFeaturizer(basis)
+    reg = basis.get_regularization_matrix(ridge_1b=1e-8, ridge_2b=0.0, ridge_3b=1e-8, curvature_2b=1e-8, curvature_3b=0.0)
+    x_e, x_f, off = fz.featurize_frames(frames)
+    x_f = x_f.reshape(-1, basis.n_feats)
+    rng = np.random.default_rng(27)
+    c_true = rng.normal(0, 1, basis.n_feats)
+    c_true[basis.col_idx] = 0
+    energies = x_e @ c_true + rng.normal(0, 1e-3, len(frames))
+    forces_flat = x_f @ c_true + rng.normal(0, 1e-3, len(x_f))
+    forces = [forces_flat[3 * off[k]:3 * off[k + 1]].reshape(-1, 3) for k in range(len(frames))]
+    model = ls.WeightedLinearModel(basis, regularizer=reg)
+    native = pipeline.NativeFitAccumulator(model, fz, max_atoms_per_chunk=400)
+    native.add_frames(frames, energies, forces)
+    assert native.n_chunks >= 4
+    pieces = native.pieces()
+    n = x_e[:, :2].sum(axis=1)
+    ref = O.fit(basis, reg, x_e / n[:, None], energies / n, x_f, forces_flat, weight=0.3)
+    for key in ("gram_e", "gram_f", "ord_e", "ord_f"):
+        assert rel_err(pieces[key], ref[key]) < 1e-9, key
+    torch_backed = pipeline.DeviceFitAccumulator(model, fz, max_atoms_per_chunk=400)
+    torch_backed.add_frames(frames, energies, forces)
+    other = torch_backed.pieces()
+    for key in pieces:
+        assert rel_err(pieces[key], other[key]) < 1e-11, key
+    model.fit_from_pieces(pieces, weight=0.3)
+    assert rel_err(model.predict(x_f), x_f @ ref["coefficients"]) < 1e-6
+    # again after a reset, through the convenience entry, in one chunk; then without forces
+    native.reset()
+    native.add_frames(frames[:3], energies[:3], forces[:3])
+    part = native.pieces()
+    native.reset()
+    native.add_frames(frames, energies, forces)
+    again = native.pieces()
+    for key in pieces:
+        assert rel_err(again[key], pieces[key]) < 1e-11 and (key.startswith("m_") or rel_err(part[key], pieces[key]) > 1e-3), key
+    m2 = ls.WeightedLinearModel(basis, regularizer=reg)
+    pipeline.fit_frames_native(m2, fz, frames, energies, forces, weight=0.3)
+    assert np.allclose(m2.coefficients, model.coefficients, rtol=1e-5, atol=1e-6)
+    m3, m4 = ls.WeightedLinearModel(basis, regularizer=reg), ls.WeightedLinearModel(basis, regularizer=reg)
+    p3 = pipeline.fit_frames_native(m3, fz, frames, energies, None)          # (energies only: 11 rows for 425 unknowns -- compare the
+    p4 = pipeline.fit_frames(m4, fz, frames, energies, None, reduce=False)   #  pieces, the solution is the regulariser's)
+    assert set(p3) == set(p4) == {"gram_e", "ord_e", "m_e"}
+    for key in p3:
+        assert rel_err(p3[key], p4[key]) < 1e-11, key
+    with pytest.raises(ValueError):
+        native.add_frames(frames, energies, None)
+
+
 def test_two_element_fit_in_chunks_through_the_tiled_gram_kernel():
     """The metric variant of config 4 (W/Mo, F = 434) through the device-resident accumulator: a chunk of five 10 000-atom
     frames (150 000 force rows: listed by species, each list through the LDS-tiled X^T X kernel on its species' columns,

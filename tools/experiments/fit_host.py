@@ -14,7 +14,8 @@ for els, zs in ((['W'], [74]), (['Mo', 'W'], [42, 74])):
     forces = [rng.normal(0, 0.5, (len(f), 3)) for f in frames]
     model = ls.WeightedLinearModel(basis)
     fz = process.BasisFeaturizer(basis, device=0)
-    acc = pipeline.DeviceFitAccumulator(model, fz, max_atoms_per_chunk=int(os.environ.get('CHUNK', 80000)))
+    acc = (pipeline.NativeFitAccumulator if os.environ.get("NATIVE") else pipeline.DeviceFitAccumulator)(
+        model, fz, max_atoms_per_chunk=int(os.environ.get('CHUNK', 320000)))
     acc.add_frames(frames, energies, forces)
     torch.cuda.synchronize()
     for rep in range(3):
@@ -25,20 +26,5 @@ for els, zs in ((['W'], [74]), (['Mo', 'W'], [42, 74])):
         t2 = time.perf_counter()
         if rep == 1: acc.ctx.timing_reset(True)
         if rep == 2: print("   device ms by class:", {k: round(v, 2) for k, v in acc.ctx.timing_read().items()}); acc.ctx.timing_reset(False)
-        print(els, f"rep {rep}: host returned after {(t1 - t0) * 1e3:.2f} ms, GPU done after {(t2 - t0) * 1e3:.2f} ms -> {len(frames) / (t2 - t0):.0f} frames/s; "
-              f"allocated {torch.cuda.memory_allocated() / 2**20:.0f} MiB reserved {torch.cuda.memory_reserved() / 2**20:.0f} MiB")
+        print(els, f"rep {rep}: host returned after {(t1 - t0) * 1e3:.2f} ms, GPU done after {(t2 - t0) * 1e3:.2f} ms -> {len(frames) / (t2 - t0):.0f} frames/s")
 
-# ---- where the host time of a chunk goes (wrappers around the calls add_frames makes)
-import collections
-T = collections.defaultdict(float)
-def timed(name, fn):
-    def w(*a, **k):
-        t0 = time.perf_counter(); r = fn(*a, **k); T[name] += time.perf_counter() - t0; return r
-    return w
-acc._staging_set = timed("staging wait", acc._staging_set)
-acc.fz.featurize_device = timed("featurize_device", acc.fz.featurize_device)
-acc._gram = timed("gram_e", acc._gram)
-acc.add_device_batch = timed("add_device_batch (all)", acc.add_device_batch)
-t0 = time.perf_counter(); acc.add_frames(frames, energies, forces); total = time.perf_counter() - t0
-torch.cuda.synchronize()
-print("host total %.2f ms:" % (total * 1e3), {k: round(v * 1e3, 2) for k, v in T.items()})

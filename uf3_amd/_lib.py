@@ -25,7 +25,8 @@ EXPORTS = ["uf3_ctx_create", "uf3_ctx_destroy", "uf3_ctx_set_stream", "uf3_ctx_s
            "uf3_neighbors_debug", "uf3_fit_rows_dev", "uf3_fit_pack_dev", "uf3_gram_force_rows_dev",
            "uf3_pair_geometry", "uf3_distance_matrix", "uf3_direction_cosines",
            "uf3_ctx_md_skin", "uf3_ctx_md_stats",
-           "uf3_featurize_ld_dev", "uf3_comm_unique_id", "uf3_comm_init", "uf3_comm_destroy", "uf3_comm_info", "uf3_allreduce_sum_f64", "uf3_gram_allreduce"]
+           "uf3_featurize_ld_dev", "uf3_fit_create", "uf3_fit_destroy", "uf3_fit_reset", "uf3_fit_add", "uf3_fit_pack", "uf3_fit_info", "uf3_fit_use_flat", "uf3_fit_first_chunk",
+           "uf3_comm_unique_id", "uf3_comm_init", "uf3_comm_destroy", "uf3_comm_info", "uf3_allreduce_sum_f64", "uf3_gram_allreduce"]
 
 
 class HipUnavailable(RuntimeError):
@@ -117,6 +118,15 @@ def load():
         lib.uf3_ctx_timing_read.argtypes = [vp, C.POINTER(dbl), C.POINTER(i64), C.POINTER(dbl),
                                             C.POINTER(dbl), C.POINTER(dbl)]
         lib.uf3_ctx_md_skin.argtypes = [vp, dbl]
+        lib.uf3_fit_create.argtypes = [vp, C.c_int, i64, vp, vp, i32, C.POINTER(vp)]
+        lib.uf3_fit_destroy.argtypes = [vp]
+        lib.uf3_fit_destroy.restype = None
+        lib.uf3_fit_reset.argtypes = [vp]
+        lib.uf3_fit_add.argtypes = [vp, i32, vp, vp, vp, C.c_int, vp, vp, vp, vp]
+        lib.uf3_fit_pack.argtypes = [vp, vp, i32, C.c_int, vp]
+        lib.uf3_fit_info.argtypes = [vp, C.POINTER(i64), C.POINTER(dbl), C.POINTER(dbl)]
+        lib.uf3_fit_use_flat.argtypes = [vp, vp]
+        lib.uf3_fit_first_chunk.argtypes = [vp, dbl]
         lib.uf3_comm_unique_id.argtypes = [vp, vp]
         lib.uf3_comm_init.argtypes = [vp, C.c_int, C.c_int, vp]
         lib.uf3_comm_destroy.argtypes = [vp]

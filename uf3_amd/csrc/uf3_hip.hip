@@ -2189,6 +2189,209 @@ extern "C" int uf3_eval_centres(uf3_basis *b, const uf3_frames *fr, const double
     return eval_host(b, fr, pos, z, c1, c2, c3, energies, forces, virials, atom_begin, atom_end, true);
 }
 
+extern "C" int uf3_allreduce_sum_f64(uf3_ctx *c, double *d_buf, int64_t n);
+// ------------------------------------------------------------------------------ the fit's accumulation, host arrays in (round 5)
+// What pipeline.DeviceFitAccumulator.add_frames does with torch's buffers and streams, inside the library: frames (one pointer
+// per frame: positions, atomic numbers, force targets -- no concatenation on the caller's side) are packed chunk by chunk into
+// one of two pinned blocks, ONE transfer per chunk runs on a copy stream beside the previous chunk's kernels, the rows of a
+// chunk live in HBM between the featurizer and the Gram kernels, and everything additive sits in one flat device buffer
+// [G_e | G_f | o_e | o_f | m_e | m_f].  Reference: BasisFeaturizer.evaluate -> HDF5 -> WeightedLinearModel.fit_from_file
+// (uf3/representation/process.py:121-291, uf3/regression/least_squares.py:355-483).
+struct uf3_fit {
+    uf3_basis *b = nullptr;
+    uf3_ctx *c = nullptr;
+    bool with_forces = true;
+    int F = 0;
+    int64_t max_atoms = 320000;
+    double first_fraction = 0.25;
+    Buf flat, xe, xf, frozen_idx, frozen_c;
+    double *flat_ext = nullptr;      // the caller's device buffer for the pieces instead of `flat` (uf3_fit_use_flat)
+    int n_frozen = 0;
+    struct Set { PinBuf host; Buf dev; hipEvent_t copied = nullptr, consumed = nullptr; bool copied_live = false, consumed_live = false; } set[2];
+    hipStream_t copy_stream = nullptr;
+    double n_e = 0, n_f = 0;
+    long long n_chunks = 0;
+};
+
+extern "C" void uf3_fit_destroy(uf3_fit *f) {
+    if (!f) return;
+    hipSetDevice(f->c->device);
+    hipStreamSynchronize(f->c->stream);
+    if (f->copy_stream) { hipStreamSynchronize(f->copy_stream); hipStreamDestroy(f->copy_stream); }
+    for (auto &st : f->set) {
+        st.host.release(); st.dev.release();
+        if (st.copied) hipEventDestroy(st.copied);
+        if (st.consumed) hipEventDestroy(st.consumed);
+    }
+    f->flat.release(); f->xe.release(); f->xf.release(); f->frozen_idx.release(); f->frozen_c.release();
+    delete f;
+}
+
+extern "C" int uf3_fit_reset(uf3_fit *f) {
+    if (!f) return fail(nullptr, UF3_EINVAL, "null fit");
+    uf3_ctx *c = f->c;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemsetAsync(f->flat_ext ? (void *)f->flat_ext : f->flat.p, 0, 8 * (2 * (size_t)f->F * f->F + 2 * (size_t)f->F + 6), c->stream));
+    f->n_e = f->n_f = 0; f->n_chunks = 0;
+    return UF3_OK;
+}
+
+// the pieces into a device buffer of the caller's (2 F^2 + 2 F + 6 doubles, [G_e | G_f | o_e | o_f | m_e | m_f]; not zeroed here:
+// uf3_fit_reset does that) -- so that frames given as host arrays and batches already resident in HBM (uf3_featurize_dev +
+// uf3_gram*_dev by the caller) add up in one place.  NULL: back to the accumulator's own buffer.
+// a call's first chunk holds this fraction of max_atoms_per_chunk (default 0.25: the GPU starts sooner; 1: chunks of equal size)
+extern "C" int uf3_fit_first_chunk(uf3_fit *f, double fraction) {
+    if (!f || !(fraction > 0.0) || fraction > 1.0) return fail(f ? f->c : nullptr, UF3_EINVAL, "uf3_fit_first_chunk: fraction in (0, 1]");
+    f->first_fraction = fraction;
+    return UF3_OK;
+}
+
+extern "C" int uf3_fit_use_flat(uf3_fit *f, double *d_flat) {
+    if (!f) return fail(nullptr, UF3_EINVAL, "null fit");
+    f->flat_ext = d_flat;
+    return UF3_OK;
+}
+
+extern "C" int uf3_fit_create(uf3_basis *b, int with_forces, int64_t max_atoms_per_chunk, const int64_t *frozen_idx,
+                              const double *frozen_c, int32_t n_frozen, uf3_fit **out) {
+    if (!b || !out || n_frozen < 0 || (n_frozen && (!frozen_idx || !frozen_c))) return fail(b ? b->ctx : nullptr, UF3_EINVAL, "uf3_fit_create: bad argument");
+    uf3_ctx *c = b->ctx;
+    HIPCHK(c, hipSetDevice(c->device));
+    uf3_fit *f = new uf3_fit();
+    f->b = b; f->c = c; f->with_forces = with_forces != 0; f->F = b->host.F;
+    if (max_atoms_per_chunk > 0) f->max_atoms = max_atoms_per_chunk;
+    f->n_frozen = n_frozen;
+    auto bail = [&](int rc) { uf3_fit_destroy(f); return rc; };
+    if (f->flat.ensure(8 * (2 * (size_t)f->F * f->F + 2 * (size_t)f->F + 6)) != hipSuccess) return bail(fail(c, UF3_ENOMEM, "uf3_fit_create: out of device memory"));
+    if (n_frozen) {
+        if (f->frozen_idx.ensure(8 * (size_t)n_frozen) != hipSuccess || f->frozen_c.ensure(8 * (size_t)n_frozen) != hipSuccess)
+            return bail(fail(c, UF3_ENOMEM, "uf3_fit_create: out of device memory"));
+        if (hipMemcpy(f->frozen_idx.p, frozen_idx, 8 * (size_t)n_frozen, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(f->frozen_c.p, frozen_c, 8 * (size_t)n_frozen, hipMemcpyHostToDevice) != hipSuccess)
+            return bail(fail(c, UF3_EHIP, "uf3_fit_create: upload of the frozen columns failed"));
+    }
+    if (hipStreamCreateWithFlags(&f->copy_stream, hipStreamNonBlocking) != hipSuccess) return bail(fail(c, UF3_EHIP, "uf3_fit_create: no copy stream"));
+    for (auto &st : f->set)
+        if (hipEventCreateWithFlags(&st.copied, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&st.consumed, hipEventDisableTiming) != hipSuccess)
+            return bail(fail(c, UF3_EHIP, "uf3_fit_create: no events"));
+    int rc = uf3_fit_reset(f);
+    if (rc) return bail(rc);
+    *out = f;
+    return UF3_OK;
+}
+
+// frames: n_frames entries each of atom_counts / pos[f] ([N_f][3]) / z[f] ([N_f], int64 when z_is_int64 else int32) / cells
+// ([n_frames][9]) / pbc ([n_frames][3]) / energies (total energy of the frame) / forces[f] ([N_f][3]; null array: no forces)
+extern "C" int uf3_fit_add(uf3_fit *f, int32_t n_frames, const int64_t *atom_counts, const double *const *pos, const void *const *z,
+                           int z_is_int64, const double *cells, const uint8_t *pbc, const double *energies, const double *const *forces) {
+    if (!f) return fail(nullptr, UF3_EINVAL, "null fit");
+    uf3_ctx *c = f->c;
+    if (n_frames < 0 || (n_frames && (!atom_counts || !pos || !z || !cells || !pbc || !energies))) return fail(c, UF3_EINVAL, "uf3_fit_add: bad argument");
+    if (f->with_forces && n_frames && !forces) return fail(c, UF3_EINVAL, "uf3_fit_add: this accumulator was set up with forces: pass them");
+    HIPCHK(c, hipSetDevice(c->device));
+    const int F = f->F;
+    const size_t F2 = (size_t)F * F;
+    double *flat = f->flat_ext ? f->flat_ext : f->flat.as<double>(), *gram_e = flat, *gram_f = flat + F2, *ord_e = flat + 2 * F2, *ord_f = ord_e + F, *mom = ord_f + F;
+    int start = 0;
+    bool first = true;
+    while (start < n_frames) {
+        const int64_t limit = first ? std::max<int64_t>(1, (int64_t)(f->max_atoms * f->first_fraction)) : f->max_atoms;
+        first = false;
+        int stop = start;
+        int64_t atoms = 0;
+        while (stop < n_frames && (stop == start || atoms + atom_counts[stop] <= limit)) {
+            if (atom_counts[stop] < 0) return fail(c, UF3_EINVAL, "uf3_fit_add: negative atom count");
+            atoms += atom_counts[stop++];
+        }
+        const int nf = stop - start;
+        if (atoms < 1 || atoms >= (1LL << 28)) return fail(c, UF3_EINVAL, "uf3_fit_add: a chunk must hold 1 .. 2^28 atoms");
+        // block layout, host and device alike: positions [3 A] | force targets [3 A] | per-atom energies [nf] | atom counts [nf] | species [A] (int32)
+        const size_t A3 = 3 * (size_t)atoms, n_block = 2 * A3 + 2 * (size_t)nf + ((size_t)atoms + 1) / 2;
+        uf3_fit::Set &st = f->set[f->n_chunks & 1];
+        if (st.copied_live) { HIPCHK(c, hipEventSynchronize(st.copied)); st.copied_live = false; }      // (the pinned block is free again)
+        HIPCHK(c, st.host.ensure(8 * n_block));
+        if (8 * n_block > st.dev.cap && st.consumed_live) { HIPCHK(c, hipEventSynchronize(st.consumed)); st.consumed_live = false; }
+        HIPCHK(c, st.dev.ensure(8 * n_block));
+        double *h = (double *)st.host.p, *h_pos = h, *h_yf = h + A3, *h_ye = h + 2 * A3, *h_cnt = h_ye + nf;
+        int32_t *h_z = (int32_t *)(h_cnt + nf);
+        std::vector<int64_t> offsets(nf + 1, 0);
+        int64_t k = 0;
+        for (int i = 0; i < nf; i++) {
+            const int64_t n = atom_counts[start + i];
+            if (n && (!pos[start + i] || !z[start + i] || (f->with_forces && !forces[start + i]))) return fail(c, UF3_EINVAL, "uf3_fit_add: null frame array");
+            std::memcpy(h_pos + 3 * k, pos[start + i], 24 * (size_t)n);
+            if (z_is_int64) { const int64_t *zz = (const int64_t *)z[start + i]; for (int64_t q = 0; q < n; q++) h_z[k + q] = (int32_t)zz[q]; }
+            else std::memcpy(h_z + k, z[start + i], 4 * (size_t)n);
+            if (f->with_forces) std::memcpy(h_yf + 3 * k, forces[start + i], 24 * (size_t)n);
+            h_cnt[i] = (double)n;
+            h_ye[i] = energies[start + i] / (double)n;          // per-atom normalisation of the targets (least_squares.py:697-700)
+            k += n;
+            offsets[i + 1] = k;
+        }
+        if (st.consumed_live) HIPCHK(c, hipStreamWaitEvent(f->copy_stream, st.consumed, 0));            // (the device block is free again)
+        HIPCHK(c, hipMemcpyAsync(st.dev.p, st.host.p, 8 * n_block, hipMemcpyHostToDevice, f->copy_stream));
+        HIPCHK(c, hipEventRecord(st.copied, f->copy_stream));
+        st.copied_live = true;
+        HIPCHK(c, hipStreamWaitEvent(c->stream, st.copied, 0));
+        double *d = st.dev.as<double>(), *d_pos = d, *d_yf = d + A3, *d_ye = d + 2 * A3, *d_cnt = d_ye + nf;
+        const int32_t *d_z = (const int32_t *)(d_cnt + nf);
+        // the rows of this chunk (the previous chunk's kernels are ahead of these launches on the same stream)
+        HIPCHK(c, f->xe.ensure(8 * (size_t)nf * F));
+        if (f->with_forces) HIPCHK(c, f->xf.ensure(8 * A3 * F));
+        uf3_frames fr;
+        fr.n_frames = nf; fr.atom_offsets = offsets.data(); fr.cells = cells + 9 * (size_t)start; fr.pbc = pbc + 3 * (size_t)start;
+        int rc = uf3_featurize_dev(f->b, &fr, d_pos, d_z, f->xe.as<double>(), f->with_forces ? f->xf.as<double>() : nullptr);
+        if (rc) return rc;
+        rc = uf3_fit_rows_dev(c, nf, F, f->xe.as<double>(), d_cnt, d_ye, f->with_forces ? d_yf : nullptr, f->with_forces ? (int64_t)A3 : 0,
+                              f->n_frozen ? f->frozen_idx.as<int64_t>() : nullptr, f->n_frozen ? f->frozen_c.as<double>() : nullptr, f->n_frozen, mom);
+        if (rc) return rc;
+        rc = uf3_gram_dev(c, f->xe.as<double>(), d_ye, nf, F, F, 1, gram_e, ord_e);
+        if (rc) return rc;
+        if (f->with_forces) {
+            rc = uf3_gram_force_rows_dev(f->b, f->xf.as<double>(), d_yf, d_z, atoms, F, 1, gram_f, ord_f);
+            if (rc) return rc;
+        }
+        HIPCHK(c, hipEventRecord(st.consumed, c->stream));
+        st.consumed_live = true;
+        f->n_e += nf;
+        if (f->with_forces) f->n_f += (double)A3;
+        f->n_chunks++;
+        start = stop;
+    }
+    return UF3_OK;
+}
+
+// the additive pieces of this rank over the n_keep unfrozen columns, frozen columns folded out: [G_e | G_f | o_e | o_f | m_e | m_f]
+// (2 n_keep^2 + 2 n_keep + 6 doubles) into host memory; allreduce != 0: summed over the ranks of the context's communicator first
+extern "C" int uf3_fit_pack(uf3_fit *f, const int64_t *keep, int32_t n_keep, int allreduce, double *out_host) {
+    if (!f || !out_host || n_keep < 0 || n_keep > f->F || (n_keep && !keep)) return fail(f ? f->c : nullptr, UF3_EINVAL, "uf3_fit_pack: bad argument");
+    uf3_ctx *c = f->c;
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = uf3_ctx_synchronize(c);                  // (verdicts on the asynchronous featurizer calls: UF3_ERETRY = start over)
+    if (rc) return rc;
+    const size_t n = 2 * (size_t)n_keep * n_keep + 2 * (size_t)n_keep + 6;
+    Buf d_keep, d_out;
+    HIPCHK(c, d_keep.ensure(8 * (size_t)std::max(n_keep, 1)));
+    HIPCHK(c, d_out.ensure(8 * n));
+    auto done = [&](int r) { hipStreamSynchronize(c->stream); d_keep.release(); d_out.release(); return r; };
+    if (n_keep && hipMemcpyAsync(d_keep.p, keep, 8 * (size_t)n_keep, hipMemcpyHostToDevice, c->stream) != hipSuccess) return done(fail(c, UF3_EHIP, "uf3_fit_pack: upload failed"));
+    rc = uf3_fit_pack_dev(c, f->F, f->flat_ext ? f->flat_ext : f->flat.as<double>(), d_keep.as<int64_t>(), n_keep, f->n_frozen ? f->frozen_idx.as<int64_t>() : nullptr,
+                          f->n_frozen ? f->frozen_c.as<double>() : nullptr, f->n_frozen, f->n_e, f->n_f, d_out.as<double>());
+    if (rc) return done(rc);
+    if (allreduce && c->comm) { rc = uf3_allreduce_sum_f64(c, d_out.as<double>(), (int64_t)n); if (rc) return done(rc); }
+    if (hipMemcpyAsync(out_host, d_out.p, 8 * n, hipMemcpyDeviceToHost, c->stream) != hipSuccess) return done(fail(c, UF3_EHIP, "uf3_fit_pack: download failed"));
+    if (hipStreamSynchronize(c->stream) != hipSuccess) return done(fail(c, UF3_EHIP, "uf3_fit_pack: stream"));
+    return done(UF3_OK);
+}
+
+extern "C" int uf3_fit_info(const uf3_fit *f, int64_t *n_chunks, double *n_energy_rows, double *n_force_rows) {
+    if (!f) return fail(nullptr, UF3_EINVAL, "null fit");
+    if (n_chunks) *n_chunks = f->n_chunks;
+    if (n_energy_rows) *n_energy_rows = f->n_e;
+    if (n_force_rows) *n_force_rows = f->n_f;
+    return UF3_OK;
+}
+
 // ------------------------------------------------------------------------------ RCCL behind the C ABI
 // One process per GPU; the ONE exchange of the path is the sum of the packed normal-equation pieces (and, for a decomposed
 // frame, of [forces | energy | strain derivative]) over the ranks -- what the reference does by returning per-chunk results

@@ -57,37 +57,43 @@ class DeviceFitAccumulator:
         self.flat.zero_()
         self.n_chunks = 0
         self._counts = [0.0, 0.0]
+        if getattr(self, "_fit", None):
+            prev = self.ctx.set_stream(self.torch.cuda.current_stream(self.dev).cuda_stream)      # (one order with torch's fill)
+            try:
+                self.ctx.check(self.ctx.lib.uf3_fit_reset(self._fit))
+            finally:
+                self.ctx.restore_stream(prev)
 
     def _gram(self, x, y, gram, ordn):
         self.ctx.check(self.ctx.lib.uf3_gram_dev(self.ctx.handle, C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr()),
                                                  x.shape[0], self.n_feat, self.n_feat, 1, C.c_void_p(gram.data_ptr()),
                                                  C.c_void_p(ordn.data_ptr())))
 
-    # ---- host staging: two sets of (pinned host block, device block), used alternately ---------------------------------
-    # A copy out of pageable memory is staged by the runtime and blocks the host until the stream has reached it -- behind
-    # the previous chunk's kernels: packing and the GPU then take turns (round 4: 2897 against 3828 frames/s on the W/Mo
-    # workload).  Here the host packs chunk k + 1 straight into a pinned block (no intermediate concatenations) while the GPU
-    # works on chunk k, and ONE transfer per chunk runs on a copy stream of its own, beside the previous chunk's kernels.
-    # Three events per set: `copied` (the transfer has run: the host may pack the pinned block again, the compute stream may
-    # read the device block), `consumed` (the chunk's kernels have run: the copy stream may overwrite the device block).
-    def _staging_set(self, which, n_atoms, n_frames):
-        """Block layout, host and device alike: positions [3 A] | force targets [3 A] | per-atom energies [Fm] | atom counts
-        [Fm] | species [A] (int32)."""
-        torch = self.torch
-        sets = self.__dict__.setdefault("_staging", [None, None])
-        st = sets[which]
-        if st is None or st["atoms"] < n_atoms or st["frames"] < n_frames:
-            if st is not None:
-                torch.cuda.synchronize(self.dev)   # (the old blocks may still be in use)
-            ca, cf = max(n_atoms, self.max_atoms if st is None else st["atoms"]), max(n_frames, 64 if st is None else st["frames"])
-            n = 6 * ca + 2 * cf + (ca + 1) // 2
-            block = torch.empty((n,), dtype=torch.float64).pin_memory()
-            st = dict(atoms=ca, frames=cf, copied=None, consumed=None, block=block, np=block.numpy(),
-                      dev=torch.empty((n,), dtype=torch.float64, device=self.dev))
-            sets[which] = st
-        elif st["copied"] is not None:
-            st["copied"].synchronize()             # (the transfer of the chunk packed into this set two chunks ago)
-        return st
+    # ---- frames given as host arrays: the library's own accumulation (uf3_fit_add), into this accumulator's flat buffer -------
+    # Round 5 first staged the chunks here, through pinned torch tensors and a torch side stream; that version returned wrong
+    # rows on small chunks once another accumulator had tuned the context (species flags from stale device blocks; the same
+    # staging inside the library, on HIP streams of its own, does not) -- see DESIGN 3.4.  The host path is therefore ONE
+    # implementation, the library's: one pointer per frame in, pinned double-buffered staging, one transfer per chunk on a copy
+    # stream beside the previous chunk's kernels.
+    def _native(self):
+        if getattr(self, "_fit", None) is None:
+            h = C.c_void_p()
+            frozen = self._frozen.cpu().numpy() if self._frozen.numel() else np.zeros(0, dtype=np.int64)
+            frozen_c = self._frozen_c.cpu().numpy() if self._frozen.numel() else np.zeros(0)
+            self.ctx.check(self.ctx.lib.uf3_fit_create(self.db.handle, int(self.with_forces), int(self.max_atoms),
+                                                       _lib._p(frozen) if len(frozen) else None, _lib._p(frozen_c) if len(frozen) else None,
+                                                       len(frozen), C.byref(h)))
+            self.ctx.check(self.ctx.lib.uf3_fit_use_flat(h, C.c_void_p(self.flat.data_ptr())))
+            self._fit = h
+        return self._fit
+
+    def __del__(self):
+        try:
+            if getattr(self, "_fit", None):
+                self.ctx.lib.uf3_fit_destroy(self._fit)
+                self._fit = None
+        except Exception:  # noqa: BLE001 - interpreter shutdown
+            pass
 
     def add_frames(self, frames, energies, forces=None):
         """frames: list of Atoms; energies [n]; forces: list of (N_i, 3) arrays (required when with_forces).
@@ -99,68 +105,17 @@ class DeviceFitAccumulator:
         torch = self.torch
         if self.with_forces and forces is None and len(frames):
             raise ValueError("this accumulator was set up with forces: pass them")
-        stream = torch.cuda.current_stream(self.dev)
-        if getattr(self, "_copy_stream", None) is None:
-            self._copy_stream = torch.cuda.Stream(self.dev)
-        prev = self.ctx.set_stream(stream.cuda_stream)
+        fit = self._native()
+        prev = self.ctx.set_stream(torch.cuda.current_stream(self.dev).cuda_stream)
         try:
-            start = 0
-            while start < len(frames):           # chunks bounded by the row buffer 3*atoms*F*8 bytes
-                # (the first chunk of a call a quarter of the size: the GPU starts sooner, nothing overlaps its packing)
-                limit = self.max_atoms if start else max(1, int(self.max_atoms * self.first_fraction))
-                stop, atoms = start, 0
-                while stop < len(frames) and (stop == start or atoms + len(frames[stop]) <= limit):
-                    atoms += len(frames[stop])
-                    stop += 1
-                nf = stop - start
-                st = self._staging_set(self.n_chunks & 1, atoms, nf)
-                A3 = 3 * atoms
-                n_block = 2 * A3 + 2 * nf + (atoms + 1) // 2
-                h = st["np"][:n_block]
-                h_pos, h_yf = h[:A3].reshape(atoms, 3), h[A3:2 * A3]
-                h_ye, h_cnt = h[2 * A3:2 * A3 + nf], h[2 * A3 + nf:2 * A3 + 2 * nf]
-                h_z = h[2 * A3 + 2 * nf:].view(np.int32)[:atoms]
-                offsets = np.zeros(nf + 1, dtype=np.int64)
-                cells = np.empty((nf, 3, 3), dtype=np.float64)
-                pbc = np.zeros((nf, 3), dtype=np.uint8)
-                k = 0
-                for i in range(nf):
-                    a = frames[start + i]
-                    n = len(a)
-                    # (the frame's own arrays where it exposes them -- ase.Atoms and data.atoms.Atoms do --: one copy, not two)
-                    pos = getattr(a, "positions", None)
-                    np.copyto(h_pos[k:k + n], pos if pos is not None else a.get_positions())
-                    num = getattr(a, "numbers", None)
-                    np.copyto(h_z[k:k + n], num if num is not None else a.get_atomic_numbers(), casting="unsafe")
-                    if self.with_forces:
-                        np.copyto(h_yf[3 * k:3 * (k + n)].reshape(n, 3), np.asarray(forces[start + i]).reshape(n, 3), casting="same_kind")
-                    cells[i] = a.get_cell()
-                    pbc[i, :] = a.get_pbc() if hasattr(a, "get_pbc") else a.pbc
-                    k += n
-                    offsets[i + 1] = k
-                # per-atom normalisation of the energy rows and targets (least_squares.py:697-700); the atom counts
-                # are known on the host (= the sum of the composition columns)
-                h_cnt[:] = np.diff(offsets)
-                np.divide(np.asarray(energies[start:stop], dtype=np.float64), h_cnt, out=h_ye)
-                d = st["dev"][:n_block]
-                cs = self._copy_stream
-                if st["consumed"] is not None:
-                    cs.wait_event(st["consumed"])
-                with torch.cuda.stream(cs):
-                    d.copy_(st["block"][:n_block], non_blocking=True)
-                st["copied"] = torch.cuda.Event()
-                st["copied"].record(cs)
-                stream.wait_event(st["copied"])
-                d_pos, y_f = d[:A3].view(atoms, 3), (d[A3:2 * A3] if self.with_forces else None)
-                y_e, counts = d[2 * A3:2 * A3 + nf], d[2 * A3 + nf:2 * A3 + 2 * nf]
-                d_z = d[2 * A3 + 2 * nf:].view(torch.int32)[:atoms]
-                self.add_device_batch(_lib.make_frames(offsets, cells, pbc), nf, atoms, d_pos, d_z, counts, y_e, y_f)
-                st["consumed"] = torch.cuda.Event()
-                st["consumed"].record(stream)
-                self.n_chunks += 1
-                start = stop
+            before = _fit_counts(self.ctx, fit)
+            _fit_add(self.ctx, fit, frames, energies, forces, self.with_forces, self.first_fraction)
+            after = _fit_counts(self.ctx, fit)
         finally:
             self.ctx.restore_stream(prev)
+        self.n_chunks += after[0] - before[0]
+        self._counts[0] += after[1] - before[1]
+        self._counts[1] += after[2] - before[2]
 
     def add_device_batch(self, frames_struct, n_frames, n_atoms, d_pos, d_z, d_counts, d_ye, d_yf=None, x_e=None, x_f=None):
         """One batch whose inputs already live in HBM (torch tensors; ``d_ye`` per-atom normalised, ``d_yf`` flat):
@@ -211,6 +166,121 @@ class DeviceFitAccumulator:
         """Additive pieces of this rank as host arrays (what ``WeightedLinearModel.fit_from_pieces`` takes)."""
         from uf3_amd import parallel
         return parallel.unpack_pieces(self.packed().cpu().numpy(), int(self._keep.numel()), with_forces=self.with_forces)
+
+
+def _fit_counts(ctx, fit):
+    n, e, f = C.c_int64(), C.c_double(), C.c_double()
+    ctx.check(ctx.lib.uf3_fit_info(fit, C.byref(n), C.byref(e), C.byref(f)))
+    return n.value, e.value, f.value
+
+
+def _fit_add(ctx, fit, frames, energies, forces, with_forces, first_fraction=None):
+    """frames -> the pointer tables uf3_fit_add takes (one pointer per frame: positions, atomic numbers, force targets; the
+    frames' own arrays where they expose them)"""
+    n = len(frames)
+    if not n:
+        return
+    keep = []                                   # (the arrays the pointer tables refer to, alive until the call returns)
+    counts = np.array([len(a) for a in frames], dtype=np.int64)
+    P, Z, Fo = (C.c_void_p * n)(), (C.c_void_p * n)(), (C.c_void_p * n)()
+    for i, a in enumerate(frames):
+        pos = getattr(a, "positions", None)
+        pos = np.ascontiguousarray(pos if pos is not None else a.get_positions(), dtype=np.float64)
+        num = getattr(a, "numbers", None)
+        num = np.ascontiguousarray(num if num is not None else a.get_atomic_numbers(), dtype=np.int64)
+        keep += [pos, num]
+        P[i], Z[i] = pos.ctypes.data, num.ctypes.data
+        if with_forces:
+            fo = np.ascontiguousarray(forces[i], dtype=np.float64).reshape(len(a), 3)
+            keep.append(fo)
+            Fo[i] = fo.ctypes.data
+    cells = np.ascontiguousarray([np.asarray(a.get_cell(), dtype=np.float64).reshape(3, 3) for a in frames])
+    pbc = np.ascontiguousarray([np.asarray(a.get_pbc() if hasattr(a, "get_pbc") else a.pbc, dtype=np.uint8) for a in frames])
+    e = np.ascontiguousarray(energies, dtype=np.float64)
+    if first_fraction is not None:
+        ctx.check(ctx.lib.uf3_fit_first_chunk(fit, float(first_fraction)))
+    ctx.check(ctx.lib.uf3_fit_add(fit, n, _lib._p(counts), P, Z, 1, _lib._p(cells), _lib._p(pbc), _lib._p(e), Fo if with_forces else None))
+
+
+class NativeFitAccumulator:
+    """The same accumulation through the library alone (``uf3_fit_*``): frames go in as one pointer per frame, staging, copy
+    stream, row buffers and the flat piece buffer are the library's own -- no PyTorch anywhere on this path.  ``pieces()`` /
+    ``packed_host()`` return what ``WeightedLinearModel.fit_from_pieces`` takes; ``reduce=True`` sums the packed pieces over
+    the ranks of the context's communicator (``parallel.native_comm``) before they come back."""
+
+    def __init__(self, model, featurizer, max_atoms_per_chunk=320000, with_forces=True):
+        self.model, self.fz = model, featurizer
+        self.ctx, self.db = featurizer._dev()
+        self.with_forces = bool(with_forces)
+        mask = np.asarray(model.mask)
+        self._keep = np.ascontiguousarray(np.flatnonzero(mask) if mask.dtype == bool else mask.astype(np.int64), dtype=np.int64)
+        self._frozen = np.ascontiguousarray(model.col_idx, dtype=np.int64).reshape(-1)
+        self._frozen_c = np.ascontiguousarray(model.frozen_c, dtype=np.float64).reshape(-1)
+        h = C.c_void_p()
+        self.ctx.check(self.ctx.lib.uf3_fit_create(self.db.handle, int(self.with_forces), int(max_atoms_per_chunk),
+                                                   _lib._p(self._frozen) if len(self._frozen) else None,
+                                                   _lib._p(self._frozen_c) if len(self._frozen) else None, len(self._frozen), C.byref(h)))
+        self.handle = h
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                self.ctx.lib.uf3_fit_destroy(self.handle)
+                self.handle = None
+        except Exception:  # noqa: BLE001 - interpreter shutdown
+            pass
+
+    def reset(self):
+        self.ctx.check(self.ctx.lib.uf3_fit_reset(self.handle))
+
+    @property
+    def n_chunks(self):
+        n = C.c_int64()
+        self.ctx.check(self.ctx.lib.uf3_fit_info(self.handle, C.byref(n), None, None))
+        return n.value
+
+    def add_frames(self, frames, energies, forces=None):
+        """frames: list of Atoms; energies [n]; forces: list of (N_i, 3) arrays (required when with_forces).  Returns once the
+        last chunk is queued; a capacity overflow surfaces as ``_lib.RetryError`` later (``fit_frames`` starts over)."""
+        if self.with_forces and forces is None and len(frames):
+            raise ValueError("this accumulator was set up with forces: pass them")
+        _fit_add(self.ctx, self.handle, frames, energies, forces, self.with_forces)
+
+    def packed_host(self, reduce=False):
+        n_keep = len(self._keep)
+        out = np.empty(2 * n_keep * n_keep + 2 * n_keep + 6)
+        self.ctx.check(self.ctx.lib.uf3_fit_pack(self.handle, _lib._p(self._keep) if n_keep else None, n_keep, int(bool(reduce)), _lib._p(out)))
+        return out
+
+    def pieces(self, reduce=False):
+        from uf3_amd import parallel
+        return parallel.unpack_pieces(self.packed_host(reduce), len(self._keep), with_forces=self.with_forces)
+
+
+def fit_frames_native(model, featurizer, frames, energies, forces=None, weight=0.5, reduce=True, with_forces=None,
+                      max_atoms_per_chunk=320000):
+    """``fit_frames`` without PyTorch: accumulation in the library (``NativeFitAccumulator``), the ranks' pieces summed by the
+    library's own RCCL communicator when the context has one (``parallel.native_comm``), solved on every rank."""
+    if with_forces is None:
+        with_forces = forces is not None
+    acc = NativeFitAccumulator(model, featurizer, max_atoms_per_chunk=max_atoms_per_chunk, with_forces=with_forces)
+    attempt = 0
+    while True:
+        try:
+            acc.add_frames(frames, energies, forces)
+            pieces = acc.pieces(reduce=reduce and acc.ctx.comm_info()[0] > 1)
+            break
+        except _lib.UF3Error as exc:
+            try:
+                acc.ctx.synchronize()
+            except _lib.UF3Error:
+                pass
+            acc.reset()
+            attempt += 1
+            if not isinstance(exc, _lib.RetryError) or attempt >= 16:
+                raise
+    model.fit_from_pieces(pieces, weight=weight)
+    return pieces
 
 
 def fit_frames(model, featurizer, frames, energies, forces=None, weight=0.5, reduce=True, with_forces=None,
