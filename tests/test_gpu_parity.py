@@ -1264,7 +1264,9 @@ def test_atom_range_shares_add_up_to_the_frame():
     coeff = np.random.default_rng(5).normal(0, 0.05, basis.n_feats)
     coeff[basis.col_idx] = 0.0
     model.coefficients = coeff
-    calc = calculator.UFCalculator(model)
+    calc = calculator.UFCalculator(model, md_skin=float(os.environ.get("UF3_MD_SKIN", "0") or 0))     # (the plain routes against each other: no lists unless forced)
+    for _ in range(2):                     # (capacities settled: a context's first call runs other kernel instances, same sums, other last bits)
+        calc.evaluate_frames([atoms], virial=True)
     e, f, _, v = calc.evaluate_frames([atoms], virial=True)
     n, world = len(atoms), 3
     assert n == 420
@@ -1314,7 +1316,10 @@ def test_atom_range_shares_add_up_to_the_frame():
         e_b, f_b, off_b = calc.evaluate_frames(big)                           # the non-deferred flag check
     finally:
         del os.environ["UF3_SEPARATE_N3"]
-    assert np.array_equal(e_s, e) and np.array_equal(f_s, f) and np.array_equal(v_s, v)
+    if float(os.environ.get("UF3_MD_SKIN", "0") or 0) > 0:     # (the whole suite on the MD route: `e, f, v` came from the lists, whose
+        assert rel_err(f_s, f) < 1e-12 and rel_err(v_s, v) < 1e-12 and abs(e_s[0] - e[0]) <= 1e-12 * abs(e[0])    # sums run in list order)
+    else:
+        assert np.array_equal(e_s, e) and np.array_equal(f_s, f) and np.array_equal(v_s, v)
     e_b2, f_b2, _ = calc.evaluate_frames(big)
     assert np.array_equal(e_b, e_b2) and np.array_equal(f_b, f_b2) and np.array_equal(f_b[off_b[7]:off_b[8]], f)
     for r, (_, fs, _) in enumerate(shares):
