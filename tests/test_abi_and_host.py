@@ -150,3 +150,22 @@ def test_bench_line_keeps_the_other_configurations_where_the_driver_looks():
     assert table["columns"] == ["value", "unit", "ms_per_step", "fp64_frac", "hbm_frac"]
     est = bench.reference_estimate(0.4, 4.8, 32)
     assert est is None or (est["label"] == "estimate" and est["frames_per_s_all_cores"] == pytest.approx(4.8 / est["reference_to_port_ratio"]))
+
+
+def test_single_frame_batch_is_refreshed_in_place():
+    """_lib.FrameBatch.refresh (what UFCalculator does between the calls of an MD loop): positions, species, cell and boundary
+    flags of the same-sized frame land in the arrays the C struct already points to; another atom count asks for a new batch."""
+    from uf3_amd import synthetic
+    from uf3_amd.data.atoms import Atoms
+    a = synthetic.lattice_frame("bcc", (2, 2, 2), 3.165, [42, 74], seed=1)
+    batch = _lib.FrameBatch([a])
+    where = (batch.pos.ctypes.data, batch.z.ctypes.data, batch.cells.ctypes.data, batch.pbc.ctypes.data)
+    b = Atoms(numbers=a.get_atomic_numbers()[::-1], positions=a.get_positions() + 0.25, cell=np.asarray(a.get_cell()) * 1.1, pbc=[True, False, True])
+    assert batch.refresh(b)
+    assert (batch.pos.ctypes.data, batch.z.ctypes.data, batch.cells.ctypes.data, batch.pbc.ctypes.data) == where
+    fresh = _lib.FrameBatch([b])
+    for name in ("pos", "z", "cells", "pbc", "offsets"):
+        assert np.array_equal(getattr(batch, name), getattr(fresh, name)), name
+    assert batch.z.dtype == np.int32 and batch.struct.n_frames == 1
+    assert not batch.refresh(synthetic.lattice_frame("bcc", (2, 2, 3), 3.165, [42, 74], seed=1))      # another size
+    assert not _lib.FrameBatch([a, b]).refresh(a)                                                         # not a single frame
