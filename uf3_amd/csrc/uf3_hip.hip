@@ -170,6 +170,33 @@ struct uf3_basis {
     int f3_nr = 0;                   // rounds of 32 window positions of the launch that serves the window (1: default trims; 2, 3: wider)
 };
 
+// ------------------------------------------------------------------------------ environment switches
+// The UF3_* switches (A/B measurements, tests) are looked at on every call -- tests flip them between two calls on one context --
+// but not through ~25 getenv scans per call: the entries of the hot paths call uf3_env_refresh(), which walks `environ` once when
+// its fingerprint (the entries' addresses: setenv / unsetenv change them) has moved and keeps the UF3_* entries; uf3_env() then
+// answers from those few (none at all in production).
+extern char **environ;
+struct Uf3EnvCache { unsigned long long print = ~0ull; std::vector<std::pair<std::string, std::string>> vars; };
+static thread_local Uf3EnvCache g_env;
+static void uf3_env_refresh() {
+    unsigned long long fp = 1469598103934665603ull;
+    for (char **e = environ; e && *e; e++) fp = (fp ^ (unsigned long long)(uintptr_t)*e) * 1099511628211ull;
+    if (fp == g_env.print) return;
+    g_env.print = fp;
+    g_env.vars.clear();
+    for (char **e = environ; e && *e; e++) {
+        if (std::strncmp(*e, "UF3_", 4)) continue;
+        const char *eq = std::strchr(*e, '=');
+        if (eq) g_env.vars.emplace_back(std::string(*e, eq - *e), std::string(eq + 1));
+    }
+}
+static const char *uf3_env(const char *name) {
+    if (g_env.print == ~0ull) uf3_env_refresh();
+    for (const auto &kv : g_env.vars)
+        if (kv.first == name) return kv.second.c_str();
+    return nullptr;
+}
+
 static thread_local std::string g_err;
 static int fail(uf3_ctx *ctx, int code, const std::string &msg) {
     if (ctx) ctx->err = msg;
@@ -186,6 +213,7 @@ static int fail(uf3_ctx *ctx, int code, const std::string &msg) {
 extern "C" const char *uf3_last_error(const uf3_ctx *ctx) { return ctx ? ctx->err.c_str() : g_err.c_str(); }
 
 extern "C" int uf3_ctx_create(int device, uf3_ctx **out) {
+    uf3_env_refresh();
     if (!out) return fail(nullptr, UF3_EINVAL, "uf3_ctx_create: null out");
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
@@ -203,10 +231,10 @@ extern "C" int uf3_ctx_create(int device, uf3_ctx **out) {
     HIPCHK(c, hipGetDeviceProperties(&prop, device));
     c->lds_max = (int)prop.sharedMemPerBlock;
     c->n_cu = prop.multiProcessorCount;
-    c->env_no_feat3 = getenv("UF3_NO_FEAT3") != nullptr;
-    c->env_f3_no_cap16 = getenv("UF3_F3_NO_CAP16") != nullptr;
-    c->env_debug_lds = getenv("UF3_DEBUG_LDS") != nullptr;
-    if (getenv("UF3_F3_BPS")) c->env_f3_bps = std::max(1, atoi(getenv("UF3_F3_BPS")));
+    c->env_no_feat3 = uf3_env("UF3_NO_FEAT3") != nullptr;
+    c->env_f3_no_cap16 = uf3_env("UF3_F3_NO_CAP16") != nullptr;
+    c->env_debug_lds = uf3_env("UF3_DEBUG_LDS") != nullptr;
+    if (uf3_env("UF3_F3_BPS")) c->env_f3_bps = std::max(1, atoi(uf3_env("UF3_F3_BPS")));
     if (std::string(prop.gcnArchName).find("gfx950") == std::string::npos) {
         std::string m = std::string("uf3_hip is built for gfx950 only, device is ") + prop.gcnArchName;
         delete c;
@@ -388,6 +416,7 @@ static double sq_root_ge(double r) {          // the smallest double s with sqrt
 }
 
 extern "C" int uf3_basis_create(uf3_ctx *c, const uf3_basis_spec *s, uf3_basis **out) {
+    uf3_env_refresh();
     if (!c || !s || !out) return fail(c, UF3_EINVAL, "uf3_basis_create: null argument");
     if (s->n_species < 1 || s->n_species > UF3_MAX_SPECIES)
         return fail(c, UF3_EINVAL, "uf3_basis_create: 1..8 species supported");
@@ -512,14 +541,14 @@ extern "C" int uf3_basis_create(uf3_ctx *c, const uf3_basis_spec *s, uf3_basis *
         // specialisation (modes 6-9); wider windows stay on the generic kernels
         DenseLayout dl = dense_layout(td.ext[0], td.ext[1], td.ext[2]);
         const int dmode = dense_mode_for(td.ext[0], td.ext[1], td.ext[2]);
-        if (dmode && !getenv("UF3_NO_MFMA_FEAT") && (dmode <= 7 || !getenv("UF3_NO_WIDE_MFMA"))) {
+        if (dmode && !uf3_env("UF3_NO_MFMA_FEAT") && (dmode <= 7 || !uf3_env("UF3_NO_WIDE_MFMA"))) {
             td.dense = dmode;
             b->dense_stride[dmode] = std::max(b->dense_stride[dmode], dl.stride);
             b->dense_dump[dmode] = std::max(b->dense_dump[dmode], td.ext[0] * dl.cw);
         }
         td.grouped = 0; td.gthr0 = -1e300; td.gthr2 = 1e300;
         if (td.dense == 7 && td.ext[1] == 3 && td.ext[0] <= 3 && td.ext[2] >= 6 && td.ext[2] <= 9 && td.nsrc <= 2 && td.ncol <= 128 &&
-            !getenv("UF3_NO_NGROUP")) {
+            !uf3_env("UF3_NO_NGROUP")) {
             // first window bin f = interval - 3 - lo_n: f <= 1 -> group 0 (bins 0..4), f >= 4 -> group 2 (bins 4..8)
             const double *tn = legn_knots[t];
             const int nk = td.leg[2].nk, i_lo = 3, i_hi = nk - 5;
@@ -531,7 +560,7 @@ extern "C" int uf3_basis_create(uf3_ctx *c, const uf3_basis_spec *s, uf3_basis *
         // wide windows (mode 9, two row tiles): cut the intervals of leg n into at most three bands whose records touch at most
         // three neighbouring column tiles (trio_block_banded); windows that do not fit keep the dense loop
         td.banded = 0; td.band_tile[0] = td.band_tile[1] = td.band_tile[2] = 0;
-        if (td.dense == 9 && dl.stride == 64 && (4 * td.ext[0] + 15) / 16 == 2 && !getenv("UF3_NO_BANDS")) {
+        if (td.dense == 9 && dl.stride == 64 && (4 * td.ext[0] + 15) / 16 == 2 && !uf3_env("UF3_NO_BANDS")) {
             const double *tn = legn_knots[t];
             const int i_lo = 3, i_hi = td.leg[2].nk - 5, n_ct = (td.ext[1] * td.ext[2] + 15) / 16;
             auto tiles_of = [&](int i, int &t0, int &t1) {
@@ -715,14 +744,14 @@ extern "C" int uf3_basis_create(uf3_ctx *c, const uf3_basis_spec *s, uf3_basis *
     if (!trios.empty())
         HIPCHK(c, hipMemcpy(b->d_trios, trios.data(), sizeof(TrioDev) * trios.size(), hipMemcpyHostToDevice));
     h.trios = b->d_trios; h.recs = b->d_recs; h.lut = b->d_lut;
-    h.pairs_uniform = !getenv("UF3_NO_UNIFORM_LEGS");
+    h.pairs_uniform = !uf3_env("UF3_NO_UNIFORM_LEGS");
     for (int a = 0; a < UF3_MAX_SPECIES * UF3_MAX_SPECIES; a++) h.pair_col[a] = h.pair_of[a] >= 0 ? h.pairs[h.pair_of[a]].col : 0;
     for (int p2 = 1; p2 < h.P && h.pairs_uniform; p2++) {
         const PairDev &a = h.pairs[0], &q = h.pairs[p2];
         if (a.leg.rec_off != q.leg.rec_off || a.leg.nk != q.leg.nk || a.leg.t0 != q.leg.t0 || a.leg.tlast != q.leg.tlast ||
             a.leg.inv_h != q.leg.inv_h || a.rmin != q.rmin || a.rmax != q.rmax || a.nb != q.nb) h.pairs_uniform = 0;
     }
-    h.trio_legs_uniform = h.T > 0 && !getenv("UF3_NO_UNIFORM_LEGS");
+    h.trio_legs_uniform = h.T > 0 && !uf3_env("UF3_NO_UNIFORM_LEGS");
     for (int t = 1; t < h.T && h.trio_legs_uniform; t++) {
         for (int d = 0; d < 3; d++) {
             const LegDev &a = trios[0].leg[d], &q = trios[t].leg[d];
@@ -735,7 +764,7 @@ extern "C" int uf3_basis_create(uf3_ctx *c, const uf3_basis_spec *s, uf3_basis *
     // ---- k_featurize3 (uf3_feat3.h): one window layout for all trios, centre legs alike, a W window of at most 31 positions;
     // trios with two equal neighbour species must fold symmetrically in (l, m)
     {
-        bool ok = h.T > 0 && h.trio_legs_uniform && !getenv("UF3_NO_FEAT3");
+        bool ok = h.T > 0 && h.trio_legs_uniform && !uf3_env("UF3_NO_FEAT3");
         auto same_leg = [](const LegDev &a, const LegDev &q) {
             return a.rec_off == q.rec_off && a.nk == q.nk && a.t0 == q.t0 && a.tlast == q.tlast && a.inv_h == q.inv_h;
         };
@@ -751,7 +780,7 @@ extern "C" int uf3_basis_create(uf3_ctx *c, const uf3_basis_spec *s, uf3_basis *
             const bool shape = prr > 0 && prr * b->f3_nr >= ep &&
                                ((ep >= 1 && ep <= 3 && prr * en <= 31 && en <= 9) || (ep == 4 && en <= 11) || ((ep == 5 || ep == 6) && en <= 13));
             ok = t0.lo[0] == t0.lo[1] && t0.ext[0] == t0.ext[1] && same_leg(t0.leg[0], t0.leg[1]) && shape &&
-                 t0.leg[0].nk >= 8 && t0.leg[2].nk >= 8 && !(ep > 3 && getenv("UF3_NO_FEAT3_WIDE"));
+                 t0.leg[0].nk >= 8 && t0.leg[2].nk >= 8 && !(ep > 3 && uf3_env("UF3_NO_FEAT3_WIDE"));
             for (int t = 0; t < h.T && ok; t++) {
                 const TrioDev &td = trios[t];
                 for (int a = 0; a < 3; a++) ok = ok && td.lo[a] == t0.lo[a] && td.ext[a] == t0.ext[a];
@@ -948,7 +977,7 @@ static int make_geom(uf3_ctx *c, const uf3_basis *b, const uf3_frames *fr, int f
     if (!invert3(eff, g.inv)) return fail(c, UF3_EINVAL, "cell is singular along a periodic direction");
     double rs = b->host.rsearch + extra;
     // bins of half the search radius (scan radius 2): 125 bins cover 15.6 r^3 instead of 27 r^3 for 27 full-size bins
-    const double bin_frac = getenv("UF3_BIN_FRAC") ? atof(getenv("UF3_BIN_FRAC")) : 0.5;
+    const double bin_frac = uf3_env("UF3_BIN_FRAC") ? atof(uf3_env("UF3_BIN_FRAC")) : 0.5;
     if (n_per) {
         reference_factors(cell, b->r_cut, g.fac);
         for (int k = 0; k < 3; k++) if (!g.per[k]) g.fac[k] = 0;
@@ -1142,7 +1171,7 @@ static int prepare(uf3_basis *b, const uf3_frames *fr, const double *d_pos, cons
         const size_t at = c->pin_in_pending;
         std::memcpy((char *)c->pin_in.p + at, geoms.data(), sizeof(FrameGeom) * nf);
         std::memcpy((char *)c->pin_in.p + at + geo_bytes, fr->atom_offsets, off_bytes);
-        if (natoms <= UF3_SMALL_ATOMS && !getenv("UF3_NO_SMALL_PREPARE") && !getenv("UF3_NO_ZERO_COPY")) {
+        if (natoms <= UF3_SMALL_ATOMS && !uf3_env("UF3_NO_SMALL_PREPARE") && !uf3_env("UF3_NO_ZERO_COPY")) {
             host_block = (const int4 *)c->pin_in.p;
             host_block_bytes = (at + geo_bytes + off_bytes + 15) / 16 * 16;
         } else {
@@ -1173,7 +1202,7 @@ static int prepare(uf3_basis *b, const uf3_frames *fr, const double *d_pos, cons
 
     Timed tm(c, T_NBR);
     int tb = 256, gb = (natoms + tb - 1) / tb;
-    if (natoms <= UF3_SMALL_ATOMS && !getenv("UF3_NO_SMALL_PREPARE")) {
+    if (natoms <= UF3_SMALL_ATOMS && !uf3_env("UF3_NO_SMALL_PREPARE")) {
         // an MD step: the whole cell-list stage in one workgroup (and the status words of the launches that follow zeroed)
         hipLaunchKernelGGL(k_prepare_small, dim3(1), dim3(natoms <= 256 ? 256 : 1024), 0, st, b->dev, d_geoms, d_offsets, nf,
                            natoms, nbins, d_pos, d_z, c->frame_of.as<int>(), c->atom_bin.as<int>(), c->atom_wrap.as<int>(),
@@ -1226,7 +1255,7 @@ static int prepare(uf3_basis *b, const uf3_frames *fr, const double *d_pos, cons
             HIPCHK(c, hipMemsetAsync(flags + 1, 0, sizeof(int), st));
             size_t lds = (size_t)cap * (8 + 32 + 16);
             if ((int)lds > c->lds_max) return fail(c, UF3_EOVERFLOW, "3-body neighbour list does not fit in LDS");
-            const bool block_only = n3_hi >= 0 && !(n3_lo == 0 && n3_hi == natoms) && !getenv("UF3_NO_HALO");
+            const bool block_only = n3_hi >= 0 && !(n3_lo == 0 && n3_hi == natoms) && !uf3_env("UF3_NO_HALO");
             if (!block_only)
                 hipLaunchKernelGGL(k_build_n3, dim3(natoms), dim3(64), lds, st, b->dev, P.geoms, P.frame_of, P.cl, P.n3,
                                    d_pos, natoms, flags + 1, 0, (const int *)nullptr, (const int *)nullptr);
@@ -1324,13 +1353,14 @@ extern "C" int uf3_featurize_ld_dev(uf3_basis *b, const uf3_frames *fr, const do
 static int featurize_dev_impl(uf3_basis *b, const uf3_frames *fr, const double *d_pos, const int32_t *d_z,
                               double *d_xe, double *d_xf, int64_t ld) {
     uf3_ctx *c = b->ctx;
+    uf3_env_refresh();
     if (!d_pos || !d_z) return fail(c, UF3_EINVAL, "null positions / species");
     if (!d_xe && !d_xf) return UF3_OK;
     // verdicts on earlier asynchronous calls that have arrived: returned to the asynchronous caller (their owner) HERE, so not
     // kept for uf3_ctx_synchronize as well -- a caller that redoes the work would meet the same verdict again after a clean redo
     { int rc0 = poll_pending(c, false, false); if (rc0) return rc0; }
     Prepared P;
-    const bool old_n3 = getenv("UF3_SEPARATE_N3") != nullptr;     // debugging: lists from k_build_n3 instead
+    const bool old_n3 = uf3_env("UF3_SEPARATE_N3") != nullptr;     // debugging: lists from k_build_n3 instead
     int rc = prepare(b, fr, d_pos, d_z, old_n3, P);       // cell list only: MODE 0 builds the 3-body lists itself
     if (rc) return rc;
     hipStream_t st = c->stream;
@@ -1353,7 +1383,7 @@ static int featurize_dev_impl(uf3_basis *b, const uf3_frames *fr, const double *
     A.dsrc = b->d_dsrc; A.n_dsrc = (int)b->n_dsrc;
     A.gsrc = b->d_gsrc; A.n_gsrc = (int)b->n_gsrc; A.gsrc_lds = 0;
     const int dense_modes = (1 << 6) | (1 << 7) | (1 << 8) | (1 << 9);
-    const bool dsrc_ok = (b->modes & dense_modes) && b->n_dsrc * sizeof(int) <= 8192 && !getenv("UF3_NO_LDS_DSRC");
+    const bool dsrc_ok = (b->modes & dense_modes) && b->n_dsrc * sizeof(int) <= 8192 && !uf3_env("UF3_NO_LDS_DSRC");
     A.dsrc_lds = dsrc_ok;
     if (b->modes & dense_modes) { rc = ensure_frag(c); if (rc) return rc; A.frag = c->frag.as<int>(); }
     A.geoms = P.geoms; A.frame_of = P.frame_of; A.cl = P.cl;
@@ -1368,8 +1398,8 @@ static int featurize_dev_impl(uf3_basis *b, const uf3_frames *fr, const double *
     A.cand_need = c->flags.as<int>() + 2;
     // (UF3_KEEP_GHOST_TERMS: keep the force terms of ghost-centred triplets whose third atom the reference's image range
     // does not reach -- rows of unwrapped atoms are then the exact gradient of the energy row instead of the reference's)
-    A.outside = getenv("UF3_KEEP_GHOST_TERMS") ? nullptr : c->flags.as<int>() + 4;
-    { const char *e = getenv("UF3_DEBUG_SKIP"); A.skip = e ? atoi(e) : 0; }
+    A.outside = uf3_env("UF3_KEEP_GHOST_TERMS") ? nullptr : c->flags.as<int>() + 4;
+    { const char *e = uf3_env("UF3_DEBUG_SKIP"); A.skip = e ? atoi(e) : 0; }
     for (int attempt = 0; attempt < 6; attempt++) {
         A.cand_cap = c->cand_cap;
         A.n_recs = (int)b->n_recs;
@@ -1416,15 +1446,15 @@ static int featurize_dev_impl(uf3_basis *b, const uf3_frames *fr, const double *
                 const bool dense_mode = mode >= 6;
                 // knot records go to LDS when the block then still reaches the occupancy its registers allow
                 // (10: mode 7 with grouped windows only -- the force launches of a basis whose mode-7 blocks are all grouped)
-                const int launch_mode = (mode == 7 && want_f && b->all_grouped7 && !img_launch && !getenv("UF3_NO_GROUPED_ONLY")) ? 10
-                                        : ((mode == 9 && want_f && b->all_banded9 && !img_launch && !getenv("UF3_NO_GROUPED_ONLY")) ? 11 : mode);
+                const int launch_mode = (mode == 7 && want_f && b->all_grouped7 && !img_launch && !uf3_env("UF3_NO_GROUPED_ONLY")) ? 10
+                                        : ((mode == 9 && want_f && b->all_banded9 && !img_launch && !uf3_env("UF3_NO_GROUPED_ONLY")) ? 11 : mode);
                 // (a grouped-only launch reads the window rows, not the knot records of the legs)
                 A.trio_rec_lo = (int)(launch_mode == 10 ? b->wrow_lo : b->trio_rec_lo);
                 size_t n_rec_mode = mode == 0 ? b->n_pair_recs : b->n_recs - (size_t)A.trio_rec_lo;
                 const int S = b->host.S;
                 const size_t cu_lds = 160 * 1024 - 1024;
                 if (dense_mode) A.dsrc_lds = dsrc_ok && !(mode == 7 && want_f && b->all_grouped7);
-                const bool gsrc_wanted = mode == 7 && want_f && b->dense_grouped[7] && b->n_gsrc > 0 && b->n_gsrc * 2 <= 4096 && !getenv("UF3_NO_LDS_GSRC");
+                const bool gsrc_wanted = mode == 7 && want_f && b->dense_grouped[7] && b->n_gsrc > 0 && b->n_gsrc * 2 <= 4096 && !uf3_env("UF3_NO_LDS_GSRC");
                 const size_t gsrc_bytes = gsrc_wanted ? b->n_gsrc * 2 : 0;
                 A.gsrc_lds = gsrc_wanted;
                 size_t lds_extra = ((dense_mode && A.dsrc_lds) ? sizeof(int) * b->n_dsrc : 0) + gsrc_bytes;
@@ -1441,14 +1471,14 @@ static int featurize_dev_impl(uf3_basis *b, const uf3_frames *fr, const double *
                     auto stage_for = [&](int nr) { return std::max(dump, (nr + (nr & 1) + (grouped ? 2 : 0)) * stride); };
                     // (21 records = 63 staging lanes = one walk step: a block of <= 63 items is one step and three passes)
                     A.dense_nrec = nrec_max; A.dense_stage = stage_for(nrec_max);
-                    if (mode <= 7 && !getenv("UF3_NO_OCC3")) {
+                    if (mode <= 7 && !uf3_env("UF3_NO_OCC3")) {
                         // records per staging pass: as many as the stage allows; fewer (smaller stage) if that lets a third
                         // workgroup onto the CU -- the kernel is latency-bound.  Three workgroups per CU need <= 52 KB each
                         // (LDS is granted in coarse granules: 53 KB did not fit).  Candidates in order of preference: the
                         // knot records / window rows in LDS first, then more records per pass
                         const int tries[3] = {nrec_max, std::min(nrec_max, 20), std::min(nrec_max, 15)};
                         const size_t budget = (WPB == 4 ? 52 : 13 * WPB) * 1024;      // (12 waves per CU: 3 x 4 or 2 x 6)
-                        const bool dsrc_allowed = A.dsrc_lds, recs_allowed = !getenv("UF3_NO_LDS_RECS") && !(img_launch && mode != 0);
+                        const bool dsrc_allowed = A.dsrc_lds, recs_allowed = !uf3_env("UF3_NO_LDS_RECS") && !(img_launch && mode != 0);
                         for (int q = 0; q < 12 && !found; q++) {
                             // (the records / window rows in LDS first: a staging lane reads eleven 16-byte pieces of them per pass)
                             const int nr = tries[(q % 6) / 2];
@@ -1467,7 +1497,7 @@ static int featurize_dev_impl(uf3_basis *b, const uf3_frames *fr, const double *
                     lds_plain = feat_lds_bytes(F, S, cap, A.cand_cap, want_e && !A.e_direct, 0, mode, A.dense_stage, A.dense_nrec, A.n_pair_cols) + lds_extra;
                     lds_recs = feat_lds_bytes(F, S, cap, A.cand_cap, want_e && !A.e_direct, n_rec_mode, mode, A.dense_stage, A.dense_nrec, A.n_pair_cols) + lds_extra;
                     const size_t lds_target = cu_lds / (mode == 0 ? 4 : 2);
-                    recs_lds = lds_recs <= lds_target && !getenv("UF3_NO_LDS_RECS") && !(img_launch && mode != 0);
+                    recs_lds = lds_recs <= lds_target && !uf3_env("UF3_NO_LDS_RECS") && !(img_launch && mode != 0);
                     lds = recs_lds ? lds_recs : lds_plain;
                 }
                 if (lds > UF3_LDS_LIMIT && mode == 0 && !c->cand_tuned && c->cand_cap > 64) {
@@ -1500,7 +1530,7 @@ static int featurize_dev_impl(uf3_basis *b, const uf3_frames *fr, const double *
                 int apb = ((P.natoms + n_blocks - 1) / n_blocks + WPB - 1) / WPB * WPB;
                 n_blocks = (P.natoms + apb - 1) / apb;
                 A.atoms_per_block = apb;
-                if (getenv("UF3_DEBUG_LDS"))
+                if (uf3_env("UF3_DEBUG_LDS"))
                     fprintf(stderr, "uf3 featurize mode %d: lds %zu B (plain %zu, with recs %zu), recs_lds %d, cap %d, cand_cap %d, "
                             "blocks %d x %d atoms, n_recs %zu, dense nrec %d stage %d\n", launch_mode, lds, lds_plain, lds_recs,
                             (int)recs_lds, cap, A.cand_cap, n_blocks, apb, n_rec_mode, A.dense_nrec, A.dense_stage);
@@ -1601,7 +1631,7 @@ static int featurize_dev_impl(uf3_basis *b, const uf3_frames *fr, const double *
         }
         HIPCHK(c, hipGetLastError());
         if (restart) continue;
-        if ((!has3 || c->n3_tuned) && c->cand_tuned && !old_n3 && !getenv("UF3_SYNC_FEATURIZE")) {
+        if ((!has3 || c->n3_tuned) && c->cand_tuned && !old_n3 && !uf3_env("UF3_SYNC_FEATURIZE")) {
             // capacities known from earlier calls: do not wait.  The status words follow the launches into a pinned
             // slot; the next call on this context / uf3_ctx_synchronize looks at them (UF3_ERETRY if they overflowed)
             int slot = -1;
@@ -1816,6 +1846,7 @@ static int eval_impl(uf3_basis *b, const uf3_frames *fr, const double *d_pos, co
                      int64_t atom_begin = 0, int64_t atom_end = -1, int *deferred_cap = nullptr, int *flags_tail = nullptr,
                      double *mirror = nullptr, bool centre_share = false) {
     uf3_ctx *c = b->ctx;
+    uf3_env_refresh();
     if (!d_pos || !d_z || !c1 || !d_energies) return fail(c, UF3_EINVAL, "uf3_eval: null argument");
     if ((b->c2_len && !c2) || (b->c3_len && !c3)) return fail(c, UF3_EINVAL, "uf3_eval: missing coefficients");
     // whole batch with forces and 3-body terms: every triplet once, at its centre, + a collection pass; a block of
@@ -1830,13 +1861,13 @@ static int eval_impl(uf3_basis *b, const uf3_frames *fr, const double *d_pos, co
     // block; the collection pass then serves the block and its halo (the atoms the block's lists mention), whose lists are
     // built for that purpose.  Rows of all other atoms stay zero; the shares of disjoint blocks add up to the frame.
     const bool centres = centre_share && !whole && d_forces && b->host.T > 0 && atom_end > atom_begin;
-    const bool two_pass = (whole || centres) && d_forces && b->host.T > 0 && !getenv("UF3_EVAL_GATHER");
-    const bool fuse = two_pass && c->n3_tuned && c->n3_cap > 0 && !getenv("UF3_SEPARATE_N3");
+    const bool two_pass = (whole || centres) && d_forces && b->host.T > 0 && !uf3_env("UF3_EVAL_GATHER");
+    const bool fuse = two_pass && c->n3_tuned && c->n3_cap > 0 && !uf3_env("UF3_SEPARATE_N3");
     Prepared P;
     int rc;
     hipStream_t st = c->stream;
     // MD route: the candidates of every atom from the context's persistent lists instead of a cell-list walk (see md_build)
-    const bool md_step = c->md.skin > 0.0 && fuse && (whole || centres) && !getenv("UF3_NO_MD");     // (a block of centres too: round 5)
+    const bool md_step = c->md.skin > 0.0 && fuse && (whole || centres) && !uf3_env("UF3_NO_MD");     // (a block of centres too: round 5)
     c->md_step = md_step;
     if (md_step) {
         HIPCHK(c, hipSetDevice(c->device));
@@ -1847,7 +1878,7 @@ static int eval_impl(uf3_basis *b, const uf3_frames *fr, const double *d_pos, co
             // a small batch staged by upload_frames: positions | species are still in the caller's pinned block
             const size_t at = c->pin_in_pending;
             c->pin_in_pending = 0;
-            if (c->md.natoms <= UF3_SMALL_ATOMS && !getenv("UF3_NO_ZERO_COPY")) {
+            if (c->md.natoms <= UF3_SMALL_ATOMS && !uf3_env("UF3_NO_ZERO_COPY")) {
                 hipLaunchKernelGGL(k_md_fetch, dim3(1), dim3(256), 0, st, (const int4 *)c->pin_in.p, (int4 *)c->stage_pos.p, (int)(at / 16),
                                    c->flags.as<int>());
                 c->pin_in_busy = true;
@@ -1897,7 +1928,7 @@ static int eval_impl(uf3_basis *b, const uf3_frames *fr, const double *d_pos, co
     A.halo_mark = nullptr;
     // (rows of atoms that no centre of the block touches: zero.  A block of centres with the fused list build zeroes rows, list
     // counts and halo marks in ONE launch inside the loop below)
-    const bool zero3 = centres && fuse && !md_step && !getenv("UF3_NO_HALO");
+    const bool zero3 = centres && fuse && !md_step && !uf3_env("UF3_NO_HALO");
     if (centre_share && !whole && d_forces && !zero3 && !md_step)
         HIPCHK(c, hipMemsetAsync(d_forces, 0, 24 * (size_t)P.natoms, st));
     {
@@ -1940,7 +1971,7 @@ static int eval_impl(uf3_basis *b, const uf3_frames *fr, const double *d_pos, co
             // TAB instances (centre legs from per-bond tables, k_eval): + leg n's knot records, + the tables when they do not fit
             // over the queue.  Chosen by the basis alone -- not by the capacity -- unless the longer layout does not fit at all
             const size_t lds_tab = lds_plain + 16 + EVAL_TAB_KN * sizeof(KnotRec) + (cap > EVAL_TAB_CAP ? 136 * cap + 16 : 0);
-            const bool tab = two_pass && b->eval_tab_ok && (int)lds_tab <= c->lds_max && !getenv("UF3_EVAL_NO_TAB");
+            const bool tab = two_pass && b->eval_tab_ok && (int)lds_tab <= c->lds_max && !uf3_env("UF3_EVAL_NO_TAB");
             const size_t lds = tab ? lds_tab : lds_plain;
             if ((int)lds > c->lds_max) return fail(c, UF3_EOVERFLOW, "3-body neighbour list does not fit in LDS");
             if (two_pass) {
@@ -1963,7 +1994,7 @@ static int eval_impl(uf3_basis *b, const uf3_frames *fr, const double *d_pos, co
                 {
                     // instance: strain derivative | list capacity 16 as a constant | candidates from the persistent lists | centre
                     // legs from per-bond tables (one set of 3-body legs, T <= 64, short lists: the usual case)
-                    const bool cap16 = cap == 16 && !getenv("UF3_EVAL_NO_CAP16");
+                    const bool cap16 = cap == 16 && !uf3_env("UF3_EVAL_NO_CAP16");
                     const int inst = (A.virial ? 1 : 0) | (cap16 ? 2 : 0) | (md_step ? 4 : 0) | (tab ? 8 : 0);
 #define UF3_EVAL_CASE(I) case I: hipLaunchKernelGGL((k_eval<false, ((I) & 1) != 0, ((I) & 2) ? 16 : 0, ((I) & 4) != 0, ((I) & 8) != 0>), eg, dim3(64), lds, st, A); break;
                     switch (inst) {
@@ -1977,7 +2008,7 @@ static int eval_impl(uf3_basis *b, const uf3_frames *fr, const double *d_pos, co
                 if (centres && !md_step) {
                     // the block's lists exist now (this launch built them, or prepare did): the halo's, then the collection
                     // pass over block + halo
-                    if (fuse || getenv("UF3_NO_HALO")) { int rh = build_halo_lists(b, P, A.n3, d_pos, (int)atom_begin, (int)atom_end, zero3); if (rh) return rh; }
+                    if (fuse || uf3_env("UF3_NO_HALO")) { int rh = build_halo_lists(b, P, A.n3, d_pos, (int)atom_begin, (int)atom_end, zero3); if (rh) return rh; }
                     A.halo_mark = c->halo.as<int>();
                 }
                 if (md_step && centres)      // every atom checks itself; the block and the atoms its centres wrote to collect
@@ -1997,7 +2028,7 @@ static int eval_impl(uf3_basis *b, const uf3_frames *fr, const double *d_pos, co
             // behind this launch (a timing event, a second mirror write) must clear `tail_signalled` so that the host waits
             // for the stream instead.
             unsigned seq = 0;
-            if (mirror && !c->timing && !getenv("UF3_NO_TAIL_SPIN")) {        // (event timing queues a record behind the chain)
+            if (mirror && !c->timing && !uf3_env("UF3_NO_TAIL_SPIN")) {        // (event timing queues a record behind the chain)
                 if (++c->eval_seq == 0) c->eval_seq = 1;
                 seq = c->eval_seq;
                 c->tail_signalled = true;
@@ -2007,7 +2038,7 @@ static int eval_impl(uf3_basis *b, const uf3_frames *fr, const double *d_pos, co
             // of 16 bytes through the runtime's staging and no wait for the stream's completion signal (~10 us of an MD step)
             int *flags_host = nullptr;
             unsigned *seq_host = nullptr;
-            if (!mirror && !flags_tail && fuse && !deferred_cap && !c->timing && !getenv("UF3_NO_TAIL_SPIN")) {
+            if (!mirror && !flags_tail && fuse && !deferred_cap && !c->timing && !uf3_env("UF3_NO_TAIL_SPIN")) {
                 HIPCHK(c, c->pin_eval.ensure(64));
                 flags_host = (int *)c->pin_eval.p; seq_host = (unsigned *)c->pin_eval.p + 4;
                 if (++c->eval_seq == 0) c->eval_seq = 1;
@@ -2076,6 +2107,7 @@ static int eval_host(uf3_basis *b, const uf3_frames *fr, const double *pos, cons
                      const double *c2, const double *c3, double *energies, double *forces, double *virials,
                      int64_t atom_begin = 0, int64_t atom_end = -1, bool centre_share = false) {
     uf3_ctx *c = b->ctx;
+    uf3_env_refresh();
     if (!energies) return fail(c, UF3_EINVAL, "uf3_eval: null energies");
     int natoms = 0;
     poll_pending(c, false);                  // (arrived verdicts on asynchronous featurizer calls: for uf3_ctx_synchronize, not for us)
@@ -2097,7 +2129,7 @@ static int eval_host(uf3_basis *b, const uf3_frames *fr, const double *pos, cons
             int cap_used = 0;
             // (up to the one-workgroup cell-list limit the last kernel writes the results into the pinned block itself; the
             // mirror's layout has the forces right behind the 7 nf sums, as d_e does)
-            const bool zero_copy = natoms <= UF3_SMALL_ATOMS && !getenv("UF3_NO_ZERO_COPY");
+            const bool zero_copy = natoms <= UF3_SMALL_ATOMS && !uf3_env("UF3_NO_ZERO_COPY");
             *(volatile unsigned *)((char *)c->pin_out.p + total + 16) = 0;
             rc = eval_impl(b, fr, c->stage_pos.as<double>(), c->d_stage_z, c1, c2, c3, d_e, forces ? d_f : nullptr,
                            virials ? d_v : nullptr, atom_begin, atom_end, &cap_used, d_flags_tail,
@@ -2414,7 +2446,7 @@ static RcclApi &rccl_api() {
     static bool tried = false;
     if (tried) return api;
     tried = true;
-    const char *names[] = {getenv("UF3_RCCL_PATH"), "librccl.so.1", "librccl.so"};
+    const char *names[] = {uf3_env("UF3_RCCL_PATH"), "librccl.so.1", "librccl.so"};
     for (int pass = 0; pass < 2 && !api.lib; pass++)                 // first: whatever is loaded already
         for (const char *nm : names) {
             if (!nm || api.lib) continue;
@@ -2435,6 +2467,7 @@ static int rccl_fail(uf3_ctx *c, const char *what, int rc) {
 }
 
 extern "C" int uf3_comm_unique_id(uf3_ctx *c, void *id128) {
+    uf3_env_refresh();
     if (!c || !id128) return fail(c, UF3_EINVAL, "uf3_comm_unique_id: null argument");
     RcclApi &r = rccl_api();
     if (!r.lib) return fail(c, UF3_EHIP, r.why);
@@ -2444,6 +2477,7 @@ extern "C" int uf3_comm_unique_id(uf3_ctx *c, void *id128) {
 }
 
 extern "C" int uf3_comm_init(uf3_ctx *c, int n_ranks, int rank, const void *id128) {
+    uf3_env_refresh();
     if (!c || !id128 || n_ranks < 1 || rank < 0 || rank >= n_ranks) return fail(c, UF3_EINVAL, "uf3_comm_init: bad argument");
     RcclApi &r = rccl_api();
     if (!r.lib) return fail(c, UF3_EHIP, r.why);
@@ -2614,6 +2648,7 @@ static int launch_gram_tiled(uf3_ctx *c, const double *dx, const double *dy, int
 
 extern "C" int uf3_gram_dev(uf3_ctx *c, const double *dx, const double *dy, int64_t n_rows, int32_t n_feat, int64_t ld,
                             int accumulate, double *d_gram, double *d_ord) {
+    uf3_env_refresh();
     if (!c) return fail(nullptr, UF3_EINVAL, "null ctx");
     if (!dx || !d_gram || n_feat < 1 || ld < n_feat || n_rows < 0) return fail(c, UF3_EINVAL, "uf3_gram: bad argument");
     HIPCHK(c, hipSetDevice(c->device));
@@ -2628,7 +2663,7 @@ extern "C" int uf3_gram_dev(uf3_ctx *c, const double *dx, const double *dy, int6
     // (up to two column ranges the patches are mostly padding: one wave per 32 x 32 tile with direct loads is faster there --
     // measured 0.62 against 0.81 ms at F = 73, 960 k rows)
     // (and below ~64 k rows the row chunks get too short for the slab pipeline: 0.24 against 0.21 ms at 30 001 x 425)
-    if (n_feat > 128 && n_rows >= 65536 && !getenv("UF3_GRAM_DIRECT")) {
+    if (n_feat > 128 && n_rows >= 65536 && !uf3_env("UF3_GRAM_DIRECT")) {
         // LDS-tiled kernel: patches of 64 x 64 packed into workgroups (at most four patches on at most four column ranges)
         Timed tm(c, T_GRAM);
         rc = launch_gram_tiled(c, dx, dy, n_rows, n_rows, n_feat, ld, d_gram, d_ord, nullptr, nullptr, nullptr, n_feat);
@@ -2637,7 +2672,7 @@ extern "C" int uf3_gram_dev(uf3_ctx *c, const double *dx, const double *dy, int6
         HIPCHK(c, hipGetLastError());
         return UF3_OK;
     }
-    if (n_feat <= GS_LDW && n_rows >= 16384 && !getenv("UF3_GRAM_DIRECT")) {
+    if (n_feat <= GS_LDW && n_rows >= 16384 && !uf3_env("UF3_GRAM_DIRECT")) {
         // narrow matrices: slabs of 32 rows through LDS, every row read once (k_gram_small); about eight workgroups per CU
         const int64_t want_blocks = (int64_t)c->n_cu * 8;
         int64_t rpb = (n_rows + want_blocks - 1) / want_blocks;
@@ -2687,6 +2722,7 @@ extern "C" int uf3_gram_dev(uf3_ctx *c, const double *dx, const double *dy, int6
 
 extern "C" int uf3_gram_force_rows_dev(uf3_basis *b, const double *d_x_f, const double *d_y_f, const int32_t *d_z, int64_t n_atoms,
                                        int64_t ld, int accumulate, double *d_gram, double *d_ord) {
+    uf3_env_refresh();
     if (!b) return fail(nullptr, UF3_EINVAL, "null basis");
     uf3_ctx *c = b->ctx;
     const int F = b->host.F, S = b->host.S;
@@ -2696,7 +2732,7 @@ extern "C" int uf3_gram_force_rows_dev(uf3_basis *b, const double *d_x_f, const 
     for (int sp = 0; sp < S; sp++) widest = std::max(widest, b->sp_ncols[sp]);
     // One species, a narrow matrix or short segments: the plain product (same result; the zero columns are multiplied).  Also
     // when no species leaves out at least one 64-column range's worth of columns.
-    if (S < 2 || F <= 128 || 3 * n_atoms / S < 65536 || (widest + 63) / 64 >= (F + 63) / 64 || getenv("UF3_GRAM_DENSE"))
+    if (S < 2 || F <= 128 || 3 * n_atoms / S < 65536 || (widest + 63) / 64 >= (F + 63) / 64 || uf3_env("UF3_GRAM_DENSE"))
         return uf3_gram_dev(c, d_x_f, d_y_f, 3 * n_atoms, F, ld, accumulate, d_gram, d_ord);
     HIPCHK(c, hipSetDevice(c->device));
     int rc = ensure_frag(c);
@@ -2791,6 +2827,7 @@ extern "C" int uf3_fit_pack_dev(uf3_ctx *c, int32_t n_feat, const double *d_flat
 static int neighbors_impl(uf3_basis *b, const uf3_frames *fr, const double *pos, const int32_t *z,
                           int64_t *pair_count, int64_t *pair_ij, double *pair_geo, int64_t pair_cap, int64_t *n3_count,
                           int64_t *n3_ij, int64_t n3_cap) {
+    uf3_env_refresh();
     if (!b) return fail(nullptr, UF3_EINVAL, "null basis");
     uf3_ctx *c = b->ctx;
     if (!fr || fr->n_frames != 1) return fail(c, UF3_EINVAL, "the neighbour queries take exactly one frame");
