@@ -126,8 +126,11 @@ __device__ __forceinline__ int f3_eval(const double *rows, const Feat3Leg &lg, d
 // (CAP: the list capacity as a compile-time constant -- 16, what a tuned context settles on for bcc / fcc cells -- or 0 for
 // the launch's run-time value: with it every per-wave LDS array sits at a constant offset from two bases, offsets that go into
 // the LDS instructions' immediate fields instead of scalar registers the kernel has too few of)
+#ifndef F3_WIDE_MINW
+#define F3_WIDE_MINW 2     // waves per SIMD the wide-window instances (NR > 1) are bounded for
+#endif
 template <bool WANT_E, int EF, int NR, int CAP = 0>
-__global__ void __launch_bounds__(WPB * WAVE, (NR == 1 ? 4 : 2))
+__global__ void __launch_bounds__(WPB * WAVE, (NR == 1 ? 4 : F3_WIDE_MINW))
 k_featurize3(Feat3Args A) {
     typedef F3Cfg<EF, NR> Cfg;
     constexpr int RS_C = Cfg::RS_C, RS_N = Cfg::RS_N, NREC = Cfg::NREC, PS = Cfg::PS, EFP = Cfg::EFP;
