@@ -116,8 +116,6 @@ int uf3_ctx_timing_read(uf3_ctx *ctx, double *featurize_ms, int64_t *featurize_l
  * results do not depend on when the lists were built.  They are rebuilt when the batch layout (offsets, cells, pbc), the basis
  * or a species changes, and when an atom has moved more than skin / 2 from where they were built (checked on the device in
  * every call; past 0.7 of that the next call rebuilds first, past all of it the call repeats itself on new lists).
- * A layout that changes on every call would pay a list build per call: after three builds that served a single call each, the
- * next sixteen calls take the rebuild-everything route before the lists get another chance.
  * uf3_ctx_md_stats: list builds | calls served from lists | calls repeated because an atom outran the skin. */
 int uf3_ctx_md_skin(uf3_ctx *ctx, double skin);
 int uf3_ctx_md_stats(uf3_ctx *ctx, int64_t *builds, int64_t *steps, int64_t *redone);

@@ -1080,40 +1080,6 @@ def test_md_route_on_small_cells_slabs_clusters_and_batches(case):
     ctx.md_skin(0.0)
 
 
-def test_md_route_steps_aside_when_every_call_brings_another_layout():
-    """A skin set by hand on a loop whose cell changes every call (or two systems taking turns on one context): after three list
-    builds that served one call each the context goes the rebuild-everything route for sixteen calls instead of paying a build
-    per call; results are the plain route's to rounding throughout, and lists come back once the layout stays."""
-    basis = synthetic.notebook_basis(['W'])
-    model, coeff = _random_model(basis, 25)
-    calc_md = calculator.UFCalculator(model, md_skin=0.4)
-    calc_plain = calculator.UFCalculator(model, md_skin=0.0)
-    start = synthetic.lattice_frame("bcc", (4, 4, 4), 3.165, [74], seed=3)
-    ctx = _lib.get_context(None)
-    for _ in range(2):
-        calc_plain.evaluate_frames([start])
-    ctx.md_skin(0.0)
-    s0 = ctx.md_stats()
-    results, frames = [], []
-    for k in range(30):
-        scale = 1.0 + 1e-3 * (k + 1)
-        a = Atoms(numbers=start.get_atomic_numbers(), positions=start.get_positions() * scale, cell=np.asarray(start.get_cell()) * scale, pbc=True)
-        frames.append(a)
-        results.append(calc_md.evaluate_frames([a]))
-    s1 = ctx.md_stats()
-    assert s1["builds"] - s0["builds"] <= 12, s1["builds"] - s0["builds"]      # (not thirty)
-    for a, got in zip(frames, results):
-        ref = calc_plain.evaluate_frames([a])
-        assert abs(got[0][0] - ref[0][0]) <= 1e-12 * abs(ref[0][0]) and rel_err(got[1], ref[1]) < 1e-12
-    ctx.md_skin(0.0)
-    b0 = ctx.md_stats()
-    for _ in range(25):                                                          # the layout stays: lists again after the pause
-        calc_md.evaluate_frames([frames[-1]])
-    b1 = ctx.md_stats()
-    assert b1["steps"] - b0["steps"] >= 5 and b1["builds"] - b0["builds"] <= 2
-    ctx.md_skin(0.0)
-
-
 def test_md_route_rebuilds_on_layout_species_and_cell_changes():
     """The lists are tied to (basis, offsets, cells, pbc, species): any change rebuilds them instead of serving stale neighbours;
     a batch of several frames runs on lists as well.  Each result against the plain route."""

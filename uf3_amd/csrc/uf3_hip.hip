@@ -116,8 +116,6 @@ struct uf3_ctx {
         size_t inbox_zeroed = 0;                          // bytes of inbox known to hold no stamp of a future launch
         size_t geo_bytes = 0;
         long long builds = 0, steps = 0, redone = 0;
-        long long steps_at_build = 0;   // `steps` when the lists were last built: lists that serve one call each are not worth building
-        int wasted = 0, pause = 0;      // consecutive builds that served a single call | calls left on the plain route after three of those
     } md;
     // RCCL communicator of this rank (uf3_comm_init): the library is opened at run time (no link dependency), see rccl_api()
     void *comm = nullptr;
@@ -1810,7 +1808,6 @@ static int md_build(uf3_basis *b, const uf3_frames *fr, const double *d_pos, con
     md.pbc.assign(fr->pbc, fr->pbc + 3 * (size_t)nf);
     md.valid = true;
     md.builds++;
-    md.steps_at_build = md.steps;
     return UF3_OK;
 }
 
@@ -1831,7 +1828,7 @@ static void md_prepared(const uf3_ctx *c, Prepared &P) {
 extern "C" int uf3_ctx_md_skin(uf3_ctx *c, double skin) {
     if (!c) return fail(nullptr, UF3_EINVAL, "null ctx");
     if (!(skin >= 0.0) || skin > 4.0) return fail(c, UF3_EINVAL, "uf3_ctx_md_skin: skin must lie in [0, 4] Angstrom");
-    if (skin != c->md.skin) { c->md.valid = false; c->md.cap = 0; c->md.wasted = 0; c->md.pause = 0; }
+    if (skin != c->md.skin) { c->md.valid = false; c->md.cap = 0; }
     c->md.skin = skin;
     return UF3_OK;
 }
@@ -1870,16 +1867,7 @@ static int eval_impl(uf3_basis *b, const uf3_frames *fr, const double *d_pos, co
     int rc;
     hipStream_t st = c->stream;
     // MD route: the candidates of every atom from the context's persistent lists instead of a cell-list walk (see md_build)
-    bool md_wanted = c->md.skin > 0.0 && fuse && (whole || centres) && !uf3_env("UF3_NO_MD");     // (a block of centres too: round 5)
-    if (md_wanted && !c->md.stale && !md_key_matches(c->md, b, fr)) {
-        // another layout than the lists': when that happens call after call (a cell that changes every step, two models taking
-        // turns on one context) every call would pay a list build for nothing -- after three builds that served one call each,
-        // sixteen calls go the rebuild-everything route before the lists get another chance
-        if (c->md.valid && c->md.steps - c->md.steps_at_build <= 1) c->md.wasted++; else c->md.wasted = 0;
-        if (c->md.wasted >= 3) { c->md.wasted = 0; c->md.pause = 16; }
-    }
-    if (md_wanted && c->md.pause > 0) { c->md.pause--; md_wanted = false; c->md.valid = false; }
-    const bool md_step = md_wanted;
+    const bool md_step = c->md.skin > 0.0 && fuse && (whole || centres) && !uf3_env("UF3_NO_MD");     // (a block of centres too: round 5)
     c->md_step = md_step;
     if (md_step) {
         HIPCHK(c, hipSetDevice(c->device));
