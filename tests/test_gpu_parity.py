@@ -1321,7 +1321,10 @@ def test_atom_range_shares_add_up_to_the_frame():
     else:
         assert np.array_equal(e_s, e) and np.array_equal(f_s, f) and np.array_equal(v_s, v)
     e_b2, f_b2, _ = calc.evaluate_frames(big)
-    assert np.array_equal(e_b, e_b2) and np.array_equal(f_b, f_b2) and np.array_equal(f_b[off_b[7]:off_b[8]], f)
+    if float(os.environ.get("UF3_MD_SKIN", "0") or 0) > 0:     # (forced lists: e_b2 ran on them, e_b -- separate list build -- could not)
+        assert np.allclose(e_b, e_b2, rtol=1e-12) and rel_err(f_b, f_b2) < 1e-12 and rel_err(f_b[off_b[7]:off_b[8]], f) < 1e-12
+    else:
+        assert np.array_equal(e_b, e_b2) and np.array_equal(f_b, f_b2) and np.array_equal(f_b[off_b[7]:off_b[8]], f)
     for r, (_, fs, _) in enumerate(shares):
         lo, hi = parallel.shard_range(n, r, world)
         assert np.array_equal(fs[lo:hi], f_g[lo:hi])
