@@ -14,9 +14,15 @@
 //   k_featurize3<E, EF, NR>   (uf3_feat3.h) the 3-body force rows of a basis that qualifies (mode bit 12), by bond
 //                     factorisation on the vector units: the launch the headline runs; the matrix-core modes above
 //                     then serve energy-only calls, batches with atoms far outside their cell and the other bases
-//   k_eval<GATHER, VIR>   energy + forces (+ virial) of a fitted model        one wave / atom: every triplet once at its
-//                     centre + k_eval_collect (whole batch), or gathered at its three atoms (a block of atoms)
-//   k_frame_sum       per-frame sums of the per-atom energies / virial shares
+//   k_eval<GATHER, VIR, CAP, MD, TAB>   energy + forces (+ virial) of a fitted model     one wave / atom: every triplet once at its
+//                     centre + k_eval_collect (whole batch, a block of centres), or gathered at its three atoms (a block of
+//                     atoms).  MD: the candidates from the context's persistent lists (k_build_sup + k_sup_reverse, built with
+//                     a skin) instead of a cell-list walk, the neighbours' force shares through a stamped inbox
+//                     (k_eval_collect_md / k_eval_collect_md_halo).  TAB: the centre legs of the triplets from per-bond tables,
+//                     leg n's knot records in LDS: four waves per SIMD
+//   k_md_fetch        a small batch's staged block out of the caller's pinned memory (MD steps: no cell-list kernel to do it)
+//   k_frame_sum       per-frame sums of the per-atom energies / virial shares; the last kernel of an evaluator call: status
+//                     words and the call's sequence number into the pinned block the host polls
 //   k_gram_tiled / k_gram_mfma   X^T X on the fp64 matrix cores, X^T y riding along in the diagonal workgroups / waves
 //
 // Formulation: every atom m GATHERS all pair terms and all triplet terms it takes part in --
