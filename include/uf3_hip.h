@@ -148,7 +148,8 @@ int uf3_fit_info(const uf3_fit *fit, int64_t *n_chunks, double *n_energy_rows, d
 /* the pieces into a device buffer of the caller's (2 F^2 + 2 F + 6 doubles; zeroed by uf3_fit_reset, not here) instead of the
  * accumulator's own: frames given as host arrays and batches already resident in HBM then add up in one place.  NULL: undo. */
 int uf3_fit_use_flat(uf3_fit *fit, double *d_flat);
-/* a call's first chunk holds this fraction of max_atoms_per_chunk (default 0.25: the GPU starts sooner; 1: equal chunks) */
+/* a call's first chunk holds this fraction of max_atoms_per_chunk and the following ones double it up to the limit (default
+ * 0.125: the GPU starts after a short pack and later packs hide behind the previous chunk's kernels; 1: equal chunks) */
 int uf3_fit_first_chunk(uf3_fit *fit, double fraction);
 
 /* RCCL behind the C ABI (round 5; SURVEY 8b's `uf3_gram_allreduce`).  One process per GPU.  The one exchange of the path is

@@ -293,7 +293,7 @@ def test_device_resident_fit_pipeline_matches_host_rows():
 
 def test_config4_fit_in_chunks_10k_atom_tungsten_frames():
     """BASELINE config 4 on one GPU's share: 10 000-atom W frames (F = 73) x 66 through the device-resident
-    accumulator in four chunks == the oracle's fit on the downloaded rows (least_squares.py:274-321)."""
+    accumulator in five chunks == the oracle's fit on the downloaded rows (least_squares.py:274-321)."""
     from uf3_amd import pipeline
     basis = synthetic.notebook_basis(['W'])
     n_frames = 66
@@ -312,7 +312,7 @@ def test_config4_fit_in_chunks_10k_atom_tungsten_frames():
     model = ls.WeightedLinearModel(basis, regularizer=reg)
     acc = pipeline.DeviceFitAccumulator(model, fz, max_atoms_per_chunk=250000)
     acc.add_frames(frames, energies, forces)
-    assert acc.n_chunks == 4                 # (6 frames -- a call's first chunk is a quarter of the size --, then 25 + 25 + 10)
+    assert acc.n_chunks == 5                 # (chunks grow from an eighth of the limit: 3 + 6 + 12 + 25 + 20 frames)
     pieces = acc.pieces()
     model.fit_from_pieces(pieces, weight=0.3)
     n = x_e[:, :1].sum(axis=1)

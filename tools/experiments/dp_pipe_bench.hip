@@ -25,6 +25,16 @@ __global__ void __launch_bounds__(768) k(int kinds, int iters, unsigned long lon
             a3 = __builtin_amdgcn_mfma_f64_16x16x4f64(y, y, a3, 0, 0, 0);
         }
         out = a0[0] + a1[1] + a2[2] + a3[3];
+    } else if (grp == 3) {                               // q: the four-block 4x4x4 form (one double per lane in and out)
+        double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+        double x = threadIdx.x * 1e-3, y = 1.0 + x;
+        for (int i = 0; i < iters; i++) {
+            a0 = __builtin_amdgcn_mfma_f64_4x4x4f64(x, y, a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f64_4x4x4f64(y, x, a1, 0, 0, 0);
+            a2 = __builtin_amdgcn_mfma_f64_4x4x4f64(x, x, a2, 0, 0, 0);
+            a3 = __builtin_amdgcn_mfma_f64_4x4x4f64(y, y, a3, 0, 0, 0);
+        }
+        out = a0 + a1 + a2 + a3;
     } else if (grp == 1) {
         double f[8];
         for (int q = 0; q < 8; q++) f[q] = threadIdx.x * 1e-3 + q;
@@ -49,10 +59,10 @@ int main() {
     unsigned long long *cyc; double *sink;
     hipMalloc(&cyc, 64); hipMalloc(&sink, 8);
     const int iters = 20000;
-    const char *cfgs[] = {"m--", "f--", "i--", "mf-", "mi-", "fi-", "mfi", "fff", "iii", "mmm", "mff", "ffi"};
+    const char *cfgs[] = {"q--", "qf-", "qi-", "qqq", "m--", "f--", "i--", "mf-", "mi-", "fi-", "mfi", "fff", "iii", "mmm", "mff", "ffi"};
     for (const char *cfg : cfgs) {
         int kinds = 0;
-        for (int q = 0; q < 3; q++) kinds |= (cfg[q] == 'm' ? 0 : cfg[q] == 'f' ? 1 : cfg[q] == 'i' ? 2 : 15) << (4 * q);
+        for (int q = 0; q < 3; q++) kinds |= (cfg[q] == 'm' ? 0 : cfg[q] == 'f' ? 1 : cfg[q] == 'i' ? 2 : cfg[q] == 'q' ? 3 : 15) << (4 * q);
         hipMemset(cyc, 0, 64);
         hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
         hipEventRecord(e0);
@@ -63,6 +73,7 @@ int main() {
         printf("%s: %.3f ms;", cfg, ms);
         for (int q = 0; q < 3; q++) {
             if (cfg[q] == 'm') printf("  wave %d mfma %.1f cycles/instr", q, (double)h[q] / (4.0 * iters));
+            if (cfg[q] == 'q') printf("  wave %d mfma4x4x4 %.1f cycles/instr", q, (double)h[q] / (4.0 * iters));
             if (cfg[q] == 'f') printf("  wave %d fma64 %.2f", q, (double)h[q] / (8.0 * iters));
             if (cfg[q] == 'i') printf("  wave %d int-mad %.2f", q, (double)h[q] / (8.0 * iters));
         }

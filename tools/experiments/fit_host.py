@@ -6,7 +6,9 @@ import numpy as np, torch
 from uf3_amd import synthetic, pipeline
 from uf3_amd.regression import least_squares as ls
 from uf3_amd.representation import process
-for els, zs in ((['W'], [74]), (['Mo', 'W'], [42, 74])):
+_CASES = ((["W"], [74]), (["Mo", "W"], [42, 74]))
+if os.environ.get("ONLY"): _CASES = tuple(c for c in _CASES if "".join(c[0]) == os.environ["ONLY"])
+for els, zs in _CASES:
     basis = synthetic.notebook_basis(els)
     frames = [synthetic.lattice_frame("bcc", (10, 20, 25), 3.165, zs, 5000 + k) for k in range(int(os.environ.get('NF', 64)))]
     rng = np.random.default_rng(3)

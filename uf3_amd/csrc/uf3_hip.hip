@@ -7,6 +7,7 @@
 #include <map>
 #include <string>
 #include <vector>
+#include <thread>
 
 #include <hip/hip_runtime.h>
 #include <rocprim/rocprim.hpp>
@@ -2235,7 +2236,8 @@ struct uf3_fit {
     bool with_forces = true;
     int F = 0;
     int64_t max_atoms = 320000;
-    double first_fraction = 0.25;
+    double first_fraction = 0.125;
+    int pack_threads = 4;
     Buf flat, xe, xf, frozen_idx, frozen_c;
     double *flat_ext = nullptr;      // the caller's device buffer for the pieces instead of `flat` (uf3_fit_use_flat)
     int n_frozen = 0;
@@ -2271,7 +2273,8 @@ extern "C" int uf3_fit_reset(uf3_fit *f) {
 // the pieces into a device buffer of the caller's (2 F^2 + 2 F + 6 doubles, [G_e | G_f | o_e | o_f | m_e | m_f]; not zeroed here:
 // uf3_fit_reset does that) -- so that frames given as host arrays and batches already resident in HBM (uf3_featurize_dev +
 // uf3_gram*_dev by the caller) add up in one place.  NULL: back to the accumulator's own buffer.
-// a call's first chunk holds this fraction of max_atoms_per_chunk (default 0.25: the GPU starts sooner; 1: chunks of equal size)
+// a call's first chunk holds this fraction of max_atoms_per_chunk and the following ones double it up to the limit (default 0.125:
+// the GPU starts sooner; 1: chunks of equal size)
 extern "C" int uf3_fit_first_chunk(uf3_fit *f, double fraction) {
     if (!f || !(fraction > 0.0) || fraction > 1.0) return fail(f ? f->c : nullptr, UF3_EINVAL, "uf3_fit_first_chunk: fraction in (0, 1]");
     f->first_fraction = fraction;
@@ -2293,6 +2296,7 @@ extern "C" int uf3_fit_create(uf3_basis *b, int with_forces, int64_t max_atoms_p
     f->b = b; f->c = c; f->with_forces = with_forces != 0; f->F = b->host.F;
     if (max_atoms_per_chunk > 0) f->max_atoms = max_atoms_per_chunk;
     f->n_frozen = n_frozen;
+    if (const char *e = uf3_env("UF3_FIT_PACK_THREADS")) f->pack_threads = std::max(1, std::min(16, atoi(e)));
     auto bail = [&](int rc) { uf3_fit_destroy(f); return rc; };
     if (f->flat.ensure(8 * (2 * (size_t)f->F * f->F + 2 * (size_t)f->F + 6)) != hipSuccess) return bail(fail(c, UF3_ENOMEM, "uf3_fit_create: out of device memory"));
     if (n_frozen) {
@@ -2325,10 +2329,12 @@ extern "C" int uf3_fit_add(uf3_fit *f, int32_t n_frames, const int64_t *atom_cou
     const size_t F2 = (size_t)F * F;
     double *flat = f->flat_ext ? f->flat_ext : f->flat.as<double>(), *gram_e = flat, *gram_f = flat + F2, *ord_e = flat + 2 * F2, *ord_f = ord_e + F, *mom = ord_f + F;
     int start = 0;
-    bool first = true;
+    // chunk sizes grow geometrically from first_fraction of the limit: the GPU starts after a short pack, and the pack of
+    // chunk k + 1 (host, about half the GPU's time per frame on a one-species basis) hides behind the kernels of chunk k
+    double fraction = f->first_fraction;
     while (start < n_frames) {
-        const int64_t limit = first ? std::max<int64_t>(1, (int64_t)(f->max_atoms * f->first_fraction)) : f->max_atoms;
-        first = false;
+        const int64_t limit = fraction < 1.0 ? std::max<int64_t>(1, (int64_t)(f->max_atoms * fraction)) : f->max_atoms;
+        fraction = std::min(1.0, 2.0 * fraction);
         int stop = start;
         int64_t atoms = 0;
         while (stop < n_frames && (stop == start || atoms + atom_counts[stop] <= limit)) {
@@ -2347,19 +2353,30 @@ extern "C" int uf3_fit_add(uf3_fit *f, int32_t n_frames, const int64_t *atom_cou
         double *h = (double *)st.host.p, *h_pos = h, *h_yf = h + A3, *h_ye = h + 2 * A3, *h_cnt = h_ye + nf;
         int32_t *h_z = (int32_t *)(h_cnt + nf);
         std::vector<int64_t> offsets(nf + 1, 0);
-        int64_t k = 0;
         for (int i = 0; i < nf; i++) {
             const int64_t n = atom_counts[start + i];
             if (n && (!pos[start + i] || !z[start + i] || (f->with_forces && !forces[start + i]))) return fail(c, UF3_EINVAL, "uf3_fit_add: null frame array");
-            std::memcpy(h_pos + 3 * k, pos[start + i], 24 * (size_t)n);
-            if (z_is_int64) { const int64_t *zz = (const int64_t *)z[start + i]; for (int64_t q = 0; q < n; q++) h_z[k + q] = (int32_t)zz[q]; }
-            else std::memcpy(h_z + k, z[start + i], 4 * (size_t)n);
-            if (f->with_forces) std::memcpy(h_yf + 3 * k, forces[start + i], 24 * (size_t)n);
-            h_cnt[i] = (double)n;
-            h_ye[i] = energies[start + i] / (double)n;          // per-atom normalisation of the targets (least_squares.py:697-700)
-            k += n;
-            offsets[i + 1] = k;
+            offsets[i + 1] = offsets[i] + n;
         }
+        auto pack = [&](int i0, int i1) {
+            for (int i = i0; i < i1; i++) {
+                const int64_t n = atom_counts[start + i], k = offsets[i];
+                std::memcpy(h_pos + 3 * k, pos[start + i], 24 * (size_t)n);
+                if (z_is_int64) { const int64_t *zz = (const int64_t *)z[start + i]; for (int64_t q = 0; q < n; q++) h_z[k + q] = (int32_t)zz[q]; }
+                else std::memcpy(h_z + k, z[start + i], 4 * (size_t)n);
+                if (f->with_forces) std::memcpy(h_yf + 3 * k, forces[start + i], 24 * (size_t)n);
+                h_cnt[i] = (double)n;
+                h_ye[i] = energies[start + i] / (double)n;      // per-atom normalisation of the targets (least_squares.py:697-700)
+            }
+        };
+        // big chunks are packed by a few threads (a single core copies ~8 GB/s into pinned memory: 2 ms per 32 frames of 10 k atoms)
+        const int n_thr = (atoms >= 100000 && nf >= 2) ? std::min(f->pack_threads, nf) : 1;
+        if (n_thr > 1) {
+            std::vector<std::thread> thr;
+            for (int t = 1; t < n_thr; t++) thr.emplace_back(pack, (int)((int64_t)nf * t / n_thr), (int)((int64_t)nf * (t + 1) / n_thr));
+            pack(0, nf / n_thr);
+            for (auto &t : thr) t.join();
+        } else pack(0, nf);
         if (st.consumed_live) HIPCHK(c, hipStreamWaitEvent(f->copy_stream, st.consumed, 0));            // (the device block is free again)
         HIPCHK(c, hipMemcpyAsync(st.dev.p, st.host.p, 8 * n_block, hipMemcpyHostToDevice, f->copy_stream));
         HIPCHK(c, hipEventRecord(st.copied, f->copy_stream));

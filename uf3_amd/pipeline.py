@@ -26,7 +26,7 @@ from uf3_amd import _lib
 
 
 class DeviceFitAccumulator:
-    def __init__(self, model, featurizer, device=None, max_atoms_per_chunk=320000, with_forces=True, first_chunk_fraction=0.25):
+    def __init__(self, model, featurizer, device=None, max_atoms_per_chunk=320000, with_forces=True, first_chunk_fraction=0.125):
         """with_forces: whether force rows take part in the fit.  It is a property of the FIT, not of the frames a
         rank happens to hold: a rank with an empty shard still contributes (zero) force pieces."""
         import torch
@@ -45,7 +45,7 @@ class DeviceFitAccumulator:
         self.m_e = self.flat[o:o + 3]; o += 3
         self.m_f = self.flat[o:o + 3]
         self.max_atoms = int(max_atoms_per_chunk)
-        self.first_fraction = float(first_chunk_fraction)     # (a call's first chunk is smaller: the GPU starts sooner)
+        self.first_fraction = float(first_chunk_fraction)     # (a call's chunks grow from this fraction of the limit, doubling: the GPU starts sooner)
         self.n_chunks = 0
         self._counts = [0.0, 0.0]
         mask = np.asarray(model.mask)
