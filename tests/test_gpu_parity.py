@@ -758,6 +758,39 @@ def test_bond_factorised_launch_at_list_capacities_24_and_32(lattice, a, r3, wan
     _lib.drop_device_basis(basis)
 
 
+def test_instance_for_short_lists_is_picked_on_the_device_when_the_context_remembers_a_dense_batch(monkeypatch, capfd):
+    """A context's list capacity only grows (a dense batch leaves it at 32 or more), and a context's first call runs at an
+    estimate: k_featurize3's instance laid out for 16 entries is then chosen on the device from the batch's longest list
+    (two launches, one leaves at once) -- rows against the oracle, and the same rows as a context that never saw the dense
+    batch (angles.py:142-286)."""
+    basis = synthetic.notebook_basis(['Mo', 'W'])
+    dense = synthetic.lattice_frame("bcc", (5, 5, 5), 2.4, [42, 74], seed=5, rattle=0.03, strain=0.0)
+    frames = [synthetic.lattice_frame("bcc", (4, 4, 5), 3.165, [42, 74], seed=90 + k) for k in range(2)]
+    monkeypatch.setenv("UF3_DEBUG_LDS", "1")                      # (read when the context is made: the launches say what they are)
+    monkeypatch.setattr(_lib, "_contexts", {})
+    fz = process.BasisFeaturizer(basis)
+    assert fz._dev()[1].featurizer_modes & 0x1000
+    _, n3 = fz.neighbor_indices(dense)
+    assert np.bincount(n3[:, 0]).max() > 16
+    _, n3 = fz.neighbor_indices(frames[0])
+    assert np.bincount(n3[:, 0]).max() <= 16
+    ob = O.OracleBasis(basis)
+    plain = fz.featurize_frames(frames)
+    plain = fz.featurize_frames(frames)                            # (tuned: capacity 16, one launch)
+    xd = fz.featurize_frames([dense])                              # the capacity grows
+    ref = O.featurize(ob, dense)
+    assert rel_err(xd[0][0], ref["xe"]) < TOL and rel_err(xd[1], ref["xf"]) < TOL
+    capfd.readouterr()
+    x_e, x_f, off = fz.featurize_frames(frames)
+    said = capfd.readouterr().err
+    assert "cap 16 (lists" in said and "selection 1" in said and "selection 2" in said, said
+    for k, atoms in enumerate(frames):
+        ref = O.featurize(ob, atoms)
+        assert rel_err(x_e[k], ref["xe"]) < TOL and rel_err(x_f[off[k]:off[k + 1]], ref["xf"]) < TOL
+    assert np.array_equal(x_f, plain[1])                           # the very same instance ran
+    _lib.drop_device_basis(basis)
+
+
 def test_three_species_wide_blocks():
     """ternary, lead 0: 18 trio blocks of 139/233 columns (several 64-column chunks, nsrc 1 and 2)."""
     d, meta, atoms = load_case("case_ternary24_slab")

@@ -55,6 +55,8 @@ struct Feat3Args {
     double *x_e, *x_f;
     int ld;                    // doubles between consecutive force rows (>= F)
     int natoms, atoms_per_block, e_direct;
+    const int *sel;            // instance selection on the device (uf3_featurize_dev launches two instances back to back when the
+    int sel_mode, sel_cap;     // context's list capacity is above 16): 0 always run; 1 run iff *sel <= sel_cap; 2 iff *sel > sel_cap
     int skip;                  // ablations (-DUF3_ABLATE builds only): 1 stage 1, 2 stage 2, 4 centre walk, 8 neighbour walk, 16 fold + stores, 32 bond tables, 64 leg evaluations of the walks
 };
 
@@ -136,7 +138,14 @@ k_featurize3(Feat3Args A) {
     constexpr int RS_C = Cfg::RS_C, RS_N = Cfg::RS_N, NREC = Cfg::NREC, PS = Cfg::PS, EFP = Cfg::EFP;
     extern __shared__ __align__(16) unsigned char smem[];
     const BasisDev *B = A.B;
+    // (cap: what the LDS arrays are laid out for -- the longest list this instance serves; ent_stride: entries per atom in the
+    // batch's list array, the context's capacity)
     const int F = load_const(&B->F), S = load_const(&B->S), n_trios = load_const(&B->T), cap = CAP > 0 ? CAP : A.n3.cap;
+    const int ent_stride = A.n3.cap;
+    if (A.sel_mode) {
+        const int seen = load_const(A.sel);                       // the batch's longest 3-body list (the list build behind us)
+        if ((seen <= A.sel_cap) != (A.sel_mode == 1)) return;
+    }
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // ---- LDS carve (feat3_lds_bytes on the host) ----------------------------------------------------------------------
@@ -226,7 +235,7 @@ k_featurize3(Feat3Args A) {
         const int n_own = load_const(A.n3.cnt + m);
         wave_sync();
         for (int e = lane; e < n_own; e += WAVE) {
-            const N3Entry en = A.n3.ent[(size_t)m * cap + e];
+            const N3Entry en = A.n3.ent[(size_t)m * ent_stride + e];
             ox[e] = en.dx; oy[e] = en.dy; oz[e] = en.dz; orr[e] = en.r; oir[e] = 1.0 / en.r;
             int s0, s1, s2;
             unpack3(en.shiftc, s0, s1, s2);
@@ -436,7 +445,7 @@ k_featurize3(Feat3Args A) {
                         const int kk = nbase[lo] + (q - noff[lo]);
                         const int pc = oparent[e];
                         const double oex = ox[e], oey = oy[e], oez = oz[e], oer = orr[e];
-                        const N3Entry ke = A.n3.ent[(size_t)pc * cap + kk];
+                        const N3Entry ke = A.n3.ent[(size_t)pc * ent_stride + kk];
                         valid = !(ke.parent == m && ke.shiftc == oshift[e]);                  // k is m itself
                         const double ex = oex + ke.dx, ey = oey + ke.dy, ez = oez + ke.dz;   // m -> k
                         const double rn = norm3_leg(ex, ey, ez), rk = ke.r;

@@ -89,7 +89,7 @@ struct uf3_ctx {
     bool frag_ready = false;
     int32_t *d_stage_z = nullptr;       // species of the staged batch (tail of stage_pos)
     // environment switches of the featurizer's asynchronous path, read once (uf3_ctx_create)
-    bool env_no_feat3 = false, env_f3_no_cap16 = false, env_debug_lds = false;
+    bool env_no_feat3 = false, env_f3_no_cap16 = false, env_f3_no_select = false, env_debug_lds = false;
     int env_f3_bps = 24;
     unsigned eval_seq = 0;              // sequence number of the last small evaluator call whose tail kernel signals through the pinned block
     bool tail_signalled = false;        // ... and whether the last eval_impl's k_frame_sum signals
@@ -234,6 +234,7 @@ extern "C" int uf3_ctx_create(int device, uf3_ctx **out) {
     c->n_cu = prop.multiProcessorCount;
     c->env_no_feat3 = uf3_env("UF3_NO_FEAT3") != nullptr;
     c->env_f3_no_cap16 = uf3_env("UF3_F3_NO_CAP16") != nullptr;
+    c->env_f3_no_select = uf3_env("UF3_F3_NO_SELECT") != nullptr;
     c->env_debug_lds = uf3_env("UF3_DEBUG_LDS") != nullptr;
     if (uf3_env("UF3_F3_BPS")) c->env_f3_bps = std::max(1, atoi(uf3_env("UF3_F3_BPS")));
     if (std::string(prop.gcnArchName).find("gfx950") == std::string::npos) {
@@ -1395,6 +1396,7 @@ static int featurize_dev_impl(uf3_basis *b, const uf3_frames *fr, const double *
     // the block-shared energy row costs 8 F bytes of LDS: past 48 KB the contributions go straight to HBM instead
     A.e_direct = (want_e && (size_t)F * 8 > 48 * 1024) ? 1 : 0;
     A.n3_need = c->flags.as<int>() + 1;
+    A.n3_seen = nullptr;
     A.pos = d_pos; A.spec = P.spec; A.x_e = d_xe; A.x_f = d_xf; A.ld = (int)ld; A.natoms = P.natoms;
     A.cand_need = c->flags.as<int>() + 2;
     // (UF3_KEEP_GHOST_TERMS: keep the force terms of ghost-centred triplets whose third atom the reference's image range
@@ -1438,6 +1440,12 @@ static int featurize_dev_impl(uf3_basis *b, const uf3_frames *fr, const double *
         // LDS layout: those calls keep the matrix-core / generic launches, which handled them before k_featurize3 existed)
         const bool feat3 = b->feat3_ok && want_f && (has3 || old_n3) && !img_launch && cap <= 255 && !c->env_no_feat3 &&
                            feat3_lds_bytes(b, cap, want_e && !A.e_direct) <= UF3_LDS_LIMIT;
+        // (the pair launch below leaves the batch's longest 3-body list in flags[7] when k_featurize3 can use it: see there)
+        A.n3_seen = nullptr;
+        if (feat3 && has3 && cap > 16 && !c->env_f3_no_cap16 && !c->env_f3_no_select) {
+            A.n3_seen = c->flags.as<int>() + 7;
+            HIPCHK(c, hipMemsetAsync(A.n3_seen, 0, sizeof(int), st));
+        }
         bool restart = false;
         {
             Timed tm(c, T_FEAT);
@@ -1586,21 +1594,11 @@ static int featurize_dev_impl(uf3_basis *b, const uf3_frames *fr, const double *
                 G.pr_rows = std::min(b->f3_ext_p, 32 / b->f3_ext_n);
                 G.geoms = P.geoms; G.frame_of = P.frame_of; G.n3 = A.n3; G.pos = d_pos; G.spec = P.spec;
                 G.x_e = d_xe; G.x_f = d_xf; G.ld = (int)ld; G.natoms = P.natoms; G.e_direct = A.e_direct; G.skip = A.skip;
+                G.sel = A.n3_seen; G.sel_mode = 0; G.sel_cap = 16;
                 int ep, stage, nrec;
                 feat3_shape(b, ep, stage, nrec);
                 (void)stage; (void)nrec;
                 const int nr = b->f3_nr;
-                const size_t lds = feat3_lds_bytes(b, cap, want_e && !A.e_direct);      // (<= UF3_LDS_LIMIT: checked where feat3 was decided)
-                int per_cu = std::max(1, std::min(8, (int)((size_t)(160 * 1024) / lds)));
-                const int bps = c->env_f3_bps;
-                int n_blocks = std::min((P.natoms + WPB - 1) / WPB, c->n_cu * per_cu * bps);
-                int apb = ((P.natoms + n_blocks - 1) / n_blocks + WPB - 1) / WPB * WPB;
-                n_blocks = (P.natoms + apb - 1) / apb;
-                G.atoms_per_block = apb;
-                if (c->env_debug_lds)
-                    fprintf(stderr, "uf3 featurize3: lds %zu B, cap %d, blocks %d x %d atoms, window %d x %d, %d round(s)\n", lds, cap, n_blocks, apb,
-                            G.ext_p, G.ext_n, nr);
-                const unsigned grid = (unsigned)((n_blocks + 7) / 8 * 8);
         /* (the attribute is set once per instance and context, and again only when a call needs more) */                     \
 #define UF3_F3_LAUNCH1(E, EFv, NRv, CAPv)                                                                                   \
     do {                                                                                                                   \
@@ -1613,18 +1611,48 @@ static int featurize_dev_impl(uf3_basis *b, const uf3_frames *fr, const double *
         hipLaunchKernelGGL((k_featurize3<E, EFv, NRv, CAPv>), dim3(grid), dim3(WPB * WAVE), lds, st, G);                    \
     } while (0)
 #define UF3_F3_LAUNCH(E, EFv, NRv)                                                                                          \
-    do { if (cap == 16 && !c->env_f3_no_cap16) UF3_F3_LAUNCH1(E, EFv, NRv, 16); else UF3_F3_LAUNCH1(E, EFv, NRv, 0); } while (0)
-                switch (ep) {
-                    case 3:      // (the default trims: the list capacity as a constant also at 24 and 32 -- fcc and denser cells)
-                        if ((cap == 24 || cap == 32) && !c->env_f3_no_cap16) {
-                            if (cap == 24) { if (want_e) UF3_F3_LAUNCH1(true, 3, 1, 24); else UF3_F3_LAUNCH1(false, 3, 1, 24); }
-                            else { if (want_e) UF3_F3_LAUNCH1(true, 3, 1, 32); else UF3_F3_LAUNCH1(false, 3, 1, 32); }
-                        }
-                        else if (want_e) UF3_F3_LAUNCH(true, 3, 1); else UF3_F3_LAUNCH(false, 3, 1);
-                        break;
-                    case 4: if (want_e) UF3_F3_LAUNCH(true, 4, 2); else UF3_F3_LAUNCH(false, 4, 2); break;
-                    case 5: if (want_e) UF3_F3_LAUNCH(true, 5, 3); else UF3_F3_LAUNCH(false, 5, 3); break;
-                    default: if (want_e) UF3_F3_LAUNCH(true, 6, 3); else UF3_F3_LAUNCH(false, 6, 3); break;
+    do { if (lcap == 16 && !c->env_f3_no_cap16) UF3_F3_LAUNCH1(E, EFv, NRv, 16); else UF3_F3_LAUNCH1(E, EFv, NRv, 0); } while (0)
+                // one launch laid out for lists of up to `lcap` entries (the batch's list array keeps the context's capacity as
+                // its stride); sel_mode: see Feat3Args
+                auto launch_f3 = [&](int lcap, int sel_mode) -> int {
+                    G.sel_mode = sel_mode;
+                    const size_t lds = feat3_lds_bytes(b, lcap, want_e && !A.e_direct);      // (<= UF3_LDS_LIMIT: checked where feat3 was decided)
+                    int per_cu = std::max(1, std::min(8, (int)((size_t)(160 * 1024) / lds)));
+                    const int bps = c->env_f3_bps;
+                    int n_blocks = std::min((P.natoms + WPB - 1) / WPB, c->n_cu * per_cu * bps);
+                    int apb = ((P.natoms + n_blocks - 1) / n_blocks + WPB - 1) / WPB * WPB;
+                    n_blocks = (P.natoms + apb - 1) / apb;
+                    G.atoms_per_block = apb;
+                    if (c->env_debug_lds)
+                        fprintf(stderr, "uf3 featurize3: lds %zu B, cap %d (lists %d apart), selection %d, blocks %d x %d atoms, window %d x %d, %d round(s)\n",
+                                lds, lcap, cap, sel_mode, n_blocks, apb, G.ext_p, G.ext_n, nr);
+                    const unsigned grid = (unsigned)((n_blocks + 7) / 8 * 8);
+                    switch (ep) {
+                        case 3:      // (the default trims: the list capacity as a constant also at 24 and 32 -- fcc and denser cells)
+                            if ((lcap == 24 || lcap == 32) && !c->env_f3_no_cap16) {
+                                if (lcap == 24) { if (want_e) UF3_F3_LAUNCH1(true, 3, 1, 24); else UF3_F3_LAUNCH1(false, 3, 1, 24); }
+                                else { if (want_e) UF3_F3_LAUNCH1(true, 3, 1, 32); else UF3_F3_LAUNCH1(false, 3, 1, 32); }
+                            }
+                            else if (want_e) UF3_F3_LAUNCH(true, 3, 1); else UF3_F3_LAUNCH(false, 3, 1);
+                            break;
+                        case 4: if (want_e) UF3_F3_LAUNCH(true, 4, 2); else UF3_F3_LAUNCH(false, 4, 2); break;
+                        case 5: if (want_e) UF3_F3_LAUNCH(true, 5, 3); else UF3_F3_LAUNCH(false, 5, 3); break;
+                        default: if (want_e) UF3_F3_LAUNCH(true, 6, 3); else UF3_F3_LAUNCH(false, 6, 3); break;
+                    }
+                    return UF3_OK;
+                };
+                // The lists of this batch were built just now at the context's capacity -- an estimate on a context's first call,
+                // what the densest batch so far needed later on -- but the instance that serves most cells is the one laid out for 16
+                // entries (4 workgroups per CU, LDS offsets as immediates).  Which one applies is known on the device only: the list
+                // build leaves the batch's longest list in flags[7], and two launches follow of which one leaves at once.
+                if (A.n3_seen && cap > 16) {
+                    int r1 = launch_f3(16, 1);
+                    if (r1) return r1;
+                    r1 = launch_f3(cap, 2);
+                    if (r1) return r1;
+                } else {
+                    int r1 = launch_f3(cap, 0);
+                    if (r1) return r1;
                 }
 #undef UF3_F3_LAUNCH
 #undef UF3_F3_LAUNCH1

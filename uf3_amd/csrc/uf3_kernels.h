@@ -673,6 +673,7 @@ struct FeatArgs {
     int *cand_need;     // overflow report of the 2-body candidate stage
     const int *outside; // != 0: some atom of the batch lies outside its cell (null: the image-range rule is switched off)
     int *n3_need;       // ... of the 3-body neighbour lists (MODE 0 builds them when build_n3 != 0)
+    int *n3_seen;       // or null: the longest list of the batch (k_featurize3's instance is picked by it on the device)
     int build_n3;
     int e_direct;       // energy row too long for LDS: every contribution goes straight to HBM (global atomics)
     int natoms, atoms_per_block;
@@ -2129,6 +2130,8 @@ __device__ __forceinline__ void build_n3_list(const FeatArgs &A, const BasisDev 
         count += __popcll(mask);
     }
     wave_sync();
+    // (the batch's longest list: a look first -- after the first few atoms nearly every wave finds its count there already)
+    if (A.n3_seen && lane == 0 && count > __builtin_nontemporal_load(A.n3_seen)) atomicMax(A.n3_seen, count);
     if (count > cap) { if (lane == 0) atomicMax(A.n3_need, count); count = cap; }
     if (lane == 0) A.n3.cnt[m] = count;
     if (count <= WAVE) {                 // entries are species-sorted: offsets per species = entries of a lower species (ballots)
