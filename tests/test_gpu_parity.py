@@ -2113,3 +2113,17 @@ def test_bench_under_the_launcher_runs_rccl_on_device_buffers(mode):
         assert out["config"]["collective"].startswith("uf3_allreduce_sum_f64" if native else "torch.distributed")
         assert np.isfinite(out["value"]) and out["value"] > 0
         values[native] = out["value"]
+
+
+def test_random_call_sequences_on_one_context_do_not_depend_on_its_history():
+    """A short run of tools/experiments/state_fuzz.py (its header: one process, the shared context, three bases x five kinds of
+    frames, a seeded random sequence of featurize / evaluate / fit calls, every result against the oracle): capacities that only
+    grow, persistent neighbour lists, staging blocks and cached coefficients must not leak from one call into the next."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    res = subprocess.run([sys.executable, os.path.join(root, "tools", "experiments", "state_fuzz.py"), "120", "9"],
+                         env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
+    assert "mismatches 0" in res.stdout
