@@ -7,7 +7,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from oracle import oracle as O
-from uf3_amd import synthetic, pipeline
+from uf3_amd import synthetic, pipeline, _lib
 from uf3_amd.data.atoms import Atoms
 from uf3_amd.representation import process
 from uf3_amd.regression import least_squares as ls
@@ -106,8 +106,15 @@ for op in range(n_ops):
         fr = [frames[(b, k)] for k in ks]
         en = rng.normal(-8.0, 1.0, len(fr)) * np.array([len(f) for f in fr])
         fo = [rng.normal(0, 0.5, (len(f), 3)) for f in fr]
-        acc.add_frames(fr, en, fo)
-        p = acc.pieces()
+        for attempt in range(4):
+            # (asynchronous calls: a batch denser than anything the context has seen overflows its capacities, the verdict
+            # arrives with the next synchronisation and the work is repeated -- what pipeline.fit_frames does)
+            try:
+                acc.add_frames(fr, en, fo)
+                p = acc.pieces()
+                break
+            except _lib.RetryError:
+                acc.reset()
         xe = np.array([oracle_rows(b, k)["xe"] for k in ks])
         xf = np.concatenate([oracle_rows(b, k)["xf"].reshape(-1, bases[b].n_feats) for k in ks])
         keep = np.setdiff1d(np.arange(bases[b].n_feats), np.asarray(bases[b].col_idx, dtype=int))
