@@ -2127,3 +2127,39 @@ def test_random_call_sequences_on_one_context_do_not_depend_on_its_history():
                          env=env, capture_output=True, text=True, timeout=900)
     assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
     assert "mismatches 0" in res.stdout
+
+
+def test_small_md_steps_staged_through_the_bar_equal_the_fetched_ones(monkeypatch):
+    """Small MD steps put positions | species straight into device memory through the BAR when the status words are known to be
+    clean (no k_md_fetch launch): the same walk on a context with the route switched off (UF3_NO_BAR_STAGE, read when the context
+    is made) gives the same bits, a step that outruns the lists in between included; against the oracle at the end."""
+    basis = synthetic.notebook_basis(['Mo', 'W'])
+    model, coeff = _random_model(basis, 4)
+    start = synthetic.lattice_frame("bcc", (4, 4, 4), 3.165, [42, 74], seed=8)
+    rng = np.random.default_rng(2)
+    path, pos = [], start.get_positions()
+    for step in range(40):
+        pos = pos + rng.uniform(-0.02, 0.02, pos.shape)
+        if step == 17:
+            pos[5] += [0.3, 0.1, -0.2]
+        path.append(pos.copy())
+    runs = []
+    for off in (False, True):
+        if off:
+            monkeypatch.setenv("UF3_NO_BAR_STAGE", "1")
+        monkeypatch.setattr(_lib, "_contexts", {})
+        calc = calculator.UFCalculator(model, md_skin=0.4)
+        out = []
+        for p in path:
+            atoms = Atoms(numbers=start.get_atomic_numbers(), positions=p, cell=start.get_cell(), pbc=True)
+            e, f, _ = calc.evaluate_frames([atoms])
+            out.append((e.copy(), f.copy()))
+        st = _lib.get_context(None).md_stats()
+        assert st["steps"] >= len(path) and st["redone"] >= 1
+        runs.append(out)
+        _lib.drop_device_basis(basis)
+    for (e0, f0), (e1, f1) in zip(*runs):
+        assert np.array_equal(e0, e1) and np.array_equal(f0, f1)
+    atoms = Atoms(numbers=start.get_atomic_numbers(), positions=path[-1], cell=start.get_cell(), pbc=True)
+    e_ref, f_ref = O.evaluate(O.OracleBasis(basis), atoms, coeff)
+    assert rel_err(runs[0][-1][0][0], e_ref) < TOL and rel_err(runs[0][-1][1], f_ref) < TOL

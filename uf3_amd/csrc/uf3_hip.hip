@@ -88,6 +88,12 @@ struct uf3_ctx {
     std::string async_msg;
     bool frag_ready = false;
     int32_t *d_stage_z = nullptr;       // species of the staged batch (tail of stage_pos)
+    // small MD steps without a fetch kernel: with a large BAR the host stores positions | species straight into a (fine-grained)
+    // device block -- no launch that reads the caller's pinned block, no dispatch gap behind a 4 us kernel (eval_impl, MD route)
+    bool bar_ok = false;
+    void *bar_stage = nullptr;
+    size_t bar_cap = 0;
+    size_t bar_staged = 0;              // bytes of the caller's pinned block the current call put there (0: it went the ordinary way)
     // environment switches of the featurizer's asynchronous path, read once (uf3_ctx_create)
     bool env_no_feat3 = false, env_f3_no_cap16 = false, env_f3_no_select = false, env_debug_lds = false;
     int env_f3_bps = 24;
@@ -104,6 +110,7 @@ struct uf3_ctx {
     // MD route of the evaluator (uf3_ctx_md_skin): persistent superset lists with a skin, see k_build_sup.  Everything a step
     // needs besides the current positions lives in its own buffers -- the workspace above belongs to whichever call ran last
     struct MdState {
+        bool flags_clean = false;       // the status words [1..3] are known to be zero (the last call was an MD step that set none)
         double skin = 0.0;              // 0: off
         bool valid = false;             // the lists describe (basis, offsets, cells, pbc) below
         bool stale = false;             // some atom has passed the early-warning displacement: rebuild before the next step
@@ -235,6 +242,7 @@ extern "C" int uf3_ctx_create(int device, uf3_ctx **out) {
     c->env_no_feat3 = uf3_env("UF3_NO_FEAT3") != nullptr;
     c->env_f3_no_cap16 = uf3_env("UF3_F3_NO_CAP16") != nullptr;
     c->env_f3_no_select = uf3_env("UF3_F3_NO_SELECT") != nullptr;
+    { int large = 0; c->bar_ok = hipDeviceGetAttribute(&large, hipDeviceAttributeIsLargeBar, device) == hipSuccess && large && !uf3_env("UF3_NO_BAR_STAGE"); }
     c->env_debug_lds = uf3_env("UF3_DEBUG_LDS") != nullptr;
     if (uf3_env("UF3_F3_BPS")) c->env_f3_bps = std::max(1, atoi(uf3_env("UF3_F3_BPS")));
     if (std::string(prop.gcnArchName).find("gfx950") == std::string::npos) {
@@ -259,6 +267,7 @@ extern "C" void uf3_ctx_destroy(uf3_ctx *c) {
     for (Buf &b : c->gram_tiles) b.release();
     if (c->comm) uf3_comm_destroy(c);
     { Buf *mdb[] = {&c->md.ent, &c->md.cnt, &c->md.pos_ref, &c->md.geo, &c->md.frame_of, &c->md.spec, &c->md.inbox, &c->md.surv, &c->md.mark}; for (Buf *b : mdb) b->release(); }
+    if (c->bar_stage) hipFree(c->bar_stage);
     c->pin_in.release(); c->pin_geo.release(); c->pin_out.release(); c->pin_flags.release(); c->pin_eval.release();
     for (auto &pd : c->pending_chk) if (pd.ev) hipEventDestroy(pd.ev);
     if (c->pin_in_done) hipEventDestroy(c->pin_in_done);
@@ -1133,6 +1142,7 @@ static int build_halo_lists(uf3_basis *b, const Prepared &P, const N3Lists &n3, 
 static int prepare(uf3_basis *b, const uf3_frames *fr, const double *d_pos, const int32_t *d_z, bool need_n3,
                    Prepared &P, bool defer_check = false, int64_t n3_lo = 0, int64_t n3_hi = -1, double extra_radius = 0.0) {
     uf3_ctx *c = b->ctx;
+    c->md.flags_clean = false;          // (the cell-list stage and what follows it use the status words)
     if (!fr || fr->n_frames < 1 || !fr->atom_offsets || !fr->cells || !fr->pbc)
         return fail(c, UF3_EINVAL, "bad uf3_frames");
     if (fr->atom_offsets[0] != 0) return fail(c, UF3_EINVAL, "atom_offsets[0] must be 0");
@@ -1898,6 +1908,9 @@ static int eval_impl(uf3_basis *b, const uf3_frames *fr, const double *d_pos, co
     // MD route: the candidates of every atom from the context's persistent lists instead of a cell-list walk (see md_build)
     const bool md_step = c->md.skin > 0.0 && fuse && (whole || centres) && !uf3_env("UF3_NO_MD");     // (a block of centres too: round 5)
     c->md_step = md_step;
+    const bool was_clean = c->md.flags_clean;      // (true only straight after an MD step of eval_host that set no status word)
+    c->md.flags_clean = false;
+    c->bar_staged = 0;
     if (md_step) {
         HIPCHK(c, hipSetDevice(c->device));
         if (c->md.stale || !md_key_matches(c->md, b, fr)) {
@@ -1907,7 +1920,25 @@ static int eval_impl(uf3_basis *b, const uf3_frames *fr, const double *d_pos, co
             // a small batch staged by upload_frames: positions | species are still in the caller's pinned block
             const size_t at = c->pin_in_pending;
             c->pin_in_pending = 0;
-            if (c->md.natoms <= UF3_SMALL_ATOMS && !uf3_env("UF3_NO_ZERO_COPY")) {
+            const bool clean = was_clean;
+            if (c->md.natoms <= UF3_SMALL_ATOMS && c->bar_ok && clean && whole && !uf3_env("UF3_NO_ZERO_COPY")) {
+                // the block through the BAR: host stores (write-combined, posted), a store fence, and the launches' doorbell
+                // behind them on the same link -- the kernels of this step read device memory that is already there.  Only when
+                // the status words are known to be zero (k_md_fetch zeroes them on the way otherwise).
+                if (at > c->bar_cap) {
+                    if (c->bar_stage) { HIPCHK(c, hipFree(c->bar_stage)); c->bar_stage = nullptr; c->bar_cap = 0; }
+                    const size_t want = std::max<size_t>(2 * at, 16384);
+                    if (hipExtMallocWithFlags(&c->bar_stage, want, hipDeviceMallocFinegrained) != hipSuccess) { c->bar_stage = nullptr; c->bar_ok = false; (void)hipGetLastError(); }
+                    else c->bar_cap = want;
+                }
+            }
+            if (c->md.natoms <= UF3_SMALL_ATOMS && c->bar_ok && clean && whole && c->bar_stage && !uf3_env("UF3_NO_ZERO_COPY")) {
+                std::memcpy(c->bar_stage, c->pin_in.p, at);
+                __builtin_ia32_sfence();
+                c->bar_staged = at;             // (a repeat of this call -- lists outrun, a capacity raised -- stages the block the ordinary way)
+                d_pos = (const double *)c->bar_stage;
+                d_z = (const int32_t *)((const char *)c->bar_stage + 24 * (size_t)c->md.natoms);
+            } else if (c->md.natoms <= UF3_SMALL_ATOMS && !uf3_env("UF3_NO_ZERO_COPY")) {
                 hipLaunchKernelGGL(k_md_fetch, dim3(1), dim3(256), 0, st, (const int4 *)c->pin_in.p, (int4 *)c->stage_pos.p, (int)(at / 16),
                                    c->flags.as<int>());
                 c->pin_in_busy = true;
@@ -2183,9 +2214,11 @@ static int eval_host(uf3_basis *b, const uf3_frames *fr, const double *pos, cons
             {
                 const int *fl = (const int *)((const char *)c->pin_out.p + total);
                 if (fl[0]) return check_flags(c);
+                if (c->bar_staged && ((c->md_step && fl[2]) || (cap_used && fl[1] > cap_used))) c->pin_in_pending = c->bar_staged;   // (the repeat fetches the block itself)
                 if (c->md_step && fl[2]) { c->md.valid = false; c->md.redone++; continue; }      // (lists outrun: rebuilt by the repeat)
                 if (c->md_step && fl[3]) c->md.stale = true;
                 if (cap_used && fl[1] > cap_used) { c->n3_cap = (fl[1] + 8 + 7) / 8 * 8; continue; }
+                c->md.flags_clean = c->md_step && !fl[1] && !fl[2] && !fl[3];
             }
             const double *h = (const double *)c->pin_out.p;
             std::memcpy(energies, h, 8 * nf);
