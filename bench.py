@@ -832,6 +832,7 @@ def extra_eval_128(calls=2000):
     from uf3_amd.forcefield import calculator
     calc = calculator.UFCalculator(model, md_skin=MD_SKIN)
     ctx = _lib.get_context(None)
+    ctx.use_own_stream()            # (what a UFCalculator user has: the context's own stream, not the null stream torch's tensors live on)
     n = len(atoms)
     rng = np.random.default_rng(19)
     noise = rng.uniform(-MD_WALK, MD_WALK, (256, n, 3))
