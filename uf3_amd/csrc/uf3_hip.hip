@@ -22,12 +22,23 @@
 struct Buf {
     void *p = nullptr;
     size_t cap = 0;
+    bool fine = false;          // fine-grained device memory (ensure_fine): the host may store into it through the BAR
     hipError_t ensure(size_t bytes) {
         if (bytes <= cap) return hipSuccess;
         if (p) { hipError_t e = hipFree(p); if (e != hipSuccess) return e; p = nullptr; cap = 0; }
+        fine = false;
         size_t want = bytes + bytes / 4 + 256;
         hipError_t e = hipMalloc(&p, want);
         if (e == hipSuccess) cap = want;
+        return e;
+    }
+    hipError_t ensure_fine(size_t bytes) {
+        if (bytes <= cap && fine) return hipSuccess;
+        if (p) { hipError_t e = hipFree(p); if (e != hipSuccess) return e; p = nullptr; cap = 0; }
+        fine = false;
+        size_t want = std::max(bytes, cap) + bytes / 4 + 256;
+        hipError_t e = hipExtMallocWithFlags(&p, want, hipDeviceMallocFinegrained);
+        if (e == hipSuccess) { cap = want; fine = true; }
         return e;
     }
     void release() { if (p) hipFree(p); p = nullptr; cap = 0; }
@@ -51,6 +62,7 @@ struct PinBuf {
     void release() { if (p) hipHostFree(p); p = nullptr; cap = 0; }
 };
 #define UF3_PIN_LIMIT (512 * 1024)   // bytes: larger transfers go straight from / to the caller's memory
+#define UF3_BAR_LIMIT (128 * 1024)   // bytes: largest block the host stores into device memory itself (beyond it the copy engine is quicker)
 
 struct uf3_ctx {
     int device = 0;
@@ -91,9 +103,7 @@ struct uf3_ctx {
     // small MD steps without a fetch kernel: with a large BAR the host stores positions | species straight into a (fine-grained)
     // device block -- no launch that reads the caller's pinned block, no dispatch gap behind a 4 us kernel (eval_impl, MD route)
     bool bar_ok = false;
-    void *bar_stage = nullptr;
-    size_t bar_cap = 0;
-    size_t bar_staged = 0;              // bytes of the caller's pinned block the current call put there (0: it went the ordinary way)
+    size_t staged_in_dev = 0;           // bytes of positions | species the host entry has stored into stage_pos already (0: none)
     // environment switches of the featurizer's asynchronous path, read once (uf3_ctx_create)
     bool env_no_feat3 = false, env_f3_no_cap16 = false, env_f3_no_select = false, env_debug_lds = false;
     int env_f3_bps = 24;
@@ -267,7 +277,6 @@ extern "C" void uf3_ctx_destroy(uf3_ctx *c) {
     for (Buf &b : c->gram_tiles) b.release();
     if (c->comm) uf3_comm_destroy(c);
     { Buf *mdb[] = {&c->md.ent, &c->md.cnt, &c->md.pos_ref, &c->md.geo, &c->md.frame_of, &c->md.spec, &c->md.inbox, &c->md.surv, &c->md.mark}; for (Buf *b : mdb) b->release(); }
-    if (c->bar_stage) hipFree(c->bar_stage);
     c->pin_in.release(); c->pin_geo.release(); c->pin_out.release(); c->pin_flags.release(); c->pin_eval.release();
     for (auto &pd : c->pending_chk) if (pd.ev) hipEventDestroy(pd.ev);
     if (c->pin_in_done) hipEventDestroy(c->pin_in_done);
@@ -1177,7 +1186,16 @@ static int prepare(uf3_basis *b, const uf3_frames *fr, const double *d_pos, cons
     const int64_t *d_offsets;
     const int4 *host_block = nullptr;           // != null: k_prepare_small fetches the staged block itself
     size_t host_block_bytes = 0;
-    if (c->pin_in_pending && d_pos == c->stage_pos.as<double>()) {
+    if (c->staged_in_dev && d_pos == c->stage_pos.as<double>()) {
+        // positions | species are in the device block already (upload_frames, through the BAR): geometry | offsets behind them
+        const size_t at = c->staged_in_dev;
+        c->staged_in_dev = 0;
+        std::memcpy((char *)c->stage_pos.p + at, geoms.data(), sizeof(FrameGeom) * nf);
+        std::memcpy((char *)c->stage_pos.p + at + geo_bytes, fr->atom_offsets, off_bytes);
+        __builtin_ia32_sfence();
+        d_geoms = (const FrameGeom *)((const char *)c->stage_pos.p + at);
+        d_offsets = (const int64_t *)((const char *)c->stage_pos.p + at + geo_bytes);
+    } else if (c->pin_in_pending && d_pos == c->stage_pos.as<double>()) {
         // small batch staged by upload_frames: positions | species | geometry | offsets leave pin_in in one piece -- fetched by
         // the cell-list kernel itself when that is the one-workgroup kernel, by one copy otherwise
         const size_t at = c->pin_in_pending;
@@ -1723,9 +1741,23 @@ static int upload_frames(uf3_ctx *c, const uf3_frames *fr, const double *pos, co
     const size_t bp = 24 * (size_t)natoms, bz = 4 * (size_t)natoms;
     // (room behind positions | species for the frame geometry: see pin_in_pending)
     const size_t geo_room = 96 + sizeof(FrameGeom) * (size_t)fr->n_frames + 8 * ((size_t)fr->n_frames + 1);
+    // small batches of the synchronous evaluator entry: with a large BAR the block is a fine-grained device allocation and the
+    // host stores into it directly (write-combined, posted; a store fence; the launches' doorbell follows over the same link) --
+    // no kernel or copy that reads the caller's memory.  The entry's previous call has been waited for: nothing reads the block.
+    bool bar = defer_small && c->bar_ok && bp + bz + geo_room <= UF3_BAR_LIMIT;
+    if (bar && c->stage_pos.ensure_fine(bp + bz + geo_room) != hipSuccess) { (void)hipGetLastError(); c->bar_ok = false; bar = false; }
     HIPCHK(c, c->stage_pos.ensure(bp + bz + geo_room));            // positions | species, one block
     c->d_stage_z = (int32_t *)((char *)c->stage_pos.p + bp);
     c->pin_in_pending = 0;
+    c->staged_in_dev = 0;
+    if (bar && c->stage_pos.fine) {
+        if (c->pin_in_busy) { HIPCHK(c, hipStreamSynchronize(c->stream)); c->pin_in_busy = false; }
+        std::memcpy(c->stage_pos.p, pos, bp);
+        std::memcpy((char *)c->stage_pos.p + bp, z, bz);
+        __builtin_ia32_sfence();
+        c->staged_in_dev = (bp + bz + 15) / 16 * 16;
+        return UF3_OK;
+    }
     if (bp + bz <= UF3_PIN_LIMIT) {
         // (an entry that returned an error behind a launch reading the staging block directly never waited for it)
         if (c->pin_in_busy) { HIPCHK(c, hipStreamSynchronize(c->stream)); c->pin_in_busy = false; }
@@ -1910,35 +1942,23 @@ static int eval_impl(uf3_basis *b, const uf3_frames *fr, const double *d_pos, co
     c->md_step = md_step;
     const bool was_clean = c->md.flags_clean;      // (true only straight after an MD step of eval_host that set no status word)
     c->md.flags_clean = false;
-    c->bar_staged = 0;
     if (md_step) {
         HIPCHK(c, hipSetDevice(c->device));
         if (c->md.stale || !md_key_matches(c->md, b, fr)) {
             rc = md_build(b, fr, d_pos, d_z, P);
             if (rc) return rc;
+        } else if (c->staged_in_dev && d_pos == c->stage_pos.as<double>()) {
+            // positions | species are in the device block already (upload_frames, through the BAR).  k_md_fetch also zeroed the
+            // step's status words: needed only when they are not known to be zero (was_clean: the previous call was an MD step
+            // of the host entry that set none -- the host has just read them)
+            c->staged_in_dev = 0;
+            if (!was_clean)
+                hipLaunchKernelGGL(k_md_fetch, dim3(1), dim3(64), 0, st, (const int4 *)nullptr, (int4 *)nullptr, 0, c->flags.as<int>());
         } else if (c->pin_in_pending && d_pos == c->stage_pos.as<double>()) {
             // a small batch staged by upload_frames: positions | species are still in the caller's pinned block
             const size_t at = c->pin_in_pending;
             c->pin_in_pending = 0;
-            const bool clean = was_clean;
-            if (c->md.natoms <= UF3_SMALL_ATOMS && c->bar_ok && clean && whole && !uf3_env("UF3_NO_ZERO_COPY")) {
-                // the block through the BAR: host stores (write-combined, posted), a store fence, and the launches' doorbell
-                // behind them on the same link -- the kernels of this step read device memory that is already there.  Only when
-                // the status words are known to be zero (k_md_fetch zeroes them on the way otherwise).
-                if (at > c->bar_cap) {
-                    if (c->bar_stage) { HIPCHK(c, hipFree(c->bar_stage)); c->bar_stage = nullptr; c->bar_cap = 0; }
-                    const size_t want = std::max<size_t>(2 * at, 16384);
-                    if (hipExtMallocWithFlags(&c->bar_stage, want, hipDeviceMallocFinegrained) != hipSuccess) { c->bar_stage = nullptr; c->bar_ok = false; (void)hipGetLastError(); }
-                    else c->bar_cap = want;
-                }
-            }
-            if (c->md.natoms <= UF3_SMALL_ATOMS && c->bar_ok && clean && whole && c->bar_stage && !uf3_env("UF3_NO_ZERO_COPY")) {
-                std::memcpy(c->bar_stage, c->pin_in.p, at);
-                __builtin_ia32_sfence();
-                c->bar_staged = at;             // (a repeat of this call -- lists outrun, a capacity raised -- stages the block the ordinary way)
-                d_pos = (const double *)c->bar_stage;
-                d_z = (const int32_t *)((const char *)c->bar_stage + 24 * (size_t)c->md.natoms);
-            } else if (c->md.natoms <= UF3_SMALL_ATOMS && !uf3_env("UF3_NO_ZERO_COPY")) {
+            if (c->md.natoms <= UF3_SMALL_ATOMS && !uf3_env("UF3_NO_ZERO_COPY")) {
                 hipLaunchKernelGGL(k_md_fetch, dim3(1), dim3(256), 0, st, (const int4 *)c->pin_in.p, (int4 *)c->stage_pos.p, (int)(at / 16),
                                    c->flags.as<int>());
                 c->pin_in_busy = true;
@@ -2214,7 +2234,6 @@ static int eval_host(uf3_basis *b, const uf3_frames *fr, const double *pos, cons
             {
                 const int *fl = (const int *)((const char *)c->pin_out.p + total);
                 if (fl[0]) return check_flags(c);
-                if (c->bar_staged && ((c->md_step && fl[2]) || (cap_used && fl[1] > cap_used))) c->pin_in_pending = c->bar_staged;   // (the repeat fetches the block itself)
                 if (c->md_step && fl[2]) { c->md.valid = false; c->md.redone++; continue; }      // (lists outrun: rebuilt by the repeat)
                 if (c->md_step && fl[3]) c->md.stale = true;
                 if (cap_used && fl[1] > cap_used) { c->n3_cap = (fl[1] + 8 + 7) / 8 * 8; continue; }
