@@ -2163,3 +2163,31 @@ def test_small_md_steps_staged_through_the_bar_equal_the_fetched_ones(monkeypatc
     atoms = Atoms(numbers=start.get_atomic_numbers(), positions=path[-1], cell=start.get_cell(), pbc=True)
     e_ref, f_ref = O.evaluate(O.OracleBasis(basis), atoms, coeff)
     assert rel_err(runs[0][-1][0][0], e_ref) < TOL and rel_err(runs[0][-1][1], f_ref) < TOL
+
+
+def test_md_rebuild_that_nobody_waits_for_overflows_into_a_repeat():
+    """A rebuild of the MD lists at a capacity that has held before does not wait for its own report (md_build, may_defer): when
+    the same atoms come back in a cell compressed by 25 % the superset lists no longer fit, k_sup_reverse raises the step's
+    "lists outrun" word, the step is discarded and the repeat builds with the host looking -- results against the oracle, and
+    the walk goes on (calculator.py:124-153: every call from scratch)."""
+    basis = synthetic.notebook_basis(['Mo', 'W'])
+    model, coeff = _random_model(basis, 6)
+    calc = calculator.UFCalculator(model, md_skin=0.5)
+    start = synthetic.lattice_frame("bcc", (4, 4, 4), 3.3, [42, 74], seed=12)
+    ob = O.OracleBasis(basis)
+    ctx = _lib.get_context(None)
+    rng = np.random.default_rng(3)
+    pos, cell = start.get_positions(), np.array(start.get_cell(), float)
+    for step in range(12):
+        pos = pos + rng.uniform(-0.02, 0.02, pos.shape)
+        calc.evaluate_frames([Atoms(numbers=start.get_atomic_numbers(), positions=pos, cell=cell, pbc=True)])
+    before = ctx.md_stats()
+    pos, cell = pos * 0.75, cell * 0.75
+    for step in range(6):
+        pos = pos + rng.uniform(-0.02, 0.02, pos.shape)
+        atoms = Atoms(numbers=start.get_atomic_numbers(), positions=pos, cell=cell, pbc=True)
+        e, f, _ = calc.evaluate_frames([atoms])
+        e_ref, f_ref = O.evaluate(ob, atoms, coeff)
+        assert rel_err(e[0], e_ref) < TOL and rel_err(f, f_ref) < TOL, step
+    after = ctx.md_stats()
+    assert after["redone"] > before["redone"] and after["builds"] >= before["builds"] + 2

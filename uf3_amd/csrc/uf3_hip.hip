@@ -120,6 +120,8 @@ struct uf3_ctx {
     // MD route of the evaluator (uf3_ctx_md_skin): persistent superset lists with a skin, see k_build_sup.  Everything a step
     // needs besides the current positions lives in its own buffers -- the workspace above belongs to whichever call ran last
     struct MdState {
+        bool cap_tuned = false;         // the list capacity has held in a build the host looked at
+        bool verify_next = false;       // the last step was discarded: the next build waits for its own report
         bool flags_clean = false;       // the status words [1..3] are known to be zero (the last call was an MD step that set none)
         double skin = 0.0;              // 0: off
         bool valid = false;             // the lists describe (basis, offsets, cells, pbc) below
@@ -1052,6 +1054,7 @@ struct Prepared {
     size_t geo_bytes = 0;       // FrameGeom [n_frames] | atom offsets [n_frames + 1] behind `geoms`, one block
     bool deferred = false;      // the list-capacity / error flags of this build have not been read yet
     bool flags_zeroed = false;  // the cell-list stage has already zeroed the n3 / candidate status words
+    bool small_prepared = false; // ... by the one-workgroup kernel, which also zeroes md_build's list-length report
 };
 
 static int check_flags(uf3_ctx *c) {
@@ -1238,6 +1241,7 @@ static int prepare(uf3_basis *b, const uf3_frames *fr, const double *d_pos, cons
                            natoms, nbins, d_pos, d_z, c->frame_of.as<int>(), c->atom_bin.as<int>(), c->atom_wrap.as<int>(),
                            c->spec.as<signed char>(), c->bin_start.as<int>(), c->slots.as<SlotRec>(), flags, 2,
                            host_block, (int4 *)c->stage_pos.p, (int)(host_block_bytes / 16));
+        P.small_prepared = true;
         if (host_block) c->pin_in_busy = true;     // (until the caller's wait for the stream: upload_frames checks)
         // (host_block: no event behind the kernel -- a record between two launches costs the next kernel ~5 us of dispatch
         // latency, and the only caller on this path, the synchronous evaluator entry, waits for the stream before it returns)
@@ -1815,10 +1819,14 @@ static bool md_key_matches(const uf3_ctx::MdState &md, const uf3_basis *b, const
            !memcmp(fr->cells, md.cells.data(), 72 * nf) && !memcmp(fr->pbc, md.pbc.data(), 3 * nf);
 }
 
-static int md_build(uf3_basis *b, const uf3_frames *fr, const double *d_pos, const int32_t *d_z, Prepared &P) {
+// may_defer: the caller's step has a verdict of its own (status words read behind its last kernel) and nothing zeroes them between
+// this build and that step -- then a build at a capacity that has held before does not wait for its own report: an overflow
+// raises the step's "lists outrun" word (k_sup_reverse), the step is discarded and the repeat builds with the host looking
+static int md_build(uf3_basis *b, const uf3_frames *fr, const double *d_pos, const int32_t *d_z, Prepared &P, bool may_defer = false) {
     uf3_ctx *c = b->ctx;
     uf3_ctx::MdState &md = c->md;
     md.valid = false; md.stale = false;
+    const bool defer = may_defer && md.cap_tuned && !md.verify_next && md.basis == b && md.cap > 0 && !uf3_env("UF3_MD_SYNC_BUILD");
     int rc = prepare(b, fr, d_pos, d_z, false, P, false, 0, -1, md.skin);      // cell list at r_cut + skin
     if (rc) return rc;
     hipStream_t st = c->stream;
@@ -1834,23 +1842,25 @@ static int md_build(uf3_basis *b, const uf3_frames *fr, const double *d_pos, con
         const int cap = md.cap;
         HIPCHK(c, md.ent.ensure(sizeof(SupEntry) * (size_t)natoms * cap));
         HIPCHK(c, md.cnt.ensure(sizeof(int) * (size_t)natoms));
-        HIPCHK(c, hipMemsetAsync(flags + 5, 0, sizeof(int), st));
+        if (!(P.small_prepared && attempt == 0)) HIPCHK(c, hipMemsetAsync(flags + 5, 0, sizeof(int), st));    // (the one-workgroup cell-list kernel has zeroed it)
         const size_t lds = (size_t)cap * 16;
         if ((int)lds > c->lds_max) return fail(c, UF3_EOVERFLOW, "MD neighbour list does not fit in LDS");
         hipLaunchKernelGGL(k_build_sup, dim3((unsigned)((natoms + 7) / 8 * 8)), dim3(64), lds, st, b->dev, P.geoms, P.frame_of, P.cl,
                            d_pos, natoms, r_sup2, md.ent.as<SupEntry>(), md.cnt.as<int>(), cap, flags + 5);
         HIPCHK(c, hipGetLastError());
+        if (defer) break;
         int fl[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         HIPCHK(c, hipMemcpyAsync(fl, flags, sizeof(fl), hipMemcpyDeviceToHost, st));
         HIPCHK(c, hipStreamSynchronize(st));
         c->pin_in_busy = false;
         if (fl[0]) return check_flags(c);
-        if (fl[5] <= cap) break;
+        if (fl[5] <= cap) { md.cap_tuned = true; md.verify_next = false; break; }
         if (attempt >= 5) return fail(c, UF3_EOVERFLOW, "MD neighbour capacity did not converge");
         md.cap = (fl[5] + 8 + 7) / 8 * 8;
     }
     hipLaunchKernelGGL(k_sup_reverse, dim3((unsigned)(((natoms + 15) / 16 + 7) / 8 * 8)), dim3(256), 0, st, md.ent.as<SupEntry>(),
-                       (const int *)md.cnt.as<int>(), md.cap, natoms, P.geoms, P.frame_of, P.spec);
+                       (const int *)md.cnt.as<int>(), md.cap, natoms, P.geoms, P.frame_of, P.spec, (const int *)(flags + 5),
+                       defer ? flags + 2 : (int *)nullptr);
     HIPCHK(c, hipGetLastError());
     // inbox of every (atom, list position): zeroed when (re)allocated -- stamps start at 1
     {
@@ -1868,10 +1878,10 @@ static int md_build(uf3_basis *b, const uf3_frames *fr, const double *d_pos, con
     HIPCHK(c, md.frame_of.ensure(4 * (size_t)natoms));
     HIPCHK(c, md.spec.ensure((size_t)natoms));
     HIPCHK(c, md.pos_ref.ensure(24 * (size_t)natoms));
-    HIPCHK(c, hipMemcpyAsync(md.geo.p, P.geoms, P.geo_bytes, hipMemcpyDeviceToDevice, st));
-    HIPCHK(c, hipMemcpyAsync(md.frame_of.p, P.frame_of, 4 * (size_t)natoms, hipMemcpyDeviceToDevice, st));
-    HIPCHK(c, hipMemcpyAsync(md.spec.p, P.spec, (size_t)natoms, hipMemcpyDeviceToDevice, st));
-    HIPCHK(c, hipMemcpyAsync(md.pos_ref.p, d_pos, 24 * (size_t)natoms, hipMemcpyDeviceToDevice, st));
+    hipLaunchKernelGGL(k_md_snapshot, dim3((unsigned)std::min<size_t>((6 * (size_t)natoms + 255) / 256, 2048)), dim3(256), 0, st,
+                       (const unsigned *)P.geoms, md.geo.as<unsigned>(), P.geo_bytes / 4, (const unsigned *)P.frame_of, md.frame_of.as<unsigned>(),
+                       (size_t)natoms, P.spec, md.spec.as<signed char>(), (const unsigned *)d_pos, md.pos_ref.as<unsigned>());
+    HIPCHK(c, hipGetLastError());
     md.geo_bytes = geo_bytes;
     md.basis = b; md.natoms = natoms; md.n_frames = nf;
     md.offsets.assign(fr->atom_offsets, fr->atom_offsets + nf + 1);
@@ -1899,7 +1909,7 @@ static void md_prepared(const uf3_ctx *c, Prepared &P) {
 extern "C" int uf3_ctx_md_skin(uf3_ctx *c, double skin) {
     if (!c) return fail(nullptr, UF3_EINVAL, "null ctx");
     if (!(skin >= 0.0) || skin > 4.0) return fail(c, UF3_EINVAL, "uf3_ctx_md_skin: skin must lie in [0, 4] Angstrom");
-    if (skin != c->md.skin) { c->md.valid = false; c->md.cap = 0; }
+    if (skin != c->md.skin) { c->md.valid = false; c->md.cap = 0; c->md.cap_tuned = false; }
     c->md.skin = skin;
     return UF3_OK;
 }
@@ -1945,7 +1955,7 @@ static int eval_impl(uf3_basis *b, const uf3_frames *fr, const double *d_pos, co
     if (md_step) {
         HIPCHK(c, hipSetDevice(c->device));
         if (c->md.stale || !md_key_matches(c->md, b, fr)) {
-            rc = md_build(b, fr, d_pos, d_z, P);
+            rc = md_build(b, fr, d_pos, d_z, P, true);
             if (rc) return rc;
         } else if (c->staged_in_dev && d_pos == c->stage_pos.as<double>()) {
             // positions | species are in the device block already (upload_frames, through the BAR).  k_md_fetch also zeroed the
@@ -2234,7 +2244,7 @@ static int eval_host(uf3_basis *b, const uf3_frames *fr, const double *pos, cons
             {
                 const int *fl = (const int *)((const char *)c->pin_out.p + total);
                 if (fl[0]) return check_flags(c);
-                if (c->md_step && fl[2]) { c->md.valid = false; c->md.redone++; continue; }      // (lists outrun: rebuilt by the repeat)
+                if (c->md_step && fl[2]) { c->md.valid = false; c->md.verify_next = true; c->md.redone++; continue; }      // (lists outrun, or clipped by a build nobody waited for: rebuilt by the repeat, with the host looking)
                 if (c->md_step && fl[3]) c->md.stale = true;
                 if (cap_used && fl[1] > cap_used) { c->n3_cap = (fl[1] + 8 + 7) / 8 * 8; continue; }
                 c->md.flags_clean = c->md_step && !fl[1] && !fl[2] && !fl[3];

@@ -149,7 +149,7 @@ k_prepare_small(const BasisDev *B, const FrameGeom *geoms, const int64_t *atom_o
         if (tid < 30) z2s_words[tid] = ((const int *)B->z2s)[tid];
         if (host_block) for (int q = tid; q < block_int4s; q += nt) dev_block[q] = host_block[q];
         if (tid < n_zero_flags) flags[1 + tid] = 0;
-        if (tid == 0) { flags[3] = 0; flags[4] = 0; flags[12] = 0; }      // ([12]: k_frame_sum's count of finished workgroups -- left over by an aborted call otherwise)
+        if (tid == 0) { flags[3] = 0; flags[4] = 0; flags[5] = 0; flags[12] = 0; }      // ([5]: md_build's list-length report; [12]: k_frame_sum's count of finished workgroups -- left over by an aborted call otherwise)
         __syncthreads();
         const FrameGeom &g = *(const FrameGeom *)geom_words;
         unsigned long long key = ~0ull;
@@ -211,7 +211,7 @@ k_prepare_small(const BasisDev *B, const FrameGeom *geoms, const int64_t *atom_o
         __syncthreads();
     }
     if (tid < n_zero_flags) flags[1 + tid] = 0;                   // (n3_need, cand_need of the launches that follow)
-    if (tid == 0) { flags[3] = 0; flags[4] = 0; flags[12] = 0; }  // (extension-list need, "some atom outside its cell", k_frame_sum's workgroup count)
+    if (tid == 0) { flags[3] = 0; flags[4] = 0; flags[5] = 0; flags[12] = 0; }  // (extension-list need, "some atom outside its cell", k_frame_sum's workgroup count)
     bool outside = false;
     int n_pow2 = 64;
     while (n_pow2 < natoms) n_pow2 <<= 1;
@@ -525,8 +525,12 @@ k_build_sup(const BasisDev *B, const FrameGeom *geoms, const int *frame_of, Cell
 // radius may round differently).  What a step's centre pass needs to hand a neighbour its share of the triplet forces directly
 // (k_eval<MD>: md_inbox) instead of leaving it to be looked for (k_eval_collect).  16 lanes per atom.
 __global__ void __launch_bounds__(256)
-k_sup_reverse(SupEntry *ent, const int *cnt, int cap, int natoms, const FrameGeom *geoms, const int *frame_of, const signed char *spec) {
+k_sup_reverse(SupEntry *ent, const int *cnt, int cap, int natoms, const FrameGeom *geoms, const int *frame_of, const signed char *spec,
+              const int *overflow_need, int *hard_flag) {
     const int wg = (int)((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3));
+    // (a build whose verdict the host did not wait for: lists that overflowed their capacity are clipped -- the step behind
+    // this launch must be discarded like one whose atoms outran the skin, and the repeat builds with the host looking)
+    if (hard_flag && blockIdx.x == 0 && threadIdx.x == 0 && *overflow_need > cap) *hard_flag = 1;
     const int m = wg * 16 + (threadIdx.x >> 4), sub = threadIdx.x & 15;
     if (m >= natoms) return;
     const int n = min(cnt[m], cap);
@@ -565,6 +569,17 @@ k_md_fetch(const int4 *host_block, int4 *dev_block, int block_int4s, int *flags)
     for (int q = threadIdx.x; q < block_int4s; q += blockDim.x) dev_block[q] = host_block[q];
     if (threadIdx.x < 6) flags[1 + threadIdx.x] = 0;
     if (threadIdx.x == 0) flags[12] = 0;
+}
+
+// what an MD step reads besides the lists -- frame geometry | offsets, frame and species of every atom, the positions of the
+// build -- into the context's persistent copies: one launch instead of four device-to-device copies
+__global__ void __launch_bounds__(256)
+k_md_snapshot(const unsigned *geo_src, unsigned *geo_dst, size_t geo_words, const unsigned *fo_src, unsigned *fo_dst, size_t natoms,
+              const signed char *sp_src, signed char *sp_dst, const unsigned *pos_src, unsigned *pos_dst) {
+    const size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x, step = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = i0; i < geo_words; i += step) geo_dst[i] = geo_src[i];
+    for (size_t i = i0; i < natoms; i += step) { fo_dst[i] = fo_src[i]; sp_dst[i] = sp_src[i]; }
+    for (size_t i = i0; i < 6 * natoms; i += step) pos_dst[i] = pos_src[i];
 }
 
 // largest list length of a batch (capacity tuning after the first build of a context)
