@@ -103,6 +103,8 @@ struct uf3_ctx {
     // small MD steps without a fetch kernel: with a large BAR the host stores positions | species straight into a (fine-grained)
     // device block -- no launch that reads the caller's pinned block, no dispatch gap behind a 4 us kernel (eval_impl, MD route)
     bool bar_ok = false;
+    Buf stage_bar;                      // the fine-grained block of small batches (upload_frames)
+    char *stage_cur = nullptr;          // the block that holds the current host-entry batch: stage_bar or stage_pos
     size_t staged_in_dev = 0;           // bytes of positions | species the host entry has stored into stage_pos already (0: none)
     // environment switches of the featurizer's asynchronous path, read once (uf3_ctx_create)
     bool env_no_feat3 = false, env_f3_no_cap16 = false, env_f3_no_select = false, env_debug_lds = false;
@@ -279,6 +281,7 @@ extern "C" void uf3_ctx_destroy(uf3_ctx *c) {
     for (Buf &b : c->gram_tiles) b.release();
     if (c->comm) uf3_comm_destroy(c);
     { Buf *mdb[] = {&c->md.ent, &c->md.cnt, &c->md.pos_ref, &c->md.geo, &c->md.frame_of, &c->md.spec, &c->md.inbox, &c->md.surv, &c->md.mark}; for (Buf *b : mdb) b->release(); }
+    c->stage_bar.release();
     c->pin_in.release(); c->pin_geo.release(); c->pin_out.release(); c->pin_flags.release(); c->pin_eval.release();
     for (auto &pd : c->pending_chk) if (pd.ev) hipEventDestroy(pd.ev);
     if (c->pin_in_done) hipEventDestroy(c->pin_in_done);
@@ -1189,16 +1192,16 @@ static int prepare(uf3_basis *b, const uf3_frames *fr, const double *d_pos, cons
     const int64_t *d_offsets;
     const int4 *host_block = nullptr;           // != null: k_prepare_small fetches the staged block itself
     size_t host_block_bytes = 0;
-    if (c->staged_in_dev && d_pos == c->stage_pos.as<double>()) {
+    if (c->staged_in_dev && d_pos == (const double *)c->stage_cur) {
         // positions | species are in the device block already (upload_frames, through the BAR): geometry | offsets behind them
         const size_t at = c->staged_in_dev;
         c->staged_in_dev = 0;
-        std::memcpy((char *)c->stage_pos.p + at, geoms.data(), sizeof(FrameGeom) * nf);
-        std::memcpy((char *)c->stage_pos.p + at + geo_bytes, fr->atom_offsets, off_bytes);
+        std::memcpy(c->stage_cur + at, geoms.data(), sizeof(FrameGeom) * nf);
+        std::memcpy(c->stage_cur + at + geo_bytes, fr->atom_offsets, off_bytes);
         __builtin_ia32_sfence();
-        d_geoms = (const FrameGeom *)((const char *)c->stage_pos.p + at);
-        d_offsets = (const int64_t *)((const char *)c->stage_pos.p + at + geo_bytes);
-    } else if (c->pin_in_pending && d_pos == c->stage_pos.as<double>()) {
+        d_geoms = (const FrameGeom *)((const char *)c->stage_cur + at);
+        d_offsets = (const int64_t *)((const char *)c->stage_cur + at + geo_bytes);
+    } else if (c->pin_in_pending && d_pos == (const double *)c->stage_cur) {
         // small batch staged by upload_frames: positions | species | geometry | offsets leave pin_in in one piece -- fetched by
         // the cell-list kernel itself when that is the one-workgroup kernel, by one copy otherwise
         const size_t at = c->pin_in_pending;
@@ -1208,12 +1211,12 @@ static int prepare(uf3_basis *b, const uf3_frames *fr, const double *d_pos, cons
             host_block = (const int4 *)c->pin_in.p;
             host_block_bytes = (at + geo_bytes + off_bytes + 15) / 16 * 16;
         } else {
-            HIPCHK(c, hipMemcpyAsync(c->stage_pos.p, c->pin_in.p, at + geo_bytes + off_bytes, hipMemcpyHostToDevice, st));
+            HIPCHK(c, hipMemcpyAsync(c->stage_cur, c->pin_in.p, at + geo_bytes + off_bytes, hipMemcpyHostToDevice, st));
             HIPCHK(c, hipEventRecord(c->pin_in_done, st));
         }
         c->pin_in_pending = 0;
-        d_geoms = (const FrameGeom *)((const char *)c->stage_pos.p + at);
-        d_offsets = (const int64_t *)((const char *)c->stage_pos.p + at + geo_bytes);
+        d_geoms = (const FrameGeom *)((const char *)c->stage_cur + at);
+        d_offsets = (const int64_t *)((const char *)c->stage_cur + at + geo_bytes);
     } else {
         HIPCHK(c, c->geoms.ensure(geo_bytes + off_bytes));
         HIPCHK(c, hipEventSynchronize(c->pin_geo_done));
@@ -1240,7 +1243,7 @@ static int prepare(uf3_basis *b, const uf3_frames *fr, const double *d_pos, cons
         hipLaunchKernelGGL(k_prepare_small, dim3(1), dim3(natoms <= 256 ? 256 : 1024), 0, st, b->dev, d_geoms, d_offsets, nf,
                            natoms, nbins, d_pos, d_z, c->frame_of.as<int>(), c->atom_bin.as<int>(), c->atom_wrap.as<int>(),
                            c->spec.as<signed char>(), c->bin_start.as<int>(), c->slots.as<SlotRec>(), flags, 2,
-                           host_block, (int4 *)c->stage_pos.p, (int)(host_block_bytes / 16));
+                           host_block, (int4 *)c->stage_cur, (int)(host_block_bytes / 16));
         P.small_prepared = true;
         if (host_block) c->pin_in_busy = true;     // (until the caller's wait for the stream: upload_frames checks)
         // (host_block: no event behind the kernel -- a record between two launches costs the next kernel ~5 us of dispatch
@@ -1749,15 +1752,17 @@ static int upload_frames(uf3_ctx *c, const uf3_frames *fr, const double *pos, co
     // host stores into it directly (write-combined, posted; a store fence; the launches' doorbell follows over the same link) --
     // no kernel or copy that reads the caller's memory.  The entry's previous call has been waited for: nothing reads the block.
     bool bar = defer_small && c->bar_ok && bp + bz + geo_room <= UF3_BAR_LIMIT;
-    if (bar && c->stage_pos.ensure_fine(bp + bz + geo_room) != hipSuccess) { (void)hipGetLastError(); c->bar_ok = false; bar = false; }
-    HIPCHK(c, c->stage_pos.ensure(bp + bz + geo_room));            // positions | species, one block
-    c->d_stage_z = (int32_t *)((char *)c->stage_pos.p + bp);
+    // (a block of its own: the big batches' staging block stays ordinary device memory)
+    if (bar && c->stage_bar.ensure_fine(bp + bz + geo_room) != hipSuccess) { (void)hipGetLastError(); c->bar_ok = false; bar = false; }
+    if (!bar) HIPCHK(c, c->stage_pos.ensure(bp + bz + geo_room));  // positions | species, one block
+    c->stage_cur = (char *)(bar ? c->stage_bar.p : c->stage_pos.p);
+    c->d_stage_z = (int32_t *)(c->stage_cur + bp);
     c->pin_in_pending = 0;
     c->staged_in_dev = 0;
-    if (bar && c->stage_pos.fine) {
+    if (bar) {
         if (c->pin_in_busy) { HIPCHK(c, hipStreamSynchronize(c->stream)); c->pin_in_busy = false; }
-        std::memcpy(c->stage_pos.p, pos, bp);
-        std::memcpy((char *)c->stage_pos.p + bp, z, bz);
+        std::memcpy(c->stage_cur, pos, bp);
+        std::memcpy(c->stage_cur + bp, z, bz);
         __builtin_ia32_sfence();
         c->staged_in_dev = (bp + bz + 15) / 16 * 16;
         return UF3_OK;
@@ -1792,7 +1797,7 @@ extern "C" int uf3_featurize(uf3_basis *b, const uf3_frames *fr, const double *p
     if (be) HIPCHK(c, c->stage_out.ensure(be));
     if (bf) HIPCHK(c, c->stage_out2.ensure(bf));
     for (int attempt = 0; attempt < 6; attempt++) {
-        rc = uf3_featurize_dev(b, fr, c->stage_pos.as<double>(), c->d_stage_z,
+        rc = uf3_featurize_dev(b, fr, (const double *)c->stage_cur, c->d_stage_z,
                                be ? c->stage_out.as<double>() : nullptr, bf ? c->stage_out2.as<double>() : nullptr);
         if (rc) return rc;
         if (be) HIPCHK(c, hipMemcpyAsync(xe, c->stage_out.p, be, hipMemcpyDeviceToHost, c->stream));
@@ -1957,23 +1962,23 @@ static int eval_impl(uf3_basis *b, const uf3_frames *fr, const double *d_pos, co
         if (c->md.stale || !md_key_matches(c->md, b, fr)) {
             rc = md_build(b, fr, d_pos, d_z, P, true);
             if (rc) return rc;
-        } else if (c->staged_in_dev && d_pos == c->stage_pos.as<double>()) {
+        } else if (c->staged_in_dev && d_pos == (const double *)c->stage_cur) {
             // positions | species are in the device block already (upload_frames, through the BAR).  k_md_fetch also zeroed the
             // step's status words: needed only when they are not known to be zero (was_clean: the previous call was an MD step
             // of the host entry that set none -- the host has just read them)
             c->staged_in_dev = 0;
             if (!was_clean)
                 hipLaunchKernelGGL(k_md_fetch, dim3(1), dim3(64), 0, st, (const int4 *)nullptr, (int4 *)nullptr, 0, c->flags.as<int>());
-        } else if (c->pin_in_pending && d_pos == c->stage_pos.as<double>()) {
+        } else if (c->pin_in_pending && d_pos == (const double *)c->stage_cur) {
             // a small batch staged by upload_frames: positions | species are still in the caller's pinned block
             const size_t at = c->pin_in_pending;
             c->pin_in_pending = 0;
             if (c->md.natoms <= UF3_SMALL_ATOMS && !uf3_env("UF3_NO_ZERO_COPY")) {
-                hipLaunchKernelGGL(k_md_fetch, dim3(1), dim3(256), 0, st, (const int4 *)c->pin_in.p, (int4 *)c->stage_pos.p, (int)(at / 16),
+                hipLaunchKernelGGL(k_md_fetch, dim3(1), dim3(256), 0, st, (const int4 *)c->pin_in.p, (int4 *)c->stage_cur, (int)(at / 16),
                                    c->flags.as<int>());
                 c->pin_in_busy = true;
             } else {
-                HIPCHK(c, hipMemcpyAsync(c->stage_pos.p, c->pin_in.p, at, hipMemcpyHostToDevice, st));
+                HIPCHK(c, hipMemcpyAsync(c->stage_cur, c->pin_in.p, at, hipMemcpyHostToDevice, st));
                 HIPCHK(c, hipEventRecord(c->pin_in_done, st));
                 HIPCHK(c, hipMemsetAsync(c->flags.as<int>() + 1, 0, 4 * sizeof(int), st));
             }
@@ -2221,7 +2226,7 @@ static int eval_host(uf3_basis *b, const uf3_frames *fr, const double *pos, cons
             // mirror's layout has the forces right behind the 7 nf sums, as d_e does)
             const bool zero_copy = natoms <= UF3_SMALL_ATOMS && !uf3_env("UF3_NO_ZERO_COPY");
             *(volatile unsigned *)((char *)c->pin_out.p + total + 16) = 0;
-            rc = eval_impl(b, fr, c->stage_pos.as<double>(), c->d_stage_z, c1, c2, c3, d_e, forces ? d_f : nullptr,
+            rc = eval_impl(b, fr, (const double *)c->stage_cur, c->d_stage_z, c1, c2, c3, d_e, forces ? d_f : nullptr,
                            virials ? d_v : nullptr, atom_begin, atom_end, &cap_used, d_flags_tail,
                            zero_copy ? (double *)c->pin_out.p : nullptr, centre_share);
             if (rc) return rc;
@@ -2257,7 +2262,7 @@ static int eval_host(uf3_basis *b, const uf3_frames *fr, const double *pos, cons
         }
         return fail(c, UF3_EOVERFLOW, "3-body neighbour capacity did not converge");
     }
-    rc = eval_impl(b, fr, c->stage_pos.as<double>(), c->d_stage_z, c1, c2, c3, d_e, forces ? d_f : nullptr,
+    rc = eval_impl(b, fr, (const double *)c->stage_cur, c->d_stage_z, c1, c2, c3, d_e, forces ? d_f : nullptr,
                    virials ? d_v : nullptr, atom_begin, atom_end, nullptr, nullptr, nullptr, centre_share);
     if (rc) return rc;
     HIPCHK(c, hipMemcpyAsync(energies, d_e, 8 * nf, hipMemcpyDeviceToHost, c->stream));
@@ -2942,7 +2947,7 @@ static int neighbors_impl(uf3_basis *b, const uf3_frames *fr, const double *pos,
     int rc = upload_frames(c, fr, pos, z, natoms);
     if (rc) return rc;
     Prepared P;
-    rc = prepare(b, fr, c->stage_pos.as<double>(), c->d_stage_z, false, P);
+    rc = prepare(b, fr, (const double *)c->stage_cur, c->d_stage_z, false, P);
     if (rc) return rc;
     int np = b->host.P;
     std::vector<long long> counts(np + 2, 0);
@@ -2956,7 +2961,7 @@ static int neighbors_impl(uf3_basis *b, const uf3_frames *fr, const double *pos,
         double *d_geo = pair_geo ? (double *)(d_tuples + 3 * ncap) : nullptr;
         HIPCHK(c, hipMemsetAsync(d_counts, 0, head, c->stream));
         hipLaunchKernelGGL(k_debug_pairs, dim3(natoms), dim3(64), 0, c->stream, b->dev, P.geoms, P.frame_of, P.cl,
-                           (const double *)c->stage_pos.as<double>(), P.spec, natoms, d_counts, d_tuples, cap, d_geo);
+                           (const double *)c->stage_cur, P.spec, natoms, d_counts, d_tuples, cap, d_geo);
         HIPCHK(c, hipMemcpyAsync(counts.data(), d_counts, head, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         if (pass == 0) { cap = counts[np + 1]; if (cap == 0) break; continue; }
