@@ -219,6 +219,15 @@ static const char *uf3_env(const char *name) {
     return nullptr;
 }
 
+// host stores into device memory through the BAR are write-combined: drain them before the launch that reads them is queued
+static inline void uf3_store_fence() {
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_sfence();
+#else
+    __sync_synchronize();
+#endif
+}
+
 static thread_local std::string g_err;
 static int fail(uf3_ctx *ctx, int code, const std::string &msg) {
     if (ctx) ctx->err = msg;
@@ -1198,7 +1207,7 @@ static int prepare(uf3_basis *b, const uf3_frames *fr, const double *d_pos, cons
         c->staged_in_dev = 0;
         std::memcpy(c->stage_cur + at, geoms.data(), sizeof(FrameGeom) * nf);
         std::memcpy(c->stage_cur + at + geo_bytes, fr->atom_offsets, off_bytes);
-        __builtin_ia32_sfence();
+        uf3_store_fence();
         d_geoms = (const FrameGeom *)((const char *)c->stage_cur + at);
         d_offsets = (const int64_t *)((const char *)c->stage_cur + at + geo_bytes);
     } else if (c->pin_in_pending && d_pos == (const double *)c->stage_cur) {
@@ -1763,7 +1772,7 @@ static int upload_frames(uf3_ctx *c, const uf3_frames *fr, const double *pos, co
         if (c->pin_in_busy) { HIPCHK(c, hipStreamSynchronize(c->stream)); c->pin_in_busy = false; }
         std::memcpy(c->stage_cur, pos, bp);
         std::memcpy(c->stage_cur + bp, z, bz);
-        __builtin_ia32_sfence();
+        uf3_store_fence();
         c->staged_in_dev = (bp + bz + 15) / 16 * 16;
         return UF3_OK;
     }
@@ -2468,8 +2477,14 @@ extern "C" int uf3_fit_add(uf3_fit *f, int32_t n_frames, const int64_t *atom_cou
         const int n_thr = (atoms >= 100000 && nf >= 2) ? std::min(f->pack_threads, nf) : 1;
         if (n_thr > 1) {
             std::vector<std::thread> thr;
-            for (int t = 1; t < n_thr; t++) thr.emplace_back(pack, (int)((int64_t)nf * t / n_thr), (int)((int64_t)nf * (t + 1) / n_thr));
-            pack(0, nf / n_thr);
+            int done_to = nf / n_thr;                   // frames [0, done_to) are this thread's; a thread that cannot be started leaves its share to it too
+            std::vector<std::pair<int, int>> mine;
+            for (int t = 1; t < n_thr; t++) {
+                const int i0 = (int)((int64_t)nf * t / n_thr), i1 = (int)((int64_t)nf * (t + 1) / n_thr);
+                try { thr.emplace_back(pack, i0, i1); } catch (...) { mine.emplace_back(i0, i1); }
+            }
+            pack(0, done_to);
+            for (auto &r : mine) pack(r.first, r.second);
             for (auto &t : thr) t.join();
         } else pack(0, nf);
         if (st.consumed_live) HIPCHK(c, hipStreamWaitEvent(f->copy_stream, st.consumed, 0));            // (the device block is free again)
