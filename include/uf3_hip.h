@@ -103,6 +103,10 @@ int uf3_ctx_set_stream(uf3_ctx *ctx, void *hip_stream);
 int uf3_ctx_use_own_stream(uf3_ctx *ctx);
 int uf3_ctx_synchronize(uf3_ctx *ctx);
 const char *uf3_last_error(const uf3_ctx *ctx);
+/* Which sources this binary was compiled from: the first 16 hex digits of the sha256 over uf3_hip.hip, uf3_kernels.h,
+ * uf3_feat3.h, uf3_device.h and this header, concatenated in that order (the Makefile passes it in; "unknown" for a build
+ * outside it).  __graft_entry__.build() rebuilds when it differs from the tree's, smoke() prints it. */
+const char *uf3_build_id(void);
 /* timing of the dominant kernel: (re)start / read accumulated HIP-event time in ms and launches */
 int uf3_ctx_timing_reset(uf3_ctx *ctx, int enable);
 int uf3_ctx_timing_read(uf3_ctx *ctx, double *featurize_ms, int64_t *featurize_launches,

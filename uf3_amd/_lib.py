@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("UF3_LIB_PATH", os.path.join(_HERE, "csrc", "libuf3hip.so"))
 
 EXPORTS = ["uf3_ctx_create", "uf3_ctx_destroy", "uf3_ctx_set_stream", "uf3_ctx_synchronize",
-           "uf3_last_error", "uf3_ctx_timing_reset", "uf3_ctx_timing_read",
+           "uf3_last_error", "uf3_build_id", "uf3_ctx_timing_reset", "uf3_ctx_timing_read",
            "uf3_ctx_use_own_stream", "uf3_basis_create", "uf3_basis_destroy", "uf3_basis_featurizer_modes",
            "uf3_featurize", "uf3_featurize_dev", "uf3_gram", "uf3_gram_dev",
            "uf3_eval", "uf3_eval_dev", "uf3_eval_virial", "uf3_eval_virial_dev", "uf3_eval_atoms", "uf3_eval_atoms_dev",
@@ -27,6 +27,25 @@ EXPORTS = ["uf3_ctx_create", "uf3_ctx_destroy", "uf3_ctx_set_stream", "uf3_ctx_s
            "uf3_ctx_md_skin", "uf3_ctx_md_stats",
            "uf3_featurize_ld_dev", "uf3_fit_create", "uf3_fit_destroy", "uf3_fit_reset", "uf3_fit_add", "uf3_fit_pack", "uf3_fit_info", "uf3_fit_use_flat", "uf3_fit_first_chunk",
            "uf3_comm_unique_id", "uf3_comm_init", "uf3_comm_destroy", "uf3_comm_info", "uf3_allreduce_sum_f64", "uf3_gram_allreduce"]
+
+
+SOURCES = ("uf3_hip.hip", "uf3_kernels.h", "uf3_feat3.h", "uf3_device.h", os.path.join("..", "..", "include", "uf3_hip.h"))
+
+
+def source_build_id(csrc_dir=None):
+    """What ``uf3_build_id()`` of a library compiled from the tree's sources returns (the Makefile's recipe)."""
+    import hashlib
+    csrc_dir = csrc_dir or os.path.join(_HERE, "csrc")
+    h = hashlib.sha256()
+    for name in SOURCES:
+        with open(os.path.join(csrc_dir, name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def build_id():
+    """The source hash the loaded library was compiled from."""
+    return load().uf3_build_id().decode()
 
 
 class HipUnavailable(RuntimeError):
@@ -114,6 +133,8 @@ def load():
         lib.uf3_ctx_synchronize.argtypes = [vp]
         lib.uf3_last_error.argtypes = [vp]
         lib.uf3_last_error.restype = C.c_char_p
+        lib.uf3_build_id.argtypes = []
+        lib.uf3_build_id.restype = C.c_char_p
         lib.uf3_ctx_timing_reset.argtypes = [vp, C.c_int]
         lib.uf3_ctx_timing_read.argtypes = [vp, C.POINTER(dbl), C.POINTER(i64), C.POINTER(dbl),
                                             C.POINTER(dbl), C.POINTER(dbl)]

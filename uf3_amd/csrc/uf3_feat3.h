@@ -58,6 +58,13 @@ struct Feat3Args {
     const int *sel;            // instance selection on the device (uf3_featurize_dev launches two instances back to back when the
     int sel_mode, sel_cap;     // context's list capacity is above 16): 0 always run; 1 run iff *sel <= sel_cap; 2 iff *sel > sel_cap
     int skip;                  // ablations (-DUF3_ABLATE builds only): 1 stage 1, 2 stage 2, 4 centre walk, 8 neighbour walk, 16 fold + stores, 32 bond tables, 64 leg evaluations of the walks
+    // hand-off of the neighbour role's stage-1 sums (round 6, k_feat3_w -> k_featurize3<.., HO = true>): W(e -> m) of every
+    // directed bond, written by the CENTRE e into the slot of the CONSUMER m: [(m - m_lo) * n3.cap + index of e in m's list]
+    // [partner species][wsz doubles]
+    double *wbuf;
+    int wsz;                   // doubles per (bond, partner species): window positions x (W_x, W_y, W_z, W_plain), padded to whole
+                               // 128-byte lines (27 positions: 112 doubles, 7 lines)
+    int m_lo;                  // first atom of the launch (the launch covers m_lo .. natoms - 1; wbuf is indexed from m_lo)
 };
 
 // Compile-time shape of a launch: EF = rows of the window on the fixed leg (= ext of the centre legs), NR = rounds of 32 W
@@ -131,9 +138,12 @@ __device__ __forceinline__ int f3_eval(const double *rows, const Feat3Leg &lg, d
 #ifndef F3_WIDE_MINW
 #define F3_WIDE_MINW 2     // waves per SIMD the wide-window instances (NR > 1) are bounded for
 #endif
-template <bool WANT_E, int EF, int NR, int CAP = 0>
+// HO: the neighbour role's stage-1 sums come from the hand-off buffer (k_feat3_w below ran over the same atoms before this
+// launch): what is left of the role is one 16-byte load per lane and bond, and the flush
+template <bool WANT_E, int EF, int NR, int CAP = 0, bool HO = false>
 __global__ void __launch_bounds__(WPB * WAVE, (NR == 1 ? 4 : F3_WIDE_MINW))
 k_featurize3(Feat3Args A) {
+    static_assert(!HO || NR == 1, "the hand-off buffer is laid out for the one-round window");
     typedef F3Cfg<EF, NR> Cfg;
     constexpr int RS_C = Cfg::RS_C, RS_N = Cfg::RS_N, NREC = Cfg::NREC, PS = Cfg::PS, EFP = Cfg::EFP;
     extern __shared__ __align__(16) unsigned char smem[];
@@ -206,7 +216,7 @@ k_featurize3(Feat3Args A) {
     };
 
     const int bid = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
-    const int block_first = bid * A.atoms_per_block;
+    const int block_first = A.m_lo + bid * A.atoms_per_block;
     const int block_end = min(block_first + A.atoms_per_block, A.natoms);
     int erow_frame = -1;
     for (int m0 = block_first; m0 < block_end; m0 += WPB) {
@@ -243,10 +253,11 @@ k_featurize3(Feat3Args A) {
         }
         if (lane <= S) so[lane] = A.n3.spoff[(size_t)m * (UF3_MAX_SPECIES + 1) + lane];
         wave_sync();
-        for (int e = lane; e < n_own; e += WAVE) {
-            const int *src = A.n3.spoff + (size_t)oparent[e] * (UF3_MAX_SPECIES + 1);
-            for (int sp = 0; sp <= S; sp++) ospoff[e * (S + 1) + sp] = src[sp];
-        }
+        if (!HO)
+            for (int e = lane; e < n_own; e += WAVE) {
+                const int *src = A.n3.spoff + (size_t)oparent[e] * (UF3_MAX_SPECIES + 1);
+                for (int sp = 0; sp <= S; sp++) ospoff[e * (S + 1) + sp] = src[sp];
+            }
         // ---- T_f of every own bond: rows over the whole window of the centre legs, zero where the bond's four functions are
         // not (and all zero when the bond is outside the legs' range) -------------------------------------------------------
         for (int e = lane; e < n_own; e += WAVE) {
@@ -415,7 +426,32 @@ k_featurize3(Feat3Args A) {
             // ---- neighbour role: m is a neighbour of the centre e (fixed bond (m, e)); k runs over e's list.  The valid items of
             // a step are compacted into the stage in order (runs of a fixed bond are found with one ballot); what a lane needs of
             // a record besides its operands -- the first n slot -- it reads itself (no per-record work on the scalar unit).
-            if (nbr && !UF3_SKIP(8)) {
+            if (HO && nbr && !UF3_SKIP(8)) {
+                // W(e -> m) of every own bond to a centre of this block, as that centre's k_feat3_w left it: consecutive bonds are
+                // consecutive slots of the buffer; four loads in flight, then their flushes
+                const int sx = sm == t_sa ? t_sb : t_sa;
+                const int rc_lo = __builtin_amdgcn_readfirstlane(so[t_sc]), ncen = __builtin_amdgcn_readfirstlane(so[t_sc + 1]) - rc_lo;
+                const bool lane_on = n_lane[0] >= 0;
+                const size_t wstep = (size_t)S * A.wsz;
+                const double *wb = A.wbuf + (((size_t)(m - A.m_lo) * ent_stride + rc_lo) * S + sx) * A.wsz + (lane & 31) * 4 + 2 * half;
+                for (int e0 = 0; e0 < ncen; e0 += 4) {
+                    F3Pair w[4];
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const int idx = min(e0 + i, ncen - 1);
+                        w[i] = lane_on ? __builtin_nontemporal_load((const F3Pair *)(wb + (size_t)idx * wstep)) : F3Pair{0.0, 0.0};
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; i++)
+                        if (e0 + i < ncen) {
+                            cur = rc_lo + e0 + i;
+                            ws[0][0] = w[i].x; ws[0][1] = w[i].y;
+                            flush(false);
+                        }
+                }
+                cur = -1;
+            }
+            if (!HO && nbr && !UF3_SKIP(8)) {
                 const int sx = sm == t_sa ? t_sb : t_sa;
                 const int rc_lo = so[t_sc], ncen = so[t_sc + 1] - rc_lo;
                 int total_n = 0;
@@ -592,5 +628,213 @@ k_featurize3(Feat3Args A) {
                 double v = erow[q];
                 if (v != 0.0) unsafeAtomicAdd(A.x_e + (size_t)erow_frame * F + q, v);
             }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// k_feat3_w (round 6) -- the neighbour role's stage-1 sums, computed ONCE, at the centre.
+//
+// k_featurize3's neighbour role has atom m rebuild, for every bond (m, e) to a centre e, the sums
+//     W_s[j][n] = sum over e's neighbours k != m of  B(r_ek)[j] * (a3 B_n'(r_mk), B_n(r_mk))_s[n],     a3 = unit(m -> k)
+// by walking e's list -- the same (bond, partner) rectangle that e's own centre role enumerates.  Here the centre e does it:
+// its ordered pairs (f, g), f the bond that stays fixed (the future consumer), g the partner, items p = fi * nG + gi of the
+// rectangle one per lane, uncompacted (a void item is a record of zeros), a record DENSE over the n window (a3 B_n' | B_n at
+// every n slot: 9 quads, zeros outside the four functions of the interval) so that stage 1 reads record and bond table at
+// constant offsets -- no clamp arithmetic, no compaction, no headers.  The sums of a fixed bond f leave as ONE 16-byte store per
+// lane into the slot of the consumer: [f's atom][index of e in f's list][species of the partners] (Feat3Args::wbuf), found with
+// a reverse look-up in the atom's prologue.  k_featurize3<.., HO = true> reads them back and keeps only the flush.
+// Reference arithmetic: angles.py:142-286 (the terms of featurize_force_3b that differentiate leg n, and the n-leg factor of
+// the terms that differentiate the centre leg of the neighbour), :517-632.
+#ifndef F3W_NRECP
+#define F3W_NRECP 32       // records per stage pass (a step of 64 items is 64 / F3W_NRECP passes)
+#endif
+struct F3WCfg {
+    static constexpr int RS_W = 38;                 // doubles per record: 9 n slots x (a3x B', a3y B', a3z B', B) | pad: 76 dwords apart, so that
+                                                    // the sixteen lanes of a 16-byte store group fall on different banks (72: eight-way conflicts)
+    static constexpr int NRECP = F3W_NRECP;
+    static constexpr int STAGE = NRECP * RS_W;
+};
+
+template <int EF, int CAP = 0>
+__global__ void __launch_bounds__(WPB * WAVE, 4)
+k_feat3_w(Feat3Args A) {
+    static_assert(EF <= 4, "one-round windows only");
+    constexpr int RS_W = F3WCfg::RS_W, NRECP = F3WCfg::NRECP;
+    extern __shared__ __align__(16) unsigned char smem[];
+    const BasisDev *B = A.B;
+    const int S = load_const(&B->S), n_trios = load_const(&B->T), cap = CAP > 0 ? CAP : A.n3.cap;
+    const int ent_stride = A.n3.cap;
+    if (A.sel_mode) {
+        const int seen = load_const(A.sel);
+        if ((seen <= A.sel_cap) != (A.sel_mode == 1)) return;
+    }
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // ---- LDS carve (feat3w_lds_bytes on the host): window rows (shared) | per wave: list (4 cap) | bond values [cap][4] | stage
+    // | ints: parent, shift, reverse index, list length of the neighbour (cap each), species offsets ------------------------------
+    double *rows_lds = (double *)smem;
+    const double *rows = rows_lds;
+    const size_t rows_d = (size_t)A.n_rows * 18;
+    const size_t per_wave_d = 8 * (size_t)cap + F3WCfg::STAGE;
+    const size_t per_wave_i = 4 * (size_t)cap + (UF3_MAX_SPECIES + 2);
+    double *wd = rows_lds + rows_d + (size_t)wave * per_wave_d;
+    int *wi = (int *)(rows_lds + rows_d + (size_t)WPB * per_wave_d) + (size_t)wave * per_wave_i;
+    double *ox = wd, *oy = ox + cap, *oz = oy + cap, *orr = oz + cap;
+    double *tb = wd + 4 * cap;                                        // [cap][4]: B(r)[window row] of every own bond
+    double *stage = tb + 4 * cap;
+    int *oparent = wi, *oshift = wi + cap, *orev = wi + 2 * cap, *ocnt = wi + 3 * cap, *so = wi + 4 * cap;
+
+    for (int q = tid; q < (int)rows_d; q += WPB * WAVE) rows_lds[q] = A.rows[q];
+    for (int q = lane; q < F3WCfg::STAGE; q += WAVE) stage[q] = 0.0;
+    __syncthreads();
+
+    const int ext_p = A.ext_p, ext_n = A.ext_n, lo_n = A.lo_n;
+    const int half = lane >> 5;
+    const int pl = (lane & 31) / ext_n;
+    const bool lane_on = pl < ext_p;
+    const int p_lane = lane_on ? pl : 0, n_lane = lane_on ? (lane & 31) - pl * ext_n : 0;     // (idle lanes sum what they like; never stored)
+    const int sbn_max = ext_n > 4 ? ext_n - 4 : 0;
+    const Feat3Leg leg_p = A.leg_p, leg_n = A.leg_n;
+    const size_t wslot = (size_t)(lane & 31) * 4 + 2 * half;
+
+    const int bid = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    const int block_first = A.m_lo + bid * A.atoms_per_block;
+    const int block_end = min(block_first + A.atoms_per_block, A.natoms);
+    for (int m0 = block_first; m0 < block_end; m0 += WPB) {
+        const int m = m0 + wave;
+        if (m >= block_end) continue;
+        const int sm = ((const __attribute__((address_space(4))) signed char *)(unsigned long long)A.spec)[m];
+        const int n_own = load_const(A.n3.cnt + m);
+        wave_sync();
+        for (int e = lane; e < n_own; e += WAVE) {
+            const N3Entry en = A.n3.ent[(size_t)m * ent_stride + e];
+            ox[e] = en.dx; oy[e] = en.dy; oz[e] = en.dz; orr[e] = en.r;
+            int s0, s1, s2;
+            unpack3(en.shiftc, s0, s1, s2);
+            oparent[e] = en.parent; oshift[e] = pack3(-s0, -s1, -s2);      // (this atom's image as the neighbour's list names it)
+            ocnt[e] = A.n3.cnt[en.parent];
+            orev[e] = -1;
+            double v[4] = {0, 0, 0, 0}, d[4];
+            if (en.r > leg_p.t0 && en.r < leg_p.tlast) f3_eval<false>(rows, leg_p, en.r, v, d);
+            *(double2 *)(tb + 4 * e) = double2{v[0], v[1]};
+            *(double2 *)(tb + 4 * e + 2) = double2{v[2], EF > 3 ? v[3] : 0.0};
+        }
+        if (lane <= S) so[lane] = A.n3.spoff[(size_t)m * (UF3_MAX_SPECIES + 1) + lane];
+        wave_sync();
+        // ---- where this atom sits in each neighbour's list (the slot its sums go to): lanes = (bond, entry of the neighbour's list)
+        for (int it = lane; it < n_own * cap; it += WAVE) {
+            const int f = it / cap, q = it - f * cap;
+            if (q < ocnt[f]) {
+                const int2 ps = *(const int2 *)&A.n3.ent[(size_t)oparent[f] * ent_stride + q].parent;
+                if (ps.x == m && ps.y == oshift[f]) orev[f] = q;
+            }
+        }
+        wave_sync();
+
+        for (int t = 0; t < n_trios; t++) {
+            const TrioDev *td = A.trios + t;
+            typedef int int8_v __attribute__((ext_vector_type(8)));
+            const int8_v hv = *(const __attribute__((address_space(4))) int8_v *)(unsigned long long)&td->head;
+            const int t_sc = hv[3], t_sa = hv[4], t_sb = hv[5];
+            if (t_sc != sm) continue;
+            const bool same = t_sa == t_sb;
+            for (int o = 0; o < (same ? 1 : 2); o++) {
+                // fixed bonds f of species fs (the consumers), partners g of species gs
+                const int fs = o ? t_sb : t_sa, gs = o ? t_sa : t_sb;
+                const int f_lo = __builtin_amdgcn_readfirstlane(so[fs]), nF = __builtin_amdgcn_readfirstlane(so[fs + 1]) - f_lo;
+                const int g_lo = __builtin_amdgcn_readfirstlane(so[gs]), nG = __builtin_amdgcn_readfirstlane(so[gs + 1]) - g_lo;
+                if (nF <= 0) continue;
+                double ws0 = 0.0, ws1 = 0.0;
+                int cur = -1;
+                auto store_w = [&]() {
+                    if (cur >= 0) {
+                        const int rv = orev[cur], pf = oparent[cur];
+                        if (rv >= 0 && lane_on && pf >= A.m_lo) {
+                            double *dst = A.wbuf + (((size_t)(pf - A.m_lo) * ent_stride + rv) * S + gs) * A.wsz + wslot;
+                            *(F3Pair *)dst = F3Pair{ws0, ws1};
+                        }
+                    }
+                    ws0 = ws1 = 0.0;
+                };
+                if (nG <= 0) {                          // no partners: the consumers read zeros
+                    for (int fi = 0; fi < nF; fi++) { cur = f_lo + fi; store_w(); }
+                    continue;
+                }
+                const int total = nF * nG;
+                const float rcp_ng = __builtin_amdgcn_rcpf((float)nG);
+                for (int p0 = 0; p0 < total; p0 += WAVE) {
+                    const int p = p0 + lane;
+                    bool valid = p < total;
+                    int fi = (int)(((float)p + 0.5f) * rcp_ng);
+                    fi -= (fi * nG > p) ? 1 : 0;
+                    fi += ((fi + 1) * nG <= p) ? 1 : 0;
+                    const int gi = p - fi * nG;
+                    valid = valid && (!same || gi != fi);
+                    double bn[4] = {0, 0, 0, 0}, bd[4] = {0, 0, 0, 0}, a3[3] = {0, 0, 0};
+                    int sbn = 0;
+                    if (valid) {
+                        const int f = f_lo + fi, gg = g_lo + gi;
+                        const double rf = orr[f], rg = orr[gg];
+                        const double ex = ox[gg] - ox[f], ey = oy[gg] - oy[f], ez = oz[gg] - oz[f];     // f -> g
+                        const double rn = norm3_leg(ex, ey, ez);
+                        valid = (rf > leg_p.t0) & (rf < leg_p.tlast) & (rg > leg_p.t0) & (rg < leg_p.tlast) &
+                                (rn > leg_n.t0) & (rn < leg_n.tlast);
+                        if (valid) {
+                            const double in = fast_rcp(rn);
+                            a3[0] = ex * in; a3[1] = ey * in; a3[2] = ez * in;
+                            const int iv = f3_eval<true>(rows, leg_n, rn, bn, bd);
+                            sbn = max(0, min(sbn_max, iv - 3 - lo_n));
+                        }
+                    }
+                    const int p1 = min(total, p0 + WAVE);
+                    for (int q0 = p0; q0 < p1; q0 += NRECP) {
+                        const int slot = p - q0;
+                        const bool mine = valid && slot >= 0 && slot < NRECP;
+                        double *rp = stage + (size_t)(slot & (NRECP - 1)) * RS_W + 4 * sbn;
+                        if (mine) {
+#pragma unroll
+                            for (int u = 0; u < 4; u++) {
+                                *(double2 *)(rp + 4 * u) = double2{a3[0] * bd[u], a3[1] * bd[u]};
+                                *(double2 *)(rp + 4 * u + 2) = double2{a3[2] * bd[u], bn[u]};
+                            }
+                        }
+                        wave_sync();
+                        const int q1 = min(q0 + NRECP, p1);
+                        int fi_s = q0 / nG;
+                        for (int pr = fi_s * nG; pr < q1; pr += nG, fi_s++) {
+                            const int s0 = max(pr, q0), s1 = min(pr + nG, q1);             // items of this fixed bond inside the pass
+                            const int key = f_lo + fi_s;
+                            if (key != cur) { store_w(); cur = key; }
+                            const double *qp = stage + (size_t)(s0 - q0) * RS_W + 4 * n_lane + 2 * half;
+                            const double *tp = tb + (size_t)(g_lo + (s0 - pr)) * 4 + p_lane;
+                            int cnt = s1 - s0;
+                            auto body = [&](auto tag) {
+                                constexpr int CNT = decltype(tag)::value;
+                                double bq[CNT];
+                                F3Pair tt[CNT];
+#pragma unroll
+                                for (int i = 0; i < CNT; i++) {
+                                    bq[i] = ((F3LdsDoubles)tp)[i * 4];
+                                    tt[i] = *(F3LdsPairs)(const F3Pair *)(qp + (size_t)i * RS_W);
+                                }
+#pragma unroll
+                                for (int i = 0; i < CNT; i++) { ws0 = fma(bq[i], tt[i].x, ws0); ws1 = fma(bq[i], tt[i].y, ws1); }
+                                qp += CNT * RS_W; tp += CNT * 4; cnt -= CNT;
+                            };
+                            while (cnt >= 4) body(std::integral_constant<int, 4>{});
+                            if (cnt == 3) body(std::integral_constant<int, 3>{});
+                            else if (cnt == 2) body(std::integral_constant<int, 2>{});
+                            else if (cnt == 1) body(std::integral_constant<int, 1>{});
+                        }
+                        wave_sync();
+                        if (mine) {                     // the record's four quads back to zero: the stage stays clean between passes
+#pragma unroll
+                            for (int u = 0; u < 8; u++) *(double2 *)(rp + 2 * u) = double2{0.0, 0.0};
+                        }
+                    }
+                }
+                store_w();
+            }
+        }
     }
 }

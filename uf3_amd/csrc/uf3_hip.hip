@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 #include <thread>
@@ -78,7 +79,8 @@ struct uf3_ctx {
         sp_rows, sp_seg,                // force rows by species (uf3_gram_force_rows_dev): row lists | segment starts, counts, cursors
         halo,                           // marks + index list of the halo atoms of a decomposed frame
         n3x_ent, n3x_off,               // extension lists (batches with atoms outside their cell; see N3Lists)
-        bin_cnt;                        // atoms per cell-list bin (counting sort)
+        bin_cnt,                        // atoms per cell-list bin (counting sort)
+        f3w;                            // hand-off buffer k_feat3_w -> k_featurize3<HO>: [atoms of a slice][list capacity][S][wsz] doubles
     int n3_cap = 0, cand_cap = 0;
     int n3x_cap = 0;                 // capacity of the extension lists (0 until a batch needed them)
     bool img_mode = false;           // a batch with atoms far outside their cell has been seen: 3-body launches with the image-range rule
@@ -242,6 +244,10 @@ static int fail(uf3_ctx *ctx, int code, const std::string &msg) {
     } while (0)
 
 extern "C" const char *uf3_last_error(const uf3_ctx *ctx) { return ctx ? ctx->err.c_str() : g_err.c_str(); }
+#ifndef UF3_BUILD_ID
+#define UF3_BUILD_ID "unknown"
+#endif
+extern "C" const char *uf3_build_id(void) { return UF3_BUILD_ID; }
 
 extern "C" int uf3_ctx_create(int device, uf3_ctx **out) {
     uf3_env_refresh();
@@ -1376,6 +1382,12 @@ static size_t feat3_lds_bytes(const uf3_basis *b, int cap, bool e_lds) {
     const size_t ints = ((size_t)WPB * per_wave_i + 3) & ~(size_t)3;
     return (e_d + rows_d + WPB * (list_d + tq_d + stage_d)) * 8 + ints * 4 + (size_t)b->n_f3src * 2 + 32;
 }
+// ... of k_feat3_w: window rows | per wave: list, bond values, stage | ints
+static size_t feat3w_lds_bytes(const uf3_basis *b, int cap) {
+    const size_t rows_d = (size_t)b->n_f3rows * 18;
+    const size_t per_wave_d = 8 * (size_t)cap + F3WCfg::STAGE, per_wave_i = 4 * (size_t)cap + (UF3_MAX_SPECIES + 2);
+    return (rows_d + WPB * per_wave_d) * 8 + WPB * per_wave_i * 4 + 32;
+}
 #define UF3_LDS_LIMIT ((size_t)160 * 1024 - 512)
 
 static int featurize_dev_impl(uf3_basis *b, const uf3_frames *fr, const double *d_pos, const int32_t *d_z,
@@ -1588,14 +1600,18 @@ static int featurize_dev_impl(uf3_basis *b, const uf3_frames *fr, const double *
                             "blocks %d x %d atoms, n_recs %zu, dense nrec %d stage %d\n", launch_mode, lds, lds_plain, lds_recs,
                             (int)recs_lds, cap, A.cand_cap, n_blocks, apb, n_rec_mode, A.dense_nrec, A.dense_stage);
 #define UF3_GRID(n) (((n) + 7) / 8 * 8)      /* whole rounds over the XCDs (surplus workgroups find no atoms) */
-/* (the attribute is set once per instance and context, and again only when a call needs more: host time on an asynchronous path) */ \
+/* (the dynamic-LDS attribute belongs to the kernel instance on a device, not to a context or a thread: one process-wide, \
+   mutex-protected high-water mark per instance and device that only grows -- ADVICE round 5) */ \
 #define UF3_LAUNCH1(E, Fo, R, M, I)                                                                                   \
     do {                                                                                                            \
-        static thread_local std::map<const uf3_ctx *, size_t> lds_set;                                               \
-        size_t &have = lds_set[c];                                                                                  \
-        if (lds > have) {                                                                                           \
-            HIPCHK(c, hipFuncSetAttribute((const void *)k_featurize<E, Fo, R, M, I>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-            have = lds;                                                                                             \
+        {                                                                                                           \
+            static std::mutex mu; static size_t have[64] = {0};                                                     \
+            std::lock_guard<std::mutex> lk(mu);                                                                     \
+            size_t &hv = have[c->device & 63];                                                                      \
+            if (lds > hv) {                                                                                         \
+                HIPCHK(c, hipFuncSetAttribute((const void *)k_featurize<E, Fo, R, M, I>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+                hv = lds;                                                                                           \
+            }                                                                                                       \
         }                                                                                                           \
         hipLaunchKernelGGL((k_featurize<E, Fo, R, M, I>), dim3(UF3_GRID(n_blocks)), dim3(WPB * WAVE), lds, st, A);   \
     } while (0)
@@ -1643,39 +1659,59 @@ static int featurize_dev_impl(uf3_basis *b, const uf3_frames *fr, const double *
                 feat3_shape(b, ep, stage, nrec);
                 (void)stage; (void)nrec;
                 const int nr = b->f3_nr;
-        /* (the attribute is set once per instance and context, and again only when a call needs more) */                     \
-#define UF3_F3_LAUNCH1(E, EFv, NRv, CAPv)                                                                                   \
+                G.wbuf = nullptr; G.wsz = 0; G.m_lo = 0;
+        /* (the dynamic-LDS attribute belongs to the kernel instance on a device: one process-wide high-water mark each) */   \
+#define UF3_F3_ATTR(KERNEL, lds)                                                                                           \
     do {                                                                                                                   \
-        static thread_local std::map<const uf3_ctx *, size_t> lds_set;                                                     \
-        size_t &have = lds_set[c];                                                                                         \
-        if (lds > have) {                                                                                                  \
-            HIPCHK(c, hipFuncSetAttribute((const void *)k_featurize3<E, EFv, NRv, CAPv>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-            have = lds;                                                                                                    \
+        static std::mutex mu; static size_t have[64] = {0};                                                                \
+        std::lock_guard<std::mutex> lk(mu);                                                                                \
+        size_t &hv = have[c->device & 63];                                                                                 \
+        if ((lds) > hv) {                                                                                                  \
+            HIPCHK(c, hipFuncSetAttribute((const void *)KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds)));  \
+            hv = (lds);                                                                                                    \
         }                                                                                                                  \
-        hipLaunchKernelGGL((k_featurize3<E, EFv, NRv, CAPv>), dim3(grid), dim3(WPB * WAVE), lds, st, G);                    \
+    } while (0)
+#define UF3_F3_LAUNCH1(E, EFv, NRv, CAPv, HOv)                                                                              \
+    do {                                                                                                                   \
+        UF3_F3_ATTR((k_featurize3<E, EFv, NRv, CAPv, HOv>), lds);                                                          \
+        hipLaunchKernelGGL((k_featurize3<E, EFv, NRv, CAPv, HOv>), dim3(grid), dim3(WPB * WAVE), lds, st, G);               \
     } while (0)
 #define UF3_F3_LAUNCH(E, EFv, NRv)                                                                                          \
-    do { if (lcap == 16 && !c->env_f3_no_cap16) UF3_F3_LAUNCH1(E, EFv, NRv, 16); else UF3_F3_LAUNCH1(E, EFv, NRv, 0); } while (0)
-                // one launch laid out for lists of up to `lcap` entries (the batch's list array keeps the context's capacity as
-                // its stride); sel_mode: see Feat3Args
-                auto launch_f3 = [&](int lcap, int sel_mode) -> int {
-                    G.sel_mode = sel_mode;
-                    const size_t lds = feat3_lds_bytes(b, lcap, want_e && !A.e_direct);      // (<= UF3_LDS_LIMIT: checked where feat3 was decided)
+    do { if (lcap == 16 && !c->env_f3_no_cap16) UF3_F3_LAUNCH1(E, EFv, NRv, 16, false); else UF3_F3_LAUNCH1(E, EFv, NRv, 0, false); } while (0)
+#define UF3_F3W_LAUNCH1(CAPv)                                                                                               \
+    do {                                                                                                                   \
+        UF3_F3_ATTR((k_feat3_w<3, CAPv>), lds);                                                                            \
+        hipLaunchKernelGGL((k_feat3_w<3, CAPv>), dim3(grid), dim3(WPB * WAVE), lds, st, G);                                 \
+    } while (0)
+                // the launch's grid over the atoms m_lo .. natoms - 1 (G.m_lo, G.natoms)
+                auto f3_grid = [&](size_t lds) -> unsigned {
+                    const int n_at = G.natoms - G.m_lo;
                     int per_cu = std::max(1, std::min(8, (int)((size_t)(160 * 1024) / lds)));
                     const int bps = c->env_f3_bps;
-                    int n_blocks = std::min((P.natoms + WPB - 1) / WPB, c->n_cu * per_cu * bps);
-                    int apb = ((P.natoms + n_blocks - 1) / n_blocks + WPB - 1) / WPB * WPB;
-                    n_blocks = (P.natoms + apb - 1) / apb;
+                    int n_blocks = std::min((n_at + WPB - 1) / WPB, c->n_cu * per_cu * bps);
+                    int apb = ((n_at + n_blocks - 1) / n_blocks + WPB - 1) / WPB * WPB;
+                    n_blocks = (n_at + apb - 1) / apb;
                     G.atoms_per_block = apb;
+                    return (unsigned)((n_blocks + 7) / 8 * 8);
+                };
+                // one launch laid out for lists of up to `lcap` entries (the batch's list array keeps the context's capacity as
+                // its stride); sel_mode: see Feat3Args
+                auto launch_f3 = [&](int lcap, int sel_mode, bool ho) -> int {
+                    G.sel_mode = sel_mode;
+                    const size_t lds = feat3_lds_bytes(b, lcap, want_e && !A.e_direct);      // (<= UF3_LDS_LIMIT: checked where feat3 was decided)
+                    const unsigned grid = f3_grid(lds);
                     if (c->env_debug_lds)
-                        fprintf(stderr, "uf3 featurize3: lds %zu B, cap %d (lists %d apart), selection %d, blocks %d x %d atoms, window %d x %d, %d round(s)\n",
-                                lds, lcap, cap, sel_mode, n_blocks, apb, G.ext_p, G.ext_n, nr);
-                    const unsigned grid = (unsigned)((n_blocks + 7) / 8 * 8);
+                        fprintf(stderr, "uf3 featurize3: lds %zu B, cap %d (lists %d apart), selection %d, hand-off %d, blocks %u x %d atoms, window %d x %d, %d round(s)\n",
+                                lds, lcap, cap, sel_mode, (int)ho, grid, G.atoms_per_block, G.ext_p, G.ext_n, nr);
                     switch (ep) {
                         case 3:      // (the default trims: the list capacity as a constant also at 24 and 32 -- fcc and denser cells)
-                            if ((lcap == 24 || lcap == 32) && !c->env_f3_no_cap16) {
-                                if (lcap == 24) { if (want_e) UF3_F3_LAUNCH1(true, 3, 1, 24); else UF3_F3_LAUNCH1(false, 3, 1, 24); }
-                                else { if (want_e) UF3_F3_LAUNCH1(true, 3, 1, 32); else UF3_F3_LAUNCH1(false, 3, 1, 32); }
+                            if (ho) {        // (the measured experiment of round 6: capacity 16 as a constant, everything else generic)
+                                if (lcap == 16 && !c->env_f3_no_cap16) { if (want_e) UF3_F3_LAUNCH1(true, 3, 1, 16, true); else UF3_F3_LAUNCH1(false, 3, 1, 16, true); }
+                                else { if (want_e) UF3_F3_LAUNCH1(true, 3, 1, 0, true); else UF3_F3_LAUNCH1(false, 3, 1, 0, true); }
+                            }
+                            else if ((lcap == 24 || lcap == 32) && !c->env_f3_no_cap16) {
+                                if (lcap == 24) { if (want_e) UF3_F3_LAUNCH1(true, 3, 1, 24, false); else UF3_F3_LAUNCH1(false, 3, 1, 24, false); }
+                                else { if (want_e) UF3_F3_LAUNCH1(true, 3, 1, 32, false); else UF3_F3_LAUNCH1(false, 3, 1, 32, false); }
                             }
                             else if (want_e) UF3_F3_LAUNCH(true, 3, 1); else UF3_F3_LAUNCH(false, 3, 1);
                             break;
@@ -1685,21 +1721,74 @@ static int featurize_dev_impl(uf3_basis *b, const uf3_frames *fr, const double *
                     }
                     return UF3_OK;
                 };
+                // the producer of the hand-off (k_feat3_w) over the same atoms, same instance selection
+                auto launch_f3w = [&](int lcap, int sel_mode) -> int {
+                    G.sel_mode = sel_mode;
+                    const size_t lds = feat3w_lds_bytes(b, lcap);
+                    const unsigned grid = f3_grid(lds);
+                    if (c->env_debug_lds)
+                        fprintf(stderr, "uf3 feat3_w: lds %zu B, cap %d (lists %d apart), selection %d, blocks %u x %d atoms, atoms %d .. %d\n",
+                                lds, lcap, cap, sel_mode, grid, G.atoms_per_block, G.m_lo, G.natoms);
+                    if (lcap == 16 && !c->env_f3_no_cap16) UF3_F3W_LAUNCH1(16); else UF3_F3W_LAUNCH1(0);
+                    return UF3_OK;
+                };
                 // The lists of this batch were built just now at the context's capacity -- an estimate on a context's first call,
                 // what the densest batch so far needed later on -- but the instance that serves most cells is the one laid out for 16
                 // entries (4 workgroups per CU, LDS offsets as immediates).  Which one applies is known on the device only: the list
                 // build leaves the batch's longest list in flags[7], and two launches follow of which one leaves at once.
-                if (A.n3_seen && cap > 16) {
-                    int r1 = launch_f3(16, 1);
-                    if (r1) return r1;
-                    r1 = launch_f3(cap, 2);
+                auto launch_pair = [&](bool producer, bool ho) -> int {
+                    if (A.n3_seen && cap > 16) {
+                        int r1 = producer ? launch_f3w(16, 1) : launch_f3(16, 1, ho);
+                        if (r1) return r1;
+                        return producer ? launch_f3w(cap, 2) : launch_f3(cap, 2, ho);
+                    }
+                    return producer ? launch_f3w(cap, 0) : launch_f3(cap, 0, ho);
+                };
+                // Hand-off (round 6; UF3_F3_HANDOFF=1 only -- it was built, measured and LOST: 4460-4630 against
+                // 6410 frames/s): the neighbour role's stage-1 sums are computed once, by the centre (k_feat3_w), and
+                // reach the neighbours through HBM: slices of whole frames, producer then consumer, one buffer re-used by every slice
+                const int ho_default = 0;
+                // (looked at on every call: tests and A/B runs flip it between calls on one context)
+                const int ho_env = uf3_env("UF3_F3_HANDOFF") ? atoi(uf3_env("UF3_F3_HANDOFF")) : ho_default;
+                const int slice_env = uf3_env("UF3_F3_SLICE") ? std::max(0, atoi(uf3_env("UF3_F3_SLICE"))) : 0;
+                const bool handoff = ho_env != 0 && ep == 3 && nr == 1 && feat3w_lds_bytes(b, cap) <= UF3_LDS_LIMIT;
+                if (!handoff) {
+                    int r1 = launch_pair(false, false);
                     if (r1) return r1;
                 } else {
-                    int r1 = launch_f3(cap, 0);
-                    if (r1) return r1;
+                    const int S_ = b->host.S;
+                    G.wsz = (G.ext_p * G.ext_n * 4 + 15) / 16 * 16;
+                    const size_t per_atom = (size_t)cap * S_ * G.wsz * sizeof(double);
+                    const int64_t slice_target = slice_env > 0 ? slice_env : 320000;
+                    const int64_t *off = fr->atom_offsets;
+                    // (slices: runs of whole frames of at most slice_target atoms, at least one frame)
+                    int64_t widest = 0;
+                    for (int f0 = 0; f0 < P.n_frames;) {
+                        int f1 = f0 + 1;
+                        while (f1 < P.n_frames && off[f1 + 1] - off[f0] <= slice_target) f1++;
+                        widest = std::max(widest, off[f1] - off[f0]);
+                        f0 = f1;
+                    }
+                    HIPCHK(c, c->f3w.ensure(per_atom * (size_t)widest));
+                    G.wbuf = c->f3w.as<double>();
+                    for (int f0 = 0; f0 < P.n_frames;) {
+                        int f1 = f0 + 1;
+                        while (f1 < P.n_frames && off[f1 + 1] - off[f0] <= slice_target) f1++;
+                        G.m_lo = (int)off[f0]; G.natoms = (int)off[f1];
+                        if (G.natoms > G.m_lo) {
+                            int r1 = launch_pair(true, true);
+                            if (r1) return r1;
+                            r1 = launch_pair(false, true);
+                            if (r1) return r1;
+                        }
+                        f0 = f1;
+                    }
+                    G.m_lo = 0; G.natoms = P.natoms;
                 }
 #undef UF3_F3_LAUNCH
 #undef UF3_F3_LAUNCH1
+#undef UF3_F3W_LAUNCH1
+#undef UF3_F3_ATTR
             }
         }
         HIPCHK(c, hipGetLastError());
