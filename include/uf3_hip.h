@@ -310,6 +310,12 @@ int uf3_eval_centres_dev(uf3_basis *basis, const uf3_frames *frames, const doubl
 int uf3_neighbors_debug(uf3_basis *basis, const uf3_frames *frame, const double *pos, const int32_t *z,
                         int64_t *pair_count, int64_t *pair_ij, int64_t pair_cap,
                         int64_t *n3_count, int64_t *n3_ij, int64_t n3_cap);
+/* The 3-body neighbour lists the LAST featurizer / evaluator call on the basis' context built and consumed (the product path's
+ * own lists, not the separate walk behind uf3_neighbors_debug): counts [natoms] and, per atom, the reference supercell index
+ * (image_rank * N + atom) of every entry in list order, sidx [natoms][sidx_cap] with sidx_cap >= *cap_out (pass sidx = NULL to
+ * learn the capacity first).  Test infrastructure (reference: uf3/representation/angles.py:289-346 identify_ij): valid only
+ * straight after a synchronised single-frame call and before anything else runs on the context. */
+int uf3_n3_lists_debug(uf3_basis *basis, int64_t natoms, int64_t *cap_out, int32_t *counts, int32_t *sidx, int64_t sidx_cap);
 
 /*
  * The same 2-body pairs with their geometry: pair_geo [P][pair_cap][4] = distance, then (R_j - R_i) / distance -- what

@@ -2191,3 +2191,81 @@ def test_md_rebuild_that_nobody_waits_for_overflows_into_a_repeat():
         assert rel_err(e[0], e_ref) < TOL and rel_err(f, f_ref) < TOL, step
     after = ctx.md_stats()
     assert after["redone"] > before["redone"] and after["builds"] >= before["builds"] + 2
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# Neighbour indices at scale.  north_star: "bit-exact neighbor indices".  The captures above are
+# <= 128 atoms; here the BASELINE-size cells -- multi-bin walks, capacity regrowth, every size class of the cell-list stage --
+# against the oracle's explicit-supercell search (reference: distances.py:48-69, angles.py:289-346), bit for bit: the pair
+# lists per interaction and the 3-body pairs from the query entry (uf3_neighbors_debug), AND the 3-body lists the featurizer's
+# own launches build and consume (uf3_n3_lists_debug).  Row parity cannot see a pair mis-classified AT a cut-off (it contributes
+# ~0 to every B-spline column); the last test puts atoms within a few ulp of each cut-off, on both sides.
+def _assert_indices_equal_oracle(basis, atoms):
+    ref = O.featurize(O.OracleBasis(basis), atoms, energy=False, forces=False, indices=True)
+    fz = process.BasisFeaturizer(basis)
+    pairs, n3 = fz.neighbor_indices(atoms)
+    assert set(pairs) == set(ref["pairs"])
+    for pair in basis.interactions_map[2]:
+        assert pairs[pair].shape == ref["pairs"][pair].shape, pair
+        assert np.array_equal(pairs[pair], ref["pairs"][pair]), pair
+    assert n3.shape == ref["n3"].shape and np.array_equal(n3, ref["n3"])
+    own = fz.product_n3_indices(atoms)                      # the lists MODE 0 built for its own 3-body launches
+    assert own.shape == ref["n3"].shape and np.array_equal(own, ref["n3"])
+    return ref
+
+
+@pytest.mark.parametrize("config", ["c2", "c3", "c4", "c5"])
+def test_neighbour_indices_bit_exact_at_baseline_sizes(config):
+    atoms, basis = {"c2": synthetic.config_c2, "c3": synthetic.config_c3, "c4": synthetic.config_c4, "c5": synthetic.config_c5}[config]()
+    ref = _assert_indices_equal_oracle(basis, atoms)
+    assert len(ref["n3"]) > 10 * len(atoms)                 # (the lists are not trivially empty)
+
+
+def test_neighbour_indices_bit_exact_within_an_ulp_of_every_cutoff():
+    basis = synthetic.notebook_basis(['Mo', 'W'])
+    r_max2 = 5.5
+    r_min3, r_max3 = 1.5, 3.5
+    atoms = synthetic.cutoff_probe_frame([r_max2, r_min3, r_max3], elements=(42, 74))
+    ref = _assert_indices_equal_oracle(basis, atoms)
+    # the probe does straddle the cut-offs: of the pairs placed around each radius some are in and some are out
+    pos, cell = atoms.get_positions(), np.asarray(atoms.cell)[0, 0]
+    d = pos[1::2] - pos[0::2]
+    d -= cell * np.round(d / cell)
+    r = np.sqrt((d * d).sum(axis=1))
+    third = len(r) // 3
+    n_pair = sum(len(v) for v in ref["pairs"].values())
+    inside2 = int((r[:third] < r_max2).sum())
+    # (this NumPy distance is not cdist's: which side a pair within an ulp falls on may differ from the oracle's verdict for a few)
+    assert 0 < inside2 < third and abs(n_pair - 2 * (inside2 + 2 * third)) <= third // 4
+    in3 = int(((r[third:] > r_min3) & (r[third:] <= r_max3)).sum())
+    assert 0 < in3 < 2 * third and abs(len(ref["n3"]) - 2 * in3) <= third // 4
+    # and the rows of that frame agree as well
+    fz = process.BasisFeaturizer(basis)
+    x_e, x_f, _ = fz.featurize_frames([atoms])
+    o = O.featurize(O.OracleBasis(basis), atoms)
+    assert rel_err(x_e[0], o["xe"]) < TOL and rel_err(x_f, o["xf"]) < TOL
+
+
+def test_hand_off_launch_pair_matches_the_one_kernel_launch_and_the_oracle():
+    """UF3_F3_HANDOFF=1 (the measured experiment of round 6, DESIGN 3.6: k_feat3_w computes the neighbour role's stage-1 sums
+    once, at the centre, and k_featurize3<HO> reads them back): same rows as the default launch and as the oracle -- one, two and
+    three species, list capacities 16 and 24, several frames per slice and one frame per slice."""
+    cases = [(synthetic.notebook_basis(['W']), [synthetic.config_c2()[0]]),
+             (synthetic.notebook_basis(['Mo', 'W']), [synthetic.lattice_frame("bcc", (6, 6, 6), 3.165, [42, 74], s) for s in (1, 2, 3)]),
+             (synthetic.notebook_basis(['Mo', 'Nb', 'W']), [synthetic.lattice_frame("bcc", (6, 6, 6), 3.2, [41, 42, 74], 5)]),
+             (synthetic.notebook_basis(['W']), [synthetic.lattice_frame("fcc", (6, 6, 6), 3.9, [74], 7)])]
+    for basis, frames in cases:
+        fz = process.BasisFeaturizer(basis)
+        e0, f0, off = fz.featurize_frames(frames)
+        for slice_atoms in ("", "1"):
+            os.environ["UF3_F3_HANDOFF"] = "1"
+            if slice_atoms:
+                os.environ["UF3_F3_SLICE"] = slice_atoms
+            try:
+                e1, f1, _ = fz.featurize_frames(frames)
+            finally:
+                os.environ.pop("UF3_F3_HANDOFF", None)
+                os.environ.pop("UF3_F3_SLICE", None)
+            assert rel_err(e1, e0) < 1e-12 and rel_err(f1, f0) < 1e-12
+        ref = O.featurize(O.OracleBasis(basis), frames[-1])
+        assert rel_err(f1[off[-2]:off[-1]], ref["xf"]) < TOL and rel_err(e1[-1], ref["xe"]) < TOL

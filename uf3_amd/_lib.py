@@ -22,7 +22,7 @@ EXPORTS = ["uf3_ctx_create", "uf3_ctx_destroy", "uf3_ctx_set_stream", "uf3_ctx_s
            "uf3_featurize", "uf3_featurize_dev", "uf3_gram", "uf3_gram_dev",
            "uf3_eval", "uf3_eval_dev", "uf3_eval_virial", "uf3_eval_virial_dev", "uf3_eval_atoms", "uf3_eval_atoms_dev",
            "uf3_eval_centres", "uf3_eval_centres_dev",
-           "uf3_neighbors_debug", "uf3_fit_rows_dev", "uf3_fit_pack_dev", "uf3_gram_force_rows_dev",
+           "uf3_neighbors_debug", "uf3_n3_lists_debug", "uf3_fit_rows_dev", "uf3_fit_pack_dev", "uf3_gram_force_rows_dev",
            "uf3_pair_geometry", "uf3_distance_matrix", "uf3_direction_cosines",
            "uf3_ctx_md_skin", "uf3_ctx_md_stats",
            "uf3_featurize_ld_dev", "uf3_fit_create", "uf3_fit_destroy", "uf3_fit_reset", "uf3_fit_add", "uf3_fit_pack", "uf3_fit_info", "uf3_fit_use_flat", "uf3_fit_first_chunk",
@@ -171,6 +171,7 @@ def load():
         for name in ("uf3_eval_atoms", "uf3_eval_atoms_dev", "uf3_eval_centres", "uf3_eval_centres_dev"):
             getattr(lib, name).argtypes = [vp, C.POINTER(Frames), vp, vp, vp, vp, vp, i64, i64, vp, vp, vp]
         lib.uf3_neighbors_debug.argtypes = [vp, C.POINTER(Frames), vp, vp, vp, vp, i64, vp, vp, i64]
+        lib.uf3_n3_lists_debug.argtypes = [vp, i64, vp, vp, vp, i64]
         lib.uf3_gram_force_rows_dev.argtypes = [vp, vp, vp, vp, i64, i64, i32, vp, vp]
         lib.uf3_pair_geometry.argtypes = [vp, C.POINTER(Frames), vp, vp, vp, vp, vp, i64]
         lib.uf3_distance_matrix.argtypes = [vp, vp, i64, vp, i64, vp]

@@ -82,6 +82,7 @@ struct uf3_ctx {
         bin_cnt,                        // atoms per cell-list bin (counting sort)
         f3w;                            // hand-off buffer k_feat3_w -> k_featurize3<HO>: [atoms of a slice][list capacity][S][wsz] doubles
     int n3_cap = 0, cand_cap = 0;
+    int n3_last_cap = 0, n3_last_natoms = 0;   // layout of the 3-body lists in the workspace right now (uf3_n3_lists_debug)
     int n3x_cap = 0;                 // capacity of the extension lists (0 until a batch needed them)
     bool img_mode = false;           // a batch with atoms far outside their cell has been seen: 3-body launches with the image-range rule
     int gram_plan_np[UF3_MAX_SPECIES + 1] = {0}, gram_plan_blocks[UF3_MAX_SPECIES + 1] = {0}, gram_plan_next = 0;   // workgroup plans of k_gram_tiled held in
@@ -1117,6 +1118,7 @@ static int n3_alloc(uf3_ctx *c, int natoms, int cap, N3Lists &n3) {
     HIPCHK(c, c->n3_cnt.ensure(sizeof(int) * (size_t)natoms * (UF3_MAX_SPECIES + 2)));
     HIPCHK(c, c->n3_dbl.ensure(sizeof(N3Entry) * (size_t)natoms * cap));
     n3.cap = cap;
+    c->n3_last_cap = cap; c->n3_last_natoms = natoms;
     n3.cnt = c->n3_cnt.as<int>();
     n3.spoff = n3.cnt + natoms;
     n3.ent = c->n3_dbl.as<N3Entry>();
@@ -3096,6 +3098,30 @@ static int neighbors_impl(uf3_basis *b, const uf3_frames *fr, const double *pos,
             }
         } else if (n3_ij && cur[np] < n3_cap) { n3_ij[2 * cur[np]] = t.i; n3_ij[2 * cur[np] + 1] = t.j; }
         cur[t.p]++;
+    }
+    return UF3_OK;
+}
+
+// The 3-body neighbour lists the LAST featurizer / evaluator call on this context built and consumed (MODE 0's build_n3_list or
+// k_build_n3 -- not the separate walk of k_debug_pairs): per atom the entry count and, per entry, the neighbour's reference
+// supercell index (image_rank * N + atom) in list order (species, then supercell index).  Test infrastructure: valid only straight
+// after a synchronised call, before anything else runs on the context.
+extern "C" int uf3_n3_lists_debug(uf3_basis *b, int64_t natoms, int64_t *cap_out, int32_t *counts, int32_t *sidx, int64_t sidx_cap) {
+    if (!b) return fail(nullptr, UF3_EINVAL, "null basis");
+    uf3_ctx *c = b->ctx;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->n3_last_cap <= 0 || natoms != c->n3_last_natoms || !c->n3_cnt.p || !c->n3_dbl.p)
+        return fail(c, UF3_EINVAL, "uf3_n3_lists_debug: no 3-body lists of a batch of this size in the workspace");
+    const int cap = c->n3_last_cap;
+    if (cap_out) *cap_out = cap;
+    if (counts) HIPCHK(c, hipMemcpy(counts, c->n3_cnt.p, sizeof(int) * (size_t)natoms, hipMemcpyDeviceToHost));
+    if (sidx) {
+        if (sidx_cap < cap) return fail(c, UF3_EINVAL, "uf3_n3_lists_debug: sidx_cap below the list capacity");
+        std::vector<N3Entry> ent((size_t)natoms * cap);
+        HIPCHK(c, hipMemcpy(ent.data(), c->n3_dbl.p, sizeof(N3Entry) * ent.size(), hipMemcpyDeviceToHost));
+        for (int64_t a = 0; a < natoms; a++)
+            for (int q = 0; q < cap; q++) sidx[a * sidx_cap + q] = ent[(size_t)a * cap + q].sidx;
     }
     return UF3_OK;
 }

@@ -150,6 +150,27 @@ class BasisFeaturizer:
         ctx.check(ctx.lib.uf3_neighbors_debug(*args, _lib._p(cnt), _lib._p(pij), cap2, _lib._p(n3), _lib._p(nij), cap3))
         return ({p: pij[k, :cnt[k]].copy() for k, p in enumerate(db.pairs)}, nij[:int(n3[0])].copy())
 
+    def product_n3_indices(self, geom):
+        """
+        The 3-body neighbour pairs (i, j) -- reference supercell numbering, row-major order as ``identify_ij`` returns them
+        (angles.py:289-346) -- read back from the lists the featurizer's OWN launches build and consume for this frame (one
+        energy-row call, then ``uf3_n3_lists_debug``), not from the separate walk behind ``neighbor_indices``.  Test surface.
+        """
+        import ctypes as C
+        ctx, db = self._dev()
+        self.featurize_frames([geom], energy=True, forces=False)
+        n = len(geom)
+        cap = C.c_int64(0)
+        ctx.check(ctx.lib.uf3_n3_lists_debug(db.handle, n, C.byref(cap), None, None, 0))
+        cnt = np.zeros(n, dtype=np.int32)
+        sidx = np.zeros((n, cap.value), dtype=np.int32)
+        ctx.check(ctx.lib.uf3_n3_lists_debug(db.handle, n, C.byref(cap), _lib._p(cnt), _lib._p(sidx), cap.value))
+        keep = np.arange(cap.value)[None, :] < cnt[:, None]
+        i = np.broadcast_to(np.arange(n, dtype=np.int64)[:, None], sidx.shape)[keep]
+        j = sidx[keep].astype(np.int64)
+        order = np.lexsort((j, i))
+        return np.stack([i[order], j[order]], axis=1)
+
     # ------------------------------------------------------------------ reference surface
     def _block(self, degree):
         sizes, offsets = self.bspline_config.get_interaction_partitions()

@@ -58,6 +58,42 @@ def config_c4(frame=0, binary=True):
     return lattice_frame("bcc", (10, 20, 25), 3.165, numbers, 3000 + frame), basis
 
 
+def config_c5():
+    """3-element alloy, 50 000-atom bcc cell: the evaluator's (MD-step) workload."""
+    return lattice_frame("bcc", (25, 25, 40), 3.165, [23, 42, 74], seed=4000), notebook_basis(['V', 'Mo', 'W'])
+
+
+def cutoff_probe_frame(radii, elements=(74,), spacing=18.0, per_radius=36, seed=77):
+    """Pairs of atoms placed AT the given cut-off radii, a few units in the last place to either side: site k of a cubic grid holds
+    atom A, and B = A + d u with u a random direction and d = r (1 + q 2^-52), q in -3 .. 3 (seven sites per direction and radius).
+    The pairs sit `spacing` apart (no atom of one pair within 5.5 A + 0.5 A of an atom of another), B is wrapped into the periodic cell, so some pairs meet through an image.
+    What a pair's distance rounds to is whatever cdist's formula makes of it -- the test asserts agreement with the oracle, on
+    both sides of each radius."""
+    rng = np.random.default_rng(seed)
+    sites = []
+    for r in radii:
+        for _ in range(per_radius):
+            u = rng.normal(size=3)
+            u /= np.linalg.norm(u)
+            if rng.random() < 0.25:
+                u = np.eye(3)[rng.integers(3)] * rng.choice([-1.0, 1.0])      # axis-aligned: exact distances
+            for q in range(-3, 4):
+                sites.append((r * (1.0 + q * 2.0 ** -52), u))
+    n_side = int(np.ceil(len(sites) ** (1 / 3)))
+    L = n_side * spacing
+    pos, z = [], []
+    for k, (d, u) in enumerate(sites):
+        idx = np.array([k // (n_side * n_side), (k // n_side) % n_side, k % n_side])
+        a = (idx + 0.5) * spacing + rng.uniform(-0.5, 0.5, 3)
+        ax = k % 3
+        if idx[ax] == 0:
+            a[ax] = 0.02                                        # next to a cell face: B may wrap to the other side
+        b = a + d * u
+        pos += [a, np.mod(b, L)]
+        z += [elements[k % len(elements)], elements[(k // 2) % len(elements)]]
+    return Atoms(numbers=np.array(z), positions=np.array(pos), cell=np.eye(3) * L, pbc=True)
+
+
 def algorithmic_bytes(n_atoms, n_feat, forces=True):
     """inputs + the rows the reference materialises."""
     rows = (3 * n_atoms + 1) if forces else 1
