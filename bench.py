@@ -179,19 +179,19 @@ def main(argv=None):
     B = args.frames_per_step
     if wl == "lead0" and B > 24:
         B = 24                    # 432 MB of rows per frame
-    frames = [synthetic.lattice_frame("bcc", reps, 3.165, numbers, 3000 + rank * 1000 + k) for k in range(B)]
-    batch = _lib.FrameBatch(frames)
-    n_atoms = len(frames[0])
+    # this rank's block of the world x B frames of a step (weak scaling: B per rank), resident in HBM with its rows:
+    # uf3_amd.parallel.featurize_sharded -- the package's driver, not a copy of it
+    from uf3_amd import parallel
     fz = process.BasisFeaturizer(basis, device=dev.index)
+    fit = args.mode == "fit"
+    fbatch, _ = parallel.featurize_sharded(
+        fz, lambda i: synthetic.lattice_frame("bcc", reps, 3.165, numbers, 3000 + (i // B) * 1000 + (i % B)), n_frames=world * B,
+        device=dev.index, ld=0 if (args.row_ld == 0 or fit) else args.row_ld, rank=rank, world_size=world)
+    frames, batch = fbatch.frames, fbatch.batch
+    n_atoms = len(frames[0])
     ctx, db = fz._dev()
     F = db.n_feat
-    d_pos = torch.from_numpy(batch.pos).to(dev)
-    d_z = torch.from_numpy(batch.z).to(dev)
-    d_xe = torch.empty((B, F), dtype=torch.float64, device=dev)
-    fit = args.mode == "fit"
-    ld = F if (args.row_ld == 0 or fit) else (fz.aligned_ld(F) if args.row_ld < 0 else max(F, args.row_ld))
-    d_xf_full = torch.empty((batch.n_atoms, 3, ld), dtype=torch.float64, device=dev)
-    d_xf = d_xf_full[:, :, :F]                                    # (the columns that hold rows; contiguous when ld == F)
+    d_pos, d_z, d_xe, d_xf_full, d_xf, ld = fbatch.pos, fbatch.z, fbatch.x_e, fbatch.x_f_full, fbatch.x_f, fbatch.ld
     ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
     acc = flat = None
     if fit:
@@ -211,7 +211,7 @@ def main(argv=None):
         if fit:
             acc.add_device_batch(batch.struct, B, batch.n_atoms, d_pos, d_z, d_counts, d_ye, d_yf, x_e=d_xe, x_f=d_xf)
         else:
-            fz.featurize_device(batch.struct, d_pos.data_ptr(), d_z.data_ptr(), d_xe.data_ptr(), d_xf_full.data_ptr(), ld=ld)
+            fbatch.run()
 
     def fence():
         if distributed:
@@ -398,51 +398,31 @@ def eval_mode(args, torch, dist, dev, distributed, world, rank):
     reps = (25, 25, 40) if args.atoms == 10000 else (max(2, round((args.atoms / 2) ** (1 / 3))),) * 3
     atoms = synthetic.lattice_frame("bcc", reps, 3.165, [23, 42, 74], 4000)
     model, calc = _random_model(basis, 11)
-    ctx = _lib.get_context(dev.index)
-    db = _lib.device_basis(basis, ctx)
-    batch = _lib.FrameBatch([atoms])
-    n = batch.n_atoms
-    lo, hi = parallel.shard_range(n, rank, world)
-    d_pos = torch.from_numpy(batch.pos).to(dev)
-    d_z = torch.from_numpy(batch.z).to(dev)
-    flat = torch.zeros(3 * n + 7, dtype=torch.float64, device=dev)
-    p_f, p_e, p_v = flat.data_ptr(), flat.data_ptr() + 8 * 3 * n, flat.data_ptr() + 8 * (3 * n + 1)
-    ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
-    common = (db.handle, C.byref(batch.struct), C.c_void_p(d_pos.data_ptr()), C.c_void_p(d_z.data_ptr()),
-              _lib._p(calc._c1), _lib._p(calc._c2), _lib._p(calc._c3))
-
     # UF3_FORCE_COLLECTIVE under the launcher with ONE rank: the decomposed route (a block of centres = the whole frame) and its
     # all_reduce on the device buffer, so that a one-GPU box exercises what the ranks of an 8-GPU node run
     forced = bool(distributed and os.environ.get("UF3_FORCE_COLLECTIVE"))
     native = bool(distributed and os.environ.get("UF3_NATIVE_RCCL"))       # the sum through uf3_allreduce_sum_f64 (librccl behind the C ABI)
-    if native:
-        parallel.native_comm(ctx, rank, world)
-
     # An MD step -- every atom moves (seeded +-0.01 A walk, one device kernel) and the evaluator runs its MD route (neighbour
     # lists kept with a 0.5 A skin, rebuilt inside the timed region when an atom nears skin / 2): the whole frame at N = 1, a
-    # block of centres on whole-frame lists per rank at N > 1
+    # block of centres on whole-frame lists per rank at N > 1.  The device-resident loop is the package's
+    # (uf3_amd.parallel.ShardedEvaluator: flat buffer [forces | energy | dE/d(strain)], uf3_eval_centres_dev, one all_reduce).
     moving = True      # (every rank applies the same seeded walk: the ranks of a decomposed frame see the same positions)
+    ev = parallel.ShardedEvaluator(calc, atoms, device=dev.index, md_skin=MD_SKIN if moving else 0.0, native=native,
+                                   force_collective=forced)
+    ctx, n, flat, d_pos = ev.ctx, ev.n, ev.flat, ev.positions
+    ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
     if moving:
         g = torch.Generator(device=dev).manual_seed(17)
         pool = (torch.rand((64, n, 3), dtype=torch.float64, device=dev, generator=g) * 2.0 - 1.0) * MD_WALK
         order = np.random.default_rng(17).integers(0, 64, 1 << 16)
         signs = np.random.default_rng(18).choice([-1.0, 1.0], 1 << 16)
-        ctx.md_skin(MD_SKIN)
     counter = [0]
 
     def step():
         k = counter[0] & 0xffff
         counter[0] += 1
         d_pos.add_(pool[order[k]], alpha=float(signs[k]))
-        if world == 1 and not forced:
-            ctx.check(ctx.lib.uf3_eval_virial_dev(*common, C.c_void_p(p_e), C.c_void_p(p_f), C.c_void_p(p_v)))
-        else:
-            # (uf3_eval_centres_dev zeroes every force row itself and overwrites energy / strain derivative: nothing to clear)
-            ctx.check(ctx.lib.uf3_eval_centres_dev(*common, lo, hi, C.c_void_p(p_e), C.c_void_p(p_f), C.c_void_p(p_v)))
-            if native:
-                ctx.allreduce_sum(flat.data_ptr(), flat.numel())
-            else:
-                dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        ev.step()
 
     def fence():
         if distributed:
@@ -468,7 +448,8 @@ def eval_mode(args, torch, dist, dev, distributed, world, rank):
         from uf3_amd.data.atoms import Atoms
         atoms = Atoms(numbers=atoms.get_atomic_numbers(), positions=d_pos.cpu().numpy(), cell=atoms.get_cell(), pbc=True)   # (what the last step saw)
         md_stats = ctx.md_stats()
-        ctx.md_skin(0.0)
+        ev.close()
+    counts = _counts_of(basis, atoms, dev.index)              # (p, T of the frame the last step saw)
     f, e = host[:3 * n].reshape(n, 3), float(host[3 * n])
     assert os.environ.get("UF3_BENCH_NOCHECK") or (np.isfinite(host).all() and np.abs(f.sum(0)).max() < 1e-8 * max(1.0, np.abs(f).max()) * n ** 0.5)
     dt = elapsed / args.steps
@@ -493,8 +474,10 @@ def eval_mode(args, torch, dist, dev, distributed, world, rank):
                                if moving else None),
                            rccl_world_size=dist.get_world_size() if distributed else 1, forced_collective=forced,
                            collective=("uf3_allreduce_sum_f64 (librccl behind the C ABI)" if native else "torch.distributed all_reduce (RCCL)")),
-               roofline=_roof(n * (100.0 * PAIRS_PER_ATOM + 700.0 * TRIPLETS_PER_ATOM), 52.0 * n + 75 + 8.0 * len(calc._c3), dt,
-                              "mfma", note="flops = N (100 p + 700 T): every triplet once at its centre"),
+               roofline=_roof(_eval_flops(n, counts), 52.0 * n + 75 + 8.0 * len(calc._c3), dt,
+                              "mfma", realised_per_atom=_counts_note(counts),
+                              note="flops = N (100 p + 700 T) at the realised p, T: every triplet once at its centre; 700 flop per triplet is "
+                                   "this build's own price (SURVEY 8d prices the evaluator by bytes only)"),
                cpu_baseline=cpu)
     print(json.dumps(out), flush=True)
     return out
@@ -550,7 +533,9 @@ def measure_traffic(frames_per_step, workload, atoms, row_ld=0):
 # ---------------------------------------------------------------------------------------------------------------
 # sub-lines of the other BASELINE configurations (rank 0, N = 1, after the headline)
 # ---------------------------------------------------------------------------------------------------------------
-PAIRS_PER_ATOM, TRIPLETS_PER_ATOM = 58.0, 91.0        # realised on the rattled bcc cells
+# (no hard-coded pair / triplet counts: every line prices its flops at the p and T REALISED on its own frame -- realised_counts)
+EVAL_FLOP_PER_TRIPLET = 700.0      # the BUILD'S OWN price of an evaluated triplet (3 legs x ~60 + the 64-term contraction with value and 3
+                                   # partials ~450 + forces): SURVEY 8d prices the evaluator by bytes only
 PEAK_FP64_TF, PEAK_HBM_GBS = 78.6, 8000.0
 
 
@@ -583,9 +568,25 @@ def realised_counts(fz, atoms):
     return sum(len(v) for v in pairs.values()) / n, float((q * (q - 1) / 2).sum()) / n
 
 
-def _featurizer_flops(n_atoms):
-    """~100 flop per directed pair, ~3.1 kflop per triplet"""
-    return n_atoms * (100.0 * PAIRS_PER_ATOM + 3100.0 * TRIPLETS_PER_ATOM)
+def _featurizer_flops(n_atoms, counts):
+    """~100 flop per directed pair, ~3.1 kflop per triplet, at the realised (p, T) of the line's own frame"""
+    return n_atoms * (100.0 * counts[0] + 3100.0 * counts[1])
+
+
+def _eval_flops(n_atoms, counts):
+    """the evaluator: ~100 flop per directed pair, EVAL_FLOP_PER_TRIPLET per triplet (every triplet once, at its centre)"""
+    return n_atoms * (100.0 * counts[0] + EVAL_FLOP_PER_TRIPLET * counts[1])
+
+
+def _counts_of(basis, atoms, device=None):
+    """realised (p, T) of a frame through a featurizer of its basis"""
+    from uf3_amd.representation import process
+    return realised_counts(process.BasisFeaturizer(basis, device=device), atoms)
+
+
+def _counts_note(counts):
+    return dict(pairs=round(counts[0], 2), triplet_candidates=round(counts[1], 2),
+                note="realised on this line's own frame, from the device's lists (uf3_neighbors_debug)")
 
 
 def _roof(flops, bytes_, seconds, bound, **more):
@@ -654,13 +655,14 @@ def extra_fit(torch, dev, basis, frames, batch, d_pos, d_z, d_xe, d_xf, steps=5,
     # and the species-wise launches of a multi-element batch the blocks a species takes no part in)
     gram_tri = 2.0 * (3 * n_atoms + 1) * 256.0 * (tiles * (tiles + 1) / 2) * B
     gram_full = 2.0 * (3 * n_atoms + 1) * n_keep * n_keep * B
-    flops = _featurizer_flops(n_atoms) * B + gram_tri
+    counts = realised_counts(fz, frames[0])
+    flops = _featurizer_flops(n_atoms, counts) * B + gram_tri
     bytes_ = (52 * n_atoms + 75) * B                               # fused-Gram mode: inputs + targets
     return dict(metric="fitted frames/sec (featurize + X^T X / X^T y accumulate)", value=round(B / dt, 2), unit="frames/s",
                 ms_per_step=round(dt * 1e3, 4), steps=steps, frames_per_step=B, atoms_per_frame=n_atoms, n_feat=F,
                 n_unfrozen_columns=n_keep,
                 roofline=_roof(flops, bytes_, dt, "mfma", featurize_ms_per_step=round(t["featurize_ms"], 4),
-                               gram_ms_per_step=round(t["gram_ms"], 4),
+                               gram_ms_per_step=round(t["gram_ms"], 4), realised_per_atom=_counts_note(counts),
                                gram_tflops_executed_triangle=round(gram_tri / max(t["gram_ms"], 1e-9) / 1e9, 3),
                                gram_flops_full_matrix=gram_full,
                                note="fp64 flops = featurizer (SURVEY 8d) + the upper-triangle tiles the Gram kernels execute; "
@@ -690,10 +692,11 @@ def extra_lead0(torch, dev, frames, d_xf, steps=5, warmup=2):
     s = xf[:n_atoms].sum(dim=0).abs().max().item()
     assert np.isfinite(s) and s < 1e-6 * xf[:n_atoms].abs().max().item(), s           # translation invariance of the rows
     bytes_ = synthetic.algorithmic_bytes(n_atoms, F) * B
+    counts = realised_counts(fz, frames[0])
     return dict(metric="featurized frames/sec (10k-atom, 2-elem, 2+3-body, no leading trim)", value=round(B / dt, 2),
                 unit="frames/s", ms_per_step=round(dt * 1e3, 4), steps=steps, frames_per_step=B, atoms_per_frame=n_atoms,
-                n_feat=F, roofline=_roof(_featurizer_flops(n_atoms) * B, bytes_, dt, "hbm",
-                                         featurize_ms_per_step=round(t["featurize_ms"], 4),
+                n_feat=F, roofline=_roof(_featurizer_flops(n_atoms, counts) * B, bytes_, dt, "hbm",
+                                         featurize_ms_per_step=round(t["featurize_ms"], 4), realised_per_atom=_counts_note(counts),
                                          note="6.7 flop/B: the one workload SURVEY 8d calls HBM-bound on paper"))
 
 
@@ -795,16 +798,19 @@ def extra_eval_50k(torch, dev, cpu=True, steps=200, warmup=20):
     finally:
         ctx.md_skin(0.0)
         ctx.restore_stream(prev)
+    counts = _counts_of(basis, atoms, dev.index)
     out = dict(metric="evaluated atom-steps/sec (50k-atom ternary frame, energy + forces, atoms moving every step)", value=round(n / dt),
                unit="atom-steps/s", ms_per_step=round(dt * 1e3, 4), steps=steps, atoms_per_frame=n, n_feat=int(basis.n_feats),
                md=dict(skin_A=MD_SKIN, walk_A=MD_WALK, list_builds_in_timed_steps=s1["builds"] - s0["builds"],
                        steps_repeated=s1["redone"] - s0["redone"],
                        rebuild_everything_route=dict(value=round(n / dt_plain), ms_per_step=round(dt_plain * 1e3, 4),
                                                      note="md skin 0 (cell list + candidate walk + list sort on every call), frozen positions")),
-               roofline=_roof(n * (100.0 * PAIRS_PER_ATOM + 700.0 * TRIPLETS_PER_ATOM), 52.0 * n + 75 + 8.0 * len(calc._c3), dt, "mfma",
+               roofline=_roof(_eval_flops(n, counts), 52.0 * n + 75 + 8.0 * len(calc._c3), dt, "mfma",
                               eval_kernels_ms_per_step=round(t["eval_ms"], 4), neighbor_ms_per_step=round(t["neighbor_ms"], 4),
-                              note="flops = N (100 p + 700 T): every triplet once at its centre (3 legs x ~60 + 64-term "
-                                   "contraction with value and 3 partials ~450 + forces); bytes = 52 N + the coefficient grids"))
+                              realised_per_atom=_counts_note(counts),
+                              note="flops = N (100 p + 700 T) at the realised p, T: every triplet once at its centre; 700 flop per triplet "
+                                   "(3 legs x ~60 + 64-term contraction with value and 3 partials ~450 + forces) is this build's own price -- "
+                                   "SURVEY 8d prices the evaluator by bytes only; bytes = 52 N + the coefficient grids"))
     if cpu:
         from oracle import oracle as O
         from uf3_amd.data.atoms import Atoms
@@ -857,13 +863,15 @@ def extra_eval_128(calls=2000):
         plain.evaluate_frames([atoms])
     dt_plain = (time.perf_counter() - t0) / 300
     assert np.abs(f - f0).max() <= 1e-12 * np.abs(f0).max() and abs(e[0] - e0[0]) <= 1e-12 * abs(e0[0])
+    counts = _counts_of(basis, atoms)
     return dict(metric="latency of one MD step: move + energy + force call (128-atom W frame, host arrays in and out)", value=round(dt * 1e6, 2),
                 unit="us/call", higher_is_better=False, ms_per_step=round(dt * 1e3, 5), steps=calls, atoms_per_frame=n,
                 md=dict(skin_A=MD_SKIN, walk_A=MD_WALK, list_builds_in_timed_steps=s1["builds"] - s0["builds"],
                         steps_repeated=s1["redone"] - s0["redone"],
                         rebuild_everything_route=dict(value=round(dt_plain * 1e6, 2), unit="us/call", note="md skin 0, frozen positions")),
-                roofline=_roof(n * (100.0 * PAIRS_PER_ATOM + 700.0 * TRIPLETS_PER_ATOM), 52.0 * n + 75, dt, "mfma",
-                               note="launch / latency bound: one dependent chain upload -> evaluation on the lists -> download"))
+                roofline=_roof(_eval_flops(n, counts), 52.0 * n + 75, dt, "mfma", realised_per_atom=_counts_note(counts),
+                               note="launch / latency bound: one dependent chain upload -> evaluation on the lists -> download; flops at the "
+                                    "realised p, T, 700 per triplet (this build's own price)"))
 
 
 def extra_lines(dev, ctx, fz, frames, batch, d_pos, d_z, d_xe, d_xf, cpu=True):

@@ -1957,6 +1957,14 @@ def _nccl_eval_worker(rank, world, port, out_dir):
     model.coefficients = coeff
     calc = calculator.UFCalculator(model, device=rank)
     e, f, v = parallel.sharded_evaluate(calc, atoms, forces=True, virial=True, device=rank)   # RCCL all_reduce of [E | dE/deps | F]
+    # the device-resident MD-loop form of the same decomposition (what bench.py --mode eval times): two steps on persistent lists
+    ev = parallel.ShardedEvaluator(calc, atoms, device=rank, md_skin=0.5)
+    e2, f2, v2 = ev.step().result()
+    ev.positions.add_(0.01)                                  # (a rigid shift: same energy and forces, through the MD route's reuse)
+    e3, f3, v3 = ev.step().result()
+    ev.close()
+    assert abs(e2 - e) <= 1e-12 * abs(e) and np.abs(f2 - f).max() <= 1e-12 * np.abs(f).max() and np.allclose(v2, v, rtol=1e-10, atol=1e-10)
+    assert abs(e3 - e) <= 1e-10 * abs(e) and np.abs(f3 - f).max() <= 1e-9 * np.abs(f).max()
     np.savez(os.path.join(out_dir, f"nccl_eval_{rank}.npz"), e=e, f=f, v=v)
     dist.destroy_process_group()
 
@@ -2269,3 +2277,44 @@ def test_hand_off_launch_pair_matches_the_one_kernel_launch_and_the_oracle():
             assert rel_err(e1, e0) < 1e-12 and rel_err(f1, f0) < 1e-12
         ref = O.featurize(O.OracleBasis(basis), frames[-1])
         assert rel_err(f1[off[-2]:off[-1]], ref["xf"]) < TOL and rel_err(e1[-1], ref["xe"]) < TOL
+
+
+def test_sharded_evaluator_and_feature_batch_on_one_gpu():
+    """The package's device-resident N > 1 drivers at world size 1: parallel.ShardedEvaluator (whole-frame
+    evaluator into the flat buffer, MD route, positions moved on the device) against UFCalculator and the oracle, and
+    parallel.featurize_sharded's DeviceFeatureBatch against featurize_frames."""
+    import torch
+    from uf3_amd import parallel
+    basis = synthetic.notebook_basis(['Mo', 'W'])
+    atoms = synthetic.lattice_frame("bcc", (6, 7, 8), 3.165, [42, 74], seed=77)
+    model = ls.WeightedLinearModel(basis)
+    coeff = np.random.default_rng(5).normal(0, 0.05, basis.n_feats)
+    coeff[basis.col_idx] = 0.0
+    model.coefficients = coeff
+    calc = calculator.UFCalculator(model)
+    e1, f1, _, v1 = calc.evaluate_frames([atoms], virial=True)
+    ev = parallel.ShardedEvaluator(calc, atoms, md_skin=0.5)
+    assert ev.device_route and not ev.decomposed and (ev.lo, ev.hi) == (0, len(atoms))
+    e, f, v = ev.step().result()
+    assert abs(e - e1[0]) <= 1e-12 * abs(e1[0]) and rel_err(f, f1) < 1e-12 and np.allclose(v, v1[0], rtol=1e-10, atol=1e-10)
+    rng = np.random.default_rng(9)
+    for _ in range(5):                                       # an MD loop on the device: the lists persist, the atoms move
+        ev.positions.add_(torch.from_numpy(rng.uniform(-0.02, 0.02, (len(atoms), 3))).to(ev.positions.device))
+        ev.step()
+    e, f, v = ev.result()
+    moved = Atoms(numbers=atoms.get_atomic_numbers(), positions=ev.host_positions(), cell=atoms.get_cell(), pbc=True)
+    ev.close()
+    e_ref, f_ref = O.evaluate(O.OracleBasis(basis), moved, coeff)
+    assert abs(e - e_ref) <= TOL * abs(e_ref) and worst_elementwise(f, f_ref) <= 1.0
+    # the featurize-only fan-out: this rank's block (all frames at world size 1), rows resident on the device
+    frames = [synthetic.lattice_frame("bcc", (4, 4, 4 + k), 3.165, [42, 74], seed=20 + k) for k in range(3)]
+    fz = process.BasisFeaturizer(basis)
+    fb, (lo, hi) = parallel.featurize_sharded(fz, frames)
+    assert (lo, hi) == (0, 3)
+    fb.run()
+    x_e, x_f, off = fz.featurize_frames(frames)
+    assert rel_err(fb.x_e.cpu().numpy(), x_e) < 1e-12 and rel_err(fb.x_f.cpu().numpy(), x_f) < 1e-12
+    fb2, (lo2, hi2) = parallel.featurize_sharded(fz, lambda i: frames[i], n_frames=3, rank=1, world_size=2, ld=-1)
+    assert (lo2, hi2) == (2, 3) and fb2.ld % 16 == 0
+    fb2.run()
+    assert rel_err(fb2.x_f.cpu().numpy(), x_f[off[2]:off[3]]) < 1e-12

@@ -80,6 +80,80 @@ def _eval_worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
+class _MovingTableCalculator(_TableCalculator):
+    """shares that depend on the positions (a harmonic well per atom), so that the stand-in sees what ShardedEvaluator hands it"""
+
+    def evaluate_atom_range(self, atoms, lo, hi, forces=True, virial=False):
+        x = atoms.get_positions()
+        f = np.zeros_like(x)
+        f[lo:hi] = -x[lo:hi] * self.f[lo:hi]
+        e = 0.5 * float((x[lo:hi] ** 2 * self.f[lo:hi]).sum())
+        return e, f, self.v[lo:hi].sum(0)
+
+
+class _Frame:
+    def __init__(self, x):
+        self.x = np.array(x)
+
+    def __len__(self):
+        return len(self.x)
+
+    def get_positions(self):
+        return self.x
+
+    def set_positions(self, x):
+        self.x = np.array(x)
+
+    def copy(self):
+        return _Frame(self.x)
+
+
+def _sharded_evaluator_worker(rank, world, port, out_dir):
+    import torch.distributed as dist
+    from uf3_amd import parallel
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rng = np.random.default_rng(3)
+    n = 101
+    k = np.abs(rng.normal(size=(n, 3))) + 0.5
+    calc = _MovingTableCalculator(None, k, rng.normal(size=(n, 6)))
+    x = rng.normal(size=(n, 3))
+    ev = parallel.ShardedEvaluator(calc, _Frame(x))
+    assert (ev.rank, ev.world, ev.decomposed) == (rank, world, True) and not ev.device_route
+    out = []
+    for step in range(3):                                    # an MD loop: positions from the host, one reduce per step
+        ev.set_positions(x)
+        e, f, v = ev.step().result()
+        out.append((e, f, v))
+        x = x + 0.01 * f
+    np.savez(os.path.join(out_dir, f"sev_{rank}.npz"), e=[o[0] for o in out], f=np.stack([o[1] for o in out]),
+             v=np.stack([o[2] for o in out]), k=k, v_ref=calc.v.sum(0), x_last=ev.host_positions())
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharded_evaluator_md_loop(tmp_path):
+    """parallel.ShardedEvaluator (what bench.py --mode eval runs on the GPUs) with the CPU stand-in calculator: block of centres
+    per rank, flat buffer [forces | energy | strain derivative], one all_reduce per step, positions updated between steps"""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_sharded_evaluator_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    d0, d1 = np.load(tmp_path / "sev_0.npz"), np.load(tmp_path / "sev_1.npz")
+    assert np.array_equal(d0["f"], d1["f"]) and np.array_equal(d0["e"], d1["e"])       # every rank holds the full result
+    rng = np.random.default_rng(3)
+    n = 101
+    k = np.abs(rng.normal(size=(n, 3))) + 0.5
+    rng.normal(size=(n, 6))
+    x = rng.normal(size=(n, 3))
+    for step in range(3):
+        f = -x * k
+        assert np.allclose(d0["f"][step], f, rtol=0, atol=1e-14) and abs(d0["e"][step] - 0.5 * (x * x * k).sum()) < 1e-10
+        assert np.allclose(d0["v"][step], d0["v_ref"], rtol=1e-12, atol=1e-12)
+        x = x + 0.01 * f
+
+
 def test_two_rank_decomposed_frame_evaluation(tmp_path):
     s = socket.socket()
     s.bind(("127.0.0.1", 0))

@@ -247,3 +247,183 @@ def sharded_evaluate(calculator, atoms, forces=True, virial=False, device=None):
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         flat = t.numpy()
     return (float(flat[0]), flat[7:].reshape(n, 3) if forces else None, flat[1:7].copy() if virial else None)
+
+
+class ShardedEvaluator:
+    """
+    The MD-loop form of ``sharded_evaluate``: ONE large frame decomposed over the ranks, everything a step touches resident on
+    the device (what ``bench.py --mode eval`` times at N > 1 is this class, not a private copy).
+
+    Per rank: the whole frame's positions and species in HBM (28 B per atom), one flat fp64 device buffer
+    ``[forces (3N) | energy | dE/d(strain) (6)]``; a step evaluates the triplets CENTRED in the rank's contiguous block of atoms
+    (``uf3_eval_centres_dev``, on the evaluator's MD route -- neighbour lists kept with a skin -- when ``md_skin`` > 0) straight
+    into that buffer and the ranks sum it with ONE ``all_reduce(SUM)`` (RCCL over xGMI under "nccl", or the library's own
+    communicator with ``native=True``); one rank runs the whole-frame evaluator (``uf3_eval_virial_dev``), no collective.
+    Positions move on the device (``positions`` is the device tensor: update it in place) or come from the host
+    (``set_positions``); results come to the host only when asked for (``result``).  The reference's calculator is a single
+    process (uf3/forcefield/calculator.py:124-153).
+
+    A calculator without device coefficient tables -- the table stand-ins of the CPU tests -- takes the host route: its
+    ``evaluate_centre_range`` / ``evaluate_atom_range`` shares fill a host buffer of the same layout, reduced over gloo.
+    """
+
+    def __init__(self, calculator, atoms, device=None, md_skin=0.0, native=False, force_collective=None):
+        import os
+        import torch
+        import torch.distributed as dist
+        self.calculator = calculator
+        self.atoms = atoms
+        self.n = len(atoms)
+        on = dist.is_available() and dist.is_initialized()
+        self.dist = dist if on else None
+        self.rank, self.world = (dist.get_rank(), dist.get_world_size()) if on else (0, 1)
+        if force_collective is None:
+            force_collective = bool(os.environ.get("UF3_FORCE_COLLECTIVE"))
+        # (forced: the decomposed route + its collective in a group of one rank -- what a one-GPU box can exercise of the N > 1 path)
+        self.decomposed = self.world > 1 or (on and force_collective)
+        self.lo, self.hi = shard_range(self.n, self.rank, self.world)
+        self.native = bool(native)
+        self.device_route = hasattr(calculator, "_pc")
+        self.steps = 0
+        if not self.device_route:
+            self.flat = torch.zeros(3 * self.n + 7, dtype=torch.float64)
+            self._pos = np.array(atoms.get_positions(), dtype=np.float64)
+            return
+        from uf3_amd import _lib
+        self._lib = _lib
+        dev_index = calculator.device if device is None else device
+        self.ctx = _lib.get_context(dev_index)
+        self.db = _lib.device_basis(calculator.bspline_config, self.ctx)
+        self.batch = _lib.FrameBatch([atoms])
+        self.dev = torch.device("cuda", self.ctx.device if hasattr(self.ctx, "device") else (dev_index or 0))
+        self.positions = torch.from_numpy(self.batch.pos).to(self.dev)          # [N, 3] (device; update in place)
+        self._z = torch.from_numpy(self.batch.z).to(self.dev)
+        self.flat = torch.zeros(3 * self.n + 7, dtype=torch.float64, device=self.dev)
+        self.md_skin = float(md_skin)
+        self._args = self._out = None
+        if self.md_skin > 0:
+            self.ctx.md_skin(self.md_skin)
+        if self.native and self.ctx.comm_info()[0] <= 0:
+            native_comm(self.ctx, self.rank, self.world)
+
+    def set_positions(self, positions):
+        """New positions from the host ([N, 3]); device callers write ``self.positions`` in place instead."""
+        import torch
+        positions = np.ascontiguousarray(positions, dtype=np.float64).reshape(self.n, 3)
+        if self.device_route:
+            self.positions.copy_(torch.from_numpy(positions))
+        else:
+            self._pos = positions
+
+    def step(self):
+        """One evaluation of the current positions into ``self.flat`` (summed over the ranks); asynchronous on the device route."""
+        import ctypes as C
+        import torch
+        self.steps += 1
+        if not self.device_route:
+            atoms = self.atoms.copy() if hasattr(self.atoms, "copy") else self.atoms
+            if hasattr(atoms, "set_positions"):
+                atoms.set_positions(self._pos)
+            share = getattr(self.calculator, "evaluate_centre_range", None) or self.calculator.evaluate_atom_range
+            e, f, v = share(atoms, self.lo, self.hi, forces=True, virial=True)
+            host = np.concatenate([np.asarray(f, dtype=np.float64).reshape(-1), [e], np.zeros(6) if v is None else v])
+            self.flat = torch.from_numpy(host)
+            if self.dist is not None and self.decomposed:
+                self.dist.all_reduce(self.flat, op=self.dist.ReduceOp.SUM)
+            return self
+        ctx = self.ctx
+        cur = torch.cuda.current_stream(self.dev).cuda_stream
+        if getattr(ctx, "_stream", None) != cur:               # (the _dev entries run on the stream the context is bound to)
+            ctx.set_stream(cur)
+        if self._args is None:                                  # (every pointer of a step is fixed: positions move in place)
+            n, base = self.n, self.flat.data_ptr()
+            self._args = (self.db.handle, C.byref(self.batch.struct), C.c_void_p(self.positions.data_ptr()),
+                          C.c_void_p(self._z.data_ptr())) + tuple(self.calculator._pc)
+            self._out = (C.c_void_p(base + 8 * 3 * n), C.c_void_p(base), C.c_void_p(base + 8 * (3 * n + 1)))    # energy | forces | strain
+        if not self.decomposed:
+            ctx.check(ctx.lib.uf3_eval_virial_dev(*self._args, *self._out))
+        else:
+            # (uf3_eval_centres_dev zeroes every force row itself and overwrites energy / strain derivative: nothing to clear)
+            ctx.check(ctx.lib.uf3_eval_centres_dev(*self._args, self.lo, self.hi, *self._out))
+            if self.native:
+                ctx.allreduce_sum(self.flat.data_ptr(), self.flat.numel())
+            else:
+                self.dist.all_reduce(self.flat, op=self.dist.ReduceOp.SUM)
+        return self
+
+    def result(self):
+        """(energy, forces [N, 3], dE/d(strain) [6]) of the last step, on the host (synchronises)."""
+        host = self.flat.cpu().numpy() if hasattr(self.flat, "cpu") else np.asarray(self.flat)
+        n = self.n
+        return float(host[3 * n]), host[:3 * n].reshape(n, 3).copy(), host[3 * n + 1:].copy()
+
+    def host_positions(self):
+        return self.positions.cpu().numpy() if self.device_route else self._pos.copy()
+
+    def close(self):
+        """Leave the evaluator's MD route (the context is shared with other callers)."""
+        if self.device_route and self.md_skin > 0:
+            self.ctx.md_skin(0.0)
+
+
+class DeviceFeatureBatch:
+    """A rank's block of frames with everything the featurizer touches resident in HBM: positions | species in, energy rows
+    ``x_e [frames][F]`` and force rows ``x_f [atoms][3][ld]`` out (``run()`` = one ``uf3_featurize_ld_dev`` on torch's current stream)."""
+
+    def __init__(self, featurizer, frames, device=None, ld=0):
+        import torch
+        from uf3_amd import _lib
+        self.featurizer = featurizer
+        self.frames = list(frames)
+        self.ctx, self.db = featurizer._dev()
+        self.batch = _lib.FrameBatch(self.frames)
+        self.F = self.db.n_feat
+        dev_index = self.ctx.device if device is None else device
+        self.dev = torch.device("cuda", dev_index or 0)
+        self.ld = self.F if ld == 0 else (featurizer.aligned_ld(self.F) if ld < 0 else max(self.F, int(ld)))
+        self.pos = torch.from_numpy(self.batch.pos).to(self.dev)
+        self.z = torch.from_numpy(self.batch.z).to(self.dev)
+        self.x_e = torch.empty((len(self.frames), self.F), dtype=torch.float64, device=self.dev)
+        self.x_f_full = torch.empty((self.batch.n_atoms, 3, self.ld), dtype=torch.float64, device=self.dev)
+        self.x_f = self.x_f_full[:, :, :self.F]
+        self.offsets = self.batch.offsets
+
+    def run(self):
+        import torch
+        cur = torch.cuda.current_stream(self.dev).cuda_stream
+        if getattr(self.ctx, "_stream", None) != cur:          # (the _dev entries run on the stream the context is bound to)
+            self.ctx.set_stream(cur)
+        self.featurizer.featurize_device(self.batch.struct, self.pos.data_ptr(), self.z.data_ptr(), self.x_e.data_ptr(),
+                                         self.x_f_full.data_ptr(), ld=self.ld)
+        return self
+
+
+def featurize_sharded(featurizer, frames, n_frames=None, device=None, ld=0, balance=False, rank=None, world_size=None):
+    """
+    The featurize-only fan-out (reference: ``BasisFeaturizer.evaluate_parallel`` over DataFrame chunks,
+    uf3/representation/process.py:196-254): this rank's contiguous block of the frames -- ``frames`` a list, or a callable
+    ``frames(i)`` over ``n_frames`` global indices so that a rank materialises only its own block -- as a ``DeviceFeatureBatch``
+    (rows resident in HBM); the data path has no collective.  ``balance``: blocks of even estimated work sum N*T instead of even
+    frame counts (needs the list).  Returns (batch, (lo, hi)): call ``batch.run()`` per pass.
+    """
+    if rank is None or world_size is None:
+        import torch.distributed as dist
+        on = dist.is_available() and dist.is_initialized()
+        rank, world_size = (dist.get_rank(), dist.get_world_size()) if on else (0, 1)
+    if callable(frames):
+        if n_frames is None:
+            raise ValueError("featurize_sharded: a frame generator needs n_frames")
+        lo, hi = shard_range(n_frames, rank, world_size)
+        mine = [frames(i) for i in range(lo, hi)]
+    else:
+        frames = list(frames)
+        if balance and world_size > 1:
+            basis = featurizer.bspline_config
+            r3 = 0.0
+            for trio in basis.interactions_map.get(3, []) if basis.degree > 2 else []:
+                r3 = max(r3, float(np.max(np.asarray(basis.r_max_map[trio])[:2])))
+            lo, hi = shard_balanced([frame_work(a, r3) for a in frames], rank, world_size)
+        else:
+            lo, hi = shard_range(len(frames), rank, world_size)
+        mine = frames[lo:hi]
+    return DeviceFeatureBatch(featurizer, mine, device=device, ld=ld), (lo, hi)
