@@ -2318,3 +2318,45 @@ def test_sharded_evaluator_and_feature_batch_on_one_gpu():
     assert (lo2, hi2) == (2, 3) and fb2.ld % 16 == 0
     fb2.run()
     assert rel_err(fb2.x_f.cpu().numpy(), x_f[off[2]:off[3]]) < 1e-12
+
+
+_BAR_ALTERNATION = r'''
+import numpy as np, sys
+from uf3_amd import synthetic
+from uf3_amd.forcefield import calculator
+from uf3_amd.regression import least_squares as ls
+basis = synthetic.notebook_basis(['W'])
+model = ls.WeightedLinearModel(basis)
+coeff = np.random.default_rng(5).normal(0, 0.05, basis.n_feats)
+coeff[basis.col_idx] = 0.0
+model.coefficients = coeff
+a = synthetic.lattice_frame("bcc", (4, 4, 4), 3.165, [74], seed=3)
+b = a.copy()
+b.positions = a.positions + np.random.default_rng(1).uniform(-0.05, 0.05, a.positions.shape)
+plain = calculator.UFCalculator(model, md_skin=0.0)
+want = [plain.evaluate_frames([x]) for x in (a, b)]
+calc = calculator.UFCalculator(model, md_skin=0.5)          # the MD route: small batches staged by the host, steps waited for on a polled word
+bad = 0
+for step in range(400):
+    k = step & 1
+    e, f, _ = calc.evaluate_frames([(a, b)[k]])
+    bad += not (abs(e[0] - want[k][0][0]) <= 1e-12 * abs(want[k][0][0]) and np.abs(f - want[k][1]).max() <= 1e-12 * np.abs(want[k][1]).max())
+print("BAD", bad)
+sys.exit(1 if bad else 0)
+'''
+
+
+@pytest.mark.parametrize("env", [{}, {"UF3_BAR_FORCE_FAIL": "1"}, {"UF3_NO_BAR_STAGE": "1"}])
+def test_alternating_positions_through_the_staged_block_for_many_steps(env):
+    """ADVICE round 5: the host stores an MD step's positions straight into a fine-grained device block (BAR staging, gated on
+    bar_self_test) and waits for the step on a polled status word, no stream synchronisation in between -- a stale cache line would
+    make a step silently use the previous step's positions.  400 consecutive steps alternate between two position sets; every
+    result must be the one of ITS positions.  Also with the self-test forced to fail / the path switched off (the pinned-block
+    route), each in a fresh process and context."""
+    import subprocess
+    import sys
+    full = dict(os.environ)
+    full.update(env)
+    full["PYTHONPATH"] = os.path.dirname(os.path.dirname(os.path.abspath(__file__))) + os.pathsep + full.get("PYTHONPATH", "")
+    r = subprocess.run([sys.executable, "-c", _BAR_ALTERNATION], env=full, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "BAD 0" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])

@@ -106,10 +106,11 @@ struct uf3_ctx {
     // small MD steps without a fetch kernel: with a large BAR the host stores positions | species straight into a (fine-grained)
     // device block -- no launch that reads the caller's pinned block, no dispatch gap behind a 4 us kernel (eval_impl, MD route)
     bool bar_ok = false;
+    bool bar_tested = false;            // bar_self_test has run on this context (it decides bar_ok once, at the first small batch)
     Buf stage_bar;                      // the fine-grained block of small batches (upload_frames)
     char *stage_cur = nullptr;          // the block that holds the current host-entry batch: stage_bar or stage_pos
     size_t staged_in_dev = 0;           // bytes of positions | species the host entry has stored into stage_pos already (0: none)
-    // environment switches of the featurizer's asynchronous path, read once (uf3_ctx_create)
+    // environment switches of the featurizer's asynchronous path, re-read at the top of every featurizer call (read_f3_env)
     bool env_no_feat3 = false, env_f3_no_cap16 = false, env_f3_no_select = false, env_debug_lds = false;
     int env_f3_bps = 24;
     unsigned eval_seq = 0;              // sequence number of the last small evaluator call whose tail kernel signals through the pinned block
@@ -250,6 +251,16 @@ extern "C" const char *uf3_last_error(const uf3_ctx *ctx) { return ctx ? ctx->er
 #endif
 extern "C" const char *uf3_build_id(void) { return UF3_BUILD_ID; }
 
+// the featurizer's switches, re-read on every call (uf3_env is a look-up in the cached UF3_* entries; tests and A/B runs flip
+// them between calls on one shared context -- ADVICE round 5)
+static void read_f3_env(uf3_ctx *c) {
+    c->env_no_feat3 = uf3_env("UF3_NO_FEAT3") != nullptr;
+    c->env_f3_no_cap16 = uf3_env("UF3_F3_NO_CAP16") != nullptr;
+    c->env_f3_no_select = uf3_env("UF3_F3_NO_SELECT") != nullptr;
+    c->env_debug_lds = uf3_env("UF3_DEBUG_LDS") != nullptr;
+    c->env_f3_bps = uf3_env("UF3_F3_BPS") ? std::max(1, atoi(uf3_env("UF3_F3_BPS"))) : 24;
+}
+
 extern "C" int uf3_ctx_create(int device, uf3_ctx **out) {
     uf3_env_refresh();
     if (!out) return fail(nullptr, UF3_EINVAL, "uf3_ctx_create: null out");
@@ -269,12 +280,8 @@ extern "C" int uf3_ctx_create(int device, uf3_ctx **out) {
     HIPCHK(c, hipGetDeviceProperties(&prop, device));
     c->lds_max = (int)prop.sharedMemPerBlock;
     c->n_cu = prop.multiProcessorCount;
-    c->env_no_feat3 = uf3_env("UF3_NO_FEAT3") != nullptr;
-    c->env_f3_no_cap16 = uf3_env("UF3_F3_NO_CAP16") != nullptr;
-    c->env_f3_no_select = uf3_env("UF3_F3_NO_SELECT") != nullptr;
+    read_f3_env(c);
     { int large = 0; c->bar_ok = hipDeviceGetAttribute(&large, hipDeviceAttributeIsLargeBar, device) == hipSuccess && large && !uf3_env("UF3_NO_BAR_STAGE"); }
-    c->env_debug_lds = uf3_env("UF3_DEBUG_LDS") != nullptr;
-    if (uf3_env("UF3_F3_BPS")) c->env_f3_bps = std::max(1, atoi(uf3_env("UF3_F3_BPS")));
     if (std::string(prop.gcnArchName).find("gfx950") == std::string::npos) {
         std::string m = std::string("uf3_hip is built for gfx950 only, device is ") + prop.gcnArchName;
         delete c;
@@ -1414,6 +1421,7 @@ static int featurize_dev_impl(uf3_basis *b, const uf3_frames *fr, const double *
                               double *d_xe, double *d_xf, int64_t ld) {
     uf3_ctx *c = b->ctx;
     uf3_env_refresh();
+    read_f3_env(c);
     if (!d_pos || !d_z) return fail(c, UF3_EINVAL, "null positions / species");
     if (!d_xe && !d_xf) return UF3_OK;
     // verdicts on earlier asynchronous calls that have arrived: returned to the asynchronous caller (their owner) HERE, so not
@@ -1837,6 +1845,52 @@ static int featurize_dev_impl(uf3_basis *b, const uf3_frames *fr, const double *
 }
 
 // host-buffer helpers
+// BAR staging rests on two things the HIP API does not promise: that host stores into a fine-grained device
+// allocation, followed by a store fence, are visible to the NEXT kernel launched -- no stale line of the block left in the GPU's
+// L2 or scalar cache from the previous launch -- and that this holds with no stream synchronisation in between (the MD steps wait on
+// a polled status word).  So the path is gated on a start-up self-test of exactly that sequence, on this device, with this driver:
+// 48 rounds of (host writes a new pattern into the block | fence | k_bar_probe reads it with vector AND scalar loads | host polls the
+// pinned word the kernel leaves last), patterns compared at the end.  One mismatch, a time-out or any HIP error: bar_ok = false and
+// the small batches take the pinned-block route (k_md_fetch / k_prepare_small fetch them) as before round 5.  Costs < 1 ms, once.
+static bool bar_self_test(uf3_ctx *c) {
+    const int n_words = 2048, rounds = 48;          // (8 KB: what a 128-atom MD step stages is 3.6 KB)
+    Buf blk, out;
+    PinBuf word;
+    bool ok = blk.ensure_fine(4 * (size_t)n_words) == hipSuccess && out.ensure(4 * (size_t)rounds * (n_words + 16)) == hipSuccess &&
+              word.ensure(64) == hipSuccess;
+    std::vector<unsigned> got;
+    if (ok) {
+        volatile unsigned *w = (volatile unsigned *)word.p;
+        *w = 0;
+        std::vector<unsigned> pat(n_words);
+        for (int r = 1; r <= rounds && ok; r++) {
+            for (int q = 0; q < n_words; q++) pat[q] = 0x9e3779b9u * (unsigned)(r * 4099 + q) + (unsigned)r;
+            std::memcpy(blk.p, pat.data(), 4 * (size_t)n_words);
+            uf3_store_fence();
+            hipLaunchKernelGGL(k_bar_probe, dim3(1), dim3(256), 0, c->stream, (const unsigned *)blk.p, n_words,
+                               out.as<unsigned>() + (size_t)(r - 1) * (n_words + 16), (unsigned *)word.p, (unsigned)r);
+            ok = hipGetLastError() == hipSuccess;
+            const auto t_end = std::chrono::steady_clock::now() + std::chrono::milliseconds(200);
+            while (ok && __atomic_load_n((const unsigned *)word.p, __ATOMIC_ACQUIRE) != (unsigned)r)
+                if (std::chrono::steady_clock::now() > t_end) ok = false;
+        }
+        ok = hipStreamSynchronize(c->stream) == hipSuccess && ok;
+        if (ok) {
+            got.resize((size_t)rounds * (n_words + 16));
+            ok = hipMemcpy(got.data(), out.p, 4 * got.size(), hipMemcpyDeviceToHost) == hipSuccess;
+        }
+        for (int r = 1; r <= rounds && ok; r++)
+            for (int q = 0; q < n_words + 16 && ok; q++) {
+                const int src = q < n_words ? q : q - n_words;
+                ok = got[(size_t)(r - 1) * (n_words + 16) + q] == 0x9e3779b9u * (unsigned)(r * 4099 + src) + (unsigned)r;
+            }
+    }
+    (void)hipGetLastError();
+    blk.release(); out.release(); word.release();
+    if (!ok && uf3_env("UF3_DEBUG_LDS")) fprintf(stderr, "uf3: BAR staging self-test failed on device %d: small batches go through the pinned block\n", c->device);
+    return ok;
+}
+
 static int upload_frames(uf3_ctx *c, const uf3_frames *fr, const double *pos, const int32_t *z, int &natoms,
                          bool defer_small = false) {
     if (!fr || fr->n_frames < 1 || !fr->atom_offsets) return fail(c, UF3_EINVAL, "bad uf3_frames");
@@ -1850,8 +1904,14 @@ static int upload_frames(uf3_ctx *c, const uf3_frames *fr, const double *pos, co
     const size_t geo_room = 96 + sizeof(FrameGeom) * (size_t)fr->n_frames + 8 * ((size_t)fr->n_frames + 1);
     // small batches of the synchronous evaluator entry: with a large BAR the block is a fine-grained device allocation and the
     // host stores into it directly (write-combined, posted; a store fence; the launches' doorbell follows over the same link) --
-    // no kernel or copy that reads the caller's memory.  The entry's previous call has been waited for: nothing reads the block.
+    // no kernel or copy that reads the caller's memory.  The entry's previous call has been waited for (pin_in_busy says when an
+    // error return skipped that wait): nothing reads the block.  Gated on bar_self_test.
     bool bar = defer_small && c->bar_ok && bp + bz + geo_room <= UF3_BAR_LIMIT;
+    if (bar && !c->bar_tested) {
+        c->bar_tested = true;
+        if (!uf3_env("UF3_BAR_NO_SELFTEST")) c->bar_ok = bar = bar_self_test(c);
+        if (uf3_env("UF3_BAR_FORCE_FAIL")) c->bar_ok = bar = false;       // (tests: the fall-back route on a box where the test passes)
+    }
     // (a block of its own: the big batches' staging block stays ordinary device memory)
     if (bar && c->stage_bar.ensure_fine(bp + bz + geo_room) != hipSuccess) { (void)hipGetLastError(); c->bar_ok = false; bar = false; }
     if (!bar) HIPCHK(c, c->stage_pos.ensure(bp + bz + geo_room));  // positions | species, one block
@@ -1865,6 +1925,9 @@ static int upload_frames(uf3_ctx *c, const uf3_frames *fr, const double *pos, co
         std::memcpy(c->stage_cur + bp, z, bz);
         uf3_store_fence();
         c->staged_in_dev = (bp + bz + 15) / 16 * 16;
+        // (kernels that read this block follow; an entry that returns an error behind them never waits for them: the flag stays up
+        // until a successful wait clears it, and the next upload waits for the stream before it stores into the block -- above)
+        c->pin_in_busy = true;
         return UF3_OK;
     }
     if (bp + bz <= UF3_PIN_LIMIT) {
@@ -2486,6 +2549,7 @@ extern "C" int uf3_fit_create(uf3_basis *b, int with_forces, int64_t max_atoms_p
                               const double *frozen_c, int32_t n_frozen, uf3_fit **out) {
     if (!b || !out || n_frozen < 0 || (n_frozen && (!frozen_idx || !frozen_c))) return fail(b ? b->ctx : nullptr, UF3_EINVAL, "uf3_fit_create: bad argument");
     uf3_ctx *c = b->ctx;
+    uf3_env_refresh();                      // (UF3_FIT_PACK_THREADS below: not a stale cache)
     HIPCHK(c, hipSetDevice(c->device));
     uf3_fit *f = new uf3_fit();
     f->b = b; f->c = c; f->with_forces = with_forces != 0; f->F = b->host.F;
@@ -2524,9 +2588,41 @@ extern "C" int uf3_fit_add(uf3_fit *f, int32_t n_frames, const int64_t *atom_cou
     const size_t F2 = (size_t)F * F;
     double *flat = f->flat_ext ? f->flat_ext : f->flat.as<double>(), *gram_e = flat, *gram_f = flat + F2, *ord_e = flat + 2 * F2, *ord_f = ord_e + F, *mom = ord_f + F;
     int start = 0;
+    for (int i = 0; i < n_frames; i++)
+        if (atom_counts[i] <= 0) return fail(c, UF3_EINVAL, "uf3_fit_add: a frame without atoms (its per-atom energy target is undefined)");
     // chunk sizes grow geometrically from first_fraction of the limit: the GPU starts after a short pack, and the pack of
     // chunk k + 1 (host, about half the GPU's time per frame on a one-species basis) hides behind the kernels of chunk k
     double fraction = f->first_fraction;
+    {
+        // the chunks of this call, planned ahead: every buffer is sized ONCE for the largest of them (a Buf that grows chunk by chunk
+        // frees and allocates -- an implicit device synchronisation -- in the middle of the copy / compute overlap: ADVICE round 5)
+        double fr_ = fraction;
+        int64_t big_atoms = 0, big_block = 0;
+        int big_nf = 0;
+        for (int s0 = 0; s0 < n_frames;) {
+            const int64_t limit = fr_ < 1.0 ? std::max<int64_t>(1, (int64_t)(f->max_atoms * fr_)) : f->max_atoms;
+            fr_ = std::min(1.0, 2.0 * fr_);
+            int s1 = s0;
+            int64_t atoms = 0;
+            while (s1 < n_frames && (s1 == s0 || atoms + atom_counts[s1] <= limit)) atoms += atom_counts[s1++];
+            big_atoms = std::max(big_atoms, atoms); big_nf = std::max(big_nf, s1 - s0);
+            big_block = std::max<int64_t>(big_block, 6 * atoms + 2 * (int64_t)(s1 - s0) + (atoms + 1) / 2);
+            s0 = s1;
+        }
+        if (big_atoms >= (1LL << 28)) return fail(c, UF3_EINVAL, "uf3_fit_add: a chunk must hold 1 .. 2^28 atoms");
+        for (int q = 0; q < 2 && n_frames; q++) {
+            uf3_fit::Set &st = f->set[q];
+            if (8 * (size_t)big_block > st.host.cap && st.copied_live) { HIPCHK(c, hipEventSynchronize(st.copied)); st.copied_live = false; }
+            HIPCHK(c, st.host.ensure(8 * (size_t)big_block));
+            if (8 * (size_t)big_block > st.dev.cap && st.consumed_live) { HIPCHK(c, hipEventSynchronize(st.consumed)); st.consumed_live = false; }
+            HIPCHK(c, st.dev.ensure(8 * (size_t)big_block));
+        }
+        if (n_frames) {
+            if (8 * (size_t)big_nf * F > f->xe.cap || (f->with_forces && 24 * (size_t)big_atoms * F > f->xf.cap)) HIPCHK(c, hipStreamSynchronize(c->stream));
+            HIPCHK(c, f->xe.ensure(8 * (size_t)big_nf * F));
+            if (f->with_forces) HIPCHK(c, f->xf.ensure(24 * (size_t)big_atoms * F));
+        }
+    }
     while (start < n_frames) {
         const int64_t limit = fraction < 1.0 ? std::max<int64_t>(1, (int64_t)(f->max_atoms * fraction)) : f->max_atoms;
         fraction = std::min(1.0, 2.0 * fraction);

@@ -571,6 +571,25 @@ k_md_fetch(const int4 *host_block, int4 *dev_block, int block_int4s, int *flags)
     if (threadIdx.x == 0) flags[12] = 0;
 }
 
+// Self-test of the BAR staging path (uf3_ctx: bar_self_test): the block the HOST has just stored into, read the two
+// ways the kernels read it -- vector loads (a lane per word) and scalar loads through the constant address space (the first words,
+// as load_const reads struct fields) -- into this round's slab of `out`, then the round's number into a pinned word the host polls:
+// the same no-stream-sync hand-shake as the evaluator's MD steps.  A stale cache line shows as an earlier round's pattern.
+__global__ void __launch_bounds__(256)
+k_bar_probe(const unsigned *block, int n_words, unsigned *out, unsigned *done_word, unsigned round) {
+    for (int q = threadIdx.x; q < n_words; q += blockDim.x) out[q] = block[q];
+    if (threadIdx.x == 0) {
+        typedef const __attribute__((address_space(4))) unsigned *ConstWords;
+        ConstWords sc = (ConstWords)(unsigned long long)block;
+        for (int q = 0; q < 16 && q < n_words; q++) out[n_words + q] = sc[q];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence_system();
+        __hip_atomic_store(done_word, round, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 // what an MD step reads besides the lists -- frame geometry | offsets, frame and species of every atom, the positions of the
 // build -- into the context's persistent copies: one launch instead of four device-to-device copies
 __global__ void __launch_bounds__(256)
