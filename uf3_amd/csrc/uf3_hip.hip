@@ -122,6 +122,8 @@ struct uf3_ctx {
     PinBuf pin_eval;                    // device-resident evaluator calls: status words [4] | sequence number, written by the last kernel
     hipEvent_t pin_in_done = nullptr, pin_geo_done = nullptr;   // the copies out of pin_in / pin_geo have executed
     std::vector<double> coeff_shadow;   // host copy of the model last uploaded by uf3_eval (c1 | c2 | c3)
+    Buf coeff_cw;                       // window table of that model's 3-body coefficients (k_eval<..., CW>), when cw_of is its basis
+    const void *cw_of = nullptr;        // the basis the table in coeff_cw was built for (null: none -- coefficients outside the window)
     const void *coeff_dev = nullptr;    // ... and where it lives
     // MD route of the evaluator (uf3_ctx_md_skin): persistent superset lists with a skin, see k_build_sup.  Everything a step
     // needs besides the current positions lives in its own buffers -- the workspace above belongs to whichever call ran last
@@ -186,6 +188,11 @@ struct uf3_basis {
     // k_featurize3 (3-body force rows by bond factorisation, uf3_feat3.h): eligibility and tables
     bool feat3_ok = false;
     bool eval_tab_ok = false;        // the evaluator's centre pass may run its TAB instances (see k_eval)
+    // k_eval<..., CW>: the coefficients inside the kept-bin window of the centre legs as a table for LDS (EvalArgs::c3w)
+    bool eval_cw_ok = false;         // one window on every trio, centre legs alike, table + zero run small enough
+    int cw_lo = 0, cw_ext = 0, cw_dim_m = 0, cw_dim_n = 0, cw_zero = 0, cw_bytes = 0;
+    std::vector<int> cw_lut_off;     // per trio: where its full grid starts in c3
+    std::vector<int> cw_dim_l;
     double *d_f3rows = nullptr;      // window rows of the centre legs and of leg n
     int n_f3rows = 0;
     unsigned short *d_f3src = nullptr;   // fold tables
@@ -299,7 +306,7 @@ extern "C" void uf3_ctx_destroy(uf3_ctx *c) {
     Buf *all[] = {&c->geoms, &c->offsets, &c->frame_of, &c->atom_bin, &c->atom_wrap, &c->spec, &c->key_in,
                   &c->key_out, &c->val_in, &c->val_out, &c->sort_tmp, &c->bin_start, &c->slots, &c->flags, &c->n3_cnt, &c->n3_int, &c->n3_dbl, &c->e_atom, &c->nbr_f, &c->coeff,
                   &c->stage_pos, &c->stage_z, &c->stage_out, &c->stage_out2, &c->sp_rows, &c->sp_seg, &c->gram_tij, &c->frag, &c->dbg, &c->halo, &c->n3x_ent, &c->n3x_off,
-                  &c->bin_cnt};
+                  &c->bin_cnt, &c->f3w, &c->coeff_cw};
     for (Buf *b : all) b->release();
     for (Buf &b : c->gram_tiles) b.release();
     if (c->comm) uf3_comm_destroy(c);
@@ -809,6 +816,28 @@ extern "C" int uf3_basis_create(uf3_ctx *c, const uf3_basis_spec *s, uf3_basis *
     }
     // k_eval<TAB>: one set of 3-body legs, the trio tables in one register each, leg n's knot records in the workgroup's LDS
     b->eval_tab_ok = h.trio_legs_uniform && h.T <= WAVE && trios[0].leg[2].nk - 7 <= EVAL_TAB_KN;
+    if (b->eval_tab_ok && h.T > 0) {
+        const TrioDev &t0 = trios[0];
+        bool ok = t0.lo[0] == t0.lo[1] && t0.ext[0] == t0.ext[1] && t0.ext[0] >= 1;
+        for (int t = 0; t < h.T && ok; t++) {
+            const TrioDev &td = trios[t];
+            ok = td.lo[0] == t0.lo[0] && td.lo[1] == t0.lo[0] && td.ext[0] == t0.ext[0] && td.ext[1] == t0.ext[0] &&
+                 td.dim_m == t0.dim_m && td.dim_n == t0.dim_n && td.dim_l == t0.dim_l;
+        }
+        if (ok) {
+            const int ext = t0.ext[0], dn = t0.dim_n;
+            const size_t table = (size_t)h.T * ext * ext * dn * 8;
+            const size_t zero = ((size_t)(3 * ext + 3) * dn * 8 + 32 + 15) / 16 * 16;        // (any row offset + one row's 32 bytes)
+            const size_t total = (table + zero + 1023) / 1024 * 1024;
+            ok = total <= 40 * 1024 && ext == EVAL_CW_EXT && !uf3_env("UF3_EVAL_NO_CW");
+            if (ok) {
+                b->cw_lo = t0.lo[0]; b->cw_ext = ext; b->cw_dim_m = t0.dim_m; b->cw_dim_n = dn;
+                b->cw_zero = (int)table; b->cw_bytes = (int)total;
+                for (int t = 0; t < h.T; t++) { b->cw_lut_off.push_back(trios[t].lut_off); b->cw_dim_l.push_back(trios[t].dim_l); }
+            }
+        }
+        b->eval_cw_ok = ok;
+    }
     // ---- k_featurize3 (uf3_feat3.h): one window layout for all trios, centre legs alike, a W window of at most 31 positions;
     // trios with two equal neighbour species must fold symmetrically in (l, m)
     {
@@ -2167,6 +2196,31 @@ static int eval_impl(uf3_basis *b, const uf3_frames *fr, const double *d_pos, co
         if (n3) memcpy(sh.data() + n1 + n2, c3, 8 * n3);
         c->coeff_dev = nullptr;
         HIPCHK(c, hipMemcpyAsync(dc, sh.data(), 8 * sh.size(), hipMemcpyHostToDevice, st));
+        // the window table of the CW instances: only when every coefficient outside the kept-bin window of the centre legs is
+        // exactly zero (bins without a column decompress to zero: any fitted or loaded model; arbitrary grids keep the global rows)
+        c->cw_of = nullptr;
+        std::vector<double> tab;
+        if (b->eval_cw_ok && n3) {
+            const double *g3 = sh.data() + n1 + n2;
+            const int lo = b->cw_lo, ext = b->cw_ext, dm = b->cw_dim_m, dn = b->cw_dim_n;
+            tab.assign((size_t)b->cw_bytes / 8, 0.0);
+            bool zero_outside = true;
+            for (size_t t = 0; t < b->cw_lut_off.size() && zero_outside; t++) {
+                const double *g = g3 + b->cw_lut_off[t];
+                for (int l = 0; l < b->cw_dim_l[t] && zero_outside; l++)
+                    for (int mm = 0; mm < dm && zero_outside; mm++) {
+                        const bool in = l >= lo && l < lo + ext && mm >= lo && mm < lo + ext;
+                        const double *row = g + ((size_t)l * dm + mm) * dn;
+                        if (in) std::memcpy(tab.data() + ((t * ext + (l - lo)) * ext + (mm - lo)) * dn, row, 8 * (size_t)dn);
+                        else for (int q = 0; q < dn; q++) zero_outside = zero_outside && row[q] == 0.0;
+                    }
+            }
+            if (zero_outside) {
+                HIPCHK(c, c->coeff_cw.ensure((size_t)b->cw_bytes));
+                HIPCHK(c, hipMemcpyAsync(c->coeff_cw.p, tab.data(), (size_t)b->cw_bytes, hipMemcpyHostToDevice, st));
+                c->cw_of = b;
+            }
+        }
         HIPCHK(c, hipStreamSynchronize(st));
         c->coeff_dev = dc;
     }
@@ -2184,6 +2238,7 @@ static int eval_impl(uf3_basis *b, const uf3_frames *fr, const double *d_pos, co
     A.virial = d_virials ? A.e_atom + P.natoms : nullptr;
     A.nbr_f = nullptr; A.n3_need = nullptr; A.fuse_n3 = 0;
     A.halo_mark = nullptr;
+    A.c3w = nullptr; A.cw_bytes = 0; A.cw_zero = 0; A.cw_lo = 0; A.cw_ext = 0; A.lds_per_wave = 0; A.cw_recs_bytes = 0; A.cw_c2 = 0;
     // (rows of atoms that no centre of the block touches: zero.  A block of centres with the fused list build zeroes rows, list
     // counts and halo marks in ONE launch inside the loop below)
     const bool zero3 = centres && fuse && !md_step && !uf3_env("UF3_NO_HALO");
@@ -2230,8 +2285,18 @@ static int eval_impl(uf3_basis *b, const uf3_frames *fr, const double *d_pos, co
             // over the queue.  Chosen by the basis alone -- not by the capacity -- unless the longer layout does not fit at all
             const size_t lds_tab = lds_plain + 16 + EVAL_TAB_KN * sizeof(KnotRec) + (cap > EVAL_TAB_CAP ? 136 * cap + 16 : 0);
             const bool tab = two_pass && b->eval_tab_ok && (int)lds_tab <= c->lds_max && !uf3_env("UF3_EVAL_NO_TAB");
-            const size_t lds = tab ? lds_tab : lds_plain;
-            if ((int)lds > c->lds_max) return fail(c, UF3_EOVERFLOW, "3-body neighbour list does not fit in LDS");
+            // CW instances (MD route only: measured 197 against 190 M atom-steps/s there, a loss on the plain route): EVAL_CW_WAVES
+            // one-atom waves per workgroup around one copy of the window table, every knot record and the pair coefficients
+            const size_t cw_per_wave = (cap * 32 + (5 * cap + 2) * 4 + 16 + 2 * WAVE * EVAL_Q * sizeof(double) + cap * 24 + 15) / 16 * 16;
+            const size_t cw_recs = b->n_recs * sizeof(KnotRec), cw_c2b = (n2 * 8 + 15) / 16 * 16;
+            const size_t lds_cw = (size_t)b->cw_bytes + cw_recs + cw_c2b + EVAL_CW_WAVES * cw_per_wave;
+            const bool cw = tab && md_step && c->cw_of == (const void *)b && cap <= EVAL_TAB_CAP && lds_cw <= UF3_LDS_LIMIT / 2 && !uf3_env("UF3_EVAL_NO_CW");
+            const size_t lds = cw ? lds_cw : (tab ? lds_tab : lds_plain);
+            if (cw) {
+                A.c3w = c->coeff_cw.as<double>(); A.cw_bytes = b->cw_bytes; A.cw_zero = b->cw_zero; A.cw_lo = b->cw_lo; A.cw_ext = b->cw_ext;
+                A.lds_per_wave = (int)cw_per_wave; A.cw_recs_bytes = (int)cw_recs; A.cw_c2 = (int)n2;
+            }
+            if (!cw && (int)lds > c->lds_max) return fail(c, UF3_EOVERFLOW, "3-body neighbour list does not fit in LDS");
             if (two_pass) {
                 if (!md_step) {
                     HIPCHK(c, c->nbr_f.ensure(24 * (size_t)P.natoms * cap));
@@ -2254,8 +2319,20 @@ static int eval_impl(uf3_basis *b, const uf3_frames *fr, const double *d_pos, co
                     // legs from per-bond tables (one set of 3-body legs, T <= 64, short lists: the usual case)
                     const bool cap16 = cap == 16 && !uf3_env("UF3_EVAL_NO_CAP16");
                     const int inst = (A.virial ? 1 : 0) | (cap16 ? 2 : 0) | (md_step ? 4 : 0) | (tab ? 8 : 0);
+#define UF3_EVAL_CW_CASE(I) case I: {                                                                                                  \
+        static std::mutex mu; static size_t have[64] = {0};                                                                           \
+        { std::lock_guard<std::mutex> lk(mu); size_t &hv = have[c->device & 63];                                                      \
+          if (lds > hv) { HIPCHK(c, hipFuncSetAttribute((const void *)k_eval<false, ((I) & 1) != 0, ((I) & 2) ? 16 : 0, ((I) & 4) != 0, true, true>, \
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); hv = lds; } }         \
+        hipLaunchKernelGGL((k_eval<false, ((I) & 1) != 0, ((I) & 2) ? 16 : 0, ((I) & 4) != 0, true, true>), eg_cw, dim3(64 * EVAL_CW_WAVES), lds, st, A); } break;
+                    const dim3 eg_cw((unsigned)(((n_centres + EVAL_CW_WAVES - 1) / EVAL_CW_WAVES + 7) / 8 * 8));
+                    if (cw) switch (inst & 7) {
+                        UF3_EVAL_CW_CASE(4) UF3_EVAL_CW_CASE(5) UF3_EVAL_CW_CASE(6) UF3_EVAL_CW_CASE(7)
+                        default: return fail(c, UF3_EINVAL, "k_eval<CW> outside the MD route");
+                    }
+#undef UF3_EVAL_CW_CASE
 #define UF3_EVAL_CASE(I) case I: hipLaunchKernelGGL((k_eval<false, ((I) & 1) != 0, ((I) & 2) ? 16 : 0, ((I) & 4) != 0, ((I) & 8) != 0>), eg, dim3(64), lds, st, A); break;
-                    switch (inst) {
+                    else switch (inst) {
                         UF3_EVAL_CASE(0) UF3_EVAL_CASE(1) UF3_EVAL_CASE(2) UF3_EVAL_CASE(3) UF3_EVAL_CASE(4) UF3_EVAL_CASE(5)
                         UF3_EVAL_CASE(6) UF3_EVAL_CASE(7) UF3_EVAL_CASE(8) UF3_EVAL_CASE(9) UF3_EVAL_CASE(10) UF3_EVAL_CASE(11)
                         UF3_EVAL_CASE(12) UF3_EVAL_CASE(13) UF3_EVAL_CASE(14) UF3_EVAL_CASE(15)

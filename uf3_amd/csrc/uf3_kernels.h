@@ -2470,6 +2470,16 @@ struct EvalArgs {
     int *md_mark;                 // a block of centres (uf3_eval_centres on the MD route): [natoms] number of the last launch whose centres
     int md_mark_now;              // wrote into the atom's inbox; null: whole batch
     int *md_flags;                // [0] = 1: some atom moved past the hard limit (results invalid, rebuild and repeat); [1] = 1: past the soft one
+    // CW instances (k_eval<..., CW = true>, round 6): the trios' coefficients inside the kept-bin window of the centre legs,
+    // [T][ext_l][ext_m][dim_n] doubles followed by a run of zeros, copied into the workgroup's LDS (uf3_eval uploads the table when
+    // every coefficient outside the window is exactly zero -- the trimmed bins of a fitted model)
+    const double *c3w;            // device table, cw_bytes long (a multiple of 1024)
+    int cw_bytes;                 // table + zero run, bytes
+    int cw_zero;                  // byte offset of the zero run (long enough for any row offset + 32)
+    int cw_lo, cw_ext;            // first kept bin and number of kept bins of the centre legs (legs l and m alike)
+    int lds_per_wave;             // bytes of the per-wave arrays of a multi-wave workgroup
+    int cw_recs_bytes;            // all knot records of the basis (BasisDev::recs), copied behind the table: the pair splines, the
+    int cw_c2;                    // per-bond leg tables and leg n read them from LDS; then the pair coefficients c2 (cw_c2 doubles)
 };
 
 #ifndef EVAL_CGROUP
@@ -2634,6 +2644,54 @@ __device__ __forceinline__ bool trio_value_tab(const KnotRec *recs, const double
     return true;
 }
 
+// trio_value_tab over the kept-bin WINDOW of the centre legs, coefficient rows out of the workgroup's LDS (k_eval<..., CW>).  The
+// table holds, per trio, the rows of the window over ALL n bins -- [EXT][EXT][dim_n]; every coefficient outside it is exactly zero
+// (checked when the model was uploaded) -- and the per-bond leg tables are dense over the window rows (value | derivative of window
+// row w, zero where the bond's four functions do not reach): the contraction runs over EXT x EXT rows instead of the 4 x 4 of the
+// interval (9 instead of 16 at the default trims), every row at a constant offset from the lane's (trio, n interval) base -- no
+// validity logic.  The terms left out are products with exact zeros and the others keep their order: the same bits as trio_value_tab.
+//   cw: the table in LDS; t_base: byte offset of the trio's block; tl / tm: [2 * EXT] window values | derivatives of legs l / m
+template <int EXT>
+__device__ __forceinline__ bool trio_value_tab_cw(const KnotRec *recs, const unsigned char *cw, int t_base, const LegDev &l2, int dim_n,
+                                                  const double *tl, const double *tm, double rn, bool want_grad, double &val, double *grad) {
+    // (rows start at any n bin: 8-byte alignment -- ds_read2_b64; a 16-byte read at an odd double took ~60 LDS cycles per wave)
+    typedef double coeff2 __attribute__((ext_vector_type(2), aligned(8)));
+    typedef const __attribute__((address_space(3))) coeff2 *LdsPairs;
+    KnotRec kn;
+    const int in = load_interval<3>(recs, l2, rn, kn);
+    const int row_b = 8 * dim_n;                                       // bytes between consecutive rows of leg m; EXT of them per row of leg l
+    const unsigned char *base = cw + (t_base + 8 * (in - 3));
+    double vn[4], dn[4];
+    bspline4<true>(kn, rn, vn, dn);
+    double v = 0, g0 = 0, g1 = 0, g2 = 0;
+    double sa = 0, sda = 0, sma = 0;
+#pragma unroll
+    for (int a = 0; a < EXT; a++) {
+        coeff2 c01[EXT], c23[EXT];
+#pragma unroll
+        for (int b = 0; b < EXT; b++) {
+            LdsPairs q = (LdsPairs)(const coeff2 *)(base + (a * EXT + b) * row_b);
+            c01[b] = q[0]; c23[b] = q[1];
+        }
+#pragma unroll
+        for (int b = 0; b < EXT; b++) {
+            const double s = c01[b].x * vn[0] + c01[b].y * vn[1] + c23[b].x * vn[2] + c23[b].y * vn[3];
+            const double vmb = tm[b];
+            if (b == 0) { sa = vmb * s; } else sa += vmb * s;
+            if (want_grad) {
+                const double sd = c01[b].x * dn[0] + c01[b].y * dn[1] + c23[b].x * dn[2] + c23[b].y * dn[3];
+                const double dmb = tm[EXT + b];
+                if (b == 0) { sda = vmb * sd; sma = dmb * s; } else { sda += vmb * sd; sma += dmb * s; }
+            }
+        }
+        const double vla = tl[a];
+        v += vla * sa;
+        if (want_grad) { g0 += tl[EXT + a] * sa; g1 += vla * sma; g2 += vla * sda; }
+    }
+    val = v; grad[0] = g0; grad[1] = g1; grad[2] = g2;
+    return true;
+}
+
 __device__ __forceinline__ double wave_sum(double v) {
     for (int sh = 32; sh > 0; sh >>= 1) v += __shfl_xor(v, sh);
     return v;
@@ -2661,14 +2719,30 @@ __device__ __forceinline__ double wave_sum(double v) {
 #ifndef EVAL_TAB_MINW
 #define EVAL_TAB_MINW 4
 #endif
-template <bool GATHER, bool VIR, int CAP = 0, bool MD = false, bool TAB = false>
-__global__ void __launch_bounds__(64, TAB ? EVAL_TAB_MINW : EVAL_MINW)
+// (CW, round 6 -- VERDICT round 5 item 3: the coefficient rows of the triplets out of LDS.  A workgroup is EVAL_CW_WAVES one-atom
+// waves instead of one; its waves copy the window table of ALL trios (EvalArgs::c3w: 19 KB for the ternary notebook basis) and leg
+// n's knot records into LDS once, with global_load_lds behind the pair phase, and meet at ONE barrier in front of the triplet
+// loop; everything else stays per wave.  TAB instances only, lists of at most EVAL_TAB_CAP entries.)
+#ifndef EVAL_CW_WAVES
+#define EVAL_CW_WAVES 8
+#endif
+#define EVAL_CW_EXT 3       // kept bins of the centre legs the CW instances are compiled for (the default trims: 3 of 9)
+// (the per-atom syncs of the body: a workgroup barrier in the one-wave workgroups, a wave barrier in the multi-wave ones, whose
+// waves run through the body independently)
+#define EVAL_SYNC() do { if (CW) wave_sync(); else __syncthreads(); } while (0)
+template <bool GATHER, bool VIR, int CAP = 0, bool MD = false, bool TAB = false, bool CW = false>
+__global__ void __launch_bounds__(CW ? 64 * EVAL_CW_WAVES : 64, TAB ? EVAL_TAB_MINW : EVAL_MINW)
 k_eval(EvalArgs A) {
-    extern __shared__ __align__(16) unsigned char smem[];
+    static_assert(!CW || (TAB && !GATHER && MD), "the LDS tables belong to the TAB centre pass of the MD route");
+    extern __shared__ __align__(16) unsigned char smem_all[];
     const BasisDev *B = A.B;
     const int cap = CAP > 0 ? CAP : A.n3.cap;
     const KnotRec *recs_g = load_const(&B->recs);
     const int S = load_const(&B->S);
+    const int wave = CW ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
+    // (CW: [window table | zero run][every knot record of the basis][pair coefficients] shared, then the waves' own arrays)
+    const size_t cw_shared = CW ? (size_t)A.cw_bytes + A.cw_recs_bytes + (((size_t)A.cw_c2 * 8 + 15) & ~(size_t)15) : 0;
+    unsigned char *smem = smem_all + (CW ? cw_shared + (size_t)wave * A.lds_per_wave : 0);
     double *ox = (double *)smem, *oy = ox + cap, *oz = oy + cap, *orr = oz + cap;
     int *oparent = (int *)(orr + cap), *oshift = oparent + cap, *osidx = oshift + cap, *ospec = osidx + cap,
         *ooff = ospec + cap;
@@ -2681,8 +2755,26 @@ k_eval(EvalArgs A) {
     const bool fuse = !GATHER && !MD && A.fuse_n3;
     int count3 = 0;
     // (one contiguous eighth of the atoms per XCD, as in k_featurize; the grid is a multiple of 8)
-    int m = A.atom_lo + (int)((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3));
-    if (m >= A.atom_hi) return;
+    int m = A.atom_lo + (int)((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3)) * (CW ? EVAL_CW_WAVES : 1) + wave;
+    if (CW) {
+        // the workgroup's tables: 1 KB per wave-instruction straight into LDS (no registers); landed by the barrier below
+        const int n_chunks = A.cw_bytes >> 10;
+        for (int ch = wave; ch < n_chunks; ch += EVAL_CW_WAVES)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)((const char *)A.c3w + ((size_t)ch << 10) + (threadIdx.x & 63) * 16),
+                                             (__attribute__((address_space(3))) void *)(smem_all + ((size_t)ch << 10)), 16, 0, 0);
+        const int4 *src = (const int4 *)recs_g;
+        int4 *dst = (int4 *)(smem_all + A.cw_bytes);
+        for (int q = threadIdx.x; q < (A.cw_recs_bytes >> 4); q += 64 * EVAL_CW_WAVES) dst[q] = src[q];
+        double *c2d = (double *)(smem_all + A.cw_bytes + A.cw_recs_bytes);
+        for (int q = threadIdx.x; q < A.cw_c2; q += 64 * EVAL_CW_WAVES) c2d[q] = A.c2[q];
+    }
+    // (CW: the knot records and pair coefficients the splines below read -- the workgroup's LDS copies once the barrier is passed)
+    const KnotRec *recs_l = CW ? (const KnotRec *)(smem_all + A.cw_bytes) : recs_g;
+    const double *c2_l = CW ? (const double *)(smem_all + A.cw_bytes + A.cw_recs_bytes) : A.c2;
+    if (m >= A.atom_hi) {
+        if (CW) __syncthreads();              // (the workgroup's one barrier: every wave arrives once)
+        return;
+    }
     int lane = lane_id();
     // (MD route: what belongs to the atom is the same for all lanes -- through scalar loads, the frame's cell included: vector
     // loads of them were a chain of dependent round trips in front of the list filter, and the cell sat in 18 vector registers)
@@ -2701,7 +2793,8 @@ k_eval(EvalArgs A) {
     double e = 0.0, fx = 0.0, fy = 0.0, fz = 0.0;
     // TAB instances: what the triplet loop needs of the basis -- the legs of trio 0, the species -> trio and trio -> grid offset
     // tables (one register each), leg n's knot records into LDS -- is requested HERE, ahead of the pair phase that hides it
-    KnotRec *kn_lds = (KnotRec *)(smem + ((((unsigned char *)(ushift + cap) - smem) + 15) & ~(size_t)15));
+    KnotRec *kn_lds = CW ? (KnotRec *)recs_l + (load_const(&load_const(&B->trios)->leg[2].rec_off) + 3)
+                         : (KnotRec *)(smem + ((((unsigned char *)(ushift + cap) - smem) + 15) & ~(size_t)15));
     int trio_tab = -1, lut_tab = 0;
     if (TAB && !GATHER) {
         // (the legs' descriptors themselves are scalar loads, read again where they are used: held from here they cost ~40 of
@@ -2713,9 +2806,11 @@ k_eval(EvalArgs A) {
         if (lane < load_const(&B->T)) lut_tab = ((GlobalTrio)t0)[lane].lut_off;
         // leg n's knot records (intervals 3 .. nk - 5) into LDS: 96 bytes per triplet less through the vector memory path,
         // which bounds this kernel (the coefficient rows stay there: 512 bytes per triplet)
-        const int4 *src = (const int4 *)(recs_g + n_rec_off + 3);
-        int4 *dst = (int4 *)kn_lds;
-        for (int q = lane; q < (n_nk - 7) * 6; q += WAVE) dst[q] = src[q];
+        if (!CW) {
+            const int4 *src = (const int4 *)(recs_g + n_rec_off + 3);
+            int4 *dst = (int4 *)kn_lds;
+            for (int q = lane; q < (n_nk - 7) * 6; q += WAVE) dst[q] = src[q];
+        }
     }
     PhaseClock pce;                   // (-DUF3_PHASE_TIMING builds only: tools/experiments/eval_phase.py)
     if (lane == 0) e = A.c1[sm];
@@ -2733,10 +2828,10 @@ k_eval(EvalArgs A) {
             KnotRec kr;
             const LegDev leg = ev_pairs_uniform ? load_const(&B->pairs[0].leg) : B->pairs[B->pair_of[pair_idx]].leg;
             const int col = B->pair_col[pair_idx];
-            int i = load_interval<1>(recs_g, leg, d, kr);
+            int i = load_interval<CW ? 3 : 1>(recs_l, leg, d, kr);
             double v[4], dv[4];
             bspline4<true>(kr, d, v, dv);
-            const double *cf = A.c2 + (col - S) + (i - 3);
+            const double *cf = c2_l + (col - S) + (i - 3);
             double phi = 0, dphi = 0;
             for (int q = 0; q < 4; q++) { phi += cf[q] * v[q]; dphi += cf[q] * dv[q]; }
             e += phi;
@@ -2802,6 +2897,8 @@ k_eval(EvalArgs A) {
             queued += __popcll(mask);
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
+            // (CW: the workgroup's ONE barrier, behind the first batch's two round trips -- the tables have landed long since)
+            if (CW && q0 == 0) __syncthreads();
             if (queued >= WAVE) {
                 drain(WAVE);
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -2864,6 +2961,7 @@ k_eval(EvalArgs A) {
         }
     });
     pce.lap(9);                       // (MD route: the list filter; else the candidate walk with its full pair batches)
+    if (CW && load_const(A.sup_cnt + m) <= 0) __syncthreads();       // (an atom without candidates never entered the loop above)
     drain(queued);
     pce.lap(10);
     if (load_const(&B->T) > 0) {
@@ -2872,7 +2970,7 @@ k_eval(EvalArgs A) {
         if (fuse) {
             // the list of this atom from the walk above, rank-sorted by (species, supercell index) like k_build_n3's:
             // into LDS for the loops below and into the batch's list array for k_eval_collect
-            __syncthreads();
+            EVAL_SYNC();
             if (count3 > cap) { if (lane == 0) atomicMax(A.n3_need, count3); count3 = cap; }
             n = count3;
             if (lane == 0) A.n3.cnt[m] = n;
@@ -2890,7 +2988,7 @@ k_eval(EvalArgs A) {
             }
         } else if (MD) {
             // (written in place by the filter above, already in order)
-            __syncthreads();
+            EVAL_SYNC();
             if (count3 > cap) { if (lane == 0) atomicMax(A.n3_need, count3); count3 = cap; }
             n = count3;
             if (lane == 0) A.n3.cnt[m] = n;
@@ -2903,7 +3001,7 @@ k_eval(EvalArgs A) {
                 if (!GATHER) { gx[q] = 0.0; gy[q] = 0.0; gz[q] = 0.0; }
             }
         }
-        __syncthreads();
+        EVAL_SYNC();
         pce.lap(11);
         int n_pairs = n * (n - 1) / 2;
         // Centre pass, one set of 3-body legs (trio_value_tab): the centre legs of every bond once, into LDS (over the queue of
@@ -2935,15 +3033,23 @@ k_eval(EvalArgs A) {
                     double v[4] = {0, 0, 0, 0}, d[4] = {0, 0, 0, 0};
                     if ((r > lg.t0) & (r < lg.tlast)) {
                         KnotRec k;
-                        i = load_interval<1>(recs_g, lg, r, k);
+                        i = load_interval<CW ? 3 : 1>(recs_l, lg, r, k);
                         bspline4<true>(k, r, v, d);
                     }
                     double *dst = (which ? tmv : tlv) + 8 * q;
+                    if (CW) {
+                        // dense over the window rows (EVAL_CW_EXT of them): value | derivative of row w, zero where the bond's four
+                        // functions (i - 3 .. i) do not reach
+                        for (int u = 0; u < 2 * EVAL_CW_EXT; u++) dst[u] = 0.0;
+                        const int w0 = i - 3 - A.cw_lo;
+                        for (int u = 0; u < 4; u++)
+                            if (i >= 0 && (unsigned)(w0 + u) < (unsigned)EVAL_CW_EXT) { dst[w0 + u] = v[u]; dst[EVAL_CW_EXT + w0 + u] = d[u]; }
+                    } else
                     for (int u = 0; u < 4; u++) { dst[u] = v[u]; dst[4 + u] = d[u]; }
                     (which ? tmi : tli)[q] = i;
                 }
             }
-            __syncthreads();
+            EVAL_SYNC();
         }
         pce.lap(14);
 #pragma unroll 1
@@ -2967,6 +3073,11 @@ k_eval(EvalArgs A) {
                 const int lut_off = __shfl(lut_tab, max(trio, 0));
                 const int il = tli[aa], im = tmi[bb];
                 if (!(act & (trio >= 0) & (il >= 0) & (im >= 0) & (rn > leg_n.t0) & (rn < leg_n.tlast))) continue;
+                if (CW) {
+                    (void)lut_off;
+                    trio_value_tab_cw<EVAL_CW_EXT>(kn_lds, smem_all, max(trio, 0) * (EVAL_CW_EXT * EVAL_CW_EXT * tab_dim_n * 8), leg_n_lds, tab_dim_n,
+                                                   tlv + 8 * aa, tmv + 8 * bb, rn, want_f || want_v, val, gr);
+                } else
                 trio_value_tab<3>(kn_lds, A.c3, lut_off, leg_n_lds, tab_dim_m, tab_dim_n, il, im, tlv + 8 * aa, tmv + 8 * bb, rn,
                                want_f || want_v, val, gr);
             } else if (!TAB) {
@@ -2998,7 +3109,7 @@ k_eval(EvalArgs A) {
         pce.lap(12);
         if (want_f && !GATHER && MD) {
             // what this centre's triplets put on each neighbour, straight into the neighbour's inbox at ITS list position of this atom
-            __syncthreads();
+            EVAL_SYNC();
             for (int q = lane; q < n; q += WAVE) {
                 const int rev1 = ooff[q];
                 if (rev1 > 0) {
@@ -3010,7 +3121,7 @@ k_eval(EvalArgs A) {
             }
         }
         if (want_f && !GATHER && !MD) {
-            __syncthreads();
+            EVAL_SYNC();
             for (int q = lane; q < n; q += WAVE) {
                 double *dst = A.nbr_f + 3 * (base + q);
                 dst[0] = gx[q]; dst[1] = gy[q]; dst[2] = gz[q];
@@ -3026,7 +3137,7 @@ k_eval(EvalArgs A) {
                 total += __builtin_amdgcn_readlane(incl, WAVE - 1);
             }
             if (lane == 0) ooff[n] = total;
-            __syncthreads();
+            EVAL_SYNC();
             int m_local = m - g.atom_lo;
             for (int p = lane; p < total; p += WAVE) {
                 int lo = 0, hi = n - 1;
