@@ -2287,10 +2287,11 @@ static int eval_impl(uf3_basis *b, const uf3_frames *fr, const double *d_pos, co
             const bool tab = two_pass && b->eval_tab_ok && (int)lds_tab <= c->lds_max && !uf3_env("UF3_EVAL_NO_TAB");
             // CW instances (MD route only: measured 197 against 190 M atom-steps/s there, a loss on the plain route): EVAL_CW_WAVES
             // one-atom waves per workgroup around one copy of the window table, every knot record and the pair coefficients
-            const size_t cw_per_wave = (cap * 32 + (5 * cap + 2) * 4 + 16 + 2 * WAVE * EVAL_Q * sizeof(double) + cap * 24 + 15) / 16 * 16;
+            const size_t cw_per_wave = ((md_step ? lds_plain - cap * 48 : lds_plain) + 15) / 16 * 16;      // (the walk-order arrays: fused builds only)
             const size_t cw_recs = b->n_recs * sizeof(KnotRec), cw_c2b = (n2 * 8 + 15) / 16 * 16;
             const size_t lds_cw = (size_t)b->cw_bytes + cw_recs + cw_c2b + EVAL_CW_WAVES * cw_per_wave;
-            const bool cw = tab && md_step && c->cw_of == (const void *)b && cap <= EVAL_TAB_CAP && lds_cw <= UF3_LDS_LIMIT / 2 && !uf3_env("UF3_EVAL_NO_CW");
+            const bool cw = tab && md_step && c->cw_of == (const void *)b && cap <= 16 &&      /* (lists of <= 16 entries: the force gather's stage, k_eval) */
+                             lds_cw <= UF3_LDS_LIMIT / (EVAL_CW_WAVES > 8 ? 1 : 2) && !uf3_env("UF3_EVAL_NO_CW");
             const size_t lds = cw ? lds_cw : (tab ? lds_tab : lds_plain);
             if (cw) {
                 A.c3w = c->coeff_cw.as<double>(); A.cw_bytes = b->cw_bytes; A.cw_zero = b->cw_zero; A.cw_lo = b->cw_lo; A.cw_ext = b->cw_ext;
@@ -2327,6 +2328,8 @@ static int eval_impl(uf3_basis *b, const uf3_frames *fr, const double *d_pos, co
         hipLaunchKernelGGL((k_eval<false, ((I) & 1) != 0, ((I) & 2) ? 16 : 0, ((I) & 4) != 0, true, true>), eg_cw, dim3(64 * EVAL_CW_WAVES), lds, st, A); } break;
                     const dim3 eg_cw((unsigned)(((n_centres + EVAL_CW_WAVES - 1) / EVAL_CW_WAVES + 7) / 8 * 8));
                     if (cw) switch (inst & 7) {
+                        // (MD route only: on the rebuild-everything route the same instances measured 149.3 against 147.2 M atom-steps/s
+                        // at 50 k atoms and 47.7 against 45.0 us on a 128-atom call -- nothing; not instantiated)
                         UF3_EVAL_CW_CASE(4) UF3_EVAL_CW_CASE(5) UF3_EVAL_CW_CASE(6) UF3_EVAL_CW_CASE(7)
                         default: return fail(c, UF3_EINVAL, "k_eval<CW> outside the MD route");
                     }

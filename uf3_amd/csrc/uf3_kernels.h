@@ -2733,7 +2733,7 @@ __device__ __forceinline__ double wave_sum(double v) {
 template <bool GATHER, bool VIR, int CAP = 0, bool MD = false, bool TAB = false, bool CW = false>
 __global__ void __launch_bounds__(CW ? 64 * EVAL_CW_WAVES : 64, TAB ? EVAL_TAB_MINW : EVAL_MINW)
 k_eval(EvalArgs A) {
-    static_assert(!CW || (TAB && !GATHER && MD), "the LDS tables belong to the TAB centre pass of the MD route");
+    static_assert(!CW || (TAB && !GATHER), "the LDS tables belong to the TAB centre pass");
     extern __shared__ __align__(16) unsigned char smem_all[];
     const BasisDev *B = A.B;
     const int cap = CAP > 0 ? CAP : A.n3.cap;
@@ -2912,7 +2912,8 @@ k_eval(EvalArgs A) {
                 __builtin_amdgcn_wave_barrier();
             }
         }
-    } else
+    } else {
+    if (CW) __syncthreads();          // (the walk drains its first batch of pair splines from the LDS copies: the workgroup's one barrier)
     for_each_candidate(g, A.cl, m, [&](bool ok, const SlotRec &sr, int sj, int s0, int s1, int s2) {
         double dx = 0, dy = 0, dz = 0, d = 0;
         bool ok3 = false;
@@ -2960,8 +2961,9 @@ k_eval(EvalArgs A) {
             __builtin_amdgcn_wave_barrier();
         }
     });
+    }
     pce.lap(9);                       // (MD route: the list filter; else the candidate walk with its full pair batches)
-    if (CW && load_const(A.sup_cnt + m) <= 0) __syncthreads();       // (an atom without candidates never entered the loop above)
+    if (CW && MD && load_const(A.sup_cnt + m) <= 0) __syncthreads();       // (an atom without candidates never entered the loop above)
     drain(queued);
     pce.lap(10);
     if (load_const(&B->T) > 0) {
@@ -3011,7 +3013,7 @@ k_eval(EvalArgs A) {
         // (the per-bond tables over the queue of the pair walk, which is done with; lists longer than EVAL_TAB_CAP: behind the knot
         // records -- the choice of the instance must not depend on the capacity, or a context's first call, at the estimated
         // capacity, would differ from the later ones in the last bit)
-        const int ts = cap <= EVAL_TAB_CAP ? EVAL_TAB_CAP : cap;
+        const int ts = CW ? cap : (cap <= EVAL_TAB_CAP ? EVAL_TAB_CAP : cap);      // (CW: the room behind the tables is the stage of the force gather)
         double *tlv = cap <= EVAL_TAB_CAP ? queue : (double *)(kn_lds + EVAL_TAB_KN), *tmv = tlv;
         int *tli = (int *)(tlv + 16 * ts), *tmi = tli;
         LegDev leg_n, leg_n_lds;
@@ -3052,6 +3054,10 @@ k_eval(EvalArgs A) {
             EVAL_SYNC();
         }
         pce.lap(14);
+        // (CW: the stage of the force gather behind the per-bond tables -- 6 x 64 doubles, into the room of gx / gy / gz, which this
+        // route does not use: lists of at most 16 entries, see the host's LDS budget -- and entry q's force in lane q)
+        double *fstage = (double *)(((size_t)(tli + 2 * ts) + 15) & ~(size_t)15);
+        double ex_f[3] = {0.0, 0.0, 0.0};
 #pragma unroll 1
         for (int p0 = 0; p0 < n_pairs; p0 += WAVE) {      // (not unrolled: two triplets' loads in flight per lane do not fit the registers)
             const bool act = p0 + lane < n_pairs;
@@ -3063,27 +3069,32 @@ k_eval(EvalArgs A) {
             int aa = p - bb * (bb - 1) / 2;
             double rl = orr[aa], rm = orr[bb];
             double rn = norm3_leg(ox[bb] - ox[aa], oy[bb] - oy[aa], oz[bb] - oz[aa]);
-            double val, gr[3];
+            double val = 0.0, gr[3] = {0.0, 0.0, 0.0};
 #if defined(UF3_ABLATE_EVAL) && UF3_ABLATE_EVAL == 1
             if (rl > 0) continue;           // (experiment: no triplet values)
 #endif
+            bool good;
             if (TAB) {
                 // (the shuffles in uniform control flow: every lane of the tables takes part)
                 const int trio = __shfl(trio_tab, ospec[aa] * UF3_MAX_SPECIES + ospec[bb]);
                 const int lut_off = __shfl(lut_tab, max(trio, 0));
                 const int il = tli[aa], im = tmi[bb];
-                if (!(act & (trio >= 0) & (il >= 0) & (im >= 0) & (rn > leg_n.t0) & (rn < leg_n.tlast))) continue;
+                good = act & (trio >= 0) & (il >= 0) & (im >= 0) & (rn > leg_n.t0) & (rn < leg_n.tlast);
+                if (!CW && !good) continue;
                 if (CW) {
                     (void)lut_off;
-                    trio_value_tab_cw<EVAL_CW_EXT>(kn_lds, smem_all, max(trio, 0) * (EVAL_CW_EXT * EVAL_CW_EXT * tab_dim_n * 8), leg_n_lds, tab_dim_n,
-                                                   tlv + 8 * aa, tmv + 8 * bb, rn, want_f || want_v, val, gr);
+                    if (good)
+                        trio_value_tab_cw<EVAL_CW_EXT>(kn_lds, smem_all, max(trio, 0) * (EVAL_CW_EXT * EVAL_CW_EXT * tab_dim_n * 8), leg_n_lds, tab_dim_n,
+                                                       tlv + 8 * aa, tmv + 8 * bb, rn, want_f || want_v, val, gr);
                 } else
                 trio_value_tab<3>(kn_lds, A.c3, lut_off, leg_n_lds, tab_dim_m, tab_dim_n, il, im, tlv + 8 * aa, tmv + 8 * bb, rn,
                                want_f || want_v, val, gr);
-            } else if (!TAB) {
+            } else {
                 int trio = B->trio_of[(sm * UF3_MAX_SPECIES + ospec[aa]) * UF3_MAX_SPECIES + ospec[bb]];
-                if (!act || !trio_value(B, A.c3, trio, rl, rm, rn, want_f || want_v, val, gr)) continue;
+                good = act && trio_value(B, A.c3, trio, rl, rm, rn, want_f || want_v, val, gr);
+                if (!good) continue;
             }
+            // (CW: a lane without a triplet carries zeros through the force arithmetic below -- every lane takes part in the gather)
             e += val;
             if (want_f) {   // F_m = -dV/dR_m = gl * u_ij + gm * u_ik
                 const double a = gr[0] * fast_rcp(rl), b = gr[1] * fast_rcp(rm);
@@ -3091,8 +3102,37 @@ k_eval(EvalArgs A) {
                 if (!GATHER) {   // F_j = -gl u_ij + gn (R_k - R_j) / rn,  F_k = -gm u_ik - gn (R_k - R_j) / rn
                     const double cc = gr[2] * fast_rcp(rn);
                     const double cx = cc * (ox[bb] - ox[aa]), cy = cc * (oy[bb] - oy[aa]), cz = cc * (oz[bb] - oz[aa]);
+                    if (CW) {
+                        // Six ds_add_f64 per lane onto 14 addresses were 15 % of the kernel (34 of 230 us at 50 k atoms: a wave's adds
+                        // to one address serialise).  Instead: every lane leaves its two forces in a stage (six conflict-free 8-byte
+                        // stores), and lane q < n gathers entry q's share of this trip -- pair (q, b) sits at lane
+                        // hi (hi - 1) / 2 + lo - p0 -- into registers it keeps across the trips, in a fixed order.
+                        double *st = fstage + lane;
+                        st[0] = cx - a * ox[aa]; st[64] = cy - a * oy[aa]; st[128] = cz - a * oz[aa];
+                        st[192] = -cx - b * ox[bb]; st[256] = -cy - b * oy[bb]; st[320] = -cz - b * oz[bb];
+                        wave_sync();
+                        {
+                            // lanes (entry q = lane / 4, part = lane % 4): the partners o = part, part + 4, ... of entry q, four loads in flight
+                            const int gq = lane >> 2, gpart = lane & 3;
+                            double t0[4], t1[4], t2[4];
+#pragma unroll
+                            for (int k = 0; k < 4; k++) {
+                                const int o = gpart + 4 * k;
+                                const int lo = min(gq, o), hi = max(gq, o);
+                                const int rel = hi * (hi - 1) / 2 + lo - p0;
+                                const bool take = (gq < n) & (o < n) & (o != gq) & ((unsigned)rel < (unsigned)WAVE);
+                                const double *src = fstage + (take ? rel + (gq == lo ? 0 : 192) : 0);
+                                t0[k] = src[0]; t1[k] = src[64]; t2[k] = src[128];
+                                if (!take) { t0[k] = 0.0; t1[k] = 0.0; t2[k] = 0.0; }
+                            }
+#pragma unroll
+                            for (int k = 0; k < 4; k++) { ex_f[0] += t0[k]; ex_f[1] += t1[k]; ex_f[2] += t2[k]; }
+                        }
+                        wave_sync();
+                    } else {
                     lds_add(gx + aa, cx - a * ox[aa]); lds_add(gy + aa, cy - a * oy[aa]); lds_add(gz + aa, cz - a * oz[aa]);
                     lds_add(gx + bb, -cx - b * ox[bb]); lds_add(gy + bb, -cy - b * oy[bb]); lds_add(gz + bb, -cz - b * oz[bb]);
+                    }
                 }
             }
             if (want_v) {   // each triplet once (at its centre): sum over legs of dV/dr * r (x) r / r
@@ -3110,11 +3150,15 @@ k_eval(EvalArgs A) {
         if (want_f && !GATHER && MD) {
             // what this centre's triplets put on each neighbour, straight into the neighbour's inbox at ITS list position of this atom
             EVAL_SYNC();
-            for (int q = lane; q < n; q += WAVE) {
+            if (CW) {
+#pragma unroll
+                for (int u = 0; u < 3; u++) { ex_f[u] += __shfl_xor(ex_f[u], 1); ex_f[u] += __shfl_xor(ex_f[u], 2); }
+            }
+            for (int q = CW ? (lane >> 2) : lane; q < n; q += WAVE) {
                 const int rev1 = ooff[q];
-                if (rev1 > 0) {
+                if (rev1 > 0 && (!CW || (lane & 3) == 0)) {
                     typedef double inbox4 __attribute__((ext_vector_type(4)));
-                    const inbox4 v = {gx[q], gy[q], gz[q], A.md_stamp};
+                    const inbox4 v = {CW ? ex_f[0] : gx[q], CW ? ex_f[1] : gy[q], CW ? ex_f[2] : gz[q], A.md_stamp};      // (CW: q == lane / 4)
                     *(inbox4 *)(A.md_inbox + 4 * ((size_t)oparent[q] * A.sup_cap + (rev1 - 1))) = v;
                     if (A.md_mark) A.md_mark[oparent[q]] = A.md_mark_now;
                 }
