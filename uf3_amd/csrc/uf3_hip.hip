@@ -2328,8 +2328,8 @@ static int eval_impl(uf3_basis *b, const uf3_frames *fr, const double *d_pos, co
         hipLaunchKernelGGL((k_eval<false, ((I) & 1) != 0, ((I) & 2) ? 16 : 0, ((I) & 4) != 0, true, true>), eg_cw, dim3(64 * EVAL_CW_WAVES), lds, st, A); } break;
                     const dim3 eg_cw((unsigned)(((n_centres + EVAL_CW_WAVES - 1) / EVAL_CW_WAVES + 7) / 8 * 8));
                     if (cw) switch (inst & 7) {
-                        // (MD route only: on the rebuild-everything route the same instances measured 149.3 against 147.2 M atom-steps/s
-                        // at 50 k atoms and 47.7 against 45.0 us on a 128-atom call -- nothing; not instantiated)
+                        // (MD route only: with the walk-order arrays of the fused list build the waves' own LDS is 7.1 KB each, and two
+                        // 8-wave workgroups + two copies of the tables do not fit a CU -- 168 of 160 KB; not instantiated)
                         UF3_EVAL_CW_CASE(4) UF3_EVAL_CW_CASE(5) UF3_EVAL_CW_CASE(6) UF3_EVAL_CW_CASE(7)
                         default: return fail(c, UF3_EINVAL, "k_eval<CW> outside the MD route");
                     }
