@@ -312,7 +312,7 @@ def test_config4_fit_in_chunks_10k_atom_tungsten_frames():
     model = ls.WeightedLinearModel(basis, regularizer=reg)
     acc = pipeline.DeviceFitAccumulator(model, fz, max_atoms_per_chunk=250000)
     acc.add_frames(frames, energies, forces)
-    assert acc.n_chunks == 5                 # (chunks grow from an eighth of the limit: 3 + 6 + 12 + 25 + 20 frames)
+    assert acc.n_chunks == 5                 # (chunks grow from an eighth of the limit, the rest is spread evenly: 3 + 6 + 12 + 23 + 22 frames)
     pieces = acc.pieces()
     model.fit_from_pieces(pieces, weight=0.3)
     n = x_e[:, :1].sum(axis=1)
