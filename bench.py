@@ -268,7 +268,7 @@ def main(argv=None):
         traffic, traffic_source = None, None
         if world == 1 and not fit and not args.no_traffic:
             traffic, traffic_source = measure_traffic(B, args.workload, args.atoms, args.row_ld)
-        for name in (() if traffic is not None else ("round4_hbm_counters.json", "round3_hbm_counters.json", "round2_hbm_counters.json", "round1_hbm_counters.json")):
+        for name in (() if traffic is not None else ("round6_hbm_counters.json", "round5_hbm_counters.json", "round4_hbm_counters.json", "round3_hbm_counters.json")):
             try:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
                 if pmc["workload"] == dict(atoms_per_frame=n_atoms, n_feat=F, frames_per_step=B):
@@ -544,7 +544,7 @@ def _executed_fp64(n_atoms, n_feat, frames_per_step, launch_ms):
     3.1 kflop; the bond-factorised kernel issues about half of that): wave-instruction counts of the committed PMC pass
     (profiles/round*_fp64_counters.json, tools/profile_round.sh) over THIS run's launch time; null when no pass matches
     the workload."""
-    for name in ("round5_fp64_counters.json",):
+    for name in ("round6_fp64_counters.json", "round5_fp64_counters.json"):
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
             if pmc["workload"] == dict(atoms_per_frame=n_atoms, n_feat=n_feat, frames_per_step=frames_per_step):
