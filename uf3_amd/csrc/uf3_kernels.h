@@ -3096,7 +3096,7 @@ k_eval(EvalArgs A) {
             }
             // (CW: a lane without a triplet carries zeros through the force arithmetic below -- every lane takes part in the gather)
             e += val;
-            if (want_f) {   // F_m = -dV/dR_m = gl * u_ij + gm * u_ik
+            if (want_f || (CW && want_v)) {   // F_m = -dV/dR_m = gl * u_ij + gm * u_ik
                 const double a = gr[0] * fast_rcp(rl), b = gr[1] * fast_rcp(rm);
                 fx += a * ox[aa] + b * ox[bb]; fy += a * oy[aa] + b * oy[bb]; fz += a * oz[aa] + b * oz[bb];
                 if (!GATHER) {   // F_j = -gl u_ij + gn (R_k - R_j) / rn,  F_k = -gm u_ik - gn (R_k - R_j) / rn
@@ -3135,7 +3135,9 @@ k_eval(EvalArgs A) {
                     }
                 }
             }
-            if (want_v) {   // each triplet once (at its centre): sum over legs of dV/dr * r (x) r / r
+            // (CW: the triplets' strain derivative comes out of the gathered forces behind the loop -- with the centre at the origin a
+            // triplet's sum over legs of dV/dr r (x) r / r is -(o_a (x) F_a + o_b (x) F_b) -- instead of 30 multiply-adds per triplet)
+            if (want_v && !CW) {   // each triplet once (at its centre): sum over legs of dV/dr * r (x) r / r
                 double ta = gr[0] * fast_rcp(rl), tb = gr[1] * fast_rcp(rm), tc = gr[2] * fast_rcp(rn);
                 double cx = ox[bb] - ox[aa], cy = oy[bb] - oy[aa], cz = oz[bb] - oz[aa];
                 vir[0] += ta * ox[aa] * ox[aa] + tb * ox[bb] * ox[bb] + tc * cx * cx;
@@ -3147,13 +3149,20 @@ k_eval(EvalArgs A) {
             }
         }
         pce.lap(12);
+        if (CW && (want_f || want_v)) {
+            EVAL_SYNC();
+#pragma unroll
+            for (int u = 0; u < 3; u++) { ex_f[u] += __shfl_xor(ex_f[u], 1); ex_f[u] += __shfl_xor(ex_f[u], 2); }
+            if (want_v && (lane & 3) == 0 && (lane >> 2) < n) {
+                const int q = lane >> 2;
+                const double qx = ox[q], qy = oy[q], qz = oz[q];
+                vir[0] -= qx * ex_f[0]; vir[1] -= qy * ex_f[1]; vir[2] -= qz * ex_f[2];
+                vir[3] -= 0.5 * (qy * ex_f[2] + qz * ex_f[1]); vir[4] -= 0.5 * (qx * ex_f[2] + qz * ex_f[0]); vir[5] -= 0.5 * (qx * ex_f[1] + qy * ex_f[0]);
+            }
+        }
         if (want_f && !GATHER && MD) {
             // what this centre's triplets put on each neighbour, straight into the neighbour's inbox at ITS list position of this atom
-            EVAL_SYNC();
-            if (CW) {
-#pragma unroll
-                for (int u = 0; u < 3; u++) { ex_f[u] += __shfl_xor(ex_f[u], 1); ex_f[u] += __shfl_xor(ex_f[u], 2); }
-            }
+            if (!CW) EVAL_SYNC();
             for (int q = CW ? (lane >> 2) : lane; q < n; q += WAVE) {
                 const int rev1 = ooff[q];
                 if (rev1 > 0 && (!CW || (lane & 3) == 0)) {
