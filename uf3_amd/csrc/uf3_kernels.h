@@ -2692,9 +2692,33 @@ __device__ __forceinline__ bool trio_value_tab_cw(const KnotRec *recs, const uns
     return true;
 }
 
+// Wave-wide sum through DPP (round 6): __shfl_xor on a double is two ds_bpermute_b32 through the LDS crossbar per step -- twelve LDS
+// instructions per sum, ten sums at the end of every k_eval wave -- where the data-parallel primitives move registers directly.
+// quad_perm [1,0,3,2] and [2,3,0,1], row_half_mirror, row_mirror: every lane of a row of 16 holds the row's sum; row_bcast:15 into
+// rows 1 and 3, row_bcast:31 into rows 2 and 3: lane 63 holds the wave's sum, returned to every lane.  A fixed tree: deterministic
+// (tools/experiments/dpp_sum_test.hip checks it against a serial sum).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_take(double v) {
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const int l2 = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, false);
+    const int h2 = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, false);
+    return __hiloint2double(h2, l2);
+}
 __device__ __forceinline__ double wave_sum(double v) {
-    for (int sh = 32; sh > 0; sh >>= 1) v += __shfl_xor(v, sh);
-    return v;
+    v += dpp_take<0xB1, 0xf>(v);
+    v += dpp_take<0x4E, 0xf>(v);
+    v += dpp_take<0x141, 0xf>(v);
+    v += dpp_take<0x140, 0xf>(v);
+    v += dpp_take<0x142, 0xa>(v);
+    v += dpp_take<0x143, 0xc>(v);
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
+}
+// the sums of three values over each aligned group of 16 lanes (a DPP row), in every lane of the group
+__device__ __forceinline__ void row16_sum3(double &a, double &b, double &c) {
+    a += dpp_take<0xB1, 0xf>(a); b += dpp_take<0xB1, 0xf>(b); c += dpp_take<0xB1, 0xf>(c);
+    a += dpp_take<0x4E, 0xf>(a); b += dpp_take<0x4E, 0xf>(b); c += dpp_take<0x4E, 0xf>(c);
+    a += dpp_take<0x141, 0xf>(a); b += dpp_take<0x141, 0xf>(b); c += dpp_take<0x141, 0xf>(c);
+    a += dpp_take<0x140, 0xf>(a); b += dpp_take<0x140, 0xf>(b); c += dpp_take<0x140, 0xf>(c);
 }
 
 #define EVAL_Q 5          // doubles per queued bond of the evaluator
@@ -3152,7 +3176,7 @@ k_eval(EvalArgs A) {
         if (CW && (want_f || want_v)) {
             EVAL_SYNC();
 #pragma unroll
-            for (int u = 0; u < 3; u++) { ex_f[u] += __shfl_xor(ex_f[u], 1); ex_f[u] += __shfl_xor(ex_f[u], 2); }
+            for (int u = 0; u < 3; u++) { ex_f[u] += dpp_take<0xB1, 0xf>(ex_f[u]); ex_f[u] += dpp_take<0x4E, 0xf>(ex_f[u]); }
             if (want_v && (lane & 3) == 0 && (lane >> 2) < n) {
                 const int q = lane >> 2;
                 const double qx = ox[q], qy = oy[q], qz = oz[q];
@@ -3266,7 +3290,7 @@ __device__ __forceinline__ void eval_collect_atom(const EvalArgs &A, int m, int 
             sx += f[0]; sy += f[1]; sz += f[2];
         }
     }
-    for (int sh = 8; sh > 0; sh >>= 1) { sx += __shfl_xor(sx, sh, 16); sy += __shfl_xor(sy, sh, 16); sz += __shfl_xor(sz, sh, 16); }
+    row16_sum3(sx, sy, sz);
 }
 
 __global__ void __launch_bounds__(256)
@@ -3312,7 +3336,7 @@ k_eval_collect_md_halo(EvalArgs A) {
         const inbox4 v = *(const inbox4 *)(A.md_inbox + 4 * ((size_t)m * A.sup_cap + q));
         if (v[3] == A.md_stamp) { sx += v[0]; sy += v[1]; sz += v[2]; }
     }
-    for (int sh = 8; sh > 0; sh >>= 1) { sx += __shfl_xor(sx, sh, 16); sy += __shfl_xor(sy, sh, 16); sz += __shfl_xor(sz, sh, 16); }
+    row16_sum3(sx, sy, sz);
     if (sub == 0) { double *f = A.forces + 3 * (size_t)m; f[0] += sx; f[1] += sy; f[2] += sz; }
 }
 
@@ -3329,7 +3353,7 @@ k_eval_collect_md(EvalArgs A) {
         const inbox4 v = *(const inbox4 *)(A.md_inbox + 4 * ((size_t)m * A.sup_cap + q));
         if (v[3] == A.md_stamp) { sx += v[0]; sy += v[1]; sz += v[2]; }
     }
-    for (int sh = 8; sh > 0; sh >>= 1) { sx += __shfl_xor(sx, sh, 16); sy += __shfl_xor(sy, sh, 16); sz += __shfl_xor(sz, sh, 16); }
+    row16_sum3(sx, sy, sz);
     if (sub == 0) { double *f = A.forces + 3 * (size_t)m; f[0] += sx; f[1] += sy; f[2] += sz; }
 }
 
