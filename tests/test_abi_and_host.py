@@ -26,6 +26,27 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), name
 
 
+def test_binary_carries_the_hash_of_the_sources_it_was_built_from():
+    """uf3_build_id(): the first 16 hex digits of the sha256 over uf3_hip.hip + headers the binary was compiled from (the Makefile
+    passes it in).  After __graft_entry__.build() it is the hash of the tree's sources -- a pushed .so that no longer matches its
+    sources cannot pass for a build of them."""
+    want = _lib.source_build_id()
+    assert re.fullmatch(r"[0-9a-f]{16}", want)
+    import __graft_entry__ as g
+    so = os.path.join(ROOT, "uf3_amd", "csrc", "libuf3hip.so")
+    have = g._binary_build_id(so)
+    assert have == _lib.build_id()
+    assert have == want, f"libuf3hip.so was built from other sources ({have}) than the tree holds ({want}): run __graft_entry__.build()"
+    # a changed source changes the id
+    import hashlib
+    h = hashlib.sha256()
+    for name in _lib.SOURCES:
+        h.update(open(os.path.join(ROOT, "uf3_amd", "csrc", name), "rb").read())
+    assert h.hexdigest()[:16] == want
+    h.update(b" ")
+    assert h.hexdigest()[:16] != want
+
+
 def test_no_gpu_means_loud_failure():
     import torch
     if torch.cuda.is_available():
