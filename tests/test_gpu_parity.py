@@ -2360,3 +2360,47 @@ def test_alternating_positions_through_the_staged_block_for_many_steps(env):
     full["PYTHONPATH"] = os.path.dirname(os.path.dirname(os.path.abspath(__file__))) + os.pathsep + full.get("PYTHONPATH", "")
     r = subprocess.run([sys.executable, "-c", _BAR_ALTERNATION], env=full, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "BAD 0" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
+
+
+def test_lds_table_instances_of_the_md_evaluator_agree_with_the_others():
+    """k_eval<..., MD, TAB, CW> (round 6: window coefficients, knot records and pair coefficients in LDS, contraction over the kept-bin
+    rows, neighbour forces gathered instead of added atomically, strain derivative from the gathered forces, DPP sums) against the
+    instances without the tables (UF3_EVAL_NO_CW=1), the rebuild-everything route and the oracle: one, two and three species, with
+    and without the strain derivative, over several moved steps."""
+    for elements, numbers, reps in ((['W'], [74], (5, 5, 5)), (['Mo', 'W'], [42, 74], (6, 5, 4)), (['V', 'Mo', 'W'], [23, 42, 74], (5, 6, 7))):
+        basis = synthetic.notebook_basis(elements)
+        atoms = synthetic.lattice_frame("bcc", reps, 3.165, numbers, seed=31)
+        model = ls.WeightedLinearModel(basis)
+        coeff = np.random.default_rng(2).normal(0, 0.05, basis.n_feats)
+        coeff[basis.col_idx] = 0.0
+        model.coefficients = coeff
+        plain = calculator.UFCalculator(model, md_skin=0.0)
+        rng = np.random.default_rng(4)
+        results = {}
+        for label, env in (("cw", {}), ("nocw", {"UF3_EVAL_NO_CW": "1"})):
+            os.environ.update(env)
+            try:
+                calc = calculator.UFCalculator(model, md_skin=0.5)
+                a = atoms.copy()
+                out = []
+                for step in range(4):
+                    a.positions = a.positions + np.random.default_rng(10 + step).uniform(-0.02, 0.02, a.positions.shape)
+                    r = calc.evaluate_frames([a], virial=(step % 2 == 1))
+                    out.append((r[0], r[1], None, r[3] if len(r) > 3 else None))
+                results[label] = (out, a)
+            finally:
+                for k in env:
+                    os.environ.pop(k, None)
+        for step in range(4):
+            e1, f1, _, v1 = results["cw"][0][step]
+            e0, f0, _, v0 = results["nocw"][0][step]
+            assert abs(e1[0] - e0[0]) <= 1e-12 * abs(e0[0]) and rel_err(f1, f0) < 1e-12
+            if v0 is not None:
+                assert np.allclose(v1, v0, rtol=1e-10, atol=1e-10 * np.abs(v0).max())
+        a = results["cw"][1]
+        e1, f1, _, _ = results["cw"][0][3]
+        ep, fp, _, vp = plain.evaluate_frames([a], virial=True)
+        assert abs(e1[0] - ep[0]) <= 1e-12 * abs(ep[0]) and rel_err(f1, fp) < 1e-12
+        assert np.allclose(results["cw"][0][3][3], vp, rtol=1e-10, atol=1e-10 * np.abs(vp).max())
+        e_ref, f_ref = O.evaluate(O.OracleBasis(basis), a, coeff)
+        assert abs(e1[0] - e_ref) <= TOL * abs(e_ref) and worst_elementwise(f1, f_ref) <= 1.0
