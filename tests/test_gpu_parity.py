@@ -2404,3 +2404,34 @@ def test_lds_table_instances_of_the_md_evaluator_agree_with_the_others():
         assert np.allclose(results["cw"][0][3][3], vp, rtol=1e-10, atol=1e-10 * np.abs(vp).max())
         e_ref, f_ref = O.evaluate(O.OracleBasis(basis), a, coeff)
         assert abs(e1[0] - e_ref) <= TOL * abs(e_ref) and worst_elementwise(f1, f_ref) <= 1.0
+
+
+def test_fit_chunk_plan_ramps_then_spreads_the_rest_evenly():
+    """uf3_fit_add plans a call's chunks ahead (round 6): a ramp from an eighth of the limit, doubling, then the remaining frames
+    spread evenly over the fewest chunks of at most the limit -- no small tail chunk -- and the pieces do not depend on the plan;
+    frames without atoms are refused."""
+    from uf3_amd import pipeline
+    basis = synthetic.notebook_basis(['W'])
+    frames = [synthetic.lattice_frame("bcc", (2, 2, 2), 3.165, [74], seed=500 + k) for k in range(128)]       # 16 atoms each
+    rng = np.random.default_rng(1)
+    energies = rng.normal(size=len(frames))
+    forces = [rng.normal(size=(16, 3)) for _ in frames]
+    model = ls.WeightedLinearModel(basis)
+    fz = process.BasisFeaturizer(basis)
+    planned = pipeline.NativeFitAccumulator(model, fz, max_atoms_per_chunk=512)          # 32 frames per full chunk
+    planned.add_frames(frames, energies, forces)
+    assert planned.n_chunks == 7                    # 4 + 8 + 16 frames, then 100 frames as 4 x 25 (not 3 x 32 + 4)
+    one = pipeline.NativeFitAccumulator(model, fz, max_atoms_per_chunk=1 << 20)
+    one.ctx.check(one.ctx.lib.uf3_fit_first_chunk(one.handle, 1.0))
+    one.add_frames(frames, energies, forces)
+    assert one.n_chunks == 1
+    a, b = planned.pieces(), one.pieces()
+    for key in a:
+        assert rel_err(a[key], b[key]) < 1e-11, key
+    odd = pipeline.NativeFitAccumulator(model, fz, max_atoms_per_chunk=512)              # 37 frames: 4 + 8 + 16 + 9
+    odd.add_frames(frames[:37], energies[:37], forces[:37])
+    assert odd.n_chunks == 4
+    from uf3_amd.data.atoms import Atoms as _A
+    empty = _A(numbers=np.zeros(0, dtype=int), positions=np.zeros((0, 3)), cell=np.eye(3) * 5, pbc=True)
+    with pytest.raises(_lib.UF3Error):
+        odd.add_frames([frames[0], empty], energies[:2], [forces[0], np.zeros((0, 3))])
