@@ -2435,3 +2435,27 @@ def test_fit_chunk_plan_ramps_then_spreads_the_rest_evenly():
     empty = _A(numbers=np.zeros(0, dtype=int), positions=np.zeros((0, 3)), cell=np.eye(3) * 5, pbc=True)
     with pytest.raises(_lib.UF3Error):
         odd.add_frames([frames[0], empty], energies[:2], [forces[0], np.zeros((0, 3))])
+
+
+def test_md_route_frame_sums_from_the_collection_pass_on_a_large_frame():
+    """One whole frame of >= 8192 atoms on the MD route: the collection pass leaves per-workgroup sums of the atoms' energies and
+    strain derivatives and k_frame_sum adds those (round 6) -- energy, forces and strain derivative against the rebuild-everything
+    route (per-atom sums) and the oracle, on moved atoms."""
+    atoms, basis = synthetic.config_c4(frame=2)
+    model = ls.WeightedLinearModel(basis)
+    coeff = np.random.default_rng(8).normal(0, 0.05, basis.n_feats)
+    coeff[basis.col_idx] = 0.0
+    model.coefficients = coeff
+    md = calculator.UFCalculator(model, md_skin=0.5)
+    plain = calculator.UFCalculator(model, md_skin=0.0)
+    a = atoms.copy()
+    for step in range(3):
+        a.positions = a.positions + np.random.default_rng(40 + step).uniform(-0.02, 0.02, a.positions.shape)
+        e1, f1, _, v1 = md.evaluate_frames([a], virial=True)
+    e0, f0, _, v0 = plain.evaluate_frames([a], virial=True)
+    assert abs(e1[0] - e0[0]) <= 1e-12 * abs(e0[0]) and rel_err(f1, f0) < 1e-12
+    assert np.allclose(v1, v0, rtol=1e-10, atol=1e-10 * np.abs(v0).max())
+    e2, f2, _ = md.evaluate_frames([a])                       # (without the strain derivative: the energy sums alone)
+    assert abs(e2[0] - e0[0]) <= 1e-12 * abs(e0[0]) and rel_err(f2, f0) < 1e-12
+    e_ref, f_ref = O.evaluate(O.OracleBasis(basis), a, coeff)
+    assert abs(e1[0] - e_ref) <= TOL * abs(e_ref) and worst_elementwise(f1, f_ref) <= 1.0

@@ -80,6 +80,7 @@ struct uf3_ctx {
         halo,                           // marks + index list of the halo atoms of a decomposed frame
         n3x_ent, n3x_off,               // extension lists (batches with atoms outside their cell; see N3Lists)
         bin_cnt,                        // atoms per cell-list bin (counting sort)
+        part_sums,                      // per-workgroup energy / strain-derivative sums of the MD collection pass (see EvalArgs)
         f3w;                            // hand-off buffer k_feat3_w -> k_featurize3<HO>: [atoms of a slice][list capacity][S][wsz] doubles
     int n3_cap = 0, cand_cap = 0;
     int n3_last_cap = 0, n3_last_natoms = 0;   // layout of the 3-body lists in the workspace right now (uf3_n3_lists_debug)
@@ -306,7 +307,7 @@ extern "C" void uf3_ctx_destroy(uf3_ctx *c) {
     Buf *all[] = {&c->geoms, &c->offsets, &c->frame_of, &c->atom_bin, &c->atom_wrap, &c->spec, &c->key_in,
                   &c->key_out, &c->val_in, &c->val_out, &c->sort_tmp, &c->bin_start, &c->slots, &c->flags, &c->n3_cnt, &c->n3_int, &c->n3_dbl, &c->e_atom, &c->nbr_f, &c->coeff,
                   &c->stage_pos, &c->stage_z, &c->stage_out, &c->stage_out2, &c->sp_rows, &c->sp_seg, &c->gram_tij, &c->frag, &c->dbg, &c->halo, &c->n3x_ent, &c->n3x_off,
-                  &c->bin_cnt, &c->f3w, &c->coeff_cw};
+                  &c->bin_cnt, &c->f3w, &c->coeff_cw, &c->part_sums};
     for (Buf *b : all) b->release();
     for (Buf &b : c->gram_tiles) b.release();
     if (c->comm) uf3_comm_destroy(c);
@@ -2239,6 +2240,7 @@ static int eval_impl(uf3_basis *b, const uf3_frames *fr, const double *d_pos, co
     A.nbr_f = nullptr; A.n3_need = nullptr; A.fuse_n3 = 0;
     A.halo_mark = nullptr;
     A.c3w = nullptr; A.cw_bytes = 0; A.cw_zero = 0; A.cw_lo = 0; A.cw_ext = 0; A.lds_per_wave = 0; A.cw_recs_bytes = 0; A.cw_c2 = 0;
+    A.part_e = nullptr; A.part_v = nullptr; A.part_off = nullptr;
     // (rows of atoms that no centre of the block touches: zero.  A block of centres with the fused list build zeroes rows, list
     // counts and halo marks in ONE launch inside the loop below)
     const bool zero3 = centres && fuse && !md_step && !uf3_env("UF3_NO_HALO");
@@ -2248,6 +2250,7 @@ static int eval_impl(uf3_basis *b, const uf3_frames *fr, const double *d_pos, co
         Timed tm(c, T_EVAL);
         for (int attempt = 0; ; attempt++) {
             c->tail_signalled = false;
+            bool part_sums = false;
             if (fuse) {
                 rc = n3_alloc(c, P.natoms, c->n3_cap, A.n3);
                 if (rc) return rc;
@@ -2351,7 +2354,17 @@ static int eval_impl(uf3_basis *b, const uf3_frames *fr, const double *d_pos, co
                 }
                 if (md_step && centres)      // every atom checks itself; the block and the atoms its centres wrote to collect
                     hipLaunchKernelGGL(k_eval_collect_md_halo, dim3((unsigned)((P.natoms + 15) / 16)), dim3(256), 0, st, A);
-                else if (md_step) hipLaunchKernelGGL(k_eval_collect_md, dim3((unsigned)(((P.natoms + 15) / 16 + 7) / 8 * 8)), dim3(256), 0, st, A);
+                else if (md_step) {
+                    // one whole frame, large: the collection pass also leaves per-workgroup sums of the atoms' energies (and strain
+                    // derivatives), and the frame sum adds those -- natoms / 16 values instead of natoms (12 -> 4 us at 50 k atoms)
+                    part_sums = P.n_frames == 1 && whole && P.natoms >= 8192 && !mirror && !uf3_env("UF3_NO_PART_SUMS");
+                    if (part_sums) {
+                        const size_t n_wg = ((size_t)P.natoms + 15) / 16;
+                        HIPCHK(c, c->part_sums.ensure(8 * (7 * n_wg + 2)));
+                        A.part_e = c->part_sums.as<double>(); A.part_v = A.part_e + n_wg; A.part_off = (long long *)(A.part_v + 6 * n_wg);
+                    }
+                    hipLaunchKernelGGL(k_eval_collect_md, dim3((unsigned)(((P.natoms + 15) / 16 + 7) / 8 * 8)), dim3(256), 0, st, A);
+                }
                 else hipLaunchKernelGGL(k_eval_collect, dim3((unsigned)(((P.natoms + 15) / 16 + 7) / 8 * 8)), dim3(256), 0, st, A);
             } else if (atom_end > atom_begin) {
                 if (A.virial) hipLaunchKernelGGL((k_eval<true, true>), dim3((unsigned)((atom_end - atom_begin + 7) / 8 * 8)), dim3(64), lds, st, A);
@@ -2382,6 +2395,12 @@ static int eval_impl(uf3_basis *b, const uf3_frames *fr, const double *d_pos, co
                 if (++c->eval_seq == 0) c->eval_seq = 1;
                 seq = c->eval_seq;
             }
+            if (part_sums)
+                hipLaunchKernelGGL(k_frame_sum, dim3(1, d_virials ? 7 : 1), dim3(1024), 0, st, (const double *)A.part_e,
+                                   (const double *)A.part_v, (const int64_t *)A.part_off, d_energies, d_virials, (const int *)c->flags.as<int>(), flags_host ? flags_host : flags_tail,
+                                   mirror, (const double *)d_forces, d_forces ? 3 * P.natoms : 0, 0, (P.natoms + 15) / 16, seq, c->flags.as<int>() + 12,
+                                   seq_host);
+            else
             hipLaunchKernelGGL(k_frame_sum, dim3(P.n_frames, d_virials ? 7 : 1), dim3(sum_threads), 0, st, A.e_atom,
                                A.virial, P.d_offsets, d_energies, d_virials, (const int *)c->flags.as<int>(), flags_host ? flags_host : flags_tail,
                                mirror, (const double *)d_forces, d_forces ? 3 * P.natoms : 0, (int)atom_begin, (int)atom_end, seq, c->flags.as<int>() + 12,

@@ -2478,6 +2478,10 @@ struct EvalArgs {
     int cw_zero;                  // byte offset of the zero run (long enough for any row offset + 32)
     int cw_lo, cw_ext;            // first kept bin and number of kept bins of the centre legs (legs l and m alike)
     int lds_per_wave;             // bytes of the per-wave arrays of a multi-wave workgroup
+    // per-workgroup sums of the collection pass (one whole frame on the MD route): [n_wg] energies | [n_wg][6] strain derivatives |
+    // int64 {0, n_wg}: k_frame_sum then adds n_wg = natoms / 16 partial sums instead of natoms per-atom values (12 -> 4 us at 50 k atoms)
+    double *part_e, *part_v;
+    long long *part_off;
     int cw_recs_bytes;            // all knot records of the basis (BasisDev::recs), copied behind the table: the pair splines, the
     int cw_c2;                    // per-bond leg tables and leg n read them from LDS; then the pair coefficients c2 (cw_c2 doubles)
 };
@@ -3344,17 +3348,33 @@ __global__ void __launch_bounds__(256)
 k_eval_collect_md(EvalArgs A) {
     const int wg = (int)((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3));
     const int m = wg * 16 + (threadIdx.x >> 4), sub = threadIdx.x & 15;
-    if (m >= A.natoms) return;
-    const int cap = A.n3.cap, n = min(A.n3.cnt[m], cap);
-    double sx = 0.0, sy = 0.0, sz = 0.0;
-    for (int t = sub; t < n; t += 16) {
-        typedef double inbox4 __attribute__((ext_vector_type(4)));
-        const int q = A.md_surv[(size_t)m * cap + t];
-        const inbox4 v = *(const inbox4 *)(A.md_inbox + 4 * ((size_t)m * A.sup_cap + q));
-        if (v[3] == A.md_stamp) { sx += v[0]; sy += v[1]; sz += v[2]; }
+    const bool active = m < A.natoms;
+    if (!active && !A.part_e) return;
+    if (active) {
+        const int cap = A.n3.cap, n = min(A.n3.cnt[m], cap);
+        double sx = 0.0, sy = 0.0, sz = 0.0;
+        for (int t = sub; t < n; t += 16) {
+            typedef double inbox4 __attribute__((ext_vector_type(4)));
+            const int q = A.md_surv[(size_t)m * cap + t];
+            const inbox4 v = *(const inbox4 *)(A.md_inbox + 4 * ((size_t)m * A.sup_cap + q));
+            if (v[3] == A.md_stamp) { sx += v[0]; sy += v[1]; sz += v[2]; }
+        }
+        row16_sum3(sx, sy, sz);
+        if (sub == 0) { double *f = A.forces + 3 * (size_t)m; f[0] += sx; f[1] += sy; f[2] += sz; }
     }
-    row16_sum3(sx, sy, sz);
-    if (sub == 0) { double *f = A.forces + 3 * (size_t)m; f[0] += sx; f[1] += sy; f[2] += sz; }
+    if (A.part_e) {
+        // this workgroup's sixteen atoms' energies (and strain derivatives), added in atom order: what k_frame_sum sums afterwards
+        __shared__ double pe[16][8];
+        const int a = threadIdx.x >> 4;
+        if (sub < 7) pe[a][sub] = !active ? 0.0 : (sub == 0 ? A.e_atom[m] : (A.virial ? A.virial[6 * (size_t)m + sub - 1] : 0.0));
+        __syncthreads();
+        if (threadIdx.x < 7 && (size_t)wg * 16 < (size_t)A.natoms) {
+            double s_ = 0.0;
+            for (int q = 0; q < 16; q++) s_ += pe[q][threadIdx.x];
+            if (threadIdx.x == 0) A.part_e[wg] = s_; else if (A.virial) A.part_v[6 * (size_t)wg + threadIdx.x - 1] = s_;
+        }
+        if (wg == 0 && threadIdx.x == 0) { A.part_off[0] = 0; A.part_off[1] = (A.natoms + 15) / 16; }
+    }
 }
 
 // per-frame sums of per-atom quantities: blockIdx.y = 0 energy (width 1), 1..6 virial components (width 6, if
