@@ -13,7 +13,7 @@ atoms = synthetic.lattice_frame("bcc", (25, 25, 40), 3.165, [23, 42, 74], 4000)
 model = ls.WeightedLinearModel(basis)
 coeff = np.random.default_rng(11).normal(0, 0.05, basis.n_feats); coeff[basis.col_idx] = 0.0
 model.coefficients = coeff
-calc = calculator.UFCalculator(model)
+calc = calculator.UFCalculator(model, md_skin=float(os.environ.get("SKIN", "0.5")))
 for _ in range(3): calc.evaluate_frames([atoms])
 ctx = _lib.get_context(None)
 buf = (ctypes.c_ulonglong * 16)()
