@@ -2296,6 +2296,9 @@ static int eval_impl(uf3_basis *b, const uf3_frames *fr, const double *d_pos, co
             const bool cw = tab && md_step && c->cw_of == (const void *)b && cap <= 16 &&      /* (lists of <= 16 entries: the force gather's stage, k_eval) */
                              lds_cw <= UF3_LDS_LIMIT / (EVAL_CW_WAVES > 8 ? 1 : 2) && !uf3_env("UF3_EVAL_NO_CW");
             const size_t lds = cw ? lds_cw : (tab ? lds_tab : lds_plain);
+            // WIN instances: the same window table read through global memory by the one-wave TAB instances CW does not serve
+            const bool win = tab && !cw && c->cw_of == (const void *)b && !uf3_env("UF3_EVAL_NO_CW");
+            if (win) { A.c3w = c->coeff_cw.as<double>(); A.cw_lo = b->cw_lo; A.cw_ext = b->cw_ext; }
             if (cw) {
                 A.c3w = c->coeff_cw.as<double>(); A.cw_bytes = b->cw_bytes; A.cw_zero = b->cw_zero; A.cw_lo = b->cw_lo; A.cw_ext = b->cw_ext;
                 A.lds_per_wave = (int)cw_per_wave; A.cw_recs_bytes = (int)cw_recs; A.cw_c2 = (int)n2;
@@ -2337,6 +2340,12 @@ static int eval_impl(uf3_basis *b, const uf3_frames *fr, const double *d_pos, co
                         default: return fail(c, UF3_EINVAL, "k_eval<CW> outside the MD route");
                     }
 #undef UF3_EVAL_CW_CASE
+#define UF3_EVAL_WIN_CASE(I) case I: hipLaunchKernelGGL((k_eval<false, ((I) & 1) != 0, ((I) & 2) ? 16 : 0, ((I) & 4) != 0, true, false, true>), eg, dim3(64), lds, st, A); break;
+                    else if (win) switch (inst & 7) {
+                        UF3_EVAL_WIN_CASE(0) UF3_EVAL_WIN_CASE(1) UF3_EVAL_WIN_CASE(2) UF3_EVAL_WIN_CASE(3)
+                        UF3_EVAL_WIN_CASE(4) UF3_EVAL_WIN_CASE(5) UF3_EVAL_WIN_CASE(6) UF3_EVAL_WIN_CASE(7)
+                    }
+#undef UF3_EVAL_WIN_CASE
 #define UF3_EVAL_CASE(I) case I: hipLaunchKernelGGL((k_eval<false, ((I) & 1) != 0, ((I) & 2) ? 16 : 0, ((I) & 4) != 0, ((I) & 8) != 0>), eg, dim3(64), lds, st, A); break;
                     else switch (inst) {
                         UF3_EVAL_CASE(0) UF3_EVAL_CASE(1) UF3_EVAL_CASE(2) UF3_EVAL_CASE(3) UF3_EVAL_CASE(4) UF3_EVAL_CASE(5)

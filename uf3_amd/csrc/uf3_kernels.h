@@ -2655,12 +2655,12 @@ __device__ __forceinline__ bool trio_value_tab(const KnotRec *recs, const double
 // interval (9 instead of 16 at the default trims), every row at a constant offset from the lane's (trio, n interval) base -- no
 // validity logic.  The terms left out are products with exact zeros and the others keep their order: the same bits as trio_value_tab.
 //   cw: the table in LDS; t_base: byte offset of the trio's block; tl / tm: [2 * EXT] window values | derivatives of legs l / m
-template <int EXT>
+template <int EXT, int AS = 3>          // AS: where the table lives -- 3: the workgroup's LDS (CW instances), 1: global memory (WIN instances)
 __device__ __forceinline__ bool trio_value_tab_cw(const KnotRec *recs, const unsigned char *cw, int t_base, const LegDev &l2, int dim_n,
                                                   const double *tl, const double *tm, double rn, bool want_grad, double &val, double *grad) {
     // (rows start at any n bin: 8-byte alignment -- ds_read2_b64; a 16-byte read at an odd double took ~60 LDS cycles per wave)
     typedef double coeff2 __attribute__((ext_vector_type(2), aligned(8)));
-    typedef const __attribute__((address_space(3))) coeff2 *LdsPairs;
+    typedef const __attribute__((address_space(AS))) coeff2 *LdsPairs;
     KnotRec kn;
     const int in = load_interval<3>(recs, l2, rn, kn);
     const int row_b = 8 * dim_n;                                       // bytes between consecutive rows of leg m; EXT of them per row of leg l
@@ -2758,10 +2758,15 @@ __device__ __forceinline__ void row16_sum3(double &a, double &b, double &c) {
 // (the per-atom syncs of the body: a workgroup barrier in the one-wave workgroups, a wave barrier in the multi-wave ones, whose
 // waves run through the body independently)
 #define EVAL_SYNC() do { if (CW) wave_sync(); else __syncthreads(); } while (0)
-template <bool GATHER, bool VIR, int CAP = 0, bool MD = false, bool TAB = false, bool CW = false>
+// (WIN: the window-row contraction -- 3 x 3 coefficient rows per triplet out of the window table EvalArgs::c3w, per-bond leg tables dense
+// over the window rows -- without the LDS copies: the table is read through global memory by the one-wave workgroups of the TAB
+// instances that CW does not serve: the rebuild-everything route, longer lists, blocks of centres.  CW implies WIN.)
+template <bool GATHER, bool VIR, int CAP = 0, bool MD = false, bool TAB = false, bool CW = false, bool WIN = CW>
 __global__ void __launch_bounds__(CW ? 64 * EVAL_CW_WAVES : 64, TAB ? EVAL_TAB_MINW : EVAL_MINW)
 k_eval(EvalArgs A) {
     static_assert(!CW || (TAB && !GATHER), "the LDS tables belong to the TAB centre pass");
+    static_assert(!WIN || (TAB && !GATHER), "the window table belongs to the TAB centre pass");
+    static_assert(!CW || WIN, "the LDS table is the window table");
     extern __shared__ __align__(16) unsigned char smem_all[];
     const BasisDev *B = A.B;
     const int cap = CAP > 0 ? CAP : A.n3.cap;
@@ -3067,7 +3072,7 @@ k_eval(EvalArgs A) {
                         bspline4<true>(k, r, v, d);
                     }
                     double *dst = (which ? tmv : tlv) + 8 * q;
-                    if (CW) {
+                    if (WIN) {
                         // dense over the window rows (EVAL_CW_EXT of them): value | derivative of row w, zero where the bond's four
                         // functions (i - 3 .. i) do not reach
                         for (int u = 0; u < 2 * EVAL_CW_EXT; u++) dst[u] = 0.0;
@@ -3109,11 +3114,12 @@ k_eval(EvalArgs A) {
                 const int il = tli[aa], im = tmi[bb];
                 good = act & (trio >= 0) & (il >= 0) & (im >= 0) & (rn > leg_n.t0) & (rn < leg_n.tlast);
                 if (!CW && !good) continue;
-                if (CW) {
+                if (WIN) {
                     (void)lut_off;
                     if (good)
-                        trio_value_tab_cw<EVAL_CW_EXT>(kn_lds, smem_all, max(trio, 0) * (EVAL_CW_EXT * EVAL_CW_EXT * tab_dim_n * 8), leg_n_lds, tab_dim_n,
-                                                       tlv + 8 * aa, tmv + 8 * bb, rn, want_f || want_v, val, gr);
+                        trio_value_tab_cw<EVAL_CW_EXT, CW ? 3 : 1>(kn_lds, CW ? smem_all : (const unsigned char *)A.c3w,
+                                                                   max(trio, 0) * (EVAL_CW_EXT * EVAL_CW_EXT * tab_dim_n * 8), leg_n_lds, tab_dim_n,
+                                                                   tlv + 8 * aa, tmv + 8 * bb, rn, want_f || want_v, val, gr);
                 } else
                 trio_value_tab<3>(kn_lds, A.c3, lut_off, leg_n_lds, tab_dim_m, tab_dim_n, il, im, tlv + 8 * aa, tmv + 8 * bb, rn,
                                want_f || want_v, val, gr);
