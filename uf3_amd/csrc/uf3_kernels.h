@@ -2748,9 +2748,11 @@ __device__ __forceinline__ void row16_sum3(double &a, double &b, double &c) {
 #define EVAL_TAB_MINW 4
 #endif
 // (CW, round 6 -- VERDICT round 5 item 3: the coefficient rows of the triplets out of LDS.  A workgroup is EVAL_CW_WAVES one-atom
-// waves instead of one; its waves copy the window table of ALL trios (EvalArgs::c3w: 19 KB for the ternary notebook basis) and leg
-// n's knot records into LDS once, with global_load_lds behind the pair phase, and meet at ONE barrier in front of the triplet
-// loop; everything else stays per wave.  TAB instances only, lists of at most EVAL_TAB_CAP entries.)
+// waves instead of one; its waves copy the window table of ALL trios (EvalArgs::c3w: 19 KB for the ternary notebook basis) with
+// global_load_lds, every knot record of the basis and the pair coefficients into LDS once and meet at ONE barrier behind the first
+// batch of the list filter; everything else stays per wave.  The forces a centre's triplets put on its list entries are gathered from
+// a per-trip stage instead of added atomically, the triplets' strain derivative comes from the gathered forces.  MD route, TAB
+// instances, lists of at most 16 entries -- uf3_eval decides.)
 #ifndef EVAL_CW_WAVES
 #define EVAL_CW_WAVES 8
 #endif
