@@ -3104,7 +3104,8 @@ k_eval(EvalArgs A) {
             int aa = p - bb * (bb - 1) / 2;
             double rl = orr[aa], rm = orr[bb];
             double rn = norm3_leg(ox[bb] - ox[aa], oy[bb] - oy[aa], oz[bb] - oz[aa]);
-            double val = 0.0, gr[3] = {0.0, 0.0, 0.0};
+            double val, gr[3];
+            if (CW) { val = 0.0; gr[0] = 0.0; gr[1] = 0.0; gr[2] = 0.0; }       // (a CW lane without a triplet carries zeros; elsewhere it leaves the trip)
 #if defined(UF3_ABLATE_EVAL) && UF3_ABLATE_EVAL == 1
             if (rl > 0) continue;           // (experiment: no triplet values)
 #endif
@@ -3127,8 +3128,8 @@ k_eval(EvalArgs A) {
                                want_f || want_v, val, gr);
             } else {
                 int trio = B->trio_of[(sm * UF3_MAX_SPECIES + ospec[aa]) * UF3_MAX_SPECIES + ospec[bb]];
-                good = act && trio_value(B, A.c3, trio, rl, rm, rn, want_f || want_v, val, gr);
-                if (!good) continue;
+                if (!act || !trio_value(B, A.c3, trio, rl, rm, rn, want_f || want_v, val, gr)) continue;
+                good = true;
             }
             // (CW: a lane without a triplet carries zeros through the force arithmetic below -- every lane takes part in the gather)
             e += val;
