@@ -830,7 +830,7 @@ extern "C" int uf3_basis_create(uf3_ctx *c, const uf3_basis_spec *s, uf3_basis *
             const size_t table = (size_t)h.T * ext * ext * dn * 8;
             const size_t zero = ((size_t)(3 * ext + 3) * dn * 8 + 32 + 15) / 16 * 16;        // (any row offset + one row's 32 bytes)
             const size_t total = (table + zero + 1023) / 1024 * 1024;
-            ok = total <= 40 * 1024 && ext == EVAL_CW_EXT && !uf3_env("UF3_EVAL_NO_CW");
+            ok = total <= 40 * 1024 && ext == EVAL_CW_EXT;        // (UF3_EVAL_NO_CW is looked at per call, where the instance is chosen)
             if (ok) {
                 b->cw_lo = t0.lo[0]; b->cw_ext = ext; b->cw_dim_m = t0.dim_m; b->cw_dim_n = dn;
                 b->cw_zero = (int)table; b->cw_bytes = (int)total;
