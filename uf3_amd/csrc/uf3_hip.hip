@@ -83,6 +83,7 @@ struct uf3_ctx {
         part_sums,                      // per-workgroup energy / strain-derivative sums of the MD collection pass (see EvalArgs)
         f3w;                            // hand-off buffer k_feat3_w -> k_featurize3<HO>: [atoms of a slice][list capacity][S][wsz] doubles
     int n3_cap = 0, cand_cap = 0;
+    size_t bin_cnt_clean = 0;        // ints of bin_cnt known to be zero (k_bin_fill leaves the counts it used at zero)
     int n3_last_cap = 0, n3_last_natoms = 0;   // layout of the 3-body lists in the workspace right now (uf3_n3_lists_debug)
     int n3x_cap = 0;                 // capacity of the extension lists (0 until a batch needed them)
     bool img_mode = false;           // a batch with atoms far outside their cell has been seen: 3-body launches with the image-range rule
@@ -1309,17 +1310,31 @@ static int prepare(uf3_basis *b, const uf3_frames *fr, const double *d_pos, cons
     HIPCHK(c, hipMemsetAsync(flags + 1, 0, 4 * sizeof(int), st));
     P.flags_zeroed = true;
     // counting sort by global bin: counts (k_frame_bins) -> exclusive scan = bin starts -> fill -> per-bin order + slot records
-    HIPCHK(c, c->bin_cnt.ensure(4 * ((size_t)nbins + 8)));
-    HIPCHK(c, hipMemsetAsync(c->bin_cnt.p, 0, (4 * ((size_t)nbins + 1) + 15) / 16 * 16, st));      // (whole 16-byte pieces: one fill kernel)
+    // (k_bin_fill takes every count back to zero: the buffer is cleared only where it has not been through a fill yet)
+    {
+        const void *before = c->bin_cnt.p;
+        HIPCHK(c, c->bin_cnt.ensure(4 * ((size_t)nbins + 8)));
+        if (c->bin_cnt.p != before) c->bin_cnt_clean = 0;
+        if ((size_t)nbins + 1 > c->bin_cnt_clean) {
+            HIPCHK(c, hipMemsetAsync(c->bin_cnt.p, 0, (4 * ((size_t)nbins + 1) + 15) / 16 * 16, st));      // (whole 16-byte pieces: one fill kernel)
+            c->bin_cnt_clean = (size_t)nbins + 1;
+        }
+    }
     hipLaunchKernelGGL(k_frame_bins, dim3(gb), dim3(tb), 0, st, b->dev, d_geoms,
                        d_offsets, nf, natoms, d_pos, d_z, c->frame_of.as<int>(), c->atom_bin.as<int>(),
                        c->atom_wrap.as<int>(), c->spec.as<signed char>(), c->key_in.as<int>(), c->bin_cnt.as<int>(), flags);
-    size_t tmp_bytes = 0;
-    HIPCHK(c, rocprim::exclusive_scan(nullptr, tmp_bytes, c->bin_cnt.as<int>(), c->bin_start.as<int>(), 0, (size_t)nbins + 1,
-                                       rocprim::plus<int>(), st));
-    HIPCHK(c, c->sort_tmp.ensure(tmp_bytes));
-    HIPCHK(c, rocprim::exclusive_scan(c->sort_tmp.p, tmp_bytes, c->bin_cnt.as<int>(), c->bin_start.as<int>(), 0, (size_t)nbins + 1,
-                                       rocprim::plus<int>(), st));
+    // (up to 16 384 bins -- frames of about 20 k atoms: one workgroup walking 36 k counts of the 50 k-atom frame took 40 us longer than the
+    // library scan's two launches)
+    if ((size_t)nbins + 1 <= 16384 && !uf3_env("UF3_NO_SMALL_SCAN"))
+        hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(1024), 0, st, (const int *)c->bin_cnt.as<int>(), c->bin_start.as<int>(), nbins + 1);
+    else {
+        size_t tmp_bytes = 0;
+        HIPCHK(c, rocprim::exclusive_scan(nullptr, tmp_bytes, c->bin_cnt.as<int>(), c->bin_start.as<int>(), 0, (size_t)nbins + 1,
+                                           rocprim::plus<int>(), st));
+        HIPCHK(c, c->sort_tmp.ensure(tmp_bytes));
+        HIPCHK(c, rocprim::exclusive_scan(c->sort_tmp.p, tmp_bytes, c->bin_cnt.as<int>(), c->bin_start.as<int>(), 0, (size_t)nbins + 1,
+                                           rocprim::plus<int>(), st));
+    }
     hipLaunchKernelGGL(k_bin_fill, dim3(gb), dim3(tb), 0, st, c->key_in.as<int>(), natoms, c->bin_start.as<int>(),
                        c->bin_cnt.as<int>(), c->val_out.as<int>());
     hipLaunchKernelGGL(k_bin_finish, dim3((nbins + tb - 1) / tb), dim3(tb), 0, st, nbins, c->bin_start.as<int>(),

@@ -84,6 +84,28 @@ __global__ void k_frame_bins(const BasisDev *B, const FrameGeom *geoms, const in
 // bin_start): k_bin_fill drops every atom into its bin in whatever order the atomics grant, k_bin_finish -- one thread per
 // bin, a bin holds a handful of atoms -- puts each bin into ascending atom order and writes the slot records.  The result is
 // the stable radix sort's (bin, then atom index), with 5 launches instead of rocPRIM's 25 for 320 k atoms.
+// exclusive prefix sums of up to 16 384 bin counts in ONE workgroup (1024 threads, a run of consecutive counts each, wave scans on the
+// DPP network): the library scan's two launches (look-back state, scan) are two dispatch latencies on a call whose every launch is
+// a few microseconds -- a 10 k-atom evaluator call is ten of them in front of the centre pass
+__global__ void __launch_bounds__(1024)
+k_scan_small(const int *cnt, int *start, int n) {
+    __shared__ int wsum[16];
+    const int t = threadIdx.x, per = (n + 1023) >> 10, lo = t * per, hi = min(lo + per, n);
+    int s = 0;
+    for (int q = lo; q < hi; q++) s += cnt[q];
+    const int incl = wave_scan_incl(s);
+    if ((t & 63) == 63) wsum[t >> 6] = incl;
+    __syncthreads();
+    if (t < 64) {
+        const int v = t < 16 ? wsum[t] : 0;
+        const int w = wave_scan_incl(v);
+        if (t < 16) wsum[t] = w - v;                    // exclusive over the waves
+    }
+    __syncthreads();
+    int run = wsum[t >> 6] + incl - s;
+    for (int q = lo; q < hi; q++) { const int c = cnt[q]; start[q] = run; run += c; }
+}
+
 __global__ void k_bin_fill(const int *atom_key, int natoms, const int *bin_start, int *bin_count, int *sorted_val) {
     int a = blockIdx.x * blockDim.x + threadIdx.x;
     if (a >= natoms) return;
