@@ -67,7 +67,7 @@ def cutoff_probe_frame(radii, elements=(74,), spacing=18.0, per_radius=36, seed=
     """Pairs of atoms placed AT the given cut-off radii, a few units in the last place to either side: site k of a cubic grid holds
     atom A, and B = A + d u with u a random direction and d = r (1 + q 2^-52), q in -3 .. 3 (seven sites per direction and radius).
     The pairs sit `spacing` apart (no atom of one pair within 5.5 A + 0.5 A of an atom of another), B is wrapped into the periodic cell, so some pairs meet through an image.
-    What a pair's distance rounds to is whatever cdist's formula makes of it -- the test asserts agreement with the oracle, on
+    What a pair's distance rounds to is whatever cdist's formula makes of it -- the test asserts agreement with the CPU restatement of the reference, on
     both sides of each radius."""
     rng = np.random.default_rng(seed)
     sites = []
